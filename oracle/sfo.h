@@ -1,0 +1,168 @@
+/*
+ * ORACLE (test infrastructure, never shipped, never on the product path).
+ *
+ * Plain-C restatement of the reference's per-frame STFT → spectrogram → fragment → SSAA → read-out
+ * path (BrokenSource/ShaderFlow v0.11.3). Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library, and only as the checker.
+ *
+ * Pinning status
+ *   audio half (sfo_audio.c): PINNED against tests/golden/ fixtures, captured from the reference's own
+ *       numpy code by tests/golden/make_golden.py (tests/test_oracle_audio.py).
+ *   pixel half (sfo_pixel.c): PARITY UNPINNED — the reference evaluates GLSL inside an OpenGL driver
+ *       (moderngl ~=5.12 → system GL ≥ 3.3), which is neither vendored nor runnable here and for which
+ *       the reference holds no golden images. The restatement follows the GLSL
+ *       sources line by line plus OpenGL 3.3 core §3.8 (sampling) and §2.1.6/§4.1 (unorm conversion),
+ *       with the built-in functions fixed by sfo_math.h; closed-form scenes pin the plumbing
+ *       (tests/test_oracle_pixel.py).
+ */
+#ifndef SFO_H
+#define SFO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Frame clock and PCM chunking */
+
+/* scheduler.py:87-89,134-173 (freewheel) + scene.py:475-479. Outputs are the values the modules
+ * SEE while frame k is produced: time_used[k], dt_used[k], rdt_used[k]. */
+void sfo_clock(double fps, double speed, int frames, double* time_used, double* dt_used, double* rdt_used);
+
+/* ffmpeg.py:1281-1333 driven by audio/module.py:447-453: samples appended on frame k and the
+ * running `tell`; total_samples bounds the file (reader runs dry → 0). */
+void sfo_reader(const double* rdt_used, int frames, int samplerate, int channels,
+                int64_t total_samples, int32_t* lengths, int64_t* tell);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* STFT */
+
+enum { SFO_WINDOW_HANNING = 0, SFO_WINDOW_HANN_POISSON = 1, SFO_WINDOW_NONE = 2 };
+enum { SFO_SCALE_OCTAVE = 0, SFO_SCALE_MEL = 1 };
+enum { SFO_INTERP_EULER = 0, SFO_INTERP_DIRAC = 1, SFO_INTERP_SINC = 2 };
+enum { SFO_REDUCER_AVERAGE = 0, SFO_REDUCER_RMS = 1, SFO_REDUCER_STD = 2 };
+
+/* spectrogram.py:90-108 */
+void sfo_window(int kind, int n, double* out);
+
+/* audio/module.py:137-138 + spectrogram.py:155-171,25-26. pcm is planar (channels, total) float32 of
+ * the whole stream; the ring-buffer window of the reference is stream[tell-n-1 : tell-1] with zeros
+ * before the start. out: (channels, n/2+1) float32 power. */
+void sfo_fft_power(const float* pcm, int64_t total, int channels, int64_t tell,
+                   int fft_n, int window_kind, float* out);
+
+/* spectrogram.py:186-224 (+ scales :73-87, kernels :44-70). Returns nnz (or -needed if cap is too
+ * small). CSR of the (bins, fft_bins) float32 matrix. */
+int sfo_filterbank(int scale, int interp, double fmin, double fmax, int bins, int fft_n,
+                   double samplerate, int32_t* indptr, int32_t* indices, float* data, int cap);
+
+/* spectrogram.py:175-176: M.dot(P.T) — out is the (bins, channels) C-ordered buffer whose bytes the
+ * reference re-views as (2, bins) (spectrogram.py:306) and uploads as RG texels. */
+void sfo_csr_dot(const int32_t* indptr, const int32_t* indices, const float* data, int bins,
+                 const float* power, int channels, int fft_bins, float* out);
+
+/* piano/notes.py:58-59,74-75 and spectrogram.py:226-245 */
+int sfo_note_of_frequency(double frequency, double tuning);
+double sfo_frequency_of_note(int note, double tuning);
+void sfo_from_notes(int start_note, int end_note, int piano, int bins_in, double tuning,
+                    double* fmin, double* fmax, int* bins);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* DynamicNumber (dynamics.py:77-255) */
+
+typedef struct {
+    double frequency, zeta, response, precision;
+    int integrate;
+} sfo_dyn_params;
+
+/* coefficient selection dynamics.py:231-242; returns 0 = clamped-k2 branch, 1 = pole matching */
+int sfo_dyn_coeffs(const sfo_dyn_params* p, double dt, double* k1, double* k2, double* k3);
+
+/* float32 array system (spectrogram.py:287-290). `previous` holds the last non-early-out target. */
+void sfo_dyn_step_f32(const sfo_dyn_params* p, int n, float* value, float* derivative,
+                      float* previous, float* integral, const float* target, double dt);
+
+/* float64 scalar system (audio/module.py:413-421, camera.py:147-185) */
+void sfo_dyn_step_f64(const sfo_dyn_params* p, double* value, double* derivative, double* previous,
+                      double* integral, double target, double dt);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Waveform and loudness */
+
+/* waveform.py:80-87,14-22. out: (points, channels) float32 */
+void sfo_waveform_row(const float* pcm, int64_t total, int channels, int64_t tell,
+                      int chunk_size, int points, int reducer, float* out);
+
+/* audio/module.py:74-75,457-458 over stream[tell-n-1 : tell-1] of all channels jointly */
+void sfo_volume_std(const float* pcm, int64_t total, int channels, int64_t tell, int n,
+                    float* volume_target, float* std_target);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Pixel half */
+
+enum { SFO_U8 = 0, SFO_F32 = 1, SFO_U16 = 2, SFO_F16 = 3 };
+enum { SFO_NEAREST = 0, SFO_LINEAR = 1 };
+
+typedef struct {
+    const void* data;      /* row 0 = bottom row (GL order), tightly packed */
+    int32_t width, height, components, dtype, filter, repeat_x, repeat_y;
+} sfo_texture;
+
+/* Every uniform the in-scope fragments can read (scene.py:687-703, camera.py:196-201 + its nine
+ * ShaderDynamics camera.py:147-185, audio/module.py:413-421, spectrogram.py:313-320, waveform.py:89-90) */
+typedef struct {
+    float iTime, iTau, iDuration, iDeltatime;
+    float iResolution[2];
+    float iWantAspect, iQuality, iSSAA, iFramerate;
+    int32_t iFrame, iRealtime, iLayer, iSubsample;
+    float iMouse[2];
+    int32_t iMouseInside, iMouse1, iMouse2;
+    int32_t iCameraMode, iCameraProjection;
+    float iCameraRight[3], iCameraUpward[3], iCameraForward[3];
+    float iCameraPosition[3], iCameraZenith[3];
+    float iCameraSeparation, iCameraZoom, iCameraIsometric, iCameraFocalLength, iCameraOrbital, iCameraDolly;
+    float iAudioVolume, iAudioVolumeIntegral, iAudioSTD;
+    int32_t iSpectrogramLength, iSpectrogramBins, iSpectrogramSmooth, iSpectrogramScroll;
+    float iSpectrogramOffset, iSpectrogramMin, iSpectrogramMax;
+    int32_t iWaveformLength;
+    float user[16];        /* scene-defined float uniforms, by slot */
+} sfo_uniforms;
+
+enum {
+    SFO_FRAG_DEFAULT = 0,      /* resources/shaders/fragment/default.glsl   */
+    SFO_FRAG_MISSING = 1,      /* resources/shaders/fragment/missing.glsl   */
+    SFO_FRAG_VISUALIZER = 2,   /* examples/basic/shaders/visualizer.frag    */
+    SFO_FRAG_BARS = 3,         /* examples/basic/shaders/bars.frag          */
+    SFO_FRAG_WAVEFORM = 4,     /* examples/basic/shaders/waveform.frag      */
+    SFO_FRAG_MULTI_CHILD = 5,  /* examples/basic/demo.py:74-79 (inline)     */
+    SFO_FRAG_MULTI_MAIN = 6,   /* examples/basic/demo.py:83-89 (inline)     */
+    SFO_FRAG_SHADERTOY = 7,    /* examples/basic/shaders/shadertoy.frag     */
+    SFO_FRAG_DYNAMICS = 8,     /* examples/basic/demo.py:121-126 (inline)   */
+    SFO_FRAG_AUDIO = 9,        /* examples/basic/demo.py:149-153 (inline)   */
+};
+
+enum { SFO_TEX_BACKGROUND = 0, SFO_TEX_SPECTROGRAM = 1, SFO_TEX_WAVEFORM = 2, SFO_TEX_CHILD = 3, SFO_TEX_SLOTS = 4 };
+
+/* shader.py:388-405 for one layer: evaluate `fragment` at every pixel centre of a (wr, hr) target
+ * and store RGBA8 (rows bottom-up). Only rows [y0, y1) are produced (band rendering for the bounded
+ * CPU baseline); `threads` > 1 splits rows over pthreads. out has wr*hr*4 bytes. */
+void sfo_render(int fragment, const sfo_uniforms* u, const sfo_texture* textures /*[SFO_TEX_SLOTS]*/,
+                int wr, int hr, int y0, int y1, int threads, uint8_t* out);
+
+/* fragment/final.glsl:1-33 + shader.py:391-396: iScreen (RGBA8, linear, clamp) → RGB8 (w, h),
+ * rows [y0, y1). */
+void sfo_resolve(const uint8_t* screen, int wr, int hr, int w, int h, int subsample,
+                 int y0, int y1, int threads, uint8_t* out);
+
+/* GL `texture()` on one coordinate, exposed for sampler unit tests */
+void sfo_sample(const sfo_texture* t, float s, float tt, float rgba[4]);
+
+/* sfmath entry points for the accuracy / cross-implementation tests */
+float sfo_test_math(int fn, float a, float b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,561 @@
+/*
+ * ORACLE (test infrastructure, never shipped, never on the product path).
+ * Pixel half: CPU restatement of the reference's GLSL (vertex/default.glsl, include/shaderflow.glsl,
+ * include/camera.glsl, fragment/{default,missing,final}.glsl, examples/basic/shaders/ fragments) and of
+ * the OpenGL 3.3 rules the reference leans on. PARITY UNPINNED: the reference has no golden images
+ * and its GL driver cannot run here (see sfo.h). Citations are file:line in /root/reference.
+ *
+ * Conventions fixed here (and restated independently by the HIP kernels):
+ *   - pixel (i, j) of a (wr, hr) target, origin bottom-left, is shaded at its centre; the varyings
+ *     are the vertex shader's formulas evaluated on agluv = 2*((i+.5)/wr, (j+.5)/hr) - 1
+ *     (vertex/default.glsl:8-16; the quad's attributes are affine, shader.py:127-128)
+ *   - `out vec4 fragColor` starts as vec4(0)
+ *   - built-ins per sfo_math.h; every expression is evaluated left to right in binary32 with no
+ *     contraction; GLSL mix/mod/smoothstep per their GLSL 3.30 §8.3 definitions
+ *   - texture(): OpenGL 3.3 core §3.8.8-3.8.9 (texel addressing, wrap, bilinear), weights applied as
+ *     fma(w11,t11, fma(w01,t01, fma(w10,t10, w00*t00))); unorm8 texel → c/255.0f
+ *   - colour write: clamp to [0,1] (NaN → 0), *255, round half to even (OpenGL 3.3 §2.1.6/§4.1)
+ */
+#include "sfo.h"
+#include "sfo_math.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+
+typedef struct { float x, y; } v2;
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y, z, w; } v4;
+
+static inline v2 V2(float x, float y) { v2 r = {x, y}; return r; }
+static inline v3 V3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v4 V4(float x, float y, float z, float w) { v4 r = {x, y, z, w}; return r; }
+static inline v3 v3_add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 v3_sub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 v3_scale(v3 a, float s) { return V3(a.x*s, a.y*s, a.z*s); }
+static inline float v3_dot(v3 a, v3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }
+static inline float v2_length(v2 a) { return sfo_sqrt(a.x*a.x + a.y*a.y); }
+
+/* ---------------------------------------------------------------------------------------------- */
+/* OpenGL 3.3 sampler */
+
+static inline int wrap_index(int i, int size, int repeat) {
+    if (repeat) { int m = i % size; return (m < 0) ? m + size : m; }      /* REPEAT: i mod size */
+    return (i < 0) ? 0 : ((i >= size) ? size - 1 : i);                    /* CLAMP_TO_EDGE */
+}
+
+static inline v4 fetch_texel(const sfo_texture* t, int i, int j) {
+    v4 c = V4(0.0f, 0.0f, 0.0f, 1.0f);
+    float* out = &c.x;
+    int64_t base = ((int64_t)j*t->width + i)*t->components;
+    for (int k = 0; k < t->components && k < 4; k++) {
+        if (t->dtype == SFO_U8) out[k] = (float)((const uint8_t*)t->data)[base + k]/255.0f;
+        else if (t->dtype == SFO_U16) out[k] = (float)((const uint16_t*)t->data)[base + k]/65535.0f;
+        else out[k] = ((const float*)t->data)[base + k];
+    }
+    return c;
+}
+
+static v4 sample(const sfo_texture* t, v2 uv) {
+    float u = uv.x*(float)t->width;
+    float v = uv.y*(float)t->height;
+    if (t->filter == SFO_NEAREST) {
+        int i = wrap_index((int)floorf(u), t->width, t->repeat_x);
+        int j = wrap_index((int)floorf(v), t->height, t->repeat_y);
+        return fetch_texel(t, i, j);
+    }
+    float ub = u - 0.5f, vb = v - 0.5f;
+    float fu = floorf(ub), fv = floorf(vb);
+    float a = ub - fu, b = vb - fv;
+    int i0 = wrap_index((int)fu, t->width, t->repeat_x), i1 = wrap_index((int)fu + 1, t->width, t->repeat_x);
+    int j0 = wrap_index((int)fv, t->height, t->repeat_y), j1 = wrap_index((int)fv + 1, t->height, t->repeat_y);
+    v4 t00 = fetch_texel(t, i0, j0), t10 = fetch_texel(t, i1, j0);
+    v4 t01 = fetch_texel(t, i0, j1), t11 = fetch_texel(t, i1, j1);
+    float na = 1.0f - a, nb = 1.0f - b;
+    float w00 = na*nb, w10 = a*nb, w01 = na*b, w11 = a*b;
+    v4 r;
+    r.x = fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00*t00.x)));
+    r.y = fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00*t00.y)));
+    r.z = fmaf(w11, t11.z, fmaf(w01, t01.z, fmaf(w10, t10.z, w00*t00.z)));
+    r.w = fmaf(w11, t11.w, fmaf(w01, t01.w, fmaf(w10, t10.w, w00*t00.w)));
+    return r;
+}
+
+void sfo_sample(const sfo_texture* t, float s, float tt, float rgba[4]) {
+    v4 c = sample(t, V2(s, tt));
+    rgba[0] = c.x; rgba[1] = c.y; rgba[2] = c.z; rgba[3] = c.w;
+}
+
+static inline uint8_t to_unorm8(float c) {
+    c = (c > 0.0f) ? c : 0.0f;            /* NaN → 0 */
+    c = (c < 1.0f) ? c : 1.0f;
+    return (uint8_t)rintf(c*255.0f);
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Varyings and prelude */
+
+typedef struct {
+    const sfo_uniforms* u;
+    const sfo_texture* tex;
+    v2 agluv, gluv, astuv, stuv, stxy, glxy, fragCoord;
+    float aspect;                         /* iAspectRatio, shaderflow.glsl:16 */
+} frag_in;
+
+/* camera.glsl:15-51 */
+typedef struct {
+    v3 position, up, right, forward, backward, origin, target, plane_point, plane_normal;
+    float orbital, dolly, separation, focal_length, isometric, zoom;
+    int projection;
+    v2 gluv, agluv, stuv, astuv, glxy, stxy;
+    int out_of_bounds;
+} camera_t;
+
+static inline v2 gluv2stuv(v2 g) { return V2((g.x + 1.0f)/2.0f, (g.y + 1.0f)/2.0f); }        /* shaderflow.glsl:95 */
+static inline v2 stuv2gluv(v2 s) { return V2((s.x*2.0f) - 1.0f, (s.y*2.0f) - 1.0f); }        /* shaderflow.glsl:91 */
+
+static void make_varyings(frag_in* f, int i, int j, int wr, int hr) {
+    const sfo_uniforms* u = f->u;
+    f->aspect = u->iResolution[0]/u->iResolution[1];
+    v2 astuv0 = V2(((float)i + 0.5f)/(float)wr, ((float)j + 0.5f)/(float)hr);
+    f->agluv = V2(astuv0.x*2.0f - 1.0f, astuv0.y*2.0f - 1.0f);
+    f->gluv = V2(f->agluv.x*f->aspect, f->agluv.y*1.0f);                 /* shaderflow.glsl:99 */
+    f->astuv = gluv2stuv(f->agluv);                                       /* vertex/default.glsl:10 */
+    f->stuv = gluv2stuv(f->gluv);                                         /* :11 */
+    f->stxy = V2(u->iResolution[0]*f->astuv.x + 1.0f, u->iResolution[1]*f->astuv.y + 1.0f);   /* :14 */
+    f->glxy = V2(f->stxy.x - u->iResolution[0]/2.0f, f->stxy.y - u->iResolution[1]/2.0f);     /* :15 */
+    f->fragCoord = f->stxy;                                               /* :16 */
+}
+
+/* shaderflow.glsl:75-77; GLSL mat2(a,b,c,d) is column-major: m*v = (a*x + c*y, b*x + d*y) */
+static inline v2 rotate2d_mul(float angle, v2 p) {
+    float c = sfo_cos(angle), s = sfo_sin(angle);
+    return V2(c*p.x + s*p.y, (-s)*p.x + c*p.y);
+}
+/* shaderflow.glsl:361-363 */
+static inline v2 zoom_anchor(v2 uv, float zoom, v2 anchor) {
+    float z2 = zoom*zoom;
+    return V2((uv.x - anchor.x)*z2 + anchor.x, (uv.y - anchor.y)*z2 + anchor.y);
+}
+/* shaderflow.glsl:165-169: textureSize, scale = (res.y/res.x, 1), texture(image, gluv2stuv(gluv*scale)) */
+static inline v4 gtexture(const sfo_texture* t, v2 gluv) {
+    v2 scale = V2((float)t->height/(float)t->width, 1.0f);
+    return sample(t, gluv2stuv(V2(gluv.x*scale.x, gluv.y*scale.y)));
+}
+static inline v4 stexture(const sfo_texture* t, v2 stuv) { return gtexture(t, stuv2gluv(stuv)); }   /* :198-200 */
+static inline float atan1n(v2 p) { return sfo_atan2(p.y, p.x)/SFO_PI; }                              /* :378-380 */
+static inline float atan2_0_tau(float y, float x) {                                                  /* :382-388 */
+    if (y < 0.0f) return SFO_TAU - sfo_atan2(-y, x);
+    return sfo_atan2(y, x);
+}
+/* shaderflow.glsl:406-425 */
+static v3 hsv2rgb(float h, float s, float v) {
+    h = sfo_mod(h, SFO_TAU);
+    float c = v*s;
+    float x = c*(1.0f - sfo_abs(sfo_mod(h/(SFO_PI/3.0f), 2.0f) - 1.0f));
+    float m = v - c;
+    v3 rgb;
+    switch ((int)floorf(6.0f*(h/(2.0f*SFO_PI)))) {
+        case 0: rgb = V3(c, x, 0.0f); break;
+        case 1: rgb = V3(x, c, 0.0f); break;
+        case 2: rgb = V3(0.0f, c, x); break;
+        case 3: rgb = V3(0.0f, x, c); break;
+        case 4: rgb = V3(x, 0.0f, c); break;
+        case 5: rgb = V3(c, 0.0f, x); break;
+        default: rgb = V3(0.0f, 0.0f, 0.0f);
+    }
+    return V3(rgb.x + m, rgb.y + m, rgb.z + m);
+}
+
+/* camera.glsl:53-71 */
+static inline v3 camera_rectangle(const camera_t* c, v2 gluv, float size) {
+    v3 a = v3_scale(c->right, gluv.x), b = v3_scale(c->up, gluv.y);
+    return v3_scale(v3_add(a, b), size);
+}
+static inline v3 camera_ray_origin(const camera_t* c, v2 gluv) {
+    v3 r = v3_add(c->position, camera_rectangle(c, gluv, c->zoom*c->isometric));
+    r = v3_add(r, v3_scale(c->backward, c->orbital));
+    return v3_add(r, v3_scale(c->backward, c->dolly));
+}
+static inline v3 camera_ray_target(const camera_t* c, v2 gluv) {
+    v3 r = v3_add(c->position, camera_rectangle(c, gluv, c->zoom));
+    r = v3_add(r, v3_scale(c->backward, c->orbital));
+    return v3_add(r, v3_scale(c->forward, c->focal_length));
+}
+/* shaderflow.glsl:81-83: mix(dot(axis,v)*axis, v, cos) + cross(axis,v)*sin */
+static v3 rotate3d(v3 vector, v3 axis, float angle) {
+    float c = sfo_cos(angle), s = sfo_sin(angle);
+    float d = v3_dot(axis, vector);
+    v3 pa = v3_scale(axis, d);
+    v3 m = V3(sfo_mix(pa.x, vector.x, c), sfo_mix(pa.y, vector.y, c), sfo_mix(pa.z, vector.z, c));
+    v3 cr = V3(axis.y*vector.z - vector.y*axis.z, axis.z*vector.x - vector.z*axis.x, axis.x*vector.y - vector.x*axis.y);
+    return v3_add(m, v3_scale(cr, s));
+}
+static inline float sfo_sign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+
+/* camera.glsl:132-155 (GetCamera) → :93-130 (CameraProject) → :73-91 (CameraRay2D) */
+static camera_t get_camera(const frag_in* f) {
+    const sfo_uniforms* u = f->u;
+    camera_t c;
+    c.plane_point = V3(0.0f, 0.0f, 1.0f);
+    c.plane_normal = V3(0.0f, 0.0f, 1.0f);
+    c.projection = u->iCameraProjection;
+    c.position = V3(u->iCameraPosition[0], u->iCameraPosition[1], u->iCameraPosition[2]);
+    c.orbital = u->iCameraOrbital;
+    c.dolly = u->iCameraDolly;
+    c.up = V3(u->iCameraUpward[0], u->iCameraUpward[1], u->iCameraUpward[2]);
+    c.right = V3(u->iCameraRight[0], u->iCameraRight[1], u->iCameraRight[2]);
+    c.forward = V3(u->iCameraForward[0], u->iCameraForward[1], u->iCameraForward[2]);
+    c.backward = v3_scale(c.forward, -1.0f);
+    c.isometric = u->iCameraIsometric;
+    c.focal_length = u->iCameraFocalLength;
+    c.zoom = u->iCameraZoom;
+    c.separation = u->iCameraSeparation;
+    c.out_of_bounds = 0;
+
+    if (c.projection == 0) {                                              /* Perspective, :96-98 */
+        c.origin = camera_ray_origin(&c, f->gluv);
+        c.target = camera_ray_target(&c, f->gluv);
+    } else if (c.projection == 1) {                                       /* Stereoscopic, :101-110 */
+        float sg = sfo_sign(f->agluv.x);
+        v2 g = V2(f->gluv.x - sg*(f->aspect/2.0f), f->gluv.y - sg*0.0f);
+        c.position = v3_add(c.position, v3_scale(c.right, sg*c.separation));
+        c.origin = camera_ray_origin(&c, g);
+        c.target = camera_ray_target(&c, g);
+    } else {                                                              /* Equirectangular, :113-126 */
+        float inclination = c.zoom*(SFO_PI*f->agluv.y/2.0f);
+        float azimuth = c.zoom*(SFO_PI*f->agluv.x/1.0f);
+        v3 target = c.forward;
+        target = rotate3d(target, c.right, -inclination);
+        target = rotate3d(target, c.up, azimuth);
+        c.origin = c.position;
+        c.target = v3_add(c.position, target);
+    }
+
+    /* CameraRay2D, :73-91 */
+    float num = v3_dot(v3_sub(c.plane_point, c.origin), c.plane_normal);
+    float den = v3_dot(v3_sub(c.target, c.origin), c.plane_normal);
+    float t = num/den;
+    c.out_of_bounds = (t < 0.0f) || (sfo_abs(f->gluv.x) > u->iWantAspect);
+    v3 hit = v3_add(c.origin, v3_scale(v3_sub(c.target, c.origin), t));
+    c.gluv = V2(hit.x, hit.y);
+    c.agluv = V2(c.gluv.x/f->aspect, c.gluv.y/1.0f);
+    c.stuv = V2((c.gluv.x + 1.0f)/2.0f, (c.gluv.y + 1.0f)/2.0f);
+    c.astuv = V2((c.agluv.x + 1.0f)/2.0f, (c.agluv.y + 1.0f)/2.0f);
+    c.stxy = V2(u->iResolution[0]*c.astuv.x, u->iResolution[1]*c.astuv.y);
+    c.glxy = V2(c.stxy.x - u->iResolution[0]/2.0f, c.stxy.y - u->iResolution[1]/2.0f);
+    return c;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Fragments */
+
+/* fragment/default.glsl:1-48 */
+static v3 default_grid(v2 uv, float grid) {                               /* :4-8 */
+    if (sfo_mod(floorf(uv.x*grid/2.0f) + floorf(uv.y*grid/2.0f), 2.0f) > 0.5f) return V3(0.22f, 0.22f, 0.22f);
+    return V3(0.20f, 0.20f, 0.20f);
+}
+static v4 frag_default(const frag_in* f) {
+    const sfo_uniforms* u = f->u;
+    camera_t cam = get_camera(f);
+    v4 col = V4(0.0f, 0.0f, 0.0f, 0.0f);
+    v2 uv = cam.gluv;
+    if (cam.out_of_bounds) return V4(0.15f, 0.15f, 0.15f, 1.0f);          /* :15-17 */
+    float angle = atan2_0_tau(uv.y, uv.x);                                /* :21 */
+    v3 hsv = hsv2rgb(angle + (2.0f*SFO_TAU*u->iTau) - (SFO_PI/4.0f), 1.0f, 1.0f);
+    v3 color = V3(0.3f + hsv.x, 0.3f + hsv.y, 0.3f + hsv.z);             /* :24 */
+    float circle = (1.333f*v2_length(uv) - 1.0f);                         /* :27 */
+    float width = 2.0f*sfo_abs(1.0f/(circle*circle))*1e-4f;               /* :28 */
+    if (circle < 0.0f) { col.x += 0.18f; col.y += 0.18f; col.z += 0.18f; }   /* :31-32 */
+    else { v3 g = default_grid(uv, 8.0f); col.x += g.x; col.y += g.y; col.z += g.z; }   /* :34 (LOGO false) */
+    col.x += (width*color.x); col.y += (width*color.y); col.z += (width*color.z);        /* :38 */
+    col.w = 1.0f;
+    v2 away = V2(f->astuv.x*(1.0f - f->astuv.y), f->astuv.y*(1.0f - f->astuv.x));       /* :42 */
+    float linear = 50.0f*(away.x*away.y);                                 /* :43 */
+    float vig = sfo_clamp(sfo_pow(linear, 0.1f), 0.0f, 1.0f);             /* :44 */
+    col.x *= vig; col.y *= vig; col.z *= vig;
+    return col;
+}
+
+/* fragment/missing.glsl:4-22 */
+static v4 frag_missing(const frag_in* f) {
+    v4 col = V4(0.0f, 0.0f, 0.0f, 0.0f);
+    v2 uv = V2(f->stuv.x + f->u->iTime/64.0f, f->stuv.y + f->u->iTime/64.0f);
+    float size = 8.0f;
+    for (int x = -5; x < 5; x++) {
+        for (int y = -5; y < 5; y++) {
+            v2 block = V2(floorf(size*uv.x), floorf(size*uv.y));
+            if (sfo_mod(block.x + block.y, 2.0f) == 0.0f) {
+                col.x += 1.0f/25.0f; col.y += 0.0f/25.0f; col.z += 1.0f/25.0f;
+            }
+        }
+    }
+    col.w = 0.2f;
+    return col;
+}
+
+/* examples/basic/shaders/visualizer.frag:6-74 */
+static v4 frag_visualizer(const frag_in* f) {
+    const sfo_uniforms* u = f->u;
+    const sfo_texture* background = &f->tex[SFO_TEX_BACKGROUND];
+    camera_t cam = get_camera(f);
+    v2 uv = cam.gluv;
+    v3 space = V3(1.0f/255.0f, 11.0f/255.0f, 26.0f/255.0f);               /* :9 */
+    v4 col = V4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (cam.out_of_bounds) { col.x = space.x; col.y = space.y; col.z = space.z; return col; }   /* :11-14 */
+
+    /* :17-19 */
+    v2 bg = zoom_anchor(gluv2stuv(uv), 0.95f + 0.01f*sfo_sin(u->iTime) - 0.02f*u->iAudioVolume - 0.03f, V2(0.5f, 0.5f));
+    bg.x += 0.005f*sfo_cos(u->iTime*3.25135f);
+    bg.y += 0.005f*sfo_sin(u->iTime*1.153469f);
+    col = stexture(background, bg);
+
+    {   /* :21-33; float loop counters evaluated in binary32 (9 directions x 10 steps) */
+        float intensity = 0.01f*sfo_clamp(sfo_pow(u->iAudioVolume, 2.5f), 0.0f, 0.3f);
+        float quality = 10.0f;
+        float directions = 8.0f;
+        v4 color = col;
+        for (float angle = 0.0f; angle < SFO_TAU; angle += SFO_TAU/directions) {
+            for (float walk = 1.0f/quality; walk <= 1.001f; walk += 1.0f/quality) {
+                v2 disp = V2(sfo_cos(angle)*walk*intensity, sfo_sin(angle)*walk*intensity);
+                v4 s = stexture(background, V2(bg.x + disp.x, bg.y + disp.y));
+                color.x += s.x; color.y += s.y; color.z += s.z; color.w += s.w;
+            }
+        }
+        float div = quality*directions;
+        col = V4(color.x/div, color.y/div, color.z/div, color.w/div);
+    }
+
+    {   /* :36 */
+        float k = 1.0f + 5.0f*u->iAudioSTD*sfo_pow(sfo_clamp(v2_length(f->agluv) - 0.3f, 0.0f, 1.0f), 6.0f);
+        col.x *= k; col.y *= k; col.z *= k; col.w *= k;
+    }
+
+    /* :39-41 */
+    v2 music_uv = rotate2d_mul(-SFO_PI/2.0f, uv);
+    float shrink = 1.0f - 0.4f*sfo_pow(sfo_abs(u->iAudioVolume), 0.5f);
+    music_uv.x *= shrink; music_uv.y *= shrink;
+    float radius = 0.17f;
+
+    /* :44-46 */
+    float circle = sfo_abs(atan1n(music_uv));
+    v4 spec = sample(&f->tex[SFO_TEX_SPECTROGRAM], V2(0.0f, circle));
+    v2 freq = V2(sfo_sqrt(spec.x/1000.0f), sfo_sqrt(spec.y/1000.0f));
+    float gain = 0.05f + 3.0f*sfo_smoothstep(0.0f, 2.0f, circle);
+    freq.x *= gain; freq.y *= gain;
+
+    /* :49-60 */
+    float len = v2_length(music_uv);
+    if (len < radius) {
+        col.x *= 0.5f; col.y *= 0.5f; col.z *= 0.5f;
+    } else {
+        float bar = (music_uv.y < 0.0f) ? freq.x : freq.y;
+        float r = radius + 0.5f*bar;
+        if (len < r) {
+            float t = sfo_smoothstep(0.0f, 1.0f, 0.5f + bar);
+            col.x = sfo_mix(col.x, 1.0f, t); col.y = sfo_mix(col.y, 1.0f, t); col.z = sfo_mix(col.z, 1.0f, t);
+        } else {
+            float k = sfo_pow((len - r)*0.5f, 0.05f);
+            col.x *= k; col.y *= k; col.z *= k;
+        }
+    }
+
+    {   /* :62 */
+        float t = sfo_smoothstep(0.0f, 1.0f, v2_length(uv)/20.0f);
+        col.x = sfo_mix(col.x, space.x, t); col.y = sfo_mix(col.y, space.y, t); col.z = sfo_mix(col.z, space.z, t);
+    }
+
+    {   /* :65-67 */
+        v2 vig = V2(f->astuv.x*(1.0f - f->astuv.y), f->astuv.y*(1.0f - f->astuv.x));
+        float k = sfo_pow(vig.x*vig.y*20.0f, 0.1f + 0.15f*u->iAudioVolume);
+        col.x *= k; col.y *= k; col.z *= k;
+        col.w = 1.0f;
+    }
+
+    {   /* :71-73 */
+        v4 w = sample(&f->tex[SFO_TEX_WAVEFORM], V2(f->astuv.x, 0.0f));
+        v2 wave = V2(0.2f*w.x, 0.2f*w.y);
+        if (1.0f - f->gluv.y < wave.x) { col.x *= 0.8f; col.y *= 0.8f; col.z *= 0.8f; col.w *= 0.8f; }
+        if (1.0f + f->gluv.y < wave.y) { col.x *= 0.8f; col.y *= 0.8f; col.z *= 0.8f; col.w *= 0.8f; }
+    }
+    return col;
+}
+
+/* examples/basic/shaders/bars.frag:5-22 */
+static v4 frag_bars(const frag_in* f) {
+    v4 col = V4(0.0f, 0.0f, 0.0f, 0.0f);
+    v4 s = sample(&f->tex[SFO_TEX_SPECTROGRAM], V2(f->astuv.y, f->astuv.x));
+    v2 intensity = V2(sfo_sqrt(s.x)/120.0f, sfo_sqrt(s.y)/120.0f);
+    if (f->astuv.y < intensity.x) { col.x += 1.0f; col.y += 0.0f; col.z += 0.0f; }
+    if (f->astuv.y < intensity.y) { col.x += 0.0f; col.y += 1.0f; col.z += 0.0f; }
+    if (f->astuv.y < (intensity.y + intensity.x)/2.0f) { col.x += 0.0f; col.y += 0.0f; col.z += 1.0f; }
+    col.z += 0.4f*(intensity.x + intensity.y)*(1.0f - f->astuv.y);
+    col.w = 1.0f;
+    return col;
+}
+
+/* examples/basic/shaders/waveform.frag:5-19 */
+static v4 frag_waveform(const frag_in* f) {
+    v4 w = sample(&f->tex[SFO_TEX_WAVEFORM], V2(f->astuv.x, 0.0f));
+    v4 col = V4(0.2f, 0.2f, 0.2f, 1.0f);
+    float ay = sfo_abs(f->gluv.y);
+    if (ay < w.x) col.x = 1.0f;
+    if (ay < w.y) col.y = 1.0f;
+    if (ay < (w.x + w.y)/2.0f) col.z = 1.0f;
+    return col;
+}
+
+/* examples/basic/demo.py:74-79 and :83-89 (MultiShader) */
+static v4 frag_multi_child(const frag_in* f) { return V4(0.0f, 1.0f - f->stuv.x, 0.0f, 1.0f); }
+static v4 frag_multi_main(const frag_in* f) {
+    v4 c = sample(&f->tex[SFO_TEX_CHILD], f->astuv);
+    return V4(f->stuv.x + c.x, 0.0f + c.y, 0.0f + c.z, 1.0f);
+}
+
+/* examples/basic/shaders/shadertoy.frag:62-66 */
+static v4 frag_shadertoy(const frag_in* f) {
+    float t = f->u->iTime;
+    return V4(0.5f + 0.5f*sfo_cos(t + f->stuv.x + 0.0f),
+              0.5f + 0.5f*sfo_cos(t + f->stuv.y + 2.0f),
+              0.5f + 0.5f*sfo_cos(t + f->stuv.x + 4.0f), 1.0f);
+}
+
+/* examples/basic/demo.py:121-126 (Dynamics): user[0] = iShaderDynamics */
+static v4 frag_dynamics(const frag_in* f) {
+    v2 uv = zoom_anchor(f->stuv, 0.85f + 0.1f*f->u->user[0], V2(0.5f, 0.5f));
+    return stexture(&f->tex[SFO_TEX_BACKGROUND], uv);
+}
+
+/* examples/basic/demo.py:149-153 (Audio) */
+static v4 frag_audio(const frag_in* f) {
+    float v = f->u->iAudioVolume;
+    return V4(v, v, v, 1.0f);
+}
+
+static v4 shade(int fragment, const frag_in* f) {
+    switch (fragment) {
+        case SFO_FRAG_DEFAULT: return frag_default(f);
+        case SFO_FRAG_VISUALIZER: return frag_visualizer(f);
+        case SFO_FRAG_BARS: return frag_bars(f);
+        case SFO_FRAG_WAVEFORM: return frag_waveform(f);
+        case SFO_FRAG_MULTI_CHILD: return frag_multi_child(f);
+        case SFO_FRAG_MULTI_MAIN: return frag_multi_main(f);
+        case SFO_FRAG_SHADERTOY: return frag_shadertoy(f);
+        case SFO_FRAG_DYNAMICS: return frag_dynamics(f);
+        case SFO_FRAG_AUDIO: return frag_audio(f);
+        default: return frag_missing(f);
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Row-band drivers */
+
+typedef struct {
+    int kind;                 /* 0 render, 1 resolve */
+    int fragment; const sfo_uniforms* u; const sfo_texture* tex;
+    int wr, hr, w, h, subsample, y0, y1;
+    const uint8_t* screen; uint8_t* out;
+} job_t;
+
+static void render_rows(const job_t* jb) {
+    frag_in f; f.u = jb->u; f.tex = jb->tex;
+    for (int j = jb->y0; j < jb->y1; j++) {
+        for (int i = 0; i < jb->wr; i++) {
+            make_varyings(&f, i, j, jb->wr, jb->hr);
+            v4 c = shade(jb->fragment, &f);
+            uint8_t* px = jb->out + ((int64_t)j*jb->wr + i)*4;
+            px[0] = to_unorm8(c.x); px[1] = to_unorm8(c.y); px[2] = to_unorm8(c.z); px[3] = to_unorm8(c.w);
+        }
+    }
+}
+
+/* fragment/final.glsl:1-33; iScreen is RGBA8, linear, repeat(False) (scene.py:192-194, texture.py:108-112) */
+static void resolve_rows(const job_t* jb) {
+    sfo_texture screen = { jb->screen, jb->wr, jb->hr, 4, SFO_U8, SFO_LINEAR, 0, 0 };
+    const int kernel = jb->subsample;
+    const float resx = (float)jb->w, resy = (float)jb->h;               /* iResolution := scene.resolution, shader.py:394 */
+    for (int j = jb->y0; j < jb->y1; j++) {
+        for (int i = 0; i < jb->w; i++) {
+            v2 astuv0 = V2(((float)i + 0.5f)/(float)jb->w, ((float)j + 0.5f)/(float)jb->h);
+            v2 agluv = V2(astuv0.x*2.0f - 1.0f, astuv0.y*2.0f - 1.0f);
+            v2 astuv = gluv2stuv(agluv);
+            v3 rgb;
+            if (kernel == 1) {                                          /* :6-10 */
+                v4 c = sample(&screen, astuv);
+                rgb = V3(c.x, c.y, c.z);
+            } else {
+                v3 acc = V3(0.0f, 0.0f, 0.0f);                          /* :13 */
+                v2 pixel_size = V2(1.0f/resx, 1.0f/resy);               /* :17 */
+                v2 corner = V2(astuv.x - (pixel_size.x/2.0f), astuv.y - (pixel_size.y/2.0f));        /* :20 */
+                v2 origin = V2(corner.x + (pixel_size.x/(float)kernel)/2.0f, corner.y + (pixel_size.y/(float)kernel)/2.0f);   /* :21 */
+                for (int x = 0; x < kernel; x++) {
+                    for (int y = 0; y < kernel; y++) {
+                        v2 offset = V2((pixel_size.x/(float)kernel)*(float)x, (pixel_size.y/(float)kernel)*(float)y);   /* :25 */
+                        v4 c = sample(&screen, V2(origin.x + offset.x, origin.y + offset.y));
+                        acc.x += c.x; acc.y += c.y; acc.z += c.z;       /* :26 */
+                    }
+                }
+                float n = (float)(kernel*kernel);
+                rgb = V3(acc.x/n, acc.y/n, acc.z/n);                    /* :31 */
+            }
+            uint8_t* px = jb->out + ((int64_t)j*jb->w + i)*3;
+            px[0] = to_unorm8(rgb.x); px[1] = to_unorm8(rgb.y); px[2] = to_unorm8(rgb.z);
+        }
+    }
+}
+
+static void* job_main(void* arg) {
+    const job_t* jb = (const job_t*)arg;
+    if (jb->kind == 0) render_rows(jb); else resolve_rows(jb);
+    return NULL;
+}
+
+static void run_jobs(job_t base, int threads) {
+    int rows = base.y1 - base.y0;
+    if (threads < 1) threads = 1;
+    if (threads > rows) threads = rows > 0 ? rows : 1;
+    if (threads == 1) { job_main(&base); return; }
+    pthread_t* tid = (pthread_t*)malloc(sizeof(pthread_t)*threads);
+    job_t* jobs = (job_t*)malloc(sizeof(job_t)*threads);
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = base;
+        jobs[t].y0 = base.y0 + (int)((int64_t)rows*t/threads);
+        jobs[t].y1 = base.y0 + (int)((int64_t)rows*(t + 1)/threads);
+        pthread_create(&tid[t], NULL, job_main, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+    free(tid); free(jobs);
+}
+
+void sfo_render(int fragment, const sfo_uniforms* u, const sfo_texture* textures,
+                int wr, int hr, int y0, int y1, int threads, uint8_t* out) {
+    job_t jb = {0};
+    jb.kind = 0; jb.fragment = fragment; jb.u = u; jb.tex = textures;
+    jb.wr = wr; jb.hr = hr; jb.y0 = y0; jb.y1 = y1; jb.out = out;
+    run_jobs(jb, threads);
+}
+
+void sfo_resolve(const uint8_t* screen, int wr, int hr, int w, int h, int subsample,
+                 int y0, int y1, int threads, uint8_t* out) {
+    job_t jb = {0};
+    jb.kind = 1; jb.screen = screen; jb.wr = wr; jb.hr = hr; jb.w = w; jb.h = h;
+    jb.subsample = subsample < 1 ? 1 : subsample; jb.y0 = y0; jb.y1 = y1; jb.out = out;
+    run_jobs(jb, threads);
+}
+
+float sfo_test_math(int fn, float a, float b) {
+    switch (fn) {
+        case 0: return sfo_sin(a);
+        case 1: return sfo_cos(a);
+        case 2: return sfo_atan2(a, b);
+        case 3: return sfo_atan(a);
+        case 4: return sfo_log2(a);
+        case 5: return sfo_exp2(a);
+        case 6: return sfo_pow(a, b);
+        case 7: return sfo_exp(a);
+        case 8: return sfo_mod(a, b);
+        case 9: return sfo_smoothstep(0.0f, a, b);
+        case 10: return sfo_mix(0.25f, a, b);
+        case 11: return sfo_sqrt(a);
+        default: return 0.0f;
+    }
+}
