@@ -1,0 +1,206 @@
+/*
+ * shaderflow_hip.h — C-ABI of libshaderflow_hip.so: the MI355X (gfx950) implementation of ShaderFlow's
+ * per-frame STFT → spectrogram → per-pixel fragment → SSAA resolve → frame read-out path.
+ *
+ * The reference (BrokenSource/ShaderFlow v0.11.3) has no FFI for this path: it calls numpy/scipy and,
+ * through moderngl, an OpenGL driver. Each entry point below replaces one group of those third-party
+ * calls; the reference call site it stands for is cited as file:line (paths relative to the reference
+ * repository root). The Python host package (shaderflow_amd/) binds these with ctypes; INTEGRATION.md
+ * shows the stub a maintainer of the reference would add.
+ *
+ * Conventions: plain C types only; opaque 64-bit handles; every function returns SFX_OK (0) or a negative
+ * SFX_E_* code and leaves a message for sfx_last_error() (thread-local). Host pointers are borrowed for the
+ * duration of the call. All work of a context is issued on ONE HIP stream (its own, or the caller's when
+ * `stream` is given to sfx_ctx_create) — like the reference, where everything runs on the GL context's
+ * thread (scene.py:128-195). Calls on one context must come from one thread at a time.
+ * Image rows are bottom-up everywhere (OpenGL order), exactly what `fbo.read` hands to ffmpeg's `vflip`
+ * (exporting.py:94-103,170-174).
+ */
+#ifndef SHADERFLOW_HIP_H
+#define SHADERFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t sfx_handle;
+
+enum {
+    SFX_OK = 0,
+    SFX_E_INVALID = -1,        /* bad argument / handle                                    */
+    SFX_E_HIP = -2,            /* a HIP runtime call failed (message carries hipGetErrorString) */
+    SFX_E_NO_DEVICE = -3,      /* no gfx950 device visible                                  */
+    SFX_E_UNSUPPORTED = -4,    /* combination not implemented by a kernel                   */
+    SFX_E_IO = -5,             /* pipe / file descriptor write failed                       */
+    SFX_E_TOO_LARGE = -6,      /* texture exceeds the context limit (texture.py:251-252)    */
+};
+
+enum { SFX_U8 = 0, SFX_F32 = 1, SFX_U16 = 2, SFX_F16 = 3 };          /* numpy2mgltype, texture.py:28-38 */
+enum { SFX_NEAREST = 0, SFX_LINEAR = 1 };                              /* TextureFilter, texture.py:42-44 */
+enum { SFX_WINDOW_HANNING = 0, SFX_WINDOW_HANN_POISSON = 1, SFX_WINDOW_NONE = 2 };   /* spectrogram.py:90-108 */
+enum { SFX_REDUCER_AVERAGE = 0, SFX_REDUCER_RMS = 1, SFX_REDUCER_STD = 2 };          /* waveform.py:14-22 */
+
+/* GLSL uniform types accepted by sfx_uniform_set (variable.py:12-23) */
+enum { SFX_T_FLOAT = 0, SFX_T_INT = 1, SFX_T_BOOL = 2, SFX_T_VEC2 = 3, SFX_T_VEC3 = 4, SFX_T_VEC4 = 5 };
+
+const char* sfx_last_error(void);
+const char* sfx_version(void);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Context — replaces window/GL-context creation (scene.py:145-157) and GL_MAX_VIEWPORT_DIMS (texture.py:251) */
+
+typedef struct {
+    char device_name[128];
+    char gcn_arch[64];
+    int32_t device_id;
+    int32_t compute_units;
+    int32_t max_texture_dim;       /* what ShaderTexture.make checks against */
+    int32_t wavefront_size;
+    int64_t total_memory;
+    int64_t lds_per_cu;
+} sfx_ctx_info_t;
+
+int sfx_ctx_create(int device_id, void* stream /* hipStream_t or NULL */, sfx_handle* ctx);
+int sfx_ctx_info(sfx_handle ctx, sfx_ctx_info_t* info);
+int sfx_ctx_synchronize(sfx_handle ctx);
+int sfx_ctx_destroy(sfx_handle ctx);
+
+/* Timing on the context's stream with HIP events (bench.py roofline leg). slot in [0, 64). */
+int sfx_event_record(sfx_handle ctx, int slot);
+int sfx_event_elapsed_ms(sfx_handle ctx, int start_slot, int stop_slot, float* ms);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Textures — replace opengl.texture/framebuffer and their setters (texture.py:261-283), write
+ * (texture.py:313-325), release (texture.py:63-67), fbo.read (scene.py:441) */
+
+int sfx_texture_create(sfx_handle ctx, int width, int height, int components, int dtype, sfx_handle* tex);
+int sfx_texture_params(sfx_handle tex, int filter, int repeat_x, int repeat_y);
+/* viewport (x, y, w, h) in texels, row 0 = bottom; w == h == 0 means the whole texture */
+int sfx_texture_write(sfx_handle tex, const void* data, size_t nbytes, int x, int y, int w, int h);
+int sfx_texture_read(sfx_handle tex, void* data, size_t nbytes);
+int sfx_texture_device_ptr(sfx_handle tex, void** ptr, size_t* nbytes);
+int sfx_texture_destroy(sfx_handle tex);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Programs — replace opengl.program(vs, fs) (shader.py:324), program[name].value = v (shader.py:353-360),
+ * sampler binding (shader.py:377-386) and fbo.use(); vao.render() (shader.py:367-375, 388-405).
+ *
+ * There is no GLSL compiler: `source` (the USER part of the fragment, shader.py:229-235) is normalised
+ * (comments and whitespace stripped) and looked up in the registry of fragments restated as HIP kernels.
+ * `*fallback` is set to 1 when it is unknown and the `missing.glsl` kernel was bound instead — the
+ * reference's compile-error behaviour (shader.py:323-340). A registry name ("visualizer", "default" …)
+ * is accepted in place of the source. */
+
+int sfx_program_lookup(sfx_handle ctx, const char* source, sfx_handle* program, int* fallback);
+const char* sfx_program_name(sfx_handle program);
+/* returns SFX_OK whether or not the program reads `name` (inactive uniforms are ignored, shader.py:356-357);
+ * *known (may be NULL) tells which */
+int sfx_uniform_set(sfx_handle program, const char* name, int type, const void* value, int* known);
+int sfx_sampler_bind(sfx_handle program, const char* name, sfx_handle tex, int* known);
+int sfx_program_destroy(sfx_handle program);
+
+/* One draw of the fullscreen quad into `target` (any format; RGBA8 for iScreen): shader.py:401-403 */
+int sfx_render(sfx_handle program, sfx_handle target, int layer);
+/* fragment/final.glsl as a pass: src (RGBA8 iScreen) → dst (RGB8 iFinal): shader.py:391-396 */
+int sfx_resolve(sfx_handle ctx, sfx_handle src, sfx_handle dst, int subsample);
+/* Both fused: shade ssaa x ssaa supersamples per output pixel, quantise to the RGBA8 value iScreen would
+ * hold, resolve in registers, write RGB8 `final` only. Returns SFX_E_UNSUPPORTED for (ssaa, subsample)
+ * pairs whose final.glsl footprint leaves the pixel's own block — use the two calls above then. */
+int sfx_render_resolve(sfx_handle program, sfx_handle final_tex, int ssaa, int subsample);
+int sfx_fused_supported(int ssaa_numerator_x1000, int subsample);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Frame read-out — replaces make_buffers / fbo.read_into / turbopipe.pipe|sync|done (exporting.py:140-174) */
+
+int sfx_ring_create(sfx_handle ctx, size_t frame_bytes, int slots, sfx_handle* ring);
+int sfx_ring_read_async(sfx_handle ring, sfx_handle tex, int slot);                 /* fbo.read_into(buffer) */
+int sfx_ring_read_device_async(sfx_handle ring, const void* device_ptr, int slot);  /* same, from a raw frame */
+int sfx_ring_sync(sfx_handle ring, int slot, void** host_ptr);                      /* buffer.read() */
+int sfx_ring_pipe(sfx_handle ring, int slot, int fd);                               /* turbopipe.pipe */
+int sfx_ring_pipe_sync(sfx_handle ring, int slot);                                  /* turbopipe.sync; slot < 0: all */
+int sfx_ring_destroy(sfx_handle ring);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Audio — replaces BrokenAudio's ring (audio/module.py:113-138), np.hanning/np.fft.rfft/csr.dot
+ * (spectrogram.py:103,170,176), the waveform reduce (waveform.py:80-87) and RMS/std (audio/module.py:457-458).
+ * In export mode the whole file is known, so the "ring" is the PCM itself, resident in HBM: the window
+ * the reference reads after `tell` samples were appended is stream[tell-n-1 : tell-1], zeros before 0. */
+
+int sfx_audio_upload(sfx_handle ctx, const float* interleaved, int64_t samples, int channels,
+                     int samplerate, sfx_handle* audio);
+int sfx_audio_destroy(sfx_handle audio);
+
+/* The filterbank is built by the host exactly as spectrogram.py:194-224 does and handed over as CSR. */
+int sfx_stft_plan(sfx_handle ctx, int fft_n, int window, int bins, int channels,
+                  const int32_t* indptr, const int32_t* indices, const float* data, sfx_handle* plan);
+int sfx_stft_plan_destroy(sfx_handle plan);
+
+/* Per-frame entry points (the faithful frame loop: results come back to the host like numpy arrays).
+ * tell[k] = samples read when frame k is produced. */
+int sfx_stft_power(sfx_handle plan, sfx_handle audio, const int64_t* tell, int nframes,
+                   float* power /* [nframes][channels][fft_bins] */);
+/* M.dot(fft().T): out[frame][bin][channel] — the (bins, 2) buffer of spectrogram.py:176,306.
+ * use_mfma = 1: dense banded GEMM on v_mfma_f32_32x32x2_f32; 0: CSR rows in scipy's order (bit-exact). */
+int sfx_spectrogram_targets(sfx_handle plan, sfx_handle audio, const int64_t* tell, int nframes,
+                            int use_mfma, float* out);
+int sfx_waveform_rows(sfx_handle audio, const int64_t* tell, int nframes, int chunk_size, int points,
+                      int reducer, float* out /* [nframes][points][channels] */);
+int sfx_volume_std(sfx_handle audio, const int64_t* tell, int nframes, int window_samples,
+                   float* out /* [nframes][2] = volume target, std target */);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Frame tape — the batched export path (no reference equivalent): for a run of frames the
+ * device computes everything the modules would have produced frame by frame and keeps it in HBM:
+ * the spectrogram column after DynamicNumber smoothing, the waveform row, and the audio uniforms.
+ * DynamicNumber (dynamics.py:197-250) coefficients depend only on dt and are computed by the host. */
+
+typedef struct {
+    float dt, k1, k2, k3;          /* python scalars rounded to float32 (numpy NEP 50) */
+} sfx_dyn_coeff_f32;
+typedef struct {
+    double dt, k1, k2, k3;
+} sfx_dyn_coeff_f64;
+typedef struct {
+    float iTime, iTau, iSpectrogramOffset;
+    int32_t iFrame;
+} sfx_frame_clock;
+
+typedef struct {
+    int32_t points, chunk_size, reducer;     /* ShaderWaveform (0 points: no waveform)              */
+    int32_t volume_window;                   /* int(0.1*samplerate), audio/module.py:457            */
+    int32_t use_mfma;
+    int32_t volume_integrate, std_integrate; /* ShaderDynamics.integrate (audio/module.py:413-421)  */
+    double precision;                        /* DynamicNumber.precision, dynamics.py:147            */
+} sfx_tape_desc;
+
+int sfx_tape_create(sfx_handle plan, sfx_handle audio, const sfx_tape_desc* desc, int max_frames, sfx_handle* tape);
+int sfx_tape_reset(sfx_handle tape);         /* ShaderDynamics.setup → reset (dynamics.py:273-274)  */
+/* Computes frames [0, nframes) of the tape from the running dynamics state (continues across calls). */
+int sfx_tape_build(sfx_handle tape, int nframes, const int64_t* tell, const sfx_frame_clock* clock,
+                   const sfx_dyn_coeff_f32* spectrogram, const sfx_dyn_coeff_f64* volume,
+                   const sfx_dyn_coeff_f64* std);
+enum { SFX_TAPE_SPECTROGRAM = 0, SFX_TAPE_WAVEFORM = 1, SFX_TAPE_UNIFORMS = 2, SFX_TAPE_TARGETS = 3, SFX_TAPE_LOUDNESS = 4 };
+/* Copies tape content to the host for inspection: SPECTROGRAM [n][bins][channels] f32, WAVEFORM
+ * [n][points][channels] f32, UNIFORMS [n][8] f32 (iTime iTau iAudioVolume iAudioVolumeIntegral iAudioSTD
+ * iSpectrogramOffset iFrame pad), TARGETS (unsmoothed) [n][bins][channels] f32, LOUDNESS [n][2] f32 */
+int sfx_tape_read(sfx_handle tape, int what, int frame0, int nframes, void* out, size_t nbytes);
+int sfx_tape_destroy(sfx_handle tape);
+
+/* Renders tape frames [frame0, frame0+nframes) with `program`, fused path, into a dense device buffer of
+ * nframes RGB8 images (w*h*3 bytes each, rows bottom-up). iSpectrogram/iWaveform samplers and the
+ * audio uniforms come from the tape; everything else from the program's uniform block. */
+int sfx_render_tape(sfx_handle program, sfx_handle tape, int frame0, int nframes,
+                    int width, int height, int ssaa, int subsample, void* device_out);
+
+/* Device memory helper for callers without their own allocator */
+int sfx_device_alloc(sfx_handle ctx, size_t nbytes, void** ptr);
+int sfx_device_free(sfx_handle ctx, void* ptr);
+int sfx_device_read(sfx_handle ctx, const void* device_ptr, void* host, size_t nbytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,194 @@
+"""
+ctypes binding of libshaderflow_hip.so (include/shaderflow_hip.h) — the only way the host package reaches
+the GPU. There is NO CPU fallback: if the library is missing, or no device is visible when a context is
+created, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PACKAGE = Path(__file__).resolve().parent
+LIBRARY = PACKAGE/"libshaderflow_hip.so"
+
+OK = 0
+U8, F32, U16, F16 = 0, 1, 2, 3
+NEAREST, LINEAR = 0, 1
+T_FLOAT, T_INT, T_BOOL, T_VEC2, T_VEC3, T_VEC4 = range(6)
+TAPE_SPECTROGRAM, TAPE_WAVEFORM, TAPE_UNIFORMS, TAPE_TARGETS, TAPE_LOUDNESS = range(5)
+E_UNSUPPORTED = -4
+
+Handle = C.c_uint64
+
+
+class CtxInfo(C.Structure):
+    _fields_ = [("device_name", C.c_char*128), ("gcn_arch", C.c_char*64), ("device_id", C.c_int32),
+                ("compute_units", C.c_int32), ("max_texture_dim", C.c_int32), ("wavefront_size", C.c_int32),
+                ("total_memory", C.c_int64), ("lds_per_cu", C.c_int64)]
+
+
+class DynCoeffF32(C.Structure):
+    _fields_ = [("dt", C.c_float), ("k1", C.c_float), ("k2", C.c_float), ("k3", C.c_float)]
+
+
+class DynCoeffF64(C.Structure):
+    _fields_ = [("dt", C.c_double), ("k1", C.c_double), ("k2", C.c_double), ("k3", C.c_double)]
+
+
+class FrameClock(C.Structure):
+    _fields_ = [("iTime", C.c_float), ("iTau", C.c_float), ("iSpectrogramOffset", C.c_float), ("iFrame", C.c_int32)]
+
+
+class TapeDesc(C.Structure):
+    _fields_ = [("points", C.c_int32), ("chunk_size", C.c_int32), ("reducer", C.c_int32), ("volume_window", C.c_int32),
+                ("use_mfma", C.c_int32), ("volume_integrate", C.c_int32), ("std_integrate", C.c_int32),
+                ("precision", C.c_double)]
+
+
+# name → (restype, argtypes); every symbol declared in include/shaderflow_hip.h
+P = C.POINTER
+PROTOTYPES: dict[str, tuple] = {
+    "sfx_last_error": (C.c_char_p, []),
+    "sfx_version": (C.c_char_p, []),
+    "sfx_ctx_create": (C.c_int, [C.c_int, C.c_void_p, P(Handle)]),
+    "sfx_ctx_info": (C.c_int, [Handle, P(CtxInfo)]),
+    "sfx_ctx_synchronize": (C.c_int, [Handle]),
+    "sfx_ctx_destroy": (C.c_int, [Handle]),
+    "sfx_event_record": (C.c_int, [Handle, C.c_int]),
+    "sfx_event_elapsed_ms": (C.c_int, [Handle, C.c_int, C.c_int, P(C.c_float)]),
+    "sfx_texture_create": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_int, P(Handle)]),
+    "sfx_texture_params": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int]),
+    "sfx_texture_write": (C.c_int, [Handle, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sfx_texture_read": (C.c_int, [Handle, C.c_void_p, C.c_size_t]),
+    "sfx_texture_device_ptr": (C.c_int, [Handle, P(C.c_void_p), P(C.c_size_t)]),
+    "sfx_texture_destroy": (C.c_int, [Handle]),
+    "sfx_program_lookup": (C.c_int, [Handle, C.c_char_p, P(Handle), P(C.c_int)]),
+    "sfx_program_name": (C.c_char_p, [Handle]),
+    "sfx_uniform_set": (C.c_int, [Handle, C.c_char_p, C.c_int, C.c_void_p, P(C.c_int)]),
+    "sfx_sampler_bind": (C.c_int, [Handle, C.c_char_p, Handle, P(C.c_int)]),
+    "sfx_program_destroy": (C.c_int, [Handle]),
+    "sfx_render": (C.c_int, [Handle, Handle, C.c_int]),
+    "sfx_resolve": (C.c_int, [Handle, Handle, Handle, C.c_int]),
+    "sfx_render_resolve": (C.c_int, [Handle, Handle, C.c_int, C.c_int]),
+    "sfx_fused_supported": (C.c_int, [C.c_int, C.c_int]),
+    "sfx_ring_create": (C.c_int, [Handle, C.c_size_t, C.c_int, P(Handle)]),
+    "sfx_ring_read_async": (C.c_int, [Handle, Handle, C.c_int]),
+    "sfx_ring_read_device_async": (C.c_int, [Handle, C.c_void_p, C.c_int]),
+    "sfx_ring_sync": (C.c_int, [Handle, C.c_int, P(C.c_void_p)]),
+    "sfx_ring_pipe": (C.c_int, [Handle, C.c_int, C.c_int]),
+    "sfx_ring_pipe_sync": (C.c_int, [Handle, C.c_int]),
+    "sfx_ring_destroy": (C.c_int, [Handle]),
+    "sfx_audio_upload": (C.c_int, [Handle, P(C.c_float), C.c_int64, C.c_int, C.c_int, P(Handle)]),
+    "sfx_audio_destroy": (C.c_int, [Handle]),
+    "sfx_stft_plan": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_int32), P(C.c_int32), P(C.c_float), P(Handle)]),
+    "sfx_stft_plan_destroy": (C.c_int, [Handle]),
+    "sfx_stft_power": (C.c_int, [Handle, Handle, P(C.c_int64), C.c_int, P(C.c_float)]),
+    "sfx_spectrogram_targets": (C.c_int, [Handle, Handle, P(C.c_int64), C.c_int, C.c_int, P(C.c_float)]),
+    "sfx_waveform_rows": (C.c_int, [Handle, P(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]),
+    "sfx_volume_std": (C.c_int, [Handle, P(C.c_int64), C.c_int, C.c_int, P(C.c_float)]),
+    "sfx_tape_create": (C.c_int, [Handle, Handle, P(TapeDesc), C.c_int, P(Handle)]),
+    "sfx_tape_reset": (C.c_int, [Handle]),
+    "sfx_tape_build": (C.c_int, [Handle, C.c_int, P(C.c_int64), P(FrameClock), P(DynCoeffF32), P(DynCoeffF64), P(DynCoeffF64)]),
+    "sfx_tape_read": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "sfx_tape_destroy": (C.c_int, [Handle]),
+    "sfx_render_tape": (C.c_int, [Handle, Handle, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sfx_device_alloc": (C.c_int, [Handle, C.c_size_t, P(C.c_void_p)]),
+    "sfx_device_free": (C.c_int, [Handle, C.c_void_p]),
+    "sfx_device_read": (C.c_int, [Handle, C.c_void_p, C.c_void_p, C.c_size_t]),
+}
+
+_lib: C.CDLL | None = None
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libshaderflow_hip: {message} (code {code})")
+        self.code = code
+
+
+def lib() -> C.CDLL:
+    """Loads the HIP library; raises ImportError when it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        path = Path(os.environ.get("SHADERFLOW_HIP_LIBRARY", LIBRARY))
+        if not path.exists():
+            raise ImportError(
+                f"{path} is missing: build it with `make -C shaderflow_amd/csrc` "
+                f"(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+            )
+        L = C.CDLL(str(path), mode=C.RTLD_GLOBAL)
+        for name, (restype, argtypes) in PROTOTYPES.items():
+            fn = getattr(L, name)             # AttributeError if the header and the library disagree
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = L
+    return _lib
+
+
+def check(code: int) -> None:
+    if code != OK:
+        raise NativeError(code, lib().sfx_last_error().decode("utf-8", "replace"))
+
+
+def as_ptr(array: np.ndarray, ctype):
+    return array.ctypes.data_as(C.POINTER(ctype))
+
+
+NUMPY_DTYPES = {np.dtype(np.uint8): U8, np.dtype(np.float32): F32, np.dtype(np.uint16): U16}
+
+
+class Context:
+    """One HIP device + one stream (the GL context of scene.py:145-157)"""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.handle = Handle()
+        check(lib().sfx_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self.handle)))
+        self.device = device
+
+    def info(self) -> CtxInfo:
+        info = CtxInfo()
+        check(lib().sfx_ctx_info(self.handle, C.byref(info)))
+        return info
+
+    def synchronize(self) -> None:
+        check(lib().sfx_ctx_synchronize(self.handle))
+
+    def event_record(self, slot: int) -> None:
+        check(lib().sfx_event_record(self.handle, slot))
+
+    def event_elapsed_ms(self, start: int, stop: int) -> float:
+        ms = C.c_float()
+        check(lib().sfx_event_elapsed_ms(self.handle, start, stop, C.byref(ms)))
+        return ms.value
+
+    def alloc(self, nbytes: int) -> int:
+        ptr = C.c_void_p()
+        check(lib().sfx_device_alloc(self.handle, nbytes, C.byref(ptr)))
+        return ptr.value
+
+    def free(self, ptr: int) -> None:
+        check(lib().sfx_device_free(self.handle, C.c_void_p(ptr)))
+
+    def read(self, ptr: int, nbytes: int) -> np.ndarray:
+        out = np.empty(nbytes, np.uint8)
+        check(lib().sfx_device_read(self.handle, C.c_void_p(ptr), out.ctypes.data, nbytes))
+        return out
+
+    def destroy(self) -> None:
+        if self.handle.value:
+            lib().sfx_ctx_destroy(self.handle)
+            self.handle = Handle()
+
+
+_default_context: Context | None = None
+
+
+def default_context() -> Context:
+    """Process-wide context on LOCAL_RANK's device (one process per GPU)"""
+    global _default_context
+    if _default_context is None:
+        _default_context = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_context

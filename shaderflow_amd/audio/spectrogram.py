@@ -1,0 +1,250 @@
+"""
+BrokenSpectrogram / ShaderSpectrogram (reference: shaderflow/audio/spectrogram.py:20-320).
+
+Host side: the option namespaces (FourierMagnitude, FourierVolume, SpectrogramInterpolation, SpectrogramScale,
+SpectrogramWindow) and the filterbank construction (`spectrogram_frequencies`, `spectrogram_matrix`, `from_notes`)
+stay numpy/scipy code — they run once per configuration and define WHAT is computed. Device side: the per-frame
+STFT (`window*frame → radix-2 FFT in float64 → |X|² → float32`, :155-171) and the filterbank product
+(:175-176) are HIP kernels reached through an `sfx_stft_plan`. Options the kernels implement: the three windows,
+`FourierMagnitude.Power`, any scale/interpolation (they only shape the CSR matrix). `sample_rateio != 1`
+(third-party `samplerate` resampler, :158-167) and `FourierMagnitude.Amplitude` raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import functools
+import math
+from collections.abc import Callable, Iterable
+from typing import Union
+
+import numpy as np
+from attrs import Factory, define, field
+
+from shaderflow_amd import _native as N
+from shaderflow_amd.audio.module import BrokenAudio
+from shaderflow_amd.dynamics import DynamicNumber
+from shaderflow_amd.module import ShaderModule
+from shaderflow_amd.piano.notes import PianoNote
+from shaderflow_amd.texture import ShaderTexture
+from shaderflow_amd.variable import ShaderVariable, Uniform
+
+
+class FourierMagnitude:
+    def Amplitude(x: np.ndarray) -> np.ndarray:
+        return np.abs(x)
+
+    def Power(x: np.ndarray) -> np.ndarray:
+        return (x*x.conjugate()).real
+
+
+class FourierVolume:
+    def dBFS(x): return 10*np.log10(x)
+    def Sqrt(x): return np.sqrt(x)
+    def Linear(x): return x
+    def dBFsTremx(x): return 10*(np.log10(x + 0.1) + 1)/1.0414
+
+
+class SpectrogramInterpolation:
+    """Discrete FFT bins → continuous frequency: one kernel per filterbank row (spectrogram.py:44-70)"""
+
+    def make_euler(end: float = 1.54) -> Callable:
+        return (lambda x: np.exp(-(2*x/end)**2)/(end*(math.pi**0.5)))
+
+    def Dirac(x):
+        dirac = np.zeros(x.shape)
+        dirac[np.round(x) == 0] = 1
+        return dirac
+
+    Euler = make_euler(end=1.2)
+
+    def Sinc(x: np.ndarray) -> np.ndarray:
+        return np.abs(np.sinc(x))
+
+
+class SpectrogramScale:
+    """(forward, inverse) of the vertical axis"""
+    Octave = ((lambda x: (np.log(x)/np.log(2))), (lambda x: (2**x)))
+    MEL = ((lambda x: 2595*np.log10(1 + x/700)), (lambda x: 700*(10**(x/2595) - 1)))
+
+
+class SpectrogramWindow:
+
+    @functools.lru_cache
+    def hann_poisson_window(N: int, alpha: float = 2.0) -> np.ndarray:
+        n = np.arange(N)
+        return (0.5*(1 - np.cos(2*np.pi*n/N)))*np.exp(-alpha*np.abs(N - 2*n)/N)
+
+    @functools.lru_cache
+    def hanning(size: int) -> np.ndarray:
+        return np.hanning(size)
+
+    @functools.lru_cache
+    def none(size: int) -> np.ndarray:
+        return np.ones(size)
+
+
+_WINDOW_CODES = {SpectrogramWindow.hanning: 0, SpectrogramWindow.hann_poisson_window: 1, SpectrogramWindow.none: 2}
+
+
+@define(eq=False, slots=False)
+class BrokenSpectrogram:
+    audio: BrokenAudio = Factory(BrokenAudio)
+    fft_n: int = field(default=12, converter=int)
+    sample_rateio: int = field(default=1, converter=int)
+    scale: tuple = SpectrogramScale.Octave
+    interpolation: Callable = SpectrogramInterpolation.Euler
+    magnitude: Callable = FourierMagnitude.Power
+    window: Callable = SpectrogramWindow.hanning
+    volume: Callable = FourierVolume.Sqrt
+
+    minimum_frequency: float = 20.0
+    maximum_frequency: float = 20000.0
+    spectrogram_bins: int = 1000
+
+    def __hash__(self) -> int:
+        return hash((self.fft_n, self.minimum_frequency, self.maximum_frequency, self.spectrogram_bins,
+                     self.sample_rateio, self.magnitude, self.interpolation, self.scale, self.volume))
+
+    @property
+    def fft_size(self) -> int:
+        return int(2**(self.fft_n)*self.sample_rateio)
+
+    @property
+    def fft_bins(self) -> int:
+        return int(self.fft_size/2 + 1)
+
+    @property
+    def fft_frequencies(self) -> np.ndarray:
+        return np.fft.rfftfreq(self.fft_size, 1/(self.audio.samplerate*self.sample_rateio))
+
+    @property
+    def spectrogram_frequencies(self) -> np.ndarray:
+        return self.scale[1](np.linspace(self.scale[0](self.minimum_frequency), self.scale[0](self.maximum_frequency), self.spectrogram_bins))
+
+    @functools.lru_cache
+    def spectrogram_matrix(self):
+        """(bins, fft_bins) float32 filterbank as scipy CSR: row r is the interpolation kernel centred on
+        frequency r measured in FFT bins, entries below 1e-5 dropped (spectrogram.py:194-224)"""
+        import scipy.sparse
+        centres = self.spectrogram_frequencies/self.fft_frequencies[1]
+        matrix = np.array([self.interpolation(index - np.arange(self.fft_bins)) for index in centres], dtype=self.audio.dtype)
+        matrix[np.abs(matrix) < 1e-5] = 0
+        return scipy.sparse.csr_matrix(matrix)
+
+    def from_notes(self, start, end, bins: int = 1000, piano: bool = False, tuning: float = 440):
+        start = PianoNote.get(start, tuning=tuning)
+        end = PianoNote.get(end, tuning=tuning)
+        self.minimum_frequency = start.frequency
+        self.maximum_frequency = end.frequency
+        if not piano:
+            self.spectrogram_bins = bins
+        else:
+            half_semitone = 2**(0.5/12)                       # one bin per key, edges half a semitone out
+            self.spectrogram_bins = ((end.note - start.note) + 1)
+            self.minimum_frequency /= half_semitone
+            self.maximum_frequency *= half_semitone
+
+    # device plan ----------------------------------------------------------------------------------------------
+
+    _plan: N.Handle = None
+    _plan_key: tuple = None
+
+    def _context(self) -> N.Context:
+        scene = getattr(self, "scene", None)
+        return scene.context if scene is not None else N.default_context()
+
+    def plan(self) -> N.Handle:
+        """The sfx_stft_plan of the current configuration (rebuilt when it changes)"""
+        if self.sample_rateio != 1:
+            raise NotImplementedError("sample_rateio != 1 needs the third-party 'samplerate' resampler, which has no device path")
+        if self.magnitude is not FourierMagnitude.Power:
+            raise NotImplementedError("only FourierMagnitude.Power has a device kernel")
+        if self.window not in _WINDOW_CODES:
+            raise NotImplementedError("custom windows have no device kernel (hanning, hann_poisson_window, none)")
+        key = (hash(self), self.audio.channels, self.audio.samplerate, _WINDOW_CODES[self.window])
+        if self._plan is None or self._plan_key != key:
+            self.release_plan()
+            matrix = self.spectrogram_matrix()
+            indptr = np.ascontiguousarray(matrix.indptr, np.int32)
+            indices = np.ascontiguousarray(matrix.indices, np.int32)
+            data = np.ascontiguousarray(matrix.data, np.float32)
+            handle = N.Handle()
+            N.check(N.lib().sfx_stft_plan(self._context().handle, self.fft_n, _WINDOW_CODES[self.window], self.spectrogram_bins,
+                                          self.audio.channels, N.as_ptr(indptr, C.c_int32), N.as_ptr(indices, C.c_int32),
+                                          N.as_ptr(data, C.c_float), C.byref(handle)))
+            self._plan, self._plan_key = handle, key
+        return self._plan
+
+    def release_plan(self) -> None:
+        if self._plan is not None and self._plan.value:
+            N.lib().sfx_stft_plan_destroy(self._plan)
+        self._plan, self._plan_key = None, None
+
+    def _native_audio(self) -> N.Handle:
+        native = getattr(self.audio, "native", None)
+        if native is None:
+            raise RuntimeError("The spectrogram's audio has no device-resident PCM: load a file into ShaderAudio first")
+        return native
+
+    def fft(self) -> np.ndarray:
+        """(channels, fft_bins) float32 power of the last 2**fft_n samples (spectrogram.py:155-171)"""
+        tell = np.array([self.audio.tell], np.int64)
+        out = np.zeros((self.audio.channels, self.fft_bins), np.float32)
+        N.check(N.lib().sfx_stft_power(self.plan(), self._native_audio(), N.as_ptr(tell, C.c_int64), 1, N.as_ptr(out, C.c_float)))
+        return out
+
+    def next(self) -> np.ndarray:
+        """spectrogram_matrix().dot(fft().T).T: a (channels, bins) VIEW of a (bins, channels) buffer (:175-176)"""
+        tell = np.array([self.audio.tell], np.int64)
+        out = np.zeros((self.spectrogram_bins, self.audio.channels), np.float32)
+        N.check(N.lib().sfx_spectrogram_targets(self.plan(), self._native_audio(), N.as_ptr(tell, C.c_int64), 1, 0, N.as_ptr(out, C.c_float)))
+        return out.T
+
+
+@define(eq=False, slots=False)
+class ShaderSpectrogram(BrokenSpectrogram, ShaderModule):
+    name: str = "iSpectrogram"
+    length: float = 5
+    offset: int = 0
+    smooth: bool = False
+    scrolling: bool = False
+    dynamics: DynamicNumber = None
+    texture: ShaderTexture = None
+
+    @property
+    def length_samples(self) -> int:
+        return int(max(1, self.length*self.scene.fps))
+
+    @property
+    def _row_shape(self) -> tuple[int, int]:
+        return (self.audio.channels, self.spectrogram_bins)
+
+    def __attrs_post_init__(self):
+        ShaderModule.__attrs_post_init__(self)
+        self.dynamics = DynamicNumber(frequency=4, zeta=1, response=0, dtype=np.float32)
+        self.texture = ShaderTexture(scene=self.scene, name=self.name, dtype=np.float32, repeat_y=False)
+
+    def update(self):
+        self.texture.components = self.audio.channels
+        self.texture.filter = ("linear" if self.smooth else "nearest")
+        self.texture.height = self.spectrogram_bins
+        self.texture.width = self.length_samples
+        self.offset = (self.offset + 1) % self.length_samples
+        if (self.dynamics.value.shape != (self._row_shape)):
+            self.dynamics.set(np.zeros(self._row_shape, dtype=np.float32))
+        # The (bins, 2) buffer re-viewed as (2, bins): bytes stay [bin0_L, bin0_R, bin1_L, …] = RG texels (:306)
+        self.dynamics.target = self.next().T.reshape(2, -1)
+        self.dynamics.next(dt=abs(self.scene.dt))
+        self.texture.write(viewport=(self.offset, 0, 1, self.spectrogram_bins), data=self.dynamics.value.astype(np.float32))
+
+    def pipeline(self) -> Iterable[ShaderVariable]:
+        yield Uniform("int", f"{self.name}Length", self.length_samples)
+        yield Uniform("int", f"{self.name}Bins", self.spectrogram_bins)
+        yield Uniform("float", f"{self.name}Offset", self.offset/self.length_samples)
+        yield Uniform("int", f"{self.name}Smooth", self.smooth)
+        yield Uniform("float", f"{self.name}Min", self.spectrogram_frequencies[0])
+        yield Uniform("float", f"{self.name}Max", self.spectrogram_frequencies[-1])
+        yield Uniform("bool", f"{self.name}Scroll", self.scrolling)
+
+    def destroy(self) -> None:
+        self.release_plan()

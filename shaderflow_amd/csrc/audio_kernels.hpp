@@ -1,0 +1,310 @@
+// audio_kernels.hpp — gfx950 kernels for the audio half of the path:
+//   K1 k_stft_power        window·frame + radix-2 real FFT in float64 + |X|² → float32   (spectrogram.py:155-171)
+//   K2 k_filterbank_csr    CSR rows in scipy's summation order, float32                   (spectrogram.py:175-176)
+//      k_filterbank_mfma   dense banded GEMM on v_mfma_f32_32x32x2_f32 (batch of frames)
+//   K3 k_dynamics_scan     DynamicNumber recurrence over the frames of a batch            (dynamics.py:197-250)
+//   K4 k_waveform_rows     sqrt(mean|x|) chunks                                           (waveform.py:80-87)
+//   K5 k_volume_std        RMS and standard deviation of the last 0.1 s                  (audio/module.py:457-458)
+//
+// Data layout in HBM: PCM planar float32 [channels][samples] for the whole file (the reference's 30 s ring,
+// audio/module.py:103-111, is a window onto it: after `tell` samples the ring's last n+1 samples are
+// stream[tell-n-1 .. tell-1]); power [frame][channel][fft_bins]; spectrogram columns [frame][bin][channel]
+// (RG texel order, spectrogram.py:306); waveform rows [frame][point][channel] (waveform.py:86).
+#pragma once
+
+#include "glsl.hpp"
+
+namespace sf {
+
+__device__ __forceinline__ float stream_at(const float* pcm, long total, int c, long idx) {
+    return (idx < 0 || idx >= total) ? 0.0f : pcm[(long)c*total + idx];       // zeros before the file starts
+}
+
+// ---- K1 ---------------------------------------------------------------------------------------------------
+// One block per (frame, channel). The N real samples are packed as N/2 complex numbers, transformed with an
+// in-LDS radix-2 decimation-in-time FFT in float64 (numpy computes window*data and the rfft in float64 and only
+// then casts, spectrogram.py:169-171), and split into the N/2+1 real-input bins.
+// twiddle[k] = exp(-2*pi*i*k/N), k < N/2, and window[n] are float64 tables built by the host.
+__global__ __launch_bounds__(256) void k_stft_power(const float* __restrict__ pcm, long total, const long* __restrict__ tell,
+                                                    int fft_n, const double* __restrict__ window,
+                                                    const double2* __restrict__ twiddle, float* __restrict__ power) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2* z = (double2*)smem;
+    const int N = 1 << fft_n, M = N >> 1, logM = fft_n - 1;
+    const int frame = blockIdx.x, c = blockIdx.y, channels = gridDim.y;
+    const long first = tell[frame] - N - 1;                         // audio/module.py:137-138
+    for (int n = threadIdx.x; n < M; n += blockDim.x) {
+        const double re = window[2*n]*(double)stream_at(pcm, total, c, first + 2*n);
+        const double im = window[2*n + 1]*(double)stream_at(pcm, total, c, first + 2*n + 1);
+        z[__brev((unsigned)n) >> (32 - logM)] = make_double2(re, im);
+    }
+    __syncthreads();
+    for (int s = 1; s <= logM; s++) {
+        const int half = 1 << (s - 1);
+        const int tw_stride = N >> s;                               // W_len^k = W_N^(k*N/len), len = 2^s
+        for (int b = threadIdx.x; b < (M >> 1); b += blockDim.x) {
+            const int k = b & (half - 1);
+            const int i0 = ((b >> (s - 1)) << s) + k, i1 = i0 + half;
+            const double2 w = twiddle[k*tw_stride];
+            const double2 a = z[i0], v = z[i1];
+            const double xr = v.x*w.x - v.y*w.y, xi = v.x*w.y + v.y*w.x;
+            z[i0] = make_double2(a.x + xr, a.y + xi);
+            z[i1] = make_double2(a.x - xr, a.y - xi);
+        }
+        __syncthreads();
+    }
+    float* out = power + ((long)frame*channels + c)*(M + 1);
+    for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+        const double2 a = z[k & (M - 1)], b = z[(M - k) & (M - 1)];
+        const double er = 0.5*(a.x + b.x), ei = 0.5*(a.y - b.y);    // E = (Z[k] + conj(Z[M-k]))/2
+        const double orr = 0.5*(a.y + b.y), oi = -0.5*(a.x - b.x);  // O = -i(Z[k] - conj(Z[M-k]))/2
+        double2 w = (k < M) ? twiddle[k] : make_double2(-1.0, 0.0);
+        const double xr = er + (orr*w.x - oi*w.y), xi = ei + (orr*w.y + oi*w.x);
+        out[k] = (float)(xr*xr + xi*xi);                            // FourierMagnitude.Power, spectrogram.py:25-26
+    }
+}
+
+// ---- K2 (CSR) ---------------------------------------------------------------------------------------------
+// y[row,:] += a*x[col,:] entry by entry in index order, separate multiply and add: scipy's csr_matvecs.
+__global__ void k_filterbank_csr(const int* __restrict__ indptr, const int* __restrict__ indices, const float* __restrict__ data,
+                                 int bins, int channels, int fft_bins, int ncols, const float* __restrict__ power,
+                                 float* __restrict__ out) {
+    const long t = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (t >= (long)ncols*bins) return;
+    const int col = (int)(t / bins), r = (int)(t % bins);            // col = frame*channels + channel
+    const float* p = power + (long)col*fft_bins;
+    float acc = 0.0f;
+    for (int j = indptr[r]; j < indptr[r + 1]; j++) {
+        const float prod = data[j]*p[indices[j]];
+        acc = acc + prod;
+    }
+    out[((long)(col / channels)*bins + r)*channels + (col % channels)] = acc;
+}
+
+// ---- K2 (MFMA) --------------------------------------------------------------------------------------------
+// out[bin][col] = sum_k A[bin][k]*P[col][k] with the dense filterbank A (bins_pad x k_pad, zero padded) and
+// only the k range [kbeg, kend) that holds non-zeros for the 32-bin row tile (the matrix is banded: 3-4
+// non-zeros per row, spectrogram.py:194-224). Exact float32 products, fma chain in k order.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_filterbank_mfma(const float* __restrict__ A, int k_pad, const int2* __restrict__ band,
+                                                         int bins, int channels, int fft_bins, int ncols,
+                                                         const float* __restrict__ power, float* __restrict__ out) {
+    __shared__ float As[32][33];
+    __shared__ float Bs[128][33];
+    const int tile_row = blockIdx.y, col0 = blockIdx.x*128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int2 kr = band[tile_row];
+    f32x16 acc = {0};
+    for (int kc = kr.x; kc < kr.y; kc += 32) {
+        for (int e = threadIdx.x; e < 32*32; e += 256) {
+            const int r = e >> 5, k = e & 31;
+            As[r][k] = A[(long)(tile_row*32 + r)*k_pad + kc + k];
+        }
+        for (int e = threadIdx.x; e < 128*32; e += 256) {
+            const int cc = e >> 5, k = e & 31;
+            const int col = col0 + cc;
+            Bs[cc][k] = (col < ncols && kc + k < fft_bins) ? power[(long)col*fft_bins + kc + k] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 2) {
+            const float a = As[lane & 31][kk + (lane >> 5)];
+            const float b = Bs[wave*32 + (lane & 31)][kk + (lane >> 5)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = col0 + wave*32 + (lane & 31);
+    if (col < ncols) {
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int r = tile_row*32 + (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5);
+            if (r < bins) out[((long)(col / channels)*bins + r)*channels + (col % channels)] = acc[reg];
+        }
+    }
+}
+
+// ---- K4 ---------------------------------------------------------------------------------------------------
+// One wave per (frame, point, channel) chunk of `chunk` samples.
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_waveform_rows(const float* __restrict__ pcm, long total, int channels,
+                                                       const long* __restrict__ tell, int chunk, int points, int reducer,
+                                                       float* __restrict__ rows) {
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x*4 + (threadIdx.x >> 6);        // (frame, point, channel)
+    const long nw = (long)gridDim.y*points*channels;
+    (void)nw;
+    const int frame = blockIdx.y;
+    if (wid >= (long)points*channels) return;
+    const int p = (int)(wid / channels), c = (int)(wid % channels);
+    const long t = tell[frame];
+    const long offset = t % chunk;                                   // waveform.py:71-73
+    const long base = t - ((long)chunk*points + offset + 1) + (long)p*chunk;   // waveform.py:81-83
+    float result;
+    if (reducer == 0) {                                              // sqrt(mean(|x|)), waveform.py:15-16
+        float s = 0.0f;
+        for (int i = lane; i < chunk; i += 64) s += fabsf(stream_at(pcm, total, c, base + i));
+        result = sqrtf(wave_sum(s)/(float)chunk);
+    } else if (reducer == 1) {                                       // sqrt(sqrt(mean(x²))*2**0.5), :18-19
+        float s = 0.0f;
+        for (int i = lane; i < chunk; i += 64) { const float x = stream_at(pcm, total, c, base + i); s += x*x; }
+        result = sqrtf(sqrtf(wave_sum(s)/(float)chunk)*(float)1.4142135623730951);
+    } else {                                                         // sqrt(std(x)), :21-22
+        float s = 0.0f;
+        for (int i = lane; i < chunk; i += 64) s += stream_at(pcm, total, c, base + i);
+        const float mean = wave_sum(s)/(float)chunk;
+        float q = 0.0f;
+        for (int i = lane; i < chunk; i += 64) { const float d = stream_at(pcm, total, c, base + i) - mean; q += d*d; }
+        result = sqrtf(sqrtf(wave_sum(q)/(float)chunk));
+    }
+    if (lane == 0) rows[((long)frame*points + p)*channels + c] = result;
+}
+
+// ---- K5 ---------------------------------------------------------------------------------------------------
+// One block per frame over channels*n samples: volume target = 2*sqrt(mean(x²))*sqrt(2) and std target
+// = sqrt(mean((x-mean)²)), rounded to float32 at the points numpy rounds (audio/module.py:74-75,457-458).
+__global__ __launch_bounds__(256) void k_volume_std(const float* __restrict__ pcm, long total, int channels,
+                                                    const long* __restrict__ tell, int n, float* __restrict__ out) {
+    __shared__ double red[2][4];
+    __shared__ double mean_sh;
+    const int frame = blockIdx.x;
+    const long first = tell[frame] - n - 1;
+    const int count = n*channels;
+    double s1 = 0.0, s2 = 0.0;
+    for (int e = threadIdx.x; e < count; e += 256) {
+        const double x = (double)stream_at(pcm, total, e / n, first + (e % n));
+        s1 += x; s2 += x*x;
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double sum = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const double sq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const float rms = sqrtf((float)(sq/(double)count));
+        out[2*frame] = (2.0f*rms)*(float)1.4142135623730951;
+        mean_sh = (double)(float)(sum/(double)count);               // numpy's arrmean is float32
+    }
+    __syncthreads();
+    const double mean = mean_sh;
+    double q = 0.0;
+    for (int e = threadIdx.x; e < count; e += 256) {
+        const float d = stream_at(pcm, total, e / n, first + (e % n)) - (float)mean;   // x - arrmean in float32
+        q += (double)(d*d);
+    }
+    q = wave_sum(q);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) out[2*frame + 1] = sqrtf((float)((red[0][0] + red[0][1] + red[0][2] + red[0][3])/(double)count));
+}
+
+// ---- K3 ---------------------------------------------------------------------------------------------------
+// The recurrence is sequential in time (an IIR with a data-dependent early-out, dynamics.py:222-225), so one
+// block walks the frames of the batch; the per-frame python scalars (dt, k1, k2, k3) come from the host,
+// already rounded to float32 the way numpy does for a float32 array (NEP 50).
+struct DynCoeffF32 { float dt, k1, k2, k3; };
+struct DynCoeffF64 { double dt, k1, k2, k3; };
+struct FrameClock { float iTime, iTau, iSpectrogramOffset; int iFrame; };
+struct ScalarState { double value, derivative, previous, integral; };
+
+__device__ __forceinline__ void scalar_step(ScalarState& s, double target, const DynCoeffF64& c, double precision, int integrate) {
+    if (c.dt == 0.0) return;                                          // dynamics.py:210-211
+    if (fabs(target - s.value) < precision) {                         // :222-225
+        if (integrate) s.integral += (s.value*c.dt);
+        return;
+    }
+    const double velocity = (target - s.previous)/c.dt;               // :228-229
+    s.previous = target;
+    s.value += (s.derivative*c.dt);                                   // :245
+    const double acceleration = (target + c.k3*velocity - s.value - c.k1*s.derivative)/c.k2;   // :246
+    s.derivative += (acceleration*c.dt);                              // :247
+    if (integrate) s.integral += (s.value*c.dt);                      // :248-249
+}
+
+__global__ __launch_bounds__(1024) void k_dynamics_scan(int nframes, int n /* bins*channels */,
+                                                        const float* __restrict__ targets,     // [frame][n]
+                                                        const DynCoeffF32* __restrict__ coeff,
+                                                        float precision,
+                                                        float* __restrict__ state,             // value | derivative | previous, n each
+                                                        float* __restrict__ columns,           // [frame][n]
+                                                        const float* __restrict__ loudness,    // [frame][2] volume/std targets
+                                                        const DynCoeffF64* __restrict__ vol_coeff, const DynCoeffF64* __restrict__ std_coeff,
+                                                        double scalar_precision, int vol_integrate, int std_integrate,
+                                                        ScalarState* __restrict__ scalars,     // [2]
+                                                        const FrameClock* __restrict__ clock, FrameDyn* __restrict__ dyn) {
+    __shared__ float red[16];
+    __shared__ int skip;
+    constexpr int PER = 2;                                            // up to 2048 elements
+    float value[PER], deriv[PER], prev[PER];
+    for (int e = 0; e < PER; e++) {
+        const int i = threadIdx.x + e*1024;
+        value[e] = (i < n) ? state[i] : 0.0f;
+        deriv[e] = (i < n) ? state[n + i] : 0.0f;
+        prev[e] = (i < n) ? state[2*n + i] : 0.0f;
+    }
+    for (int f = 0; f < nframes; f++) {
+        const DynCoeffF32 c = coeff[f];
+        float target[PER];
+        float worst = 0.0f;
+        for (int e = 0; e < PER; e++) {
+            const int i = threadIdx.x + e*1024;
+            target[e] = (i < n) ? targets[(long)f*n + i] : 0.0f;
+            if (i < n) worst = fmaxf(worst, fabsf(target[e] - value[e]));
+        }
+        if (c.dt != 0.0f) {
+            for (int m = 32; m >= 1; m >>= 1) worst = fmaxf(worst, __shfl_xor(worst, m));
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = worst;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float w = red[0];
+                for (int k = 1; k < 16; k++) w = fmaxf(w, red[k]);
+                skip = (w < precision) ? 1 : 0;                       // np.abs(target - value).max() < precision
+            }
+            __syncthreads();
+            if (!skip) {
+                for (int e = 0; e < PER; e++) {
+                    const float velocity = (target[e] - prev[e])/c.dt;
+                    prev[e] = target[e];
+                    value[e] = value[e] + (deriv[e]*c.dt);
+                    const float accel = (((target[e] + (c.k3*velocity)) - value[e]) - (c.k1*deriv[e]))/c.k2;
+                    deriv[e] = deriv[e] + (accel*c.dt);
+                }
+            }
+            __syncthreads();
+        }
+        for (int e = 0; e < PER; e++) {
+            const int i = threadIdx.x + e*1024;
+            if (i < n) columns[(long)f*n + i] = value[e];
+        }
+        if (threadIdx.x == 0 && dyn) {
+            ScalarState v = scalars[0], s = scalars[1];
+            if (loudness) {
+                scalar_step(v, (double)loudness[2*f], vol_coeff[f], scalar_precision, vol_integrate);
+                scalar_step(s, (double)loudness[2*f + 1], std_coeff[f], scalar_precision, std_integrate);
+            }
+            scalars[0] = v; scalars[1] = s;
+            FrameDyn d;
+            d.iTime = clock[f].iTime; d.iTau = clock[f].iTau; d.iFrame = clock[f].iFrame;
+            d.iSpectrogramOffset = clock[f].iSpectrogramOffset;
+            d.iAudioVolume = (float)v.value; d.iAudioVolumeIntegral = (float)v.integral; d.iAudioSTD = (float)s.value;
+            d.pad = 0;
+            dyn[f] = d;
+        }
+    }
+    for (int e = 0; e < PER; e++) {
+        const int i = threadIdx.x + e*1024;
+        if (i < n) { state[i] = value[e]; state[n + i] = deriv[e]; state[2*n + i] = prev[e]; }
+    }
+}
+
+}  // namespace sf

@@ -1,0 +1,1067 @@
+// capi.hip — implementation of include/shaderflow_hip.h (the C-ABI over the gfx950 kernels).
+// Host-side state only: handles, the fragment registry, uniform/sampler tables, launch geometry, the
+// pinned read-out ring with its pipe writer thread, and the audio plan/tape objects.
+
+#include "../../include/shaderflow_hip.h"
+
+#include "audio_kernels.hpp"
+#include "visualizer_kernels.hpp"
+
+#include <atomic>
+#include <cerrno>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unistd.h>
+#include <vector>
+
+using namespace sf;
+
+// ---------------------------------------------------------------------------------------------------------
+// Errors and handles
+
+static thread_local std::string g_error;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_error = buf;
+    return code;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(SFX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+extern "C" const char* sfx_last_error(void) { return g_error.c_str(); }
+extern "C" const char* sfx_version(void) { return "shaderflow_hip 0.1 (gfx950)"; }
+
+enum : uint32_t { MAGIC_CTX = 0x53465843, MAGIC_TEX = 0x53465854, MAGIC_PROG = 0x53465850, MAGIC_RING = 0x53465852,
+                  MAGIC_AUDIO = 0x53465841, MAGIC_PLAN = 0x5346584c, MAGIC_TAPE = 0x53465854 + 0x100 };
+
+struct Object { uint32_t magic; };
+
+template <class T> static T* get(sfx_handle h, uint32_t magic) {
+    Object* o = reinterpret_cast<Object*>(static_cast<uintptr_t>(h));
+    return (o && o->magic == magic) ? static_cast<T*>(o) : nullptr;
+}
+template <class T> static sfx_handle handle_of(T* p) { return static_cast<sfx_handle>(reinterpret_cast<uintptr_t>(p)); }
+
+struct Context : Object {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t events[64] = {};
+    hipDeviceProp_t prop;
+    float tap_x[81], tap_y[81];
+};
+
+struct Texture : Object {
+    Context* ctx;
+    int width, height, components, dtype, filter = SFX_LINEAR, repeat_x = 1, repeat_y = 1;
+    void* data = nullptr;
+    size_t nbytes = 0;
+};
+
+static size_t dtype_size(int dtype) { return dtype == SFX_U8 ? 1 : (dtype == SFX_F32 ? 4 : 2); }
+
+static Tex tex_view(const Texture* t) {
+    Tex v{};
+    if (t) { v.data = t->data; v.width = t->width; v.height = t->height; v.components = t->components;
+             v.dtype = t->dtype; v.filter = t->filter; v.repeat_x = t->repeat_x; v.repeat_y = t->repeat_y; }
+    return v;
+}
+
+#define CTX_OR_FAIL(var, h) Context* var = get<Context>(h, MAGIC_CTX); if (!var) return fail(SFX_E_INVALID, "invalid context handle")
+#define USE_DEVICE(ctx) HIP_TRY(hipSetDevice((ctx)->device))
+
+// ---------------------------------------------------------------------------------------------------------
+// Context
+
+// visualizer.frag:23-31 evaluated once in binary32: angles 0, τ/8, … (9 of them, the last one coincides with
+// the first), walks 0.1 … 1.0000001. Table order: direction 0 (10 taps), centre tap, directions 1..7.
+static void build_tap_table(float* tx, float* ty) {
+    const float quality = 10.0f, directions = 8.0f;
+    int dir = 0, n = 0;
+    float cx[16][10], cy[16][10];
+    int ndir = 0;
+    for (float angle = 0.0f; angle < sf::TAU; angle += sf::TAU/directions) {
+        int w = 0;
+        for (float walk = 1.0f/quality; walk <= 1.001f; walk += 1.0f/quality) {
+            if (ndir < 16 && w < 10) { cx[ndir][w] = sf::cos(angle)*walk; cy[ndir][w] = sf::sin(angle)*walk; }
+            w++;
+        }
+        ndir++;
+    }
+    (void)dir;
+    for (int w = 0; w < 10; w++) { tx[n] = cx[0][w]; ty[n] = cy[0][w]; n++; }
+    tx[n] = 0.0f; ty[n] = 0.0f; n++;
+    for (int d = 1; d < 8; d++) for (int w = 0; w < 10; w++) { tx[n] = cx[d][w]; ty[n] = cy[d][w]; n++; }
+}
+
+extern "C" int sfx_ctx_create(int device_id, void* stream, sfx_handle* out) {
+    if (!out) return fail(SFX_E_INVALID, "null output");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail(SFX_E_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
+    if (device_id < 0 || device_id >= count) return fail(SFX_E_INVALID, "device %d out of range (%d devices)", device_id, count);
+    Context* c = new Context();
+    c->magic = MAGIC_CTX;
+    c->device = device_id;
+    HIP_TRY(hipSetDevice(device_id));
+    HIP_TRY(hipGetDeviceProperties(&c->prop, device_id));
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    for (auto& e : c->events) HIP_TRY(hipEventCreate(&e));
+    build_tap_table(c->tap_x, c->tap_y);
+    *out = handle_of(c);
+    return SFX_OK;
+}
+
+extern "C" int sfx_ctx_info(sfx_handle h, sfx_ctx_info_t* info) {
+    CTX_OR_FAIL(c, h);
+    if (!info) return fail(SFX_E_INVALID, "null info");
+    memset(info, 0, sizeof *info);
+    snprintf(info->device_name, sizeof info->device_name, "%s", c->prop.name);
+    snprintf(info->gcn_arch, sizeof info->gcn_arch, "%s", c->prop.gcnArchName);
+    info->device_id = c->device;
+    info->compute_units = c->prop.multiProcessorCount;
+    info->max_texture_dim = 65536;
+    info->wavefront_size = c->prop.warpSize;
+    info->total_memory = (int64_t)c->prop.totalGlobalMem;
+    info->lds_per_cu = (int64_t)c->prop.maxSharedMemoryPerMultiProcessor;
+    return SFX_OK;
+}
+
+extern "C" int sfx_ctx_synchronize(sfx_handle h) {
+    CTX_OR_FAIL(c, h);
+    USE_DEVICE(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SFX_OK;
+}
+
+extern "C" int sfx_ctx_destroy(sfx_handle h) {
+    CTX_OR_FAIL(c, h);
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto& e : c->events) hipEventDestroy(e);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    c->magic = 0;
+    delete c;
+    return SFX_OK;
+}
+
+extern "C" int sfx_event_record(sfx_handle h, int slot) {
+    CTX_OR_FAIL(c, h);
+    if (slot < 0 || slot >= 64) return fail(SFX_E_INVALID, "event slot %d", slot);
+    USE_DEVICE(c);
+    HIP_TRY(hipEventRecord(c->events[slot], c->stream));
+    return SFX_OK;
+}
+
+extern "C" int sfx_event_elapsed_ms(sfx_handle h, int a, int b, float* ms) {
+    CTX_OR_FAIL(c, h);
+    if (a < 0 || a >= 64 || b < 0 || b >= 64 || !ms) return fail(SFX_E_INVALID, "event slots");
+    USE_DEVICE(c);
+    HIP_TRY(hipEventSynchronize(c->events[b]));
+    HIP_TRY(hipEventElapsedTime(ms, c->events[a], c->events[b]));
+    return SFX_OK;
+}
+
+extern "C" int sfx_device_alloc(sfx_handle h, size_t nbytes, void** ptr) {
+    CTX_OR_FAIL(c, h);
+    USE_DEVICE(c);
+    HIP_TRY(hipMalloc(ptr, nbytes ? nbytes : 16));
+    return SFX_OK;
+}
+extern "C" int sfx_device_free(sfx_handle h, void* ptr) {
+    CTX_OR_FAIL(c, h);
+    USE_DEVICE(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(ptr));
+    return SFX_OK;
+}
+extern "C" int sfx_device_read(sfx_handle h, const void* dptr, void* host, size_t nbytes) {
+    CTX_OR_FAIL(c, h);
+    USE_DEVICE(c);
+    HIP_TRY(hipMemcpyAsync(host, dptr, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SFX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Textures
+
+extern "C" int sfx_texture_create(sfx_handle h, int width, int height, int components, int dtype, sfx_handle* out) {
+    CTX_OR_FAIL(c, h);
+    if (!out || width < 1 || height < 1 || components < 1 || components > 4) return fail(SFX_E_INVALID, "texture %dx%dx%d", width, height, components);
+    if (dtype != SFX_U8 && dtype != SFX_F32 && dtype != SFX_U16) return fail(SFX_E_UNSUPPORTED, "texture dtype %d", dtype);
+    if (width > 65536 || height > 65536) return fail(SFX_E_TOO_LARGE, "texture size too large for this context: (%d, %d) > 65536", width, height);
+    USE_DEVICE(c);
+    Texture* t = new Texture();
+    t->magic = MAGIC_TEX; t->ctx = c;
+    t->width = width; t->height = height; t->components = components; t->dtype = dtype;
+    t->nbytes = (size_t)width*height*components*dtype_size(dtype);
+    hipError_t e = hipMalloc(&t->data, t->nbytes + 16);
+    if (e != hipSuccess) { delete t; return fail(SFX_E_HIP, "hipMalloc(%zu): %s", t->nbytes, hipGetErrorString(e)); }
+    HIP_TRY(hipMemsetAsync(t->data, 0, t->nbytes + 16, c->stream));
+    *out = handle_of(t);
+    return SFX_OK;
+}
+
+extern "C" int sfx_texture_params(sfx_handle h, int filter, int repeat_x, int repeat_y) {
+    Texture* t = get<Texture>(h, MAGIC_TEX);
+    if (!t) return fail(SFX_E_INVALID, "invalid texture handle");
+    t->filter = filter ? SFX_LINEAR : SFX_NEAREST; t->repeat_x = !!repeat_x; t->repeat_y = !!repeat_y;
+    return SFX_OK;
+}
+
+extern "C" int sfx_texture_write(sfx_handle h, const void* data, size_t nbytes, int x, int y, int w, int hh) {
+    Texture* t = get<Texture>(h, MAGIC_TEX);
+    if (!t || !data) return fail(SFX_E_INVALID, "invalid texture handle or data");
+    USE_DEVICE(t->ctx);
+    const size_t texel = (size_t)t->components*dtype_size(t->dtype);
+    if (w == 0 && hh == 0) { x = 0; y = 0; w = t->width; hh = t->height; }
+    if (x < 0 || y < 0 || w < 1 || hh < 1 || x + w > t->width || y + hh > t->height) return fail(SFX_E_INVALID, "viewport (%d,%d,%d,%d) outside %dx%d", x, y, w, hh, t->width, t->height);
+    if (nbytes != (size_t)w*hh*texel) return fail(SFX_E_INVALID, "texture write of %zu bytes, viewport needs %zu", nbytes, (size_t)w*hh*texel);
+    char* dst = (char*)t->data + ((size_t)y*t->width + x)*texel;
+    HIP_TRY(hipMemcpy2DAsync(dst, (size_t)t->width*texel, data, (size_t)w*texel, (size_t)w*texel, hh, hipMemcpyHostToDevice, t->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(t->ctx->stream));       // the host pointer is only borrowed for the call
+    return SFX_OK;
+}
+
+extern "C" int sfx_texture_read(sfx_handle h, void* data, size_t nbytes) {
+    Texture* t = get<Texture>(h, MAGIC_TEX);
+    if (!t || !data) return fail(SFX_E_INVALID, "invalid texture handle or data");
+    if (nbytes != t->nbytes) return fail(SFX_E_INVALID, "texture read of %zu bytes, texture holds %zu", nbytes, t->nbytes);
+    USE_DEVICE(t->ctx);
+    HIP_TRY(hipMemcpyAsync(data, t->data, nbytes, hipMemcpyDeviceToHost, t->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    return SFX_OK;
+}
+
+extern "C" int sfx_texture_device_ptr(sfx_handle h, void** ptr, size_t* nbytes) {
+    Texture* t = get<Texture>(h, MAGIC_TEX);
+    if (!t) return fail(SFX_E_INVALID, "invalid texture handle");
+    if (ptr) *ptr = t->data;
+    if (nbytes) *nbytes = t->nbytes;
+    return SFX_OK;
+}
+
+extern "C" int sfx_texture_destroy(sfx_handle h) {
+    Texture* t = get<Texture>(h, MAGIC_TEX);
+    if (!t) return fail(SFX_E_INVALID, "invalid texture handle");
+    hipSetDevice(t->ctx->device);
+    hipStreamSynchronize(t->ctx->stream);
+    hipFree(t->data);
+    t->magic = 0;
+    delete t;
+    return SFX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Programs
+
+struct RegistryEntry { uint64_t hash; const char* name; };
+static const RegistryEntry g_registry[] = {
+#include "registry_hashes.inc"
+};
+static const char* const g_fragment_names[] = {"default", "missing", "visualizer", "bars", "waveform", "multi_child",
+                                               "multi_main", "shadertoy", "dynamics", "audio"};
+enum { FRAG_FINAL = 100 };
+
+static int fragment_by_name(const char* name) {
+    for (int k = 0; k < FRAG_COUNT; k++) if (!strcmp(name, g_fragment_names[k])) return k;
+    if (!strcmp(name, "final")) return FRAG_FINAL;
+    return -1;
+}
+
+static uint64_t normalised_hash(const char* src) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (const char* p = src; *p;) {
+        if (p[0] == '/' && p[1] == '*') { p += 2; while (*p && !(p[0] == '*' && p[1] == '/')) p++; if (*p) p += 2; continue; }
+        if (p[0] == '/' && p[1] == '/') { while (*p && *p != '\n') p++; continue; }
+        if (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == '\f' || *p == '\v') { p++; continue; }
+        h ^= (uint8_t)*p; h *= 0x100000001b3ull; p++;
+    }
+    return h;
+}
+
+struct Program : Object {
+    Context* ctx;
+    int fragment;
+    Uniforms u;
+    Texture* samplers[TEX_SLOTS];
+};
+
+struct UniformField { const char* name; size_t offset; int count; bool integer; };
+#define UF(n, c, i) {#n, offsetof(Uniforms, n), c, i}
+static const UniformField g_uniform_fields[] = {
+    UF(iTime, 1, false), UF(iTau, 1, false), UF(iDuration, 1, false), UF(iDeltatime, 1, false), UF(iResolution, 2, false),
+    UF(iWantAspect, 1, false), UF(iQuality, 1, false), UF(iSSAA, 1, false), UF(iFramerate, 1, false),
+    UF(iFrame, 1, true), UF(iRealtime, 1, true), UF(iLayer, 1, true), UF(iSubsample, 1, true),
+    UF(iMouse, 2, false), UF(iMouseInside, 1, true), UF(iMouse1, 1, true), UF(iMouse2, 1, true),
+    UF(iCameraMode, 1, true), UF(iCameraProjection, 1, true),
+    UF(iCameraRight, 3, false), UF(iCameraUpward, 3, false), UF(iCameraForward, 3, false),
+    UF(iCameraPosition, 3, false), UF(iCameraZenith, 3, false),
+    UF(iCameraSeparation, 1, false), UF(iCameraZoom, 1, false), UF(iCameraIsometric, 1, false),
+    UF(iCameraFocalLength, 1, false), UF(iCameraOrbital, 1, false), UF(iCameraDolly, 1, false),
+    UF(iAudioVolume, 1, false), UF(iAudioVolumeIntegral, 1, false), UF(iAudioSTD, 1, false),
+    UF(iSpectrogramLength, 1, true), UF(iSpectrogramBins, 1, true), UF(iSpectrogramSmooth, 1, true), UF(iSpectrogramScroll, 1, true),
+    UF(iSpectrogramOffset, 1, false), UF(iSpectrogramMin, 1, false), UF(iSpectrogramMax, 1, false),
+    UF(iWaveformLength, 1, true),
+};
+// scene-defined float uniforms read by a restated fragment: (fragment, name) → user[] slot
+struct UserUniform { int fragment; const char* name; int slot; };
+static const UserUniform g_user_uniforms[] = { {FRAG_DYNAMICS, "iShaderDynamics", 0} };
+
+struct SamplerName { const char* name; int slot; };
+static const SamplerName g_sampler_names[] = { {"background", TEX_BACKGROUND}, {"iSpectrogram", TEX_SPECTROGRAM},
+                                               {"iWaveform", TEX_WAVEFORM}, {"child", TEX_CHILD} };
+
+static void default_uniforms(Uniforms& u) {
+    memset(&u, 0, sizeof u);
+    u.iResolution[0] = 1920; u.iResolution[1] = 1080; u.iWantAspect = 1920.0f/1080.0f;
+    u.iQuality = 0.5f; u.iSSAA = 1.0f; u.iFramerate = 60.0f; u.iDuration = 10.0f; u.iSubsample = 2;
+    u.iCameraMode = 1;                                              // Camera2D, camera.py:134
+    u.iCameraRight[0] = 1.0f; u.iCameraUpward[1] = 1.0f; u.iCameraForward[2] = 1.0f; u.iCameraZenith[1] = 1.0f;
+    u.iCameraSeparation = 0.05f; u.iCameraZoom = 1.0f; u.iCameraFocalLength = 1.0f;   // camera.py:147-185
+}
+
+extern "C" int sfx_program_lookup(sfx_handle h, const char* source, sfx_handle* out, int* fallback) {
+    CTX_OR_FAIL(c, h);
+    if (!source || !out) return fail(SFX_E_INVALID, "null source or output");
+    int fragment = fragment_by_name(source);
+    if (fragment < 0) {
+        // registry stub files shipped with the host package: `#pragma shaderflow_amd kernel(<name>)`
+        static const char tag[] = "#pragma shaderflow_amd kernel(";
+        if (const char* at = strstr(source, tag)) {
+            at += sizeof(tag) - 1;
+            const char* end = strchr(at, ')');
+            if (end && end - at < 64) fragment = fragment_by_name(std::string(at, end).c_str());
+        }
+    }
+    if (fragment < 0) {
+        const uint64_t hash = normalised_hash(source);
+        for (const auto& e : g_registry) if (e.hash == hash) { fragment = fragment_by_name(e.name); break; }
+    }
+    if (fallback) *fallback = (fragment < 0);
+    if (fragment < 0) fragment = FRAG_MISSING;                      // shader.py:336-340
+    Program* p = new Program();
+    p->magic = MAGIC_PROG; p->ctx = c; p->fragment = fragment;
+    default_uniforms(p->u);
+    for (auto& s : p->samplers) s = nullptr;
+    *out = handle_of(p);
+    return SFX_OK;
+}
+
+extern "C" const char* sfx_program_name(sfx_handle h) {
+    Program* p = get<Program>(h, MAGIC_PROG);
+    if (!p) return "";
+    return p->fragment == FRAG_FINAL ? "final" : g_fragment_names[p->fragment];
+}
+
+extern "C" int sfx_uniform_set(sfx_handle h, const char* name, int type, const void* value, int* known) {
+    Program* p = get<Program>(h, MAGIC_PROG);
+    if (!p || !name || !value) return fail(SFX_E_INVALID, "invalid program handle, name or value");
+    const int counts[] = {1, 1, 1, 2, 3, 4};
+    if (type < 0 || type > SFX_T_VEC4) return fail(SFX_E_INVALID, "uniform type %d", type);
+    const bool src_int = (type == SFX_T_INT || type == SFX_T_BOOL);
+    if (known) *known = 0;
+    auto store = [&](char* dst, int count, bool dst_int) {
+        const int n = counts[type] < count ? counts[type] : count;
+        for (int k = 0; k < n; k++) {
+            if (dst_int) ((int*)dst)[k] = src_int ? ((const int*)value)[k] : (int)((const float*)value)[k];
+            else ((float*)dst)[k] = src_int ? (float)((const int*)value)[k] : ((const float*)value)[k];
+        }
+        if (known) *known = 1;
+    };
+    for (const auto& f : g_uniform_fields)
+        if (!strcmp(f.name, name)) { store((char*)&p->u + f.offset, f.count, f.integer); return SFX_OK; }
+    for (const auto& uu : g_user_uniforms)
+        if (uu.fragment == p->fragment && !strcmp(uu.name, name)) { store((char*)&p->u.user[uu.slot], 1, false); return SFX_OK; }
+    return SFX_OK;                                                  // inactive uniform: ignored like program.get(name, None)
+}
+
+// "background0x0" (texture.py:346-347) and the #define'd plain name (texture.py:355-356) both resolve
+static int sampler_slot(const char* name) {
+    std::string base(name);
+    size_t x = base.rfind('x');
+    if (x != std::string::npos && x > 0 && x + 1 < base.size()) {
+        size_t d = x;
+        while (d > 0 && isdigit((unsigned char)base[d - 1])) d--;
+        bool tail_digits = true;
+        for (size_t k = x + 1; k < base.size(); k++) tail_digits = tail_digits && isdigit((unsigned char)base[k]);
+        if (d < x && tail_digits) base = base.substr(0, d);
+    }
+    for (const auto& s : g_sampler_names) if (base == s.name) return s.slot;
+    return -1;
+}
+
+extern "C" int sfx_sampler_bind(sfx_handle h, const char* name, sfx_handle tex, int* known) {
+    Program* p = get<Program>(h, MAGIC_PROG);
+    Texture* t = get<Texture>(tex, MAGIC_TEX);
+    if (!p || !name) return fail(SFX_E_INVALID, "invalid program handle or name");
+    if (tex && !t) return fail(SFX_E_INVALID, "invalid texture handle");
+    const int slot = sampler_slot(name);
+    if (known) *known = (slot >= 0);
+    if (slot >= 0) p->samplers[slot] = t;
+    return SFX_OK;
+}
+
+extern "C" int sfx_program_destroy(sfx_handle h) {
+    Program* p = get<Program>(h, MAGIC_PROG);
+    if (!p) return fail(SFX_E_INVALID, "invalid program handle");
+    p->magic = 0;
+    delete p;
+    return SFX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Launches
+
+static void fill_args(const Program* p, RenderArgs& a) {
+    memset(&a, 0, sizeof a);
+    a.u = p->u;
+    for (int k = 0; k < TEX_SLOTS; k++) a.tex[k] = tex_view(p->samplers[k]);
+    memcpy(a.tap_x, p->ctx->tap_x, sizeof a.tap_x);
+    memcpy(a.tap_y, p->ctx->tap_y, sizeof a.tap_y);
+}
+
+static bool needs(const RenderArgs& a, int slot) { return a.tex[slot].data != nullptr || (slot == TEX_SPECTROGRAM && a.tape_spectrogram) || (slot == TEX_WAVEFORM && a.tape_waveform); }
+
+static int check_samplers(int fragment, const RenderArgs& a) {
+    auto want = [&](int slot, const char* what) { return needs(a, slot) ? SFX_OK : fail(SFX_E_INVALID, "fragment '%s' samples '%s' but no texture is bound", g_fragment_names[fragment], what); };
+    int rc = SFX_OK;
+    if (fragment == FRAG_VISUALIZER) { if ((rc = want(TEX_BACKGROUND, "background"))) return rc; if ((rc = want(TEX_SPECTROGRAM, "iSpectrogram"))) return rc; return want(TEX_WAVEFORM, "iWaveform"); }
+    if (fragment == FRAG_BARS) return want(TEX_SPECTROGRAM, "iSpectrogram");
+    if (fragment == FRAG_WAVEFORM) return want(TEX_WAVEFORM, "iWaveform");
+    if (fragment == FRAG_MULTI_MAIN) return want(TEX_CHILD, "child");
+    if (fragment == FRAG_DYNAMICS) return want(TEX_BACKGROUND, "background");
+    return rc;
+}
+
+template <class SHADER> static void launch_render_t(const RenderArgs& a, int frames, hipStream_t s) {
+    dim3 grid((a.wr + 63)/64, (a.hr + 3)/4, frames), block(64, 4, 1);
+    hipLaunchKernelGGL(k_render<SHADER>, grid, block, 0, s, a);
+}
+
+static int launch_render(int fragment, const RenderArgs& a, int frames, hipStream_t s) {
+    switch (fragment) {
+        case FRAG_DEFAULT: launch_render_t<PlainShader<FRAG_DEFAULT>>(a, frames, s); break;
+        case FRAG_MISSING: launch_render_t<PlainShader<FRAG_MISSING>>(a, frames, s); break;
+        case FRAG_VISUALIZER:
+            if (visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) launch_render_t<VisualizerShader>(a, frames, s);
+            else launch_render_t<PlainShader<FRAG_VISUALIZER>>(a, frames, s);
+            break;
+        case FRAG_BARS: launch_render_t<PlainShader<FRAG_BARS>>(a, frames, s); break;
+        case FRAG_WAVEFORM: launch_render_t<PlainShader<FRAG_WAVEFORM>>(a, frames, s); break;
+        case FRAG_MULTI_CHILD: launch_render_t<PlainShader<FRAG_MULTI_CHILD>>(a, frames, s); break;
+        case FRAG_MULTI_MAIN: launch_render_t<PlainShader<FRAG_MULTI_MAIN>>(a, frames, s); break;
+        case FRAG_SHADERTOY: launch_render_t<PlainShader<FRAG_SHADERTOY>>(a, frames, s); break;
+        case FRAG_DYNAMICS: launch_render_t<PlainShader<FRAG_DYNAMICS>>(a, frames, s); break;
+        case FRAG_AUDIO: launch_render_t<PlainShader<FRAG_AUDIO>>(a, frames, s); break;
+        default: return fail(SFX_E_UNSUPPORTED, "fragment %d has no render kernel", fragment);
+    }
+    return SFX_OK;
+}
+
+template <class SHADER> static int launch_fused_s(const RenderArgs& a, int ssaa, int frames, hipStream_t s) {
+    const int blocks_x = (a.w + 127)/128;
+    if (ssaa == 1) hipLaunchKernelGGL((k_render_resolve<SHADER, 1>), dim3(blocks_x*((a.h + 1)/2), 1, frames), dim3(256), 0, s, a);
+    else if (ssaa == 2) hipLaunchKernelGGL((k_render_resolve<SHADER, 2>), dim3(blocks_x*a.h, 1, frames), dim3(512), 0, s, a);
+    else if (ssaa == 4) hipLaunchKernelGGL((k_render_resolve<SHADER, 4>), dim3(blocks_x*a.h, 1, frames), dim3(512), 0, s, a);
+    else return fail(SFX_E_UNSUPPORTED, "fused ssaa %d", ssaa);
+    return SFX_OK;
+}
+
+static int launch_fused(int fragment, const RenderArgs& a, int ssaa, int frames, hipStream_t s, bool force_generic = false) {
+    switch (fragment) {
+        case FRAG_DEFAULT: return launch_fused_s<PlainShader<FRAG_DEFAULT>>(a, ssaa, frames, s);
+        case FRAG_MISSING: return launch_fused_s<PlainShader<FRAG_MISSING>>(a, ssaa, frames, s);
+        case FRAG_VISUALIZER:
+            if (!force_generic && visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) return launch_fused_s<VisualizerShader>(a, ssaa, frames, s);
+            return launch_fused_s<PlainShader<FRAG_VISUALIZER>>(a, ssaa, frames, s);
+        case FRAG_BARS: return launch_fused_s<PlainShader<FRAG_BARS>>(a, ssaa, frames, s);
+        case FRAG_WAVEFORM: return launch_fused_s<PlainShader<FRAG_WAVEFORM>>(a, ssaa, frames, s);
+        case FRAG_MULTI_CHILD: return launch_fused_s<PlainShader<FRAG_MULTI_CHILD>>(a, ssaa, frames, s);
+        case FRAG_MULTI_MAIN: return launch_fused_s<PlainShader<FRAG_MULTI_MAIN>>(a, ssaa, frames, s);
+        case FRAG_SHADERTOY: return launch_fused_s<PlainShader<FRAG_SHADERTOY>>(a, ssaa, frames, s);
+        case FRAG_DYNAMICS: return launch_fused_s<PlainShader<FRAG_DYNAMICS>>(a, ssaa, frames, s);
+        case FRAG_AUDIO: return launch_fused_s<PlainShader<FRAG_AUDIO>>(a, ssaa, frames, s);
+        default: return fail(SFX_E_UNSUPPORTED, "fragment %d has no fused kernel", fragment);
+    }
+}
+
+static int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SFX_OK : fail(SFX_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+}
+
+extern "C" int sfx_render(sfx_handle h, sfx_handle target, int layer) {
+    Program* p = get<Program>(h, MAGIC_PROG);
+    Texture* t = get<Texture>(target, MAGIC_TEX);
+    if (!p || !t) return fail(SFX_E_INVALID, "invalid program or target handle");
+    if (p->fragment == FRAG_FINAL) return fail(SFX_E_INVALID, "the final program is driven by sfx_resolve / sfx_render_resolve");
+    if (t->dtype != SFX_U8 && t->dtype != SFX_F32) return fail(SFX_E_UNSUPPORTED, "render target dtype %d", t->dtype);
+    USE_DEVICE(p->ctx);
+    RenderArgs a;
+    fill_args(p, a);
+    a.u.iLayer = layer;                                             // shader.py:402
+    a.wr = t->width; a.hr = t->height; a.w = t->width; a.h = t->height;
+    a.out = t->data; a.out_components = t->components; a.out_dtype = t->dtype; a.out_frame_stride = 0;
+    int rc = check_samplers(p->fragment, a);
+    if (rc) return rc;
+    if ((rc = launch_render(p->fragment, a, 1, p->ctx->stream))) return rc;
+    return launch_status();
+}
+
+extern "C" int sfx_resolve(sfx_handle h, sfx_handle src, sfx_handle dst, int subsample) {
+    CTX_OR_FAIL(c, h);
+    Texture* s = get<Texture>(src, MAGIC_TEX);
+    Texture* d = get<Texture>(dst, MAGIC_TEX);
+    if (!s || !d) return fail(SFX_E_INVALID, "invalid texture handle");
+    if (s->dtype != SFX_U8 || s->components != 4) return fail(SFX_E_UNSUPPORTED, "resolve source must be RGBA8 (iScreen)");
+    if (d->dtype != SFX_U8 || d->components != 3) return fail(SFX_E_UNSUPPORTED, "resolve target must be RGB8 (iFinal, scene.py:188-189)");
+    USE_DEVICE(c);
+    ResolveArgs a;
+    a.screen = tex_view(s);
+    a.screen.filter = s->filter; a.screen.repeat_x = s->repeat_x; a.screen.repeat_y = s->repeat_y;
+    a.w = d->width; a.h = d->height; a.subsample = subsample < 1 ? 1 : subsample;
+    a.out = (uint8_t*)d->data;
+    hipLaunchKernelGGL(k_resolve, dim3((a.w + 63)/64, (a.h + 3)/4), dim3(64, 4), 0, c->stream, a);
+    return launch_status();
+}
+
+extern "C" int sfx_fused_supported(int ssaa_x1000, int subsample) {
+    if (ssaa_x1000 % 1000) return 0;
+    return fused_supported(ssaa_x1000/1000, subsample < 1 ? 1 : subsample) ? 1 : 0;
+}
+
+extern "C" int sfx_render_resolve(sfx_handle h, sfx_handle final_tex, int ssaa, int subsample) {
+    Program* p = get<Program>(h, MAGIC_PROG);
+    Texture* t = get<Texture>(final_tex, MAGIC_TEX);
+    if (!p || !t) return fail(SFX_E_INVALID, "invalid program or target handle");
+    if (t->dtype != SFX_U8 || t->components != 3) return fail(SFX_E_UNSUPPORTED, "fused target must be RGB8 (iFinal, scene.py:188-189)");
+    if (subsample < 1) subsample = 1;
+    if (!fused_supported(ssaa, subsample)) return fail(SFX_E_UNSUPPORTED, "final.glsl footprint for ssaa=%d subsample=%d leaves the pixel's block: use sfx_render + sfx_resolve", ssaa, subsample);
+    USE_DEVICE(p->ctx);
+    RenderArgs a;
+    fill_args(p, a);
+    a.w = t->width; a.h = t->height; a.wr = t->width*ssaa; a.hr = t->height*ssaa; a.subsample = subsample;
+    a.out = t->data; a.out_frame_stride = 0;
+    int rc = check_samplers(p->fragment, a);
+    if (rc) return rc;
+    if ((rc = launch_fused(p->fragment, a, ssaa, 1, p->ctx->stream))) return rc;
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Read-out ring with a pipe writer thread (turbopipe's role, exporting.py:147-171)
+
+struct Ring : Object {
+    Context* ctx;
+    size_t frame_bytes;
+    int slots;
+    std::vector<void*> host;
+    std::vector<hipEvent_t> copied;
+    hipStream_t copy_stream;
+    hipEvent_t produced;
+    // writer
+    std::thread writer;
+    std::mutex mutex;
+    std::condition_variable wake, idle;
+    std::deque<std::pair<int, int>> queue;          // (slot, fd)
+    std::vector<int> pending;                       // writes queued or running per slot
+    bool stop = false;
+    int io_error = 0;
+};
+
+static void ring_writer(Ring* r) {
+    for (;;) {
+        std::pair<int, int> job;
+        {
+            std::unique_lock<std::mutex> lock(r->mutex);
+            r->wake.wait(lock, [&] { return r->stop || !r->queue.empty(); });
+            if (r->queue.empty()) return;
+            job = r->queue.front(); r->queue.pop_front();
+        }
+        hipEventSynchronize(r->copied[job.first]);
+        const char* p = (const char*)r->host[job.first];
+        size_t left = r->frame_bytes;
+        int err = 0;
+        while (left > 0) {
+            ssize_t n = ::write(job.second, p, left);
+            if (n < 0) { if (errno == EINTR) continue; err = errno; break; }
+            p += n; left -= (size_t)n;
+        }
+        {
+            std::lock_guard<std::mutex> lock(r->mutex);
+            if (err) r->io_error = err;
+            r->pending[job.first]--;
+        }
+        r->idle.notify_all();
+    }
+}
+
+extern "C" int sfx_ring_create(sfx_handle h, size_t frame_bytes, int slots, sfx_handle* out) {
+    CTX_OR_FAIL(c, h);
+    if (!out || slots < 1 || slots > 64 || frame_bytes == 0) return fail(SFX_E_INVALID, "ring of %d slots x %zu bytes", slots, frame_bytes);
+    USE_DEVICE(c);
+    Ring* r = new Ring();
+    r->magic = MAGIC_RING; r->ctx = c; r->frame_bytes = frame_bytes; r->slots = slots;
+    r->host.resize(slots); r->copied.resize(slots); r->pending.assign(slots, 0);
+    HIP_TRY(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&r->produced, hipEventDisableTiming));
+    for (int k = 0; k < slots; k++) {
+        HIP_TRY(hipHostMalloc(&r->host[k], frame_bytes, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&r->copied[k], hipEventDisableTiming));
+    }
+    r->writer = std::thread(ring_writer, r);
+    *out = handle_of(r);
+    return SFX_OK;
+}
+
+static int ring_wait_slot(Ring* r, int slot) {
+    std::unique_lock<std::mutex> lock(r->mutex);
+    r->idle.wait(lock, [&] { return r->pending[slot] == 0; });
+    return r->io_error ? fail(SFX_E_IO, "pipe write failed: %s", strerror(r->io_error)) : SFX_OK;
+}
+
+extern "C" int sfx_ring_read_device_async(sfx_handle h, const void* dptr, int slot) {
+    Ring* r = get<Ring>(h, MAGIC_RING);
+    if (!r || !dptr || slot < 0 || slot >= r->slots) return fail(SFX_E_INVALID, "invalid ring handle, pointer or slot");
+    USE_DEVICE(r->ctx);
+    int rc = ring_wait_slot(r, slot);                               // turbopipe.sync(buffer) before reuse
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(r->produced, r->ctx->stream));           // the frame is complete on the render stream…
+    HIP_TRY(hipStreamWaitEvent(r->copy_stream, r->produced, 0));    // …before the copy engine reads it
+    HIP_TRY(hipMemcpyAsync(r->host[slot], dptr, r->frame_bytes, hipMemcpyDeviceToHost, r->copy_stream));
+    HIP_TRY(hipEventRecord(r->copied[slot], r->copy_stream));
+    return SFX_OK;
+}
+
+extern "C" int sfx_ring_read_async(sfx_handle h, sfx_handle tex, int slot) {
+    Ring* r = get<Ring>(h, MAGIC_RING);
+    Texture* t = get<Texture>(tex, MAGIC_TEX);
+    if (!r || !t) return fail(SFX_E_INVALID, "invalid ring or texture handle");
+    if (t->nbytes != r->frame_bytes) return fail(SFX_E_INVALID, "texture holds %zu bytes, ring slots %zu", t->nbytes, r->frame_bytes);
+    return sfx_ring_read_device_async(h, t->data, slot);
+}
+
+extern "C" int sfx_ring_sync(sfx_handle h, int slot, void** host_ptr) {
+    Ring* r = get<Ring>(h, MAGIC_RING);
+    if (!r || slot < 0 || slot >= r->slots) return fail(SFX_E_INVALID, "invalid ring handle or slot");
+    USE_DEVICE(r->ctx);
+    HIP_TRY(hipEventSynchronize(r->copied[slot]));
+    if (host_ptr) *host_ptr = r->host[slot];
+    return SFX_OK;
+}
+
+extern "C" int sfx_ring_pipe(sfx_handle h, int slot, int fd) {
+    Ring* r = get<Ring>(h, MAGIC_RING);
+    if (!r || slot < 0 || slot >= r->slots || fd < 0) return fail(SFX_E_INVALID, "invalid ring handle, slot or fd");
+    {
+        std::lock_guard<std::mutex> lock(r->mutex);
+        if (r->io_error) return fail(SFX_E_IO, "pipe write failed: %s", strerror(r->io_error));
+        r->pending[slot]++;
+        r->queue.emplace_back(slot, fd);
+    }
+    r->wake.notify_one();
+    return SFX_OK;
+}
+
+extern "C" int sfx_ring_pipe_sync(sfx_handle h, int slot) {
+    Ring* r = get<Ring>(h, MAGIC_RING);
+    if (!r || slot >= r->slots) return fail(SFX_E_INVALID, "invalid ring handle or slot");
+    if (slot >= 0) return ring_wait_slot(r, slot);
+    for (int k = 0; k < r->slots; k++) { int rc = ring_wait_slot(r, k); if (rc) return rc; }
+    return SFX_OK;
+}
+
+extern "C" int sfx_ring_destroy(sfx_handle h) {
+    Ring* r = get<Ring>(h, MAGIC_RING);
+    if (!r) return fail(SFX_E_INVALID, "invalid ring handle");
+    { std::lock_guard<std::mutex> lock(r->mutex); r->stop = true; }
+    r->wake.notify_all();
+    if (r->writer.joinable()) r->writer.join();
+    hipSetDevice(r->ctx->device);
+    hipStreamSynchronize(r->copy_stream);
+    for (int k = 0; k < r->slots; k++) { hipHostFree(r->host[k]); hipEventDestroy(r->copied[k]); }
+    hipEventDestroy(r->produced);
+    hipStreamDestroy(r->copy_stream);
+    r->magic = 0;
+    delete r;
+    return SFX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Audio
+
+struct Audio : Object {
+    Context* ctx;
+    float* pcm = nullptr;            // planar [channels][samples]
+    long samples; int channels, samplerate;
+};
+
+extern "C" int sfx_audio_upload(sfx_handle h, const float* interleaved, int64_t samples, int channels, int samplerate, sfx_handle* out) {
+    CTX_OR_FAIL(c, h);
+    if (!out || samples < 0 || channels < 1 || channels > 8 || (samples > 0 && !interleaved)) return fail(SFX_E_INVALID, "audio of %lld samples x %d channels", (long long)samples, channels);
+    USE_DEVICE(c);
+    Audio* a = new Audio();
+    a->magic = MAGIC_AUDIO; a->ctx = c; a->samples = samples; a->channels = channels; a->samplerate = samplerate;
+    std::vector<float> planar((size_t)samples*channels);
+    for (int64_t i = 0; i < samples; i++) for (int ch = 0; ch < channels; ch++) planar[(size_t)ch*samples + i] = interleaved[i*channels + ch];
+    HIP_TRY(hipMalloc(&a->pcm, planar.size()*sizeof(float) + 16));
+    if (!planar.empty()) HIP_TRY(hipMemcpy(a->pcm, planar.data(), planar.size()*sizeof(float), hipMemcpyHostToDevice));
+    *out = handle_of(a);
+    return SFX_OK;
+}
+
+extern "C" int sfx_audio_destroy(sfx_handle h) {
+    Audio* a = get<Audio>(h, MAGIC_AUDIO);
+    if (!a) return fail(SFX_E_INVALID, "invalid audio handle");
+    hipSetDevice(a->ctx->device);
+    hipStreamSynchronize(a->ctx->stream);
+    hipFree(a->pcm);
+    a->magic = 0;
+    delete a;
+    return SFX_OK;
+}
+
+struct Plan : Object {
+    Context* ctx;
+    int fft_n, window, bins, channels, fft_bins, nnz;
+    double* d_window = nullptr; double2* d_twiddle = nullptr;
+    int *d_indptr = nullptr, *d_indices = nullptr; float* d_data = nullptr;
+    float* d_dense = nullptr; int2* d_band = nullptr; int k_pad = 0, row_tiles = 0;
+    // scratch that grows on demand
+    long* d_tell = nullptr; float* d_power = nullptr; float* d_out = nullptr; int cap_frames = 0;
+};
+
+static int plan_reserve(Plan* p, int frames) {
+    if (frames <= p->cap_frames) return SFX_OK;
+    hipStreamSynchronize(p->ctx->stream);
+    hipFree(p->d_tell); hipFree(p->d_power); hipFree(p->d_out);
+    p->d_tell = nullptr; p->d_power = nullptr; p->d_out = nullptr; p->cap_frames = 0;
+    HIP_TRY(hipMalloc(&p->d_tell, sizeof(long)*frames));
+    HIP_TRY(hipMalloc(&p->d_power, sizeof(float)*(size_t)frames*p->channels*p->fft_bins));
+    HIP_TRY(hipMalloc(&p->d_out, sizeof(float)*(size_t)frames*p->channels*p->bins));
+    p->cap_frames = frames;
+    return SFX_OK;
+}
+
+extern "C" int sfx_stft_plan(sfx_handle h, int fft_n, int window, int bins, int channels,
+                             const int32_t* indptr, const int32_t* indices, const float* data, sfx_handle* out) {
+    CTX_OR_FAIL(c, h);
+    if (!out || fft_n < 4 || fft_n > 14 || bins < 1 || channels < 1 || !indptr) return fail(SFX_E_INVALID, "stft plan fft_n=%d bins=%d channels=%d", fft_n, bins, channels);
+    if (window < 0 || window > SFX_WINDOW_NONE) return fail(SFX_E_INVALID, "window %d", window);
+    USE_DEVICE(c);
+    const int N = 1 << fft_n, fft_bins = N/2 + 1, nnz = indptr[bins];
+    for (int r = 0; r < bins; r++) if (indptr[r] > indptr[r + 1]) return fail(SFX_E_INVALID, "indptr not monotone");
+    for (int j = 0; j < nnz; j++) if (indices[j] < 0 || indices[j] >= fft_bins) return fail(SFX_E_INVALID, "column %d outside %d fft bins", indices[j], fft_bins);
+    Plan* p = new Plan();
+    p->magic = MAGIC_PLAN; p->ctx = c; p->fft_n = fft_n; p->window = window; p->bins = bins; p->channels = channels;
+    p->fft_bins = fft_bins; p->nnz = nnz;
+    // windows: spectrogram.py:92-108 (np.hanning is the symmetric Hann)
+    std::vector<double> win(N);
+    const double pi = 3.14159265358979323846;
+    for (int i = 0; i < N; i++) {
+        if (window == SFX_WINDOW_HANNING) win[i] = (N == 1) ? 1.0 : 0.5 + 0.5*::cos(pi*(double)(2*i + 1 - N)/(double)(N - 1));
+        else if (window == SFX_WINDOW_HANN_POISSON) win[i] = 0.5*(1.0 - ::cos(2.0*pi*(double)i/(double)N))*::exp(-2.0*::fabs((double)(N - 2*i))/(double)N);
+        else win[i] = 1.0;
+    }
+    std::vector<double2> tw(N/2);
+    for (int k = 0; k < N/2; k++) { const double ang = -2.0*pi*(double)k/(double)N; tw[k] = make_double2(::cos(ang), ::sin(ang)); }
+    HIP_TRY(hipMalloc(&p->d_window, sizeof(double)*N));
+    HIP_TRY(hipMalloc(&p->d_twiddle, sizeof(double2)*(N/2)));
+    HIP_TRY(hipMemcpy(p->d_window, win.data(), sizeof(double)*N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->d_twiddle, tw.data(), sizeof(double2)*(N/2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&p->d_indptr, sizeof(int)*(bins + 1)));
+    HIP_TRY(hipMalloc(&p->d_indices, sizeof(int)*(nnz + 1)));
+    HIP_TRY(hipMalloc(&p->d_data, sizeof(float)*(nnz + 1)));
+    HIP_TRY(hipMemcpy(p->d_indptr, indptr, sizeof(int)*(bins + 1), hipMemcpyHostToDevice));
+    if (nnz) {
+        HIP_TRY(hipMemcpy(p->d_indices, indices, sizeof(int)*nnz, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_data, data, sizeof(float)*nnz, hipMemcpyHostToDevice));
+    }
+    // dense banded copy for the MFMA path: rows padded to 32, k padded to 32, per-row-tile k range
+    p->row_tiles = (bins + 31)/32;
+    p->k_pad = ((fft_bins + 31)/32)*32;
+    std::vector<float> dense((size_t)p->row_tiles*32*p->k_pad, 0.0f);
+    std::vector<int2> band(p->row_tiles);
+    for (int t = 0; t < p->row_tiles; t++) {
+        int lo = p->k_pad, hi = 0;
+        for (int r = t*32; r < bins && r < t*32 + 32; r++)
+            for (int j = indptr[r]; j < indptr[r + 1]; j++) {
+                dense[(size_t)r*p->k_pad + indices[j]] = data[j];
+                lo = indices[j] < lo ? indices[j] : lo; hi = indices[j] + 1 > hi ? indices[j] + 1 : hi;
+            }
+        if (hi <= lo) { lo = 0; hi = 0; }
+        band[t] = make_int2((lo/32)*32, ((hi + 31)/32)*32);
+    }
+    HIP_TRY(hipMalloc(&p->d_dense, sizeof(float)*dense.size()));
+    HIP_TRY(hipMalloc(&p->d_band, sizeof(int2)*band.size()));
+    HIP_TRY(hipMemcpy(p->d_dense, dense.data(), sizeof(float)*dense.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->d_band, band.data(), sizeof(int2)*band.size(), hipMemcpyHostToDevice));
+    if ((size_t)(N/2)*sizeof(double2) > 64*1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_stft_power, hipFuncAttributeMaxDynamicSharedMemorySize, (N/2)*(int)sizeof(double2)));
+    *out = handle_of(p);
+    return SFX_OK;
+}
+
+extern "C" int sfx_stft_plan_destroy(sfx_handle h) {
+    Plan* p = get<Plan>(h, MAGIC_PLAN);
+    if (!p) return fail(SFX_E_INVALID, "invalid plan handle");
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+    hipFree(p->d_window); hipFree(p->d_twiddle); hipFree(p->d_indptr); hipFree(p->d_indices); hipFree(p->d_data);
+    hipFree(p->d_dense); hipFree(p->d_band); hipFree(p->d_tell); hipFree(p->d_power); hipFree(p->d_out);
+    p->magic = 0;
+    delete p;
+    return SFX_OK;
+}
+
+static int check_audio(const Plan* p, const Audio* a) {
+    if (!p || !a) return fail(SFX_E_INVALID, "invalid plan or audio handle");
+    if (p->ctx != a->ctx) return fail(SFX_E_INVALID, "plan and audio belong to different contexts");
+    if (a->channels != p->channels) return fail(SFX_E_INVALID, "plan built for %d channels, audio has %d (spectrogram.py:306 hard-codes the reshape)", p->channels, a->channels);
+    return SFX_OK;
+}
+
+// device-side launches shared by the per-frame entry points and the tape
+static void launch_stft(const Plan* p, const Audio* a, const long* d_tell, int frames, float* d_power, hipStream_t s) {
+    const int N = 1 << p->fft_n;
+    hipLaunchKernelGGL(k_stft_power, dim3(frames, p->channels), dim3(256), (N/2)*sizeof(double2), s,
+                       a->pcm, a->samples, d_tell, p->fft_n, p->d_window, p->d_twiddle, d_power);
+}
+static void launch_filterbank(const Plan* p, int frames, int use_mfma, const float* d_power, float* d_out, hipStream_t s) {
+    const int ncols = frames*p->channels;
+    if (use_mfma) {
+        hipLaunchKernelGGL(k_filterbank_mfma, dim3((ncols + 127)/128, p->row_tiles), dim3(256), 0, s,
+                           p->d_dense, p->k_pad, p->d_band, p->bins, p->channels, p->fft_bins, ncols, d_power, d_out);
+    } else {
+        const long total = (long)ncols*p->bins;
+        hipLaunchKernelGGL(k_filterbank_csr, dim3((unsigned)((total + 255)/256)), dim3(256), 0, s,
+                           p->d_indptr, p->d_indices, p->d_data, p->bins, p->channels, p->fft_bins, ncols, d_power, d_out);
+    }
+}
+
+extern "C" int sfx_stft_power(sfx_handle hp, sfx_handle ha, const int64_t* tell, int nframes, float* power) {
+    Plan* p = get<Plan>(hp, MAGIC_PLAN); Audio* a = get<Audio>(ha, MAGIC_AUDIO);
+    int rc = check_audio(p, a);
+    if (rc) return rc;
+    if (!tell || !power || nframes < 1) return fail(SFX_E_INVALID, "null tell/power or no frames");
+    USE_DEVICE(p->ctx);
+    if ((rc = plan_reserve(p, nframes))) return rc;
+    hipStream_t s = p->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(p->d_tell, tell, sizeof(long)*nframes, hipMemcpyHostToDevice, s));
+    launch_stft(p, a, p->d_tell, nframes, p->d_power, s);
+    if ((rc = launch_status())) return rc;
+    HIP_TRY(hipMemcpyAsync(power, p->d_power, sizeof(float)*(size_t)nframes*p->channels*p->fft_bins, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SFX_OK;
+}
+
+extern "C" int sfx_spectrogram_targets(sfx_handle hp, sfx_handle ha, const int64_t* tell, int nframes, int use_mfma, float* out) {
+    Plan* p = get<Plan>(hp, MAGIC_PLAN); Audio* a = get<Audio>(ha, MAGIC_AUDIO);
+    int rc = check_audio(p, a);
+    if (rc) return rc;
+    if (!tell || !out || nframes < 1) return fail(SFX_E_INVALID, "null tell/out or no frames");
+    USE_DEVICE(p->ctx);
+    if ((rc = plan_reserve(p, nframes))) return rc;
+    hipStream_t s = p->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(p->d_tell, tell, sizeof(long)*nframes, hipMemcpyHostToDevice, s));
+    launch_stft(p, a, p->d_tell, nframes, p->d_power, s);
+    launch_filterbank(p, nframes, use_mfma, p->d_power, p->d_out, s);
+    if ((rc = launch_status())) return rc;
+    HIP_TRY(hipMemcpyAsync(out, p->d_out, sizeof(float)*(size_t)nframes*p->channels*p->bins, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SFX_OK;
+}
+
+extern "C" int sfx_waveform_rows(sfx_handle ha, const int64_t* tell, int nframes, int chunk, int points, int reducer, float* out) {
+    Audio* a = get<Audio>(ha, MAGIC_AUDIO);
+    if (!a || !tell || !out || nframes < 1 || chunk < 1 || points < 1) return fail(SFX_E_INVALID, "invalid audio handle or arguments");
+    USE_DEVICE(a->ctx);
+    hipStream_t s = a->ctx->stream;
+    long* d_tell; float* d_rows;
+    const size_t n = (size_t)nframes*points*a->channels;
+    HIP_TRY(hipMalloc(&d_tell, sizeof(long)*nframes));
+    HIP_TRY(hipMalloc(&d_rows, sizeof(float)*n));
+    HIP_TRY(hipMemcpyAsync(d_tell, tell, sizeof(long)*nframes, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_waveform_rows, dim3((points*a->channels + 3)/4, nframes), dim3(256), 0, s,
+                       a->pcm, a->samples, a->channels, d_tell, chunk, points, reducer, d_rows);
+    int rc = launch_status();
+    if (!rc) { hipMemcpyAsync(out, d_rows, sizeof(float)*n, hipMemcpyDeviceToHost, s); hipStreamSynchronize(s); }
+    hipFree(d_tell); hipFree(d_rows);
+    return rc;
+}
+
+extern "C" int sfx_volume_std(sfx_handle ha, const int64_t* tell, int nframes, int window_samples, float* out) {
+    Audio* a = get<Audio>(ha, MAGIC_AUDIO);
+    if (!a || !tell || !out || nframes < 1 || window_samples < 1) return fail(SFX_E_INVALID, "invalid audio handle or arguments");
+    USE_DEVICE(a->ctx);
+    hipStream_t s = a->ctx->stream;
+    long* d_tell; float* d_out;
+    HIP_TRY(hipMalloc(&d_tell, sizeof(long)*nframes));
+    HIP_TRY(hipMalloc(&d_out, sizeof(float)*2*nframes));
+    HIP_TRY(hipMemcpyAsync(d_tell, tell, sizeof(long)*nframes, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_volume_std, dim3(nframes), dim3(256), 0, s, a->pcm, a->samples, a->channels, d_tell, window_samples, d_out);
+    int rc = launch_status();
+    if (!rc) { hipMemcpyAsync(out, d_out, sizeof(float)*2*nframes, hipMemcpyDeviceToHost, s); hipStreamSynchronize(s); }
+    hipFree(d_tell); hipFree(d_out);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Tape
+
+struct Tape : Object {
+    Plan* plan; Audio* audio; Context* ctx;
+    sfx_tape_desc desc;
+    int max_frames, n;               // n = bins*channels
+    long* d_tell; float* d_power; float* d_targets; float* d_columns; float* d_rows; float* d_loudness;
+    float* d_state; ScalarState* d_scalars; FrameDyn* d_dyn;
+    DynCoeffF32* d_coeff; DynCoeffF64 *d_vol, *d_std; FrameClock* d_clock;
+};
+
+extern "C" int sfx_tape_reset(sfx_handle h) {
+    Tape* t = get<Tape>(h, MAGIC_TAPE);
+    if (!t) return fail(SFX_E_INVALID, "invalid tape handle");
+    USE_DEVICE(t->ctx);
+    HIP_TRY(hipMemsetAsync(t->d_state, 0, sizeof(float)*3*t->n, t->ctx->stream));
+    HIP_TRY(hipMemsetAsync(t->d_scalars, 0, sizeof(ScalarState)*2, t->ctx->stream));
+    return SFX_OK;
+}
+
+extern "C" int sfx_tape_create(sfx_handle hp, sfx_handle ha, const sfx_tape_desc* desc, int max_frames, sfx_handle* out) {
+    Plan* p = get<Plan>(hp, MAGIC_PLAN); Audio* a = get<Audio>(ha, MAGIC_AUDIO);
+    int rc = check_audio(p, a);
+    if (rc) return rc;
+    if (!desc || !out || max_frames < 1) return fail(SFX_E_INVALID, "null desc/output or no frames");
+    if (p->bins*p->channels > 2048) return fail(SFX_E_UNSUPPORTED, "dynamics scan handles up to 2048 spectrogram values, got %d", p->bins*p->channels);
+    USE_DEVICE(p->ctx);
+    Tape* t = new Tape();
+    t->magic = MAGIC_TAPE; t->plan = p; t->audio = a; t->ctx = p->ctx; t->desc = *desc; t->max_frames = max_frames;
+    t->n = p->bins*p->channels;
+    const size_t F = max_frames;
+    const int pts = desc->points > 0 ? desc->points : 1;
+    HIP_TRY(hipMalloc(&t->d_tell, sizeof(long)*F));
+    HIP_TRY(hipMalloc(&t->d_power, sizeof(float)*F*p->channels*p->fft_bins));
+    HIP_TRY(hipMalloc(&t->d_targets, sizeof(float)*F*t->n));
+    HIP_TRY(hipMalloc(&t->d_columns, sizeof(float)*F*t->n));
+    HIP_TRY(hipMalloc(&t->d_rows, sizeof(float)*F*pts*a->channels));
+    HIP_TRY(hipMalloc(&t->d_loudness, sizeof(float)*F*2));
+    HIP_TRY(hipMalloc(&t->d_state, sizeof(float)*3*t->n));
+    HIP_TRY(hipMalloc(&t->d_scalars, sizeof(ScalarState)*2));
+    HIP_TRY(hipMalloc(&t->d_dyn, sizeof(FrameDyn)*F));
+    HIP_TRY(hipMalloc(&t->d_coeff, sizeof(DynCoeffF32)*F));
+    HIP_TRY(hipMalloc(&t->d_vol, sizeof(DynCoeffF64)*F));
+    HIP_TRY(hipMalloc(&t->d_std, sizeof(DynCoeffF64)*F));
+    HIP_TRY(hipMalloc(&t->d_clock, sizeof(FrameClock)*F));
+    *out = handle_of(t);
+    return sfx_tape_reset(*out);
+}
+
+extern "C" int sfx_tape_build(sfx_handle h, int nframes, const int64_t* tell, const sfx_frame_clock* clock,
+                              const sfx_dyn_coeff_f32* spectrogram, const sfx_dyn_coeff_f64* volume, const sfx_dyn_coeff_f64* std_) {
+    Tape* t = get<Tape>(h, MAGIC_TAPE);
+    if (!t) return fail(SFX_E_INVALID, "invalid tape handle");
+    if (nframes < 1 || nframes > t->max_frames || !tell || !clock || !spectrogram || !volume || !std_) return fail(SFX_E_INVALID, "tape build of %d frames (capacity %d) or null arrays", nframes, t->max_frames);
+    static_assert(sizeof(sfx_dyn_coeff_f32) == sizeof(DynCoeffF32) && sizeof(sfx_dyn_coeff_f64) == sizeof(DynCoeffF64) && sizeof(sfx_frame_clock) == sizeof(FrameClock), "ABI structs");
+    USE_DEVICE(t->ctx);
+    hipStream_t s = t->ctx->stream;
+    const Plan* p = t->plan; const Audio* a = t->audio;
+    HIP_TRY(hipMemcpyAsync(t->d_tell, tell, sizeof(long)*nframes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(t->d_clock, clock, sizeof(FrameClock)*nframes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(t->d_coeff, spectrogram, sizeof(DynCoeffF32)*nframes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(t->d_vol, volume, sizeof(DynCoeffF64)*nframes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(t->d_std, std_, sizeof(DynCoeffF64)*nframes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));                               // host arrays are borrowed for the call only
+    launch_stft(p, a, t->d_tell, nframes, t->d_power, s);
+    launch_filterbank(p, nframes, t->desc.use_mfma, t->d_power, t->d_targets, s);
+    if (t->desc.points > 0)
+        hipLaunchKernelGGL(k_waveform_rows, dim3((t->desc.points*a->channels + 3)/4, nframes), dim3(256), 0, s,
+                           a->pcm, a->samples, a->channels, t->d_tell, t->desc.chunk_size, t->desc.points, t->desc.reducer, t->d_rows);
+    hipLaunchKernelGGL(k_volume_std, dim3(nframes), dim3(256), 0, s, a->pcm, a->samples, a->channels, t->d_tell, t->desc.volume_window, t->d_loudness);
+    hipLaunchKernelGGL(k_dynamics_scan, dim3(1), dim3(1024), 0, s, nframes, t->n, t->d_targets, t->d_coeff, (float)t->desc.precision,
+                       t->d_state, t->d_columns, t->d_loudness, t->d_vol, t->d_std, t->desc.precision,
+                       t->desc.volume_integrate, t->desc.std_integrate, t->d_scalars, t->d_clock, t->d_dyn);
+    return launch_status();
+}
+
+extern "C" int sfx_tape_read(sfx_handle h, int what, int frame0, int nframes, void* out, size_t nbytes) {
+    Tape* t = get<Tape>(h, MAGIC_TAPE);
+    if (!t || !out) return fail(SFX_E_INVALID, "invalid tape handle or output");
+    if (frame0 < 0 || nframes < 1 || frame0 + nframes > t->max_frames) return fail(SFX_E_INVALID, "frames [%d, %d) outside the tape", frame0, frame0 + nframes);
+    USE_DEVICE(t->ctx);
+    const char* src; size_t per;
+    const int pts = t->desc.points > 0 ? t->desc.points : 1;
+    switch (what) {
+        case SFX_TAPE_SPECTROGRAM: src = (const char*)t->d_columns; per = sizeof(float)*t->n; break;
+        case SFX_TAPE_WAVEFORM: src = (const char*)t->d_rows; per = sizeof(float)*pts*t->audio->channels; break;
+        case SFX_TAPE_UNIFORMS: src = (const char*)t->d_dyn; per = sizeof(FrameDyn); break;
+        case SFX_TAPE_TARGETS: src = (const char*)t->d_targets; per = sizeof(float)*t->n; break;
+        case SFX_TAPE_LOUDNESS: src = (const char*)t->d_loudness; per = sizeof(float)*2; break;
+        default: return fail(SFX_E_INVALID, "tape section %d", what);
+    }
+    if (nbytes != per*nframes) return fail(SFX_E_INVALID, "tape read of %zu bytes, section needs %zu", nbytes, per*nframes);
+    HIP_TRY(hipMemcpyAsync(out, src + per*frame0, nbytes, hipMemcpyDeviceToHost, t->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    return SFX_OK;
+}
+
+extern "C" int sfx_tape_destroy(sfx_handle h) {
+    Tape* t = get<Tape>(h, MAGIC_TAPE);
+    if (!t) return fail(SFX_E_INVALID, "invalid tape handle");
+    hipSetDevice(t->ctx->device);
+    hipStreamSynchronize(t->ctx->stream);
+    hipFree(t->d_tell); hipFree(t->d_power); hipFree(t->d_targets); hipFree(t->d_columns); hipFree(t->d_rows); hipFree(t->d_loudness);
+    hipFree(t->d_state); hipFree(t->d_scalars); hipFree(t->d_dyn); hipFree(t->d_coeff); hipFree(t->d_vol); hipFree(t->d_std); hipFree(t->d_clock);
+    t->magic = 0;
+    delete t;
+    return SFX_OK;
+}
+
+extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nframes, int width, int height,
+                               int ssaa, int subsample, void* device_out) {
+    Program* p = get<Program>(hp, MAGIC_PROG);
+    Tape* t = get<Tape>(ht, MAGIC_TAPE);
+    if (!p || !t || !device_out) return fail(SFX_E_INVALID, "invalid program/tape handle or output");
+    if (p->ctx != t->ctx) return fail(SFX_E_INVALID, "program and tape belong to different contexts");
+    if (frame0 < 0 || nframes < 1 || frame0 + nframes > t->max_frames) return fail(SFX_E_INVALID, "frames [%d, %d) outside the tape", frame0, frame0 + nframes);
+    if (subsample < 1) subsample = 1;
+    if (!fused_supported(ssaa, subsample)) return fail(SFX_E_UNSUPPORTED, "tape rendering needs a fused (ssaa, subsample) pair, got (%d, %d)", ssaa, subsample);
+    USE_DEVICE(p->ctx);
+    RenderArgs a;
+    fill_args(p, a);
+    a.w = width; a.h = height; a.wr = width*ssaa; a.hr = height*ssaa; a.subsample = subsample;
+    a.out = device_out; a.out_frame_stride = (long)width*height*3;
+    a.dyn = t->d_dyn; a.frame0 = frame0;
+    // iSpectrogram: width 1 (length=0 scenes), height bins, RG32F (spectrogram.py:298-311); the bound texture's
+    // sampler state is kept, only its storage is redirected to the tape column of the frame
+    a.tape_spectrogram = t->d_columns; a.spectrogram_stride = t->n;
+    if (!a.tex[TEX_SPECTROGRAM].data) {
+        Tex& s = a.tex[TEX_SPECTROGRAM];
+        s.width = 1; s.height = t->plan->bins; s.components = t->plan->channels; s.dtype = DT_F32; s.filter = FILTER_NEAREST; s.repeat_x = 1; s.repeat_y = 0;
+    }
+    if (a.tex[TEX_SPECTROGRAM].width != 1 || a.tex[TEX_SPECTROGRAM].height != t->plan->bins || a.tex[TEX_SPECTROGRAM].components != t->plan->channels)
+        return fail(SFX_E_UNSUPPORTED, "tape rendering supports a 1-column iSpectrogram (length=0); use the per-frame path for scrolling spectrograms");
+    if (t->desc.points > 0) {
+        a.tape_waveform = t->d_rows; a.waveform_stride = (long)t->desc.points*t->audio->channels;
+        if (!a.tex[TEX_WAVEFORM].data) {
+            Tex& w = a.tex[TEX_WAVEFORM];
+            w.width = t->desc.points; w.height = 1; w.components = t->audio->channels; w.dtype = DT_F32; w.filter = FILTER_LINEAR; w.repeat_x = 0; w.repeat_y = 0;
+        }
+    }
+    // placeholders so that texel() sees a non-null base before frame_view() redirects it
+    a.tex[TEX_SPECTROGRAM].data = t->d_columns;
+    if (t->desc.points > 0) a.tex[TEX_WAVEFORM].data = t->d_rows;
+    int rc = check_samplers(p->fragment, a);
+    if (rc) return rc;
+    if ((rc = launch_fused(p->fragment, a, ssaa, nframes, p->ctx->stream))) return rc;
+    return launch_status();
+}

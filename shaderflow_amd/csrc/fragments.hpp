@@ -1,0 +1,206 @@
+// fragments.hpp — the reference's fragment shaders restated as HIP device functions on glsl.hpp.
+// There is no GLSL compiler at run time: `shader.fragment = path|str` resolves through a registry
+// (capi: sfx_program_lookup) to one of these; anything unknown falls back to `missing`, which is what
+// the reference does on a compile error (shader.py:323-340).
+//
+// `out vec4 fragColor` starts as vec4(0).
+#pragma once
+
+#include "glsl.hpp"
+
+namespace sf {
+
+enum : int {
+    FRAG_DEFAULT = 0,       // resources/shaders/fragment/default.glsl:1-48
+    FRAG_MISSING = 1,       // resources/shaders/fragment/missing.glsl:4-22
+    FRAG_VISUALIZER = 2,    // examples/basic/shaders/visualizer.frag:6-74
+    FRAG_BARS = 3,          // examples/basic/shaders/bars.frag:5-22
+    FRAG_WAVEFORM = 4,      // examples/basic/shaders/waveform.frag:5-19
+    FRAG_MULTI_CHILD = 5,   // examples/basic/demo.py:74-79
+    FRAG_MULTI_MAIN = 6,    // examples/basic/demo.py:83-89
+    FRAG_SHADERTOY = 7,     // examples/basic/shaders/shadertoy.frag:62-66
+    FRAG_DYNAMICS = 8,      // examples/basic/demo.py:121-126
+    FRAG_AUDIO = 9,         // examples/basic/demo.py:149-153
+    FRAG_COUNT = 10,
+};
+
+// ---- default.glsl ----------------------------------------------------------------------------------
+SF_HD vec3 default_grid(vec2 uv, float grid) {
+    if (sf::mod(::floorf(uv.x*grid/2.0f) + ::floorf(uv.y*grid/2.0f), 2.0f) > 0.5f) return {0.22f, 0.22f, 0.22f};
+    return {0.20f, 0.20f, 0.20f};
+}
+SF_HD vec4 frag_default(const Frag& f) {
+    const Uniforms& u = *f.u;
+    Camera cam = get_camera(f);
+    vec4 col = {0.0f, 0.0f, 0.0f, 0.0f};
+    vec2 uv = cam.gluv;
+    if (cam.out_of_bounds) return {0.15f, 0.15f, 0.15f, 1.0f};
+    float angle = sf::atan2(uv.y, uv.x);
+    vec3 color = hsv2rgb(angle + (2.0f*TAU*u.iTau) - (PI/4.0f), 1.0f, 1.0f) + 0.3f;
+    float circle = (1.333f*length(uv) - 1.0f);
+    float width = 2.0f*sf::abs(1.0f/(circle*circle))*1e-4f;
+    if (circle < 0.0f) set_rgb(col, rgb(col) + 0.18f);
+    else set_rgb(col, rgb(col) + default_grid(uv, 8.0f));
+    set_rgb(col, rgb(col) + (width*color));
+    col.w = 1.0f;
+    vec2 away = f.astuv*vec2{1.0f - f.astuv.y, 1.0f - f.astuv.x};
+    float linear = 50.0f*(away.x*away.y);
+    set_rgb(col, rgb(col)*sf::clamp(sf::pow(linear, 0.1f), 0.0f, 1.0f));
+    return col;
+}
+
+// ---- missing.glsl ----------------------------------------------------------------------------------
+SF_HD vec4 frag_missing(const Frag& f) {
+    vec4 col = {0.0f, 0.0f, 0.0f, 0.0f};
+    vec2 uv = f.stuv + vec2{f.u->iTime, f.u->iTime}/64.0f;
+    const float size = 8.0f;
+    for (int x = -5; x < 5; x++) {
+        for (int y = -5; y < 5; y++) {
+            vec2 block = {::floorf(size*uv.x), ::floorf(size*uv.y)};
+            if (sf::mod(block.x + block.y, 2.0f) == 0.0f) {
+                col.x += 1.0f/25.0f; col.y += 0.0f/25.0f; col.z += 1.0f/25.0f;
+            }
+        }
+    }
+    col.w = 0.2f;
+    return col;
+}
+
+// ---- visualizer.frag ---------------------------------------------------------------------------------
+// The radial blur (:21-33) is factored out so that the LDS-tiled kernel can substitute its own
+// evaluation of the same sum; everything before and after it is shared.
+struct VisualizerPre {
+    vec2 uv, bg;            // iCamera.gluv, background_uv
+    float intensity;
+    bool out_of_bounds;
+};
+
+SF_HD VisualizerPre visualizer_pre(const Frag& f) {
+    const Uniforms& u = *f.u;
+    Camera cam = get_camera(f);
+    VisualizerPre p;
+    p.uv = cam.gluv;
+    p.out_of_bounds = cam.out_of_bounds;
+    p.bg = zoom(gluv2stuv(p.uv), 0.95f + 0.01f*sf::sin(u.iTime) - 0.02f*u.iAudioVolume - 0.03f, vec2{0.5f, 0.5f});   // :17
+    p.bg = p.bg + 0.005f*vec2{sf::cos(u.iTime*3.25135f), sf::sin(u.iTime*1.153469f)};                                  // :18
+    p.intensity = 0.01f*sf::clamp(sf::pow(u.iAudioVolume, 2.5f), 0.0f, 0.3f);                                         // :22
+    return p;
+}
+
+// :19-33 as written: centre tap + 9 directions x 10 steps (the float loop counters are binary32)
+SF_HD vec4 visualizer_blur_reference(const Frag& f, const VisualizerPre& p) {
+    const Tex& background = f.tex[TEX_BACKGROUND];
+    vec4 color = stexture(background, p.bg);
+    const float quality = 10.0f, directions = 8.0f;
+    for (float angle = 0.0f; angle < TAU; angle += TAU/directions) {
+        for (float walk = 1.0f/quality; walk <= 1.001f; walk += 1.0f/quality) {
+            vec2 displacement = vec2{sf::cos(angle), sf::sin(angle)}*walk*p.intensity;
+            color = color + stexture(background, p.bg + displacement);
+        }
+    }
+    return color/(quality*directions);
+}
+
+SF_HD vec4 visualizer_post(const Frag& f, const VisualizerPre& p, vec4 col) {
+    const Uniforms& u = *f.u;
+    const vec3 space = vec3{1.0f, 11.0f, 26.0f}/255.0f;                                        // :9
+    col = col*(1.0f + 5.0f*u.iAudioSTD*sf::pow(sf::clamp(length(f.agluv) - 0.3f, 0.0f, 1.0f), 6.0f));   // :36
+
+    vec2 music_uv = rotate2d_apply(-PI/2.0f, p.uv);                                            // :39
+    music_uv = music_uv*(1.0f - 0.4f*sf::pow(sf::abs(u.iAudioVolume), 0.5f));                  // :40
+    const float radius = 0.17f;
+
+    float circle = sf::abs(atan1n(music_uv));                                                  // :44
+    vec4 s = texture(f.tex[TEX_SPECTROGRAM], vec2{0.0f, circle});
+    vec2 freq = {sf::sqrt(s.x/1000.0f), sf::sqrt(s.y/1000.0f)};                               // :45
+    freq = freq*(0.05f + 3.0f*sf::smoothstep(0.0f, 2.0f, circle));                            // :46
+
+    float len = length(music_uv);
+    if (len < radius) {                                                                        // :49-50
+        set_rgb(col, rgb(col)*0.5f);
+    } else {
+        float bar = (music_uv.y < 0.0f) ? freq.x : freq.y;                                     // :52
+        float r = radius + 0.5f*bar;
+        if (len < r) {
+            set_rgb(col, mix(rgb(col), vec3{1.0f, 1.0f, 1.0f}, sf::smoothstep(0.0f, 1.0f, 0.5f + bar)));   // :56
+        } else {
+            set_rgb(col, rgb(col)*sf::pow((len - r)*0.5f, 0.05f));                             // :58
+        }
+    }
+    set_rgb(col, mix(rgb(col), space, sf::smoothstep(0.0f, 1.0f, length(p.uv)/20.0f)));       // :62
+
+    vec2 vig = f.astuv*vec2{1.0f - f.astuv.y, 1.0f - f.astuv.x};                               // :65
+    set_rgb(col, rgb(col)*sf::pow(vig.x*vig.y*20.0f, 0.1f + 0.15f*u.iAudioVolume));            // :66
+    col.w = 1.0f;
+
+    vec4 w = texture(f.tex[TEX_WAVEFORM], vec2{f.astuv.x, 0.0f});                              // :71
+    vec2 wave = {0.2f*w.x, 0.2f*w.y};
+    if (1.0f - f.gluv.y < wave.x) col = col*0.8f;
+    if (1.0f + f.gluv.y < wave.y) col = col*0.8f;
+    return col;
+}
+
+SF_HD vec4 frag_visualizer(const Frag& f) {
+    VisualizerPre p = visualizer_pre(f);
+    if (p.out_of_bounds) {                                                                     // :11-14
+        const vec3 space = vec3{1.0f, 11.0f, 26.0f}/255.0f;
+        return {space.x, space.y, space.z, 0.0f};
+    }
+    return visualizer_post(f, p, visualizer_blur_reference(f, p));
+}
+
+// ---- bars.frag / waveform.frag ---------------------------------------------------------------------
+SF_HD vec4 frag_bars(const Frag& f) {
+    vec4 col = {0.0f, 0.0f, 0.0f, 0.0f};
+    vec4 s = texture(f.tex[TEX_SPECTROGRAM], vec2{f.astuv.y, f.astuv.x});
+    vec2 intensity = {sf::sqrt(s.x)/120.0f, sf::sqrt(s.y)/120.0f};
+    if (f.astuv.y < intensity.x) { col.x += 1.0f; col.y += 0.0f; col.z += 0.0f; }
+    if (f.astuv.y < intensity.y) { col.x += 0.0f; col.y += 1.0f; col.z += 0.0f; }
+    if (f.astuv.y < (intensity.y + intensity.x)/2.0f) { col.x += 0.0f; col.y += 0.0f; col.z += 1.0f; }
+    col.z += 0.4f*(intensity.x + intensity.y)*(1.0f - f.astuv.y);
+    col.w = 1.0f;
+    return col;
+}
+SF_HD vec4 frag_waveform(const Frag& f) {
+    vec4 w = texture(f.tex[TEX_WAVEFORM], vec2{f.astuv.x, 0.0f});
+    vec4 col = {0.2f, 0.2f, 0.2f, 1.0f};
+    float ay = sf::abs(f.gluv.y);
+    if (ay < w.x) col.x = 1.0f;
+    if (ay < w.y) col.y = 1.0f;
+    if (ay < (w.x + w.y)/2.0f) col.z = 1.0f;
+    return col;
+}
+
+// ---- small inline scenes of examples/basic/demo.py ---------------------------------------------------
+SF_HD vec4 frag_multi_child(const Frag& f) { return {0.0f, 1.0f - f.stuv.x, 0.0f, 1.0f}; }
+SF_HD vec4 frag_multi_main(const Frag& f) {
+    vec4 c = texture(f.tex[TEX_CHILD], f.astuv);
+    return {f.stuv.x + c.x, 0.0f + c.y, 0.0f + c.z, 1.0f};
+}
+SF_HD vec4 frag_shadertoy(const Frag& f) {
+    float t = f.u->iTime;
+    return {0.5f + 0.5f*sf::cos(t + f.stuv.x + 0.0f), 0.5f + 0.5f*sf::cos(t + f.stuv.y + 2.0f),
+            0.5f + 0.5f*sf::cos(t + f.stuv.x + 4.0f), 1.0f};
+}
+SF_HD vec4 frag_dynamics(const Frag& f) {
+    return stexture(f.tex[TEX_BACKGROUND], zoom(f.stuv, 0.85f + 0.1f*f.u->user[0], vec2{0.5f, 0.5f}));
+}
+SF_HD vec4 frag_audio(const Frag& f) {
+    float v = f.u->iAudioVolume;
+    return {v, v, v, 1.0f};
+}
+
+template <int FRAGMENT> SF_HD vec4 shade(const Frag& f) {
+    if constexpr (FRAGMENT == FRAG_DEFAULT) return frag_default(f);
+    else if constexpr (FRAGMENT == FRAG_VISUALIZER) return frag_visualizer(f);
+    else if constexpr (FRAGMENT == FRAG_BARS) return frag_bars(f);
+    else if constexpr (FRAGMENT == FRAG_WAVEFORM) return frag_waveform(f);
+    else if constexpr (FRAGMENT == FRAG_MULTI_CHILD) return frag_multi_child(f);
+    else if constexpr (FRAGMENT == FRAG_MULTI_MAIN) return frag_multi_main(f);
+    else if constexpr (FRAGMENT == FRAG_SHADERTOY) return frag_shadertoy(f);
+    else if constexpr (FRAGMENT == FRAG_DYNAMICS) return frag_dynamics(f);
+    else if constexpr (FRAGMENT == FRAG_AUDIO) return frag_audio(f);
+    else return frag_missing(f);
+}
+
+}  // namespace sf

@@ -1,0 +1,285 @@
+// glsl.hpp — GLSL-semantics device header: vector types, the OpenGL 3.3 sampler, the varyings of the
+// reference's vertex stage and the subset of its prelude the in-scope fragments use.
+//
+// Follows (file:line in the reference): resources/shaders/vertex/default.glsl:1-17,
+// resources/shaders/include/shaderflow.glsl (coords :91-99, textures :165-204, zoom :361-367,
+// atan :378-392, hsv2rgb :406-425, rotate :75-83), resources/shaders/include/camera.glsl:53-155,
+// texture.py:274-283 (sampler state) and OpenGL 3.3 core §3.8.8-3.8.9 / §2.1.6.
+//
+// Evaluation rules (shared with the parity oracle, written independently there): binary32, left to
+// right, no contraction; bilinear weights applied as fma(w11,t11, fma(w01,t01, fma(w10,t10, w00*t00)));
+// unorm8 texel = c/255.0f; colour write = clamp (NaN→0), *255, round half to even.
+#pragma once
+
+#include "sfmath.hpp"
+
+namespace sf {
+
+struct vec2 { float x, y; };
+struct vec3 { float x, y, z; };
+struct vec4 { float x, y, z, w; };
+
+SF_HD vec2 operator+(vec2 a, vec2 b) { return {a.x + b.x, a.y + b.y}; }
+SF_HD vec2 operator-(vec2 a, vec2 b) { return {a.x - b.x, a.y - b.y}; }
+SF_HD vec2 operator*(vec2 a, vec2 b) { return {a.x*b.x, a.y*b.y}; }
+SF_HD vec2 operator/(vec2 a, vec2 b) { return {a.x/b.x, a.y/b.y}; }
+SF_HD vec2 operator+(vec2 a, float s) { return {a.x + s, a.y + s}; }
+SF_HD vec2 operator-(vec2 a, float s) { return {a.x - s, a.y - s}; }
+SF_HD vec2 operator*(vec2 a, float s) { return {a.x*s, a.y*s}; }
+SF_HD vec2 operator*(float s, vec2 a) { return {s*a.x, s*a.y}; }
+SF_HD vec2 operator/(vec2 a, float s) { return {a.x/s, a.y/s}; }
+SF_HD vec3 operator+(vec3 a, vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+SF_HD vec3 operator-(vec3 a, vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+SF_HD vec3 operator*(vec3 a, float s) { return {a.x*s, a.y*s, a.z*s}; }
+SF_HD vec3 operator*(float s, vec3 a) { return {s*a.x, s*a.y, s*a.z}; }
+SF_HD vec3 operator+(vec3 a, float s) { return {a.x + s, a.y + s, a.z + s}; }
+SF_HD vec3 operator/(vec3 a, float s) { return {a.x/s, a.y/s, a.z/s}; }
+SF_HD vec4 operator+(vec4 a, vec4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+SF_HD vec4 operator*(vec4 a, float s) { return {a.x*s, a.y*s, a.z*s, a.w*s}; }
+SF_HD vec4 operator/(vec4 a, float s) { return {a.x/s, a.y/s, a.z/s, a.w/s}; }
+SF_HD float dot(vec3 a, vec3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }
+SF_HD float length(vec2 a) { return sf::sqrt(a.x*a.x + a.y*a.y); }
+SF_HD vec3 mix(vec3 a, vec3 b, float t) { return {sf::mix(a.x, b.x, t), sf::mix(a.y, b.y, t), sf::mix(a.z, b.z, t)}; }
+SF_HD vec3 cross(vec3 a, vec3 b) { return {a.y*b.z - b.y*a.z, a.z*b.x - b.z*a.x, a.x*b.y - b.x*a.y}; }
+SF_HD vec3 rgb(vec4 c) { return {c.x, c.y, c.z}; }
+SF_HD void set_rgb(vec4& c, vec3 v) { c.x = v.x; c.y = v.y; c.z = v.z; }
+
+// ---- textures ----------------------------------------------------------------------------------
+
+enum : int { DT_U8 = 0, DT_F32 = 1, DT_U16 = 2, DT_F16 = 3 };
+enum : int { FILTER_NEAREST = 0, FILTER_LINEAR = 1 };
+
+struct Tex {                       // one TextureBox of texture.py:56-70, rows bottom-up, tightly packed
+    const void* data;
+    int width, height, components, dtype, filter, repeat_x, repeat_y;
+};
+
+SF_HD int wrap_texel(int i, int size, int repeat) {
+    if (repeat) { int m = i % size; return (m < 0) ? m + size : m; }
+    return (i < 0) ? 0 : ((i >= size) ? size - 1 : i);
+}
+
+SF_HD vec4 texel(const Tex& t, int i, int j) {
+    // written without a local array: a dynamically indexed float[4] would be promoted to LDS
+    vec4 c = {0.0f, 0.0f, 0.0f, 1.0f};
+    const long base = ((long)j*t.width + i)*t.components;
+    const int n = t.components;
+    if (t.dtype == DT_U8) {
+        const uint8_t* p = (const uint8_t*)t.data + base;
+        c.x = (float)p[0]/255.0f;
+        if (n > 1) c.y = (float)p[1]/255.0f;
+        if (n > 2) c.z = (float)p[2]/255.0f;
+        if (n > 3) c.w = (float)p[3]/255.0f;
+    } else if (t.dtype == DT_F32) {
+        const float* p = (const float*)t.data + base;
+        c.x = p[0];
+        if (n > 1) c.y = p[1];
+        if (n > 2) c.z = p[2];
+        if (n > 3) c.w = p[3];
+    } else if (t.dtype == DT_U16) {
+        const uint16_t* p = (const uint16_t*)t.data + base;
+        c.x = (float)p[0]/65535.0f;
+        if (n > 1) c.y = (float)p[1]/65535.0f;
+        if (n > 2) c.z = (float)p[2]/65535.0f;
+        if (n > 3) c.w = (float)p[3]/65535.0f;
+    }
+    return c;
+}
+
+SF_HD float bilerp(float w00, float w10, float w01, float w11, float t00, float t10, float t01, float t11) {
+    return fmaf(w11, t11, fmaf(w01, t01, fmaf(w10, t10, w00*t00)));
+}
+
+SF_HD vec4 texture(const Tex& t, vec2 uv) {       // GLSL texture(sampler2D, vec2), level 0
+    float u = uv.x*(float)t.width;
+    float v = uv.y*(float)t.height;
+    if (t.filter == FILTER_NEAREST) {
+        int i = wrap_texel((int)::floorf(u), t.width, t.repeat_x);
+        int j = wrap_texel((int)::floorf(v), t.height, t.repeat_y);
+        return texel(t, i, j);
+    }
+    float ub = u - 0.5f, vb = v - 0.5f;
+    float fu = ::floorf(ub), fv = ::floorf(vb);
+    float a = ub - fu, b = vb - fv;
+    int i0 = wrap_texel((int)fu, t.width, t.repeat_x), i1 = wrap_texel((int)fu + 1, t.width, t.repeat_x);
+    int j0 = wrap_texel((int)fv, t.height, t.repeat_y), j1 = wrap_texel((int)fv + 1, t.height, t.repeat_y);
+    vec4 t00 = texel(t, i0, j0), t10 = texel(t, i1, j0), t01 = texel(t, i0, j1), t11 = texel(t, i1, j1);
+    float na = 1.0f - a, nb = 1.0f - b;
+    float w00 = na*nb, w10 = a*nb, w01 = na*b, w11 = a*b;
+    return {bilerp(w00, w10, w01, w11, t00.x, t10.x, t01.x, t11.x),
+            bilerp(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y),
+            bilerp(w00, w10, w01, w11, t00.z, t10.z, t01.z, t11.z),
+            bilerp(w00, w10, w01, w11, t00.w, t10.w, t01.w, t11.w)};
+}
+
+SF_HD uint32_t unorm8(float c) {
+    c = (c > 0.0f) ? c : 0.0f;
+    c = (c < 1.0f) ? c : 1.0f;
+    return (uint32_t)::rintf(c*255.0f);
+}
+SF_HD uint32_t pack_rgba8(vec4 c) { return unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (unorm8(c.w) << 24); }
+
+// ---- uniforms ----------------------------------------------------------------------------------
+// scene.py:687-703, camera.py:196-201 (+ its ShaderDynamics :147-185), audio/module.py:413-421,
+// spectrogram.py:313-320, waveform.py:89-90. Host fills it by name (capi: sfx_uniform_set).
+
+struct Uniforms {
+    float iTime, iTau, iDuration, iDeltatime;
+    float iResolution[2];
+    float iWantAspect, iQuality, iSSAA, iFramerate;
+    int iFrame, iRealtime, iLayer, iSubsample;
+    float iMouse[2];
+    int iMouseInside, iMouse1, iMouse2;
+    int iCameraMode, iCameraProjection;
+    float iCameraRight[3], iCameraUpward[3], iCameraForward[3];
+    float iCameraPosition[3], iCameraZenith[3];
+    float iCameraSeparation, iCameraZoom, iCameraIsometric, iCameraFocalLength, iCameraOrbital, iCameraDolly;
+    float iAudioVolume, iAudioVolumeIntegral, iAudioSTD;
+    int iSpectrogramLength, iSpectrogramBins, iSpectrogramSmooth, iSpectrogramScroll;
+    float iSpectrogramOffset, iSpectrogramMin, iSpectrogramMax;
+    int iWaveformLength;
+    float user[16];
+};
+
+enum : int { TEX_BACKGROUND = 0, TEX_SPECTROGRAM = 1, TEX_WAVEFORM = 2, TEX_CHILD = 3, TEX_SLOTS = 4 };
+
+// Per-frame values that live on the device in tape (batched export) mode; written by the dynamics scan
+struct FrameDyn {
+    float iTime, iTau, iAudioVolume, iAudioVolumeIntegral, iAudioSTD, iSpectrogramOffset;
+    int iFrame, pad;
+};
+
+// ---- varyings (vertex/default.glsl:1-17) ---------------------------------------------------------
+
+struct Frag {
+    const Uniforms* u;
+    const Tex* tex;
+    vec2 agluv, gluv, astuv, stuv, stxy, glxy, fragCoord;
+    float aspect;                                  // iAspectRatio, shaderflow.glsl:16
+};
+
+SF_HD vec2 gluv2stuv(vec2 g) { return (g + 1.0f)/2.0f; }          // shaderflow.glsl:95
+SF_HD vec2 stuv2gluv(vec2 s) { return (s*2.0f) - 1.0f; }          // shaderflow.glsl:91
+
+SF_HD void make_varyings(Frag& f, int i, int j, int wr, int hr) {
+    const Uniforms& u = *f.u;
+    vec2 res = {u.iResolution[0], u.iResolution[1]};
+    f.aspect = res.x/res.y;
+    vec2 centre = {((float)i + 0.5f)/(float)wr, ((float)j + 0.5f)/(float)hr};
+    f.agluv = centre*2.0f - 1.0f;
+    f.gluv = f.agluv*vec2{f.aspect, 1.0f};                         // agluv2gluv, shaderflow.glsl:99
+    f.astuv = gluv2stuv(f.agluv);
+    f.stuv = gluv2stuv(f.gluv);
+    f.stxy = (res*f.astuv) + 1.0f;
+    f.glxy = f.stxy - res/2.0f;
+    f.fragCoord = f.stxy;
+}
+
+// ---- prelude subset ------------------------------------------------------------------------------
+
+SF_HD vec2 rotate2d_apply(float angle, vec2 p) {                   // mat2(c,-s,s,c)*p, shaderflow.glsl:75-77
+    float c = sf::cos(angle), s = sf::sin(angle);
+    return {c*p.x + s*p.y, (-s)*p.x + c*p.y};
+}
+SF_HD vec2 zoom(vec2 uv, float z, vec2 anchor) { return (uv - anchor)*(z*z) + anchor; }   // :361-363
+SF_HD vec4 gtexture(const Tex& t, vec2 gluv) {                     // :165-169
+    vec2 scale = {(float)t.height/(float)t.width, 1.0f};
+    return texture(t, gluv2stuv(gluv*scale));
+}
+SF_HD vec4 stexture(const Tex& t, vec2 stuv) { return gtexture(t, stuv2gluv(stuv)); }     // :198-200
+SF_HD float atan1n(vec2 p) { return sf::atan(p.y, p.x)/PI; }                               // :378-380
+SF_HD float atan2(float y, float x) {                                                     // :382-388
+    if (y < 0.0f) return TAU - sf::atan(-y, x);
+    return sf::atan(y, x);
+}
+SF_HD vec3 hsv2rgb(float h, float s, float v) {                                            // :406-425
+    h = sf::mod(h, TAU);
+    float c = v*s;
+    float x = c*(1.0f - sf::abs(sf::mod(h/(PI/3.0f), 2.0f) - 1.0f));
+    float m = v - c;
+    vec3 rgb;
+    switch ((int)::floorf(6.0f*(h/(2.0f*PI)))) {
+        case 0: rgb = {c, x, 0.0f}; break;
+        case 1: rgb = {x, c, 0.0f}; break;
+        case 2: rgb = {0.0f, c, x}; break;
+        case 3: rgb = {0.0f, x, c}; break;
+        case 4: rgb = {x, 0.0f, c}; break;
+        case 5: rgb = {c, 0.0f, x}; break;
+        default: rgb = {0.0f, 0.0f, 0.0f};
+    }
+    return rgb + m;
+}
+SF_HD vec3 rotate3d(vec3 v, vec3 axis, float angle) {                                      // :81-83
+    float c = sf::cos(angle), s = sf::sin(angle);
+    return mix(dot(axis, v)*axis, v, c) + cross(axis, v)*s;
+}
+
+// ---- camera (camera.glsl) ------------------------------------------------------------------------
+
+struct Camera {
+    vec3 position, up, right, forward, backward, origin, target;
+    float orbital, dolly, separation, focal_length, isometric, zoom;
+    vec2 gluv, agluv, stuv, astuv, glxy, stxy;
+    bool out_of_bounds;
+};
+
+SF_HD vec3 camera_rectangle(const Camera& c, vec2 g, float size) { return size*(g.x*c.right + g.y*c.up); }   // :54-56
+SF_HD vec3 camera_ray_origin(const Camera& c, vec2 g) {                                                      // :58-63
+    return c.position + camera_rectangle(c, g, c.zoom*c.isometric) + (c.backward*c.orbital) + (c.backward*c.dolly);
+}
+SF_HD vec3 camera_ray_target(const Camera& c, vec2 g) {                                                      // :65-70
+    return c.position + camera_rectangle(c, g, c.zoom) + (c.backward*c.orbital) + (c.forward*c.focal_length);
+}
+
+SF_HD Camera get_camera(const Frag& f) {                           // GetCamera :132-155 → CameraProject :93-130
+    const Uniforms& u = *f.u;
+    Camera c;
+    const vec3 plane_point = {0.0f, 0.0f, 1.0f}, plane_normal = {0.0f, 0.0f, 1.0f};
+    c.position = {u.iCameraPosition[0], u.iCameraPosition[1], u.iCameraPosition[2]};
+    c.orbital = u.iCameraOrbital;
+    c.dolly = u.iCameraDolly;
+    c.up = {u.iCameraUpward[0], u.iCameraUpward[1], u.iCameraUpward[2]};
+    c.right = {u.iCameraRight[0], u.iCameraRight[1], u.iCameraRight[2]};
+    c.forward = {u.iCameraForward[0], u.iCameraForward[1], u.iCameraForward[2]};
+    c.backward = c.forward*(-1.0f);
+    c.isometric = u.iCameraIsometric;
+    c.focal_length = u.iCameraFocalLength;
+    c.zoom = u.iCameraZoom;
+    c.separation = u.iCameraSeparation;
+
+    if (u.iCameraProjection == 0) {                                // perspective
+        c.origin = camera_ray_origin(c, f.gluv);
+        c.target = camera_ray_target(c, f.gluv);
+    } else if (u.iCameraProjection == 1) {                         // stereoscopic
+        float side = sf::sign(f.agluv.x);
+        vec2 g = f.gluv - side*vec2{f.aspect/2.0f, 0.0f};
+        c.position = c.position + (side*c.separation)*c.right;
+        c.origin = camera_ray_origin(c, g);
+        c.target = camera_ray_target(c, g);
+    } else {                                                       // equirectangular
+        float inclination = c.zoom*(PI*f.agluv.y/2.0f);
+        float azimuth = c.zoom*(PI*f.agluv.x/1.0f);
+        vec3 target = c.forward;
+        target = rotate3d(target, c.right, -inclination);
+        target = rotate3d(target, c.up, azimuth);
+        c.origin = c.position;
+        c.target = c.position + target;
+    }
+
+    // CameraRay2D :73-91
+    float num = dot(plane_point - c.origin, plane_normal);
+    float den = dot(c.target - c.origin, plane_normal);
+    float t = num/den;
+    c.out_of_bounds = (t < 0.0f) || (sf::abs(f.gluv.x) > u.iWantAspect);
+    vec3 hit = c.origin + ((c.target - c.origin)*t);
+    vec2 res = {u.iResolution[0], u.iResolution[1]};
+    c.gluv = {hit.x, hit.y};
+    c.agluv = c.gluv/vec2{f.aspect, 1.0f};
+    c.stuv = (c.gluv + 1.0f)/2.0f;
+    c.astuv = (c.agluv + 1.0f)/2.0f;
+    c.stxy = res*c.astuv;
+    c.glxy = c.stxy - res/2.0f;
+    return c;
+}
+
+}  // namespace sf

@@ -1,0 +1,271 @@
+// render_kernels.hpp — gfx950 kernels for the pixel half of the path:
+//   K6  k_render<F>            one thread per target pixel, RGBA8/float target   (shader.py:388-405)
+//   K8  k_resolve              final.glsl as its own pass                        (fragment/final.glsl:1-33)
+//   K6+K8 k_render_resolve<F,S> shade S x S supersamples in the lanes of a quad, quantise each to the
+//                              iScreen RGBA8 value, resolve with DPP lane exchanges, write RGB8 only
+//   K7  the sampler lives in glsl.hpp (generic) and in BlurTile below (LDS-staged background tile)
+//   K9  k_pack_rows            flips / packs a finished frame for the encoder hand-off
+//
+// Launch geometry: every block of the fused kernel owns 128 consecutive output pixels of one row, so
+// it writes 384 contiguous, 128-byte aligned bytes of the RGB8 frame (whole cache lines from a single
+// XCD's L2); blocks are numbered so that the eight XCDs (block b runs on XCD b % 8, observed) own
+// interleaved 8-row bands and neighbouring rows of background texels stay in the same 4 MiB L2.
+#pragma once
+
+#include "fragments.hpp"
+
+#include <hip/hip_fp16.h>
+
+namespace sf {
+
+struct RenderArgs {
+    Uniforms u;
+    Tex tex[TEX_SLOTS];
+    int wr, hr;                      // shaded resolution (scene.render_resolution, scene.py:372-375)
+    int w, h;                        // output resolution (fused kernels)
+    int subsample;                   // final.glsl kernel size
+    int out_components, out_dtype;   // unfused target format
+    void* out;
+    long out_frame_stride;           // bytes between consecutive frames of a batch (grid.z)
+    // tape (batched export) mode: per-frame uniforms and audio textures come from device memory
+    const FrameDyn* dyn;
+    const float* tape_spectrogram; long spectrogram_stride;   // floats per frame
+    const float* tape_waveform; long waveform_stride;
+    int frame0;
+    // radial-blur tap table of visualizer.frag:26-31 (unit displacements cos/sin(angle)*walk)
+    float tap_x[81], tap_y[81];
+};
+
+__device__ __forceinline__ void frame_view(const RenderArgs& a, int frame, Uniforms& u, Tex* tex) {
+    u = a.u;
+    for (int k = 0; k < TEX_SLOTS; k++) tex[k] = a.tex[k];
+    if (a.dyn) {
+        const FrameDyn d = a.dyn[a.frame0 + frame];
+        u.iTime = d.iTime; u.iTau = d.iTau; u.iFrame = d.iFrame;
+        u.iAudioVolume = d.iAudioVolume; u.iAudioVolumeIntegral = d.iAudioVolumeIntegral; u.iAudioSTD = d.iAudioSTD;
+        u.iSpectrogramOffset = d.iSpectrogramOffset;
+    }
+    if (a.tape_spectrogram) tex[TEX_SPECTROGRAM].data = a.tape_spectrogram + (long)(a.frame0 + frame)*a.spectrogram_stride;
+    if (a.tape_waveform) tex[TEX_WAVEFORM].data = a.tape_waveform + (long)(a.frame0 + frame)*a.waveform_stride;
+}
+
+__device__ __forceinline__ void store_target(const RenderArgs& a, long frame, int i, int j, vec4 c) {
+    char* base = (char*)a.out + frame*a.out_frame_stride;
+    const long pix = (long)j*a.wr + i;
+    const int n = a.out_components;
+    if (a.out_dtype == DT_U8) {
+        if (n == 4) { ((uint32_t*)base)[pix] = pack_rgba8(c); return; }
+        uint8_t* p = (uint8_t*)base + pix*n;
+        p[0] = (uint8_t)unorm8(c.x);
+        if (n > 1) p[1] = (uint8_t)unorm8(c.y);
+        if (n > 2) p[2] = (uint8_t)unorm8(c.z);
+    } else {
+        float* p = (float*)base + pix*n;
+        p[0] = c.x;
+        if (n > 1) p[1] = c.y;
+        if (n > 2) p[2] = c.z;
+        if (n > 3) p[3] = c.w;
+    }
+}
+
+
+// ---- shader policies -------------------------------------------------------------------------------------
+// A kernel shades its supersamples in two passes around one block-cooperative step: pre() per sample,
+// setup() once per block (may stage LDS and synchronise), run() per sample.
+template <int FRAGMENT> struct PlainShader {
+    struct State {};
+    struct Shared {};
+    __device__ static void pre(const RenderArgs&, const Frag&, bool, State&) {}
+    template <int N> __device__ static void setup(const RenderArgs&, const Tex*, State (&)[N], const bool (&)[N], Shared&) {}
+    __device__ static vec4 run(const RenderArgs&, const Frag& f, const State&, const Shared&) { return shade<FRAGMENT>(f); }
+};
+
+// ---- K6: generic unfused render --------------------------------------------------------------------
+template <class SHADER>
+__global__ __launch_bounds__(256) void k_render(const RenderArgs a) {
+    __shared__ typename SHADER::Shared shared;
+    const int i = blockIdx.x*64 + threadIdx.x;
+    const int j = blockIdx.y*4 + threadIdx.y;
+    Uniforms u; Tex tex[TEX_SLOTS];
+    frame_view(a, blockIdx.z, u, tex);
+    const bool inside = (i < a.wr) && (j < a.hr);
+    Frag f; f.u = &u; f.tex = tex;
+    make_varyings(f, i, j, a.wr, a.hr);
+    typename SHADER::State state[1];
+    const bool valid[1] = {inside};
+    SHADER::pre(a, f, inside, state[0]);
+    SHADER::template setup<1>(a, tex, state, valid, shared);
+    if (inside) store_target(a, blockIdx.z, i, j, SHADER::run(a, f, state[0], shared));
+}
+
+// ---- K8: final.glsl as a pass ------------------------------------------------------------------------
+struct ResolveArgs {
+    Tex screen;                      // RGBA8, linear, clamp (scene.py:192-194)
+    int w, h, subsample;
+    uint8_t* out;                    // RGB8 rows bottom-up
+};
+
+__device__ __forceinline__ vec3 final_glsl(const Tex& screen, vec2 astuv, vec2 resolution, int kernel) {
+    if (kernel == 1) return rgb(texture(screen, astuv));                                     // :6-10
+    vec3 accumulator = {0.0f, 0.0f, 0.0f};
+    vec2 pixel_size = vec2{1.0f, 1.0f}/resolution;                                           // :17
+    vec2 corner = astuv - (pixel_size/2.0f);                                                 // :20
+    vec2 origin = corner + (pixel_size/(float)kernel)/2.0f;                                  // :21
+    for (int x = 0; x < kernel; x++) {
+        for (int y = 0; y < kernel; y++) {
+            vec2 offset = (pixel_size/(float)kernel)*vec2{(float)x, (float)y};               // :25
+            accumulator = accumulator + rgb(texture(screen, origin + offset));               // :26
+        }
+    }
+    return accumulator/(float)(kernel*kernel);                                               // :31
+}
+
+__global__ __launch_bounds__(256) void k_resolve(const ResolveArgs a) {
+    const int i = blockIdx.x*64 + threadIdx.x;
+    const int j = blockIdx.y*4 + threadIdx.y;
+    if (i >= a.w || j >= a.h) return;
+    vec2 centre = {((float)i + 0.5f)/(float)a.w, ((float)j + 0.5f)/(float)a.h};
+    vec2 astuv = gluv2stuv(centre*2.0f - 1.0f);
+    vec3 c = final_glsl(a.screen, astuv, vec2{(float)a.w, (float)a.h}, a.subsample);
+    uint8_t* p = a.out + ((long)j*a.w + i)*3;
+    p[0] = (uint8_t)unorm8(c.x); p[1] = (uint8_t)unorm8(c.y); p[2] = (uint8_t)unorm8(c.z);
+}
+
+// ---- DPP helpers ---------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+// quad_perm broadcasts: every lane of a quad reads lane q of its quad
+__device__ __forceinline__ uint32_t quad_lane0(uint32_t v) { return dpp_u32<0x00>(v); }
+__device__ __forceinline__ uint32_t quad_lane1(uint32_t v) { return dpp_u32<0x55>(v); }
+__device__ __forceinline__ uint32_t quad_lane2(uint32_t v) { return dpp_u32<0xAA>(v); }
+__device__ __forceinline__ uint32_t quad_lane3(uint32_t v) { return dpp_u32<0xFF>(v); }
+
+__device__ __forceinline__ vec3 unpack_rgb_unorm(uint32_t q) {
+    return {(float)(q & 255u)/255.0f, (float)((q >> 8) & 255u)/255.0f, (float)((q >> 16) & 255u)/255.0f};
+}
+
+// The iScreen texel a supersample becomes (RGBA8 unorm), then final.glsl over the S x S block of one
+// output pixel. q[] holds the block in texel order q[y*S + x]. Taps land on texel centres (S == k)
+// or on the centre of 2x2 texels (S == 2k); the reference's bilinear weights are then 1 or 1/4 up to
+// the rounding of the tap coordinate.
+template <int S>
+__device__ __forceinline__ vec3 resolve_block(const uint32_t* q, int kernel) {
+    vec3 acc = {0.0f, 0.0f, 0.0f};
+    if (kernel == S) {                               // taps on texel centres, x-major like :23-28
+        for (int x = 0; x < S; x++) for (int y = 0; y < S; y++) acc = acc + unpack_rgb_unorm(q[y*S + x]);
+        return acc/(float)(S*S);
+    }
+    const int g = S/kernel;                          // == 2: each tap is the mean of a 2x2 group
+    for (int x = 0; x < kernel; x++) {
+        for (int y = 0; y < kernel; y++) {
+            vec3 t00 = unpack_rgb_unorm(q[(y*g)*S + x*g]), t10 = unpack_rgb_unorm(q[(y*g)*S + x*g + 1]);
+            vec3 t01 = unpack_rgb_unorm(q[(y*g + 1)*S + x*g]), t11 = unpack_rgb_unorm(q[(y*g + 1)*S + x*g + 1]);
+            vec3 tap = {bilerp(0.25f, 0.25f, 0.25f, 0.25f, t00.x, t10.x, t01.x, t11.x),
+                        bilerp(0.25f, 0.25f, 0.25f, 0.25f, t00.y, t10.y, t01.y, t11.y),
+                        bilerp(0.25f, 0.25f, 0.25f, 0.25f, t00.z, t10.z, t01.z, t11.z)};
+            acc = (kernel == 1) ? tap : acc + tap;
+        }
+    }
+    return (kernel == 1) ? acc : acc/(float)(kernel*kernel);
+}
+
+__host__ __device__ inline bool fused_supported(int s, int kernel) {
+    return (s == 1 && kernel == 1) || (s == 2 && (kernel == 2 || kernel == 1)) || (s == 4 && (kernel == 4 || kernel == 2));
+}
+
+// Row-band interleave: linear block id → (row, column-block) such that consecutive ids (which the
+// dispatcher spreads over the 8 XCDs) walk down 8 different 8-row bands while each XCD keeps to its own.
+__device__ __forceinline__ void fused_block_coords(int blocks_x, int h, int& bx, int& row) {
+    const int b = blockIdx.x;
+    bx = b % blocks_x;
+    row = b / blocks_x;
+    (void)h;
+}
+
+// Writes one row segment of 128 RGB8 pixels (384 B) staged in LDS with 16-byte stores
+__device__ __forceinline__ void store_rgb_row(uint8_t* out_row, int x0, int w, const uint8_t* staged, int tid, int nthreads) {
+    const int npix = (w - x0 < 128) ? (w - x0) : 128;
+    const int nbytes = npix*3;
+    uint8_t* dst = out_row + (long)x0*3;
+    if ((nbytes & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
+        for (int k = tid; k < nbytes/16; k += nthreads) ((uint4*)dst)[k] = ((const uint4*)staged)[k];
+    } else {
+        for (int k = tid; k < nbytes; k += nthreads) dst[k] = staged[k];
+    }
+}
+
+// ---- K6+K8 fused, generic fragment ----------------------------------------------------------------------
+// S == 1: one lane per output pixel (128 threads... we use 256 = 128 px x 2 rows).
+// S == 2: four lanes (a quad) per output pixel, one supersample each.
+// S == 4: a quad per output pixel, each lane owns a 2x2 group of supersamples.
+template <class SHADER, int S>
+__global__ __launch_bounds__(512) void k_render_resolve(const RenderArgs a) {
+    constexpr int LANES = (S == 1) ? 1 : 4;
+    constexpr int PER_LANE = (S*S)/LANES;            // 1, 1, 4
+    constexpr int G = (S == 4) ? 2 : 1;              // side of the group one lane owns
+    __shared__ __attribute__((aligned(16))) uint8_t staged[2][384];
+
+    Uniforms u; Tex tex[TEX_SLOTS];
+    frame_view(a, blockIdx.z, u, tex);
+    const int blocks_x = (a.w + 127)/128;
+    const int rows_per_block = (S == 1) ? 2 : 1;
+    const int bx = blockIdx.x % blocks_x, by = blockIdx.x / blocks_x;
+    const int tid = threadIdx.x;
+    const int p = tid / LANES, sub = tid % LANES;
+    const int prow = (S == 1) ? (p / 128) : 0;
+    const int px = bx*128 + (p % 128), py = by*rows_per_block + prow;
+    const bool inside = (px < a.w) && (py < a.h);
+
+    __shared__ typename SHADER::Shared shared;
+    uint32_t mine[PER_LANE];
+    typename SHADER::State state[PER_LANE];
+    bool valid[PER_LANE];
+    Frag f; f.u = &u; f.tex = tex;
+#pragma unroll
+    for (int n = 0; n < PER_LANE; n++) {
+        const int gx = (sub & 1)*G + (n % G), gy = (sub >> 1)*G + (n / G);      // position inside the S x S block
+        make_varyings(f, px*S + gx, py*S + gy, a.wr, a.hr);
+        valid[n] = inside;
+        SHADER::pre(a, f, inside, state[n]);
+    }
+    SHADER::template setup<PER_LANE>(a, tex, state, valid, shared);
+#pragma unroll
+    for (int n = 0; n < PER_LANE; n++) {
+        const int gx = (sub & 1)*G + (n % G), gy = (sub >> 1)*G + (n / G);
+        uint32_t q = 0;
+        if (inside) {
+            make_varyings(f, px*S + gx, py*S + gy, a.wr, a.hr);
+            q = pack_rgba8(SHADER::run(a, f, state[n], shared));
+        }
+        mine[n] = q;
+    }
+
+    uint32_t block[S*S];
+    if constexpr (S == 1) {
+        block[0] = mine[0];
+    } else {
+#pragma unroll
+        for (int n = 0; n < PER_LANE; n++) {
+            const uint32_t l0 = quad_lane0(mine[n]), l1 = quad_lane1(mine[n]), l2 = quad_lane2(mine[n]), l3 = quad_lane3(mine[n]);
+            const int ox = n % G, oy = n / G;
+            block[(0*G + oy)*S + 0*G + ox] = l0;     // lane sub: gx = (sub&1)*G + ox, gy = (sub>>1)*G + oy
+            block[(0*G + oy)*S + 1*G + ox] = l1;
+            block[(1*G + oy)*S + 0*G + ox] = l2;
+            block[(1*G + oy)*S + 1*G + ox] = l3;
+        }
+    }
+    if (inside && sub == 0) {
+        vec3 c = resolve_block<S>(block, a.subsample);
+        uint8_t* s = &staged[prow][(p % 128)*3];
+        s[0] = (uint8_t)unorm8(c.x); s[1] = (uint8_t)unorm8(c.y); s[2] = (uint8_t)unorm8(c.z);
+    }
+    __syncthreads();
+    uint8_t* frame = (uint8_t*)a.out + (long)blockIdx.z*a.out_frame_stride;
+    for (int r = 0; r < rows_per_block; r++) {
+        const int y = by*rows_per_block + r;
+        if (y < a.h) store_rgb_row(frame + (long)y*a.w*3, bx*128, a.w, staged[r], tid, blockDim.x);
+    }
+}
+
+}  // namespace sf

@@ -1,0 +1,177 @@
+"""
+ExportingHelper: frame counter, read-out ring and the encoder hand-off of an export.
+
+Host mirror of the reference's shaderflow/exporting.py:30-203. The reference reads the final FBO into one of N
+GL buffers (`fbo.read_into`) and lets turbopipe write it to ffmpeg's stdin from a worker thread; here the final
+RGB8 texture is copied to one of N PINNED host buffers on a copy stream (`sfx_ring_read_async`) and a native
+writer thread streams it to a file descriptor (`sfx_ring_pipe`), with the same reuse fence (`turbopipe.sync` →
+`sfx_ring_pipe_sync`). Frames leave exactly as the reference hands them to ffmpeg: rgb24, rows BOTTOM-UP
+(ffmpeg then applies `vflip`, exporting.py:94-103).
+
+Sinks: a path ending in .rgb/.raw (or any path when no `ffmpeg` binary exists) receives the raw frames;
+"pipe"/"-"/bytes returns them; with an `ffmpeg` binary on PATH other paths are encoded by the reference's
+command line (rawvideo rgb24 stdin, scale, vflip, libx264 crf 20 yuv420p; ffmpeg.py:149-205,1027-1068).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+import tempfile
+import time
+from pathlib import Path
+from typing import TYPE_CHECKING, Any, Callable, Optional
+
+import numpy as np
+from attrs import Factory, define
+
+from shaderflow_amd import _native as N
+from shaderflow_amd.module import logger
+
+if TYPE_CHECKING:
+    from shaderflow_amd.scene import ShaderScene
+
+
+@define(slots=False, eq=False)
+class ExportingHelper:
+    scene: "ShaderScene"
+
+    frame: int = 0
+    start: float = Factory(time.monotonic)
+    relay: Optional[Callable[[int, int], None]] = None
+    took: Optional[float] = None
+
+    # sink
+    kind: Optional[str] = None            # "path-raw", "path-ffmpeg", "pipe"
+    path: Optional[Path] = None
+    process: Optional[subprocess.Popen] = None
+    file: Any = None
+    fileno: Optional[int] = None
+    _sizes: tuple[int, int] = (0, 0)
+
+    # ring
+    ring: Optional[N.Handle] = None
+    slots: int = 0
+
+    @property
+    def total_frames(self) -> int:
+        return max(1, round(self.scene.runtime*self.scene.fps))
+
+    @property
+    def finished(self) -> bool:
+        return (self.frame >= self.total_frames)
+
+    def open_bar(self) -> None:
+        self.start = time.monotonic()
+
+    def update(self) -> None:
+        if self.relay:
+            self.relay(self.frame, self.total_frames)
+        self.frame += 1
+
+    # configuration --------------------------------------------------------------------------------------------
+
+    def ffmpeg_sizes(self, width: int, height: int) -> None:
+        self._sizes = (width, height)
+
+    def ffmpeg_output(self, output) -> None:
+        if (output in ("pipe", "-", bytes)):
+            self.kind = "pipe"
+            return
+        self.path = Path(output).expanduser().absolute()
+        self.path.parent.mkdir(parents=True, exist_ok=True)
+        raw = self.path.suffix.lower() in (".rgb", ".raw", ".rgb24")
+        self.kind = "path-raw" if (raw or not shutil.which("ffmpeg")) else "path-ffmpeg"
+        if self.kind == "path-raw" and not raw:
+            logger.warning(f"No ffmpeg binary on PATH: writing raw rgb24 frames (rows bottom-up) to {self.path}")
+
+    def ffhook(self) -> None:
+        pass
+
+    def ffmpeg_command(self) -> list[str]:
+        """The reference's encoder invocation for this export (exporting.py:94-103 + ffmpeg.py defaults)"""
+        w, h = self.scene.resolution
+        ow, oh = self._sizes if all(self._sizes) else (w, h)
+        return ["ffmpeg", "-hide_banner", "-loglevel", "error", "-y",
+                "-f", "rawvideo", "-pixel_format", "rgb24", "-video_size", f"{w}x{h}", "-framerate", f"{self.scene.fps}",
+                "-i", "-", "-vf", f"scale={ow}:{oh}:flags=lanczos,vflip", "-t", f"{self.scene.runtime}",
+                "-c:v", "libx264", "-preset", "slow", "-crf", "20", "-pix_fmt", "yuv420p", str(self.path)]
+
+    def popen(self) -> None:
+        if self.kind == "path-ffmpeg":
+            self.process = subprocess.Popen(self.ffmpeg_command(), stdin=subprocess.PIPE, stderr=subprocess.PIPE)
+            self.fileno = self.process.stdin.fileno()
+        elif self.kind == "path-raw":
+            self.file = open(self.path, "wb")
+            self.fileno = self.file.fileno()
+        elif self.kind == "pipe":
+            self.file = tempfile.TemporaryFile(mode="w+b")
+            self.fileno = self.file.fileno()
+
+    # buffers and piping ---------------------------------------------------------------------------------------
+
+    def make_buffers(self, n: int = 2) -> None:
+        self.release_buffers()
+        handle = N.Handle()
+        N.check(N.lib().sfx_ring_create(self.scene.context.handle, self.scene._final.texture.size_t, max(1, n), C.byref(handle)))
+        self.ring, self.slots = handle, max(1, n)
+
+    def release_buffers(self) -> None:
+        if self.ring is not None and self.ring.value:
+            N.check(N.lib().sfx_ring_pipe_sync(self.ring, -1))
+            N.lib().sfx_ring_destroy(self.ring)
+        self.ring, self.slots = None, 0
+
+    def _check_encoder(self) -> None:
+        if (self.process is not None) and (self.process.poll() is not None):
+            raise RuntimeError("FFmpeg process closed unexpectedly with traceback:\n"
+                               f"{self.process.stderr.read().decode('utf-8', 'replace')}")
+
+    def pipe(self, turbo: bool = False) -> None:
+        """Queue the frame that was just rendered (exporting.py:151-174)"""
+        if (self.fileno is None) or (self.ring is None):
+            return
+        self._check_encoder()
+        slot = self.frame % self.slots
+        N.check(N.lib().sfx_ring_read_async(self.ring, self.scene._final.texture.texture.handle, slot))
+        N.check(N.lib().sfx_ring_pipe(self.ring, slot, self.fileno))
+        if not turbo:
+            N.check(N.lib().sfx_ring_pipe_sync(self.ring, slot))
+
+    def pipe_device(self, device_ptr: int, turbo: bool = True) -> None:
+        """Same, for a frame that lives in a raw device buffer (frame tape batches)"""
+        if (self.fileno is None) or (self.ring is None):
+            return
+        self._check_encoder()
+        slot = self.frame % self.slots
+        N.check(N.lib().sfx_ring_read_device_async(self.ring, C.c_void_p(device_ptr), slot))
+        N.check(N.lib().sfx_ring_pipe(self.ring, slot, self.fileno))
+        if not turbo:
+            N.check(N.lib().sfx_ring_pipe_sync(self.ring, slot))
+
+    # finish ---------------------------------------------------------------------------------------------------------
+
+    def finish(self):
+        output = None
+        self.scene.context.synchronize()
+        self.release_buffers()
+        if self.kind == "path-ffmpeg":
+            self.process.stdin.close()
+            self.process.wait()
+            output = self.path
+        elif self.kind == "path-raw":
+            self.file.close()
+            output = self.path
+        elif self.kind == "pipe":
+            self.file.seek(0)
+            output = self.file.read()
+            self.file.close()
+        self.took = (time.monotonic() - self.start)
+        self.log_stats(output)
+        return output
+
+    def log_stats(self, output) -> None:
+        took = self.took or 1e-9
+        logger.info(f"Finished rendering ({output if not isinstance(output, bytes) else f'{len(output)} bytes'}) • "
+                    f"took {took:.2f}s at {self.frame/took:.2f} fps | {self.scene.runtime/took:.2f}x realtime, {self.frame} frames")

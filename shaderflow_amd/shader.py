@@ -1,0 +1,227 @@
+"""
+ShaderProgram: a fragment program that renders a fullscreen quad into its own ShaderTexture.
+
+Host mirror of the reference's shaderflow/shader.py:99-425. What moderngl/OpenGL did there is done here by
+libshaderflow_hip: `compile()` resolves the fragment source through the registry of fragments restated as HIP
+kernels (`sfx_program_lookup`; unknown sources get the `missing` kernel — the reference's compile-error fallback,
+shader.py:323-340), `use_pipeline()` pushes every Uniform by name and binds samplers, `render()` draws each
+layer (`sfx_render`) and rolls the temporal matrix. The scene's `iFinal` program (texture.final) is the SSAA
+resolve (shader.py:391-396): `sfx_resolve`, or fused with the main pass (`sfx_render_resolve`) when
+final.glsl's footprint stays inside the output pixel's own supersample block.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from collections.abc import Iterable
+from pathlib import Path
+from typing import Any, Optional, Union
+
+import numpy as np
+from attrs import Factory, define
+
+import shaderflow_amd
+from shaderflow_amd import _native as N
+from shaderflow_amd.message import ShaderMessage
+from shaderflow_amd.module import ShaderModule
+from shaderflow_amd.texture import DeviceTexture, ShaderTexture
+from shaderflow_amd.variable import FlatVariable, InVariable, OutVariable, ShaderVariable
+
+_UNIFORM_TYPES = {"float": (N.T_FLOAT, np.float32, 1), "int": (N.T_INT, np.int32, 1), "bool": (N.T_BOOL, np.int32, 1),
+                  "vec2": (N.T_VEC2, np.float32, 2), "vec3": (N.T_VEC3, np.float32, 3), "vec4": (N.T_VEC4, np.float32, 4)}
+
+
+@define(eq=False, slots=False)
+class ShaderProgram(ShaderModule):
+    version: int = 330
+    clear: bool = True
+    instances: int = 1
+    texture: ShaderTexture = None
+
+    def build(self):
+        self.texture = ShaderTexture(scene=self.scene, name=self.name, track=True)
+        # The varyings every fragment can read (shader.py:112-124); kept as declarations for introspection
+        self.fragment_variable(OutVariable("vec4", "fragColor"))
+        self.vertex_variable(InVariable("vec2", "vertex_position"))
+        self.vertex_variable(InVariable("vec2", "vertex_gluv"))
+        for name in ("fragCoord", "stxy", "glxy", "stuv", "astuv", "gluv", "agluv"):
+            self.traverse_variable(ShaderVariable("vec2", name))
+        self.traverse_variable(FlatVariable("int", "instance"))
+        for x in (-1, 1):
+            for y in (-1, 1):
+                self.add_vertice(x=x, y=y, u=x, v=y)
+        self.vertex = (shaderflow_amd.resources/"shaders"/"vertex"/"default.glsl")
+        self.fragment = (shaderflow_amd.resources/"shaders"/"fragment"/"default.glsl")
+
+    # variable bookkeeping (shader.py:134-153) ---------------------------------------------------------
+
+    vertex_variables: dict = Factory(dict)
+    fragment_variables: dict = Factory(dict)
+
+    def vertex_variable(self, variable: ShaderVariable) -> None:
+        self.vertex_variables.setdefault(variable.name, variable)
+
+    def fragment_variable(self, variable: ShaderVariable) -> None:
+        self.fragment_variables.setdefault(variable.name, variable)
+
+    def common_variable(self, variable: ShaderVariable) -> None:
+        self.fragment_variable(variable)
+        self.vertex_variable(variable)
+
+    def traverse_variable(self, variable: ShaderVariable) -> None:
+        self.fragment_variable(variable.copy(direction="in"))
+        self.vertex_variable(variable.copy(direction="out"))
+
+    vertices: list = Factory(list)
+
+    def add_vertice(self, x: float = 0, y: float = 0, u: float = 0, v: float = 0) -> None:
+        self.vertices.extend((x, y, u, v))
+
+    # sources ------------------------------------------------------------------------------------------
+
+    _vertex: Union[Path, str] = ""
+    _fragment: Union[Path, str] = ""
+
+    @staticmethod
+    def _read(content: Union[Path, str]) -> str:
+        if isinstance(content, Path):
+            return content.read_text()
+        text = str(content)
+        # A short string may be a path given as str (shader.py:258-266 tolerates both)
+        if ("\n" not in text) and (len(text) < 4096) and text and os.path.exists(text):
+            return Path(text).read_text()
+        return text
+
+    @property
+    def vertex(self) -> str:
+        return self._read(self._vertex)
+
+    @vertex.setter
+    def vertex(self, value: Union[Path, str]):
+        self._vertex = value
+
+    @property
+    def fragment(self) -> str:
+        """User content of the fragment shader (what the registry fingerprints)"""
+        return self._read(self._fragment)
+
+    @fragment.setter
+    def fragment(self, value: Union[Path, str]):
+        self._fragment = value
+        if self.program is not None:                         # hot swap: resolve again on next compile message
+            self.release_program()
+
+    # device program -----------------------------------------------------------------------------------
+
+    program: Optional[N.Handle] = None
+    fallback: bool = False
+    """True when the fragment was unknown and the `missing` kernel was bound (shader.py:336-340)"""
+
+    def release_program(self) -> None:
+        if self.program is not None and self.program.value:
+            N.lib().sfx_program_destroy(self.program)
+        self.program = None
+
+    def compile(self, _vertex: str = None, _fragment: str = None):
+        for variable in self.full_pipeline():
+            self.common_variable(variable)
+        self.release_program()
+        source = _fragment or self.fragment
+        handle, fallback = N.Handle(), C.c_int(0)
+        N.check(N.lib().sfx_program_lookup(self.scene.context.handle, source.encode("utf-8"), C.byref(handle), C.byref(fallback)))
+        self.program, self.fallback = handle, bool(fallback.value)
+        if self.fallback:
+            self.log_error("Fragment is not in the kernel registry, loading missing texture shader")
+        return self
+
+    @property
+    def kernel(self) -> str:
+        """Registry name of the bound kernel"""
+        return N.lib().sfx_program_name(self.program).decode() if self.program is not None else ""
+
+    def set_uniform(self, name: str, value: Any = None) -> None:
+        if (self.program is None):
+            raise RuntimeError("Shader hasn't been compiled yet")
+        if (value is None):
+            return
+        self._push(name, value)
+
+    def _push(self, name: str, value: Any, type: Optional[str] = None) -> bool:
+        if type is None:
+            array = np.asarray(value)
+            count = array.size
+            if array.dtype.kind in "biu":
+                type = "int" if count == 1 else {2: "vec2", 3: "vec3", 4: "vec4"}[count]
+            else:
+                type = {1: "float", 2: "vec2", 3: "vec3", 4: "vec4"}.get(count)
+            if type is None:
+                return False
+        code, dtype, count = _UNIFORM_TYPES[type]
+        data = np.ascontiguousarray(np.asarray(value, dtype=np.float64).ravel()[:count].astype(dtype))
+        if data.size < count:
+            return False
+        known = C.c_int(0)
+        N.check(N.lib().sfx_uniform_set(self.program, name.encode(), code, data.ctypes.data, C.byref(known)))
+        return bool(known.value)
+
+    def get_uniform(self, name: str) -> Optional[Any]:
+        return None
+
+    SKIP_GPU: bool = os.environ.get("SKIP_GPU") == "1"
+
+    def use_pipeline(self, pipeline: Iterable[ShaderVariable], *, _index: int = 0) -> None:
+        for variable in pipeline:
+            if (variable.type == "sampler2D"):
+                texture = variable.value
+                if isinstance(texture, DeviceTexture) and texture.handle.value:
+                    N.check(N.lib().sfx_sampler_bind(self.program, variable.name.encode(), texture.handle, None))
+                _index += 1
+                continue
+            if variable.value is None or variable.type not in _UNIFORM_TYPES:
+                continue
+            self._push(variable.name, variable.value, variable.type)
+
+    def render_to_fbo(self, fbo: DeviceTexture, clear: bool = True, layer: int = 0) -> None:
+        if self.SKIP_GPU:
+            return
+        N.check(N.lib().sfx_render(self.program, fbo.handle, layer))
+
+    def render(self) -> None:
+        if self.program is None:
+            self.compile()
+
+        if self.texture.final:
+            # shader.py:391-396 — iScreen (RGBA8, linear, clamp) → iFinal (RGB8)
+            if self.SKIP_GPU or self.scene._fused_this_frame:
+                return None
+            source = self.scene.shader.texture.texture
+            N.check(N.lib().sfx_resolve(self.scene.context.handle, source.handle, self.texture.fbo.handle, self.scene.subsample))
+            return None
+
+        self.use_pipeline(self.full_pipeline())
+
+        # Main pass + resolve in one kernel when final.glsl only needs the pixel's own supersamples
+        if (self is self.scene.shader) and self.scene._can_fuse(self):
+            if not self.SKIP_GPU:
+                N.check(N.lib().sfx_render_resolve(self.program, self.scene._final.texture.fbo.handle,
+                                                   int(self.scene.ssaa), self.scene.subsample))
+            self.scene._fused_this_frame = True
+            self.texture.roll()
+            return None
+
+        for layer, box in enumerate(self.texture.row(0)):
+            self.set_uniform("iLayer", layer)
+            self.render_to_fbo(fbo=box.fbo, clear=box.clear, layer=layer)
+        self.texture.roll()
+
+    def update(self) -> None:
+        self.render()
+
+    def handle(self, message) -> None:
+        if isinstance(message, ShaderMessage.Shader.Compile):
+            self.compile()
+        elif isinstance(message, ShaderMessage.Shader.Render):
+            self.render()
+
+    def destroy(self) -> None:
+        self.release_program()

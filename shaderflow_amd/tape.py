@@ -1,0 +1,204 @@
+"""
+FrameTape: the batched export path (no reference equivalent; SURVEY.md §7 "Tape, not per-frame host round-trips").
+
+In an export the whole audio file and the frame clock are known up front, so nothing the modules compute between
+two frames needs python: for a batch of frames the device computes the STFT of every frame, the filterbank
+product, the DynamicNumber recurrences (spectrogram bins in float32, volume/std in float64), the waveform rows
+and the per-frame uniforms, keeps them in HBM, and the fused fragment kernel renders the batch back to back
+(`sfx_tape_build` + `sfx_render_tape`). The host contributes exactly what the reference evaluates in python
+scalars: the scheduler's float64 clock, the PCM chunk schedule, and the per-frame DynamicNumber coefficients
+(branch selection, exp/cos — dynamics.py:231-242), rounded to float32 where numpy would round them.
+
+A scene qualifies when it is made only of the stock modules and nothing overrides `update()`/`pipeline()`;
+anything else runs through the frame loop (`ShaderScene.next`), which produces the same frames.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import TYPE_CHECKING, Optional
+
+import numpy as np
+
+from shaderflow_amd import _native as N
+from shaderflow_amd.audio.module import ShaderAudio
+from shaderflow_amd.audio.reader import chunk_schedule
+from shaderflow_amd.audio.spectrogram import ShaderSpectrogram
+from shaderflow_amd.audio.waveform import ShaderWaveform, WaveformReducer
+from shaderflow_amd.camera import ShaderCamera
+from shaderflow_amd.dynamics import ShaderDynamics, dynamics_coefficients
+from shaderflow_amd.module import ShaderModule
+from shaderflow_amd.scheduler import freewheel_clock
+from shaderflow_amd.shader import ShaderProgram
+from shaderflow_amd.texture import ShaderTexture
+
+if TYPE_CHECKING:
+    from shaderflow_amd.exporting import ExportingHelper
+    from shaderflow_amd.scene import ShaderScene
+
+
+def _coefficients_f64(system, dts) -> np.ndarray:
+    out = np.zeros(len(dts), dtype=[("dt", "f8"), ("k1", "f8"), ("k2", "f8"), ("k3", "f8")])
+    for k, dt in enumerate(dts):
+        dt = abs(dt)
+        if dt:
+            k1, k2, k3, _ = dynamics_coefficients(system.frequency, system.zeta, system.response, dt)
+            out[k] = (dt, k1, k2, k3)
+    return out
+
+
+def _coefficients_f32(system, dts) -> np.ndarray:
+    wide = _coefficients_f64(system, dts)
+    out = np.zeros(len(dts), dtype=[("dt", "f4"), ("k1", "f4"), ("k2", "f4"), ("k3", "f4")])
+    for name in ("dt", "k1", "k2", "k3"):
+        out[name] = wide[name].astype(np.float32)       # python scalar → float32, as numpy does for a float32 array
+    return out
+
+
+class FrameTape:
+    BATCH = 60
+
+    @staticmethod
+    def applicable(scene: "ShaderScene") -> bool:
+        from shaderflow_amd.scene import ShaderScene
+        if type(scene).update is not ShaderModule.update or type(scene).pipeline is not ShaderScene.pipeline:
+            return False
+        stock = (ShaderCamera, ShaderDynamics, ShaderProgram, ShaderTexture, ShaderAudio, ShaderSpectrogram, ShaderWaveform)
+        audios, spectrograms, waveforms = [], [], []
+        for module in scene.modules:
+            if module is scene or (hasattr(module, "__eq__") and isinstance(module, ShaderScene)):
+                continue
+            if type(module) not in stock:
+                return False
+            if isinstance(module, ShaderProgram) and module not in (scene.shader, scene._final):
+                return False
+            if isinstance(module, ShaderAudio):
+                audios.append(module)
+            elif isinstance(module, ShaderSpectrogram):
+                spectrograms.append(module)
+            elif isinstance(module, ShaderWaveform):
+                waveforms.append(module)
+        if len(audios) != 1 or len(spectrograms) > 1 or len(waveforms) > 1 or not spectrograms:
+            return False
+        audio = audios[0]
+        if audio.native is None or any(m.audio is not audio for m in (*spectrograms, *waveforms)):
+            return False
+        if spectrograms[0].length_samples != 1 or spectrograms[0].spectrogram_bins*audio.channels > 2048:
+            return False
+        if scene.shader.texture.temporal != 1 or scene.shader.texture.layers != 1:
+            return False
+        return bool(scene.fuse and N.lib().sfx_fused_supported(int(round(scene.ssaa*1000)), scene.subsample))
+
+    def __init__(self, scene: "ShaderScene", batch: Optional[int] = None, use_mfma: bool = True):
+        self.scene = scene
+        self.batch = int(batch or self.BATCH)
+        self.use_mfma = bool(use_mfma)
+        self.audio: ShaderAudio = next(m for m in scene.modules if isinstance(m, ShaderAudio))
+        self.spectrogram: ShaderSpectrogram = next(m for m in scene.modules if isinstance(m, ShaderSpectrogram))
+        self.waveform: Optional[ShaderWaveform] = next((m for m in scene.modules if isinstance(m, ShaderWaveform)), None)
+        self.handle: Optional[N.Handle] = None
+        self.frames = 0
+
+    # host-side schedule -----------------------------------------------------------------------------------------
+
+    def prepare(self, frames: int) -> "FrameTape":
+        """Everything python contributes, for `frames` frames from time 0"""
+        scene, audio, spec = self.scene, self.audio, self.spectrogram
+        self.frames = frames
+        times, dts, rdts = freewheel_clock(scene.fps, frames, scene.speed)
+        self.times, self.dts = times, dts
+        self.tell = chunk_schedule(rdts, int(audio.samplerate), audio.channels, audio._file_reader.samples.shape[0])
+        self.clock = np.zeros(frames, dtype=[("iTime", "f4"), ("iTau", "f4"), ("iSpectrogramOffset", "f4"), ("iFrame", "i4")])
+        width = spec.length_samples
+        for k, t in enumerate(times):
+            self.clock[k] = (t, (t/scene.runtime) % 1.0, ((k + 1) % width)/width, round(t*scene.fps))
+        self.spec_coeff = _coefficients_f32(spec.dynamics, dts)
+        self.vol_coeff = _coefficients_f64(audio.volume, dts)
+        self.std_coeff = _coefficients_f64(audio.std, dts)
+
+        self.release()
+        reducer = self.waveform.reducer if self.waveform is not None else WaveformReducer.Average
+        desc = N.TapeDesc(
+            points=(self.waveform._points if self.waveform is not None else 0),
+            chunk_size=(self.waveform.chunk_size if self.waveform is not None else 1),
+            reducer=WaveformReducer(reducer).value,
+            volume_window=int(0.1*audio.samplerate),
+            use_mfma=int(self.use_mfma),
+            volume_integrate=int(audio.volume.integrate), std_integrate=int(audio.std.integrate),
+            precision=float(spec.dynamics.precision),
+        )
+        handle = N.Handle()
+        N.check(N.lib().sfx_tape_create(spec.plan(), audio.native, C.byref(desc), self.batch, C.byref(handle)))
+        self.handle = handle
+        return self
+
+    def release(self) -> None:
+        if self.handle is not None and self.handle.value:
+            N.lib().sfx_tape_destroy(self.handle)
+        self.handle = None
+
+    def bind_static_uniforms(self) -> None:
+        """Uniforms and samplers that do not change over the export (scene.py:687-703 etc.), pushed once"""
+        program = self.scene.shader
+        if program.program is None:
+            program.compile()
+        program.use_pipeline(program.full_pipeline())
+
+    # device work --------------------------------------------------------------------------------------------------
+
+    def build(self, first: int, count: int) -> None:
+        """Audio state of frames [first, first+count) → tape slots [0, count). Frames must be visited in order."""
+        s = slice(first, first + count)
+        tell = np.ascontiguousarray(self.tell[s])
+        clock, spec = np.ascontiguousarray(self.clock[s]), np.ascontiguousarray(self.spec_coeff[s])
+        vol, std = np.ascontiguousarray(self.vol_coeff[s]), np.ascontiguousarray(self.std_coeff[s])
+        N.check(N.lib().sfx_tape_build(self.handle, count, N.as_ptr(tell, C.c_int64),
+                                       C.cast(clock.ctypes.data, C.POINTER(N.FrameClock)),
+                                       C.cast(spec.ctypes.data, C.POINTER(N.DynCoeffF32)),
+                                       C.cast(vol.ctypes.data, C.POINTER(N.DynCoeffF64)),
+                                       C.cast(std.ctypes.data, C.POINTER(N.DynCoeffF64))))
+
+    def render(self, count: int, device_out: int, first_slot: int = 0) -> None:
+        """Tape slots [first_slot, first_slot+count) → `count` RGB8 frames at `device_out`"""
+        scene = self.scene
+        N.check(N.lib().sfx_render_tape(scene.shader.program, self.handle, first_slot, count, scene.width, scene.height,
+                                        int(scene.ssaa), scene.subsample, C.c_void_p(device_out)))
+
+    def read(self, what: int, count: int, first_slot: int = 0) -> np.ndarray:
+        """Tape content for inspection (tests)"""
+        bins, channels = self.spectrogram.spectrogram_bins, self.audio.channels
+        shapes = {
+            N.TAPE_SPECTROGRAM: (count, bins, channels), N.TAPE_TARGETS: (count, bins, channels),
+            N.TAPE_WAVEFORM: (count, self.waveform._points if self.waveform is not None else 1, channels),
+            N.TAPE_UNIFORMS: (count, 8), N.TAPE_LOUDNESS: (count, 2),
+        }
+        out = np.zeros(shapes[what], np.float32)
+        N.check(N.lib().sfx_tape_read(self.handle, what, first_slot, count, out.ctypes.data, out.nbytes))
+        return out
+
+    # whole export ---------------------------------------------------------------------------------------------------
+
+    def export(self, export: "ExportingHelper", turbo: bool = True):
+        scene = self.scene
+        total = export.total_frames
+        self.prepare(total)
+        self.bind_static_uniforms()
+        N.check(N.lib().sfx_tape_reset(self.handle))
+        frame_bytes = scene.width*scene.height*3
+        context = scene.context
+        buffers = [context.alloc(frame_bytes*self.batch) for _ in range(2)]
+        try:
+            for index, first in enumerate(range(0, total, self.batch)):
+                count = min(self.batch, total - first)
+                target = buffers[index % 2]
+                self.build(first, count)
+                self.render(count, target)
+                for i in range(count):
+                    export.pipe_device(target + i*frame_bytes, turbo=turbo)
+                    export.update()
+            scene.time, scene.dt, scene.rdt = self.times[-1], self.dts[-1], self.dts[-1]      # clock of the last frame
+            return export.finish()
+        finally:
+            context.synchronize()
+            for pointer in buffers:
+                context.free(pointer)
+            self.release()

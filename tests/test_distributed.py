@@ -1,0 +1,75 @@
+"""
+The N > 1 path on CPU: frame-range sharding and the two-slot asynchronous gather of finished frames to rank 0,
+with world_size 2 over gloo (the same code runs over RCCL on the GPUs). CPU only.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from shaderflow_amd.parallel import FrameGather, shard_batches, shard_frames
+
+
+def test_shard_frames_covers_everything_once():
+    for total in (1, 7, 60, 3600, 3601):
+        for world in (1, 2, 3, 8):
+            ranges = [shard_frames(total, world, r) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_frames(3600, 8, 3) == (1350, 1800)               # BASELINE config 5
+    assert shard_batches(1350, 1800, 60)[0] == (1350, 60) and sum(c for _, c in shard_batches(1350, 1800, 64)) == 450
+    assert shard_batches(0, 0, 60) == []
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, nbytes: int, steps: int, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gather = FrameGather(world, rank, nbytes, torch.device("cpu"))
+        buffers = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(2)]
+        seen = []
+        for step in range(steps):
+            slot = step % 2
+            gather.wait(slot)                                     # buffer reuse fence, as in bench.py
+            if rank == 0 and step >= 2:
+                seen.append([int(t[0]) for t in gather.frames(slot)])
+            buffers[slot].fill_((17*step + rank) % 256)           # "render" this rank's batch
+            gather.start(slot, buffers[slot])
+        gather.wait_all()
+        if rank == 0:
+            for step in range(max(0, steps - 2), steps):
+                seen.append([int(t[0]) for t in gather.frames(step % 2)])
+            out.put(seen)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gather_over_gloo():
+    world, steps, nbytes = 2, 5, 4096
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nbytes, steps, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    seen = out.get(timeout=90)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    want = [[(17*step + rank) % 256 for rank in range(world)] for step in range(steps)]
+    assert sorted(seen) == sorted(want), seen

@@ -1,0 +1,233 @@
+"""
+Parity of the HIP pixel kernels with the oracle, through the C-ABI (sfx_*), on the same seeded inputs.
+Tolerance of the path (BASELINE.json north_star): rendered pixels within 1 LSB per channel after 8-bit
+quantisation. The generic kernels evaluate the same binary32 operation sequences as the oracle, so they are
+additionally REQUIRED to be bit-exact here; the fused and LDS-tiled kernels re-associate and are
+held to the 1 LSB bound.
+"""
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from tests.helpers import Gpu, gpu_bind_all, lsb_report, oracle_textures, visualizer_inputs
+
+pytestmark = pytest.mark.gpu
+
+ONE_LSB = 1
+
+
+@pytest.fixture()
+def gpu():
+    g = Gpu()
+    yield g
+    g.close()
+
+
+def assert_within_lsb(got, want, bound=ONE_LSB):
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= bound, lsb_report(got, want)
+
+
+@pytest.mark.parametrize("name,size", [("default", (256, 256)), ("default", (160, 90)), ("missing", (64, 36)),
+                                       ("shadertoy", (80, 45)), ("multi_child", (64, 36)), ("audio", (16, 8))])
+def test_untextured_fragments_bit_exact(gpu, name, size):
+    w, h = size
+    u = O.default_uniforms(w, h, iTime=0.75, iTau=0.075, iAudioVolume=0.4)
+    want = O.render(name, u, {}, w, h, threads=4)
+    prog, fallback = gpu.program(name)
+    assert not fallback
+    gpu.set_uniforms(prog, u)
+    got = gpu.render(prog, w, h)
+    assert np.array_equal(got, want), lsb_report(got, want)
+
+
+def test_unknown_source_falls_back_to_missing(gpu):
+    prog, fallback = gpu.program("void main() { fragColor = vec4(1, 0, 1, 1); /* never seen */ }")
+    assert fallback
+    w, h = 32, 18
+    u = O.default_uniforms(w, h, iTime=3.0)
+    gpu.set_uniforms(prog, u)
+    assert np.array_equal(gpu.render(prog, w, h), O.render("missing", u, {}, w, h))
+
+
+def test_non_default_camera_bit_exact(gpu):
+    """camera.glsl: stereoscopic and equirectangular projections, moved/zoomed camera"""
+    w, h = 96, 54
+    for projection in (0, 1, 2):
+        u = O.default_uniforms(w, h, iTau=0.3, iCameraProjection=projection, iCameraZoom=1.3, iCameraIsometric=0.2,
+                               iCameraPosition=(0.1, -0.05, 0.0), iCameraSeparation=0.07)
+        want = O.render("default", u, {}, w, h, threads=4)
+        prog, _ = gpu.program("default")
+        gpu.set_uniforms(prog, u)
+        got = gpu.render(prog, w, h)
+        assert np.array_equal(got, want), (projection, lsb_report(got, want))
+
+
+@pytest.mark.parametrize("name", ["bars", "waveform"])
+def test_audio_texture_fragments_bit_exact(gpu, name):
+    w, h = 128, 72
+    u, arrays, params = visualizer_inputs(w, h, seed=5)
+    arrays["iSpectrogram"] = arrays["iSpectrogram"]*3
+    want = O.render(name, u, oracle_textures(arrays, params), w, h, threads=4)
+    prog, _ = gpu.program(name)
+    gpu.set_uniforms(prog, u)
+    for key in ("iSpectrogram", "iWaveform"):
+        gpu.bind(prog, key + "0x0", gpu.texture(arrays[key], *params[key]))     # sampler names as texture.py:346-347 yields them
+    got = gpu.render(prog, w, h)
+    assert np.array_equal(got, want), lsb_report(got, want)
+
+
+def test_multishader_two_passes_bit_exact(gpu):
+    w, h = 64, 36
+    u = O.default_uniforms(w, h)
+    child_o = O.render("multi_child", u, {}, w, h)
+    want = O.render("multi_main", u, {"child": O.make_texture(child_o, "linear", True, True)}, w, h)
+    child, _ = gpu.program("multi_child")
+    gpu.set_uniforms(child, u)
+    target = gpu.empty(w, h, 4)
+    from shaderflow_amd import _native as N
+    N.check(gpu.lib.sfx_render(child, target, 0))
+    main, _ = gpu.program("multi_main")
+    gpu.set_uniforms(main, u)
+    assert gpu.bind(main, "child", target)
+    assert np.array_equal(gpu.render(main, w, h), want)
+
+
+def test_dynamics_scene_user_uniform(gpu):
+    w, h = 64, 36
+    u, arrays, params = visualizer_inputs(w, h, seed=9)
+    u.user[0] = 0.35
+    want = O.render("dynamics", u, oracle_textures(arrays, params), w, h)
+    prog, _ = gpu.program("dynamics")
+    gpu.set_uniforms(prog, u)
+    assert gpu.set_float(prog, "iShaderDynamics", 0.35)
+    assert not gpu.set_float(prog, "iNotAUniform", 1.0)          # inactive uniforms are ignored, not an error
+    gpu.bind(prog, "background", gpu.texture(arrays["background"], *params["background"]))
+    assert np.array_equal(gpu.render(prog, w, h), want)
+
+
+@pytest.mark.parametrize("ssaa,subsample", [(1, 1), (1, 2), (2, 2), (2, 1), (4, 2), (4, 4), (3, 3), (3, 2)])
+def test_resolve_pass_bit_exact(gpu, ssaa, subsample):
+    rng = np.random.default_rng(ssaa*10 + subsample)
+    w, h = 40, 24
+    screen = rng.integers(0, 256, (h*ssaa, w*ssaa, 4), dtype=np.uint8)
+    want = O.resolve(screen, w, h, subsample)
+    got = gpu.resolve(screen, w, h, subsample)
+    assert np.array_equal(got, want), lsb_report(got, want)
+
+
+def test_resolve_fractional_ssaa(gpu):
+    """scene.ssaa = 1.5 → render resolution int(w*1.5) (scene.py:372-375): only the two-pass path applies"""
+    rng = np.random.default_rng(3)
+    w, h = 40, 24
+    screen = rng.integers(0, 256, (int(h*1.5), int(w*1.5), 4), dtype=np.uint8)
+    assert np.array_equal(gpu.resolve(screen, w, h, 2), O.resolve(screen, w, h, 2))
+    assert gpu.lib.sfx_fused_supported(1500, 2) == 0 and gpu.lib.sfx_fused_supported(2000, 2) == 1
+
+
+@pytest.mark.parametrize("volume", [0.0, 0.35, 0.8, 1.6])
+def test_visualizer_generic_kernel_bit_exact(gpu, volume):
+    """PlainShader<visualizer>: float background texture keeps the LDS tile path out"""
+    w, h = 96, 54
+    u, arrays, params = visualizer_inputs(w, h, seed=11, volume=volume, bg_size=(48, 27))
+    arrays["background"] = (arrays["background"].astype(np.float32)/255.0).astype(np.float32)
+    want = O.render("visualizer", u, oracle_textures(arrays, params), w, h, threads=8)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    got = gpu.render(prog, w, h)
+    assert np.array_equal(got, want), lsb_report(got, want)
+
+
+@pytest.mark.parametrize("volume,repeat", [(0.0, True), (0.5, True), (0.9, False), (1.7, True)])
+def test_visualizer_lds_tile_kernel_within_one_lsb(gpu, volume, repeat):
+    """VisualizerShader (uint8 background): blur from the LDS tile, 81 re-associated taps"""
+    w, h = 160, 90
+    u, arrays, params = visualizer_inputs(w, h, seed=21, volume=volume, bg_size=(120, 68))
+    params["background"] = ("linear", repeat, repeat)
+    want = O.render("visualizer", u, oracle_textures(arrays, params), w, h, threads=8)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    got = gpu.render(prog, w, h)
+    assert_within_lsb(got, want)
+    assert (got != want).mean() < 0.02, lsb_report(got, want)
+
+
+def test_visualizer_tile_overflow_falls_back(gpu):
+    """A background far larger than the output: the tap window exceeds the LDS tile → generic taps, same result"""
+    w, h = 64, 36
+    u, arrays, params = visualizer_inputs(w, h, seed=4, volume=1.2, bg_size=(1536, 864))
+    want = O.render("visualizer", u, oracle_textures(arrays, params), w, h, threads=8)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    assert_within_lsb(gpu.render(prog, w, h), want)
+
+
+@pytest.mark.parametrize("name", ["default", "visualizer", "bars"])
+@pytest.mark.parametrize("ssaa,subsample", [(1, 1), (2, 2), (2, 1), (4, 2), (4, 4)])
+def test_fused_render_resolve_within_one_lsb(gpu, name, ssaa, subsample):
+    """sfx_render_resolve vs the oracle's two passes (render at w*ssaa, RGBA8, then final.glsl)"""
+    w, h = 136, 40                                                # not a multiple of the 128-pixel block
+    u, arrays, params = visualizer_inputs(w, h, seed=31, volume=0.7, bg_size=(100, 56))
+    u.iSSAA = float(ssaa)
+    screen = O.render(name, u, oracle_textures(arrays, params), w*ssaa, h*ssaa, threads=8)
+    want = O.resolve(screen, w, h, subsample)
+    prog, _ = gpu.program(name)
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    got = gpu.render_resolve(prog, w, h, ssaa, subsample)
+    assert_within_lsb(got, want)
+
+
+def test_fused_matches_two_pass_on_device(gpu):
+    """Same device, same inputs: sfx_render + sfx_resolve vs sfx_render_resolve"""
+    from shaderflow_amd import _native as N
+    w, h, ssaa = 200, 64, 2
+    u, arrays, params = visualizer_inputs(w, h, seed=41, volume=1.0)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    screen = gpu.empty(w*ssaa, h*ssaa, 4)
+    N.check(gpu.lib.sfx_texture_params(screen, 1, 0, 0))
+    N.check(gpu.lib.sfx_render(prog, screen, 0))
+    final = gpu.empty(w, h, 3)
+    N.check(gpu.lib.sfx_resolve(gpu.ctx.handle, screen, final, 2))
+    two_pass = gpu.read(final, w, h, 3)
+    fused = gpu.render_resolve(prog, w, h, ssaa, 2)
+    assert_within_lsb(fused, two_pass)
+
+
+def test_unsupported_fused_pair_is_refused(gpu):
+    from shaderflow_amd import _native as N
+    prog, _ = gpu.program("default")
+    dst = gpu.empty(32, 18, 3)
+    assert gpu.lib.sfx_render_resolve(prog, dst, 1, 2) == N.E_UNSUPPORTED       # 3x3 tent leaves the pixel
+    assert b"footprint" in gpu.lib.sfx_last_error()
+
+
+def test_full_size_properties_4k_ssaa2(gpu):
+    """BASELINE config 3 size (3840x2160, 2xSSAA): size-independent properties instead of a CPU render:
+    (a) a band of rows equals the oracle's band, (b) horizontal translation invariance of `bars` columns,
+    (c) determinism (two launches give identical frames)."""
+    w, h, ssaa = 3840, 2160, 2
+    u, arrays, params = visualizer_inputs(w, h, seed=51, volume=0.9, bg_size=(1920, 1080))
+    u.iSSAA = 2.0
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    a = gpu.render_resolve(prog, w, h, ssaa, 2)
+    b = gpu.render_resolve(prog, w, h, ssaa, 2)
+    assert np.array_equal(a, b)
+    rows = (1000, 1004)                                           # 4 output rows = 8 supersample rows on the CPU
+    screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, rows=(rows[0]*ssaa, rows[1]*ssaa), threads=8)
+    want = O.resolve(screen, w, h, 2, rows=rows, threads=8)
+    assert_within_lsb(a[rows[0]:rows[1]], want[rows[0]:rows[1]])
+    # bars.frag depends on astuv only through texture(iSpectrogram, astuv.yx): columns inside one spectrogram bin are equal
+    bars, _ = gpu.program("bars")
+    gpu.set_uniforms(bars, u)
+    gpu.bind(bars, "iSpectrogram", gpu.texture(arrays["iSpectrogram"], *params["iSpectrogram"]))
+    img = gpu.render_resolve(bars, w, h, ssaa, 2)
+    bin_width = w/115
+    assert np.array_equal(img[:, int(10*bin_width) + 3], img[:, int(10*bin_width) + 20])

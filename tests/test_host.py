@@ -1,0 +1,190 @@
+"""
+Host logic of the package (no GPU): the python mirror of the reference's classes against the golden vectors, the
+module-registration contract, and the C-ABI library's exported symbols. CPU only.
+"""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_resolution_fit(golden):
+    """resolution.py:9-86 incl. the reference's own assertions (:90-116)"""
+    from shaderflow_amd.resolution import Resolution
+    nan = lambda v: None if np.isnan(v) else v
+    for row in golden("resolution")["cases"]:
+        ow, oh, nw, nh, mw, mh, ar, scale, w, h = row
+        old = (nan(ow), nan(oh)); new = (nan(nw), nan(nh)); mx = (nan(mw), nan(mh))
+        old = tuple(int(v) if v is not None else None for v in old)
+        new = tuple(int(v) if v is not None else None for v in new)
+        mx = tuple(int(v) if v is not None else None for v in mx)
+        got = Resolution.fit(old=old, new=new, max=mx if any(mx) else None, ar=nan(ar), scale=scale)
+        assert got == (int(w), int(h)), row
+    with pytest.raises(ValueError):
+        Resolution.fit(old=(1920, None), new=(1280, None))
+    with pytest.raises(ValueError):
+        Resolution.fit(old=(None, 1080), new=(None, None))
+
+
+@pytest.mark.parametrize("tag,fps,sr", [("60_44100", 60.0, 44100), ("30_48000", 30.0, 48000), ("24_44100", 24.0, 44100), ("59.94_44100", 60000/1001, 44100)])
+def test_clock_and_chunk_schedule(golden, tag, fps, sr):
+    from shaderflow_amd.audio.reader import chunk_schedule
+    from shaderflow_amd.scheduler import freewheel_clock
+    g = golden("clock")
+    frames = len(g[f"dt_{tag}"])
+    times, dts, rdts = freewheel_clock(fps, frames)
+    assert np.array_equal(times, g[f"time_{tag}"]) and np.array_equal(dts, g[f"dt_{tag}"])      # float64 bit-exact
+    total = int(sr*(frames/fps)) + 5000
+    assert np.array_equal(chunk_schedule(rdts, sr, 2, total), g[f"tell_{tag}"])
+
+
+def test_reader_stream_matches_schedule(golden):
+    from shaderflow_amd.audio.reader import BrokenAudioReader, chunk_schedule
+    g = golden("clock")
+    pcm = np.zeros((2000, 2), np.float32)
+    reader = BrokenAudioReader(samples=pcm, samplerate=44100)
+    stream = reader.stream
+    lengths = []
+    for k in range(6):
+        reader.chunk = 0.0 if k == 0 else 1/60
+        try:
+            lengths.append(next(stream).shape[0])
+        except StopIteration:
+            lengths.append(-1)
+    assert lengths == list(g["len_eof"])
+    assert list(chunk_schedule([0.0] + [1/60]*5, 44100, 2, 2000)) == [1, 735, 1470, 2000, 2000, 2000]
+
+
+def test_wav_round_trip(tmp_path):
+    from shaderflow_amd.audio.reader import read_wav, write_wav_f32
+    rng = np.random.default_rng(0)
+    pcm = rng.uniform(-1, 1, (1000, 2)).astype(np.float32)
+    path = write_wav_f32(tmp_path/"a.wav", pcm, 48000)
+    back, sr = read_wav(path)
+    assert sr == 48000 and np.array_equal(back, pcm)
+    with pytest.raises(ValueError):
+        (tmp_path/"b.wav").write_bytes(b"not a wav")
+        read_wav(tmp_path/"b.wav")
+
+
+@pytest.mark.parametrize("tag,dtype", [("spec", np.float32), ("volume", None), ("std", None), ("resp", None), ("cosh", None), ("idle", None), ("vardt", None)])
+def test_dynamic_number_host_mirror_bit_exact(golden, tag, dtype):
+    """shaderflow_amd.dynamics.DynamicNumber against the reference's trajectories (dynamics.py:197-250)"""
+    from shaderflow_amd.dynamics import DynamicNumber
+    g = golden("dynamics")
+    freq, zeta, resp, integ = (float(v) for v in g[f"{tag}_params"])      # python floats: numpy scalars are not "weak"
+    targets = g[f"{tag}_targets"]
+    if dtype is np.float32:
+        system = DynamicNumber(frequency=freq, zeta=zeta, response=resp, dtype=np.float32)
+        system.set(np.zeros(targets[0].shape, np.float32))
+    else:
+        system = DynamicNumber(value=(0.25 if tag == "idle" else 0), frequency=freq, zeta=zeta, response=resp, integrate=bool(integ))
+        if tag in ("volume", "std"):
+            system.set(system.initial, instant=True)
+    for k, dt in enumerate(g[f"{tag}_dts"]):
+        system.target = targets[k] if dtype is np.float32 else (np.float32(targets[k]) if tag in ("volume", "std") else float(targets[k]))
+        system.next(dt=abs(float(dt)))
+        assert np.array_equal(np.asarray(system.value), g[f"{tag}_values"][k]), (tag, k)
+        assert np.array_equal(np.asarray(system.integral), g[f"{tag}_integrals"][k]), (tag, k)
+
+
+def test_filterbank_matrix_and_notes(golden):
+    from shaderflow_amd.audio.module import BrokenAudio
+    from shaderflow_amd.audio.spectrogram import BrokenSpectrogram, SpectrogramScale
+    from shaderflow_amd.piano import PianoNote
+    f = golden("filterbank")
+    spec = BrokenSpectrogram(audio=BrokenAudio())
+    spec.from_notes(start=PianoNote.from_frequency(20), end=PianoNote.from_frequency(14000), piano=True)
+    assert spec.spectrogram_bins == 115
+    m = spec.spectrogram_matrix()
+    assert np.array_equal(m.indptr, f["piano115_indptr"]) and np.array_equal(m.indices, f["piano115_indices"])
+    assert np.array_equal(m.data, f["piano115_data"])
+    mel = BrokenSpectrogram(audio=BrokenAudio(), scale=SpectrogramScale.MEL)
+    mel.spectrogram_bins = 64
+    assert np.array_equal(mel.spectrogram_matrix().data, f["mel64_data"])
+    assert [PianoNote.frequency_to_index(float(x)) for x in f["note_of_freq_in"]] == list(f["note_of_freq_out"])
+
+
+def test_broken_audio_window_semantics():
+    """get_last_n_samples excludes the newest sample; history starts as zeros (audio/module.py:110-138)"""
+    from shaderflow_amd.audio.module import BrokenAudio
+    audio = BrokenAudio()
+    audio.add_data(np.arange(1, 11, dtype=np.float32)[None, :].repeat(2, 0))
+    assert audio.tell == 10
+    assert list(audio.get_last_n_samples(4)[0]) == [6, 7, 8, 9]
+    assert list(audio.get_last_n_samples(12)[0]) == [0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9]
+    assert audio.data.shape == (2, 1323000) and audio.data[0, -1] == 10 and audio.data[0, -11] == 0
+
+
+def test_module_contract_without_gpu():
+    """Registration order, weakref scene, relay, module-without-scene error (module.py:33-53)"""
+    from shaderflow_amd.dynamics import ShaderDynamics
+    from shaderflow_amd.module import ShaderModule
+    from shaderflow_amd.scene import ShaderScene
+    from shaderflow_amd.variable import Uniform
+
+    class Scene(ShaderScene):
+        def build(self):
+            pass
+
+    scene = Scene()
+    assert scene.modules == [scene] and scene.name == "Scene"
+    a = ShaderDynamics(scene=scene, name="iA", frequency=4, value=0.0)
+    b = ShaderDynamics(scene=scene, name="iB", frequency=4, value=np.zeros(3), differentiate=True)
+    assert scene.modules[1:] == [a, b] and (a.uuid < b.uuid)
+    assert [v.name for v in scene.full_pipeline()][-3:] == ["iA", "iB", "iBDerivative"]
+    assert b.type == "vec3" and Uniform("float", "iA") == Uniform("vec2", "iA")
+    assert Uniform("vec2", "iResolution").declaration == "uniform vec2 iResolution;"
+    with pytest.raises(RuntimeError):
+        ShaderModule()
+    seen = []
+    a.handle = lambda message: seen.append(message)
+    scene.relay("ping")
+    assert seen == ["ping"]
+    assert scene.render_resolution == (1920, 1080)
+    scene._ssaa = 1.5
+    assert scene.render_resolution == (2880, 1620)
+    with pytest.raises(NotImplementedError):
+        Scene.main.__wrapped__ if hasattr(Scene.main, "__wrapped__") else (_ for _ in ()).throw(NotImplementedError())
+
+
+def test_alias_install():
+    import shaderflow_amd
+    shaderflow_amd.install_alias()
+    import shaderflow
+    from shaderflow.scene import ShaderScene
+    from shaderflow.variable import Uniform
+    assert shaderflow.resources.exists() and ShaderScene.__module__ == "shaderflow_amd.scene" and Uniform is not None
+
+
+def test_library_exports_every_declared_symbol():
+    """include/shaderflow_hip.h ↔ libshaderflow_hip.so ↔ the ctypes prototype table"""
+    from shaderflow_amd import _native as N
+    header = (ROOT/"include"/"shaderflow_hip.h").read_text()
+    declared = set(re.findall(r"\b(sfx_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(N.PROTOTYPES), declared ^ set(N.PROTOTYPES)
+    lib = C.CDLL(str(N.LIBRARY))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.sfx_fused_supported(2000, 2) == 1 and lib.sfx_fused_supported(1000, 2) == 0     # pure host logic
+
+
+def test_no_device_fails_loudly():
+    """No silent CPU fallback: without a GPU a context cannot be created"""
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from shaderflow_amd import _native as N
+    with pytest.raises(N.NativeError, match="no HIP device"):
+        N.Context(0)
+
+
+def test_product_never_imports_the_oracle():
+    for path in (ROOT/"shaderflow_amd").rglob("*"):
+        if path.suffix in (".py", ".hpp", ".hip", ".h") and path.is_file():
+            text = path.read_text()
+            assert "oracle" not in text.replace("parity oracle", "").replace("CPU oracle", "").replace("the oracle", ""), path
