@@ -224,11 +224,15 @@ class ShaderSpectrogram(BrokenSpectrogram, ShaderModule):
         self.dynamics = DynamicNumber(frequency=4, zeta=1, response=0, dtype=np.float32)
         self.texture = ShaderTexture(scene=self.scene, name=self.name, dtype=np.float32, repeat_y=False)
 
-    def update(self):
+    def configure_texture(self) -> None:
+        """Size and sampler state of the scrolling texture (spectrogram.py:299-302)"""
         self.texture.components = self.audio.channels
         self.texture.filter = ("linear" if self.smooth else "nearest")
         self.texture.height = self.spectrogram_bins
         self.texture.width = self.length_samples
+
+    def update(self):
+        self.configure_texture()
         self.offset = (self.offset + 1) % self.length_samples
         if (self.dynamics.value.shape != (self._row_shape)):
             self.dynamics.set(np.zeros(self._row_shape, dtype=np.float32))

@@ -21,7 +21,7 @@ if TYPE_CHECKING:
 logger = logging.getLogger("shaderflow_amd")
 
 
-@define(slots=False)
+@define(slots=False, eq=False)
 class ShaderModule:
 
     scene: "ShaderScene" = field(default=None, repr=False)

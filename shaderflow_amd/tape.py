@@ -141,6 +141,7 @@ class FrameTape:
         program = self.scene.shader
         if program.program is None:
             program.compile()
+        self.spectrogram.configure_texture()                 # what its first update() would do
         program.use_pipeline(program.full_pipeline())
 
     # device work --------------------------------------------------------------------------------------------------
