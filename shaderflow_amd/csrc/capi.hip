@@ -428,6 +428,13 @@ static void fill_args(const Program* p, RenderArgs& a) {
     for (int k = 0; k < TEX_SLOTS; k++) a.tex[k] = tex_view(p->samplers[k]);
     memcpy(a.tap_x, p->ctx->tap_x, sizeof a.tap_x);
     memcpy(a.tap_y, p->ctx->tap_y, sizeof a.tap_y);
+    // uniform-only terms of visualizer.frag, evaluated once here with the same binary32 operations (sfmath.hpp is
+    // host/device); the tape path replaces them per frame on the device (k_visualizer_consts)
+    a.vis = visualizer_consts(p->u.iTime, p->u.iAudioVolume, p->u.iAudioSTD);
+    a.has_vis = 1;
+    a.vis_consts = nullptr;
+    a.one = 1.0f;
+    a.aspect = p->u.iResolution[0]/p->u.iResolution[1];
 }
 
 static bool needs(const RenderArgs& a, int slot) { return a.tex[slot].data != nullptr || (slot == TEX_SPECTROGRAM && a.tape_spectrogram) || (slot == TEX_WAVEFORM && a.tape_waveform); }
@@ -444,7 +451,7 @@ static int check_samplers(int fragment, const RenderArgs& a) {
 }
 
 template <class SHADER> static void launch_render_t(const RenderArgs& a, int frames, hipStream_t s) {
-    dim3 grid((a.wr + 63)/64, (a.hr + 3)/4, frames), block(64, 4, 1);
+    dim3 grid((a.wr + SHADER::BLOCK_W - 1)/SHADER::BLOCK_W, (a.hr + SHADER::BLOCK_H - 1)/SHADER::BLOCK_H, frames), block(SHADER::BLOCK_W, SHADER::BLOCK_H, 1);
     hipLaunchKernelGGL(k_render<SHADER>, grid, block, 0, s, a);
 }
 
@@ -926,6 +933,7 @@ struct Tape : Object {
     long* d_tell; float* d_power; float* d_targets; float* d_columns; float* d_rows; float* d_loudness;
     float* d_state; ScalarState* d_scalars; FrameDyn* d_dyn;
     DynCoeffF32* d_coeff; DynCoeffF64 *d_vol, *d_std; FrameClock* d_clock;
+    VisualizerConsts* d_vis;
 };
 
 extern "C" int sfx_tape_reset(sfx_handle h) {
@@ -962,6 +970,7 @@ extern "C" int sfx_tape_create(sfx_handle hp, sfx_handle ha, const sfx_tape_desc
     HIP_TRY(hipMalloc(&t->d_vol, sizeof(DynCoeffF64)*F));
     HIP_TRY(hipMalloc(&t->d_std, sizeof(DynCoeffF64)*F));
     HIP_TRY(hipMalloc(&t->d_clock, sizeof(FrameClock)*F));
+    HIP_TRY(hipMalloc(&t->d_vis, sizeof(VisualizerConsts)*F));
     *out = handle_of(t);
     return sfx_tape_reset(*out);
 }
@@ -1020,7 +1029,7 @@ extern "C" int sfx_tape_destroy(sfx_handle h) {
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
     hipFree(t->d_tell); hipFree(t->d_power); hipFree(t->d_targets); hipFree(t->d_columns); hipFree(t->d_rows); hipFree(t->d_loudness);
-    hipFree(t->d_state); hipFree(t->d_scalars); hipFree(t->d_dyn); hipFree(t->d_coeff); hipFree(t->d_vol); hipFree(t->d_std); hipFree(t->d_clock);
+    hipFree(t->d_state); hipFree(t->d_scalars); hipFree(t->d_dyn); hipFree(t->d_coeff); hipFree(t->d_vol); hipFree(t->d_std); hipFree(t->d_clock); hipFree(t->d_vis);
     t->magic = 0;
     delete t;
     return SFX_OK;
@@ -1062,6 +1071,11 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
     if (t->desc.points > 0) a.tex[TEX_WAVEFORM].data = t->d_rows;
     int rc = check_samplers(p->fragment, a);
     if (rc) return rc;
+    a.has_vis = 0;                                                  // per-frame audio uniforms live on the device
+    if (p->fragment == FRAG_VISUALIZER) {
+        hipLaunchKernelGGL(k_visualizer_consts, dim3((nframes + 63)/64), dim3(64), 0, p->ctx->stream, t->d_dyn, frame0, nframes, t->d_vis);
+        a.vis_consts = t->d_vis;
+    }
     if ((rc = launch_fused(p->fragment, a, ssaa, nframes, p->ctx->stream))) return rc;
     return launch_status();
 }

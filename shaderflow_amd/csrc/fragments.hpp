@@ -67,47 +67,71 @@ SF_HD vec4 frag_missing(const Frag& f) {
 }
 
 // ---- visualizer.frag ---------------------------------------------------------------------------------
-// The radial blur (:21-33) is factored out so that the LDS-tiled kernel can substitute its own
-// evaluation of the same sum; everything before and after it is shared.
+// Split in three so that the LDS-tiled kernel can substitute its own evaluation of the radial blur (:21-33):
+//   visualizer_consts  everything that depends on uniforms only (evaluated once per frame on the fast path,
+//                      per fragment on the generic path: same operations, same bits),
+//   visualizer_pre     camera + background coordinate of the fragment (:7-18),
+//   visualizer_post    everything after the blur (:36-73).
+struct VisualizerConsts {
+    float zoom2;            // z*z, z = 0.95 + 0.01*sin(iTime) - 0.02*iAudioVolume - 0.03      (:17, shaderflow.glsl:361-363)
+    float off_x, off_y;     // 0.005*cos(iTime*3.25135), 0.005*sin(iTime*1.153469)             (:18)
+    float intensity;        // 0.01*clamp(pow(iAudioVolume, 2.5), 0, 0.3)                      (:22)
+    float flash;            // 5*iAudioSTD                                                     (:36)
+    float rot_c, rot_s;     // cos(-PI/2), sin(-PI/2)                                          (:39)
+    float shrink;           // 1 - 0.4*pow(abs(iAudioVolume), 0.5)                             (:40)
+    float vig_exp;          // 0.1 + 0.15*iAudioVolume                                         (:66)
+};
+
+SF_HD VisualizerConsts visualizer_consts(float iTime, float iAudioVolume, float iAudioSTD) {
+    VisualizerConsts c;
+    const float z = 0.95f + 0.01f*sf::sin(iTime) - 0.02f*iAudioVolume - 0.03f;
+    c.zoom2 = z*z;
+    c.off_x = 0.005f*sf::cos(iTime*3.25135f);
+    c.off_y = 0.005f*sf::sin(iTime*1.153469f);
+    c.intensity = 0.01f*sf::clamp(sf::pow(iAudioVolume, 2.5f), 0.0f, 0.3f);
+    c.flash = 5.0f*iAudioSTD;
+    c.rot_c = sf::cos(-PI/2.0f);
+    c.rot_s = sf::sin(-PI/2.0f);
+    c.shrink = 1.0f - 0.4f*sf::pow(sf::abs(iAudioVolume), 0.5f);
+    c.vig_exp = 0.1f + 0.15f*iAudioVolume;
+    return c;
+}
+
 struct VisualizerPre {
     vec2 uv, bg;            // iCamera.gluv, background_uv
-    float intensity;
     bool out_of_bounds;
 };
 
-SF_HD VisualizerPre visualizer_pre(const Frag& f) {
-    const Uniforms& u = *f.u;
+SF_HD VisualizerPre visualizer_pre(const Frag& f, const VisualizerConsts& c) {
     Camera cam = get_camera(f);
     VisualizerPre p;
     p.uv = cam.gluv;
     p.out_of_bounds = cam.out_of_bounds;
-    p.bg = zoom(gluv2stuv(p.uv), 0.95f + 0.01f*sf::sin(u.iTime) - 0.02f*u.iAudioVolume - 0.03f, vec2{0.5f, 0.5f});   // :17
-    p.bg = p.bg + 0.005f*vec2{sf::cos(u.iTime*3.25135f), sf::sin(u.iTime*1.153469f)};                                  // :18
-    p.intensity = 0.01f*sf::clamp(sf::pow(u.iAudioVolume, 2.5f), 0.0f, 0.3f);                                         // :22
+    p.bg = (gluv2stuv(p.uv) - vec2{0.5f, 0.5f})*c.zoom2 + vec2{0.5f, 0.5f};                   // zoom(uv, z, vec2(0.5)) :17
+    p.bg = p.bg + vec2{c.off_x, c.off_y};                                                      // :18
     return p;
 }
 
 // :19-33 as written: centre tap + 9 directions x 10 steps (the float loop counters are binary32)
-SF_HD vec4 visualizer_blur_reference(const Frag& f, const VisualizerPre& p) {
+SF_HD vec4 visualizer_blur_reference(const Frag& f, const VisualizerPre& p, const VisualizerConsts& c) {
     const Tex& background = f.tex[TEX_BACKGROUND];
     vec4 color = stexture(background, p.bg);
     const float quality = 10.0f, directions = 8.0f;
     for (float angle = 0.0f; angle < TAU; angle += TAU/directions) {
         for (float walk = 1.0f/quality; walk <= 1.001f; walk += 1.0f/quality) {
-            vec2 displacement = vec2{sf::cos(angle), sf::sin(angle)}*walk*p.intensity;
+            vec2 displacement = vec2{sf::cos(angle), sf::sin(angle)}*walk*c.intensity;
             color = color + stexture(background, p.bg + displacement);
         }
     }
     return color/(quality*directions);
 }
 
-SF_HD vec4 visualizer_post(const Frag& f, const VisualizerPre& p, vec4 col) {
-    const Uniforms& u = *f.u;
+SF_HD vec4 visualizer_post(const Frag& f, const VisualizerPre& p, const VisualizerConsts& c, vec4 col) {
     const vec3 space = vec3{1.0f, 11.0f, 26.0f}/255.0f;                                        // :9
-    col = col*(1.0f + 5.0f*u.iAudioSTD*sf::pow(sf::clamp(length(f.agluv) - 0.3f, 0.0f, 1.0f), 6.0f));   // :36
+    col = col*(1.0f + c.flash*sf::pow(sf::clamp(length(f.agluv) - 0.3f, 0.0f, 1.0f), 6.0f));  // :36
 
-    vec2 music_uv = rotate2d_apply(-PI/2.0f, p.uv);                                            // :39
-    music_uv = music_uv*(1.0f - 0.4f*sf::pow(sf::abs(u.iAudioVolume), 0.5f));                  // :40
+    vec2 music_uv = {c.rot_c*p.uv.x + c.rot_s*p.uv.y, (-c.rot_s)*p.uv.x + c.rot_c*p.uv.y};     // rotate2d(-PI/2)*uv :39
+    music_uv = music_uv*c.shrink;                                                              // :40
     const float radius = 0.17f;
 
     float circle = sf::abs(atan1n(music_uv));                                                  // :44
@@ -130,7 +154,7 @@ SF_HD vec4 visualizer_post(const Frag& f, const VisualizerPre& p, vec4 col) {
     set_rgb(col, mix(rgb(col), space, sf::smoothstep(0.0f, 1.0f, length(p.uv)/20.0f)));       // :62
 
     vec2 vig = f.astuv*vec2{1.0f - f.astuv.y, 1.0f - f.astuv.x};                               // :65
-    set_rgb(col, rgb(col)*sf::pow(vig.x*vig.y*20.0f, 0.1f + 0.15f*u.iAudioVolume));            // :66
+    set_rgb(col, rgb(col)*sf::pow(vig.x*vig.y*20.0f, c.vig_exp));                              // :66
     col.w = 1.0f;
 
     vec4 w = texture(f.tex[TEX_WAVEFORM], vec2{f.astuv.x, 0.0f});                              // :71
@@ -141,12 +165,13 @@ SF_HD vec4 visualizer_post(const Frag& f, const VisualizerPre& p, vec4 col) {
 }
 
 SF_HD vec4 frag_visualizer(const Frag& f) {
-    VisualizerPre p = visualizer_pre(f);
+    const VisualizerConsts c = visualizer_consts(f.u->iTime, f.u->iAudioVolume, f.u->iAudioSTD);
+    VisualizerPre p = visualizer_pre(f, c);
     if (p.out_of_bounds) {                                                                     // :11-14
         const vec3 space = vec3{1.0f, 11.0f, 26.0f}/255.0f;
         return {space.x, space.y, space.z, 0.0f};
     }
-    return visualizer_post(f, p, visualizer_blur_reference(f, p));
+    return visualizer_post(f, p, c, visualizer_blur_reference(f, p, c));
 }
 
 // ---- bars.frag / waveform.frag ---------------------------------------------------------------------

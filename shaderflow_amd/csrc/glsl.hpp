@@ -55,6 +55,7 @@ struct Tex {                       // one TextureBox of texture.py:56-70, rows b
 };
 
 SF_HD int wrap_texel(int i, int size, int repeat) {
+    if ((unsigned)i < (unsigned)size) return i;    // inside the texture: no integer division
     if (repeat) { int m = i % size; return (m < 0) ? m + size : m; }
     return (i < 0) ? 0 : ((i >= size) ? size - 1 : i);
 }
@@ -161,10 +162,11 @@ struct Frag {
 SF_HD vec2 gluv2stuv(vec2 g) { return (g + 1.0f)/2.0f; }          // shaderflow.glsl:95
 SF_HD vec2 stuv2gluv(vec2 s) { return (s*2.0f) - 1.0f; }          // shaderflow.glsl:91
 
-SF_HD void make_varyings(Frag& f, int i, int j, int wr, int hr) {
+// `aspect` = iResolution.x/iResolution.y, the same IEEE division done once by the caller
+SF_HD void make_varyings(Frag& f, int i, int j, int wr, int hr, float aspect) {
     const Uniforms& u = *f.u;
     vec2 res = {u.iResolution[0], u.iResolution[1]};
-    f.aspect = res.x/res.y;
+    f.aspect = aspect;
     vec2 centre = {((float)i + 0.5f)/(float)wr, ((float)j + 0.5f)/(float)hr};
     f.agluv = centre*2.0f - 1.0f;
     f.gluv = f.agluv*vec2{f.aspect, 1.0f};                         // agluv2gluv, shaderflow.glsl:99

@@ -34,6 +34,12 @@ struct RenderArgs {
     int frame0;
     // radial-blur tap table of visualizer.frag:26-31 (unit displacements cos/sin(angle)*walk)
     float tap_x[81], tap_y[81];
+    // visualizer.frag terms that depend on uniforms only: per frame on the device (tape), or by value
+    const VisualizerConsts* vis_consts;
+    VisualizerConsts vis;
+    int has_vis;
+    float one;                       // 1.0f, kept opaque to the optimiser (visualizer_kernels.hpp tap())
+    float aspect;                    // iResolution.x/iResolution.y (iAspectRatio, shaderflow.glsl:16), divided once on the host
 };
 
 __device__ __forceinline__ void frame_view(const RenderArgs& a, int frame, Uniforms& u, Tex* tex) {
@@ -73,10 +79,12 @@ __device__ __forceinline__ void store_target(const RenderArgs& a, long frame, in
 // A kernel shades its supersamples in two passes around one block-cooperative step: pre() per sample,
 // setup() once per block (may stage LDS and synchronise), run() per sample.
 template <int FRAGMENT> struct PlainShader {
+    static constexpr int BLOCK_W = 64, BLOCK_H = 4;      // unfused block shape
+    static constexpr int MIN_WAVES_PER_SIMD = 1;
     struct State {};
     struct Shared {};
     __device__ static void pre(const RenderArgs&, const Frag&, bool, State&) {}
-    template <int N> __device__ static void setup(const RenderArgs&, const Tex*, State (&)[N], const bool (&)[N], Shared&) {}
+    template <int N> __device__ static void setup(const RenderArgs&, const Tex*, const Frag&, State (&)[N], const bool (&)[N], Shared&) {}
     __device__ static vec4 run(const RenderArgs&, const Frag& f, const State&, const Shared&) { return shade<FRAGMENT>(f); }
 };
 
@@ -84,17 +92,17 @@ template <int FRAGMENT> struct PlainShader {
 template <class SHADER>
 __global__ __launch_bounds__(256) void k_render(const RenderArgs a) {
     __shared__ typename SHADER::Shared shared;
-    const int i = blockIdx.x*64 + threadIdx.x;
-    const int j = blockIdx.y*4 + threadIdx.y;
+    const int i = blockIdx.x*SHADER::BLOCK_W + threadIdx.x;
+    const int j = blockIdx.y*SHADER::BLOCK_H + threadIdx.y;
     Uniforms u; Tex tex[TEX_SLOTS];
     frame_view(a, blockIdx.z, u, tex);
     const bool inside = (i < a.wr) && (j < a.hr);
     Frag f; f.u = &u; f.tex = tex;
-    make_varyings(f, i, j, a.wr, a.hr);
+    make_varyings(f, i, j, a.wr, a.hr, a.aspect);
     typename SHADER::State state[1];
     const bool valid[1] = {inside};
     SHADER::pre(a, f, inside, state[0]);
-    SHADER::template setup<1>(a, tex, state, valid, shared);
+    SHADER::template setup<1>(a, tex, f, state, valid, shared);
     if (inside) store_target(a, blockIdx.z, i, j, SHADER::run(a, f, state[0], shared));
 }
 
@@ -141,46 +149,56 @@ __device__ __forceinline__ uint32_t quad_lane1(uint32_t v) { return dpp_u32<0x55
 __device__ __forceinline__ uint32_t quad_lane2(uint32_t v) { return dpp_u32<0xAA>(v); }
 __device__ __forceinline__ uint32_t quad_lane3(uint32_t v) { return dpp_u32<0xFF>(v); }
 
-__device__ __forceinline__ vec3 unpack_rgb_unorm(uint32_t q) {
-    return {(float)(q & 255u)/255.0f, (float)((q >> 8) & 255u)/255.0f, (float)((q >> 16) & 255u)/255.0f};
+__device__ __forceinline__ float unorm_channel(uint32_t q, int shift) { return (float)((q >> shift) & 255u)/255.0f; }
+
+// The iScreen texel a supersample becomes (RGBA8 unorm), then final.glsl (:13-31) over the S x S block of one
+// output pixel, for ONE colour channel (bits [shift, shift+8) of the packed texels). q[] holds the block in texel
+// order q[y*S + x]. Taps land on texel centres (S == K) or on the centre of 2x2 texels (S == 2K); the reference's
+// bilinear weights are then 1 or 1/4 up to the rounding of the tap coordinate.
+template <int S, int K>
+__device__ __forceinline__ float resolve_channel(const uint32_t (&q)[S*S], int shift) {
+    float acc = 0.0f;
+    if constexpr (K == S) {                          // taps on texel centres, x-major like final.glsl:23-28
+#pragma unroll
+        for (int x = 0; x < S; x++)
+#pragma unroll
+            for (int y = 0; y < S; y++) acc = acc + unorm_channel(q[y*S + x], shift);
+        return acc/(float)(S*S);
+    } else {
+        constexpr int G = S/K;                       // == 2: each tap is the mean of a 2x2 group
+        static_assert(G == 2, "fused resolve needs S == K or S == 2K");
+#pragma unroll
+        for (int x = 0; x < K; x++) {
+#pragma unroll
+            for (int y = 0; y < K; y++) {
+                const float tap = bilerp(0.25f, 0.25f, 0.25f, 0.25f,
+                                         unorm_channel(q[(y*G)*S + x*G], shift), unorm_channel(q[(y*G)*S + x*G + 1], shift),
+                                         unorm_channel(q[(y*G + 1)*S + x*G], shift), unorm_channel(q[(y*G + 1)*S + x*G + 1], shift));
+                acc = (K == 1) ? tap : acc + tap;
+            }
+        }
+        return (K == 1) ? acc : acc/(float)(K*K);
+    }
 }
 
-// The iScreen texel a supersample becomes (RGBA8 unorm), then final.glsl over the S x S block of one
-// output pixel. q[] holds the block in texel order q[y*S + x]. Taps land on texel centres (S == k)
-// or on the centre of 2x2 texels (S == 2k); the reference's bilinear weights are then 1 or 1/4 up to
-// the rounding of the tap coordinate.
 template <int S>
-__device__ __forceinline__ vec3 resolve_block(const uint32_t* q, int kernel) {
-    vec3 acc = {0.0f, 0.0f, 0.0f};
-    if (kernel == S) {                               // taps on texel centres, x-major like :23-28
-        for (int x = 0; x < S; x++) for (int y = 0; y < S; y++) acc = acc + unpack_rgb_unorm(q[y*S + x]);
-        return acc/(float)(S*S);
-    }
-    const int g = S/kernel;                          // == 2: each tap is the mean of a 2x2 group
-    for (int x = 0; x < kernel; x++) {
-        for (int y = 0; y < kernel; y++) {
-            vec3 t00 = unpack_rgb_unorm(q[(y*g)*S + x*g]), t10 = unpack_rgb_unorm(q[(y*g)*S + x*g + 1]);
-            vec3 t01 = unpack_rgb_unorm(q[(y*g + 1)*S + x*g]), t11 = unpack_rgb_unorm(q[(y*g + 1)*S + x*g + 1]);
-            vec3 tap = {bilerp(0.25f, 0.25f, 0.25f, 0.25f, t00.x, t10.x, t01.x, t11.x),
-                        bilerp(0.25f, 0.25f, 0.25f, 0.25f, t00.y, t10.y, t01.y, t11.y),
-                        bilerp(0.25f, 0.25f, 0.25f, 0.25f, t00.z, t10.z, t01.z, t11.z)};
-            acc = (kernel == 1) ? tap : acc + tap;
-        }
-    }
-    return (kernel == 1) ? acc : acc/(float)(kernel*kernel);
+__device__ __forceinline__ uint32_t resolve_channel_any(const uint32_t (&q)[S*S], int kernel, int shift) {
+    float c;
+    if constexpr (S == 1) c = resolve_channel<1, 1>(q, shift);
+    else if constexpr (S == 2) c = (kernel == 2) ? resolve_channel<2, 2>(q, shift) : resolve_channel<2, 1>(q, shift);
+    else c = (kernel == 4) ? resolve_channel<4, 4>(q, shift) : resolve_channel<4, 2>(q, shift);
+    return unorm8(c);
 }
 
 __host__ __device__ inline bool fused_supported(int s, int kernel) {
     return (s == 1 && kernel == 1) || (s == 2 && (kernel == 2 || kernel == 1)) || (s == 4 && (kernel == 4 || kernel == 2));
 }
 
-// Row-band interleave: linear block id → (row, column-block) such that consecutive ids (which the
-// dispatcher spreads over the 8 XCDs) walk down 8 different 8-row bands while each XCD keeps to its own.
-__device__ __forceinline__ void fused_block_coords(int blocks_x, int h, int& bx, int& row) {
-    const int b = blockIdx.x;
-    bx = b % blocks_x;
-    row = b / blocks_x;
-    (void)h;
+// Block id → tile. The dispatcher places block b on XCD b % 8 (observed, never relied on for correctness): giving
+// XCD k the k-th eighth of the (row-major) tile list keeps one horizontal band of the frame — and the band of
+// background texels under it — in one XCD's 4 MiB L2.
+__device__ __forceinline__ int xcd_band_order(int b, int nblocks) {
+    return (nblocks % 8 == 0) ? (b % 8)*(nblocks/8) + (b/8) : b;
 }
 
 // Writes one row segment of 128 RGB8 pixels (384 B) staged in LDS with 16-byte stores
@@ -195,12 +213,14 @@ __device__ __forceinline__ void store_rgb_row(uint8_t* out_row, int x0, int w, c
     }
 }
 
-// ---- K6+K8 fused, generic fragment ----------------------------------------------------------------------
-// S == 1: one lane per output pixel (128 threads... we use 256 = 128 px x 2 rows).
+// ---- K6+K8 fused ------------------------------------------------------------------------------------------
+// S == 1: one lane per output pixel (256 threads = 128 px x 2 rows).
 // S == 2: four lanes (a quad) per output pixel, one supersample each.
 // S == 4: a quad per output pixel, each lane owns a 2x2 group of supersamples.
+// After shading, every lane of a quad receives the quad's packed RGBA8 texels through DPP quad_perm moves and
+// lane c of the quad resolves colour channel c (lane 3 idles); lane 0 collects the three bytes.
 template <class SHADER, int S>
-__global__ __launch_bounds__(512) void k_render_resolve(const RenderArgs a) {
+__global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_resolve(const RenderArgs a) {
     constexpr int LANES = (S == 1) ? 1 : 4;
     constexpr int PER_LANE = (S*S)/LANES;            // 1, 1, 4
     constexpr int G = (S == 4) ? 2 : 1;              // side of the group one lane owns
@@ -210,7 +230,8 @@ __global__ __launch_bounds__(512) void k_render_resolve(const RenderArgs a) {
     frame_view(a, blockIdx.z, u, tex);
     const int blocks_x = (a.w + 127)/128;
     const int rows_per_block = (S == 1) ? 2 : 1;
-    const int bx = blockIdx.x % blocks_x, by = blockIdx.x / blocks_x;
+    const int tile = xcd_band_order(blockIdx.x, gridDim.x);
+    const int bx = tile % blocks_x, by = tile / blocks_x;
     const int tid = threadIdx.x;
     const int p = tid / LANES, sub = tid % LANES;
     const int prow = (S == 1) ? (p / 128) : 0;
@@ -225,17 +246,19 @@ __global__ __launch_bounds__(512) void k_render_resolve(const RenderArgs a) {
 #pragma unroll
     for (int n = 0; n < PER_LANE; n++) {
         const int gx = (sub & 1)*G + (n % G), gy = (sub >> 1)*G + (n / G);      // position inside the S x S block
-        make_varyings(f, px*S + gx, py*S + gy, a.wr, a.hr);
+        make_varyings(f, px*S + gx, py*S + gy, a.wr, a.hr, a.aspect);
         valid[n] = inside;
         SHADER::pre(a, f, inside, state[n]);
     }
-    SHADER::template setup<PER_LANE>(a, tex, state, valid, shared);
+    SHADER::template setup<PER_LANE>(a, tex, f, state, valid, shared);
 #pragma unroll
     for (int n = 0; n < PER_LANE; n++) {
-        const int gx = (sub & 1)*G + (n % G), gy = (sub >> 1)*G + (n / G);
         uint32_t q = 0;
         if (inside) {
-            make_varyings(f, px*S + gx, py*S + gy, a.wr, a.hr);
+            if constexpr (PER_LANE > 1) {            // with one sample per lane the varyings of pass 1 are still live
+                const int gx = (sub & 1)*G + (n % G), gy = (sub >> 1)*G + (n / G);
+                make_varyings(f, px*S + gx, py*S + gy, a.wr, a.hr, a.aspect);
+            }
             q = pack_rgba8(SHADER::run(a, f, state[n], shared));
         }
         mine[n] = q;
@@ -244,6 +267,12 @@ __global__ __launch_bounds__(512) void k_render_resolve(const RenderArgs a) {
     uint32_t block[S*S];
     if constexpr (S == 1) {
         block[0] = mine[0];
+        if (inside) {
+            uint8_t* s = &staged[prow][(p % 128)*3];
+            s[0] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 0);
+            s[1] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 8);
+            s[2] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 16);
+        }
     } else {
 #pragma unroll
         for (int n = 0; n < PER_LANE; n++) {
@@ -254,11 +283,12 @@ __global__ __launch_bounds__(512) void k_render_resolve(const RenderArgs a) {
             block[(1*G + oy)*S + 0*G + ox] = l2;
             block[(1*G + oy)*S + 1*G + ox] = l3;
         }
-    }
-    if (inside && sub == 0) {
-        vec3 c = resolve_block<S>(block, a.subsample);
-        uint8_t* s = &staged[prow][(p % 128)*3];
-        s[0] = (uint8_t)unorm8(c.x); s[1] = (uint8_t)unorm8(c.y); s[2] = (uint8_t)unorm8(c.z);
+        const uint32_t channel = resolve_channel_any<S>(block, a.subsample, 8*(sub < 3 ? sub : 0));
+        const uint32_t green = quad_lane1(channel), blue = quad_lane2(channel);
+        if (inside && sub == 0) {
+            uint8_t* s = &staged[prow][(p % 128)*3];
+            s[0] = (uint8_t)channel; s[1] = (uint8_t)green; s[2] = (uint8_t)blue;
+        }
     }
     __syncthreads();
     uint8_t* frame = (uint8_t*)a.out + (long)blockIdx.z*a.out_frame_stride;

@@ -1,54 +1,75 @@
 // visualizer_kernels.hpp — visualizer.frag with its radial blur (examples/basic/shaders/visualizer.frag:21-33)
 // evaluated from an LDS-staged tile of the background texture.
 //
-// The blur is 1 + 9x10 bilinear taps of the background per supersample: ~3.0 G taps per 4K 2xSSAA
-// frame, so this loop IS the frame time (FP32 VALU bound, not HBM bound). Every tap of
-// every supersample of a block falls inside one small window of the background, so the block:
+// The blur is 1 + 9x10 bilinear taps of the background per supersample: ~3.0 G taps per 4K 2xSSAA frame, so this
+// loop IS the frame time (FP32 VALU bound, not HBM bound). Every tap of every supersample of
+// a block falls inside one small window of the background, so the block:
 //   1. reduces the bounding box of its centre taps (wave shuffles + LDS),
-//   2. stages that window once — wrapped/clamped per texture.py:274-283 — as float16 texel PAIRS
-//      {T[x,y], T[x+1,y]} (16 B per position: one ds_read_b128 per bilinear row),
-//   3. runs the taps in tile-local texel coordinates: 2 fma for the position, floor/fract, 5 weight ops,
-//      12 v_fma_mix_f32 (f16 texel x f32 weight, f32 accumulate — byte values are exact in f16).
-// Direction 8 of the float-counter loop coincides with direction 0 to 3e-9 texel (SURVEY.md §7 hard part
-// 4), so direction 0 is evaluated once and counted twice: 81 taps instead of 91.
+//   2. stages that window once — texel addressing (repeat / clamp) per texture.py:274-283 — in the bilinear
+//      "difference basis" of each texel cell, as float16 (byte differences are exact in f16):
+//          A = T00,  B = T10 - T00,  C = T01 - T00,  D = T00 - T10 - T01 + T11        (per channel)
+//      so that a tap at fractional position (ax, ay) of the cell is  A + ax*B + ay*C + (ax*ay)*D ;
+//      32 bytes per cell: two ds_read_b128 per tap;
+//   3. runs the taps in tile-local texel coordinates: 2 fma (position), 2 v_fract, 2 v_cvt_i32 (the window origin
+//      makes positions non-negative, so truncation is floor), 2 address ops, 1 multiply and 12 v_fma_mix_f32
+//      (f16 texel term x f32 weight, f32 accumulate) = 21 VALU instructions per tap.
+// Direction 8 of the float-counter loop coincides with direction 0 to 3e-9 texel (SURVEY.md §7 hard part 4), so
+// direction 0 is evaluated once and counted twice: 81 taps instead of 91.
+// Everything that depends on uniforms only (sin/cos of iTime, pow of the volume, …) is evaluated once per frame
+// (k_visualizer_consts, or by the host for single launches) instead of once per supersample.
 //
-// Accuracy contract: the tap POSITIONS differ from the generic chain (glsl.hpp stexture) by the rounding
-// of an affine re-association (≤ 1e-4 texel) and the sum is scaled by 1/255 once instead of per texel:
-// ≤ 1e-6 relative on the blurred colour, i.e. far inside the 1 LSB pixel tolerance. Everything outside
-// the blur (visualizer_pre / visualizer_post) is the same code as the generic kernel. If the window
-// does not fit the tile (huge background, extreme zoom) the block falls back to the generic taps.
+// Accuracy contract: tap POSITIONS differ from the generic chain (glsl.hpp stexture) by the rounding of an affine
+// re-association (≤ 1e-4 texel), the bilinear sum is re-associated and scaled by 1/255 once instead of per texel:
+// ≤ 1e-6 relative on the blurred colour, far inside the 1 LSB pixel tolerance. Everything outside the blur is the
+// same code as the generic kernel. If the window does not fit the tile the block falls back to the generic taps.
 #pragma once
 
 #include "render_kernels.hpp"
 
 namespace sf {
 
-constexpr int TILE_PITCH = 128;      // positions per tile row (16 B each)
-constexpr int TILE_ROWS = 16;
+constexpr int TILE_PITCH = 128;      // cells per tile row (32 B each)
+constexpr int TILE_ROWS = 12;
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+__global__ void k_visualizer_consts(const FrameDyn* __restrict__ dyn, int frame0, int nframes, VisualizerConsts* __restrict__ out) {
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= nframes) return;
+    const FrameDyn d = dyn[frame0 + k];
+    out[frame0 + k] = visualizer_consts(d.iTime, d.iAudioVolume, d.iAudioSTD);
+}
 
 struct VisualizerShader {
+    static constexpr int BLOCK_W = 128, BLOCK_H = 2;     // unfused block shape (render_kernels.hpp k_render)
+    static constexpr int MIN_WAVES_PER_SIMD = 1;
+
     struct State {
         VisualizerPre pre;
         float xc, yc;                // centre tap in texel space (u*w - 0.5, v*h - 0.5)
     };
     struct Shared {
-        half8 tile[TILE_ROWS*TILE_PITCH];
-        float red[5][8];
-        int x0, y0, ok;
+        half8 tile[TILE_ROWS*TILE_PITCH*2];
+        float red[5][16];
+        VisualizerConsts consts;
+        int x0, y0, tw, th, ok;
     };
 
-    __device__ static void pre(const RenderArgs&, const Frag& f, bool valid, State& s) {
-        s.pre = visualizer_pre(f);
+    __device__ static VisualizerConsts frame_consts(const RenderArgs& a, const Frag& f) {
+        if (a.vis_consts) return a.vis_consts[a.frame0 + blockIdx.z];
+        if (a.has_vis) return a.vis;
+        return visualizer_consts(f.u->iTime, f.u->iAudioVolume, f.u->iAudioSTD);
+    }
+
+    __device__ static void pre(const RenderArgs& a, const Frag& f, bool, State& s) {
+        const VisualizerConsts c = frame_consts(a, f);
+        s.pre = visualizer_pre(f, c);
         const Tex& bg = f.tex[TEX_BACKGROUND];
         // same chain as stexture() → texture() for the centre tap (glsl.hpp)
         vec2 scale = {(float)bg.height/(float)bg.width, 1.0f};
         vec2 st = gluv2stuv(stuv2gluv(s.pre.bg)*scale);
         s.xc = st.x*(float)bg.width - 0.5f;
         s.yc = st.y*(float)bg.height - 0.5f;
-        (void)valid;
     }
 
     __device__ static float wave_min(float v) {
@@ -57,94 +78,108 @@ struct VisualizerShader {
     }
 
     template <int N>
-    __device__ static void setup(const RenderArgs& a, const Tex* tex, State (&s)[N], const bool (&valid)[N], Shared& sh) {
+    __device__ static void setup(const RenderArgs& a, const Tex* tex, const Frag& f, State (&s)[N], const bool (&valid)[N], Shared& sh) {
         const Tex& bg = tex[TEX_BACKGROUND];
         const int tid = threadIdx.y*blockDim.x + threadIdx.x, nthreads = blockDim.x*blockDim.y;
         const int wave = tid >> 6, nwaves = (nthreads + 63) >> 6;
+        const VisualizerConsts c = frame_consts(a, f);
         // 1. bounding box of the centre taps (as minima of x, -x, y, -y)
-        float lo_x = INFINITY, hi_x = INFINITY, lo_y = INFINITY, hi_y = INFINITY, neg_i = INFINITY;
-        bool any = false, bad = false;
+        float lo_x = INFINITY, hi_x = INFINITY, lo_y = INFINITY, hi_y = INFINITY;
+        bool bad = !(c.intensity == c.intensity);
 #pragma unroll
         for (int n = 0; n < N; n++) {
             if (valid[n] && !s[n].pre.out_of_bounds) {
-                any = true;
-                bad = bad || !(fabsf(s[n].xc) < 1e8f) || !(fabsf(s[n].yc) < 1e8f) || !(s[n].pre.intensity == s[n].pre.intensity);
+                bad = bad || !(fabsf(s[n].xc) < 1e8f) || !(fabsf(s[n].yc) < 1e8f);
                 lo_x = fminf(lo_x, s[n].xc); hi_x = fminf(hi_x, -s[n].xc);
                 lo_y = fminf(lo_y, s[n].yc); hi_y = fminf(hi_y, -s[n].yc);
-                neg_i = fminf(neg_i, -fabsf(s[n].pre.intensity));
             }
         }
-        lo_x = wave_min(lo_x); hi_x = wave_min(hi_x); lo_y = wave_min(lo_y); hi_y = wave_min(hi_y); neg_i = wave_min(neg_i);
+        lo_x = wave_min(lo_x); hi_x = wave_min(hi_x); lo_y = wave_min(lo_y); hi_y = wave_min(hi_y);
         const int n_bad = __syncthreads_count(bad ? 1 : 0);
-        if ((tid & 63) == 0) { sh.red[0][wave] = lo_x; sh.red[1][wave] = hi_x; sh.red[2][wave] = lo_y; sh.red[3][wave] = hi_y; sh.red[4][wave] = neg_i; }
+        if ((tid & 63) == 0) { sh.red[0][wave] = lo_x; sh.red[1][wave] = hi_x; sh.red[2][wave] = lo_y; sh.red[3][wave] = hi_y; }
         __syncthreads();
         if (tid == 0) {
-            float m[5];
-            for (int k = 0; k < 5; k++) { m[k] = sh.red[k][0]; for (int w = 1; w < nwaves; w++) m[k] = fminf(m[k], sh.red[k][w]); }
+            float m[4];
+            for (int k = 0; k < 4; k++) { m[k] = sh.red[k][0]; for (int w = 1; w < nwaves; w++) m[k] = fminf(m[k], sh.red[k][w]); }
             // tap radius in texels: |cos|,|sin| <= 1, walk <= 1.0000001 (visualizer.frag:26-28)
-            float intensity = -m[4];                         // uniform over the frame (visualizer.frag:22)
-            float rx = fabsf(intensity*((float)bg.height/(float)bg.width)*(float)bg.width)*1.001f + 0.001f;
-            float ry = fabsf(intensity*(float)bg.height)*1.001f + 0.001f;
-            int ok = 0, x0 = 0, y0 = 0;
-            if (n_bad == 0 && m[0] < INFINITY && rx == rx && rx < 64.0f && ry < 64.0f) {
+            const float rx = fabsf(c.intensity*((float)bg.height/(float)bg.width)*(float)bg.width)*1.001f + 0.001f;
+            const float ry = fabsf(c.intensity*(float)bg.height)*1.001f + 0.001f;
+            int ok = 0, x0 = 0, y0 = 0, tw = 0, th = 0;
+            if (n_bad == 0 && m[0] < INFINITY && rx < 64.0f && ry < 64.0f) {
                 x0 = (int)floorf(m[0] - rx); y0 = (int)floorf(m[2] - ry);
-                int x1 = (int)floorf(-m[1] + rx) + 1, y1 = (int)floorf(-m[3] + ry) + 1;     // right/top neighbours of the last tap
-                ok = (x1 - x0 + 1 <= TILE_PITCH) && (y1 - y0 + 1 <= TILE_ROWS);
-                if (ok) { sh.red[0][0] = (float)(x1 - x0 + 1); sh.red[0][1] = (float)(y1 - y0 + 1); }
+                tw = (int)floorf(-m[1] + rx) - x0 + 1;                // cells [x0, x0+tw) hold every tap's floor()
+                th = (int)floorf(-m[3] + ry) - y0 + 1;
+                ok = (tw <= TILE_PITCH) && (th <= TILE_ROWS);
             } else if (n_bad == 0 && !(m[0] < INFINITY)) {
-                ok = 2;                                      // nothing to blur in this block
+                ok = 2;                                               // nothing to blur in this block
             }
-            sh.x0 = x0; sh.y0 = y0; sh.ok = ok;
+            sh.x0 = x0; sh.y0 = y0; sh.tw = tw; sh.th = th; sh.ok = ok;
+            sh.consts = c;
         }
         __syncthreads();
         if (sh.ok != 1) return;
-        // 2. stage {T[x,y], T[x+1,y]} as float16, addressing per texture.py:274-283 (repeat or clamp)
-        const int tw = (int)sh.red[0][0], th = (int)sh.red[0][1];
-        const int x0 = sh.x0, y0 = sh.y0;
+        // 2. stage the cells
+        const int tw = sh.tw, th = sh.th, x0 = sh.x0, y0 = sh.y0;
         const uint8_t* data = (const uint8_t*)bg.data;
         const int comps = bg.components;
         for (int idx = tid; idx < tw*th; idx += nthreads) {
             const int ty = idx / tw, tx = idx - ty*tw;
-            const int j = wrap_texel(y0 + ty, bg.height, bg.repeat_y);
+            const int j0 = wrap_texel(y0 + ty, bg.height, bg.repeat_y), j1 = wrap_texel(y0 + ty + 1, bg.height, bg.repeat_y);
             const int i0 = wrap_texel(x0 + tx, bg.width, bg.repeat_x), i1 = wrap_texel(x0 + tx + 1, bg.width, bg.repeat_x);
-            const uint8_t* p0 = data + ((long)j*bg.width + i0)*comps;
-            const uint8_t* p1 = data + ((long)j*bg.width + i1)*comps;
-            half8 v;
-            v[0] = (_Float16)(float)p0[0]; v[1] = (_Float16)(float)p0[1]; v[2] = (_Float16)(float)p0[2]; v[3] = (_Float16)0.0f;
-            v[4] = (_Float16)(float)p1[0]; v[5] = (_Float16)(float)p1[1]; v[6] = (_Float16)(float)p1[2]; v[7] = (_Float16)0.0f;
-            sh.tile[ty*TILE_PITCH + tx] = v;
+            const uint8_t* p00 = data + ((long)j0*bg.width + i0)*comps;
+            const uint8_t* p10 = data + ((long)j0*bg.width + i1)*comps;
+            const uint8_t* p01 = data + ((long)j1*bg.width + i0)*comps;
+            const uint8_t* p11 = data + ((long)j1*bg.width + i1)*comps;
+            half8 lo, hi;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const int t00 = p00[ch], t10 = p10[ch], t01 = p01[ch], t11 = p11[ch];
+                const _Float16 A = (_Float16)(float)t00, B = (_Float16)(float)(t10 - t00);
+                const _Float16 C = (_Float16)(float)(t01 - t00), D = (_Float16)(float)(t00 - t10 - t01 + t11);
+                // lo = {Ar Ag Ab Br | Bg Bb Cr Cg}, hi = {Cb Dr Dg Db | 0 0 0 0}
+                if (ch == 0) { lo[0] = A; lo[3] = B; lo[6] = C; hi[1] = D; }
+                if (ch == 1) { lo[1] = A; lo[4] = B; lo[7] = C; hi[2] = D; }
+                if (ch == 2) { lo[2] = A; lo[5] = B; hi[0] = C; hi[3] = D; }
+            }
+            hi[4] = hi[5] = hi[6] = hi[7] = (_Float16)0.0f;
+            sh.tile[(ty*TILE_PITCH + tx)*2] = lo;
+            sh.tile[(ty*TILE_PITCH + tx)*2 + 1] = hi;
         }
         __syncthreads();
-        (void)any;
     }
 
-    __device__ __forceinline__ static void tap(const half8* tile, float x, float y, float& r, float& g, float& b) {
-        const float fx = floorf(x), fy = floorf(y);
-        const float ax = x - fx, ay = y - fy;
-        const half8* p = tile + (int)fy*TILE_PITCH + (int)fx;
-        const half8 lo = p[0], hi = p[TILE_PITCH];
-        const float w11 = ax*ay;
-        const float w10 = ax - w11, w01 = ay - w11;
-        const float w00 = (1.0f - ax) - w01;
-        r = fmaf(w00, (float)lo[0], r); g = fmaf(w00, (float)lo[1], g); b = fmaf(w00, (float)lo[2], b);
-        r = fmaf(w10, (float)lo[4], r); g = fmaf(w10, (float)lo[5], g); b = fmaf(w10, (float)lo[6], b);
-        r = fmaf(w01, (float)hi[0], r); g = fmaf(w01, (float)hi[1], g); b = fmaf(w01, (float)hi[2], b);
-        r = fmaf(w11, (float)hi[4], r); g = fmaf(w11, (float)hi[5], g); b = fmaf(w11, (float)hi[6], b);
+    __device__ __forceinline__ static void tap(const half8* tile, float x, float y, float one, float& r, float& g, float& b) {
+        const float ax = __builtin_amdgcn_fractf(x), ay = __builtin_amdgcn_fractf(y);
+        const int ix = (int)x, iy = (int)y;                           // x, y >= 0 inside the staged window
+        const half8* p = tile + (iy*TILE_PITCH + ix)*2;
+        const half8 lo = p[0], hi = p[1];
+        const float axy = ax*ay;
+        // `one` is 1.0f passed through the kernel arguments: opaque to the optimiser, so the A term stays ONE v_fma_mix_f32
+        // (a literal 1.0 is folded into v_cvt_f32_f16 + v_add_f32)
+        r = fmaf(one, (float)lo[0], r); g = fmaf(one, (float)lo[1], g); b = fmaf(one, (float)lo[2], b);
+        r = fmaf(ax, (float)lo[3], r);   g = fmaf(ax, (float)lo[4], g);   b = fmaf(ax, (float)lo[5], b);
+        r = fmaf(ay, (float)lo[6], r);   g = fmaf(ay, (float)lo[7], g);   b = fmaf(ay, (float)hi[0], b);
+        r = fmaf(axy, (float)hi[1], r);  g = fmaf(axy, (float)hi[2], g);  b = fmaf(axy, (float)hi[3], b);
     }
 
     __device__ static vec4 blur_tile(const RenderArgs& a, const Tex& bg, const State& s, const Shared& sh) {
         const float xr = s.xc - (float)sh.x0, yr = s.yc - (float)sh.y0;
         // displacement of tap k in texels: d_k * intensity * (scale.x*w, h)   (glsl.hpp gtexture)
-        const float ax = s.pre.intensity*((float)bg.height/(float)bg.width)*(float)bg.width;
-        const float ay = s.pre.intensity*(float)bg.height;
+        const float ax = sh.consts.intensity*((float)bg.height/(float)bg.width)*(float)bg.width;
+        const float ay = sh.consts.intensity*(float)bg.height;
         float r = 0.0f, g = 0.0f, b = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 10; k++) tap(sh.tile, fmaf(a.tap_x[k], ax, xr), fmaf(a.tap_y[k], ay, yr), r, g, b);
-        r = r*2.0f; g = g*2.0f; b = b*2.0f;          // direction 8 == direction 0
-        for (int d = 0; d < 71; d += 1) {            // centre tap + directions 1..7
-            const int k = 10 + d;
-            tap(sh.tile, fmaf(a.tap_x[k], ax, xr), fmaf(a.tap_y[k], ay, yr), r, g, b);
+        for (int k = 0; k < 10; k++) tap(sh.tile, fmaf(a.tap_x[k], ax, xr), fmaf(a.tap_y[k], ay, yr), a.one, r, g, b);
+        r = r*2.0f; g = g*2.0f; b = b*2.0f;                           // direction 8 == direction 0
+#pragma unroll 1
+        for (int d = 0; d < 7; d++) {                                 // directions 1..7
+#pragma unroll
+            for (int w = 0; w < 10; w++) {
+                const int k = 11 + d*10 + w;
+                tap(sh.tile, fmaf(a.tap_x[k], ax, xr), fmaf(a.tap_y[k], ay, yr), a.one, r, g, b);
+            }
         }
+        tap(sh.tile, xr, yr, a.one, r, g, b);                                // centre tap (:19)
         const float quality = 10.0f, directions = 8.0f;
         return {(r/255.0f)/(quality*directions), (g/255.0f)/(quality*directions), (b/255.0f)/(quality*directions), 91.0f/(quality*directions)};
     }
@@ -155,8 +190,9 @@ struct VisualizerShader {
             return {space.x, space.y, space.z, 0.0f};
         }
         const Tex& bg = f.tex[TEX_BACKGROUND];
-        vec4 blurred = (sh.ok == 1) ? blur_tile(a, bg, s, sh) : visualizer_blur_reference(f, s.pre);
-        return visualizer_post(f, s.pre, blurred);
+        const VisualizerConsts c = sh.consts;
+        vec4 blurred = (sh.ok == 1) ? blur_tile(a, bg, s, sh) : visualizer_blur_reference(f, s.pre, c);
+        return visualizer_post(f, s.pre, c, blurred);
     }
 };
 
