@@ -81,7 +81,7 @@ static Tex tex_view(const Texture* t) {
 // Context
 
 // visualizer.frag:23-31 evaluated once in binary32: angles 0, τ/8, … (9 of them, the last one coincides with
-// the first), walks 0.1 … 1.0000001. Table order: direction 0 (10 taps), centre tap, directions 1..7.
+// the first), walks 0.1 … 1.0000001. Table order: directions 0..7 (10 taps each), then the centre tap.
 static void build_tap_table(float* tx, float* ty) {
     const float quality = 10.0f, directions = 8.0f;
     int dir = 0, n = 0;
@@ -96,9 +96,8 @@ static void build_tap_table(float* tx, float* ty) {
         ndir++;
     }
     (void)dir;
-    for (int w = 0; w < 10; w++) { tx[n] = cx[0][w]; ty[n] = cy[0][w]; n++; }
-    tx[n] = 0.0f; ty[n] = 0.0f; n++;
-    for (int d = 1; d < 8; d++) for (int w = 0; w < 10; w++) { tx[n] = cx[d][w]; ty[n] = cy[d][w]; n++; }
+    for (int d = 0; d < 8; d++) for (int w = 0; w < 10; w++) { tx[n] = cx[d][w]; ty[n] = cy[d][w]; n++; }
+    tx[n] = 0.0f; ty[n] = 0.0f;                                   // [80]: the centre tap
 }
 
 extern "C" int sfx_ctx_create(int device_id, void* stream, sfx_handle* out) {
@@ -460,7 +459,7 @@ static int launch_render(int fragment, const RenderArgs& a, int frames, hipStrea
         case FRAG_DEFAULT: launch_render_t<PlainShader<FRAG_DEFAULT>>(a, frames, s); break;
         case FRAG_MISSING: launch_render_t<PlainShader<FRAG_MISSING>>(a, frames, s); break;
         case FRAG_VISUALIZER:
-            if (visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) launch_render_t<VisualizerShader>(a, frames, s);
+            if (visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) launch_render_t<VisualizerShader<128, 10, 1>>(a, frames, s);
             else launch_render_t<PlainShader<FRAG_VISUALIZER>>(a, frames, s);
             break;
         case FRAG_BARS: launch_render_t<PlainShader<FRAG_BARS>>(a, frames, s); break;
@@ -474,6 +473,16 @@ static int launch_render(int fragment, const RenderArgs& a, int frames, hipStrea
     }
     return SFX_OK;
 }
+
+#ifndef VIS_PITCH_SS
+#define VIS_PITCH_SS 80
+#endif
+#ifndef VIS_ROWS_SS
+#define VIS_ROWS_SS 10
+#endif
+#ifndef VIS_MIN_WAVES_SS
+#define VIS_MIN_WAVES_SS 8
+#endif
 
 template <class SHADER> static int launch_fused_s(const RenderArgs& a, int ssaa, int frames, hipStream_t s) {
     const int blocks_x = (a.w + 127)/128;
@@ -489,7 +498,10 @@ static int launch_fused(int fragment, const RenderArgs& a, int ssaa, int frames,
         case FRAG_DEFAULT: return launch_fused_s<PlainShader<FRAG_DEFAULT>>(a, ssaa, frames, s);
         case FRAG_MISSING: return launch_fused_s<PlainShader<FRAG_MISSING>>(a, ssaa, frames, s);
         case FRAG_VISUALIZER:
-            if (!force_generic && visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) return launch_fused_s<VisualizerShader>(a, ssaa, frames, s);
+            if (!force_generic && visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) {
+                if (ssaa == 1) return launch_fused_s<VisualizerShader<128, 10, 1>>(a, ssaa, frames, s);
+                return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_SS>>(a, ssaa, frames, s);
+            }
             return launch_fused_s<PlainShader<FRAG_VISUALIZER>>(a, ssaa, frames, s);
         case FRAG_BARS: return launch_fused_s<PlainShader<FRAG_BARS>>(a, ssaa, frames, s);
         case FRAG_WAVEFORM: return launch_fused_s<PlainShader<FRAG_WAVEFORM>>(a, ssaa, frames, s);

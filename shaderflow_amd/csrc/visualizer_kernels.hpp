@@ -28,10 +28,12 @@
 
 namespace sf {
 
-constexpr int TILE_PITCH = 128;      // cells per tile row (32 B each)
-constexpr int TILE_ROWS = 12;
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+#ifndef VIS_TILE_F32
+#define VIS_TILE_F32 1
+#endif
 
 __global__ void k_visualizer_consts(const FrameDyn* __restrict__ dyn, int frame0, int nframes, VisualizerConsts* __restrict__ out) {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
@@ -40,16 +42,23 @@ __global__ void k_visualizer_consts(const FrameDyn* __restrict__ dyn, int frame0
     out[frame0 + k] = visualizer_consts(d.iTime, d.iAudioVolume, d.iAudioSTD);
 }
 
+// TILE_PITCH: cells per tile row (32 B each): 128 covers a 128-pixel block without supersampling, 80 is enough when
+// the block's 128 pixels are 2x or 4x supersampled (the window is then ~64 cells wide) and lets more blocks share a CU.
+template <int TILE_PITCH, int TILE_ROWS, int MIN_WAVES>
 struct VisualizerShader {
     static constexpr int BLOCK_W = 128, BLOCK_H = 2;     // unfused block shape (render_kernels.hpp k_render)
-    static constexpr int MIN_WAVES_PER_SIMD = 1;
+    static constexpr int MIN_WAVES_PER_SIMD = MIN_WAVES;
 
     struct State {
         VisualizerPre pre;
         float xc, yc;                // centre tap in texel space (u*w - 0.5, v*h - 0.5)
     };
     struct Shared {
+#if VIS_TILE_F32
+        float4 tile[TILE_ROWS*TILE_PITCH*3];
+#else
         half8 tile[TILE_ROWS*TILE_PITCH*2];
+#endif
         float red[5][16];
         VisualizerConsts consts;
         int x0, y0, tw, th, ok;
@@ -130,6 +139,19 @@ struct VisualizerShader {
             const uint8_t* p10 = data + ((long)j0*bg.width + i1)*comps;
             const uint8_t* p01 = data + ((long)j1*bg.width + i0)*comps;
             const uint8_t* p11 = data + ((long)j1*bg.width + i1)*comps;
+#if VIS_TILE_F32
+            float4 q0, q1, q2;                                        // {Ar Ag Ab Br} {Bg Bb Cr Cg} {Cb Dr Dg Db}
+            {
+                const int r00 = p00[0], r10 = p10[0], r01 = p01[0], r11 = p11[0];
+                const int g00 = p00[1], g10 = p10[1], g01 = p01[1], g11 = p11[1];
+                const int b00 = p00[2], b10 = p10[2], b01 = p01[2], b11 = p11[2];
+                q0 = make_float4((float)r00, (float)g00, (float)b00, (float)(r10 - r00));
+                q1 = make_float4((float)(g10 - g00), (float)(b10 - b00), (float)(r01 - r00), (float)(g01 - g00));
+                q2 = make_float4((float)(b01 - b00), (float)(r00 - r10 - r01 + r11), (float)(g00 - g10 - g01 + g11), (float)(b00 - b10 - b01 + b11));
+            }
+            float4* cell = sh.tile + (ty*TILE_PITCH + tx)*3;
+            cell[0] = q0; cell[1] = q1; cell[2] = q2;
+#else
             half8 lo, hi;
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
@@ -144,10 +166,31 @@ struct VisualizerShader {
             hi[4] = hi[5] = hi[6] = hi[7] = (_Float16)0.0f;
             sh.tile[(ty*TILE_PITCH + tx)*2] = lo;
             sh.tile[(ty*TILE_PITCH + tx)*2 + 1] = hi;
+#endif
         }
         __syncthreads();
     }
 
+    // One bilinear tap from the staged cells: value = A + ax*B + ay*C + (ax*ay)*D per channel.
+    // Issue cost on gfx950 (tools/ubench_valu.hip): v_fma/v_add/v_mul_f32 with VGPR operands 2 cycles per wave64,
+    // everything else (v_fract, v_cvt, shifts, v_fma_mix, any VALU with an SGPR operand) 4 cycles — so the float32
+    // tile (12 plain fma/add = 24 cycles) beats the float16 tile (12 v_fma_mix = 48 cycles) although it reads 48
+    // instead of 32 bytes of LDS per tap, and every per-tap operand is kept in VGPRs.
+#if VIS_TILE_F32
+    __device__ __forceinline__ static void tap(const float4* tile, float x, float y, float, float& r, float& g, float& b) {
+        const float ax = __builtin_amdgcn_fractf(x), ay = __builtin_amdgcn_fractf(y);
+        // byte offset of the cell, in float arithmetic (exact: < 2^24) so that only ONE conversion is needed:
+        // (floor(y)*PITCH + floor(x))*48; x, y >= 0 inside the staged window
+        const float cell = fmaf(y - ay, (float)(TILE_PITCH*48), (x - ax)*48.0f);
+        const float4* p = (const float4*)((const char*)tile + (unsigned)cell);
+        const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+        const float axy = ax*ay;
+        r = r + q0.x;           g = g + q0.y;           b = b + q0.z;
+        r = fmaf(ax, q0.w, r);  g = fmaf(ax, q1.x, g);  b = fmaf(ax, q1.y, b);
+        r = fmaf(ay, q1.z, r);  g = fmaf(ay, q1.w, g);  b = fmaf(ay, q2.x, b);
+        r = fmaf(axy, q2.y, r); g = fmaf(axy, q2.z, g); b = fmaf(axy, q2.w, b);
+    }
+#else
     __device__ __forceinline__ static void tap(const half8* tile, float x, float y, float one, float& r, float& g, float& b) {
         const float ax = __builtin_amdgcn_fractf(x), ay = __builtin_amdgcn_fractf(y);
         const int ix = (int)x, iy = (int)y;                           // x, y >= 0 inside the staged window
@@ -155,12 +198,12 @@ struct VisualizerShader {
         const half8 lo = p[0], hi = p[1];
         const float axy = ax*ay;
         // `one` is 1.0f passed through the kernel arguments: opaque to the optimiser, so the A term stays ONE v_fma_mix_f32
-        // (a literal 1.0 is folded into v_cvt_f32_f16 + v_add_f32)
         r = fmaf(one, (float)lo[0], r); g = fmaf(one, (float)lo[1], g); b = fmaf(one, (float)lo[2], b);
         r = fmaf(ax, (float)lo[3], r);   g = fmaf(ax, (float)lo[4], g);   b = fmaf(ax, (float)lo[5], b);
         r = fmaf(ay, (float)lo[6], r);   g = fmaf(ay, (float)lo[7], g);   b = fmaf(ay, (float)hi[0], b);
         r = fmaf(axy, (float)hi[1], r);  g = fmaf(axy, (float)hi[2], g);  b = fmaf(axy, (float)hi[3], b);
     }
+#endif
 
     __device__ static vec4 blur_tile(const RenderArgs& a, const Tex& bg, const State& s, const Shared& sh) {
         const float xr = s.xc - (float)sh.x0, yr = s.yc - (float)sh.y0;
@@ -168,20 +211,23 @@ struct VisualizerShader {
         const float ax = sh.consts.intensity*((float)bg.height/(float)bg.width)*(float)bg.width;
         const float ay = sh.consts.intensity*(float)bg.height;
         float r = 0.0f, g = 0.0f, b = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 10; k++) tap(sh.tile, fmaf(a.tap_x[k], ax, xr), fmaf(a.tap_y[k], ay, yr), a.one, r, g, b);
-        r = r*2.0f; g = g*2.0f; b = b*2.0f;                           // direction 8 == direction 0
+        // Taps of one direction are (up to 1e-7 relative) an arithmetic progression: walk = 0.1, 0.2, … (:27); stepping
+        // with VGPR adds keeps the position update on the 2-cycle path (an fma with the SGPR table entry costs 4).
 #pragma unroll 1
-        for (int d = 0; d < 7; d++) {                                 // directions 1..7
+        for (int d = 0; d < 8; d++) {
+            const float sx = (a.tap_x[d*10 + 1] - a.tap_x[d*10])*ax, sy = (a.tap_y[d*10 + 1] - a.tap_y[d*10])*ay;
+            float x = fmaf(a.tap_x[d*10], ax, xr), y = fmaf(a.tap_y[d*10], ay, yr);
 #pragma unroll
             for (int w = 0; w < 10; w++) {
-                const int k = 11 + d*10 + w;
-                tap(sh.tile, fmaf(a.tap_x[k], ax, xr), fmaf(a.tap_y[k], ay, yr), a.one, r, g, b);
+                tap(sh.tile, x, y, a.one, r, g, b);
+                x = x + sx; y = y + sy;
             }
+            if (d == 0) { r = r*2.0f; g = g*2.0f; b = b*2.0f; }     // direction 8 == direction 0
         }
-        tap(sh.tile, xr, yr, a.one, r, g, b);                                // centre tap (:19)
-        const float quality = 10.0f, directions = 8.0f;
-        return {(r/255.0f)/(quality*directions), (g/255.0f)/(quality*directions), (b/255.0f)/(quality*directions), 91.0f/(quality*directions)};
+        tap(sh.tile, xr, yr, a.one, r, g, b);                        // centre tap (:19)
+        // (sum/255)/(quality*directions) (:32) as one multiplication: part of this path's re-association (≤ 1 ulp)
+        const float norm = 1.0f/(255.0f*10.0f*8.0f);
+        return {r*norm, g*norm, b*norm, 91.0f/80.0f};
     }
 
     __device__ static vec4 run(const RenderArgs& a, const Frag& f, const State& s, const Shared& sh) {
