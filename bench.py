@@ -38,7 +38,10 @@ B_ALG_PER_FRAME = {  # iScreen write + resolve read + iFinal w
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 256*4*32*2.4e9    # 256 CU x 4 SIMD32 x 2.4 GHz = 78.6e12 lane-instructions/s (157.3 TFLOP/s FMA)
-TAPS_PER_SAMPLE, OPS_PER_TAP = 81, 27  # LDS-tiled blur: taps evaluated per supersample, VALU instructions per tap
+# From profiles/r01_rocprofv3_bench_c3_summary.txt (rocprofv3 --pmc, separate passes, same command):
+PROFILE = {"file": "profiles/r01_rocprofv3_bench_c3_summary.txt",
+           "valu_instr_per_supersample": 3070.0,   # SQ_INSTS_VALU / SQ_WAVES of the fused visualizer kernel
+           "hbm_bytes_per_frame": (3376.2 + 1458000.0)*1024/60}   # FETCH_SIZE + WRITE_SIZE (KiB) per 60-frame launch
 
 
 def parse_args():
@@ -196,7 +199,8 @@ def main() -> None:
         b_alg = B_ALG_PER_FRAME.get((w, h, s), float(w*s*h*s*8 + w*h*6))
         achieved = b_alg*fpb/launch_s/1e9
         samples_per_s = (w*s)*(h*s)*fpb/launch_s
-        lane_ops = samples_per_s*TAPS_PER_SAMPLE*OPS_PER_TAP
+        lane_ops = samples_per_s*PROFILE["valu_instr_per_supersample"]
+        c3 = (w, h, s) == (3840, 2160, 2)
         result = {
             "metric": "frames/sec at 4K 2xSSAA music-visualizer",
             "value": round(value, 2), "unit": "frames/s",
@@ -210,12 +214,15 @@ def main() -> None:
                        "parallelism": f"frame-range sharding x{world}" + (", RCCL gather to rank 0" if distributed else "")},
             "realtime_factor": round(value/60.0, 2),
             "roofline": {"bound": "hbm", "kernel": "k_render_resolve<VisualizerShader, 2>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved/HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved/HBM_PEAK_GBS, 4),
+                         "traffic": (PROFILE["hbm_bytes_per_frame"]*fpb if c3 else None), "traffic_source": PROFILE["file"],
                          "algorithmic_bytes_per_launch": b_alg*fpb, "launch_ms": round(launch_s*1e3, 3), "frames_per_launch": fpb,
-                         "note": "FP32-VALU bound kernel (81 bilinear taps per supersample); HBM is not the binding roof, see valu"},
-            "valu": {"bound": "fp32_valu", "achieved": round(lane_ops/1e12, 2), "peak": round(VALU_PEAK_LANE_OPS/1e12, 1), "unit": "T lane-instr/s",
-                     "frac": round(lane_ops/VALU_PEAK_LANE_OPS, 4), "taps_per_s": round(samples_per_s*TAPS_PER_SAMPLE/1e9, 1),
-                     "taps_unit": "G taps/s", "model": f"{TAPS_PER_SAMPLE} taps x {OPS_PER_TAP} VALU instr per supersample (blur loop only)"},
+                         "note": "FP32-VALU bound kernel (81 bilinear taps per supersample): the fused kernel writes only the RGB8 frame, "
+                                 "12.6x less HBM traffic than the two-pass data-flow the algorithmic bytes describe; the binding roof is under valu"},
+            "valu": {"bound": "fp32_valu_issue", "achieved": round(lane_ops/1e12, 2), "peak": round(VALU_PEAK_LANE_OPS/1e12, 1), "unit": "T lane-instr/s",
+                     "frac": round(lane_ops/VALU_PEAK_LANE_OPS, 4), "taps_per_s": round(samples_per_s*81/1e9, 1), "taps_unit": "G taps/s",
+                     "model": f"{PROFILE['valu_instr_per_supersample']:.0f} VALU instructions per supersample (rocprofv3 SQ_INSTS_VALU/SQ_WAVES) at the "
+                              "2-cycle wave64 issue rate of plain f32 ops at 2.4 GHz; non-f32 ops and SGPR-operand ops issue at 4 cycles, so this is a lower bound on VALU busy"},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, pcm, background)
