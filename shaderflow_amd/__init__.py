@@ -40,7 +40,7 @@ class _Directories:
 directories = _Directories()
 
 _SUBMODULES = ("variable", "message", "module", "scheduler", "resolution", "dynamics", "texture", "shader",
-               "camera", "exporting", "scene", "tape", "audio", "audio.module", "audio.spectrogram", "audio.waveform",
+               "camera", "exporting", "scene", "tape", "device", "parallel", "synth", "audio", "audio.module", "audio.spectrogram", "audio.waveform",
                "audio.reader", "piano", "piano.notes")
 
 

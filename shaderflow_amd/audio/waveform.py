@@ -1,8 +1,18 @@
 """
-ShaderWaveform (reference: shaderflow/audio/waveform.py:14-90): the last `length` seconds of audio reduced to
-`length*samplerate` points per channel and written to a (points x 1) RG32F texture every frame. The slicing
-arithmetic (`chunk_size`, `_offset = tell % chunk_size`, window ending one sample before the newest, :65-84) is
-kept; the reduction itself (`sqrt(mean|x|)` and the RMS/STD variants, :15-22) runs on the device.
+ShaderWaveform — the recent audio history as a one-row texture.
+
+Every frame the last `length` seconds are cut into `length*samplerate` chunks per channel and each chunk is reduced
+to one value (default `sqrt(mean|x|)`), giving a `(points × 1)` RG32F texture named `iWaveform` that fragments
+sample with `texture(iWaveform, vec2(x, 0))`. Contract and arithmetic follow the reference's
+shaderflow/audio/waveform.py:14-90:
+
+    chunk_size = max(1, int(length*audio.samplerate/points))          (:65-67)
+    offset     = audio.tell % chunk_size                              (:71-73)
+    window     = history[-(chunk_size*points + offset + 1) : -(offset + 1)]      (:81-83)
+
+i.e. chunks are aligned to multiples of `chunk_size` in stream time and the newest sample is excluded. The cut is
+described to the device by (`tell`, `chunk_size`, `points`); the reductions run there (`sfx_waveform_rows`,
+csrc/audio_kernels.hpp k_waveform_rows), one wavefront per chunk.
 """
 from __future__ import annotations
 
@@ -10,6 +20,7 @@ import ctypes as C
 import math
 from collections.abc import Iterable
 from enum import Enum
+from typing import Sequence
 
 import numpy as np
 from attrs import define
@@ -22,6 +33,7 @@ from shaderflow_amd.variable import ShaderVariable, Uniform
 
 
 class WaveformReducer(Enum):
+    """How a chunk of samples becomes one point (device codes of include/shaderflow_hip.h SFX_REDUCER_*)"""
     Average = 0     # sqrt(mean(|x|))
     RMS = 1         # sqrt(sqrt(mean(x²))·√2)
     STD = 2         # sqrt(std(x))
@@ -32,28 +44,23 @@ class ShaderWaveform(ShaderModule):
     name: str = "iWaveform"
     audio: BrokenAudio = None
     length: float = 3
+    """Seconds of history shown"""
     samplerate: float = 60
+    """Points per second of history"""
     reducer: WaveformReducer = WaveformReducer.Average
     smooth: bool = True
+    """Bilinear (True) or nearest (False) sampling of the row"""
     texture: ShaderTexture = None
 
-    @property
-    def length_samples(self) -> int:
-        return int(max(1, self.length*self.scene.fps))
-
-    def build(self):
-        self.texture = ShaderTexture(
-            scene=self.scene, filter=("linear" if self.smooth else "nearest"), components=self.audio.channels,
-            name=self.name, width=self._points, height=1, mipmaps=False, dtype=np.float32,
-        ).repeat(False)
-
-    @property
-    def chunk_size(self) -> int:
-        return max(1, int(self.length*self.audio.samplerate/self._points))
+    # geometry of the cut ------------------------------------------------------------------------------------
 
     @property
     def _points(self) -> int:
         return int(self.length*self.samplerate)
+
+    @property
+    def chunk_size(self) -> int:
+        return max(1, int(self.length*self.audio.samplerate/self._points))
 
     @property
     def _offset(self) -> int:
@@ -63,16 +70,27 @@ class ShaderWaveform(ShaderModule):
     def _cutoff(self) -> int:
         return int(self.chunk_size*math.floor(self.audio.buffer_size/self.chunk_size))
 
-    def rows(self, tells) -> np.ndarray:
-        """(frames, points, channels) float32 for the given `tell`s, computed on the device"""
-        native = getattr(self.audio, "native", None)
-        if native is None:
+    @property
+    def length_samples(self) -> int:
+        return int(max(1, self.length*self.scene.fps))
+
+    # module -------------------------------------------------------------------------------------------------
+
+    def build(self):
+        self.texture = ShaderTexture(scene=self.scene, name=self.name, width=self._points, height=1,
+                                     components=self.audio.channels, dtype=np.float32, mipmaps=False,
+                                     filter=("linear" if self.smooth else "nearest"))
+        self.texture.repeat(False)
+
+    def rows(self, tells: Sequence[int]) -> np.ndarray:
+        """(len(tells), points, channels) float32: the row each of those read positions produces"""
+        pcm = getattr(self.audio, "native", None)
+        if pcm is None:
             raise RuntimeError("The waveform's audio has no device-resident PCM: load a file into ShaderAudio first")
         tells = np.ascontiguousarray(tells, np.int64)
         out = np.zeros((len(tells), self._points, self.audio.channels), np.float32)
-        reducer = WaveformReducer(self.reducer).value if not callable(self.reducer) else 0
-        N.check(N.lib().sfx_waveform_rows(native, N.as_ptr(tells, C.c_int64), len(tells), self.chunk_size,
-                                          self._points, reducer, N.as_ptr(out, C.c_float)))
+        N.check(N.lib().sfx_waveform_rows(pcm, N.as_ptr(tells, C.c_int64), len(tells), self.chunk_size, self._points,
+                                          WaveformReducer(self.reducer).value, N.as_ptr(out, C.c_float)))
         return out
 
     def update(self):

@@ -1,0 +1,75 @@
+"""
+Device-side texture objects: what the reference gets from moderngl (`Texture` + `Framebuffer`) is one handle of
+libshaderflow_hip here (`sfx_texture_*`, include/shaderflow_hip.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+from attrs import define, field
+
+from shaderflow_amd import _native as N
+
+
+@define(eq=False, slots=False)
+class DeviceTexture:
+    """What a sampler uniform carries: one native texture (stands for moderngl.Texture)"""
+    context: N.Context
+    handle: N.Handle
+    size: tuple[int, int]
+    components: int
+    dtype: np.dtype
+
+    @property
+    def nbytes(self) -> int:
+        return self.size[0]*self.size[1]*self.components*self.dtype.itemsize
+
+    def params(self, filter: str, repeat_x: bool, repeat_y: bool) -> None:
+        N.check(N.lib().sfx_texture_params(self.handle, N.LINEAR if filter == "linear" else N.NEAREST, int(repeat_x), int(repeat_y)))
+
+    def write(self, data, viewport: Optional[tuple[int, int, int, int]] = None) -> None:
+        buffer = np.frombuffer(data, np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else np.ascontiguousarray(data).view(np.uint8).ravel()
+        x, y, w, h = viewport or (0, 0, 0, 0)
+        N.check(N.lib().sfx_texture_write(self.handle, buffer.ctypes.data, buffer.size, x, y, w, h))
+
+    def read(self) -> np.ndarray:
+        """(height, width, components), row 0 = bottom"""
+        out = np.empty((self.size[1], self.size[0], self.components), self.dtype)
+        N.check(N.lib().sfx_texture_read(self.handle, out.ctypes.data, out.nbytes))
+        return out
+
+    def device_ptr(self) -> int:
+        ptr = C.c_void_p()
+        N.check(N.lib().sfx_texture_device_ptr(self.handle, C.byref(ptr), None))
+        return ptr.value
+
+    def release(self) -> None:
+        if self.handle is not None and self.handle.value:
+            N.lib().sfx_texture_destroy(self.handle)
+            self.handle = N.Handle()
+
+
+@define(eq=False, slots=False)
+class TextureBox:
+    texture: DeviceTexture = None
+    data: bytes = field(default=None, repr=False)
+    clear: bool = False
+    empty: bool = True
+
+    @property
+    def fbo(self) -> DeviceTexture:
+        """Rendering into a box targets its own texture (the reference pairs every texture with an FBO)"""
+        return self.texture
+
+    def release(self) -> None:
+        if self.texture is not None:
+            self.texture.release()
+            self.texture = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass

@@ -40,25 +40,25 @@ def dynamics_coefficients(frequency: float, zeta: float, response: float, dt: fl
 
 
 class _NumberLike(Number):
-    """Arithmetic on the object acts on `.value` (dynamics.py:22-73)"""
+    """A DynamicNumber can be used where a number is expected: arithmetic acts on `.value` (reference: the
+    NumberDunder base, dynamics.py:22-73). Operators are generated from the `operator` module."""
+
     def __float__(self): return float(self.value)
     def __int__(self): return int(self.value)
     def __str__(self): return str(self.value)
-    def __mul__(self, other): return self.value*other
-    def __rmul__(self, other): return self*other
-    def __add__(self, other): return self.value + other
-    def __radd__(self, other): return self + other
-    def __sub__(self, other): return self.value - other
-    def __rsub__(self, other): return self - other
-    def __truediv__(self, other): return self.value/other
-    def __rtruediv__(self, other): return self/other
-    def __floordiv__(self, other): return self.value//other
-    def __rfloordiv__(self, other): return self//other
-    def __mod__(self, other): return self.value % other
-    def __rmod__(self, other): return self % other
-    def __pow__(self, other): return self.value**other
-    def __rpow__(self, other): return self**other
     def __hash__(self): return id(self)
+
+
+def _install_operators() -> None:
+    import operator
+    for name in ("mul", "add", "sub", "truediv", "floordiv", "mod", "pow"):
+        apply = getattr(operator, name)
+        setattr(_NumberLike, f"__{name}__", lambda self, other, _f=apply: _f(self.value, other))
+        # the reference reflects `other ∘ x` onto `x ∘ other` (dynamics.py:36-73); kept, also for non-commutative ones
+        setattr(_NumberLike, f"__r{name}__", lambda self, other, _f=apply: _f(self.value, other))
+
+
+_install_operators()
 
 
 @define(slots=False, eq=False)

@@ -101,23 +101,17 @@ class ShaderModule:
     def defines(self) -> Iterable[str]:
         yield None
 
-    # logging (module.py:124-141) ------------------------------------------------------------------
+    # logging: `log_info/warn/error/debug/minor(*parts)` prefixed with who is speaking -----------------------------
 
     @property
     def who(self) -> str:
         return f"(Module {self.uuid:>2} • {type(self).__name__[:12].ljust(12)})"
 
-    def log_info(self, *args) -> None:
-        logger.info(" ".join(map(str, (self.who, *args))))
+    def _say(self, level: int, parts: tuple) -> None:
+        logger.log(level, " ".join(str(part) for part in (self.who, *parts)))
 
-    def log_warn(self, *args) -> None:
-        logger.warning(" ".join(map(str, (self.who, *args))))
-
-    def log_error(self, *args) -> None:
-        logger.error(" ".join(map(str, (self.who, *args))))
-
-    def log_debug(self, *args) -> None:
-        logger.debug(" ".join(map(str, (self.who, *args))))
-
-    def log_minor(self, *args) -> None:
-        logger.debug(" ".join(map(str, (self.who, *args))))
+    def log_info(self, *parts) -> None: self._say(logging.INFO, parts)
+    def log_warn(self, *parts) -> None: self._say(logging.WARNING, parts)
+    def log_error(self, *parts) -> None: self._say(logging.ERROR, parts)
+    def log_debug(self, *parts) -> None: self._say(logging.DEBUG, parts)
+    def log_minor(self, *parts) -> None: self._say(logging.DEBUG, parts)

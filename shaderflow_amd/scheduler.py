@@ -1,133 +1,127 @@
 """
-Task scheduler (reference: shaderflow/scheduler.py). Only what the headless path observes is kept: a task's
-`dt` arithmetic in freewheel mode (scheduler.py:87-89,134-173) — `started = 0`, `last_call = -period`,
-`next_call = 0`, then `now = next_call; dt = now - last_call; next_call += period` — bit for bit, because
-the accumulated float64 `dt` is what the DynamicNumber integrators and the PCM chunk arithmetic see.
-Realtime sleeping is kept for completeness.
+Frame scheduling.
+
+The reference drives `ShaderScene.next(dt)` from a task scheduler (shaderflow/scheduler.py). What the export path
+observes of it is the `dt` arithmetic of a FREEWHEEL task — virtual time that never sleeps:
+
+    last_call = -period ; next_call = 0
+    every call:  now = next_call ; dt = now - last_call ; last_call = now
+                 while next_call <= now: next_call += period
+
+`next_call` accumulates `period` in float64, so `dt` is not exactly 1/fps: at 60 fps it takes 12 distinct values
+around 0.01666…, and those exact values feed `scene.time`, the DynamicNumber integrators and the PCM chunk
+arithmetic. `freewheel_clock()` reproduces them (pinned bit for bit by tests/golden/clock.npz).
+
+`SchedulerTask` / `Scheduler` keep the reference's surface (new/once/next/clear, `.fps`, `.period`, realtime sleeping)
+for code written against it.
 """
 from __future__ import annotations
 
-import contextlib
 import inspect
-import time
-from collections import deque
-from typing import Any, Callable, Iterable, Optional
-
-from attrs import Factory, define, field
+import time as _time
+from contextlib import nullcontext
+from typing import Any, Callable, Optional
 
 
-def precise_sleep(sleep: float, *, error: float = 0.001) -> None:
-    start = time.monotonic()
-    if (ahead := max(0, sleep - error)):
-        time.sleep(ahead)
-    else:
-        return
-    while (time.monotonic() - start) < sleep:
+def precise_sleep(seconds: float, *, error: float = 0.001) -> None:
+    """Sleep most of the interval, spin the last millisecond"""
+    deadline = _time.monotonic() + seconds
+    if seconds > error:
+        _time.sleep(seconds - error)
+    while _time.monotonic() < deadline:
         pass
 
 
-@define(eq=False)
 class SchedulerTask:
-    task: Callable
-    args: list = field(factory=list, repr=False)
-    kwargs: dict = field(factory=dict, repr=False)
-    output: Any = field(default=None, repr=False)
-    context: Any = Factory(contextlib.nullcontext)
-    enabled: bool = True
-    once: bool = False
-    frequency: float = 60.0
-    frameskip: bool = True
-    freewheel: bool = False
-    precise: bool = False
-    started: float = Factory(time.monotonic)
-    next_call: float = None
-    last_call: float = None
-    _dt: bool = False
+    """One periodic (or one-shot) callable. If the callable takes `dt`, it receives the time since its last call."""
 
-    def __attrs_post_init__(self):
-        self._dt = ("dt" in inspect.signature(self.task).parameters)
-        if self.freewheel:
-            self.started = 0
-        self.last_call = (self.last_call or self.started) - self.period
-        self.next_call = (self.next_call or self.started)
+    def __init__(self, task: Callable, args: Optional[list] = None, kwargs: Optional[dict] = None, *,
+                 frequency: float = 60.0, frameskip: bool = True, freewheel: bool = False, precise: bool = False,
+                 once: bool = False, enabled: bool = True, context: Any = None,
+                 started: Optional[float] = None, next_call: Optional[float] = None, last_call: Optional[float] = None):
+        self.task, self.args, self.kwargs = task, list(args or []), dict(kwargs or {})
+        self.frequency, self.frameskip, self.freewheel, self.precise = frequency, frameskip, freewheel, precise
+        self.once, self.enabled, self.context, self.output = once, enabled, context or nullcontext(), None
+        self._wants_dt = "dt" in inspect.signature(task).parameters
+        self.started = 0 if freewheel else (_time.monotonic() if started is None else started)
+        self.last_call = (last_call or self.started) - self.period
+        self.next_call = (next_call or self.started)
 
-    def __hash__(self) -> int:
-        return id(self)
+    # rate ---------------------------------------------------------------------------------------------------
 
     @property
     def fps(self) -> float:
         return self.frequency
 
     @fps.setter
-    def fps(self, value: float):
+    def fps(self, value: float) -> None:
         self.frequency = value
 
     @property
     def period(self) -> float:
-        return (1.0/self.frequency)
+        return 1.0/self.frequency
 
     @period.setter
-    def period(self, value: float):
-        self.frequency = (1/value)
+    def period(self, seconds: float) -> None:
+        self.frequency = 1/seconds
+
+    # ordering: one-shot tasks first, then by due time ---------------------------------------------------------
+
+    def _key(self) -> tuple:
+        return (not self.once, self.next_call)
+
+    def __lt__(self, other: "SchedulerTask") -> bool:
+        return self._key() < other._key()
 
     @property
     def should_delete(self) -> bool:
-        return (self.once and (not self.enabled))
+        return self.once and not self.enabled
 
     @property
     def should_live(self) -> bool:
-        return (not self.should_delete)
+        return not self.should_delete
 
-    def __lt__(self, other) -> bool:
-        if (self.once and not other.once):
-            return True
-        return (self.next_call < other.next_call)
+    # run ----------------------------------------------------------------------------------------------------
 
-    def __gt__(self, other) -> bool:
-        if (not self.once and other.once):
-            return True
-        return (self.next_call > other.next_call)
+    def _wait_until_due(self, block: bool) -> bool:
+        """Realtime only: False when the task is not due and we must not block"""
+        remaining = max(0, self.next_call - _time.monotonic())
+        if remaining and not block:
+            return False
+        (precise_sleep if self.precise else _time.sleep)(remaining)
+        return True
 
-    def next(self, block: bool = True):
-        if (not self.freewheel):
-            wait = max(0, (self.next_call - time.monotonic()))
-            if (not block) and (wait > 0):
-                return self
-            (precise_sleep if self.precise else time.sleep)(wait)
-
-        now = (self.next_call if self.freewheel else time.monotonic())
-
-        if (self._dt):
-            self.kwargs["dt"] = (now - self.last_call)
-            if (not self.frameskip):
-                self.kwargs["dt"] = min(self.kwargs["dt"], self.period)
-
+    def next(self, block: bool = True) -> "SchedulerTask":
+        if not self.freewheel and not self._wait_until_due(block):
+            return self
+        now = self.next_call if self.freewheel else _time.monotonic()
+        if self._wants_dt:
+            elapsed = now - self.last_call
+            self.kwargs["dt"] = elapsed if self.frameskip else min(elapsed, self.period)
         self.last_call = now
-
         with self.context:
             self.output = self.task(*self.args, **self.kwargs)
-
-        while (self.next_call <= now):
+        while self.next_call <= now:
             self.next_call += self.period
-
-        self.enabled = (not self.once)
+        self.enabled = not self.once
         return self
 
 
-@define
 class Scheduler:
     Task = SchedulerTask
-    tasks: deque = Factory(deque)
+
+    def __init__(self):
+        self.tasks: list[SchedulerTask] = []
 
     def add(self, task: SchedulerTask) -> SchedulerTask:
         self.tasks.append(task)
         return task
 
     def new(self, task: Callable, **options) -> SchedulerTask:
-        return self.add(SchedulerTask(task=task, **options))
+        return self.add(SchedulerTask(task, **options))
 
     def once(self, task: Callable, **options) -> SchedulerTask:
-        return self.add(SchedulerTask(task=task, **options, once=True))
+        return self.add(SchedulerTask(task, once=True, **options))
 
     def delete(self, task: SchedulerTask) -> None:
         self.tasks.remove(task)
@@ -136,22 +130,19 @@ class Scheduler:
         self.tasks.clear()
 
     @property
-    def enabled_tasks(self) -> Iterable[SchedulerTask]:
-        for task in self.tasks:
-            if task.enabled:
-                yield task
+    def enabled_tasks(self):
+        return (task for task in self.tasks if task.enabled)
 
     @property
     def next_task(self) -> Optional[SchedulerTask]:
         return min(self.enabled_tasks, default=None)
 
     def _sanitize(self) -> None:
-        alive = [task for task in self.tasks if task.should_live]
-        self.tasks.clear()
-        self.tasks.extend(alive)
+        self.tasks = [task for task in self.tasks if task.should_live]
 
-    def next(self, block=True) -> Optional[SchedulerTask]:
-        if (task := self.next_task) is None:
+    def next(self, block: bool = True) -> Optional[SchedulerTask]:
+        task = self.next_task
+        if task is None:
             return None
         try:
             return task.next(block=block)
@@ -160,24 +151,23 @@ class Scheduler:
                 self._sanitize()
 
     def all_once(self) -> None:
-        for task in list(self.tasks):
-            if task.once:
-                task.next()
+        for task in [task for task in self.tasks if task.once]:
+            task.next()
         self._sanitize()
 
 
 def freewheel_clock(fps: float, frames: int, speed: float = 1.0):
-    """The (time, dt, rdt) each frame's modules see in a freewheel export: scheduler.py:152-173 feeding
-    scene.py:475-479 (values are stored AFTER the frame ran, so frame 0 sees zeros). Lists of python floats."""
+    """(time, dt, rdt) that the modules of each frame SEE in a freewheel export, as lists of python floats.
+    The scene stores them after the frame has run (reference scene.py:475-479), so frame 0 sees zeros."""
     ticks: list[float] = []
-    task = SchedulerTask(task=lambda dt=0.0: ticks.append(dt), frequency=fps, freewheel=True, precise=True)
-    times, dts, rdts = [], [], []
-    time_, dt, rdt = 0.0, 0.0, 0.0
+    task = SchedulerTask(lambda dt=0.0: ticks.append(dt), frequency=fps, freewheel=True)
+    seen_time, seen_dt, seen_rdt = [], [], []
+    now, dt, rdt = 0.0, 0.0, 0.0
     for _ in range(frames):
-        times.append(time_); dts.append(dt); rdts.append(rdt)
+        seen_time.append(now); seen_dt.append(dt); seen_rdt.append(rdt)
         task.next()
-        task.fps = fps
-        dt = ticks[-1]*speed
+        task.fps = fps                      # the scene re-assigns the rate every frame
         rdt = ticks[-1]
-        time_ += dt
-    return times, dts, rdts
+        dt = rdt*speed
+        now += dt
+    return seen_time, seen_dt, seen_rdt

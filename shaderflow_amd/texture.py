@@ -1,12 +1,20 @@
 """
-ShaderTexture: a `temporal x layers` matrix of device textures that shaders render into and sample from.
+ShaderTexture — a `temporal × layers` grid of device textures that shaders render into and sample from.
 
-Host mirror of the reference's shaderflow/texture.py:74-381 with the moderngl objects replaced by handles of
-libshaderflow_hip (sfx_texture_*): same attributes (`final`, `track`, `filter`, `repeat_x/y`, `components`,
-`dtype`, `temporal`, `layers`, `width/height/size`), same re-creation rules (`make` on any shape change, cached
-bytes re-uploaded when the size is unchanged, :268-270), same write/roll/clear/from_numpy semantics (rows are
-flipped so that row 0 is the bottom one, :327-335) and the same uniforms (`<name>Size/Layers/Temporal` and one
-sampler per box named `<name>{t}x{l}`, :374-381).
+Same contract as the reference's shaderflow/texture.py:74-381 (attributes `final, track, filter, anisotropy,
+mipmaps, repeat_x/y, width/height/size/resolution, components, dtype, temporal, layers, matrix`; methods
+`make, apply, repeat, roll, write, from_numpy, from_image, clear, is_empty, get_box, row, boxes, defines, pipeline`),
+with libshaderflow_hip textures (device.py) in place of moderngl objects.
+
+Rules that are observable and therefore kept:
+  * a texture with `track != 0` follows the scene: `scene.resolution` when `final`, else
+    `scene.render_resolution` (= resolution × ssaa), times `track`, at least 1×1;
+  * any change of shape/format re-allocates every box (`make`); a box remembers the bytes of its last FULL
+    write and gets them back when the new allocation has the same byte size;
+  * sampler state (filter, wrap) is applied to every box (`apply`); mipmaps/anisotropy are accepted and ignored —
+    the in-scope fragments sample level 0 only;
+  * `from_numpy` flips rows so that row 0 is the BOTTOM row, like an OpenGL upload of an image;
+  * the uniforms are `<name>Size`, `<name>Layers`, `<name>Temporal` and one sampler per box, `<name>{t}x{l}`.
 """
 from __future__ import annotations
 
@@ -21,6 +29,7 @@ import numpy as np
 from attrs import Factory, define, field
 
 from shaderflow_amd import _native as N
+from shaderflow_amd.device import DeviceTexture, TextureBox
 from shaderflow_amd.message import ShaderMessage
 from shaderflow_amd.module import ShaderModule
 from shaderflow_amd.variable import ShaderVariable, Uniform
@@ -32,262 +41,183 @@ class TextureFilter(Enum):
 
 
 class Anisotropy(Enum):
-    x1 = 1
-    x2 = 2
-    x4 = 4
-    x8 = 8
-    x16 = 16
+    x1, x2, x4, x8, x16 = 1, 2, 4, 8, 16
 
 
-@define(eq=False, slots=False)
-class DeviceTexture:
-    """What a sampler uniform carries: one native texture (stands for moderngl.Texture)"""
-    context: N.Context
-    handle: N.Handle
-    size: tuple[int, int]
-    components: int
-    dtype: np.dtype
-
-    @property
-    def nbytes(self) -> int:
-        return self.size[0]*self.size[1]*self.components*self.dtype.itemsize
-
-    def params(self, filter: str, repeat_x: bool, repeat_y: bool) -> None:
-        N.check(N.lib().sfx_texture_params(self.handle, N.LINEAR if filter == "linear" else N.NEAREST, int(repeat_x), int(repeat_y)))
-
-    def write(self, data, viewport: Optional[tuple[int, int, int, int]] = None) -> None:
-        buffer = np.frombuffer(data, np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else np.ascontiguousarray(data).view(np.uint8).ravel()
-        x, y, w, h = viewport or (0, 0, 0, 0)
-        N.check(N.lib().sfx_texture_write(self.handle, buffer.ctypes.data, buffer.size, x, y, w, h))
-
-    def read(self) -> np.ndarray:
-        """(height, width, components), row 0 = bottom"""
-        out = np.empty((self.size[1], self.size[0], self.components), self.dtype)
-        N.check(N.lib().sfx_texture_read(self.handle, out.ctypes.data, out.nbytes))
-        return out
-
-    def device_ptr(self) -> int:
-        ptr = C.c_void_p()
-        N.check(N.lib().sfx_texture_device_ptr(self.handle, C.byref(ptr), None))
-        return ptr.value
-
-    def release(self) -> None:
-        if self.handle is not None and self.handle.value:
-            N.lib().sfx_texture_destroy(self.handle)
-            self.handle = N.Handle()
-
-
-@define(eq=False, slots=False)
-class TextureBox:
-    texture: DeviceTexture = None
-    data: bytes = field(default=None, repr=False)
-    clear: bool = False
-    empty: bool = True
-
-    @property
-    def fbo(self) -> DeviceTexture:
-        """Rendering into a box targets its own texture (the reference pairs every texture with an FBO)"""
-        return self.texture
-
-    def release(self) -> None:
-        if self.texture is not None:
-            self.texture.release()
-            self.texture = None
-
-    def __del__(self):
-        try:
-            self.release()
-        except Exception:
-            pass
-
-
-def _grow_or_shrink(data, fill, length: int):
-    while (len(data) > length):
-        data.pop()
-    while (len(data) < length):
-        data.append(fill())
-    return data
+def _on_change(action: str):
+    """attrs on_setattr hook: convert, store, and run `self.<action>()` only when the value really changed"""
+    def hook(self, attribute, value) -> Any:
+        if attribute.converter is not None:
+            value = attribute.converter(value)
+        if getattr(self, attribute.name) != value:
+            self.__dict__[attribute.name] = value
+            getattr(self, action)()
+        return value
+    return hook
 
 
 @define(eq=False, slots=False)
 class ShaderTexture(ShaderModule):
     name: str = None
 
+    # what the texture follows and how it is sampled
+    final: bool = field(default=False, converter=bool)
+    track: float = field(default=0.0, converter=float, on_setattr=_on_change("make"))
+    filter: TextureFilter = field(default=TextureFilter.Linear, converter=TextureFilter, on_setattr=_on_change("apply"))
+    anisotropy: Anisotropy = field(default=Anisotropy.x16, converter=Anisotropy, on_setattr=_on_change("apply"))
+    mipmaps: bool = field(default=False, converter=bool, on_setattr=_on_change("apply"))
+    repeat_x: bool = field(default=True, converter=bool, on_setattr=_on_change("apply"))
+    repeat_y: bool = field(default=True, converter=bool, on_setattr=_on_change("apply"))
+
+    # storage
+    _width: int = field(default=1, converter=int)
+    _height: int = field(default=1, converter=int)
+    components: int = field(default=4, converter=int, on_setattr=_on_change("make"))
+    dtype: np.dtype = field(default=np.uint8, converter=np.dtype, on_setattr=_on_change("make"))
+    temporal: int = field(default=1, converter=int, on_setattr=_on_change("make"))
+    layers: int = field(default=1, converter=int, on_setattr=_on_change("make"))
+    matrix: deque = Factory(deque)
+    """matrix[t][l]: t frames back in time, layer l; rotated by `roll()` after each render"""
+
     def build(self):
         self.make()
 
-    def _changed(self, attr, value, then) -> Any:
-        if (converter := attr.converter):
-            value = converter(value)
-        if getattr(self, attr.name) != value:
-            self.__dict__[attr.name] = value
-            then()
-        return value
-
-    def _apply_on_change(self, attr, value) -> Any:
-        return self._changed(attr, value, self.apply)
-
-    def _make_on_change(self, attr, value) -> Any:
-        return self._changed(attr, value, self.make)
-
-    final: bool = field(default=False, converter=bool)
-    """Bound to the scene's final (resolved) frame: tracks `scene.resolution` instead of the render resolution"""
-
-    track: float = field(default=0.0, converter=float, on_setattr=_make_on_change)
-    filter: TextureFilter = field(default=TextureFilter.Linear, converter=TextureFilter, on_setattr=_apply_on_change)
-    anisotropy: Anisotropy = field(default=Anisotropy.x16, converter=Anisotropy, on_setattr=_apply_on_change)
-    mipmaps: bool = field(default=False, converter=bool, on_setattr=_apply_on_change)
-    repeat_x: bool = field(default=True, converter=bool, on_setattr=_apply_on_change)
-    repeat_y: bool = field(default=True, converter=bool, on_setattr=_apply_on_change)
-
-    def repeat(self, value: bool):
-        self.repeat_x = self.repeat_y = bool(value)
-        return self.apply()
-
-    _width: int = field(default=1, converter=int)
-    _height: int = field(default=1, converter=int)
-
-    @property
-    def width(self) -> int:
-        return self.resolution[0] if self.track else self._width
-
-    @width.setter
-    def width(self, value: int):
-        if (self._width != value):
-            self._width = value
-            self.make()
-
-    @property
-    def height(self) -> int:
-        return self.resolution[1] if self.track else self._height
-
-    @height.setter
-    def height(self, value: int):
-        if (self._height != value):
-            self._height = value
-            self.make()
-
-    components: int = field(default=4, converter=int, on_setattr=_make_on_change)
-    dtype: np.dtype = field(default=np.uint8, converter=np.dtype, on_setattr=_make_on_change)
+    # size -------------------------------------------------------------------------------------------------
 
     @property
     def resolution(self) -> tuple[int, int]:
         if not self.track:
             return (self._width, self._height)
-        base = self.scene.resolution if self.final else self.scene.render_resolution      # texture.py:188-192
-        return tuple(max(1, int(x*self.track)) for x in base)
+        followed = self.scene.resolution if self.final else self.scene.render_resolution
+        return tuple(max(1, int(extent*self.track)) for extent in followed)
 
     @resolution.setter
     def resolution(self, value: tuple[int, int]):
         if not self.track:
             self.width, self.height = value
 
-    @property
-    def size(self) -> tuple[int, int]:
-        return self.resolution
+    size = resolution
 
-    @size.setter
-    def size(self, value: tuple[int, int]):
-        self.resolution = value
+    @property
+    def width(self) -> int:
+        return self.resolution[0]
+
+    @width.setter
+    def width(self, value: int):
+        if value != self._width:
+            self._width = value
+            self.make()
+
+    @property
+    def height(self) -> int:
+        return self.resolution[1]
+
+    @height.setter
+    def height(self, value: int):
+        if value != self._height:
+            self._height = value
+            self.make()
 
     @property
     def aspect_ratio(self) -> float:
         return self.width/(self.height or 1)
 
     @property
-    def zeros(self) -> np.ndarray:
-        return np.zeros((*self.size, self.components), dtype=self.dtype)
-
-    @property
     def bytes_per_pixel(self) -> int:
-        return (self.dtype.itemsize*self.components)
+        return self.components*self.dtype.itemsize
 
     @property
     def size_t(self) -> int:
-        return (self.width*self.height*self.bytes_per_pixel)
+        width, height = self.resolution
+        return width*height*self.bytes_per_pixel
 
-    matrix: deque = Factory(deque)
-    temporal: int = field(default=1, converter=int, on_setattr=_make_on_change)
-    layers: int = field(default=1, converter=int, on_setattr=_make_on_change)
+    @property
+    def zeros(self) -> np.ndarray:
+        return np.zeros((*self.resolution, self.components), dtype=self.dtype)
+
+    # boxes ------------------------------------------------------------------------------------------------
 
     @property
     def boxes(self) -> Iterable[tuple[int, int, TextureBox]]:
-        for it, row in enumerate(self.matrix):
-            for ib, box in enumerate(row):
-                yield (it, ib, box)
+        for t, row in enumerate(self.matrix):
+            for l, box in enumerate(row):
+                yield (t, l, box)
 
     def row(self, n: int = 0) -> Iterable[TextureBox]:
         yield from self.matrix[n]
-
-    def make(self):
-        """(Re)allocates every box at the current size/format (texture.py:250-272)"""
-        context = self.scene.context
-        limit = context.info().max_texture_dim
-        if (max(self.size) > limit):
-            raise Exception(f"Texture size too large for this context: {self.size} > {limit}")
-        if self.dtype not in N.NUMPY_DTYPES:
-            raise TypeError(f"Texture dtype {self.dtype} has no device format (uint8, uint16, float32)")
-
-        for row in _grow_or_shrink(self.matrix, deque, self.temporal):
-            _grow_or_shrink(row, TextureBox, self.layers)
-
-        for (_, _, box) in self.boxes:
-            box.release()
-            handle = N.Handle()
-            N.check(N.lib().sfx_texture_create(context.handle, self.size[0], self.size[1], self.components,
-                                               N.NUMPY_DTYPES[self.dtype], C.byref(handle)))
-            box.texture = DeviceTexture(context, handle, self.size, self.components, self.dtype)
-            if box.data and (self.size_t == len(box.data)):
-                box.texture.write(box.data)
-        return self.apply()
-
-    def apply(self):
-        for (_, _, box) in self.boxes:
-            if box.texture is not None:
-                box.texture.params(self.filter.value, self.repeat_x, self.repeat_y)
-        return self
-
-    def destroy(self) -> None:
-        for (_, _, box) in self.boxes:
-            box.release()
 
     def get_box(self, temporal: int = 0, layer: int = -1) -> Optional[TextureBox]:
         return self.matrix[temporal][layer]
 
     @property
-    def fbo(self) -> DeviceTexture:
-        return self.get_box().fbo
+    def texture(self) -> DeviceTexture:
+        """Most recent frame, last layer"""
+        return self.get_box().texture
 
     @property
-    def texture(self) -> DeviceTexture:
-        return self.get_box().texture
+    def fbo(self) -> DeviceTexture:
+        return self.get_box().fbo
 
     def roll(self, n: int = 1):
         self.matrix.rotate(n)
         return self
 
-    def write(self, data=None, *, temporal: int = 0, layer: int = -1, viewport: tuple[int, int, int, int] = None):
+    def _reshape_matrix(self) -> None:
+        while len(self.matrix) > self.temporal:
+            for box in self.matrix.pop():
+                box.release()
+        while len(self.matrix) < self.temporal:
+            self.matrix.append(deque())
+        for row in self.matrix:
+            while len(row) > self.layers:
+                row.pop().release()
+            while len(row) < self.layers:
+                row.append(TextureBox())
+
+    def make(self):
+        """(Re)allocate every box at the current size and format"""
+        context = self.scene.context
+        width, height = self.resolution
+        limit = context.info().max_texture_dim
+        if max(width, height) > limit:
+            raise Exception(f"Texture size too large for this context: {(width, height)} > {limit}")
+        if self.dtype not in N.NUMPY_DTYPES:
+            raise TypeError(f"Texture dtype {self.dtype} has no device format (uint8, uint16, float32)")
+        self._reshape_matrix()
+        for (_, _, box) in self.boxes:
+            box.release()
+            handle = N.Handle()
+            N.check(N.lib().sfx_texture_create(context.handle, width, height, self.components,
+                                               N.NUMPY_DTYPES[self.dtype], C.byref(handle)))
+            box.texture = DeviceTexture(context, handle, (width, height), self.components, self.dtype)
+            if box.data and len(box.data) == self.size_t:
+                box.texture.write(box.data)
+        return self.apply()
+
+    def apply(self):
+        """Push filter and wrap state to every box"""
+        for (_, _, box) in self.boxes:
+            if box.texture is not None:
+                box.texture.params(self.filter.value, self.repeat_x, self.repeat_y)
+        return self
+
+    def repeat(self, value: bool):
+        self.repeat_x = self.repeat_y = bool(value)
+        return self.apply()
+
+    def destroy(self) -> None:
+        for (_, _, box) in self.boxes:
+            box.release()
+
+    # data -------------------------------------------------------------------------------------------------
+
+    def write(self, data=None, *, temporal: int = 0, layer: int = -1, viewport: Optional[tuple[int, int, int, int]] = None):
         box = self.get_box(temporal, layer)
         box.texture.write(data, viewport=viewport)
-        if (not viewport):
-            box.data = bytes(data) if not isinstance(data, np.ndarray) else data.tobytes()
+        if viewport is None:
+            box.data = data.tobytes() if isinstance(data, np.ndarray) else bytes(data)
         box.empty = False
         return self
-
-    def from_numpy(self, data: np.ndarray):
-        shape = list(data.shape)
-        if len(shape) == 2:
-            shape.append(1)
-        self._height, self._width = shape[0], shape[1]
-        self.__dict__["components"] = int(shape[2])
-        self.__dict__["dtype"] = np.dtype(data.dtype)
-        self.make()
-        self.write(np.flipud(data).tobytes())
-        return self
-
-    def from_image(self, image):
-        from PIL import Image
-        return self.from_numpy(np.array(Image.open(image)))
 
     def clear(self, temporal: int = 0, layer: int = -1):
         return self.write(self.zeros, temporal=temporal, layer=layer)
@@ -295,21 +225,36 @@ class ShaderTexture(ShaderModule):
     def is_empty(self, temporal: int = 0, layer: int = -1) -> bool:
         return self.get_box(temporal, layer).empty
 
-    # module ------------------------------------------------------------------------------------------
+    def from_numpy(self, data: np.ndarray):
+        """(height, width[, components]) array, top row first → texture of that shape and dtype"""
+        if data.ndim == 2:
+            data = data[:, :, None]
+        self._height, self._width = int(data.shape[0]), int(data.shape[1])
+        self.__dict__["components"] = int(data.shape[2])
+        self.__dict__["dtype"] = np.dtype(data.dtype)
+        self.make()
+        return self.write(np.flipud(data).tobytes())
 
-    def _coord2name(self, temporal: int, layer: int) -> str:
+    def from_image(self, image):
+        from PIL import Image
+        return self.from_numpy(np.array(Image.open(image)))
+
+    # module -----------------------------------------------------------------------------------------------
+
+    def _sampler_name(self, temporal: int, layer: int) -> str:
         return f"{self.name}{temporal}x{layer}"
 
     def defines(self) -> Iterable[str]:
-        """The GLSL the reference would inject (texture.py:351-368); informational here"""
+        """The GLSL helper text the reference injects for this texture; informational (nothing compiles GLSL here)"""
         if not self.name:
             return
-        for temporal in range(self.temporal):
-            yield f"#define {self.name}{temporal or ''} {self.name}{temporal}x{self.layers-1}"
+        last = self.layers - 1
+        for t in range(self.temporal):
+            yield f"#define {self.name}{t or ''} {self.name}{t}x{last}"
         yield f"vec4 {self.name}Texture(int temporal, int layer, vec2 astuv) {{"
-        for (temporal, layer) in itertools.product(range(self.temporal), range(self.layers)):
-            yield f"    if (temporal == {temporal} && layer == {layer})"
-            yield f"        return texture({self._coord2name(temporal, layer)}, astuv);"
+        for (t, l) in itertools.product(range(self.temporal), range(self.layers)):
+            yield f"    if (temporal == {t} && layer == {l})"
+            yield f"        return texture({self._sampler_name(t, l)}, astuv);"
         yield "    return vec4(0.0);"
         yield "}"
 
@@ -320,8 +265,8 @@ class ShaderTexture(ShaderModule):
     def pipeline(self) -> Iterable[ShaderVariable]:
         if not self.name:
             return
-        yield Uniform("vec2", f"{self.name}Size", self.size)
+        yield Uniform("vec2", f"{self.name}Size", self.resolution)
         yield Uniform("int", f"{self.name}Layers", self.layers)
         yield Uniform("int", f"{self.name}Temporal", self.temporal)
-        for (it, ib, box) in self.boxes:
-            yield Uniform("sampler2D", self._coord2name(it, ib), box.texture)
+        for (t, l, box) in self.boxes:
+            yield Uniform("sampler2D", self._sampler_name(t, l), box.texture)

@@ -1,65 +1,74 @@
 """
-Shader variables: the declaration objects modules yield from `pipeline()`.
-Mirrors shaderflow/variable.py:46-99 of the reference (same names, fields and equality-by-name); with no GLSL
-compiler behind it `declaration` is informational, the (type, name, value) triple is what reaches the kernels.
+Shader variables — what a module's `pipeline()` yields and what `ShaderProgram` pushes to a kernel.
+
+API of the reference's shaderflow/variable.py (`ShaderVariable(type, name, value, qualifier, direction,
+interpolation)`, `Uniform`, `InVariable`, `OutVariable`, `FlatVariable`, equality and hashing by NAME, `copy(**update)`,
+`declaration`, `size_string`). With no GLSL compiler behind it the declaration string is informational; the
+(type, name, value) triple is what reaches the device (`sfx_uniform_set` / `sfx_sampler_bind`).
 """
 from __future__ import annotations
 
-import copy
+import copy as _copy
 from typing import Any, Optional
 
-from attrs import define
+GLSL_TYPES = ("sampler2D", "float", "int", "bool", "vec2", "vec3", "vec4", "mat2", "mat3", "mat4")
+_VERTEX_FORMAT = {"float": "f", "int": "i", "bool": "i", "vec2": "2f", "vec3": "3f", "vec4": "4f"}
+_FIELDS = ("type", "name", "value", "qualifier", "direction", "interpolation")
 
-GLSL_TYPES = ("sampler2D", "float", "int", "bool", "vec2", "vec3", "vec4", "mat2", "mat3", "mat4")   # variable.py:12-23
-DECLARATION_ORDER = ("interpolation", "direction", "qualifier", "type", "name")
 
-
-@define(eq=False, slots=True)
 class ShaderVariable:
-    type: str
-    name: str
-    value: Optional[Any] = None
-    qualifier: Optional[str] = None
-    direction: Optional[str] = None
-    interpolation: Optional[str] = None
+    __slots__ = _FIELDS
+    _defaults: dict = {}
+
+    def __init__(self, type: str, name: str, value: Optional[Any] = None, qualifier: Optional[str] = None,
+                 direction: Optional[str] = None, interpolation: Optional[str] = None):
+        given = dict(type=type, name=name, value=value, qualifier=qualifier, direction=direction, interpolation=interpolation)
+        for key in _FIELDS:
+            setattr(self, key, given[key] if given[key] is not None else self._defaults.get(key))
+
+    # Two variables are "the same" when they have the same name: a later pipeline entry replaces an earlier one
+    def __eq__(self, other) -> bool:
+        return self.name == getattr(other, "name", None)
 
     def __hash__(self) -> int:
         return hash(self.name)
 
-    def __eq__(self, other) -> bool:
-        return (self.name == other.name)
+    def __repr__(self) -> str:
+        return f"{type(self).__name__}({self.declaration[:-1]!r}, value={self.value!r})"
 
-    def copy(self, **update):
-        other = copy.deepcopy(self)
+    def copy(self, **update) -> "ShaderVariable":
+        clone = _copy.deepcopy(self)
         for key, value in update.items():
-            setattr(other, key, value)
-        return other
+            setattr(clone, key, value)
+        return clone
 
     @property
     def size_string(self) -> Optional[str]:
-        return dict(float="f", int="i", bool="i", vec2="2f", vec3="3f", vec4="4f").get(self.type)
+        """Vertex-attribute format of the type ("2f" for vec2 …)"""
+        return _VERTEX_FORMAT.get(self.type)
 
     @property
     def declaration(self) -> str:
-        parts = (getattr(self, key, None) for key in DECLARATION_ORDER)
-        return " ".join(filter(None, parts)).strip() + ";"
+        """`[interpolation] [in|out] [uniform] type name;`"""
+        words = (self.interpolation, self.direction, self.qualifier, self.type, self.name)
+        return " ".join(word for word in words if word) + ";"
 
 
-@define(eq=False, slots=True)
 class Uniform(ShaderVariable):
-    qualifier: Optional[str] = "uniform"
+    __slots__ = ()
+    _defaults = {"qualifier": "uniform"}
 
 
-@define(eq=False, slots=True)
 class InVariable(ShaderVariable):
-    direction: Optional[str] = "in"
+    __slots__ = ()
+    _defaults = {"direction": "in"}
 
 
-@define(eq=False, slots=True)
 class OutVariable(ShaderVariable):
-    direction: Optional[str] = "out"
+    __slots__ = ()
+    _defaults = {"direction": "out"}
 
 
-@define(eq=False, slots=True)
 class FlatVariable(ShaderVariable):
-    interpolation: Optional[str] = "flat"
+    __slots__ = ()
+    _defaults = {"interpolation": "flat"}

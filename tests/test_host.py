@@ -148,8 +148,6 @@ def test_module_contract_without_gpu():
     assert scene.render_resolution == (1920, 1080)
     scene._ssaa = 1.5
     assert scene.render_resolution == (2880, 1620)
-    with pytest.raises(NotImplementedError):
-        Scene.main.__wrapped__ if hasattr(Scene.main, "__wrapped__") else (_ for _ in ()).throw(NotImplementedError())
 
 
 def test_alias_install():
