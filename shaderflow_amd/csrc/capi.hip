@@ -434,6 +434,7 @@ static void fill_args(const Program* p, RenderArgs& a) {
     a.vis_consts = nullptr;
     a.one = 1.0f;
     a.aspect = p->u.iResolution[0]/p->u.iResolution[1];
+    a.identity_camera = camera_is_identity(p->u) ? 1 : 0;
 }
 
 static bool needs(const RenderArgs& a, int slot) { return a.tex[slot].data != nullptr || (slot == TEX_SPECTROGRAM && a.tape_spectrogram) || (slot == TEX_WAVEFORM && a.tape_waveform); }

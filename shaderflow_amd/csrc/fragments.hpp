@@ -102,11 +102,16 @@ struct VisualizerPre {
     bool out_of_bounds;
 };
 
-SF_HD VisualizerPre visualizer_pre(const Frag& f, const VisualizerConsts& c) {
-    Camera cam = get_camera(f);
+SF_HD VisualizerPre visualizer_pre(const Frag& f, const VisualizerConsts& c, bool identity_camera = false) {
     VisualizerPre p;
-    p.uv = cam.gluv;
-    p.out_of_bounds = cam.out_of_bounds;
+    if (identity_camera) {                                         // glsl.hpp camera_is_identity(): same bits, no ray maths
+        p.uv = f.gluv;
+        p.out_of_bounds = (sf::abs(f.gluv.x) > f.u->iWantAspect);  // t == 1 (camera.glsl:83)
+    } else {
+        Camera cam = get_camera(f);
+        p.uv = cam.gluv;
+        p.out_of_bounds = cam.out_of_bounds;
+    }
     p.bg = (gluv2stuv(p.uv) - vec2{0.5f, 0.5f})*c.zoom2 + vec2{0.5f, 0.5f};                   // zoom(uv, z, vec2(0.5)) :17
     p.bg = p.bg + vec2{c.off_x, c.off_y};                                                      // :18
     return p;
@@ -135,7 +140,7 @@ SF_HD vec4 visualizer_post(const Frag& f, const VisualizerPre& p, const Visualiz
     const float radius = 0.17f;
 
     float circle = sf::abs(atan1n(music_uv));                                                  // :44
-    vec4 s = texture(f.tex[TEX_SPECTROGRAM], vec2{0.0f, circle});
+    vec2 s = texture_xy(f.tex[TEX_SPECTROGRAM], vec2{0.0f, circle});
     vec2 freq = {sf::sqrt(s.x/1000.0f), sf::sqrt(s.y/1000.0f)};                               // :45
     freq = freq*(0.05f + 3.0f*sf::smoothstep(0.0f, 2.0f, circle));                            // :46
 
@@ -157,7 +162,7 @@ SF_HD vec4 visualizer_post(const Frag& f, const VisualizerPre& p, const Visualiz
     set_rgb(col, rgb(col)*sf::pow(vig.x*vig.y*20.0f, c.vig_exp));                              // :66
     col.w = 1.0f;
 
-    vec4 w = texture(f.tex[TEX_WAVEFORM], vec2{f.astuv.x, 0.0f});                              // :71
+    vec2 w = texture_xy(f.tex[TEX_WAVEFORM], vec2{f.astuv.x, 0.0f});                           // :71
     vec2 wave = {0.2f*w.x, 0.2f*w.y};
     if (1.0f - f.gluv.y < wave.x) col = col*0.8f;
     if (1.0f + f.gluv.y < wave.y) col = col*0.8f;
@@ -177,7 +182,7 @@ SF_HD vec4 frag_visualizer(const Frag& f) {
 // ---- bars.frag / waveform.frag ---------------------------------------------------------------------
 SF_HD vec4 frag_bars(const Frag& f) {
     vec4 col = {0.0f, 0.0f, 0.0f, 0.0f};
-    vec4 s = texture(f.tex[TEX_SPECTROGRAM], vec2{f.astuv.y, f.astuv.x});
+    vec2 s = texture_xy(f.tex[TEX_SPECTROGRAM], vec2{f.astuv.y, f.astuv.x});
     vec2 intensity = {sf::sqrt(s.x)/120.0f, sf::sqrt(s.y)/120.0f};
     if (f.astuv.y < intensity.x) { col.x += 1.0f; col.y += 0.0f; col.z += 0.0f; }
     if (f.astuv.y < intensity.y) { col.x += 0.0f; col.y += 1.0f; col.z += 0.0f; }
@@ -187,7 +192,7 @@ SF_HD vec4 frag_bars(const Frag& f) {
     return col;
 }
 SF_HD vec4 frag_waveform(const Frag& f) {
-    vec4 w = texture(f.tex[TEX_WAVEFORM], vec2{f.astuv.x, 0.0f});
+    vec2 w = texture_xy(f.tex[TEX_WAVEFORM], vec2{f.astuv.x, 0.0f});
     vec4 col = {0.2f, 0.2f, 0.2f, 1.0f};
     float ay = sf::abs(f.gluv.y);
     if (ay < w.x) col.x = 1.0f;

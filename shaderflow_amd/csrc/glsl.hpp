@@ -60,6 +60,15 @@ SF_HD int wrap_texel(int i, int size, int repeat) {
     return (i < 0) ? 0 : ((i >= size) ? size - 1 : i);
 }
 
+// c/255.0f for an integer-valued 0 <= c <= 255 without the IEEE division sequence: one Newton correction of
+// c*RN(1/255) is the correctly rounded quotient for EVERY finite float (exhaustive: tools/check_divconst.c), so the
+// result is bit-identical to `c/255.0f` (the parity oracle writes the division).
+SF_HD float unorm8_to_float(float c) {
+    const float r = 1.0f/255.0f;
+    const float q = c*r;
+    return fmaf(fmaf(-q, 255.0f, c), r, q);
+}
+
 SF_HD vec4 texel(const Tex& t, int i, int j) {
     // written without a local array: a dynamically indexed float[4] would be promoted to LDS
     vec4 c = {0.0f, 0.0f, 0.0f, 1.0f};
@@ -67,10 +76,10 @@ SF_HD vec4 texel(const Tex& t, int i, int j) {
     const int n = t.components;
     if (t.dtype == DT_U8) {
         const uint8_t* p = (const uint8_t*)t.data + base;
-        c.x = (float)p[0]/255.0f;
-        if (n > 1) c.y = (float)p[1]/255.0f;
-        if (n > 2) c.z = (float)p[2]/255.0f;
-        if (n > 3) c.w = (float)p[3]/255.0f;
+        c.x = unorm8_to_float((float)p[0]);
+        if (n > 1) c.y = unorm8_to_float((float)p[1]);
+        if (n > 2) c.z = unorm8_to_float((float)p[2]);
+        if (n > 3) c.w = unorm8_to_float((float)p[3]);
     } else if (t.dtype == DT_F32) {
         const float* p = (const float*)t.data + base;
         c.x = p[0];
@@ -111,6 +120,31 @@ SF_HD vec4 texture(const Tex& t, vec2 uv) {       // GLSL texture(sampler2D, vec
             bilerp(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y),
             bilerp(w00, w10, w01, w11, t00.z, t10.z, t01.z, t11.z),
             bilerp(w00, w10, w01, w11, t00.w, t10.w, t01.w, t11.w)};
+}
+
+// texture(t, uv).xy for fragments that read two components only: the same operations as texture() on .x and .y
+// (so the same bits), without blending the two components the caller drops
+SF_HD vec2 texel_xy(const Tex& t, int i, int j) {
+    vec4 c = texel(t, i, j);
+    return {c.x, c.y};
+}
+SF_HD vec2 texture_xy(const Tex& t, vec2 uv) {
+    float u = uv.x*(float)t.width;
+    float v = uv.y*(float)t.height;
+    if (t.filter == FILTER_NEAREST) {
+        int i = wrap_texel((int)::floorf(u), t.width, t.repeat_x);
+        int j = wrap_texel((int)::floorf(v), t.height, t.repeat_y);
+        return texel_xy(t, i, j);
+    }
+    float ub = u - 0.5f, vb = v - 0.5f;
+    float fu = ::floorf(ub), fv = ::floorf(vb);
+    float a = ub - fu, b = vb - fv;
+    int i0 = wrap_texel((int)fu, t.width, t.repeat_x), i1 = wrap_texel((int)fu + 1, t.width, t.repeat_x);
+    int j0 = wrap_texel((int)fv, t.height, t.repeat_y), j1 = wrap_texel((int)fv + 1, t.height, t.repeat_y);
+    vec2 t00 = texel_xy(t, i0, j0), t10 = texel_xy(t, i1, j0), t01 = texel_xy(t, i0, j1), t11 = texel_xy(t, i1, j1);
+    float na = 1.0f - a, nb = 1.0f - b;
+    float w00 = na*nb, w10 = a*nb, w01 = na*b, w11 = a*b;
+    return {bilerp(w00, w10, w01, w11, t00.x, t10.x, t01.x, t11.x), bilerp(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y)};
 }
 
 SF_HD uint32_t unorm8(float c) {
@@ -231,6 +265,19 @@ SF_HD vec3 camera_ray_origin(const Camera& c, vec2 g) {                         
 }
 SF_HD vec3 camera_ray_target(const Camera& c, vec2 g) {                                                      // :65-70
     return c.position + camera_rectangle(c, g, c.zoom) + (c.backward*c.orbital) + (c.forward*c.focal_length);
+}
+
+// The freshly built camera (camera.py:147-185: position 0, identity basis, zoom 1, isometric 0, focal length 1,
+// orbital 0, dolly 0, perspective) projects every fragment onto itself: origin = 0, target = (gluv, 1), t = 1, and
+// every product with 0 or 1 is exact, so iCamera.gluv == gluv bit for bit. Hosts may set `identity_camera`.
+SF_HD bool camera_is_identity(const Uniforms& u) {
+    return u.iCameraProjection == 0
+        && u.iCameraPosition[0] == 0.0f && u.iCameraPosition[1] == 0.0f && u.iCameraPosition[2] == 0.0f
+        && u.iCameraRight[0] == 1.0f && u.iCameraRight[1] == 0.0f && u.iCameraRight[2] == 0.0f
+        && u.iCameraUpward[0] == 0.0f && u.iCameraUpward[1] == 1.0f && u.iCameraUpward[2] == 0.0f
+        && u.iCameraForward[0] == 0.0f && u.iCameraForward[1] == 0.0f && u.iCameraForward[2] == 1.0f
+        && u.iCameraZoom == 1.0f && u.iCameraIsometric == 0.0f && u.iCameraFocalLength == 1.0f
+        && u.iCameraOrbital == 0.0f && u.iCameraDolly == 0.0f;
 }
 
 SF_HD Camera get_camera(const Frag& f) {                           // GetCamera :132-155 → CameraProject :93-130

@@ -39,6 +39,7 @@ struct RenderArgs {
     VisualizerConsts vis;
     int has_vis;
     float one;                       // 1.0f, kept opaque to the optimiser (visualizer_kernels.hpp tap())
+    int identity_camera;             // glsl.hpp camera_is_identity(u): iCamera.gluv == gluv exactly
     float aspect;                    // iResolution.x/iResolution.y (iAspectRatio, shaderflow.glsl:16), divided once on the host
 };
 
@@ -149,7 +150,7 @@ __device__ __forceinline__ uint32_t quad_lane1(uint32_t v) { return dpp_u32<0x55
 __device__ __forceinline__ uint32_t quad_lane2(uint32_t v) { return dpp_u32<0xAA>(v); }
 __device__ __forceinline__ uint32_t quad_lane3(uint32_t v) { return dpp_u32<0xFF>(v); }
 
-__device__ __forceinline__ float unorm_channel(uint32_t q, int shift) { return (float)((q >> shift) & 255u)/255.0f; }
+__device__ __forceinline__ float unorm_channel(uint32_t q, int shift) { return unorm8_to_float((float)((q >> shift) & 255u)); }
 
 // The iScreen texel a supersample becomes (RGBA8 unorm), then final.glsl (:13-31) over the S x S block of one
 // output pixel, for ONE colour channel (bits [shift, shift+8) of the packed texels). q[] holds the block in texel

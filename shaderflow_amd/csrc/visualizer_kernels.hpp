@@ -72,7 +72,7 @@ struct VisualizerShader {
 
     __device__ static void pre(const RenderArgs& a, const Frag& f, bool, State& s) {
         const VisualizerConsts c = frame_consts(a, f);
-        s.pre = visualizer_pre(f, c);
+        s.pre = visualizer_pre(f, c, a.identity_camera != 0);
         const Tex& bg = f.tex[TEX_BACKGROUND];
         // same chain as stexture() → texture() for the centre tap (glsl.hpp)
         vec2 scale = {(float)bg.height/(float)bg.width, 1.0f};
