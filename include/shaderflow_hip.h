@@ -189,11 +189,14 @@ enum { SFX_TAPE_SPECTROGRAM = 0, SFX_TAPE_WAVEFORM = 1, SFX_TAPE_UNIFORMS = 2, S
 int sfx_tape_read(sfx_handle tape, int what, int frame0, int nframes, void* out, size_t nbytes);
 int sfx_tape_destroy(sfx_handle tape);
 
-/* Renders tape frames [frame0, frame0+nframes) with `program`, fused path, into a dense device buffer of
- * nframes RGB8 images (w*h*3 bytes each, rows bottom-up). iSpectrogram/iWaveform samplers and the
- * audio uniforms come from the tape; everything else from the program's uniform block. */
+/* Renders tape frames [frame0, frame0+nframes) with `program` into a dense device buffer of nframes RGB8 images
+ * (w*h*3 bytes each, rows bottom-up). ssaa is given times 1000 (scene.ssaa may be fractional, scene.py:372-375).
+ * (ssaa, subsample) pairs that sfx_fused_supported() accepts use the fused kernel; any other pair renders the
+ * batch in two passes (fragment → RGBA8 iScreen scratch → final.glsl), exactly like shader.py:388-405.
+ * iSpectrogram/iWaveform samplers and the audio uniforms come from the tape; everything else from the program's
+ * uniform block. */
 int sfx_render_tape(sfx_handle program, sfx_handle tape, int frame0, int nframes,
-                    int width, int height, int ssaa, int subsample, void* device_out);
+                    int width, int height, int ssaa_x1000, int subsample, void* device_out);
 
 /* Device memory helper for callers without their own allocator */
 int sfx_device_alloc(sfx_handle ctx, size_t nbytes, void** ptr);

@@ -551,6 +551,7 @@ extern "C" int sfx_resolve(sfx_handle h, sfx_handle src, sfx_handle dst, int sub
     a.screen.filter = s->filter; a.screen.repeat_x = s->repeat_x; a.screen.repeat_y = s->repeat_y;
     a.w = d->width; a.h = d->height; a.subsample = subsample < 1 ? 1 : subsample;
     a.out = (uint8_t*)d->data;
+    a.screen_frame_stride = 0; a.out_frame_stride = 0;
     hipLaunchKernelGGL(k_resolve, dim3((a.w + 63)/64, (a.h + 3)/4), dim3(64, 4), 0, c->stream, a);
     return launch_status();
 }
@@ -947,6 +948,7 @@ struct Tape : Object {
     float* d_state; ScalarState* d_scalars; FrameDyn* d_dyn;
     DynCoeffF32* d_coeff; DynCoeffF64 *d_vol, *d_std; FrameClock* d_clock;
     VisualizerConsts* d_vis;
+    void* d_screen = nullptr; size_t screen_bytes = 0;   // iScreen scratch of the two-pass path (frames of a batch)
 };
 
 extern "C" int sfx_tape_reset(sfx_handle h) {
@@ -1042,25 +1044,28 @@ extern "C" int sfx_tape_destroy(sfx_handle h) {
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
     hipFree(t->d_tell); hipFree(t->d_power); hipFree(t->d_targets); hipFree(t->d_columns); hipFree(t->d_rows); hipFree(t->d_loudness);
-    hipFree(t->d_state); hipFree(t->d_scalars); hipFree(t->d_dyn); hipFree(t->d_coeff); hipFree(t->d_vol); hipFree(t->d_std); hipFree(t->d_clock); hipFree(t->d_vis);
+    hipFree(t->d_state); hipFree(t->d_scalars); hipFree(t->d_dyn); hipFree(t->d_coeff); hipFree(t->d_vol); hipFree(t->d_std); hipFree(t->d_clock); hipFree(t->d_vis); hipFree(t->d_screen);
     t->magic = 0;
     delete t;
     return SFX_OK;
 }
 
 extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nframes, int width, int height,
-                               int ssaa, int subsample, void* device_out) {
+                               int ssaa_x1000, int subsample, void* device_out) {
     Program* p = get<Program>(hp, MAGIC_PROG);
     Tape* t = get<Tape>(ht, MAGIC_TAPE);
     if (!p || !t || !device_out) return fail(SFX_E_INVALID, "invalid program/tape handle or output");
     if (p->ctx != t->ctx) return fail(SFX_E_INVALID, "program and tape belong to different contexts");
     if (frame0 < 0 || nframes < 1 || frame0 + nframes > t->max_frames) return fail(SFX_E_INVALID, "frames [%d, %d) outside the tape", frame0, frame0 + nframes);
     if (subsample < 1) subsample = 1;
-    if (!fused_supported(ssaa, subsample)) return fail(SFX_E_UNSUPPORTED, "tape rendering needs a fused (ssaa, subsample) pair, got (%d, %d)", ssaa, subsample);
+    if (ssaa_x1000 < 10) return fail(SFX_E_INVALID, "ssaa %d/1000", ssaa_x1000);
+    const bool fused = (ssaa_x1000 % 1000 == 0) && fused_supported(ssaa_x1000/1000, subsample);
+    const int ssaa = ssaa_x1000/1000;
     USE_DEVICE(p->ctx);
     RenderArgs a;
     fill_args(p, a);
-    a.w = width; a.h = height; a.wr = width*ssaa; a.hr = height*ssaa; a.subsample = subsample;
+    a.w = width; a.h = height; a.subsample = subsample;
+    a.wr = (int)((double)width*ssaa_x1000/1000.0); a.hr = (int)((double)height*ssaa_x1000/1000.0);   // scene.py:372-375
     a.out = device_out; a.out_frame_stride = (long)width*height*3;
     a.dyn = t->d_dyn; a.frame0 = frame0;
     // iSpectrogram: width 1 (length=0 scenes), height bins, RG32F (spectrogram.py:298-311); the bound texture's
@@ -1089,6 +1094,24 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
         hipLaunchKernelGGL(k_visualizer_consts, dim3((nframes + 63)/64), dim3(64), 0, p->ctx->stream, t->d_dyn, frame0, nframes, t->d_vis);
         a.vis_consts = t->d_vis;
     }
-    if ((rc = launch_fused(p->fragment, a, ssaa, nframes, p->ctx->stream))) return rc;
+    if (fused) {
+        if ((rc = launch_fused(p->fragment, a, ssaa, nframes, p->ctx->stream))) return rc;
+        return launch_status();
+    }
+    // two passes, batched: the fragment into an RGBA8 iScreen scratch per frame, then final.glsl (shader.py:388-405)
+    const size_t screen_frame = (size_t)a.wr*a.hr*4;
+    if (t->screen_bytes < screen_frame*nframes) {
+        HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+        hipFree(t->d_screen); t->d_screen = nullptr; t->screen_bytes = 0;
+        HIP_TRY(hipMalloc(&t->d_screen, screen_frame*nframes));
+        t->screen_bytes = screen_frame*nframes;
+    }
+    a.out = t->d_screen; a.out_frame_stride = (long)screen_frame; a.out_components = 4; a.out_dtype = DT_U8;
+    if ((rc = launch_render(p->fragment, a, nframes, p->ctx->stream))) return rc;
+    ResolveArgs r;
+    r.screen = Tex{t->d_screen, a.wr, a.hr, 4, DT_U8, FILTER_LINEAR, 0, 0};      // iScreen: linear, repeat(False) (scene.py:192-194)
+    r.w = width; r.h = height; r.subsample = subsample; r.out = (uint8_t*)device_out;
+    r.screen_frame_stride = (long)screen_frame; r.out_frame_stride = (long)width*height*3;
+    hipLaunchKernelGGL(k_resolve, dim3((width + 63)/64, (height + 3)/4, nframes), dim3(64, 4), 0, p->ctx->stream, r);
     return launch_status();
 }

@@ -112,6 +112,7 @@ struct ResolveArgs {
     Tex screen;                      // RGBA8, linear, clamp (scene.py:192-194)
     int w, h, subsample;
     uint8_t* out;                    // RGB8 rows bottom-up
+    long screen_frame_stride, out_frame_stride;    // bytes between frames of a batch (grid.z)
 };
 
 __device__ __forceinline__ vec3 final_glsl(const Tex& screen, vec2 astuv, vec2 resolution, int kernel) {
@@ -135,8 +136,10 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveArgs a) {
     if (i >= a.w || j >= a.h) return;
     vec2 centre = {((float)i + 0.5f)/(float)a.w, ((float)j + 0.5f)/(float)a.h};
     vec2 astuv = gluv2stuv(centre*2.0f - 1.0f);
-    vec3 c = final_glsl(a.screen, astuv, vec2{(float)a.w, (float)a.h}, a.subsample);
-    uint8_t* p = a.out + ((long)j*a.w + i)*3;
+    Tex screen = a.screen;
+    screen.data = (const char*)a.screen.data + (long)blockIdx.z*a.screen_frame_stride;
+    vec3 c = final_glsl(screen, astuv, vec2{(float)a.w, (float)a.h}, a.subsample);
+    uint8_t* p = a.out + (long)blockIdx.z*a.out_frame_stride + ((long)j*a.w + i)*3;
     p[0] = (uint8_t)unorm8(c.x); p[1] = (uint8_t)unorm8(c.y); p[2] = (uint8_t)unorm8(c.z);
 }
 

@@ -86,7 +86,7 @@ class FrameTape:
             return False
         if scene.shader.texture.temporal != 1 or scene.shader.texture.layers != 1:
             return False
-        return bool(scene.fuse and N.lib().sfx_fused_supported(int(round(scene.ssaa*1000)), scene.subsample))
+        return True                                               # any (ssaa, subsample): fused when possible, else two passes
 
     def __init__(self, scene: "ShaderScene", batch: Optional[int] = None, use_mfma: bool = True):
         self.scene = scene
@@ -162,7 +162,7 @@ class FrameTape:
         """Tape slots [first_slot, first_slot+count) → `count` RGB8 frames at `device_out`"""
         scene = self.scene
         N.check(N.lib().sfx_render_tape(scene.shader.program, self.handle, first_slot, count, scene.width, scene.height,
-                                        int(scene.ssaa), scene.subsample, C.c_void_p(device_out)))
+                                        int(round(scene.ssaa*1000)), scene.subsample, C.c_void_p(device_out)))
 
     def read(self, what: int, count: int, first_slot: int = 0) -> np.ndarray:
         """Tape content for inspection (tests)"""

@@ -91,12 +91,12 @@ def test_visualizer_frame_loop_and_tape_match_oracle(ssaa, subsample):
     assert got_loop.shape == want.shape
     mostly_within_one_lsb(got_loop, want)
 
-    if ssaa == subsample:                                         # the tape renders through the fused kernel only
-        tape = make(Visualizer, audio=(pcm, sr), background=background)
-        raw = tape.main(width=w, height=h, fps=fps, ssaa=ssaa, subsample=subsample, time=seconds, output=bytes, batch=None)
-        got_tape = frames_of(raw, w, h)
-        mostly_within_one_lsb(got_tape, want)
-        mostly_within_one_lsb(got_tape, got_loop, fraction=0.9995)
+    # the tape renders (2, 2) through the fused kernel and (1, 2) in two batched passes
+    tape = make(Visualizer, audio=(pcm, sr), background=background)
+    raw = tape.main(width=w, height=h, fps=fps, ssaa=ssaa, subsample=subsample, time=seconds, output=bytes, batch=None)
+    got_tape = frames_of(raw, w, h)
+    mostly_within_one_lsb(got_tape, want)
+    mostly_within_one_lsb(got_tape, got_loop, fraction=0.9995)
 
 
 def test_tape_is_chosen_only_for_stock_scenes():
@@ -106,8 +106,8 @@ def test_tape_is_chosen_only_for_stock_scenes():
     vis = make(Visualizer, audio=(pcm, sr), background=synth.background_image(64, 36))
     vis.initialize(); vis._ssaa = 2.0
     assert FrameTape.applicable(vis)
-    vis._ssaa = 1.0                                               # (1, 2) needs the two-pass path
-    assert not FrameTape.applicable(vis)
+    vis._ssaa = 1.5                                               # fractional SSAA: two batched passes
+    assert FrameTape.applicable(vis)
     dyn = Dynamics()
     dyn.initialize()
     assert not FrameTape.applicable(dyn)                          # python update() every frame

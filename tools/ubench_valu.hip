@@ -46,6 +46,7 @@
 #define I_FMAC(r) "v_fmac_f32 " r ", %8, %9"
 #define I_FMAAK(r) "v_fmaak_f32 " r ", %8, " r ", 0x3f9d70a4"
 #define I_MOV(r) "v_mov_b32 " r ", %8"
+#define I_PK_FMA32(r) "v_pk_fma_f32 %0, %8, %9, %0 \n v_pk_fma_f32 %1, %8, %9, %1"
 #define I_MAD_MIX_LEGACY(r) "v_fma_mix_f32 " r ", %8, %9, %8 op_sel_hi:[0,1,0]"
 
 template <int WHICH>
@@ -92,6 +93,25 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, float sxf) {
     out[blockIdx.x*blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 
+__global__ __launch_bounds__(512) void k_pk(double* out, int iters) {
+    double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    double x = 1.0001, y = 0.9999;
+    for (int i = 0; i < iters; i++) {
+#define PK8(OP) asm volatile(OP " %0, %8, %9, %0\n" OP " %1, %8, %9, %1\n" OP " %2, %8, %9, %2\n" OP " %3, %8, %9, %3\n" OP " %4, %8, %9, %4\n" OP " %5, %8, %9, %5\n" OP " %6, %8, %9, %6\n" OP " %7, %8, %9, %7\n" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y));
+        PK8("v_pk_fma_f32") PK8("v_pk_fma_f32") PK8("v_pk_fma_f32") PK8("v_pk_fma_f32")
+    }
+    out[blockIdx.x*blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+__global__ __launch_bounds__(512) void k_pkadd(double* out, int iters) {
+    double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    double x = 1.0001;
+    for (int i = 0; i < iters; i++) {
+#define PA8(OP) asm volatile(OP " %0, %8, %0\n" OP " %1, %8, %1\n" OP " %2, %8, %2\n" OP " %3, %8, %3\n" OP " %4, %8, %4\n" OP " %5, %8, %5\n" OP " %6, %8, %6\n" OP " %7, %8, %7\n" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x));
+        PA8("v_pk_add_f32") PA8("v_pk_add_f32") PA8("v_pk_add_f32") PA8("v_pk_add_f32")
+    }
+    out[blockIdx.x*blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
 template <int WHICH> double run(const char* name, float* d_out, int cus, double clock_ghz) {
     const int iters = 4096, blocks = cus*4;                  // 4 blocks x 8 waves = 32 waves per CU = 8 per SIMD
     hipEvent_t e0, e1;
@@ -115,6 +135,20 @@ int main() {
     const double ghz = prop.clockRate/1e6;
     printf("%s: %d CUs, %.2f GHz max\n", prop.name, cus, ghz);
     float* d_out; hipMalloc(&d_out, sizeof(float)*cus*4*512);
+    {
+        double* d2; hipMalloc(&d2, sizeof(double)*cus*4*512);
+        for (int which = 0; which < 2; which++) {
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            if (which == 0) hipLaunchKernelGGL(k_pk, dim3(cus*4), dim3(512), 0, 0, d2, 64); else hipLaunchKernelGGL(k_pkadd, dim3(cus*4), dim3(512), 0, 0, d2, 64);
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            if (which == 0) hipLaunchKernelGGL(k_pk, dim3(cus*4), dim3(512), 0, 0, d2, 4096); else hipLaunchKernelGGL(k_pkadd, dim3(cus*4), dim3(512), 0, 0, d2, 4096);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            const double ns = ms*1e6/(4096.0*32*8);
+            printf("%-28s %8.3f ms   %6.3f ns per wave-instruction per SIMD  = %5.2f cycles @ %.2f GHz (2 lanes-ops per lane)\n", which == 0 ? "v_pk_fma_f32" : "v_pk_add_f32", ms, ns, ns*ghz, ghz);
+        }
+    }
     run<0>("v_fma_f32", d_out, cus, ghz);
     run<13>("v_fma_f32 (sgpr operand)", d_out, cus, ghz);
     run<12>("v_mul_f32", d_out, cus, ghz);
