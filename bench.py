@@ -54,6 +54,8 @@ def parse_args():
     p.add_argument("--ssaa", type=int, default=2)
     p.add_argument("--frames-per-step", type=int, default=60)
     p.add_argument("--seconds", type=float, default=60.0, help="length of the synthetic clip")
+    p.add_argument("--scene", choices=("visualizer", "bars"), default="visualizer",
+                   help="visualizer = the metric's scene; bars = MusicBars (a light, HBM-write-bound fragment)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-rows", type=int, default=0, help="output rows of the CPU baseline band (0 = auto, ~15 s)")
     return p.parse_args()
@@ -117,7 +119,7 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from examples.scenes import Visualizer, make
+    from examples.scenes import MusicBars, Visualizer, make
     from shaderflow_amd import _native as N
     from shaderflow_amd import synth
     from shaderflow_amd.parallel import FrameGather
@@ -130,7 +132,8 @@ def main() -> None:
     w, h, s, fpb = args.width, args.height, args.ssaa, args.frames_per_step
     pcm = synth.sweep_clip(args.seconds, 44100)
     background = synth.background_image(1920, 1080, seed=0)
-    scene = make(Visualizer, audio=(pcm, 44100), background=background, context=context)
+    scene_class = Visualizer if args.scene == "visualizer" else MusicBars
+    scene = make(scene_class, audio=(pcm, 44100), background=(background if args.scene == "visualizer" else None), context=context)
     scene.initialize()
     scene.exporting = scene.freewheel = scene.headless = True
     scene.realtime = False
@@ -150,7 +153,8 @@ def main() -> None:
     N.check(N.lib().sfx_tape_reset(tape.handle))
 
     frame_bytes = w*h*3
-    buffers = [torch.empty(fpb*frame_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    # zeros, not empty: the first touch of fresh device memory is paid here, outside the timed region
+    buffers = [torch.zeros(fpb*frame_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
     gather = FrameGather(world, rank, fpb*frame_bytes, torch.device("cuda", local_rank)) if distributed else None
 
     def step(index: int, timed_slot: int | None):
@@ -172,6 +176,14 @@ def main() -> None:
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # Initialisation, not a measured or counted step: first launches load code objects, commit the scratch buffers and
+    # bring the GPU out of its idle power state (observed: a one-off ~70 ms stall otherwise lands in short runs)
+    for i in range(2):
+        tape.build(0, fpb)
+        tape.render(fpb, buffers[i].data_ptr())
+    torch.cuda.synchronize()
+    N.check(N.lib().sfx_tape_reset(tape.handle))
 
     for i in range(args.warmup):
         step(i, None)
@@ -200,15 +212,15 @@ def main() -> None:
         achieved = b_alg*fpb/launch_s/1e9
         samples_per_s = (w*s)*(h*s)*fpb/launch_s
         lane_ops = samples_per_s*PROFILE["valu_instr_per_supersample"]
-        c3 = (w, h, s) == (3840, 2160, 2)
+        c3 = (w, h, s) == (3840, 2160, 2) and args.scene == "visualizer"
         result = {
-            "metric": "frames/sec at 4K 2xSSAA music-visualizer",
+            "metric": "frames/sec at 4K 2xSSAA music-visualizer" if args.scene == "visualizer" else f"frames/sec {args.scene}",
             "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed/args.steps*1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Visualizer scene {w}x{h} {s}xSSAA subsample 2, 60 fps, 60 s synthetic stereo sine sweep @44.1 kHz, "
+            "config": {"workload": f"{scene_class.__name__} scene {w}x{h} {s}xSSAA subsample 2, 60 fps, 60 s synthetic stereo sine sweep @44.1 kHz, "
                                    f"1920x1080 synthetic background; step = {fpb} frames (STFT+filterbank+dynamics tape, fused fragment+resolve)",
                        "frames_per_step": fpb, "global_frames_per_step": fpb*world,
                        "parallelism": f"frame-range sharding x{world}" + (", RCCL gather to rank 0" if distributed else "")},
