@@ -15,6 +15,15 @@ from __future__ import annotations
 from typing import Optional
 
 
+def rank_world() -> tuple[int, int]:
+    """(rank, world) of the process group, (0, 1) when torch.distributed is not in use"""
+    import sys
+    dist = sys.modules.get("torch.distributed")
+    if dist is not None and dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def shard_frames(total: int, world: int, rank: int) -> tuple[int, int]:
     """Contiguous frame range [first, last) of `rank`: sizes differ by at most one, earlier ranks get the extra"""
     base, extra = divmod(total, world)
@@ -57,3 +66,45 @@ class FrameGather:
         """Rank 0: the `world` buffers of the last completed gather of `slot`, in rank order"""
         self.wait(slot)
         return self.received[slot]
+
+
+def round_robin_export(world: int, rank: int, batches: list[tuple[int, int]], advance, render, emit, gather: "FrameGather | None",
+                       buffers: list, frame_bytes: int) -> None:
+    """Sharded export of `batches` = [(first frame, count), …] (in time order) over `world` ranks.
+
+    Batch b is RENDERED by rank b % world; every rank ADVANCES the audio tape through every batch (the DynamicNumber
+    recurrences must see all frames, and doing that redundantly costs microseconds per frame and no communication).
+    After each round of `world` batches the finished frames are gathered to rank 0, which `emit`s them in frame order
+    — so the encoder-side rank never holds more than one round. The gather of round r overlaps the render of round r+1
+    (two alternating buffers per rank).
+
+        advance(first, count)            compute the tape for those frames (all ranks, all batches)
+        render(count, buffer)            render the tape slots [0, count) into `buffer` (the owner of the batch)
+        emit(buffer, count)              rank 0: hand `count` frames at the start of `buffer` to the sink
+        buffers                          two equally sized per-rank frame buffers (torch uint8 tensors)
+    """
+    rounds = [batches[k:k + world] for k in range(0, len(batches), world)]
+    pending: list[tuple[int, list[tuple[int, int]]]] = []            # (slot, round) whose gather is in flight
+
+    def drain(slot: int, members: list[tuple[int, int]]) -> None:
+        if gather is None:
+            emit(buffers[slot], members[0][1])
+            return
+        received = gather.frames(slot)
+        if rank == 0:
+            for owner, (_, count) in enumerate(members):
+                emit(received[owner], count)
+
+    for index, members in enumerate(rounds):
+        slot = index % 2
+        while pending and pending[0][0] == slot:                     # this buffer's previous round must have left
+            drain(*pending.pop(0))
+        for owner, (first, count) in enumerate(members):
+            advance(first, count)
+            if owner == rank:
+                render(count, buffers[slot])
+        if gather is not None:
+            gather.start(slot, buffers[slot])                        # ranks without a batch in a short last round send stale bytes
+        pending.append((slot, members))
+    while pending:
+        drain(*pending.pop(0))

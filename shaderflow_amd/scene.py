@@ -318,7 +318,10 @@ class ShaderScene(ShaderModule):
             self.ssaa = ssaa
 
         export = ExportingHelper(self)
-        if (self.exporting):
+        from shaderflow_amd.parallel import rank_world
+        if (self.exporting) and rank_world()[0] != 0:
+            pass                                             # sharded export: only rank 0 owns the sink (tape.py)
+        elif (self.exporting):
             export.ffmpeg_sizes(width=_width, height=_height)
             export.ffmpeg_output(output)
             export.make_buffers(buffers)

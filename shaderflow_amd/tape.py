@@ -179,27 +179,52 @@ class FrameTape:
     # whole export ---------------------------------------------------------------------------------------------------
 
     def export(self, export: "ExportingHelper", turbo: bool = True):
+        """The whole export. With an initialised torch.distributed process group (one process per GPU) the batches are
+        rendered round-robin by the ranks and gathered to rank 0, which owns the sink (parallel.round_robin_export)."""
+        from shaderflow_amd.parallel import FrameGather, rank_world, round_robin_export, shard_batches
         scene = self.scene
         total = export.total_frames
+        rank, world = rank_world()
         self.prepare(total)
         self.bind_static_uniforms()
         N.check(N.lib().sfx_tape_reset(self.handle))
         frame_bytes = scene.width*scene.height*3
         context = scene.context
-        buffers = [context.alloc(frame_bytes*self.batch) for _ in range(2)]
+        batches = shard_batches(0, total, self.batch)
+
+        def emit_frames(pointer: int, count: int) -> None:
+            for i in range(count):
+                export.pipe_device(pointer + i*frame_bytes, turbo=turbo)
+                export.update()
+
         try:
-            for index, first in enumerate(range(0, total, self.batch)):
-                count = min(self.batch, total - first)
-                target = buffers[index % 2]
-                self.build(first, count)
-                self.render(count, target)
-                for i in range(count):
-                    export.pipe_device(target + i*frame_bytes, turbo=turbo)
-                    export.update()
+            if world == 1:
+                buffers = [context.alloc(frame_bytes*self.batch) for _ in range(2)]
+                try:
+                    for index, (first, count) in enumerate(batches):
+                        self.build(first, count)
+                        self.render(count, buffers[index % 2])
+                        emit_frames(buffers[index % 2], count)
+                finally:
+                    context.synchronize()
+                    for pointer in buffers:
+                        context.free(pointer)
+            else:
+                import torch
+                device = torch.device("cuda", context.device)
+                buffers = [torch.zeros(frame_bytes*self.batch, dtype=torch.uint8, device=device) for _ in range(2)]
+                gather = FrameGather(world, rank, frame_bytes*self.batch, device)
+
+                def render(count, buffer):
+                    self.render(count, buffer.data_ptr())
+                    context.synchronize()                       # the context's stream is not torch's: order before the gather
+
+                round_robin_export(world, rank, batches, self.build, render,
+                                   lambda buffer, count: emit_frames(buffer.data_ptr(), count), gather, buffers, frame_bytes)
+                if rank != 0:
+                    export.frame = total
             scene.time, scene.dt, scene.rdt = self.times[-1], self.dts[-1], self.dts[-1]      # clock of the last frame
             return export.finish()
         finally:
             context.synchronize()
-            for pointer in buffers:
-                context.free(pointer)
             self.release()

@@ -73,3 +73,66 @@ def test_two_rank_gather_over_gloo():
         assert p.exitcode == 0
     want = [[(17*step + rank) % 256 for rank in range(world)] for step in range(steps)]
     assert sorted(seen) == sorted(want), seen
+
+
+def _export_worker(rank: int, world: int, port: int, total: int, batch: int, out):
+    import numpy as np
+    from shaderflow_amd.parallel import round_robin_export
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frame_bytes = 8
+        buffers = [torch.zeros(batch*frame_bytes, dtype=torch.uint8) for _ in range(2)]
+        gather = FrameGather(world, rank, batch*frame_bytes, torch.device("cpu"))
+        state = {"tape": None, "seen": 0}                        # the "recurrence": every rank must advance through every frame in order
+        emitted = []
+
+        def advance(first, count):
+            assert first == state["seen"], (rank, first, state["seen"])
+            state["seen"] += count
+            state["tape"] = (first, count)
+
+        def render(count, buffer):
+            first, n = state["tape"]
+            frames = torch.arange(first, first + n, dtype=torch.int64).view(torch.uint8)     # frame k is the 8 bytes of int64(k)
+            buffer[:n*frame_bytes] = frames
+
+        def emit(buffer, count):
+            emitted.extend(np.frombuffer(buffer[:count*frame_bytes].numpy().tobytes(), np.int64).tolist())
+
+        round_robin_export(world, rank, shard_batches(0, total, batch), advance, render, emit, gather, buffers, frame_bytes)
+        assert state["seen"] == total
+        if rank == 0:
+            out.put(emitted)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("total,batch", [(50, 8), (64, 8), (7, 4)])
+def test_round_robin_export_emits_every_frame_in_order(total, batch):
+    """The sharded export orchestration (batch b rendered by rank b % world, gathered per round) with fake renders"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_export_worker, args=(r, world, port, total, batch, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    emitted = out.get(timeout=90)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert emitted == list(range(total))
+
+
+def test_round_robin_export_single_rank():
+    from shaderflow_amd.parallel import round_robin_export
+    log = []
+    buffers = [bytearray(4), bytearray(4)]
+    round_robin_export(1, 0, shard_batches(0, 10, 4), lambda f, c: log.append(("advance", f, c)),
+                       lambda c, b: log.append(("render", c)), lambda b, c: log.append(("emit", c)), None, buffers, 1)
+    assert [e for e in log if e[0] == "emit"] == [("emit", 4), ("emit", 4), ("emit", 2)]
+    assert [e for e in log if e[0] == "advance"] == [("advance", 0, 4), ("advance", 4, 4), ("advance", 8, 2)]
