@@ -118,6 +118,12 @@ int sfx_fused_supported(int ssaa_numerator_x1000, int subsample);
 int sfx_ring_create(sfx_handle ctx, size_t frame_bytes, int slots, sfx_handle* ring);
 int sfx_ring_read_async(sfx_handle ring, sfx_handle tex, int slot);                 /* fbo.read_into(buffer) */
 int sfx_ring_read_device_async(sfx_handle ring, const void* device_ptr, int slot);  /* same, from a raw frame */
+/* Batched producers (the frame tape renders many frames per launch): mark "everything launched so far is what the
+ * next reads may depend on" with one of two fences, read frames against that fence, and make the render stream
+ * wait for a slot's copy before the frame buffer it came from is overwritten. */
+int sfx_ring_fence(sfx_handle ring, int which /* 0 or 1 */);
+int sfx_ring_read_fenced_async(sfx_handle ring, const void* device_ptr, int slot, int which);
+int sfx_ring_stream_wait(sfx_handle ring, int slot);
 int sfx_ring_sync(sfx_handle ring, int slot, void** host_ptr);                      /* buffer.read() */
 int sfx_ring_pipe(sfx_handle ring, int slot, int fd);                               /* turbopipe.pipe */
 int sfx_ring_pipe_sync(sfx_handle ring, int slot);                                  /* turbopipe.sync; slot < 0: all */

@@ -590,6 +590,7 @@ struct Ring : Object {
     std::vector<hipEvent_t> copied;
     hipStream_t copy_stream;
     hipEvent_t produced;
+    hipEvent_t fences[2];
     // writer
     std::thread writer;
     std::mutex mutex;
@@ -636,6 +637,7 @@ extern "C" int sfx_ring_create(sfx_handle h, size_t frame_bytes, int slots, sfx_
     r->host.resize(slots); r->copied.resize(slots); r->pending.assign(slots, 0);
     HIP_TRY(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&r->produced, hipEventDisableTiming));
+    for (auto& f : r->fences) HIP_TRY(hipEventCreateWithFlags(&f, hipEventDisableTiming));
     for (int k = 0; k < slots; k++) {
         HIP_TRY(hipHostMalloc(&r->host[k], frame_bytes, hipHostMallocDefault));
         HIP_TRY(hipEventCreateWithFlags(&r->copied[k], hipEventDisableTiming));
@@ -661,6 +663,34 @@ extern "C" int sfx_ring_read_device_async(sfx_handle h, const void* dptr, int sl
     HIP_TRY(hipStreamWaitEvent(r->copy_stream, r->produced, 0));    // …before the copy engine reads it
     HIP_TRY(hipMemcpyAsync(r->host[slot], dptr, r->frame_bytes, hipMemcpyDeviceToHost, r->copy_stream));
     HIP_TRY(hipEventRecord(r->copied[slot], r->copy_stream));
+    return SFX_OK;
+}
+
+extern "C" int sfx_ring_fence(sfx_handle h, int which) {
+    Ring* r = get<Ring>(h, MAGIC_RING);
+    if (!r || which < 0 || which > 1) return fail(SFX_E_INVALID, "invalid ring handle or fence");
+    USE_DEVICE(r->ctx);
+    HIP_TRY(hipEventRecord(r->fences[which], r->ctx->stream));
+    return SFX_OK;
+}
+
+extern "C" int sfx_ring_read_fenced_async(sfx_handle h, const void* dptr, int slot, int which) {
+    Ring* r = get<Ring>(h, MAGIC_RING);
+    if (!r || !dptr || slot < 0 || slot >= r->slots || which < 0 || which > 1) return fail(SFX_E_INVALID, "invalid ring handle, pointer, slot or fence");
+    USE_DEVICE(r->ctx);
+    int rc = ring_wait_slot(r, slot);
+    if (rc) return rc;
+    HIP_TRY(hipStreamWaitEvent(r->copy_stream, r->fences[which], 0));
+    HIP_TRY(hipMemcpyAsync(r->host[slot], dptr, r->frame_bytes, hipMemcpyDeviceToHost, r->copy_stream));
+    HIP_TRY(hipEventRecord(r->copied[slot], r->copy_stream));
+    return SFX_OK;
+}
+
+extern "C" int sfx_ring_stream_wait(sfx_handle h, int slot) {
+    Ring* r = get<Ring>(h, MAGIC_RING);
+    if (!r || slot < 0 || slot >= r->slots) return fail(SFX_E_INVALID, "invalid ring handle or slot");
+    USE_DEVICE(r->ctx);
+    HIP_TRY(hipStreamWaitEvent(r->ctx->stream, r->copied[slot], 0));
     return SFX_OK;
 }
 
@@ -712,6 +742,7 @@ extern "C" int sfx_ring_destroy(sfx_handle h) {
     hipStreamSynchronize(r->copy_stream);
     for (int k = 0; k < r->slots; k++) { hipHostFree(r->host[k]); hipEventDestroy(r->copied[k]); }
     hipEventDestroy(r->produced);
+    for (auto& f : r->fences) hipEventDestroy(f);
     hipStreamDestroy(r->copy_stream);
     r->magic = 0;
     delete r;

@@ -139,13 +139,26 @@ class ExportingHelper:
         if not turbo:
             N.check(N.lib().sfx_ring_pipe_sync(self.ring, slot))
 
-    def pipe_device(self, device_ptr: int, turbo: bool = True) -> None:
+    def fence(self, which: int) -> None:
+        """Everything launched on the render stream so far is what frames read against fence `which` depend on"""
+        if self.ring is not None:
+            N.check(N.lib().sfx_ring_fence(self.ring, which))
+
+    def render_waits_for_last_read(self) -> None:
+        """The render stream may not overwrite a frame buffer before the last queued read of it has finished"""
+        if self.ring is not None and self.frame > 0:
+            N.check(N.lib().sfx_ring_stream_wait(self.ring, (self.frame - 1) % self.slots))
+
+    def pipe_device(self, device_ptr: int, turbo: bool = True, fence: Optional[int] = None) -> None:
         """Same, for a frame that lives in a raw device buffer (frame tape batches)"""
         if (self.fileno is None) or (self.ring is None):
             return
         self._check_encoder()
         slot = self.frame % self.slots
-        N.check(N.lib().sfx_ring_read_device_async(self.ring, C.c_void_p(device_ptr), slot))
+        if fence is None:
+            N.check(N.lib().sfx_ring_read_device_async(self.ring, C.c_void_p(device_ptr), slot))
+        else:
+            N.check(N.lib().sfx_ring_read_fenced_async(self.ring, C.c_void_p(device_ptr), slot, fence))
         N.check(N.lib().sfx_ring_pipe(self.ring, slot, self.fileno))
         if not turbo:
             N.check(N.lib().sfx_ring_pipe_sync(self.ring, slot))

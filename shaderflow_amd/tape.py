@@ -192,19 +192,26 @@ class FrameTape:
         context = scene.context
         batches = shard_batches(0, total, self.batch)
 
-        def emit_frames(pointer: int, count: int) -> None:
+        def emit_frames(pointer: int, count: int, fence: Optional[int] = None) -> None:
             for i in range(count):
-                export.pipe_device(pointer + i*frame_bytes, turbo=turbo)
+                export.pipe_device(pointer + i*frame_bytes, turbo=turbo, fence=fence)
                 export.update()
 
         try:
             if world == 1:
                 buffers = [context.alloc(frame_bytes*self.batch) for _ in range(2)]
                 try:
+                    # software pipeline: batch b+1 is rendering while the frames of batch b travel to the host
+                    self.build(*batches[0])
+                    self.render(batches[0][1], buffers[0])
+                    export.fence(0)
                     for index, (first, count) in enumerate(batches):
-                        self.build(first, count)
-                        self.render(count, buffers[index % 2])
-                        emit_frames(buffers[index % 2], count)
+                        if index + 1 < len(batches):
+                            export.render_waits_for_last_read()          # buffers[(index+1) % 2] held batch index-1
+                            self.build(*batches[index + 1])
+                            self.render(batches[index + 1][1], buffers[(index + 1) % 2])
+                            export.fence((index + 1) % 2)
+                        emit_frames(buffers[index % 2], count, fence=index % 2)
                 finally:
                     context.synchronize()
                     for pointer in buffers:
