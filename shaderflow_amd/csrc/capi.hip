@@ -478,6 +478,9 @@ static int launch_render(int fragment, const RenderArgs& a, int frames, hipStrea
 #ifndef VIS_PITCH_SS
 #define VIS_PITCH_SS 80
 #endif
+#ifndef VIS_FUSED_ROWS
+#define VIS_FUSED_ROWS 1
+#endif
 #ifndef VIS_ROWS_SS
 #define VIS_ROWS_SS 10
 #endif
@@ -487,9 +490,10 @@ static int launch_render(int fragment, const RenderArgs& a, int frames, hipStrea
 
 template <class SHADER> static int launch_fused_s(const RenderArgs& a, int ssaa, int frames, hipStream_t s) {
     const int blocks_x = (a.w + 127)/128;
+    const int row_blocks = (a.h + SHADER::FUSED_ROWS - 1)/SHADER::FUSED_ROWS;
     if (ssaa == 1) hipLaunchKernelGGL((k_render_resolve<SHADER, 1>), dim3(blocks_x*((a.h + 1)/2), 1, frames), dim3(256), 0, s, a);
-    else if (ssaa == 2) hipLaunchKernelGGL((k_render_resolve<SHADER, 2>), dim3(blocks_x*a.h, 1, frames), dim3(512), 0, s, a);
-    else if (ssaa == 4) hipLaunchKernelGGL((k_render_resolve<SHADER, 4>), dim3(blocks_x*a.h, 1, frames), dim3(512), 0, s, a);
+    else if (ssaa == 2) hipLaunchKernelGGL((k_render_resolve<SHADER, 2>), dim3(blocks_x*row_blocks, 1, frames), dim3(512), 0, s, a);
+    else if (ssaa == 4) hipLaunchKernelGGL((k_render_resolve<SHADER, 4>), dim3(blocks_x*row_blocks, 1, frames), dim3(512), 0, s, a);
     else return fail(SFX_E_UNSUPPORTED, "fused ssaa %d", ssaa);
     return SFX_OK;
 }
@@ -501,7 +505,7 @@ static int launch_fused(int fragment, const RenderArgs& a, int ssaa, int frames,
         case FRAG_VISUALIZER:
             if (!force_generic && visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) {
                 if (ssaa == 1) return launch_fused_s<VisualizerShader<128, 10, 1>>(a, ssaa, frames, s);
-                return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_SS>>(a, ssaa, frames, s);
+                return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_SS, VIS_FUSED_ROWS>>(a, ssaa, frames, s);
             }
             return launch_fused_s<PlainShader<FRAG_VISUALIZER>>(a, ssaa, frames, s);
         case FRAG_BARS: return launch_fused_s<PlainShader<FRAG_BARS>>(a, ssaa, frames, s);

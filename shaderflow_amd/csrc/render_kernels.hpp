@@ -82,6 +82,7 @@ __device__ __forceinline__ void store_target(const RenderArgs& a, long frame, in
 template <int FRAGMENT> struct PlainShader {
     static constexpr int BLOCK_W = 64, BLOCK_H = 4;      // unfused block shape
     static constexpr int MIN_WAVES_PER_SIMD = 1;
+    static constexpr int FUSED_ROWS = 1;                 // output rows per block of the fused kernel (S >= 2)
     struct State {};
     struct Shared {};
     __device__ static void pre(const RenderArgs&, const Frag&, bool, State&) {}
@@ -226,21 +227,24 @@ __device__ __forceinline__ void store_rgb_row(uint8_t* out_row, int x0, int w, c
 template <class SHADER, int S>
 __global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_resolve(const RenderArgs a) {
     constexpr int LANES = (S == 1) ? 1 : 4;
-    constexpr int PER_LANE = (S*S)/LANES;            // 1, 1, 4
-    constexpr int G = (S == 4) ? 2 : 1;              // side of the group one lane owns
-    __shared__ __attribute__((aligned(16))) uint8_t staged[2][384];
+    constexpr int GROUP = (S*S)/LANES;               // supersamples of one pixel owned by one lane: 1, 1, 4
+    constexpr int G = (S == 4) ? 2 : 1;              // side of that group
+    // Output rows per block: S == 1 packs 2 rows of 128 pixels into its 256 threads; otherwise every quad walks
+    // SHADER::FUSED_ROWS vertically adjacent pixels, which amortises the shader's per-block setup (LDS staging)
+    constexpr int ROWS = (S == 1) ? 2 : SHADER::FUSED_ROWS;
+    constexpr int WALK = (S == 1) ? 1 : ROWS;        // pixels a lane group visits one after the other
+    constexpr int PER_LANE = GROUP*WALK;
+    __shared__ __attribute__((aligned(16))) uint8_t staged[ROWS][384];
 
     Uniforms u; Tex tex[TEX_SLOTS];
     frame_view(a, blockIdx.z, u, tex);
     const int blocks_x = (a.w + 127)/128;
-    const int rows_per_block = (S == 1) ? 2 : 1;
     const int tile = xcd_band_order(blockIdx.x, gridDim.x);
     const int bx = tile % blocks_x, by = tile / blocks_x;
     const int tid = threadIdx.x;
     const int p = tid / LANES, sub = tid % LANES;
     const int prow = (S == 1) ? (p / 128) : 0;
-    const int px = bx*128 + (p % 128), py = by*rows_per_block + prow;
-    const bool inside = (px < a.w) && (py < a.h);
+    const int px = bx*128 + (p % 128), py0 = by*ROWS + prow;
 
     __shared__ typename SHADER::Shared shared;
     uint32_t mine[PER_LANE];
@@ -249,29 +253,30 @@ __global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_reso
     Frag f; f.u = &u; f.tex = tex;
 #pragma unroll
     for (int n = 0; n < PER_LANE; n++) {
-        const int gx = (sub & 1)*G + (n % G), gy = (sub >> 1)*G + (n / G);      // position inside the S x S block
-        make_varyings(f, px*S + gx, py*S + gy, a.wr, a.hr, a.aspect);
-        valid[n] = inside;
-        SHADER::pre(a, f, inside, state[n]);
+        const int r = n / GROUP, m = n % GROUP;
+        const int gx = (sub & 1)*G + (m % G), gy = (sub >> 1)*G + (m / G);       // position inside the S x S block
+        valid[n] = (px < a.w) && (py0 + r < a.h);
+        make_varyings(f, px*S + gx, (py0 + r)*S + gy, a.wr, a.hr, a.aspect);
+        SHADER::pre(a, f, valid[n], state[n]);
     }
     SHADER::template setup<PER_LANE>(a, tex, f, state, valid, shared);
 #pragma unroll
     for (int n = 0; n < PER_LANE; n++) {
         uint32_t q = 0;
-        if (inside) {
+        if (valid[n]) {
             if constexpr (PER_LANE > 1) {            // with one sample per lane the varyings of pass 1 are still live
-                const int gx = (sub & 1)*G + (n % G), gy = (sub >> 1)*G + (n / G);
-                make_varyings(f, px*S + gx, py*S + gy, a.wr, a.hr, a.aspect);
+                const int r = n / GROUP, m = n % GROUP;
+                const int gx = (sub & 1)*G + (m % G), gy = (sub >> 1)*G + (m / G);
+                make_varyings(f, px*S + gx, (py0 + r)*S + gy, a.wr, a.hr, a.aspect);
             }
             q = pack_rgba8(SHADER::run(a, f, state[n], shared));
         }
         mine[n] = q;
     }
 
-    uint32_t block[S*S];
     if constexpr (S == 1) {
-        block[0] = mine[0];
-        if (inside) {
+        const uint32_t block[1] = {mine[0]};
+        if (valid[0]) {
             uint8_t* s = &staged[prow][(p % 128)*3];
             s[0] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 0);
             s[1] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 8);
@@ -279,25 +284,31 @@ __global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_reso
         }
     } else {
 #pragma unroll
-        for (int n = 0; n < PER_LANE; n++) {
-            const uint32_t l0 = quad_lane0(mine[n]), l1 = quad_lane1(mine[n]), l2 = quad_lane2(mine[n]), l3 = quad_lane3(mine[n]);
-            const int ox = n % G, oy = n / G;
-            block[(0*G + oy)*S + 0*G + ox] = l0;     // lane sub: gx = (sub&1)*G + ox, gy = (sub>>1)*G + oy
-            block[(0*G + oy)*S + 1*G + ox] = l1;
-            block[(1*G + oy)*S + 0*G + ox] = l2;
-            block[(1*G + oy)*S + 1*G + ox] = l3;
-        }
-        const uint32_t channel = resolve_channel_any<S>(block, a.subsample, 8*(sub < 3 ? sub : 0));
-        const uint32_t green = quad_lane1(channel), blue = quad_lane2(channel);
-        if (inside && sub == 0) {
-            uint8_t* s = &staged[prow][(p % 128)*3];
-            s[0] = (uint8_t)channel; s[1] = (uint8_t)green; s[2] = (uint8_t)blue;
+        for (int r = 0; r < WALK; r++) {
+            uint32_t block[S*S];
+#pragma unroll
+            for (int m = 0; m < GROUP; m++) {
+                const uint32_t v = mine[r*GROUP + m];
+                const uint32_t l0 = quad_lane0(v), l1 = quad_lane1(v), l2 = quad_lane2(v), l3 = quad_lane3(v);
+                const int ox = m % G, oy = m / G;
+                block[(0*G + oy)*S + 0*G + ox] = l0;     // lane sub: gx = (sub&1)*G + ox, gy = (sub>>1)*G + oy
+                block[(0*G + oy)*S + 1*G + ox] = l1;
+                block[(1*G + oy)*S + 0*G + ox] = l2;
+                block[(1*G + oy)*S + 1*G + ox] = l3;
+            }
+            const uint32_t channel = resolve_channel_any<S>(block, a.subsample, 8*(sub < 3 ? sub : 0));
+            const uint32_t green = quad_lane1(channel), blue = quad_lane2(channel);
+            if (valid[r*GROUP] && sub == 0) {
+                uint8_t* s = &staged[r][(p % 128)*3];
+                s[0] = (uint8_t)channel; s[1] = (uint8_t)green; s[2] = (uint8_t)blue;
+            }
         }
     }
     __syncthreads();
     uint8_t* frame = (uint8_t*)a.out + (long)blockIdx.z*a.out_frame_stride;
-    for (int r = 0; r < rows_per_block; r++) {
-        const int y = by*rows_per_block + r;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const int y = by*ROWS + r;
         if (y < a.h) store_rgb_row(frame + (long)y*a.w*3, bx*128, a.w, staged[r], tid, blockDim.x);
     }
 }

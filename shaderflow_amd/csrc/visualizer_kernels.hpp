@@ -44,8 +44,9 @@ __global__ void k_visualizer_consts(const FrameDyn* __restrict__ dyn, int frame0
 
 // TILE_PITCH: cells per tile row (32 B each): 128 covers a 128-pixel block without supersampling, 80 is enough when
 // the block's 128 pixels are 2x or 4x supersampled (the window is then ~64 cells wide) and lets more blocks share a CU.
-template <int TILE_PITCH, int TILE_ROWS, int MIN_WAVES>
+template <int TILE_PITCH, int TILE_ROWS, int MIN_WAVES, int ROWS_PER_BLOCK = 1>
 struct VisualizerShader {
+    static constexpr int FUSED_ROWS = ROWS_PER_BLOCK;    // one LDS window serves this many output rows
     static constexpr int BLOCK_W = 128, BLOCK_H = 2;     // unfused block shape (render_kernels.hpp k_render)
     static constexpr int MIN_WAVES_PER_SIMD = MIN_WAVES;
 
@@ -237,8 +238,16 @@ struct VisualizerShader {
         }
         const Tex& bg = f.tex[TEX_BACKGROUND];
         const VisualizerConsts c = sh.consts;
+#if defined(VIS_ABLATE_BLUR)
+        vec4 blurred = {s.xc*1e-3f, s.yc*1e-3f, 0.5f, 1.0f};             // ablation builds only (tools/variants.sh)
+#else
         vec4 blurred = (sh.ok == 1) ? blur_tile(a, bg, s, sh) : visualizer_blur_reference(f, s.pre, c);
+#endif
+#if defined(VIS_ABLATE_POST)
+        return blurred;
+#else
         return visualizer_post(f, s.pre, c, blurred);
+#endif
     }
 };
 
