@@ -66,6 +66,9 @@ typedef struct {
 int sfx_ctx_create(int device_id, void* stream /* hipStream_t or NULL */, sfx_handle* ctx);
 int sfx_ctx_info(sfx_handle ctx, sfx_ctx_info_t* info);
 int sfx_ctx_synchronize(sfx_handle ctx);
+/* Encoder hand-off (exporting.py:94-103 adds ffmpeg's `vflip` filter because GL rows are bottom-up): with enabled != 0
+ * sfx_resolve / sfx_render_resolve / sfx_render_tape write their RGB8 frames top-down, so no filter is needed. */
+int sfx_ctx_output_top_down(sfx_handle ctx, int enabled);
 int sfx_ctx_destroy(sfx_handle ctx);
 
 /* Timing on the context's stream with HIP events (bench.py roofline leg). slot in [0, 64). */

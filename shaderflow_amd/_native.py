@@ -56,6 +56,7 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_ctx_create": (C.c_int, [C.c_int, C.c_void_p, P(Handle)]),
     "sfx_ctx_info": (C.c_int, [Handle, P(CtxInfo)]),
     "sfx_ctx_synchronize": (C.c_int, [Handle]),
+    "sfx_ctx_output_top_down": (C.c_int, [Handle, C.c_int]),
     "sfx_ctx_destroy": (C.c_int, [Handle]),
     "sfx_event_record": (C.c_int, [Handle, C.c_int]),
     "sfx_event_elapsed_ms": (C.c_int, [Handle, C.c_int, C.c_int, P(C.c_float)]),
@@ -158,6 +159,9 @@ class Context:
 
     def synchronize(self) -> None:
         check(lib().sfx_ctx_synchronize(self.handle))
+
+    def output_top_down(self, enabled: bool) -> None:
+        check(lib().sfx_ctx_output_top_down(self.handle, 1 if enabled else 0))
 
     def event_record(self, slot: int) -> None:
         check(lib().sfx_event_record(self.handle, slot))

@@ -220,7 +220,7 @@ class ShaderAudio(BrokenAudio, ShaderModule):
             self.tell = 0
 
     def ffhook(self, ffmpeg) -> None:
-        if (self.file is not None) and self.file.exists() and hasattr(ffmpeg, "input"):
+        if (self.file is not None) and self.file.exists():
             ffmpeg.input(path=self.file)
             ffmpeg.shortest = True
 

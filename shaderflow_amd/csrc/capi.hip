@@ -56,6 +56,7 @@ struct Context : Object {
     hipEvent_t events[64] = {};
     hipDeviceProp_t prop;
     float tap_x[81], tap_y[81];
+    int top_down = 0;                // frames leave with rows top-down (sfx_ctx_output_top_down)
 };
 
 struct Texture : Object {
@@ -138,6 +139,12 @@ extern "C" int sfx_ctx_synchronize(sfx_handle h) {
     CTX_OR_FAIL(c, h);
     USE_DEVICE(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return SFX_OK;
+}
+
+extern "C" int sfx_ctx_output_top_down(sfx_handle h, int enabled) {
+    CTX_OR_FAIL(c, h);
+    c->top_down = enabled ? 1 : 0;
     return SFX_OK;
 }
 
@@ -435,6 +442,7 @@ static void fill_args(const Program* p, RenderArgs& a) {
     a.one = 1.0f;
     a.aspect = p->u.iResolution[0]/p->u.iResolution[1];
     a.identity_camera = camera_is_identity(p->u) ? 1 : 0;
+    a.top_down = p->ctx->top_down;
 }
 
 static bool needs(const RenderArgs& a, int slot) { return a.tex[slot].data != nullptr || (slot == TEX_SPECTROGRAM && a.tape_spectrogram) || (slot == TEX_WAVEFORM && a.tape_waveform); }
@@ -555,7 +563,7 @@ extern "C" int sfx_resolve(sfx_handle h, sfx_handle src, sfx_handle dst, int sub
     a.screen.filter = s->filter; a.screen.repeat_x = s->repeat_x; a.screen.repeat_y = s->repeat_y;
     a.w = d->width; a.h = d->height; a.subsample = subsample < 1 ? 1 : subsample;
     a.out = (uint8_t*)d->data;
-    a.screen_frame_stride = 0; a.out_frame_stride = 0;
+    a.screen_frame_stride = 0; a.out_frame_stride = 0; a.top_down = c->top_down;
     hipLaunchKernelGGL(k_resolve, dim3((a.w + 63)/64, (a.h + 3)/4), dim3(64, 4), 0, c->stream, a);
     return launch_status();
 }
@@ -1146,7 +1154,7 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
     ResolveArgs r;
     r.screen = Tex{t->d_screen, a.wr, a.hr, 4, DT_U8, FILTER_LINEAR, 0, 0};      // iScreen: linear, repeat(False) (scene.py:192-194)
     r.w = width; r.h = height; r.subsample = subsample; r.out = (uint8_t*)device_out;
-    r.screen_frame_stride = (long)screen_frame; r.out_frame_stride = (long)width*height*3;
+    r.screen_frame_stride = (long)screen_frame; r.out_frame_stride = (long)width*height*3; r.top_down = p->ctx->top_down;
     hipLaunchKernelGGL(k_resolve, dim3((width + 63)/64, (height + 3)/4, nframes), dim3(64, 4), 0, p->ctx->stream, r);
     return launch_status();
 }

@@ -4,7 +4,7 @@
 //   K6+K8 k_render_resolve<F,S> shade S x S supersamples in the lanes of a quad, quantise each to the
 //                              iScreen RGBA8 value, resolve with DPP lane exchanges, write RGB8 only
 //   K7  the sampler lives in glsl.hpp (generic) and in BlurTile below (LDS-staged background tile)
-//   K9  k_pack_rows            flips / packs a finished frame for the encoder hand-off
+//   K9  encoder hand-off       the resolve kernels write rows top-down on request (RenderArgs/ResolveArgs.top_down)
 //
 // Launch geometry: every block of the fused kernel owns 128 consecutive output pixels of one row, so
 // it writes 384 contiguous, 128-byte aligned bytes of the RGB8 frame (whole cache lines from a single
@@ -41,6 +41,7 @@ struct RenderArgs {
     float one;                       // 1.0f, kept opaque to the optimiser (visualizer_kernels.hpp tap())
     int identity_camera;             // glsl.hpp camera_is_identity(u): iCamera.gluv == gluv exactly
     float aspect;                    // iResolution.x/iResolution.y (iAspectRatio, shaderflow.glsl:16), divided once on the host
+    int top_down;                    // K9: write the RGB8 frame rows top-down (the encoder's `vflip`, exporting.py:103, done here)
 };
 
 __device__ __forceinline__ void frame_view(const RenderArgs& a, int frame, Uniforms& u, Tex* tex) {
@@ -114,6 +115,7 @@ struct ResolveArgs {
     int w, h, subsample;
     uint8_t* out;                    // RGB8 rows bottom-up
     long screen_frame_stride, out_frame_stride;    // bytes between frames of a batch (grid.z)
+    int top_down;                    // rows of `out` top-down instead of GL's bottom-up
 };
 
 __device__ __forceinline__ vec3 final_glsl(const Tex& screen, vec2 astuv, vec2 resolution, int kernel) {
@@ -140,7 +142,8 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveArgs a) {
     Tex screen = a.screen;
     screen.data = (const char*)a.screen.data + (long)blockIdx.z*a.screen_frame_stride;
     vec3 c = final_glsl(screen, astuv, vec2{(float)a.w, (float)a.h}, a.subsample);
-    uint8_t* p = a.out + (long)blockIdx.z*a.out_frame_stride + ((long)j*a.w + i)*3;
+    const int row = a.top_down ? (a.h - 1 - j) : j;
+    uint8_t* p = a.out + (long)blockIdx.z*a.out_frame_stride + ((long)row*a.w + i)*3;
     p[0] = (uint8_t)unorm8(c.x); p[1] = (uint8_t)unorm8(c.y); p[2] = (uint8_t)unorm8(c.z);
 }
 
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_reso
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         const int y = by*ROWS + r;
-        if (y < a.h) store_rgb_row(frame + (long)y*a.w*3, bx*128, a.w, staged[r], tid, blockDim.x);
+        if (y < a.h) store_rgb_row(frame + (long)(a.top_down ? a.h - 1 - y : y)*a.w*3, bx*128, a.w, staged[r], tid, blockDim.x);
     }
 }
 

@@ -9,14 +9,19 @@ writer thread streams it to a file descriptor (`sfx_ring_pipe`), with the same r
 (ffmpeg then applies `vflip`, exporting.py:94-103).
 
 Sinks: a path ending in .rgb/.raw (or any path when no `ffmpeg` binary exists) receives the raw frames;
-"pipe"/"-"/bytes returns them; with an `ffmpeg` binary on PATH other paths are encoded by the reference's
-command line (rawvideo rgb24 stdin, scale, vflip, libx264 crf 20 yuv420p; ffmpeg.py:149-205,1027-1068).
+"pipe"/"-"/bytes returns them; with an `ffmpeg` binary on PATH other paths are encoded by the command line
+`scene.ffmpeg` (shaderflow_amd/ffmpeg.py) builds exactly as the reference does: rawvideo rgb24 stdin, scale, vflip,
+the configured codecs, `module.ffhook` additions such as the audio track (exporting.py:91-120).
+
+Encoder hand-off on the device: when frames go to an ffmpeg process the resolve kernels write the
+rows top-down (`sfx_ctx_output_top_down`) and the `vflip` filter is left out of the command, which takes a full
+pass over every frame off the encoder's CPU threads. Raw sinks keep the reference's byte stream (rows bottom-up)
+unless `top_down=True` is asked for.
 """
 from __future__ import annotations
 
 import ctypes as C
 import os
-import shutil
 import subprocess
 import tempfile
 import time
@@ -48,7 +53,7 @@ class ExportingHelper:
     process: Optional[subprocess.Popen] = None
     file: Any = None
     fileno: Optional[int] = None
-    _sizes: tuple[int, int] = (0, 0)
+    top_down: Optional[bool] = None       # None: top-down exactly when an ffmpeg process is the sink
 
     # ring
     ring: Optional[N.Handle] = None
@@ -72,35 +77,47 @@ class ExportingHelper:
 
     # configuration --------------------------------------------------------------------------------------------
 
+    @property
+    def ffmpeg(self):
+        return self.scene.ffmpeg
+
+    def ffmpeg_clean(self) -> None:
+        self.ffmpeg.clear(video_codec=False, audio_codec=False)
+
     def ffmpeg_sizes(self, width: int, height: int) -> None:
-        self._sizes = (width, height)
+        self.ffmpeg.time = self.scene.runtime
+        self.ffmpeg.pipe_input(pixel_format="rgb24", width=self.scene.width, height=self.scene.height, framerate=self.scene.fps)
+        self.ffmpeg.scale(width=width, height=height)
+        self.ffmpeg.vflip()
 
     def ffmpeg_output(self, output) -> None:
         if (output in ("pipe", "-", bytes)):
             self.kind = "pipe"
-            return
-        self.path = Path(output).expanduser().absolute()
-        self.path.parent.mkdir(parents=True, exist_ok=True)
-        raw = self.path.suffix.lower() in (".rgb", ".raw", ".rgb24")
-        self.kind = "path-raw" if (raw or not shutil.which("ffmpeg")) else "path-ffmpeg"
-        if self.kind == "path-raw" and not raw:
-            logger.warning(f"No ffmpeg binary on PATH: writing raw rgb24 frames (rows bottom-up) to {self.path}")
+            self.ffmpeg.pipe_output()
+        elif ("tcp://" in str(output)):
+            raise NotImplementedError
+        else:
+            self.path = Path(output).expanduser().absolute()
+            self.path.parent.mkdir(parents=True, exist_ok=True)
+            raw = self.path.suffix.lower() in (".rgb", ".raw", ".rgb24")
+            self.kind = "path-raw" if (raw or not self.ffmpeg.available()) else "path-ffmpeg"
+            if self.kind == "path-raw" and not raw:
+                logger.warning(f"No ffmpeg binary on PATH: writing raw rgb24 frames (rows bottom-up) to {self.path}")
+            self.ffmpeg.output(path=self.path)
+        if self.top_down is None:
+            self.top_down = (self.kind == "path-ffmpeg")
+        if self.top_down:                                     # the flip happens while the frame is written on the device
+            self.ffmpeg.filters = [stage for stage in self.ffmpeg.filters if stage.kind != "vflip"]
+            self.ffmpeg.vflip(device=True)
 
     def ffhook(self) -> None:
-        pass
-
-    def ffmpeg_command(self) -> list[str]:
-        """The reference's encoder invocation for this export (exporting.py:94-103 + ffmpeg.py defaults)"""
-        w, h = self.scene.resolution
-        ow, oh = self._sizes if all(self._sizes) else (w, h)
-        return ["ffmpeg", "-hide_banner", "-loglevel", "error", "-y",
-                "-f", "rawvideo", "-pixel_format", "rgb24", "-video_size", f"{w}x{h}", "-framerate", f"{self.scene.fps}",
-                "-i", "-", "-vf", f"scale={ow}:{oh}:flags=lanczos,vflip", "-t", f"{self.scene.runtime}",
-                "-c:v", "libx264", "-preset", "slow", "-crf", "20", "-pix_fmt", "yuv420p", str(self.path)]
+        for module in self.scene.modules:
+            module.ffhook(self.ffmpeg)
 
     def popen(self) -> None:
+        self.scene.context.output_top_down(bool(self.top_down))
         if self.kind == "path-ffmpeg":
-            self.process = subprocess.Popen(self.ffmpeg_command(), stdin=subprocess.PIPE, stderr=subprocess.PIPE)
+            self.process = self.ffmpeg.popen(stdin=subprocess.PIPE, stderr=subprocess.PIPE)
             self.fileno = self.process.stdin.fileno()
         elif self.kind == "path-raw":
             self.file = open(self.path, "wb")
@@ -169,6 +186,7 @@ class ExportingHelper:
         output = None
         self.scene.context.synchronize()
         self.release_buffers()
+        self.scene.context.output_top_down(False)
         if self.kind == "path-ffmpeg":
             self.process.stdin.close()
             self.process.wait()

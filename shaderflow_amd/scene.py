@@ -30,6 +30,7 @@ import shaderflow_amd
 from shaderflow_amd import _native as N
 from shaderflow_amd.camera import ShaderCamera
 from shaderflow_amd.exporting import ExportingHelper
+from shaderflow_amd.ffmpeg import FFmpeg
 from shaderflow_amd.message import ShaderMessage
 from shaderflow_amd.module import ShaderModule, logger
 from shaderflow_amd.resolution import Resolution
@@ -229,6 +230,8 @@ class ShaderScene(ShaderModule):
     # frame loop -------------------------------------------------------------------------------------------------
 
     scheduler: Scheduler = Factory(Scheduler)
+    ffmpeg: FFmpeg = Factory(FFmpeg)
+    """Encoder command-line builder of the export (scene.py:85): `scene.ffmpeg.h264(crf=18)`, `.h265()`, …"""
     vsync: Any = None
     quit: bool = False
     realtime: bool = True
@@ -283,10 +286,12 @@ class ShaderScene(ShaderModule):
         turbo: bool = True,
         buffers: int = 5,
         batch: Optional[bool] = None,
+        top_down: Optional[bool] = None,
     ) -> Optional[Union[Path, bytes]]:
         """Render the scene to `output` (scene.py:493-639). `output` may be a path (raw rgb24 frames, or a video
         when an `ffmpeg` binary exists), "pipe"/"-"/bytes (returns the raw frames), or None with freewheel=True
-        (renders without writing). `batch`: None = frame tape when the scene allows it, False = frame loop."""
+        (renders without writing). `batch`: None = frame tape when the scene allows it, False = frame loop.
+        `top_down`: write frame rows top-down on the device (None = exactly when an ffmpeg process is the sink)."""
         self.initialize()
         self.exporting = (bool(output))
         self.freewheel = (self.exporting or freewheel)
@@ -317,11 +322,12 @@ class ShaderScene(ShaderModule):
         else:
             self.ssaa = ssaa
 
-        export = ExportingHelper(self)
+        export = ExportingHelper(self, top_down=top_down)
         from shaderflow_amd.parallel import rank_world
         if (self.exporting) and rank_world()[0] != 0:
             pass                                             # sharded export: only rank 0 owns the sink (tape.py)
         elif (self.exporting):
+            export.ffmpeg_clean()
             export.ffmpeg_sizes(width=_width, height=_height)
             export.ffmpeg_output(output)
             export.make_buffers(buffers)

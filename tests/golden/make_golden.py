@@ -108,6 +108,7 @@ class _FakeFFmpeg:
         return _FakeFFmpeg.samplerate
 
 
+RealFFmpeg = ref_ffmpeg.FFmpeg                 # the builder itself (make_golden_ffmpeg.py)
 ref_ffmpeg.FFmpeg = _FakeFFmpeg
 
 

@@ -149,3 +149,60 @@ def test_screenshot_and_texture_api():
     assert np.array_equal(tex.texture.read(), np.flipud(data))
     with pytest.raises(Exception, match="too large"):
         ShaderTexture(scene=scene, name="huge", width=70000, height=8)
+
+
+FAKE_FFMPEG = """#!/usr/bin/env python3
+# stands in for the encoder in the hand-off test: records argv, copies the rawvideo stdin to the output path
+import json, sys
+argv = sys.argv[1:]
+out = [a for a in argv if a.endswith(".mp4")][-1]
+open(out + ".argv.json", "w").write(json.dumps(argv))
+with open(out, "wb") as f:
+    while chunk := sys.stdin.buffer.read(1 << 20):
+        f.write(chunk)
+"""
+
+
+@pytest.mark.parametrize("batch", [None, False])
+def test_encoder_handoff_top_down_rows_and_command(tmp_path, monkeypatch, batch):
+    """with an ffmpeg process as the sink the frames arrive top-down (flipped while written on the device),
+    the command is the reference's (exporting.py:91-120) minus `vflip`, and ShaderAudio.ffhook adds the audio track"""
+    import json
+    import os
+    from examples.scenes import Visualizer, make
+    from shaderflow_amd.audio.reader import write_wav_f32
+    bindir = tmp_path/"bin"
+    bindir.mkdir()
+    (bindir/"ffmpeg").write_text(FAKE_FFMPEG)
+    (bindir/"ffmpeg").chmod(0o755)
+    monkeypatch.setenv("PATH", f"{bindir}{os.pathsep}{os.environ['PATH']}")
+    pcm, sr = clip(0.3)
+    wav = tmp_path/"clip.wav"
+    write_wav_f32(wav, pcm, sr)
+    background = synth.background_image(96, 54, seed=3)
+    w, h, fps, seconds = 96, 54, 30.0, 0.2
+
+    reference_stream = make(Visualizer, audio=wav, background=background).main(
+        width=w, height=h, fps=fps, ssaa=2, time=seconds, output=bytes, batch=batch)          # rows bottom-up, as the reference pipes them
+    want = frames_of(reference_stream, w, h)
+
+    scene = make(Visualizer, audio=wav, background=background)
+    scene.ffmpeg.h264(crf=18, preset="fast")
+    out = scene.main(width=w, height=h, fps=fps, ssaa=2, time=seconds, output=tmp_path/"video.mp4", batch=batch)
+    assert out == tmp_path/"video.mp4"
+    got = frames_of(out.read_bytes(), w, h)
+    assert got.shape == want.shape == (6, h, w, 3)
+    assert np.array_equal(got, want[:, ::-1]), "frames handed to the encoder must be the bottom-up frames with rows reversed"
+
+    argv = json.loads((tmp_path/"video.mp4.argv.json").read_text())
+    assert argv == ["-hide_banner", "-loglevel", "error", "-f", "rawvideo", "-s", f"{w}x{h}", "-pix_fmt", "rgb24", "-r", "30.0", "-i", "-",
+                    "-i", str(wav), "-t", "0.2", "-shortest", "-c:v", "libx264", "-movflags", "+faststart", "-preset", "fast", "-crf", "18",
+                    "-vf", f"scale={w}x{h}:flags=lanczos", "-pix_fmt", "yuv420p", str(tmp_path/"video.mp4"), "-y"]
+
+    # the next export of the same context is bottom-up again (the switch is reset in finish())
+    again = make(Visualizer, audio=wav, background=background).main(width=w, height=h, fps=fps, ssaa=2, time=seconds, output=bytes, batch=batch)
+    assert np.array_equal(frames_of(again, w, h), want)
+    # raw sinks can ask for top-down rows explicitly
+    flipped = make(Visualizer, audio=wav, background=background).main(width=w, height=h, fps=fps, ssaa=2, time=seconds, output=bytes,
+                                                                        batch=batch, top_down=True)
+    assert np.array_equal(frames_of(flipped, w, h), want[:, ::-1])

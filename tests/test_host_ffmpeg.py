@@ -1,0 +1,70 @@
+"""
+The encoder command-line builder against argv produced by the reference's builder (tests/golden/ffmpeg_commands.json,
+written by tests/golden/make_golden_ffmpeg.py from shaderflow/ffmpeg.py:753-1068). CPU only.
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from shaderflow_amd.ffmpeg import FFmpeg, Stage, pcm_dtype
+
+GOLDEN = json.loads((Path(__file__).parent/"golden"/"ffmpeg_commands.json").read_text())
+
+
+def build(fields, calls) -> FFmpeg:
+    ffmpeg = FFmpeg()
+    ffmpeg.executable = "ffmpeg"
+    for name, value in fields.items():
+        setattr(ffmpeg, name, value)
+    for method, kwargs in calls:
+        assert getattr(ffmpeg, method)(**kwargs) is ffmpeg               # fluent: every call returns the builder
+    return ffmpeg
+
+
+@pytest.mark.parametrize("case", GOLDEN["cases"], ids=lambda c: "+".join(m for m, _ in c["calls"])[:60])
+def test_command_line_matches_the_reference_builder(case):
+    assert list(build(case["fields"], case["calls"]).command) == case["argv"]
+
+
+@pytest.mark.parametrize("case", GOLDEN["errors"], ids=lambda c: f"{len(c['calls'])}-calls")
+def test_command_needs_input_and_output(case):
+    with pytest.raises(ValueError) as info:
+        build({}, case["calls"]).command
+    assert str(info.value) == case["error"]
+
+
+def test_defaults_and_recycling():
+    ffmpeg = FFmpeg()
+    assert ffmpeg.vcodec.kind == "h264" and ffmpeg.vcodec.crf == 20 and ffmpeg.acodec is None      # ffmpeg.py:811-815
+    ffmpeg.pipe_input().scale(width=8, height=8).vflip().output("/tmp/x.mp4").aac()
+    ffmpeg.clear(video_codec=False, audio_codec=False)                                             # exporting.py:91-92
+    assert (ffmpeg.inputs, ffmpeg.filters, ffmpeg.outputs) == ([], [], []) and ffmpeg.vcodec.kind == "h264" and ffmpeg.acodec.kind == "aac"
+    ffmpeg.clear()
+    assert ffmpeg.vcodec is None and ffmpeg.acodec is None
+    with pytest.raises(TypeError):
+        ffmpeg.h264(quality=3)
+    with pytest.raises(TypeError):
+        ffmpeg.scale(width=3)
+    with pytest.raises(AttributeError):
+        ffmpeg.h264_nvenc()
+    with pytest.raises(TypeError):
+        ffmpeg.smartset("h264")
+    ffmpeg.h264()
+    ffmpeg.vcodec.crf = 17
+    assert 17 in Stage.arguments(ffmpeg.vcodec, ffmpeg)
+
+
+def test_device_vflip_drops_the_filter():
+    a = FFmpeg().pipe_input().scale(width=64, height=36).vflip().output(path="/tmp/a.mp4")
+    b = FFmpeg().pipe_input().scale(width=64, height=36).vflip(device=True).output(path="/tmp/a.mp4")
+    a.executable = b.executable = "ffmpeg"
+    assert "scale=64x36:flags=lanczos,vflip" in a.command and "scale=64x36:flags=lanczos" in b.command
+    assert b.device_vflip and not a.device_vflip
+    assert [x for x in a.command if "vflip" not in x] == [x for x in b.command if "scale" not in x]
+
+
+def test_pcm_dtypes():
+    assert pcm_dtype("pcm_f32le") == np.dtype("<f4") and pcm_dtype("pcm_s16be") == np.dtype(">i2")
+    assert pcm_dtype("pcm_u8") == np.dtype("u1") and pcm_dtype("pcm_f64le") == np.dtype("<f8")
