@@ -104,6 +104,88 @@ class Visualizer(_AudioScene):
         self.shader.fragment = "visualizer"
 
 
+class Multipass(ShaderScene):
+    """Multi layers done on a single shader (demo.py:93-99)"""
+    background: Optional[np.ndarray] = None
+
+    def build(self):
+        image = self.background if self.background is not None else synth.background_image(480, 270)
+        ShaderTexture(scene=self, name="background").from_numpy(image)
+        self.shader.texture.layers = 2
+        self.shader.fragment = "multipass"
+
+
+class MotionBlur(ShaderScene):
+    """Poor's man Motion Blur (demo.py:103-110)"""
+    background: Optional[np.ndarray] = None
+
+    def build(self):
+        image = self.background if self.background is not None else synth.background_image(480, 270)
+        ShaderTexture(scene=self, name="background").from_numpy(image)
+        self.shader.texture.temporal = 10
+        self.shader.texture.layers = 2
+        self.shader.fragment = "motionblur"
+
+
+class RayMarch(ShaderScene):
+    """Ray Marching demo (demo.py:215-219)"""
+    def build(self):
+        self.shader.fragment = "raymarch"
+
+
+class Life(ShaderScene):
+    """Conway's Game of Life on the GPU (demo.py:223-247): a float simulation texture with ten frames of history"""
+    life_period: int = 6
+
+    def setup(self):
+        width, height = 192, 108
+        random = np.random.randint(0, 2, (width, height), dtype=bool)
+        self.simulation.texture.size = (width, height)
+        self.simulation.texture.write(random.astype(np.float32), temporal=1)
+
+    def build(self):
+        self.simulation = ShaderProgram(scene=self, name="iLife")
+        self.simulation.texture.temporal = 10
+        self.simulation.texture.filter = "nearest"
+        self.simulation.texture.dtype = "f4"
+        self.simulation.texture.components = 1
+        self.simulation.texture.track = False
+        self.simulation.fragment = "life_simulation"
+        self.shader.fragment = "life_visuals"
+
+    def pipeline(self):
+        from shaderflow_amd.variable import Uniform
+        yield from ShaderScene.pipeline(self)
+        yield Uniform("int", "iLifePeriod", self.life_period)
+
+
+class Mandelbrot(ShaderScene):
+    """Mandelbrot fractal (examples/fractals/fractals.py:7-10)"""
+    def build(self):
+        self.shader.fragment = "mandelbrot"
+
+
+class Tetration(ShaderScene):
+    """Complex tetration fractal (examples/fractals/fractals.py:12-15)"""
+    def build(self):
+        self.shader.fragment = "tetration"
+
+
+class Video(ShaderScene):
+    """Video as a texture (shaderflow/video.py + examples/basic/shaders/video.frag; demo.py has no scene for it):
+    `clip` = (frames (n, h, w, 3) uint8, fps) or a path"""
+    clip = None
+
+    def build(self):
+        from shaderflow_amd.video import ShaderVideo
+        if isinstance(self.clip, (str, Path)):
+            self.video = ShaderVideo(scene=self, path=self.clip)
+        else:
+            frames, fps = self.clip if self.clip is not None else (synth.background_image(64, 36)[None].repeat(4, 0), 30.0)
+            self.video = ShaderVideo(scene=self, frames=frames, fps=fps)
+        self.shader.fragment = "video"
+
+
 def make(cls, audio=None, background=None, **fields):
     """Build a scene class with its inputs set before `build()` runs (class attributes, like demo.py's Life)"""
     attrs = {}

@@ -59,10 +59,12 @@ class DynParams(C.Structure):
 
 
 FRAGMENTS = dict(default=0, missing=1, visualizer=2, bars=3, waveform=4, multi_child=5, multi_main=6,
-                 shadertoy=7, dynamics=8, audio=9)
+                 shadertoy=7, dynamics=8, audio=9, multipass=10, motionblur=11, life_simulation=12, life_visuals=13,
+                 video=14, raymarch=15, mandelbrot=16, tetration=17)
 TEX_SLOTS = dict(background=0, iSpectrogram=1, iWaveform=2, child=3)
+TEX_HISTORY, TEX_HISTORY_DEPTH, TEX_SLOT_COUNT = 4, 12, 16
 DTYPES = {np.dtype(np.uint8): 0, np.dtype(np.float32): 1, np.dtype(np.uint16): 2}
-MATH_FN = dict(sin=0, cos=1, atan2=2, atan=3, log2=4, exp2=5, pow=6, exp=7, mod=8, smoothstep=9, mix=10, sqrt=11)
+MATH_FN = dict(sin=0, cos=1, atan2=2, atan=3, log2=4, exp2=5, pow=6, exp=7, mod=8, smoothstep=9, mix=10, sqrt=11, log=12)
 
 _lib = None
 
@@ -93,6 +95,7 @@ def lib() -> C.CDLL:
         L.sfo_waveform_row.argtypes = [P(C.c_float), C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, P(C.c_float)]
         L.sfo_volume_std.argtypes = [P(C.c_float), C.c_int64, C.c_int, C.c_int64, C.c_int, P(C.c_float), P(C.c_float)]
         L.sfo_render.argtypes = [C.c_int, P(Uniforms), P(Texture), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_uint8)]
+        L.sfo_render_to.argtypes = [C.c_int, P(Uniforms), P(Texture), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.sfo_resolve.argtypes = [P(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_uint8)]
         L.sfo_sample.argtypes = [P(Texture), C.c_float, C.c_float, P(C.c_float)]
         L.sfo_test_math.argtypes = [C.c_int, C.c_float, C.c_float]
@@ -241,15 +244,31 @@ def default_uniforms(width: int, height: int, **kw) -> Uniforms:
     return u
 
 
-def render(fragment: str, u: Uniforms, textures: dict[str, Texture], wr: int, hr: int,
+def _slots(textures: dict) -> "C.Array":
+    """name → texture; a key ("history", t) (or an int t) is the history slot `<name>{t}x0`"""
+    slots = (Texture*TEX_SLOT_COUNT)()
+    for name, tex in textures.items():
+        if isinstance(name, tuple):
+            name = name[1]
+        slots[TEX_HISTORY + name if isinstance(name, int) else TEX_SLOTS[name]] = tex
+    return slots
+
+
+def render(fragment: str, u: Uniforms, textures: dict, wr: int, hr: int,
            rows: tuple[int, int] | None = None, threads: int = 1) -> np.ndarray:
     """Returns (hr, wr, 4) uint8, row 0 = bottom; rows outside `rows` stay zero"""
-    slots = (Texture*4)()
-    for name, tex in textures.items():
-        slots[TEX_SLOTS[name]] = tex
     out = np.zeros((hr, wr, 4), np.uint8)
     y0, y1 = rows or (0, hr)
-    lib().sfo_render(FRAGMENTS[fragment], C.byref(u), slots, wr, hr, y0, y1, threads, _p(out, C.c_uint8))
+    lib().sfo_render(FRAGMENTS[fragment], C.byref(u), _slots(textures), wr, hr, y0, y1, threads, _p(out, C.c_uint8))
+    return out
+
+
+def render_to(fragment: str, u: Uniforms, textures: dict, wr: int, hr: int, components: int, dtype,
+              threads: int = 1) -> np.ndarray:
+    """Render into a (hr, wr, components) target of uint8 or float32 (any ShaderTexture format, texture.py:177-184)"""
+    out = np.zeros((hr, wr, components), dtype)
+    lib().sfo_render_to(FRAGMENTS[fragment], C.byref(u), _slots(textures), wr, hr, 0, hr, threads, components,
+                        DTYPES[np.dtype(dtype)], out.ctypes.data_as(C.c_void_p))
     return out
 
 

@@ -141,15 +141,31 @@ enum {
     SFO_FRAG_SHADERTOY = 7,    /* examples/basic/shaders/shadertoy.frag     */
     SFO_FRAG_DYNAMICS = 8,     /* examples/basic/demo.py:121-126 (inline)   */
     SFO_FRAG_AUDIO = 9,        /* examples/basic/demo.py:149-153 (inline)   */
+    SFO_FRAG_MULTIPASS = 10,   /* examples/basic/shaders/multipass.frag     */
+    SFO_FRAG_MOTIONBLUR = 11,  /* examples/basic/shaders/motionblur.frag    */
+    SFO_FRAG_LIFE_SIMULATION = 12, /* examples/basic/shaders/life/simulation.glsl */
+    SFO_FRAG_LIFE_VISUALS = 13,    /* examples/basic/shaders/life/visuals.glsl    */
+    SFO_FRAG_VIDEO = 14,       /* examples/basic/shaders/video.frag         */
+    SFO_FRAG_RAYMARCH = 15,    /* examples/basic/shaders/raymarch.frag      */
+    SFO_FRAG_MANDELBROT = 16,  /* examples/fractals/shaders/mandelbrot.frag */
+    SFO_FRAG_TETRATION = 17,   /* examples/fractals/shaders/tetration.frag  */
 };
 
-enum { SFO_TEX_BACKGROUND = 0, SFO_TEX_SPECTROGRAM = 1, SFO_TEX_WAVEFORM = 2, SFO_TEX_CHILD = 3, SFO_TEX_SLOTS = 4 };
+/* slots 4.. are the temporal history `<name>{t}x0` of the texture the fragment reads by coordinates
+ * (texture.py:346-347, 380-381): iScreen for multipass/motionblur, iLife for life, iVideo for video */
+enum { SFO_TEX_BACKGROUND = 0, SFO_TEX_SPECTROGRAM = 1, SFO_TEX_WAVEFORM = 2, SFO_TEX_CHILD = 3,
+       SFO_TEX_HISTORY = 4, SFO_TEX_HISTORY_DEPTH = 12, SFO_TEX_SLOTS = 16 };
 
 /* shader.py:388-405 for one layer: evaluate `fragment` at every pixel centre of a (wr, hr) target
  * and store RGBA8 (rows bottom-up). Only rows [y0, y1) are produced (band rendering for the bounded
  * CPU baseline); `threads` > 1 splits rows over pthreads. out has wr*hr*4 bytes. */
 void sfo_render(int fragment, const sfo_uniforms* u, const sfo_texture* textures /*[SFO_TEX_SLOTS]*/,
                 int wr, int hr, int y0, int y1, int threads, uint8_t* out);
+
+/* Same, into a target of `components` channels of SFO_U8 or SFO_F32 (texture.py:177-184: any ShaderTexture
+ * format can be a render target; life/simulation renders into R32F, demo.py:236-238) */
+void sfo_render_to(int fragment, const sfo_uniforms* u, const sfo_texture* textures,
+                   int wr, int hr, int y0, int y1, int threads, int components, int dtype, void* out);
 
 /* fragment/final.glsl:1-33 + shader.py:391-396: iScreen (RGBA8, linear, clamp) → RGB8 (w, h),
  * rows [y0, y1). */

@@ -165,5 +165,6 @@ static inline float sfo_pow(float x, float y) {
     return sfo_exp2(y*sfo_log2(x));
 }
 static inline float sfo_exp(float x) { return sfo_exp2(x*0x1.715476p+0f); }
+static inline float sfo_log(float x) { return sfo_log2(x)*0x1.62e430p-1f; }   /* ln 2 */
 
 #endif

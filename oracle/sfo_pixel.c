@@ -431,6 +431,216 @@ static v4 frag_audio(const frag_in* f) {
     return V4(v, v, v, 1.0f);
 }
 
+/* ---------------------------------------------------------------------------------------------- */
+/* Multipass / temporal fragments: textures[SFO_TEX_HISTORY + t] is `<name>{t}x0`, t frames back
+ * (texture.py:346-347, 380-381; shader.py:399-405 renders row 0 layer by layer, then rolls) */
+
+/* texelFetch: out-of-range is undefined in GL 3.3; robust-access drivers return zeros — the rule here */
+static v4 texel_fetch(const sfo_texture* t, int i, int j) {
+    if (i < 0 || j < 0 || i >= t->width || j >= t->height) return V4(0.0f, 0.0f, 0.0f, 0.0f);
+    return fetch_texel(t, i, j);
+}
+
+static inline v4 v4_axpy(v4 acc, v4 x, float a) { return V4(acc.x + x.x*a, acc.y + x.y*a, acc.z + x.z*a, acc.w + x.w*a); }
+
+/* examples/basic/shaders/multipass.frag:10-26 */
+static v4 multipass_blur(const sfo_texture* image, v2 stuv, float radius, int directions, int steps) {
+    v4 color = V4(0.0f, 0.0f, 0.0f, 0.0f);
+    float weights = 0.0f;
+    const float dstep = SFO_TAU/(float)directions, wstep = 1.0f/(float)steps;
+    for (float direction = 0.0f; direction < SFO_TAU; direction += dstep) {
+        for (float walk = wstep; walk < 1.0f; walk += wstep) {
+            float ox = ((sfo_cos(direction)*radius)*walk)/2000.0f;
+            float oy = ((sfo_sin(direction)*radius)*walk)/2000.0f;
+            v4 smp = sample(image, V2(stuv.x + ox, stuv.y + oy));
+            float dx = ox - 0.0f, dy = oy - 0.0f;                          /* distance(offset, vec2(0)) */
+            float weight = 1.0f - sfo_sqrt(dx*dx + dy*dy)/radius;
+            color = v4_axpy(color, smp, weight);
+            weights += weight;
+        }
+    }
+    return V4(color.x/weights, color.y/weights, color.z/weights, color.w/weights);
+}
+
+/* examples/basic/shaders/multipass.frag:28-45 */
+static v4 frag_multipass(const frag_in* f) {
+    v4 out = V4(0.0f, 0.0f, 0.0f, 0.0f);
+    switch (f->u->iLayer) {
+        case 0:
+            out = stexture(&f->tex[SFO_TEX_BACKGROUND], f->stuv);
+            break;
+        case 1: {
+            const sfo_texture* iScreen0x0 = &f->tex[SFO_TEX_HISTORY];
+            out = sample(iScreen0x0, f->astuv);
+            if (f->gluv.x < 0.0f) out.x = 1.0f - out.x;
+            else out = multipass_blur(iScreen0x0, f->astuv, 5.0f, 8, 8);
+            break;
+        }
+        default: break;
+    }
+    out.w = 1.0f;
+    return out;
+}
+
+/* examples/basic/shaders/motionblur.frag:1-18; user[0] = iScreenTemporal */
+static v4 frag_motionblur(const frag_in* f) {
+    v4 out = V4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (f->u->iLayer == 0) {
+        camera_t cam = get_camera(f);
+        out = stexture(&f->tex[SFO_TEX_BACKGROUND], cam.stuv);
+    } else if (f->u->iLayer == 1) {
+        int T = (int)f->u->user[0];
+        v4 color = V4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int i = 0; i < T; i++) {
+            float factor = sfo_smoothstep(1.0f, 0.0f, (float)i/(float)T);
+            v4 past = (i < SFO_TEX_HISTORY_DEPTH) ? sample(&f->tex[SFO_TEX_HISTORY + i], f->astuv) : V4(0.0f, 0.0f, 0.0f, 0.0f);
+            color = v4_axpy(color, past, factor);
+        }
+        out = V4((2.0f*color.x)/(float)T, (2.0f*color.y)/(float)T, (2.0f*color.z)/(float)T, (2.0f*color.w)/(float)T);
+    }
+    out.w = 1.0f;
+    return out;
+}
+
+/* examples/basic/shaders/life/simulation.glsl:7-54; user[0..1] = iLifeSize, user[2] = iLifePeriod */
+static v4 frag_life_simulation(const frag_in* f) {
+    static const int alive[9] = {0, 0, 1, 1, 0, 0, 0, 0, 0};
+    static const int dead[9] = {0, 0, 0, 1, 0, 0, 0, 0, 0};
+    const sfo_texture* iLife1x0 = &f->tex[SFO_TEX_HISTORY + 1];
+    v4 out = V4(0.0f, 0.0f, 0.0f, 0.0f);
+    int period = (int)f->u->user[2];
+    if ((f->u->iFrame % period) != 0) {
+        out.x = sample(iLife1x0, f->astuv).x;
+        out.w = 1.0f;
+        return out;
+    }
+    int pixel_x = (int)(f->astuv.x*f->u->user[0]);
+    int pixel_y = (int)(f->astuv.y*f->u->user[1]);
+    int near = 0, current = 0;
+    for (int x = -1; x <= 1; x++)
+        for (int y = -1; y <= 1; y++) {
+            int cell = texel_fetch(iLife1x0, pixel_x + x, pixel_y + y).x > 0.5f ? 1 : 0;
+            if (x == 0 && y == 0) current = cell;
+            else near += cell;
+        }
+    out.x = (float)((current == 1) ? alive[near] : dead[near]);
+    out.w = 1.0f;
+    return out;
+}
+
+/* shaderflow.glsl:210-218 */
+static v3 palette4(float t, v3 A, v3 B, v3 C, v3 D) {
+    v3 lo, hi; float k;
+    if (t < 0.25f) { lo = A; hi = B; k = t*4.0f; }
+    else if (t < 0.5f) { lo = B; hi = C; k = (t - 0.25f)*4.0f; }
+    else { lo = C; hi = D; k = (t - 0.5f)*4.0f; }
+    return V3(sfo_mix(lo.x, hi.x, k), sfo_mix(lo.y, hi.y, k), sfo_mix(lo.z, hi.z, k));
+}
+static const v3 MAGMA[4] = {{0.01060815f, 0.01808215f, 0.10018654f}, {0.38092887f, 0.12061482f, 0.32506528f},
+                            {0.79650140f, 0.10506637f, 0.31063031f}, {0.95922872f, 0.53307513f, 0.37488950f}};
+
+/* examples/basic/shaders/life/visuals.glsl:6-41 */
+static v4 frag_life_visuals(const frag_in* f) {
+    camera_t cam = get_camera(f);
+    if (cam.out_of_bounds) return V4(MAGMA[0].x, MAGMA[0].y, MAGMA[0].z, 1.0f);
+    float exponent = 1.3f;
+    float area = 1.0f/(exponent + 1.0f);
+    static const float base[5] = {1.0f, 0.8f, 0.6f, 0.4f, 0.2f};
+    float life = 0.0f;
+    for (int t = 0; t < 5; t++) {
+        float r = stexture(&f->tex[SFO_TEX_HISTORY + t], cam.stuv).x;
+        life += (t == 0) ? r : r*sfo_pow(base[t], exponent);
+    }
+    life /= (5.0f*area);
+    v3 c = palette4(life, MAGMA[0], MAGMA[1], MAGMA[2], MAGMA[3]);
+    return V4(c.x, c.y, c.z, 1.0f);
+}
+
+/* examples/basic/shaders/video.frag:1-6; iVideo = iVideo0x0 (texture.py:355-356) */
+static v4 frag_video(const frag_in* f) {
+    camera_t cam = get_camera(f);
+    v4 c = stexture(&f->tex[SFO_TEX_HISTORY], cam.stuv);
+    c.w = 1.0f;
+    return c;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Remaining example fragments */
+
+/* shaderflow.glsl:290-293 */
+static float sdBox(v3 origin, v3 point, v3 size) {
+    v3 d = V3(sfo_abs(origin.x - point.x) - size.x/2.0f, sfo_abs(origin.y - point.y) - size.y/2.0f, sfo_abs(origin.z - point.z) - size.z/2.0f);
+    v3 q = V3(sfo_max(d.x, 0.0f), sfo_max(d.y, 0.0f), sfo_max(d.z, 0.0f));
+    return sfo_min(sfo_max(d.x, sfo_max(d.y, d.z)), 0.0f) + sfo_sqrt(v3_dot(q, q));
+}
+
+/* examples/basic/shaders/raymarch.frag:5-59 */
+static v4 frag_raymarch(const frag_in* f) {
+    const int MAX_STEPS = 100; const float MAX_DIST = 100.0f, MIN_DIST = 0.001f;
+    camera_t cam = get_camera(f);
+    v3 dir = v3_sub(cam.target, cam.origin);
+    float norm = sfo_sqrt(v3_dot(dir, dir));
+    v3 forward = V3(dir.x/norm, dir.y/norm, dir.z/norm);
+    float traveled = 0.0f, walk = 0.0f;
+    int steps;
+    for (steps = 0; steps < MAX_STEPS; steps++) {
+        v3 point = v3_add(cam.origin, v3_scale(forward, traveled));
+        float sdf = 2.0f*MAX_DIST;
+        for (int i = 2; i < 8; i++) sdf = sfo_min(sdf, sdBox(point, V3(0.0f, 0.0f, (float)i), V3((float)(i - 1), (float)(i - 1), (float)(i - 1))));
+        walk = sdf;
+        traveled += walk;
+        if (walk < MIN_DIST || walk > MAX_DIST) break;
+    }
+    float g = 1.0f - sfo_sqrt((float)steps)*0.1f;
+    return V4(g, g, g, 1.0f);
+}
+
+/* examples/fractals/shaders/mandelbrot.frag:1-30 */
+static v4 frag_mandelbrot(const frag_in* f) {
+    camera_t cam = get_camera(f);
+    float t = 0.0f;
+    if (!cam.out_of_bounds) {
+        float zx = cam.gluv.x - 0.5f, zy = cam.gluv.y - 0.0f;
+        float cx = zx, cy = zy;
+        int quality = (int)(1000.0f*f->u->iQuality);
+        int iter = 0;
+        for (; iter < quality; iter++) {
+            if (sfo_sqrt(zx*zx + zy*zy) > 3.0f) break;
+            float nx = (zx*zx - zy*zy) + cx;
+            float ny = (zx*zy + zy*zx) + cy;
+            zx = nx; zy = ny;
+        }
+        t = sfo_pow(1.0f - (float)iter/(float)quality, 20.0f);
+    }
+    v3 c = palette4(t, MAGMA[0], MAGMA[1], MAGMA[2], MAGMA[3]);
+    return V4(c.x, c.y, c.z, 1.0f);
+}
+
+/* examples/fractals/shaders/tetration.frag:1-54 */
+typedef struct { float x, y, r, t; } complex_t;
+static v4 frag_tetration(const frag_in* f) {
+    camera_t cam = get_camera(f);
+    complex_t C = {cam.gluv.x, cam.gluv.y, 0.0f, 0.0f};
+    C.r = sfo_sqrt(C.x*C.x + C.y*C.y);
+    C.t = sfo_atan2(C.y, C.x);
+    complex_t Z = C;
+    const int MAX_STEPS = 67;
+    int it;
+    for (it = 0; it < MAX_STEPS; it++) {
+        complex_t W;                                                      /* ComplexNumberPower(C, Z) :20-25 */
+        W.r = sfo_pow(C.r, Z.x)*sfo_exp(-Z.y*C.t);
+        W.t = Z.y*sfo_log(C.r) + (Z.x*C.t);
+        W.x = W.r*sfo_cos(W.t);
+        W.y = W.r*sfo_sin(W.t);
+        Z = W;
+        if (Z.r > 100.0f) break;
+    }
+    float k = (float)(it/MAX_STEPS);
+    float theta = atan2_0_tau(Z.y, Z.x)/SFO_TAU;
+    v3 c = hsv2rgb(theta, 1.0f, k);
+    return V4(c.x, c.y, c.z, 1.0f);
+}
+
 static v4 shade(int fragment, const frag_in* f) {
     switch (fragment) {
         case SFO_FRAG_DEFAULT: return frag_default(f);
@@ -442,6 +652,14 @@ static v4 shade(int fragment, const frag_in* f) {
         case SFO_FRAG_SHADERTOY: return frag_shadertoy(f);
         case SFO_FRAG_DYNAMICS: return frag_dynamics(f);
         case SFO_FRAG_AUDIO: return frag_audio(f);
+        case SFO_FRAG_MULTIPASS: return frag_multipass(f);
+        case SFO_FRAG_MOTIONBLUR: return frag_motionblur(f);
+        case SFO_FRAG_LIFE_SIMULATION: return frag_life_simulation(f);
+        case SFO_FRAG_LIFE_VISUALS: return frag_life_visuals(f);
+        case SFO_FRAG_VIDEO: return frag_video(f);
+        case SFO_FRAG_RAYMARCH: return frag_raymarch(f);
+        case SFO_FRAG_MANDELBROT: return frag_mandelbrot(f);
+        case SFO_FRAG_TETRATION: return frag_tetration(f);
         default: return frag_missing(f);
     }
 }
@@ -454,6 +672,7 @@ typedef struct {
     int fragment; const sfo_uniforms* u; const sfo_texture* tex;
     int wr, hr, w, h, subsample, y0, y1;
     const uint8_t* screen; uint8_t* out;
+    int out_components, out_dtype;   /* render target format: RGBA8 unless sfo_render_to says otherwise */
 } job_t;
 
 static void render_rows(const job_t* jb) {
@@ -462,8 +681,12 @@ static void render_rows(const job_t* jb) {
         for (int i = 0; i < jb->wr; i++) {
             make_varyings(&f, i, j, jb->wr, jb->hr);
             v4 c = shade(jb->fragment, &f);
-            uint8_t* px = jb->out + ((int64_t)j*jb->wr + i)*4;
-            px[0] = to_unorm8(c.x); px[1] = to_unorm8(c.y); px[2] = to_unorm8(c.z); px[3] = to_unorm8(c.w);
+            const float channel[4] = {c.x, c.y, c.z, c.w};
+            const int n = jb->out_components;
+            for (int k = 0; k < n; k++) {
+                if (jb->out_dtype == SFO_F32) ((float*)jb->out)[((int64_t)j*jb->wr + i)*n + k] = channel[k];
+                else jb->out[((int64_t)j*jb->wr + i)*n + k] = to_unorm8(channel[k]);
+            }
         }
     }
 }
@@ -531,6 +754,16 @@ void sfo_render(int fragment, const sfo_uniforms* u, const sfo_texture* textures
     job_t jb = {0};
     jb.kind = 0; jb.fragment = fragment; jb.u = u; jb.tex = textures;
     jb.wr = wr; jb.hr = hr; jb.y0 = y0; jb.y1 = y1; jb.out = out;
+    jb.out_components = 4; jb.out_dtype = SFO_U8;
+    run_jobs(jb, threads);
+}
+
+void sfo_render_to(int fragment, const sfo_uniforms* u, const sfo_texture* textures,
+                   int wr, int hr, int y0, int y1, int threads, int components, int dtype, void* out) {
+    job_t jb = {0};
+    jb.kind = 0; jb.fragment = fragment; jb.u = u; jb.tex = textures;
+    jb.wr = wr; jb.hr = hr; jb.y0 = y0; jb.y1 = y1; jb.out = (uint8_t*)out;
+    jb.out_components = components; jb.out_dtype = dtype;
     run_jobs(jb, threads);
 }
 
@@ -556,6 +789,7 @@ float sfo_test_math(int fn, float a, float b) {
         case 9: return sfo_smoothstep(0.0f, a, b);
         case 10: return sfo_mix(0.25f, a, b);
         case 11: return sfo_sqrt(a);
+        case 12: return sfo_log(a);
         default: return 0.0f;
     }
 }

@@ -275,7 +275,9 @@ static const RegistryEntry g_registry[] = {
 #include "registry_hashes.inc"
 };
 static const char* const g_fragment_names[] = {"default", "missing", "visualizer", "bars", "waveform", "multi_child",
-                                               "multi_main", "shadertoy", "dynamics", "audio"};
+                                               "multi_main", "shadertoy", "dynamics", "audio", "multipass", "motionblur",
+                                               "life_simulation", "life_visuals", "video", "raymarch", "mandelbrot", "tetration"};
+static_assert(sizeof(g_fragment_names)/sizeof(g_fragment_names[0]) == FRAG_COUNT, "one name per fragment");
 enum { FRAG_FINAL = 100 };
 
 static int fragment_by_name(const char* name) {
@@ -320,8 +322,18 @@ static const UniformField g_uniform_fields[] = {
     UF(iWaveformLength, 1, true),
 };
 // scene-defined float uniforms read by a restated fragment: (fragment, name) → user[] slot
-struct UserUniform { int fragment; const char* name; int slot; };
-static const UserUniform g_user_uniforms[] = { {FRAG_DYNAMICS, "iShaderDynamics", 0} };
+struct UserUniform { int fragment; const char* name; int slot; int count; };
+static const UserUniform g_user_uniforms[] = {
+    {FRAG_DYNAMICS, "iShaderDynamics", 0, 1},
+    {FRAG_MOTIONBLUR, "iScreenTemporal", USER_SCREEN_TEMPORAL, 1},      // texture.py:377-379 (<name>Temporal)
+    {FRAG_LIFE_SIMULATION, "iLifeSize", USER_LIFE_SIZE, 2},             // texture.py:376 (<name>Size)
+    {FRAG_LIFE_SIMULATION, "iLifePeriod", USER_LIFE_PERIOD, 1},         // demo.py:244-246
+};
+// the texture whose temporal history `<prefix>{t}x0` a fragment samples → slots TEX_HISTORY + t
+struct HistoryPrefix { int fragment; const char* prefix; };
+static const HistoryPrefix g_history_prefixes[] = {
+    {FRAG_MULTIPASS, "iScreen"}, {FRAG_MOTIONBLUR, "iScreen"}, {FRAG_LIFE_SIMULATION, "iLife"}, {FRAG_LIFE_VISUALS, "iLife"}, {FRAG_VIDEO, "iVideo"},
+};
 
 struct SamplerName { const char* name; int slot; };
 static const SamplerName g_sampler_names[] = { {"background", TEX_BACKGROUND}, {"iSpectrogram", TEX_SPECTROGRAM},
@@ -387,21 +399,30 @@ extern "C" int sfx_uniform_set(sfx_handle h, const char* name, int type, const v
     for (const auto& f : g_uniform_fields)
         if (!strcmp(f.name, name)) { store((char*)&p->u + f.offset, f.count, f.integer); return SFX_OK; }
     for (const auto& uu : g_user_uniforms)
-        if (uu.fragment == p->fragment && !strcmp(uu.name, name)) { store((char*)&p->u.user[uu.slot], 1, false); return SFX_OK; }
+        if (uu.fragment == p->fragment && !strcmp(uu.name, name)) { store((char*)&p->u.user[uu.slot], uu.count, false); return SFX_OK; }
     return SFX_OK;                                                  // inactive uniform: ignored like program.get(name, None)
 }
 
-// "background0x0" (texture.py:346-347) and the #define'd plain name (texture.py:355-356) both resolve
-static int sampler_slot(const char* name) {
+// "background0x0" (texture.py:346-347) and the #define'd plain name (texture.py:355-356) both resolve to the named
+// slot; "<prefix>{t}x0" of the fragment's history texture resolves to TEX_HISTORY + t
+static int sampler_slot(int fragment, const char* name) {
     std::string base(name);
+    int temporal = 0, layer = 0;
     size_t x = base.rfind('x');
     if (x != std::string::npos && x > 0 && x + 1 < base.size()) {
         size_t d = x;
         while (d > 0 && isdigit((unsigned char)base[d - 1])) d--;
         bool tail_digits = true;
         for (size_t k = x + 1; k < base.size(); k++) tail_digits = tail_digits && isdigit((unsigned char)base[k]);
-        if (d < x && tail_digits) base = base.substr(0, d);
+        if (d < x && tail_digits && x - d < 6 && base.size() - x < 7) {
+            temporal = atoi(base.substr(d, x - d).c_str());
+            layer = atoi(base.substr(x + 1).c_str());
+            base = base.substr(0, d);
+        }
     }
+    for (const auto& hp : g_history_prefixes)
+        if (hp.fragment == fragment && base == hp.prefix) return (layer == 0 && temporal < TEX_HISTORY_DEPTH) ? TEX_HISTORY + temporal : -1;
+    if (temporal != 0) return -1;                                   // named slots hold the most recent frame only
     for (const auto& s : g_sampler_names) if (base == s.name) return s.slot;
     return -1;
 }
@@ -411,7 +432,7 @@ extern "C" int sfx_sampler_bind(sfx_handle h, const char* name, sfx_handle tex, 
     Texture* t = get<Texture>(tex, MAGIC_TEX);
     if (!p || !name) return fail(SFX_E_INVALID, "invalid program handle or name");
     if (tex && !t) return fail(SFX_E_INVALID, "invalid texture handle");
-    const int slot = sampler_slot(name);
+    const int slot = sampler_slot(p->fragment, name);
     if (known) *known = (slot >= 0);
     if (slot >= 0) p->samplers[slot] = t;
     return SFX_OK;
@@ -455,6 +476,20 @@ static int check_samplers(int fragment, const RenderArgs& a) {
     if (fragment == FRAG_WAVEFORM) return want(TEX_WAVEFORM, "iWaveform");
     if (fragment == FRAG_MULTI_MAIN) return want(TEX_CHILD, "child");
     if (fragment == FRAG_DYNAMICS) return want(TEX_BACKGROUND, "background");
+    if (fragment == FRAG_MULTIPASS) { if (a.u.iLayer == 0) return want(TEX_BACKGROUND, "background"); return want(TEX_HISTORY, "iScreen0x0"); }
+    if (fragment == FRAG_MOTIONBLUR) {
+        if (a.u.iLayer == 0) return want(TEX_BACKGROUND, "background");
+        const int temporal = (int)a.u.user[USER_SCREEN_TEMPORAL];
+        if (temporal < 1 || temporal > TEX_HISTORY_DEPTH) return fail(SFX_E_UNSUPPORTED, "motionblur: iScreenTemporal = %d, supported 1..%d", temporal, TEX_HISTORY_DEPTH);
+        for (int t = 0; t < temporal; t++) if ((rc = want(TEX_HISTORY + t, "iScreen{t}x0"))) return rc;
+        return rc;
+    }
+    if (fragment == FRAG_LIFE_SIMULATION) {
+        if ((int)a.u.user[USER_LIFE_PERIOD] < 1) return fail(SFX_E_INVALID, "life_simulation: iLifePeriod must be >= 1");
+        return want(TEX_HISTORY + 1, "iLife1x0");
+    }
+    if (fragment == FRAG_LIFE_VISUALS) { for (int t = 0; t < 5; t++) if ((rc = want(TEX_HISTORY + t, "iLife{t}x0"))) return rc; return rc; }
+    if (fragment == FRAG_VIDEO) return want(TEX_HISTORY, "iVideo");
     return rc;
 }
 
@@ -478,6 +513,14 @@ static int launch_render(int fragment, const RenderArgs& a, int frames, hipStrea
         case FRAG_SHADERTOY: launch_render_t<PlainShader<FRAG_SHADERTOY>>(a, frames, s); break;
         case FRAG_DYNAMICS: launch_render_t<PlainShader<FRAG_DYNAMICS>>(a, frames, s); break;
         case FRAG_AUDIO: launch_render_t<PlainShader<FRAG_AUDIO>>(a, frames, s); break;
+        case FRAG_MULTIPASS: launch_render_t<PlainShader<FRAG_MULTIPASS>>(a, frames, s); break;
+        case FRAG_MOTIONBLUR: launch_render_t<PlainShader<FRAG_MOTIONBLUR>>(a, frames, s); break;
+        case FRAG_LIFE_SIMULATION: launch_render_t<PlainShader<FRAG_LIFE_SIMULATION>>(a, frames, s); break;
+        case FRAG_LIFE_VISUALS: launch_render_t<PlainShader<FRAG_LIFE_VISUALS>>(a, frames, s); break;
+        case FRAG_VIDEO: launch_render_t<PlainShader<FRAG_VIDEO>>(a, frames, s); break;
+        case FRAG_RAYMARCH: launch_render_t<PlainShader<FRAG_RAYMARCH>>(a, frames, s); break;
+        case FRAG_MANDELBROT: launch_render_t<PlainShader<FRAG_MANDELBROT>>(a, frames, s); break;
+        case FRAG_TETRATION: launch_render_t<PlainShader<FRAG_TETRATION>>(a, frames, s); break;
         default: return fail(SFX_E_UNSUPPORTED, "fragment %d has no render kernel", fragment);
     }
     return SFX_OK;
@@ -523,6 +566,11 @@ static int launch_fused(int fragment, const RenderArgs& a, int ssaa, int frames,
         case FRAG_SHADERTOY: return launch_fused_s<PlainShader<FRAG_SHADERTOY>>(a, ssaa, frames, s);
         case FRAG_DYNAMICS: return launch_fused_s<PlainShader<FRAG_DYNAMICS>>(a, ssaa, frames, s);
         case FRAG_AUDIO: return launch_fused_s<PlainShader<FRAG_AUDIO>>(a, ssaa, frames, s);
+        case FRAG_LIFE_VISUALS: return launch_fused_s<PlainShader<FRAG_LIFE_VISUALS>>(a, ssaa, frames, s);
+        case FRAG_VIDEO: return launch_fused_s<PlainShader<FRAG_VIDEO>>(a, ssaa, frames, s);
+        case FRAG_RAYMARCH: return launch_fused_s<PlainShader<FRAG_RAYMARCH>>(a, ssaa, frames, s);
+        case FRAG_MANDELBROT: return launch_fused_s<PlainShader<FRAG_MANDELBROT>>(a, ssaa, frames, s);
+        case FRAG_TETRATION: return launch_fused_s<PlainShader<FRAG_TETRATION>>(a, ssaa, frames, s);
         default: return fail(SFX_E_UNSUPPORTED, "fragment %d has no fused kernel", fragment);
     }
 }

@@ -21,8 +21,19 @@ enum : int {
     FRAG_SHADERTOY = 7,     // examples/basic/shaders/shadertoy.frag:62-66
     FRAG_DYNAMICS = 8,      // examples/basic/demo.py:121-126
     FRAG_AUDIO = 9,         // examples/basic/demo.py:149-153
-    FRAG_COUNT = 10,
+    FRAG_MULTIPASS = 10,    // examples/basic/shaders/multipass.frag:10-45   (layers = 2, demo.py:93-99)
+    FRAG_MOTIONBLUR = 11,   // examples/basic/shaders/motionblur.frag:1-18   (temporal = 10, layers = 2, demo.py:103-110)
+    FRAG_LIFE_SIMULATION = 12,  // examples/basic/shaders/life/simulation.glsl:7-54 (R32F, temporal = 10, demo.py:223-242)
+    FRAG_LIFE_VISUALS = 13, // examples/basic/shaders/life/visuals.glsl:6-41
+    FRAG_VIDEO = 14,        // examples/basic/shaders/video.frag:1-6
+    FRAG_RAYMARCH = 15,     // examples/basic/shaders/raymarch.frag:5-59
+    FRAG_MANDELBROT = 16,   // examples/fractals/shaders/mandelbrot.frag:1-30
+    FRAG_TETRATION = 17,    // examples/fractals/shaders/tetration.frag:1-54
+    FRAG_COUNT = 18,
 };
+
+// scene-defined uniforms of the fragments below, by user[] slot (capi: g_user_uniforms)
+enum : int { USER_SCREEN_TEMPORAL = 0, USER_LIFE_SIZE = 0 /* vec2: 0, 1 */, USER_LIFE_PERIOD = 2 };
 
 // ---- default.glsl ----------------------------------------------------------------------------------
 SF_HD vec3 default_grid(vec2 uv, float grid) {
@@ -220,6 +231,184 @@ SF_HD vec4 frag_audio(const Frag& f) {
     return {v, v, v, 1.0f};
 }
 
+// ---- multipass.frag ---------------------------------------------------------------------------------
+// blur() :10-26 with its float loop counters; `radius` arrives as float 5, `directions` and `steps` as int 8
+SF_HD vec4 multipass_blur(const Tex& image, vec2 stuv, float radius, int directions, int steps) {
+    vec4 color = {0.0f, 0.0f, 0.0f, 0.0f};
+    float weights = 0.0f;
+    for (float direction = 0.0f; direction < TAU; direction += TAU/(float)directions) {
+        for (float walk = 1.0f/(float)steps; walk < 1.0f; walk += 1.0f/(float)steps) {
+            vec2 offset = vec2{sf::cos(direction), sf::sin(direction)}*radius*walk/2000.0f;
+            vec4 sample = texture(image, stuv + offset);
+            float weight = 1.0f - length(offset - vec2{0.0f, 0.0f})/radius;
+            color = color + sample*weight;
+            weights += weight;
+        }
+    }
+    return color/weights;
+}
+SF_HD vec4 frag_multipass(const Frag& f) {
+    vec4 col = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (f.u->iLayer == 0) {
+        col = stexture(f.tex[TEX_BACKGROUND], f.stuv);                                         // :32
+    } else if (f.u->iLayer == 1) {
+        const Tex& first = f.history[0];                                             // iScreen0x0
+        col = texture(first, f.astuv);                                                         // :35
+        if (f.gluv.x < 0.0f) col.x = 1.0f - col.x;                                             // :38-39
+        else col = multipass_blur(first, f.astuv, 5.0f, 8, 8);                                 // :41
+    }
+    col.w = 1.0f;
+    return col;
+}
+
+// ---- motionblur.frag --------------------------------------------------------------------------------
+SF_HD vec4 frag_motionblur(const Frag& f) {
+    vec4 col = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (f.u->iLayer == 0) {
+        Camera cam = get_camera(f);
+        col = stexture(f.tex[TEX_BACKGROUND], cam.stuv);                                       // :5-6
+    } else if (f.u->iLayer == 1) {
+        const int temporal = (int)f.u->user[USER_SCREEN_TEMPORAL];                             // iScreenTemporal
+        vec4 color = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < temporal; i++) {
+            float factor = sf::smoothstep(1.0f, 0.0f, (float)i/(float)temporal);               // :11
+            color = color + texture(f.history[i], f.astuv)*factor;                             // iScreenTexture(i, 0, astuv) :12
+        }
+        col = (color*2.0f)/(float)temporal;                                                    // :14
+    }
+    col.w = 1.0f;
+    return col;
+}
+
+// ---- life/simulation.glsl, life/visuals.glsl ---------------------------------------------------------------
+SF_HD vec4 frag_life_simulation(const Frag& f) {
+    const Tex& previous = f.history[1];                                              // iLife1x0
+    const int period = (int)f.u->user[USER_LIFE_PERIOD];
+    vec4 col = {0.0f, 0.0f, 0.0f, 0.0f};
+    col.w = 1.0f;
+    if ((f.u->iFrame % period) != 0) {                                                         // :26-30
+        col.x = texture(previous, f.astuv).x;
+        return col;
+    }
+    const int px = (int)(f.astuv.x*f.u->user[USER_LIFE_SIZE]), py = (int)(f.astuv.y*f.u->user[USER_LIFE_SIZE + 1]);   // :32
+    int near = 0, current = 0;
+    for (int x = -1; x <= 1; x++) {
+        for (int y = -1; y <= 1; y++) {
+            const int cell = (texel_fetch(previous, px + x, py + y).x > 0.5f) ? 1 : 0;        // :38
+            if (x == 0 && y == 0) current = cell; else near += cell;
+        }
+    }
+    // alive[] :8-12 survives with two or three neighbours, dead[] :15-19 is born with three
+    const bool lives = (current == 1) ? (near == 2 || near == 3) : (near == 3);
+    col.x = lives ? 1.0f : 0.0f;
+    return col;
+}
+SF_HD vec4 frag_life_visuals(const Frag& f) {
+    const vec3 c1 = {0.01060815f, 0.01808215f, 0.10018654f}, c2 = {0.38092887f, 0.12061482f, 0.32506528f};
+    const vec3 c3 = {0.79650140f, 0.10506637f, 0.31063031f}, c4 = {0.95922872f, 0.53307513f, 0.37488950f};
+    Camera cam = get_camera(f);
+    if (cam.out_of_bounds) return {c1.x, c1.y, c1.z, 1.0f};                                    // :15-18
+    const float exponent = 1.3f;
+    const float area = 1.0f/(exponent + 1.0f);
+    float life = 0.0f;
+    life += stexture(f.history[0], cam.stuv).x;                                      // :27-31
+    life += stexture(f.history[1], cam.stuv).x*sf::pow(0.8f, exponent);
+    life += stexture(f.history[2], cam.stuv).x*sf::pow(0.6f, exponent);
+    life += stexture(f.history[3], cam.stuv).x*sf::pow(0.4f, exponent);
+    life += stexture(f.history[4], cam.stuv).x*sf::pow(0.2f, exponent);
+    life /= (5.0f*area);
+    vec3 c = palette(life, c1, c2, c3, c4);
+    return {c.x, c.y, c.z, 1.0f};
+}
+
+// ---- video.frag -------------------------------------------------------------------------------------
+SF_HD vec4 frag_video(const Frag& f) {
+    Camera cam = get_camera(f);
+    vec4 col = stexture(f.history[0], cam.stuv);                                     // iVideo = iVideo0x0
+    col.w = 1.0f;
+    return col;
+}
+
+// ---- raymarch.frag ----------------------------------------------------------------------------------
+SF_HD float sd_box(vec3 origin, vec3 point, vec3 size) {                                        // shaderflow.glsl:290-293
+    vec3 d = {sf::abs(origin.x - point.x) - size.x/2.0f, sf::abs(origin.y - point.y) - size.y/2.0f, sf::abs(origin.z - point.z) - size.z/2.0f};
+    vec3 m = {sf::max(d.x, 0.0f), sf::max(d.y, 0.0f), sf::max(d.z, 0.0f)};
+    return sf::min(sf::max(d.x, sf::max(d.y, d.z)), 0.0f) + sf::sqrt(dot(m, m));
+}
+SF_HD float raymarch_scene(vec3 origin) {                                                       // :9-32
+    float sdf = 2.0f*100.0f;
+    for (int i = 2; i < 8; i++) {
+        const float side = (float)(i - 1);
+        sdf = sf::min(sdf, sd_box(origin, vec3{0.0f, 0.0f, (float)i}, vec3{side, side, side}));
+    }
+    return sdf;
+}
+SF_HD vec4 frag_raymarch(const Frag& f) {
+    Camera cam = get_camera(f);
+    vec3 delta = cam.target - cam.origin;
+    vec3 forward = delta/sf::sqrt(dot(delta, delta));                                          // normalize :41
+    float traveled = 0.0f, walk = 0.0f;
+    int steps;
+    for (steps = 0; steps < 100; steps++) {                                                    // :48-53
+        vec3 point = cam.origin + (forward*traveled);
+        walk = raymarch_scene(point);
+        traveled += walk;
+        if (walk < 0.001f || walk > 100.0f) break;
+    }
+    const float v = 1.0f - sf::sqrt((float)steps)*0.1f;                                        // :58
+    return {v, v, v, 1.0f};
+}
+
+// ---- mandelbrot.frag, tetration.frag ---------------------------------------------------------------------
+SF_HD vec3 palette_magma(float t) {                                                             // shaderflow.glsl:220-224
+    return palette(t, vec3{0.01060815f, 0.01808215f, 0.10018654f}, vec3{0.38092887f, 0.12061482f, 0.32506528f},
+                   vec3{0.79650140f, 0.10506637f, 0.31063031f}, vec3{0.95922872f, 0.53307513f, 0.37488950f});
+}
+SF_HD vec4 frag_mandelbrot(const Frag& f) {
+    Camera cam = get_camera(f);
+    vec3 c3;
+    if (cam.out_of_bounds) {
+        c3 = palette_magma(0.0f);
+    } else {
+        vec2 z = cam.gluv - vec2{0.5f, 0.0f};
+        const vec2 c = z;
+        const int quality = (int)(1000.0f*f.u->iQuality);
+        int iter = 0;
+        for (; iter < quality; iter++) {
+            if (length(z) > 3.0f) break;
+            z = vec2{z.x*z.x - z.y*z.y, z.x*z.y + z.y*z.x} + c;                                // cmul(z, z) + c :2-7,21
+        }
+        c3 = palette_magma(sf::pow(1.0f - (float)iter/(float)quality, 20.0f));                 // :25
+    }
+    return {c3.x, c3.y, c3.z, 1.0f};
+}
+struct ComplexNumber { float x, y, r, t; };                                                     // tetration.frag:2-5
+SF_HD ComplexNumber complex_power(ComplexNumber a, ComplexNumber b) {                           // :20-25
+    ComplexNumber z;
+    z.r = sf::pow(a.r, b.x)*sf::exp(-b.y*a.t);
+    z.t = b.y*sf::log(a.r) + (b.x*a.t);
+    z.x = z.r*sf::cos(z.t);
+    z.y = z.r*sf::sin(z.t);
+    return z;
+}
+SF_HD vec4 frag_tetration(const Frag& f) {
+    Camera cam = get_camera(f);
+    ComplexNumber C;
+    C.x = cam.gluv.x; C.y = cam.gluv.y;
+    C.r = sf::sqrt(C.x*C.x + C.y*C.y); C.t = sf::atan(C.y, C.x);                               // UpdatePolar :7-11
+    ComplexNumber Z = C;
+    const int max_steps = 67;
+    int it = 0;
+    for (it = 0; it < max_steps; it++) {
+        Z = complex_power(C, Z);
+        if (Z.r > 100.0f) break;
+    }
+    const float k = (float)(it/max_steps);                                                     // integer division :49
+    const float theta = atan2(Z.y, Z.x)/TAU;                                                   // atan2n :394-396
+    vec3 c = hsv2rgb(theta, 1.0f, k);
+    return {c.x, c.y, c.z, 1.0f};
+}
+
 template <int FRAGMENT> SF_HD vec4 shade(const Frag& f) {
     if constexpr (FRAGMENT == FRAG_DEFAULT) return frag_default(f);
     else if constexpr (FRAGMENT == FRAG_VISUALIZER) return frag_visualizer(f);
@@ -230,6 +419,14 @@ template <int FRAGMENT> SF_HD vec4 shade(const Frag& f) {
     else if constexpr (FRAGMENT == FRAG_SHADERTOY) return frag_shadertoy(f);
     else if constexpr (FRAGMENT == FRAG_DYNAMICS) return frag_dynamics(f);
     else if constexpr (FRAGMENT == FRAG_AUDIO) return frag_audio(f);
+    else if constexpr (FRAGMENT == FRAG_MULTIPASS) return frag_multipass(f);
+    else if constexpr (FRAGMENT == FRAG_MOTIONBLUR) return frag_motionblur(f);
+    else if constexpr (FRAGMENT == FRAG_LIFE_SIMULATION) return frag_life_simulation(f);
+    else if constexpr (FRAGMENT == FRAG_LIFE_VISUALS) return frag_life_visuals(f);
+    else if constexpr (FRAGMENT == FRAG_VIDEO) return frag_video(f);
+    else if constexpr (FRAGMENT == FRAG_RAYMARCH) return frag_raymarch(f);
+    else if constexpr (FRAGMENT == FRAG_MANDELBROT) return frag_mandelbrot(f);
+    else if constexpr (FRAGMENT == FRAG_TETRATION) return frag_tetration(f);
     else return frag_missing(f);
 }
 

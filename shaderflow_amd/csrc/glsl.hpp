@@ -147,6 +147,13 @@ SF_HD vec2 texture_xy(const Tex& t, vec2 uv) {
     return {bilerp(w00, w10, w01, w11, t00.x, t10.x, t01.x, t11.x), bilerp(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y)};
 }
 
+// texelFetch(sampler, ivec2, 0). Out-of-range coordinates are undefined in GL 3.3 (§3.8.9); with robust buffer
+// access — what desktop drivers do in practice — the fetch returns zeros, and that is the rule here.
+SF_HD vec4 texel_fetch(const Tex& t, int i, int j) {
+    if ((unsigned)i >= (unsigned)t.width || (unsigned)j >= (unsigned)t.height) return {0.0f, 0.0f, 0.0f, 0.0f};
+    return texel(t, i, j);
+}
+
 SF_HD uint32_t unorm8(float c) {
     c = (c > 0.0f) ? c : 0.0f;
     c = (c < 1.0f) ? c : 1.0f;
@@ -176,7 +183,9 @@ struct Uniforms {
     float user[16];
 };
 
-enum : int { TEX_BACKGROUND = 0, TEX_SPECTROGRAM = 1, TEX_WAVEFORM = 2, TEX_CHILD = 3, TEX_SLOTS = 4 };
+// Sampler slots: four named textures, then the temporal history of the texture a fragment reads by
+// `<name>{t}x0` (texture.py:346-347, 380-381): slot TEX_HISTORY + t is `t` frames back, layer 0.
+enum : int { TEX_BACKGROUND = 0, TEX_SPECTROGRAM = 1, TEX_WAVEFORM = 2, TEX_CHILD = 3, TEX_HISTORY = 4, TEX_HISTORY_DEPTH = 12, TEX_SLOTS = 16 };
 
 // Per-frame values that live on the device in tape (batched export) mode; written by the dynamics scan
 struct FrameDyn {
@@ -188,7 +197,8 @@ struct FrameDyn {
 
 struct Frag {
     const Uniforms* u;
-    const Tex* tex;
+    const Tex* tex;                                // the named slots [0, TEX_HISTORY)
+    const Tex* history;                            // history[t] = slot TEX_HISTORY + t (read in place from the kernel arguments)
     vec2 agluv, gluv, astuv, stuv, stxy, glxy, fragCoord;
     float aspect;                                  // iAspectRatio, shaderflow.glsl:16
 };
@@ -244,6 +254,11 @@ SF_HD vec3 hsv2rgb(float h, float s, float v) {                                 
         default: rgb = {0.0f, 0.0f, 0.0f};
     }
     return rgb + m;
+}
+SF_HD vec3 palette(float t, vec3 A, vec3 B, vec3 C, vec3 D) {                                // :210-218
+    if (t < 0.25f) return mix(A, B, t*4.0f);
+    if (t < 0.5f) return mix(B, C, (t - 0.25f)*4.0f);
+    return mix(C, D, (t - 0.5f)*4.0f);
 }
 SF_HD vec3 rotate3d(vec3 v, vec3 axis, float angle) {                                      // :81-83
     float c = sf::cos(angle), s = sf::sin(angle);

@@ -46,7 +46,7 @@ struct RenderArgs {
 
 __device__ __forceinline__ void frame_view(const RenderArgs& a, int frame, Uniforms& u, Tex* tex) {
     u = a.u;
-    for (int k = 0; k < TEX_SLOTS; k++) tex[k] = a.tex[k];
+    for (int k = 0; k < TEX_HISTORY; k++) tex[k] = a.tex[k];        // history slots are read in place (Frag::history)
     if (a.dyn) {
         const FrameDyn d = a.dyn[a.frame0 + frame];
         u.iTime = d.iTime; u.iTau = d.iTau; u.iFrame = d.iFrame;
@@ -97,10 +97,10 @@ __global__ __launch_bounds__(256) void k_render(const RenderArgs a) {
     __shared__ typename SHADER::Shared shared;
     const int i = blockIdx.x*SHADER::BLOCK_W + threadIdx.x;
     const int j = blockIdx.y*SHADER::BLOCK_H + threadIdx.y;
-    Uniforms u; Tex tex[TEX_SLOTS];
+    Uniforms u; Tex tex[TEX_HISTORY];
     frame_view(a, blockIdx.z, u, tex);
     const bool inside = (i < a.wr) && (j < a.hr);
-    Frag f; f.u = &u; f.tex = tex;
+    Frag f; f.u = &u; f.tex = tex; f.history = a.tex + TEX_HISTORY;
     make_varyings(f, i, j, a.wr, a.hr, a.aspect);
     typename SHADER::State state[1];
     const bool valid[1] = {inside};
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_reso
     constexpr int PER_LANE = GROUP*WALK;
     __shared__ __attribute__((aligned(16))) uint8_t staged[ROWS][384];
 
-    Uniforms u; Tex tex[TEX_SLOTS];
+    Uniforms u; Tex tex[TEX_HISTORY];
     frame_view(a, blockIdx.z, u, tex);
     const int blocks_x = (a.w + 127)/128;
     const int tile = xcd_band_order(blockIdx.x, gridDim.x);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_reso
     uint32_t mine[PER_LANE];
     typename SHADER::State state[PER_LANE];
     bool valid[PER_LANE];
-    Frag f; f.u = &u; f.tex = tex;
+    Frag f; f.u = &u; f.tex = tex; f.history = a.tex + TEX_HISTORY;
 #pragma unroll
     for (int n = 0; n < PER_LANE; n++) {
         const int r = n / GROUP, m = n % GROUP;

@@ -157,5 +157,6 @@ SF_HD float pow(float x, float y) {
     return sf::exp2(y*sf::log2(x));
 }
 SF_HD float exp(float x) { return sf::exp2(x*0x1.715476p+0f); }
+SF_HD float log(float x) { return sf::log2(x)*0x1.62e430p-1f; }
 
 }  // namespace sf

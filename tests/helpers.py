@@ -78,10 +78,18 @@ class Gpu:
         N.check(self.lib.sfx_sampler_bind(prog, name.encode(), tex, C.byref(known)))
         return bool(known.value)
 
-    def render(self, prog, w, h, comps=4, dtype=np.uint8) -> np.ndarray:
+    def render(self, prog, w, h, comps=4, dtype=np.uint8, layer=0) -> np.ndarray:
         target = self.empty(w, h, comps, dtype)
-        N.check(self.lib.sfx_render(prog, target, 0))
+        N.check(self.lib.sfx_render(prog, target, layer))
         return self.read(target, w, h, comps, dtype)
+
+    def set_values(self, prog, name: str, values, integer=False) -> bool:
+        """Push a scalar / vec2-4 uniform by name; True when the program consumes it"""
+        arr = np.atleast_1d(np.asarray(values, np.int32 if integer else np.float32))
+        code = N.T_INT if integer else {1: N.T_FLOAT, 2: N.T_VEC2, 3: N.T_VEC3, 4: N.T_VEC4}[arr.size]
+        known = C.c_int()
+        N.check(self.lib.sfx_uniform_set(prog, name.encode(), code, arr.ctypes.data, C.byref(known)))
+        return bool(known.value)
 
     def resolve(self, screen: np.ndarray, w, h, subsample) -> np.ndarray:
         src = self.texture(screen, "linear", False, False)

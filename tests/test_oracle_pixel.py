@@ -148,3 +148,115 @@ def test_visualizer_silent_is_background_scaled():
     assert img[:, :, :3].std() > 5                                            # background shows through
     # threads do not change results
     assert np.array_equal(img, O.render("visualizer", u, tex, w, h, threads=1))
+
+
+# ---- multipass / temporal / remaining fragments: known answers ---------------------------------
+
+def life_step(state: np.ndarray, frame: int = 0, period: int = 1) -> np.ndarray:
+    h, w = state.shape
+    u = O.default_uniforms(w, h, iFrame=frame)
+    u.user[0], u.user[1], u.user[2] = w, h, period
+    tex = O.make_texture(state.astype(np.float32)[:, :, None], "nearest", True, True)
+    return O.render_to("life_simulation", u, {1: tex}, w, h, 1, np.float32)[..., 0]
+
+
+def test_life_simulation_known_patterns():
+    """simulation.glsl:21-53 — still lifes stay, the blinker has period 2, the glider moves one cell diagonally every
+    4 generations; cells outside the texture are dead (texelFetch out of range reads zero)"""
+    block = np.zeros((8, 8)); block[3:5, 3:5] = 1
+    assert np.array_equal(life_step(block), block)
+    blinker = np.zeros((7, 7)); blinker[3, 2:5] = 1
+    once = life_step(blinker)
+    assert np.array_equal(once, blinker.T) and np.array_equal(life_step(once), blinker)
+    glider = np.zeros((12, 12)); glider[1, 2] = glider[2, 3] = glider[3, 1] = glider[3, 2] = glider[3, 3] = 1
+    state = glider
+    for _ in range(4):
+        state = life_step(state)
+    assert np.array_equal(state, np.roll(np.roll(glider, 1, 0), 1, 1))
+    edge = np.zeros((6, 6)); edge[0, 0:3] = 1                        # a blinker on the border: no wrap-around neighbours
+    assert np.array_equal(life_step(edge), np.array([[0, 1, 0, 0, 0, 0], [0, 1, 0, 0, 0, 0]] + [[0]*6]*4))
+    assert np.array_equal(life_step(blinker, frame=5, period=6), blinker)      # held between life periods (:26-30)
+    assert np.array_equal(life_step(blinker, frame=12, period=6), blinker.T)
+
+
+def test_motionblur_constant_history_closed_form():
+    """motionblur.frag:9-14 with every past frame equal to c: 2*c*sum(smoothstep(1, 0, i/T))/T"""
+    w, h, T = 16, 9, 10
+    frame = np.full((h, w, 4), 100, np.uint8)
+    u = O.default_uniforms(w, h, iLayer=1)
+    u.user[0] = T
+    got = O.render("motionblur", u, {t: O.make_texture(frame, "linear", False, False) for t in range(T)}, w, h)
+    x = 1.0 - np.arange(T)/T                                         # smoothstep(1, 0, s) = S(1 - s)
+    factors = x*x*(3 - 2*x)
+    want = np.rint(255*min(1.0, 2*(100/255)*factors.sum()/T))
+    assert np.abs(got[..., :3].astype(int) - want).max() <= 1 and (got[..., 3] == 255).all()
+    # an empty history is black: what the first temporal-1 frames of the scene show
+    zero = np.zeros((h, w, 4), np.uint8)
+    assert not O.render("motionblur", u, {t: O.make_texture(zero) for t in range(T)}, w, h)[..., :3].any()
+
+
+def test_multipass_layers():
+    """multipass.frag:28-45: layer 0 shows the background, layer 1 inverts red left of the centre and blurs the right"""
+    w, h = 64, 36
+    rng = np.random.default_rng(2)
+    background = rng.integers(0, 256, (18, 32, 3), dtype=np.uint8)
+    u = O.default_uniforms(w, h, iLayer=0)
+    layer0 = O.render("multipass", u, {"background": O.make_texture(background)}, w, h)
+    dyn = O.render("dynamics", u, {"background": O.make_texture(background)}, w, h)      # zoom(stuv, 0.85 + 0) ≠ identity, so only the sampler is shared
+    assert layer0.shape == dyn.shape and (layer0[..., 3] == 255).all() and layer0[..., :3].std() > 10
+    flat = np.zeros((h, w, 4), np.uint8); flat[..., 0] = 40; flat[..., 1] = 90; flat[..., 2] = 200; flat[..., 3] = 255
+    u.iLayer = 1
+    layer1 = O.render("multipass", u, {0: O.make_texture(flat, "linear", False, False)}, w, h)
+    assert (layer1[:, :w//2, 0] == 215).all() and (layer1[:, :w//2, 1] == 90).all() and (layer1[:, :w//2, 2] == 200).all()
+    assert np.abs(layer1[:, w//2:, :3].astype(int) - np.array([40, 90, 200])).max() <= 1  # the blur of a constant is the constant
+
+
+def test_mandelbrot_membership_and_raymarch_depth():
+    w, h = 96, 54
+    u = O.default_uniforms(w, h)
+    img = O.render("mandelbrot", u, {}, w, h, threads=4)
+    # c = gluv - (0.5, 0): the pixel whose gluv ≈ (0.5, 0) is c ≈ 0, inside the set → t = pow(0, 20) = 0 → first palette colour
+    inside = img[h//2, int((0.5/(16/9) + 1)/2*w)]
+    assert np.abs(inside[:3].astype(int) - np.rint(255*np.array([0.01060815, 0.01808215, 0.10018654]))).max() <= 1
+    # escape-time image against a float64 restatement (the last palette segment extrapolates: (t - 0.5)*4 reaches 2,
+    # shaderflow.glsl:216 — kept as is), compared where the iteration count is far from a float32/float64 disagreement
+    ys, xs = np.mgrid[0:h, 0:w]
+    c = ((2*(xs + 0.5)/w - 1)*(16/9) - 0.5) + 1j*(2*(ys + 0.5)/h - 1)
+    z, count = c.copy(), np.zeros(c.shape, int)
+    alive = np.ones(c.shape, bool)
+    for _ in range(500):
+        alive &= np.abs(z) <= 3.0
+        count += alive
+        z = np.where(alive, z*z + c, z)
+    t = (1 - count/500)**20
+    magma = np.array([[0.01060815, 0.01808215, 0.10018654], [0.38092887, 0.12061482, 0.32506528],
+                      [0.79650140, 0.10506637, 0.31063031], [0.95922872, 0.53307513, 0.37488950]])
+    seg = np.where(t < 0.25, 0, np.where(t < 0.5, 1, 2))
+    k = ((t - 0.25*seg)*4)[..., None]
+    want = np.rint(255*np.clip(magma[seg]*(1 - k) + magma[seg + 1]*k, 0, 1))
+    stable = (count < 30) | (count == 500)
+    assert stable.mean() > 0.8
+    assert np.abs(img[..., :3].astype(int) - want)[stable].max() <= 2
+
+    ray = O.render("raymarch", u, {}, w, h, threads=4)
+    # the central ray meets the first box (centre z = 2, side 1) head-on: one step of 1.5, then a zero step → steps = 1
+    assert abs(int(ray[h//2, w//2, 0]) - round(255*0.9)) <= 1 and (ray[..., 3] == 255).all()
+    assert ray[0, 0, 0] < ray[h//2, w//2, 0]                          # rays that graze or miss take more steps
+
+
+def test_tetration_and_video_are_well_formed():
+    w, h = 64, 36
+    u = O.default_uniforms(w, h)
+    img = O.render("tetration", u, {}, w, h, threads=4)
+    # k = it / MAX_STEPS is an INTEGER division (tetration.frag:49): value is 0 unless the loop ran to the end → black or a pure hue
+    rgb = img[..., :3].astype(int)
+    assert set(np.unique(rgb.max(axis=2))) <= {0, 255} and (img[..., 3] == 255).all() and 0 < (rgb.max(axis=2) == 255).mean() < 1
+    frame = np.random.default_rng(0).integers(0, 256, (18, 32, 3), dtype=np.uint8)
+    vid = O.render("video", u, {0: O.make_texture(frame)}, w, h)
+    bg = O.render("multipass", u, {"background": O.make_texture(frame)}, w, h)         # layer 0: stexture(background, stuv)
+    assert np.array_equal(vid, bg)                                   # identity camera: iCamera.stuv == stuv
+
+
+def test_log_matches_libm():
+    x = np.exp(np.random.default_rng(3).uniform(-20, 20, 2000)).astype(np.float32)
+    assert np.allclose(O.math("log", x), np.log(x.astype(np.float64)), rtol=0, atol=4e-6*20)
