@@ -460,7 +460,6 @@ static void fill_args(const Program* p, RenderArgs& a) {
     a.vis = visualizer_consts(p->u.iTime, p->u.iAudioVolume, p->u.iAudioSTD);
     a.has_vis = 1;
     a.vis_consts = nullptr;
-    a.one = 1.0f;
     a.aspect = p->u.iResolution[0]/p->u.iResolution[1];
     a.identity_camera = camera_is_identity(p->u) ? 1 : 0;
     a.top_down = p->ctx->top_down;
@@ -549,7 +548,38 @@ template <class SHADER> static int launch_fused_s(const RenderArgs& a, int ssaa,
     return SFX_OK;
 }
 
-static int launch_fused(int fragment, const RenderArgs& a, int ssaa, int frames, hipStream_t s, bool force_generic = false) {
+#ifdef SF_SECTION_TIMERS
+static int launch_fused_inner(int fragment, const RenderArgs& a, int ssaa, int frames, hipStream_t s, bool force_generic);
+// profiling builds: run the launch with section timers and print the share of wave time per section
+static int launch_fused(int fragment, const RenderArgs& a0, int ssaa, int frames, hipStream_t s, bool force_generic = false) {
+    static unsigned long long* d_timers = nullptr;
+    static std::vector<unsigned long long> host(SF_TIMER_ROWS*8);
+    if (!d_timers) hipMalloc(&d_timers, host.size()*sizeof(unsigned long long));
+    hipMemsetAsync(d_timers, 0, host.size()*sizeof(unsigned long long), s);
+    RenderArgs a = a0;
+    a.timers = d_timers;
+    const int rc = launch_fused_inner(fragment, a, ssaa, frames, s, force_generic);
+    unsigned long long t[8] = {};
+    hipMemcpyAsync(host.data(), d_timers, host.size()*sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    hipStreamSynchronize(s);
+    for (size_t k = 0; k < host.size(); k++) t[k % 8] += host[k];
+    const double total = (double)(t[0] + t[1] + t[2] + t[3]);
+    static const char* names[] = {"varyings+pre", "setup", "run", "resolve+store", "  setup.reduce", "  setup.stage", "  setup.barrier", "  run.blur"};
+    fprintf(stderr, "[section timers] %d frames:", frames);
+    for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f%%", names[k], 100.0*(double)t[k]/total);
+    fprintf(stderr, "\n");
+    return rc;
+}
+#define launch_fused_body launch_fused_inner
+#else
+#define launch_fused_body launch_fused
+#endif
+
+static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int frames, hipStream_t s, bool force_generic
+#ifndef SF_SECTION_TIMERS
+                             = false
+#endif
+                             ) {
     switch (fragment) {
         case FRAG_DEFAULT: return launch_fused_s<PlainShader<FRAG_DEFAULT>>(a, ssaa, frames, s);
         case FRAG_MISSING: return launch_fused_s<PlainShader<FRAG_MISSING>>(a, ssaa, frames, s);

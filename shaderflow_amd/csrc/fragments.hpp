@@ -142,9 +142,34 @@ SF_HD vec4 visualizer_blur_reference(const Frag& f, const VisualizerPre& p, cons
     return color/(quality*directions);
 }
 
+// COLOUR_ONLY_FAST: the LDS-tiled kernel evaluates the four terms that only scale colours (never decide a branch or
+// a texel index) with the hardware's v_log/v_exp/v_sqrt/v_rcp (1 ulp) instead of the sfmath sequences: <= 1e-6
+// relative on a colour, far inside the 1 LSB tolerance of that path. Everything that feeds a comparison or a
+// nearest-texel lookup (atan, the bar height, the lengths compared with it) stays bit-identical to the generic chain.
+template <bool COLOUR_ONLY_FAST>
+struct ColourMath {
+    SF_HD static float pow(float x, float y) { return sf::pow(x, y); }
+    SF_HD static float pow6(float x) { return sf::pow(x, 6.0f); }
+    SF_HD static float length(vec2 a) { return sf::length(a); }
+    SF_HD static float over20(float x) { return x/20.0f; }
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+template <> struct ColourMath<true> {
+    __device__ __forceinline__ static float pow(float x, float y) {
+        if (x == 0.0f) return (y > 0.0f) ? 0.0f : ((y == 0.0f) ? 1.0f : INFINITY);      // as sf::pow
+        return __builtin_amdgcn_exp2f(y*__builtin_amdgcn_logf(x));                      // v_exp_f32(y*v_log_f32(x)); x < 0 gives NaN like sf::pow
+    }
+    __device__ __forceinline__ static float pow6(float x) { const float x2 = x*x; return x2*x2*x2; }
+    __device__ __forceinline__ static float length(vec2 a) { return __builtin_amdgcn_sqrtf(a.x*a.x + a.y*a.y); }
+    __device__ __forceinline__ static float over20(float x) { return x*0.05f; }
+};
+#endif
+
+template <bool COLOUR_ONLY_FAST = false>
 SF_HD vec4 visualizer_post(const Frag& f, const VisualizerPre& p, const VisualizerConsts& c, vec4 col) {
+    using CM = ColourMath<COLOUR_ONLY_FAST>;
     const vec3 space = vec3{1.0f, 11.0f, 26.0f}/255.0f;                                        // :9
-    col = col*(1.0f + c.flash*sf::pow(sf::clamp(length(f.agluv) - 0.3f, 0.0f, 1.0f), 6.0f));  // :36
+    col = col*(1.0f + c.flash*CM::pow6(sf::clamp(CM::length(f.agluv) - 0.3f, 0.0f, 1.0f)));   // :36
 
     vec2 music_uv = {c.rot_c*p.uv.x + c.rot_s*p.uv.y, (-c.rot_s)*p.uv.x + c.rot_c*p.uv.y};     // rotate2d(-PI/2)*uv :39
     music_uv = music_uv*c.shrink;                                                              // :40
@@ -164,13 +189,13 @@ SF_HD vec4 visualizer_post(const Frag& f, const VisualizerPre& p, const Visualiz
         if (len < r) {
             set_rgb(col, mix(rgb(col), vec3{1.0f, 1.0f, 1.0f}, sf::smoothstep(0.0f, 1.0f, 0.5f + bar)));   // :56
         } else {
-            set_rgb(col, rgb(col)*sf::pow((len - r)*0.5f, 0.05f));                             // :58
+            set_rgb(col, rgb(col)*CM::pow((len - r)*0.5f, 0.05f));                             // :58
         }
     }
-    set_rgb(col, mix(rgb(col), space, sf::smoothstep(0.0f, 1.0f, length(p.uv)/20.0f)));       // :62
+    set_rgb(col, mix(rgb(col), space, sf::smoothstep(0.0f, 1.0f, CM::over20(CM::length(p.uv)))));   // :62
 
     vec2 vig = f.astuv*vec2{1.0f - f.astuv.y, 1.0f - f.astuv.x};                               // :65
-    set_rgb(col, rgb(col)*sf::pow(vig.x*vig.y*20.0f, c.vig_exp));                              // :66
+    set_rgb(col, rgb(col)*CM::pow(vig.x*vig.y*20.0f, c.vig_exp));                              // :66
     col.w = 1.0f;
 
     vec2 w = texture_xy(f.tex[TEX_WAVEFORM], vec2{f.astuv.x, 0.0f});                           // :71
@@ -187,7 +212,7 @@ SF_HD vec4 frag_visualizer(const Frag& f) {
         const vec3 space = vec3{1.0f, 11.0f, 26.0f}/255.0f;
         return {space.x, space.y, space.z, 0.0f};
     }
-    return visualizer_post(f, p, c, visualizer_blur_reference(f, p, c));
+    return visualizer_post<false>(f, p, c, visualizer_blur_reference(f, p, c));
 }
 
 // ---- bars.frag / waveform.frag ---------------------------------------------------------------------

@@ -38,11 +38,32 @@ struct RenderArgs {
     const VisualizerConsts* vis_consts;
     VisualizerConsts vis;
     int has_vis;
-    float one;                       // 1.0f, kept opaque to the optimiser (visualizer_kernels.hpp tap())
     int identity_camera;             // glsl.hpp camera_is_identity(u): iCamera.gluv == gluv exactly
     float aspect;                    // iResolution.x/iResolution.y (iAspectRatio, shaderflow.glsl:16), divided once on the host
     int top_down;                    // K9: write the RGB8 frame rows top-down (the encoder's `vflip`, exporting.py:103, done here)
+#ifdef SF_SECTION_TIMERS
+    unsigned long long* timers;      // profiling builds (tools/variants.sh): per-section shader-clock sums, see SF_TICK
+#endif
 };
+
+// Section timers of profiling builds: every wave adds the shader-clock cycles it spent since its previous mark to
+// timers[section]; compiled out otherwise.
+#ifdef SF_SECTION_TIMERS
+#define SF_TIMER_ROWS 8192
+__device__ __forceinline__ unsigned long long sf_clock() {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_readcyclecounter();
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define SF_TICK_INIT() unsigned long long sf_tick_last = sf_clock()
+#define SF_TICK(a, section) do { const unsigned long long sf_now = sf_clock(); \
+    if ((threadIdx.x & 63) == 0 && (a).timers) atomicAdd(&(a).timers[(((blockIdx.x + blockIdx.z*gridDim.x)*8 + (threadIdx.x >> 6)) % SF_TIMER_ROWS)*8 + section], sf_now - sf_tick_last); \
+    sf_tick_last = sf_clock(); } while (0)
+#else
+#define SF_TICK_INIT() do {} while (0)
+#define SF_TICK(a, section) do {} while (0)
+#endif
 
 __device__ __forceinline__ void frame_view(const RenderArgs& a, int frame, Uniforms& u, Tex* tex) {
     u = a.u;
@@ -254,6 +275,7 @@ __global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_reso
     typename SHADER::State state[PER_LANE];
     bool valid[PER_LANE];
     Frag f; f.u = &u; f.tex = tex; f.history = a.tex + TEX_HISTORY;
+    SF_TICK_INIT();
 #pragma unroll
     for (int n = 0; n < PER_LANE; n++) {
         const int r = n / GROUP, m = n % GROUP;
@@ -262,7 +284,9 @@ __global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_reso
         make_varyings(f, px*S + gx, (py0 + r)*S + gy, a.wr, a.hr, a.aspect);
         SHADER::pre(a, f, valid[n], state[n]);
     }
+    SF_TICK(a, 0);                                   // varyings + pre
     SHADER::template setup<PER_LANE>(a, tex, f, state, valid, shared);
+    SF_TICK(a, 1);                                   // setup (window reduction + LDS staging)
 #pragma unroll
     for (int n = 0; n < PER_LANE; n++) {
         uint32_t q = 0;
@@ -276,6 +300,7 @@ __global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_reso
         }
         mine[n] = q;
     }
+    SF_TICK(a, 2);                                   // run (blur + post)
 
     if constexpr (S == 1) {
         const uint32_t block[1] = {mine[0]};
@@ -314,6 +339,7 @@ __global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_reso
         const int y = by*ROWS + r;
         if (y < a.h) store_rgb_row(frame + (long)(a.top_down ? a.h - 1 - y : y)*a.w*3, bx*128, a.w, staged[r], tid, blockDim.x);
     }
+    SF_TICK(a, 3);                                   // resolve + store
 }
 
 }  // namespace sf

@@ -6,13 +6,14 @@
 // a block falls inside one small window of the background, so the block:
 //   1. reduces the bounding box of its centre taps (wave shuffles + LDS),
 //   2. stages that window once — texel addressing (repeat / clamp) per texture.py:274-283 — in the bilinear
-//      "difference basis" of each texel cell, as float16 (byte differences are exact in f16):
+//      "difference basis" of each texel cell, as float32 (byte values and their differences are exact):
 //          A = T00,  B = T10 - T00,  C = T01 - T00,  D = T00 - T10 - T01 + T11        (per channel)
 //      so that a tap at fractional position (ax, ay) of the cell is  A + ax*B + ay*C + (ax*ay)*D ;
-//      32 bytes per cell: two ds_read_b128 per tap;
-//   3. runs the taps in tile-local texel coordinates: 2 fma (position), 2 v_fract, 2 v_cvt_i32 (the window origin
-//      makes positions non-negative, so truncation is floor), 2 address ops, 1 multiply and 12 v_fma_mix_f32
-//      (f16 texel term x f32 weight, f32 accumulate) = 21 VALU instructions per tap.
+//      48 bytes per cell: three ds_read_b128 per tap (a float16 cell with v_fma_mix_f32 was measured slower:
+//      v_fma_mix issues at half the rate of v_fma_f32 on gfx950, tools/ubench_valu.hip);
+//   3. runs the taps in tile-local texel coordinates: positions advance by VGPR adds, 2 v_fract, the LDS byte
+//      offset formed in float arithmetic and converted once, 1 weight product and 12 v_fma/v_add = 24 VALU
+//      instructions per tap.
 // Direction 8 of the float-counter loop coincides with direction 0 to 3e-9 texel (SURVEY.md §7 hard part 4), so
 // direction 0 is evaluated once and counted twice: 81 taps instead of 91.
 // Everything that depends on uniforms only (sin/cos of iTime, pow of the volume, …) is evaluated once per frame
@@ -29,12 +30,6 @@
 namespace sf {
 
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-
-#ifndef VIS_TILE_F32
-#define VIS_TILE_F32 1
-#endif
-
 __global__ void k_visualizer_consts(const FrameDyn* __restrict__ dyn, int frame0, int nframes, VisualizerConsts* __restrict__ out) {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= nframes) return;
@@ -42,7 +37,7 @@ __global__ void k_visualizer_consts(const FrameDyn* __restrict__ dyn, int frame0
     out[frame0 + k] = visualizer_consts(d.iTime, d.iAudioVolume, d.iAudioSTD);
 }
 
-// TILE_PITCH: cells per tile row (32 B each): 128 covers a 128-pixel block without supersampling, 80 is enough when
+// TILE_PITCH: cells per tile row (48 B each): 128 covers a 128-pixel block without supersampling, 80 is enough when
 // the block's 128 pixels are 2x or 4x supersampled (the window is then ~64 cells wide) and lets more blocks share a CU.
 template <int TILE_PITCH, int TILE_ROWS, int MIN_WAVES, int ROWS_PER_BLOCK = 1>
 struct VisualizerShader {
@@ -55,11 +50,7 @@ struct VisualizerShader {
         float xc, yc;                // centre tap in texel space (u*w - 0.5, v*h - 0.5)
     };
     struct Shared {
-#if VIS_TILE_F32
-        float4 tile[TILE_ROWS*TILE_PITCH*3];
-#else
-        half8 tile[TILE_ROWS*TILE_PITCH*2];
-#endif
+        float4 tile[TILE_ROWS*TILE_PITCH*3];   // 48-byte cells {Ar Ag Ab Br} {Bg Bb Cr Cg} {Cb Dr Dg Db}
         float red[5][16];
         VisualizerConsts consts;
         int x0, y0, tw, th, ok;
@@ -82,9 +73,20 @@ struct VisualizerShader {
         s.yc = st.y*(float)bg.height - 0.5f;
     }
 
+    // Minimum over the wave with DPP row operations (quad swaps, half-mirror, mirror, then the two row broadcasts):
+    // six v_min_f32_dpp and one v_readlane instead of six ds_bpermute round trips.
+    template <int CTRL, int ROW_MASK> __device__ __forceinline__ static float min_dpp(float v) {
+        const int moved = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+        return fminf(v, __int_as_float(moved));
+    }
     __device__ static float wave_min(float v) {
-        for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
-        return v;
+        v = min_dpp<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]
+        v = min_dpp<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]
+        v = min_dpp<0x141, 0xF>(v);      // row_half_mirror
+        v = min_dpp<0x140, 0xF>(v);      // row_mirror: every lane holds the minimum of its row of 16
+        v = min_dpp<0x142, 0xA>(v);      // row_bcast15 into rows 1 and 3
+        v = min_dpp<0x143, 0xC>(v);      // row_bcast31 into rows 2 and 3: lane 63 holds the wave minimum
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
     }
 
     template <int N>
@@ -105,6 +107,7 @@ struct VisualizerShader {
             }
         }
         lo_x = wave_min(lo_x); hi_x = wave_min(hi_x); lo_y = wave_min(lo_y); hi_y = wave_min(hi_y);
+        SF_TICK_INIT();
         const int n_bad = __syncthreads_count(bad ? 1 : 0);
         if ((tid & 63) == 0) { sh.red[0][wave] = lo_x; sh.red[1][wave] = hi_x; sh.red[2][wave] = lo_y; sh.red[3][wave] = hi_y; }
         __syncthreads();
@@ -127,49 +130,42 @@ struct VisualizerShader {
             sh.consts = c;
         }
         __syncthreads();
+        SF_TICK(a, 4);                               // window reduction incl. its barriers
         if (sh.ok != 1) return;
         // 2. stage the cells
         const int tw = sh.tw, th = sh.th, x0 = sh.x0, y0 = sh.y0;
         const uint8_t* data = (const uint8_t*)bg.data;
         const int comps = bg.components;
-        for (int idx = tid; idx < tw*th; idx += nthreads) {
-            const int ty = idx / tw, tx = idx - ty*tw;
+        // one thread per cell of the TILE_PITCH-wide grid (constant divisor); a texel is fetched with ONE unaligned
+        // 4-byte load (the allocation is padded, capi sfx_texture_create) and unpacked with v_cvt_f32_ubyteN
+        typedef uint32_t unaligned_u32 __attribute__((aligned(1)));
+        for (int idx = tid; idx < TILE_PITCH*th; idx += nthreads) {
+            const int ty = idx / TILE_PITCH, tx = idx - ty*TILE_PITCH;
+            if (tx >= tw) continue;
             const int j0 = wrap_texel(y0 + ty, bg.height, bg.repeat_y), j1 = wrap_texel(y0 + ty + 1, bg.height, bg.repeat_y);
             const int i0 = wrap_texel(x0 + tx, bg.width, bg.repeat_x), i1 = wrap_texel(x0 + tx + 1, bg.width, bg.repeat_x);
-            const uint8_t* p00 = data + ((long)j0*bg.width + i0)*comps;
-            const uint8_t* p10 = data + ((long)j0*bg.width + i1)*comps;
-            const uint8_t* p01 = data + ((long)j1*bg.width + i0)*comps;
-            const uint8_t* p11 = data + ((long)j1*bg.width + i1)*comps;
-#if VIS_TILE_F32
+            const uint32_t row0 = (uint32_t)j0*(uint32_t)bg.width, row1 = (uint32_t)j1*(uint32_t)bg.width;
+            const uint32_t w00 = *(const unaligned_u32*)(data + (size_t)(row0 + i0)*comps);
+            const uint32_t w10 = *(const unaligned_u32*)(data + (size_t)(row0 + i1)*comps);
+            const uint32_t w01 = *(const unaligned_u32*)(data + (size_t)(row1 + i0)*comps);
+            const uint32_t w11 = *(const unaligned_u32*)(data + (size_t)(row1 + i1)*comps);
             float4 q0, q1, q2;                                        // {Ar Ag Ab Br} {Bg Bb Cr Cg} {Cb Dr Dg Db}
             {
-                const int r00 = p00[0], r10 = p10[0], r01 = p01[0], r11 = p11[0];
-                const int g00 = p00[1], g10 = p10[1], g01 = p01[1], g11 = p11[1];
-                const int b00 = p00[2], b10 = p10[2], b01 = p01[2], b11 = p11[2];
-                q0 = make_float4((float)r00, (float)g00, (float)b00, (float)(r10 - r00));
-                q1 = make_float4((float)(g10 - g00), (float)(b10 - b00), (float)(r01 - r00), (float)(g01 - g00));
-                q2 = make_float4((float)(b01 - b00), (float)(r00 - r10 - r01 + r11), (float)(g00 - g10 - g01 + g11), (float)(b00 - b10 - b01 + b11));
+                // byte values and their differences are exact in binary32
+                const float r00 = (float)(w00 & 255u), g00 = (float)((w00 >> 8) & 255u), b00 = (float)((w00 >> 16) & 255u);
+                const float r10 = (float)(w10 & 255u), g10 = (float)((w10 >> 8) & 255u), b10 = (float)((w10 >> 16) & 255u);
+                const float r01 = (float)(w01 & 255u), g01 = (float)((w01 >> 8) & 255u), b01 = (float)((w01 >> 16) & 255u);
+                const float r11 = (float)(w11 & 255u), g11 = (float)((w11 >> 8) & 255u), b11 = (float)((w11 >> 16) & 255u);
+                q0 = make_float4(r00, g00, b00, r10 - r00);
+                q1 = make_float4(g10 - g00, b10 - b00, r01 - r00, g01 - g00);
+                q2 = make_float4(b01 - b00, (r00 - r10) - (r01 - r11), (g00 - g10) - (g01 - g11), (b00 - b10) - (b01 - b11));
             }
             float4* cell = sh.tile + (ty*TILE_PITCH + tx)*3;
             cell[0] = q0; cell[1] = q1; cell[2] = q2;
-#else
-            half8 lo, hi;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const int t00 = p00[ch], t10 = p10[ch], t01 = p01[ch], t11 = p11[ch];
-                const _Float16 A = (_Float16)(float)t00, B = (_Float16)(float)(t10 - t00);
-                const _Float16 C = (_Float16)(float)(t01 - t00), D = (_Float16)(float)(t00 - t10 - t01 + t11);
-                // lo = {Ar Ag Ab Br | Bg Bb Cr Cg}, hi = {Cb Dr Dg Db | 0 0 0 0}
-                if (ch == 0) { lo[0] = A; lo[3] = B; lo[6] = C; hi[1] = D; }
-                if (ch == 1) { lo[1] = A; lo[4] = B; lo[7] = C; hi[2] = D; }
-                if (ch == 2) { lo[2] = A; lo[5] = B; hi[0] = C; hi[3] = D; }
-            }
-            hi[4] = hi[5] = hi[6] = hi[7] = (_Float16)0.0f;
-            sh.tile[(ty*TILE_PITCH + tx)*2] = lo;
-            sh.tile[(ty*TILE_PITCH + tx)*2 + 1] = hi;
-#endif
         }
+        SF_TICK(a, 5);                               // staging (loads + conversion + LDS writes)
         __syncthreads();
+        SF_TICK(a, 6);                               // barrier after staging
     }
 
     // One bilinear tap from the staged cells: value = A + ax*B + ay*C + (ax*ay)*D per channel.
@@ -177,11 +173,11 @@ struct VisualizerShader {
     // everything else (v_fract, v_cvt, shifts, v_fma_mix, any VALU with an SGPR operand) 4 cycles — so the float32
     // tile (12 plain fma/add = 24 cycles) beats the float16 tile (12 v_fma_mix = 48 cycles) although it reads 48
     // instead of 32 bytes of LDS per tap, and every per-tap operand is kept in VGPRs.
-#if VIS_TILE_F32
-    __device__ __forceinline__ static void tap(const float4* tile, float x, float y, float, float& r, float& g, float& b) {
+    __device__ __forceinline__ static void tap(const float4* tile, float x, float y, float& r, float& g, float& b) {
         const float ax = __builtin_amdgcn_fractf(x), ay = __builtin_amdgcn_fractf(y);
         // byte offset of the cell, in float arithmetic (exact: < 2^24) so that only ONE conversion is needed:
-        // (floor(y)*PITCH + floor(x))*48; x, y >= 0 inside the staged window
+        // (floor(y)*PITCH + floor(x))*48; x, y >= 0 inside the staged window. (Carrying the offset along with the
+        // position — one more add, two fewer ops — was measured: 32 fewer VALU per wave, same time.)
         const float cell = fmaf(y - ay, (float)(TILE_PITCH*48), (x - ax)*48.0f);
         const float4* p = (const float4*)((const char*)tile + (unsigned)cell);
         const float4 q0 = p[0], q1 = p[1], q2 = p[2];
@@ -191,20 +187,6 @@ struct VisualizerShader {
         r = fmaf(ay, q1.z, r);  g = fmaf(ay, q1.w, g);  b = fmaf(ay, q2.x, b);
         r = fmaf(axy, q2.y, r); g = fmaf(axy, q2.z, g); b = fmaf(axy, q2.w, b);
     }
-#else
-    __device__ __forceinline__ static void tap(const half8* tile, float x, float y, float one, float& r, float& g, float& b) {
-        const float ax = __builtin_amdgcn_fractf(x), ay = __builtin_amdgcn_fractf(y);
-        const int ix = (int)x, iy = (int)y;                           // x, y >= 0 inside the staged window
-        const half8* p = tile + (iy*TILE_PITCH + ix)*2;
-        const half8 lo = p[0], hi = p[1];
-        const float axy = ax*ay;
-        // `one` is 1.0f passed through the kernel arguments: opaque to the optimiser, so the A term stays ONE v_fma_mix_f32
-        r = fmaf(one, (float)lo[0], r); g = fmaf(one, (float)lo[1], g); b = fmaf(one, (float)lo[2], b);
-        r = fmaf(ax, (float)lo[3], r);   g = fmaf(ax, (float)lo[4], g);   b = fmaf(ax, (float)lo[5], b);
-        r = fmaf(ay, (float)lo[6], r);   g = fmaf(ay, (float)lo[7], g);   b = fmaf(ay, (float)hi[0], b);
-        r = fmaf(axy, (float)hi[1], r);  g = fmaf(axy, (float)hi[2], g);  b = fmaf(axy, (float)hi[3], b);
-    }
-#endif
 
     __device__ static vec4 blur_tile(const RenderArgs& a, const Tex& bg, const State& s, const Shared& sh) {
         const float xr = s.xc - (float)sh.x0, yr = s.yc - (float)sh.y0;
@@ -220,12 +202,12 @@ struct VisualizerShader {
             float x = fmaf(a.tap_x[d*10], ax, xr), y = fmaf(a.tap_y[d*10], ay, yr);
 #pragma unroll
             for (int w = 0; w < 10; w++) {
-                tap(sh.tile, x, y, a.one, r, g, b);
+                tap(sh.tile, x, y, r, g, b);
                 x = x + sx; y = y + sy;
             }
             if (d == 0) { r = r*2.0f; g = g*2.0f; b = b*2.0f; }     // direction 8 == direction 0
         }
-        tap(sh.tile, xr, yr, a.one, r, g, b);                        // centre tap (:19)
+        tap(sh.tile, xr, yr, r, g, b);                               // centre tap (:19)
         // (sum/255)/(quality*directions) (:32) as one multiplication: part of this path's re-association (≤ 1 ulp)
         const float norm = 1.0f/(255.0f*10.0f*8.0f);
         return {r*norm, g*norm, b*norm, 91.0f/80.0f};
@@ -241,12 +223,18 @@ struct VisualizerShader {
 #if defined(VIS_ABLATE_BLUR)
         vec4 blurred = {s.xc*1e-3f, s.yc*1e-3f, 0.5f, 1.0f};             // ablation builds only (tools/variants.sh)
 #else
+        SF_TICK_INIT();
         vec4 blurred = (sh.ok == 1) ? blur_tile(a, bg, s, sh) : visualizer_blur_reference(f, s.pre, c);
+        SF_TICK(a, 7);                               // blur only
 #endif
 #if defined(VIS_ABLATE_POST)
         return blurred;
 #else
-        return visualizer_post(f, s.pre, c, blurred);
+#ifndef VIS_EXACT_POST
+        return visualizer_post<true>(f, s.pre, c, blurred);
+#else
+        return visualizer_post<false>(f, s.pre, c, blurred);
+#endif
 #endif
     }
 };
