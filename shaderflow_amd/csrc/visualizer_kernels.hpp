@@ -16,6 +16,8 @@
 //      instructions per tap.
 // Direction 8 of the float-counter loop coincides with direction 0 to 3e-9 texel (SURVEY.md §7 hard part 4), so
 // direction 0 is evaluated once and counted twice: 81 taps instead of 91.
+// The four axis-aligned directions are summed one texel cell at a time (runs_axis): the ten equally spaced taps of
+// such a direction cross at most ceil(9*step) cell boundaries, and inside a cell their sum has a closed form.
 // Everything that depends on uniforms only (sin/cos of iTime, pow of the volume, …) is evaluated once per frame
 // (k_visualizer_consts, or by the host for single launches) instead of once per supersample.
 //
@@ -115,8 +117,9 @@ struct VisualizerShader {
             float m[4];
             for (int k = 0; k < 4; k++) { m[k] = sh.red[k][0]; for (int w = 1; w < nwaves; w++) m[k] = fminf(m[k], sh.red[k][w]); }
             // tap radius in texels: |cos|,|sin| <= 1, walk <= 1.0000001 (visualizer.frag:26-28)
-            const float rx = fabsf(c.intensity*((float)bg.height/(float)bg.width)*(float)bg.width)*1.001f + 0.001f;
-            const float ry = fabsf(c.intensity*(float)bg.height)*1.001f + 0.001f;
+            // + one step (0.1 of the radius): runs_axis leaves its position one step past the last tap
+            const float rx = fabsf(c.intensity*((float)bg.height/(float)bg.width)*(float)bg.width)*1.101f + 0.001f;
+            const float ry = fabsf(c.intensity*(float)bg.height)*1.101f + 0.001f;
             int ok = 0, x0 = 0, y0 = 0, tw = 0, th = 0;
             if (n_bad == 0 && m[0] < INFINITY && rx < 64.0f && ry < 64.0f) {
                 x0 = (int)floorf(m[0] - rx); y0 = (int)floorf(m[2] - ry);
@@ -188,6 +191,38 @@ struct VisualizerShader {
         r = fmaf(axy, q2.y, r); g = fmaf(axy, q2.z, g); b = fmaf(axy, q2.w, b);
     }
 
+    // The ten taps of an axis-aligned direction, one texel cell at a time. Inside a cell the bilinear basis is fixed and
+    // the taps m_j = m + j*s are equally spaced, so a run of n taps sums to
+    //     n*A + S*B' + (n*f)*C' + (S*f)*D,   S = sum_j fract(m_j) = n*(a + s*(n-1)/2),
+    // (B', C' = the moving / fixed axis terms, f = the fixed fraction): ONE cell fetch and 12 fma per run instead of
+    // per tap. n = min(taps left, floor(t) + 1) with t = (1 - a)/s for s > 0 and a/|s| for s < 0 — the number of
+    // steps that stay inside the cell. A tap within rounding distance of a cell boundary may be counted on either
+    // side: the bilinear surface is continuous there, so the sum moves by ~1e-7. At most 1 + ceil(9|s|) runs are
+    // needed (the loop bound is wave-uniform); the tail loop only runs if rounding split a run.
+    template <bool ALONG_X>
+    __device__ __forceinline__ static void runs_axis(const float4* tile, float m, float s, float f, float fixed_offset, float& r, float& g, float& b) {
+        const float inv = fminf(__builtin_amdgcn_rcpf(fabsf(s)), 1.0e6f);          // s == 0: every tap in the first cell
+        const float k1 = (s > 0.0f) ? -inv : inv, k0 = (s > 0.0f) ? inv : 0.0f;     // t = k0 + a*k1
+        const float hs = 0.5f*s;
+        const int bound = __builtin_amdgcn_readfirstlane(1 + (int)ceilf(9.0f*fabsf(s) + 1.0e-3f));
+        float left = 10.0f;
+        for (int it = 0; it < bound || __any(left > 0.0f); it++) {
+            const float a = __builtin_amdgcn_fractf(m);
+            const float cell = fmaf(m - a, ALONG_X ? 48.0f : (float)(TILE_PITCH*48), fixed_offset);
+            const float4* p = (const float4*)((const char*)tile + (unsigned)cell);
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+            const float n = fminf(floorf(fmaf(a, k1, k0)) + 1.0f, left);
+            left = left - n;
+            const float sum = n*(a + fmaf(n, hs, -hs));
+            const float wx = ALONG_X ? sum : n*f, wy = ALONG_X ? n*f : sum, wxy = sum*f;
+            r = fmaf(n, q0.x, r);    g = fmaf(n, q0.y, g);    b = fmaf(n, q0.z, b);
+            r = fmaf(wx, q0.w, r);   g = fmaf(wx, q1.x, g);   b = fmaf(wx, q1.y, b);
+            r = fmaf(wy, q1.z, r);   g = fmaf(wy, q1.w, g);   b = fmaf(wy, q2.x, b);
+            r = fmaf(wxy, q2.y, r);  g = fmaf(wxy, q2.z, g);  b = fmaf(wxy, q2.w, b);
+            m = fmaf(n, s, m);
+        }
+    }
+
     __device__ static vec4 blur_tile(const RenderArgs& a, const Tex& bg, const State& s, const Shared& sh) {
         const float xr = s.xc - (float)sh.x0, yr = s.yc - (float)sh.y0;
         // displacement of tap k in texels: d_k * intensity * (scale.x*w, h)   (glsl.hpp gtexture)
@@ -196,14 +231,21 @@ struct VisualizerShader {
         float r = 0.0f, g = 0.0f, b = 0.0f;
         // Taps of one direction are (up to 1e-7 relative) an arithmetic progression: walk = 0.1, 0.2, … (:27); stepping
         // with VGPR adds keeps the position update on the 2-cycle path (an fma with the SGPR table entry costs 4).
+        // Directions 0/4 and 2/6 run along a texel row / column: their cross-axis displacement is |cos(k*TAU/4)| <= 2e-7
+        // of the radius (< 1e-6 texel), which is dropped so that the fixed coordinate is decomposed once per direction.
+        const float fy = __builtin_amdgcn_fractf(yr), fx = __builtin_amdgcn_fractf(xr);
+        const float row_offset = (yr - fy)*(float)(TILE_PITCH*48), column_offset = (xr - fx)*48.0f;
 #pragma unroll 1
         for (int d = 0; d < 8; d++) {
             const float sx = (a.tap_x[d*10 + 1] - a.tap_x[d*10])*ax, sy = (a.tap_y[d*10 + 1] - a.tap_y[d*10])*ay;
             float x = fmaf(a.tap_x[d*10], ax, xr), y = fmaf(a.tap_y[d*10], ay, yr);
+            if ((d & 3) == 0) {                                       // 0 and 180 degrees
+                runs_axis<true>(sh.tile, x, sx, fy, row_offset, r, g, b);
+            } else if ((d & 3) == 2) {                                // 90 and 270 degrees
+                runs_axis<false>(sh.tile, y, sy, fx, column_offset, r, g, b);
+            } else {
 #pragma unroll
-            for (int w = 0; w < 10; w++) {
-                tap(sh.tile, x, y, r, g, b);
-                x = x + sx; y = y + sy;
+                for (int w = 0; w < 10; w++) { tap(sh.tile, x, y, r, g, b); x = x + sx; y = y + sy; }
             }
             if (d == 0) { r = r*2.0f; g = g*2.0f; b = b*2.0f; }     // direction 8 == direction 0
         }
