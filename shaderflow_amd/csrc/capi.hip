@@ -462,6 +462,7 @@ static void fill_args(const Program* p, RenderArgs& a) {
     a.vis_consts = nullptr;
     a.aspect = p->u.iResolution[0]/p->u.iResolution[1];
     a.identity_camera = camera_is_identity(p->u) ? 1 : 0;
+    a.bg_scale_x = a.tex[TEX_BACKGROUND].data ? (float)a.tex[TEX_BACKGROUND].height/(float)a.tex[TEX_BACKGROUND].width : 1.0f;
     a.top_down = p->ctx->top_down;
 }
 

@@ -40,6 +40,7 @@ struct RenderArgs {
     int has_vis;
     int identity_camera;             // glsl.hpp camera_is_identity(u): iCamera.gluv == gluv exactly
     float aspect;                    // iResolution.x/iResolution.y (iAspectRatio, shaderflow.glsl:16), divided once on the host
+    float bg_scale_x;                // background.height/background.width (gtexture, shaderflow.glsl:166-167), divided once on the host
     int top_down;                    // K9: write the RGB8 frame rows top-down (the encoder's `vflip`, exporting.py:103, done here)
 #ifdef SF_SECTION_TIMERS
     unsigned long long* timers;      // profiling builds (tools/variants.sh): per-section shader-clock sums, see SF_TICK
@@ -108,7 +109,7 @@ template <int FRAGMENT> struct PlainShader {
     struct State {};
     struct Shared {};
     __device__ static void pre(const RenderArgs&, const Frag&, bool, State&) {}
-    template <int N> __device__ static void setup(const RenderArgs&, const Tex*, const Frag&, State (&)[N], const bool (&)[N], Shared&) {}
+    template <int N> __device__ static void setup(const RenderArgs&, const Tex*, const Frag&, State (&)[N], const bool (&)[N], Shared&, int) {}
     __device__ static vec4 run(const RenderArgs&, const Frag& f, const State&, const Shared&) { return shade<FRAGMENT>(f); }
 };
 
@@ -126,7 +127,10 @@ __global__ __launch_bounds__(256) void k_render(const RenderArgs a) {
     typename SHADER::State state[1];
     const bool valid[1] = {inside};
     SHADER::pre(a, f, inside, state[0]);
-    SHADER::template setup<1>(a, tex, f, state, valid, shared);
+    // the thread that owns the block's last valid pixel (thread 0 owns the first): corner samples for monotone shaders
+    const int i_last = min((int)(blockIdx.x + 1)*SHADER::BLOCK_W, a.wr) - 1 - (int)blockIdx.x*SHADER::BLOCK_W;
+    const int j_last = min((int)(blockIdx.y + 1)*SHADER::BLOCK_H, a.hr) - 1 - (int)blockIdx.y*SHADER::BLOCK_H;
+    SHADER::template setup<1>(a, tex, f, state, valid, shared, j_last*SHADER::BLOCK_W + i_last);
     if (inside) store_target(a, blockIdx.z, i, j, SHADER::run(a, f, state[0], shared));
 }
 
@@ -285,7 +289,10 @@ __global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_reso
         SHADER::pre(a, f, valid[n], state[n]);
     }
     SF_TICK(a, 0);                                   // varyings + pre
-    SHADER::template setup<PER_LANE>(a, tex, f, state, valid, shared);
+    // the thread whose LAST sample is the block's top-right valid supersample (thread 0's first one is the bottom-left)
+    const int p_last = min(127, a.w - 1 - bx*128);
+    const int corner_tid = (S == 1) ? min(1, a.h - 1 - by*2)*128 + p_last : p_last*LANES + (LANES - 1);
+    SHADER::template setup<PER_LANE>(a, tex, f, state, valid, shared, corner_tid);
     SF_TICK(a, 1);                                   // setup (window reduction + LDS staging)
 #pragma unroll
     for (int n = 0; n < PER_LANE; n++) {

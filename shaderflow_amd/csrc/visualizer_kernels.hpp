@@ -69,7 +69,7 @@ struct VisualizerShader {
         s.pre = visualizer_pre(f, c, a.identity_camera != 0);
         const Tex& bg = f.tex[TEX_BACKGROUND];
         // same chain as stexture() → texture() for the centre tap (glsl.hpp)
-        vec2 scale = {(float)bg.height/(float)bg.width, 1.0f};
+        vec2 scale = {a.bg_scale_x, 1.0f};                           // (float)bg.height/(float)bg.width, the same division on the host
         vec2 st = gluv2stuv(stuv2gluv(s.pre.bg)*scale);
         s.xc = st.x*(float)bg.width - 0.5f;
         s.yc = st.y*(float)bg.height - 0.5f;
@@ -92,12 +92,35 @@ struct VisualizerShader {
     }
 
     template <int N>
-    __device__ static void setup(const RenderArgs& a, const Tex* tex, const Frag& f, State (&s)[N], const bool (&valid)[N], Shared& sh) {
+    __device__ static void setup(const RenderArgs& a, const Tex* tex, const Frag& f, State (&s)[N], const bool (&valid)[N], Shared& sh, int corner_tid) {
         const Tex& bg = tex[TEX_BACKGROUND];
         const int tid = threadIdx.y*blockDim.x + threadIdx.x, nthreads = blockDim.x*blockDim.y;
         const int wave = tid >> 6, nwaves = (nthreads + 63) >> 6;
         const VisualizerConsts c = frame_consts(a, f);
-        // 1. bounding box of the centre taps (as minima of x, -x, y, -y)
+        // tap radius in texels: |cos|,|sin| <= 1, walk <= 1.0000001 (visualizer.frag:26-28), + one step (0.1 of the
+        // radius): the run loops leave their position one step past the last tap
+        const float rx = fabsf(c.intensity*a.bg_scale_x*(float)bg.width)*1.101f + 0.001f;
+        const float ry = fabsf(c.intensity*(float)bg.height)*1.101f + 0.001f;
+        SF_TICK_INIT();
+        int ok = 0, x0 = 0, y0 = 0, tw = 0, th = 0;                  // block-uniform window [x0, x0+tw) x [y0, y0+th)
+        if (a.identity_camera) {
+            // 1a. With the identity camera the centre tap is a monotone (non-decreasing, rounding included) function of the
+            // pixel column for x and of the pixel row for y, so the block's two corner samples bound all of them: no
+            // reduction, one barrier, and every thread derives the window itself.
+            if (tid == 0) { sh.red[0][0] = s[0].xc; sh.red[0][1] = s[0].yc; }
+            if (tid == corner_tid) { sh.red[1][0] = s[N - 1].xc; sh.red[1][1] = s[N - 1].yc; }
+            __syncthreads();
+            const float x_lo = fminf(sh.red[0][0], sh.red[1][0]), x_hi = fmaxf(sh.red[0][0], sh.red[1][0]);
+            const float y_lo = fminf(sh.red[0][1], sh.red[1][1]), y_hi = fmaxf(sh.red[0][1], sh.red[1][1]);
+            if ((c.intensity == c.intensity) && fabsf(x_lo) < 1e8f && fabsf(x_hi) < 1e8f && fabsf(y_lo) < 1e8f && fabsf(y_hi) < 1e8f && rx < 64.0f && ry < 64.0f) {
+                x0 = (int)floorf(x_lo - rx); y0 = (int)floorf(y_lo - ry);
+                tw = (int)floorf(x_hi + rx) - x0 + 1;
+                th = (int)floorf(y_hi + ry) - y0 + 1;
+                ok = (tw <= TILE_PITCH) && (th <= TILE_ROWS);
+            }
+            if (tid == 0) { sh.x0 = x0; sh.y0 = y0; sh.ok = ok; sh.consts = c; }      // read by run() after the staging barrier
+        } else {
+        // 1b. bounding box of the centre taps (as minima of x, -x, y, -y)
         float lo_x = INFINITY, hi_x = INFINITY, lo_y = INFINITY, hi_y = INFINITY;
         bool bad = !(c.intensity == c.intensity);
 #pragma unroll
@@ -109,18 +132,12 @@ struct VisualizerShader {
             }
         }
         lo_x = wave_min(lo_x); hi_x = wave_min(hi_x); lo_y = wave_min(lo_y); hi_y = wave_min(hi_y);
-        SF_TICK_INIT();
         const int n_bad = __syncthreads_count(bad ? 1 : 0);
         if ((tid & 63) == 0) { sh.red[0][wave] = lo_x; sh.red[1][wave] = hi_x; sh.red[2][wave] = lo_y; sh.red[3][wave] = hi_y; }
         __syncthreads();
         if (tid == 0) {
             float m[4];
             for (int k = 0; k < 4; k++) { m[k] = sh.red[k][0]; for (int w = 1; w < nwaves; w++) m[k] = fminf(m[k], sh.red[k][w]); }
-            // tap radius in texels: |cos|,|sin| <= 1, walk <= 1.0000001 (visualizer.frag:26-28)
-            // + one step (0.1 of the radius): runs_axis leaves its position one step past the last tap
-            const float rx = fabsf(c.intensity*((float)bg.height/(float)bg.width)*(float)bg.width)*1.101f + 0.001f;
-            const float ry = fabsf(c.intensity*(float)bg.height)*1.101f + 0.001f;
-            int ok = 0, x0 = 0, y0 = 0, tw = 0, th = 0;
             if (n_bad == 0 && m[0] < INFINITY && rx < 64.0f && ry < 64.0f) {
                 x0 = (int)floorf(m[0] - rx); y0 = (int)floorf(m[2] - ry);
                 tw = (int)floorf(-m[1] + rx) - x0 + 1;                // cells [x0, x0+tw) hold every tap's floor()
@@ -133,10 +150,11 @@ struct VisualizerShader {
             sh.consts = c;
         }
         __syncthreads();
-        SF_TICK(a, 4);                               // window reduction incl. its barriers
-        if (sh.ok != 1) return;
+        ok = sh.ok; x0 = sh.x0; y0 = sh.y0; tw = sh.tw; th = sh.th;
+        }
+        SF_TICK(a, 4);                               // window (incl. its barriers)
+        if (ok != 1) { __syncthreads(); return; }    // sh.ok is read by run(): publish it like the staged path does
         // 2. stage the cells
-        const int tw = sh.tw, th = sh.th, x0 = sh.x0, y0 = sh.y0;
         const uint8_t* data = (const uint8_t*)bg.data;
         const int comps = bg.components;
         // one thread per cell of the TILE_PITCH-wide grid (constant divisor); a texel is fetched with ONE unaligned
@@ -176,6 +194,17 @@ struct VisualizerShader {
     // everything else (v_fract, v_cvt, shifts, v_fma_mix, any VALU with an SGPR operand) 4 cycles — so the float32
     // tile (12 plain fma/add = 24 cycles) beats the float16 tile (12 v_fma_mix = 48 cycles) although it reads 48
     // instead of 32 bytes of LDS per tap, and every per-tap operand is kept in VGPRs.
+    // the lerp of one tap whose cell offset (bytes, exact in float) and fractions are known
+    __device__ __forceinline__ static void tap_at(const float4* tile, float cell, float ax, float ay, float& r, float& g, float& b) {
+        const float4* p = (const float4*)((const char*)tile + (unsigned)cell);
+        const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+        const float axy = ax*ay;
+        r = r + q0.x;           g = g + q0.y;           b = b + q0.z;
+        r = fmaf(ax, q0.w, r);  g = fmaf(ax, q1.x, g);  b = fmaf(ax, q1.y, b);
+        r = fmaf(ay, q1.z, r);  g = fmaf(ay, q1.w, g);  b = fmaf(ay, q2.x, b);
+        r = fmaf(axy, q2.y, r); g = fmaf(axy, q2.z, g); b = fmaf(axy, q2.w, b);
+    }
+
     __device__ __forceinline__ static void tap(const float4* tile, float x, float y, float& r, float& g, float& b) {
         const float ax = __builtin_amdgcn_fractf(x), ay = __builtin_amdgcn_fractf(y);
         // byte offset of the cell, in float arithmetic (exact: < 2^24) so that only ONE conversion is needed:
@@ -223,11 +252,48 @@ struct VisualizerShader {
         }
     }
 
+    // One run of one axis direction: state (m = position of the next tap, left = taps left); see runs_axis.
+    template <bool ALONG_X>
+    __device__ __forceinline__ static void one_run(const float4* tile, float& m, float& left, float s, float k0, float k1, float hs,
+                                                   float f, float fixed_offset, float weight, float& r, float& g, float& b) {
+        const float a = __builtin_amdgcn_fractf(m);
+        const float cell = fmaf(m - a, ALONG_X ? 48.0f : (float)(TILE_PITCH*48), fixed_offset);
+        const float4* p = (const float4*)((const char*)tile + (unsigned)cell);
+        const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+        const float n = fminf(floorf(fmaf(a, k1, k0)) + 1.0f, left);
+        left = left - n;
+        m = fmaf(n, s, m);
+        const float nw = n*weight;
+        const float sum = nw*(a + fmaf(n, hs, -hs));
+        const float wx = ALONG_X ? sum : nw*f, wy = ALONG_X ? nw*f : sum, wxy = sum*f;
+        r = fmaf(nw, q0.x, r);   g = fmaf(nw, q0.y, g);   b = fmaf(nw, q0.z, b);
+        r = fmaf(wx, q0.w, r);   g = fmaf(wx, q1.x, g);   b = fmaf(wx, q1.y, b);
+        r = fmaf(wy, q1.z, r);   g = fmaf(wy, q1.w, g);   b = fmaf(wy, q2.x, b);
+        r = fmaf(wxy, q2.y, r);  g = fmaf(wxy, q2.z, g);  b = fmaf(wxy, q2.w, b);
+    }
+
+    // The four axis-aligned directions together: every loop iteration advances each of them by one run, which gives the
+    // scheduler four independent dependency chains and one loop test. `step` > 0 is the common |step| (texels per tap),
+    // `first` the offset of the first tap; direction 0 (+x) carries weight 2 (direction 8 == direction 0).
+    __device__ __forceinline__ static void runs_axes(const float4* tile, float xr, float yr, float first, float step, float fx, float fy,
+                                                     float row_offset, float column_offset, float& r, float& g, float& b) {
+        const float inv = fminf(__builtin_amdgcn_rcpf(step), 1.0e6f);
+        const float hs = 0.5f*step;
+        const int bound = __builtin_amdgcn_readfirstlane(1 + (int)ceilf(9.0f*step + 1.0e-3f));
+        float m0 = xr + first, m1 = yr + first, m2 = xr - first, m3 = yr - first;
+        float l0 = 10.0f, l1 = 10.0f, l2 = 10.0f, l3 = 10.0f;
+        for (int it = 0; it < bound || __any((l0 + l1) + (l2 + l3) > 0.0f); it++) {
+            one_run<true>(tile, m0, l0, step, inv, -inv, hs, fy, row_offset, 2.0f, r, g, b);
+            one_run<false>(tile, m1, l1, step, inv, -inv, hs, fx, column_offset, 1.0f, r, g, b);
+            one_run<true>(tile, m2, l2, -step, 0.0f, inv, -hs, fy, row_offset, 1.0f, r, g, b);
+            one_run<false>(tile, m3, l3, -step, 0.0f, inv, -hs, fx, column_offset, 1.0f, r, g, b);
+        }
+    }
+
     __device__ static vec4 blur_tile(const RenderArgs& a, const Tex& bg, const State& s, const Shared& sh) {
         const float xr = s.xc - (float)sh.x0, yr = s.yc - (float)sh.y0;
         // displacement of tap k in texels: d_k * intensity * (scale.x*w, h)   (glsl.hpp gtexture)
-        const float ax = sh.consts.intensity*((float)bg.height/(float)bg.width)*(float)bg.width;
-        const float ay = sh.consts.intensity*(float)bg.height;
+        const float ax = sh.consts.intensity*a.bg_scale_x*(float)bg.width;
         float r = 0.0f, g = 0.0f, b = 0.0f;
         // Taps of one direction are (up to 1e-7 relative) an arithmetic progression: walk = 0.1, 0.2, … (:27); stepping
         // with VGPR adds keeps the position update on the 2-cycle path (an fma with the SGPR table entry costs 4).
@@ -235,19 +301,40 @@ struct VisualizerShader {
         // of the radius (< 1e-6 texel), which is dropped so that the fixed coordinate is decomposed once per direction.
         const float fy = __builtin_amdgcn_fractf(yr), fx = __builtin_amdgcn_fractf(xr);
         const float row_offset = (yr - fy)*(float)(TILE_PITCH*48), column_offset = (xr - fx)*48.0f;
-#pragma unroll 1
-        for (int d = 0; d < 8; d++) {
-            const float sx = (a.tap_x[d*10 + 1] - a.tap_x[d*10])*ax, sy = (a.tap_y[d*10 + 1] - a.tap_y[d*10])*ay;
-            float x = fmaf(a.tap_x[d*10], ax, xr), y = fmaf(a.tap_y[d*10], ay, yr);
-            if ((d & 3) == 0) {                                       // 0 and 180 degrees
-                runs_axis<true>(sh.tile, x, sx, fy, row_offset, r, g, b);
-            } else if ((d & 3) == 2) {                                // 90 and 270 degrees
-                runs_axis<false>(sh.tile, y, sy, fx, column_offset, r, g, b);
-            } else {
-#pragma unroll
-                for (int w = 0; w < 10; w++) { tap(sh.tile, x, y, r, g, b); x = x + sx; y = y + sy; }
+#ifdef VIS_AXIS_SEQUENTIAL
+        // axis-aligned directions: closed-form runs; direction 0 counts twice (direction 8 == direction 0)
+        runs_axis<true>(sh.tile, fmaf(a.tap_x[0], ax, xr), (a.tap_x[1] - a.tap_x[0])*ax, fy, row_offset, r, g, b);
+        r = r*2.0f; g = g*2.0f; b = b*2.0f;
+        runs_axis<false>(sh.tile, fmaf(a.tap_y[20], ay, yr), (a.tap_y[21] - a.tap_y[20])*ay, fx, column_offset, r, g, b);
+        runs_axis<true>(sh.tile, fmaf(a.tap_x[40], ax, xr), (a.tap_x[41] - a.tap_x[40])*ax, fy, row_offset, r, g, b);
+        runs_axis<false>(sh.tile, fmaf(a.tap_y[60], ay, yr), (a.tap_y[61] - a.tap_y[60])*ay, fx, column_offset, r, g, b);
+#else
+        // axis-aligned directions: closed-form runs, the four directions interleaved (the two axes have the same texel
+        // scale up to 1 ulp, see below)
+        runs_axes(sh.tile, xr, yr, a.tap_x[0]*ax, (a.tap_x[1] - a.tap_x[0])*ax, fx, fy, row_offset, column_offset, r, g, b);
+#endif
+        // The four diagonal directions walk (+-k*s, +-k*s) from the centre (|cos| and |sin| of 45 degrees agree to 1 ulp,
+        // and so do the texel scales of the two axes: differences below 1e-6 texel are dropped): at every walk step
+        // the four taps share two x and two y coordinates, so two fractions and two cell offsets per axis serve all four.
+        {
+            constexpr float ROW = (float)(TILE_PITCH*48);
+            const float step = (a.tap_x[11] - a.tap_x[10])*ax, first = a.tap_x[10]*ax;      // direction 1 = 45 degrees: both positive
+            float xp = xr + first, xm = xr - first, yp = yr + first, ym = yr - first;
+#ifndef VIS_DIAG_UNROLL
+#define VIS_DIAG_UNROLL 1
+#endif
+#pragma unroll VIS_DIAG_UNROLL
+            for (int w = 0; w < 10; w++) {
+                const float axp = __builtin_amdgcn_fractf(xp), axm = __builtin_amdgcn_fractf(xm);
+                const float ayp = __builtin_amdgcn_fractf(yp), aym = __builtin_amdgcn_fractf(ym);
+                const float cxp = (xp - axp)*48.0f, cxm = (xm - axm)*48.0f;
+                const float ryp = (yp - ayp)*ROW, rym = (ym - aym)*ROW;
+                tap_at(sh.tile, cxp + ryp, axp, ayp, r, g, b);       // 45
+                tap_at(sh.tile, cxm + ryp, axm, ayp, r, g, b);       // 135
+                tap_at(sh.tile, cxm + rym, axm, aym, r, g, b);       // 225
+                tap_at(sh.tile, cxp + rym, axp, aym, r, g, b);       // 315
+                xp = xp + step; xm = xm - step; yp = yp + step; ym = ym - step;
             }
-            if (d == 0) { r = r*2.0f; g = g*2.0f; b = b*2.0f; }     // direction 8 == direction 0
         }
         tap(sh.tile, xr, yr, r, g, b);                               // centre tap (:19)
         // (sum/255)/(quality*directions) (:32) as one multiplication: part of this path's re-association (≤ 1 ulp)
