@@ -214,7 +214,7 @@ def main() -> None:
         lane_ops = samples_per_s*PROFILE["valu_instr_per_supersample"]
         c3 = (w, h, s) == (3840, 2160, 2) and args.scene == "visualizer"
         result = {
-            "metric": "frames/sec at 4K 2xSSAA music-visualizer" if args.scene == "visualizer" else f"frames/sec {args.scene}",
+            "metric": "frames/sec at 4K 2xSSAA music-visualizer" if c3 else f"frames/sec {args.scene} {w}x{h} {s}xSSAA",
             "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed/args.steps*1e3, 3),

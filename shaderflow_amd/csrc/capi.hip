@@ -587,6 +587,8 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
         case FRAG_VISUALIZER:
             if (!force_generic && visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) {
                 if (ssaa == 1) return launch_fused_s<VisualizerShader<128, 10, 1>>(a, ssaa, frames, s);
+                // four samples per lane need more registers: 6 waves per SIMD without spills beat 8 with (8K 4xSSAA: 55 -> 63 frames/s)
+                if (ssaa == 4) return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, 6, VIS_FUSED_ROWS>>(a, ssaa, frames, s);
                 return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_SS, VIS_FUSED_ROWS>>(a, ssaa, frames, s);
             }
             return launch_fused_s<PlainShader<FRAG_VISUALIZER>>(a, ssaa, frames, s);

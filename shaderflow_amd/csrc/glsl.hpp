@@ -141,7 +141,8 @@ SF_HD vec2 texture_xy(const Tex& t, vec2 uv) {
     float a = ub - fu, b = vb - fv;
     int i0 = wrap_texel((int)fu, t.width, t.repeat_x), i1 = wrap_texel((int)fu + 1, t.width, t.repeat_x);
     int j0 = wrap_texel((int)fv, t.height, t.repeat_y), j1 = wrap_texel((int)fv + 1, t.height, t.repeat_y);
-    vec2 t00 = texel_xy(t, i0, j0), t10 = texel_xy(t, i1, j0), t01 = texel_xy(t, i0, j1), t11 = texel_xy(t, i1, j1);
+    vec2 t00 = texel_xy(t, i0, j0), t10 = texel_xy(t, i1, j0), t01 = t00, t11 = t10;
+    if (j1 != j0) { t01 = texel_xy(t, i0, j1); t11 = texel_xy(t, i1, j1); }      // one-row textures (iWaveform): both rows are row 0
     float na = 1.0f - a, nb = 1.0f - b;
     float w00 = na*nb, w10 = a*nb, w01 = na*b, w11 = a*b;
     return {bilerp(w00, w10, w01, w11, t00.x, t10.x, t01.x, t11.x), bilerp(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y)};
