@@ -186,6 +186,9 @@ typedef struct {
 } sfx_tape_desc;
 
 int sfx_tape_create(sfx_handle plan, sfx_handle audio, const sfx_tape_desc* desc, int max_frames, sfx_handle* tape);
+/* A tape for scenes without audio modules: only the frame clock (iTime, iTau, iFrame) varies between the frames of a batch;
+ * built with sfx_tape_build(tape, n, NULL, clock, NULL, NULL, NULL), rendered with sfx_render_tape (scene.py:456-479 per frame). */
+int sfx_clock_tape_create(sfx_handle ctx, int max_frames, sfx_handle* tape);
 int sfx_tape_reset(sfx_handle tape);         /* ShaderDynamics.setup → reset (dynamics.py:273-274)  */
 /* Computes frames [0, nframes) of the tape from the running dynamics state (continues across calls). */
 int sfx_tape_build(sfx_handle tape, int nframes, const int64_t* tell, const sfx_frame_clock* clock,

@@ -94,6 +94,7 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_waveform_rows": (C.c_int, [Handle, P(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]),
     "sfx_volume_std": (C.c_int, [Handle, P(C.c_int64), C.c_int, C.c_int, P(C.c_float)]),
     "sfx_tape_create": (C.c_int, [Handle, Handle, P(TapeDesc), C.c_int, P(Handle)]),
+    "sfx_clock_tape_create": (C.c_int, [Handle, C.c_int, P(Handle)]),
     "sfx_tape_reset": (C.c_int, [Handle]),
     "sfx_tape_build": (C.c_int, [Handle, C.c_int, P(C.c_int64), P(FrameClock), P(DynCoeffF32), P(DynCoeffF64), P(DynCoeffF64)]),
     "sfx_tape_read": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),

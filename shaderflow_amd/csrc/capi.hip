@@ -1078,9 +1078,27 @@ struct Tape : Object {
 extern "C" int sfx_tape_reset(sfx_handle h) {
     Tape* t = get<Tape>(h, MAGIC_TAPE);
     if (!t) return fail(SFX_E_INVALID, "invalid tape handle");
+    if (!t->plan) return SFX_OK;                                    // clock tape: no recurrences to reset
     USE_DEVICE(t->ctx);
     HIP_TRY(hipMemsetAsync(t->d_state, 0, sizeof(float)*3*t->n, t->ctx->stream));
     HIP_TRY(hipMemsetAsync(t->d_scalars, 0, sizeof(ScalarState)*2, t->ctx->stream));
+    return SFX_OK;
+}
+
+// A tape without audio (plan == 0 and audio == 0, `ctx_for_clock_tape` says where it lives): only the frame clock varies
+// between the frames of a batch — scenes without audio modules (Basic, ShaderToy, RayMarch, the fractals).
+extern "C" int sfx_clock_tape_create(sfx_handle hc, int max_frames, sfx_handle* out) {
+    CTX_OR_FAIL(c, hc);
+    if (!out || max_frames < 1) return fail(SFX_E_INVALID, "null output or no frames");
+    USE_DEVICE(c);
+    Tape* t = new Tape();
+    memset(static_cast<void*>(&t->desc), 0, sizeof t->desc);
+    t->magic = MAGIC_TAPE; t->plan = nullptr; t->audio = nullptr; t->ctx = c; t->max_frames = max_frames; t->n = 0;
+    t->d_tell = nullptr; t->d_power = t->d_targets = t->d_columns = t->d_rows = t->d_loudness = t->d_state = nullptr;
+    t->d_scalars = nullptr; t->d_coeff = nullptr; t->d_vol = t->d_std = nullptr; t->d_clock = nullptr;
+    HIP_TRY(hipMalloc(&t->d_dyn, sizeof(FrameDyn)*max_frames));
+    HIP_TRY(hipMalloc(&t->d_vis, sizeof(VisualizerConsts)*max_frames));
+    *out = handle_of(t);
     return SFX_OK;
 }
 
@@ -1118,7 +1136,19 @@ extern "C" int sfx_tape_build(sfx_handle h, int nframes, const int64_t* tell, co
                               const sfx_dyn_coeff_f32* spectrogram, const sfx_dyn_coeff_f64* volume, const sfx_dyn_coeff_f64* std_) {
     Tape* t = get<Tape>(h, MAGIC_TAPE);
     if (!t) return fail(SFX_E_INVALID, "invalid tape handle");
-    if (nframes < 1 || nframes > t->max_frames || !tell || !clock || !spectrogram || !volume || !std_) return fail(SFX_E_INVALID, "tape build of %d frames (capacity %d) or null arrays", nframes, t->max_frames);
+    if (nframes < 1 || nframes > t->max_frames || !clock) return fail(SFX_E_INVALID, "tape build of %d frames (capacity %d) or null clock", nframes, t->max_frames);
+    if (!t->plan) {                                                 // clock tape: the per-frame uniforms are the clock itself
+        USE_DEVICE(t->ctx);
+        std::vector<FrameDyn> dyn(nframes);
+        for (int k = 0; k < nframes; k++) {
+            memset(&dyn[k], 0, sizeof(FrameDyn));
+            dyn[k].iTime = clock[k].iTime; dyn[k].iTau = clock[k].iTau; dyn[k].iSpectrogramOffset = clock[k].iSpectrogramOffset; dyn[k].iFrame = clock[k].iFrame;
+        }
+        HIP_TRY(hipMemcpyAsync(t->d_dyn, dyn.data(), sizeof(FrameDyn)*nframes, hipMemcpyHostToDevice, t->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+        return SFX_OK;
+    }
+    if (!tell || !spectrogram || !volume || !std_) return fail(SFX_E_INVALID, "tape build with null audio schedule arrays");
     static_assert(sizeof(sfx_dyn_coeff_f32) == sizeof(DynCoeffF32) && sizeof(sfx_dyn_coeff_f64) == sizeof(DynCoeffF64) && sizeof(sfx_frame_clock) == sizeof(FrameClock), "ABI structs");
     USE_DEVICE(t->ctx);
     hipStream_t s = t->ctx->stream;
@@ -1148,6 +1178,7 @@ extern "C" int sfx_tape_read(sfx_handle h, int what, int frame0, int nframes, vo
     USE_DEVICE(t->ctx);
     const char* src; size_t per;
     const int pts = t->desc.points > 0 ? t->desc.points : 1;
+    if (!t->plan && what != SFX_TAPE_UNIFORMS) return fail(SFX_E_INVALID, "a clock tape holds the per-frame uniforms only");
     switch (what) {
         case SFX_TAPE_SPECTROGRAM: src = (const char*)t->d_columns; per = sizeof(float)*t->n; break;
         case SFX_TAPE_WAVEFORM: src = (const char*)t->d_rows; per = sizeof(float)*pts*t->audio->channels; break;
@@ -1192,6 +1223,7 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
     a.wr = (int)((double)width*ssaa_x1000/1000.0); a.hr = (int)((double)height*ssaa_x1000/1000.0);   // scene.py:372-375
     a.out = device_out; a.out_frame_stride = (long)width*height*3;
     a.dyn = t->d_dyn; a.frame0 = frame0;
+    if (t->plan) {
     // iSpectrogram: width 1 (length=0 scenes), height bins, RG32F (spectrogram.py:298-311); the bound texture's
     // sampler state is kept, only its storage is redirected to the tape column of the frame
     a.tape_spectrogram = t->d_columns; a.spectrogram_stride = t->n;
@@ -1211,6 +1243,7 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
     // placeholders so that texel() sees a non-null base before frame_view() redirects it
     a.tex[TEX_SPECTROGRAM].data = t->d_columns;
     if (t->desc.points > 0) a.tex[TEX_WAVEFORM].data = t->d_rows;
+    }
     int rc = check_samplers(p->fragment, a);
     if (rc) return rc;
     a.has_vis = 0;                                                  // per-frame audio uniforms live on the device

@@ -77,6 +77,10 @@ class FrameTape:
                 spectrograms.append(module)
             elif isinstance(module, ShaderWaveform):
                 waveforms.append(module)
+        if scene.shader.texture.temporal != 1 or scene.shader.texture.layers != 1:
+            return False
+        if not (audios or spectrograms or waveforms):
+            return True                                           # clock tape: only iTime/iTau/iFrame change between frames
         if len(audios) != 1 or len(spectrograms) > 1 or len(waveforms) > 1 or not spectrograms:
             return False
         audio = audios[0]
@@ -84,16 +88,14 @@ class FrameTape:
             return False
         if spectrograms[0].length_samples != 1 or spectrograms[0].spectrogram_bins*audio.channels > 2048:
             return False
-        if scene.shader.texture.temporal != 1 or scene.shader.texture.layers != 1:
-            return False
         return True                                               # any (ssaa, subsample): fused when possible, else two passes
 
     def __init__(self, scene: "ShaderScene", batch: Optional[int] = None, use_mfma: bool = True):
         self.scene = scene
         self.batch = int(batch or self.BATCH)
         self.use_mfma = bool(use_mfma)
-        self.audio: ShaderAudio = next(m for m in scene.modules if isinstance(m, ShaderAudio))
-        self.spectrogram: ShaderSpectrogram = next(m for m in scene.modules if isinstance(m, ShaderSpectrogram))
+        self.audio: Optional[ShaderAudio] = next((m for m in scene.modules if isinstance(m, ShaderAudio)), None)
+        self.spectrogram: Optional[ShaderSpectrogram] = next((m for m in scene.modules if isinstance(m, ShaderSpectrogram)), None)
         self.waveform: Optional[ShaderWaveform] = next((m for m in scene.modules if isinstance(m, ShaderWaveform)), None)
         self.handle: Optional[N.Handle] = None
         self.frames = 0
@@ -106,6 +108,15 @@ class FrameTape:
         self.frames = frames
         times, dts, rdts = freewheel_clock(scene.fps, frames, scene.speed)
         self.times, self.dts = times, dts
+        self.release()
+        if audio is None:                                    # clock tape (scenes without audio modules)
+            self.clock = np.zeros(frames, dtype=[("iTime", "f4"), ("iTau", "f4"), ("iSpectrogramOffset", "f4"), ("iFrame", "i4")])
+            for k, t in enumerate(times):
+                self.clock[k] = (t, (t/scene.runtime) % 1.0, 0.0, round(t*scene.fps))
+            handle = N.Handle()
+            N.check(N.lib().sfx_clock_tape_create(scene.context.handle, self.batch, C.byref(handle)))
+            self.handle = handle
+            return self
         self.tell = chunk_schedule(rdts, int(audio.samplerate), audio.channels, audio._file_reader.samples.shape[0])
         self.clock = np.zeros(frames, dtype=[("iTime", "f4"), ("iTau", "f4"), ("iSpectrogramOffset", "f4"), ("iFrame", "i4")])
         width = spec.length_samples
@@ -115,7 +126,6 @@ class FrameTape:
         self.vol_coeff = _coefficients_f64(audio.volume, dts)
         self.std_coeff = _coefficients_f64(audio.std, dts)
 
-        self.release()
         reducer = self.waveform.reducer if self.waveform is not None else WaveformReducer.Average
         desc = N.TapeDesc(
             points=(self.waveform._points if self.waveform is not None else 0),
@@ -141,7 +151,8 @@ class FrameTape:
         program = self.scene.shader
         if program.program is None:
             program.compile()
-        self.spectrogram.configure_texture()                 # what its first update() would do
+        if self.spectrogram is not None:
+            self.spectrogram.configure_texture()             # what its first update() would do
         program.use_pipeline(program.full_pipeline())
 
     # device work --------------------------------------------------------------------------------------------------
@@ -149,6 +160,10 @@ class FrameTape:
     def build(self, first: int, count: int) -> None:
         """Audio state of frames [first, first+count) → tape slots [0, count). Frames must be visited in order."""
         s = slice(first, first + count)
+        if self.audio is None:
+            clock = np.ascontiguousarray(self.clock[s])
+            N.check(N.lib().sfx_tape_build(self.handle, count, None, C.cast(clock.ctypes.data, C.POINTER(N.FrameClock)), None, None, None))
+            return
         tell = np.ascontiguousarray(self.tell[s])
         clock, spec = np.ascontiguousarray(self.clock[s]), np.ascontiguousarray(self.spec_coeff[s])
         vol, std = np.ascontiguousarray(self.vol_coeff[s]), np.ascontiguousarray(self.std_coeff[s])
@@ -166,7 +181,10 @@ class FrameTape:
 
     def read(self, what: int, count: int, first_slot: int = 0) -> np.ndarray:
         """Tape content for inspection (tests)"""
-        bins, channels = self.spectrogram.spectrogram_bins, self.audio.channels
+        if self.audio is None:
+            bins, channels = 1, 1
+        else:
+            bins, channels = self.spectrogram.spectrogram_bins, self.audio.channels
         shapes = {
             N.TAPE_SPECTROGRAM: (count, bins, channels), N.TAPE_TARGETS: (count, bins, channels),
             N.TAPE_WAVEFORM: (count, self.waveform._points if self.waveform is not None else 1, channels),
@@ -212,6 +230,11 @@ class FrameTape:
                             self.render(batches[index + 1][1], buffers[(index + 1) % 2])
                             export.fence((index + 1) % 2)
                         emit_frames(buffers[index % 2], count, fence=index % 2)
+                    # leave the last frame in iFinal, where the frame loop would have left it (scene.screenshot(), scene.py:439-443)
+                    context.synchronize()
+                    last = context.read(buffers[(len(batches) - 1) % 2] + (batches[-1][1] - 1)*frame_bytes, frame_bytes)
+                    last = last.reshape(scene.height, scene.width, 3)
+                    scene._final.texture.texture.write(np.ascontiguousarray(last[::-1] if export.top_down else last))
                 finally:
                     context.synchronize()
                     for pointer in buffers:

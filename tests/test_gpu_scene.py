@@ -206,3 +206,21 @@ def test_encoder_handoff_top_down_rows_and_command(tmp_path, monkeypatch, batch)
     flipped = make(Visualizer, audio=wav, background=background).main(width=w, height=h, fps=fps, ssaa=2, time=seconds, output=bytes,
                                                                         batch=batch, top_down=True)
     assert np.array_equal(frames_of(flipped, w, h), want[:, ::-1])
+
+
+@pytest.mark.parametrize("name,ssaa", [("Basic", 1), ("Basic", 2), ("ShaderToy", 2), ("Mandelbrot", 1), ("RayMarch", 2)])
+def test_clock_tape_equals_frame_loop(name, ssaa):
+    """Scenes without audio modules batch through a clock-only tape (iTime/iTau/iFrame per frame on the device):
+    the same kernels with the same uniform values, so the frames are identical to the python frame loop's"""
+    import examples.scenes as scenes
+    from shaderflow_amd.tape import FrameTape
+    cls = getattr(scenes, name)
+    probe = cls()
+    probe.initialize()
+    assert FrameTape.applicable(probe)
+    kw = dict(width=96, height=54, fps=60, time=70/60, ssaa=ssaa, output=bytes)              # 70 frames: two batches of the tape
+    loop = frames_of(cls().main(batch=False, **kw), 96, 54)
+    tape = frames_of(cls().main(batch=None, **kw), 96, 54)
+    assert loop.shape == tape.shape == (70, 54, 96, 3)
+    assert np.array_equal(loop, tape), lsb_report(tape, loop)
+    assert not np.array_equal(tape[0], tape[-1]) or name in ("Mandelbrot", "RayMarch")       # time-dependent scenes move
