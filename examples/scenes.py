@@ -136,6 +136,7 @@ class RayMarch(ShaderScene):
 class Life(ShaderScene):
     """Conway's Game of Life on the GPU (demo.py:223-247): a float simulation texture with ten frames of history"""
     life_period: int = 6
+    shard_warmup = None                  # every generation depends on all earlier ones: a shard renders from frame 0
 
     def setup(self):
         width, height = 192, 108

@@ -213,6 +213,8 @@ int sfx_render_tape(sfx_handle program, sfx_handle tape, int frame0, int nframes
 /* Device memory helper for callers without their own allocator */
 int sfx_device_alloc(sfx_handle ctx, size_t nbytes, void** ptr);
 int sfx_device_free(sfx_handle ctx, void* ptr);
+/* asynchronous device-to-device copy on the context's stream (a finished frame into a batch buffer) */
+int sfx_device_copy(sfx_handle ctx, void* dst, const void* src, size_t nbytes);
 int sfx_device_read(sfx_handle ctx, const void* device_ptr, void* host, size_t nbytes);
 
 #ifdef __cplusplus

@@ -102,6 +102,7 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_render_tape": (C.c_int, [Handle, Handle, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sfx_device_alloc": (C.c_int, [Handle, C.c_size_t, P(C.c_void_p)]),
     "sfx_device_free": (C.c_int, [Handle, C.c_void_p]),
+    "sfx_device_copy": (C.c_int, [Handle, C.c_void_p, C.c_void_p, C.c_size_t]),
     "sfx_device_read": (C.c_int, [Handle, C.c_void_p, C.c_void_p, C.c_size_t]),
 }
 
@@ -179,6 +180,9 @@ class Context:
 
     def free(self, ptr: int) -> None:
         check(lib().sfx_device_free(self.handle, C.c_void_p(ptr)))
+
+    def copy(self, dst: int, src: int, nbytes: int) -> None:
+        check(lib().sfx_device_copy(self.handle, C.c_void_p(dst), C.c_void_p(src), nbytes))
 
     def read(self, ptr: int, nbytes: int) -> np.ndarray:
         out = np.empty(nbytes, np.uint8)

@@ -189,6 +189,14 @@ extern "C" int sfx_device_free(sfx_handle h, void* ptr) {
     HIP_TRY(hipFree(ptr));
     return SFX_OK;
 }
+extern "C" int sfx_device_copy(sfx_handle h, void* dst, const void* src, size_t nbytes) {
+    CTX_OR_FAIL(c, h);
+    if (!dst || !src) return fail(SFX_E_INVALID, "null device pointer");
+    USE_DEVICE(c);
+    HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, c->stream));
+    return SFX_OK;
+}
+
 extern "C" int sfx_device_read(sfx_handle h, const void* dptr, void* host, size_t nbytes) {
     CTX_OR_FAIL(c, h);
     USE_DEVICE(c);

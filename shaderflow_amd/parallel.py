@@ -108,3 +108,40 @@ def round_robin_export(world: int, rank: int, batches: list[tuple[int, int]], ad
         pending.append((slot, members))
     while pending:
         drain(*pending.pop(0))
+
+
+def frame_modes(batches: list[tuple[int, int]], world: int, rank: int, warmup: Optional[int]) -> list[int]:
+    """What `rank` does with every frame of a frame-loop export sharded batch-wise (batch b belongs to rank b % world):
+
+        2  render and keep: the frame belongs to one of this rank's batches
+        1  render only: within `warmup` frames before one of its batches (temporal textures need their history —
+           SURVEY.md §8e; `warmup=None` means unbounded feedback: everything before an owned batch is rendered)
+        0  host logic only: modules update (clocks, DynamicNumbers, video uploads), no shader is launched
+    """
+    total = sum(count for _, count in batches)
+    modes = [0]*total
+    for index, (first, count) in enumerate(batches):
+        if index % world != rank:
+            continue
+        start = 0 if warmup is None else max(0, first - warmup)
+        for k in range(start, first):
+            modes[k] = max(modes[k], 1)
+        for k in range(first, first + count):
+            modes[k] = 2
+    return modes
+
+
+def sharded_frame_loop(world: int, rank: int, batches: list[tuple[int, int]], modes: list[int], step, finish_batch, emit,
+                       gather: "FrameGather | None", buffers: list, frame_bytes: int) -> None:
+    """Frame-loop scenes (python logic between frames, temporal textures) over `world` ranks: every rank walks ALL frames
+    in order — `step(frame, mode, buffer, offset)` with the mode of `frame_modes` — and keeps the frames of its own
+    batches in `buffer` at `offset`; the rounds, the gather to rank 0 and the in-order `emit` are `round_robin_export`'s.
+    `finish_batch()` is called by the owner after its batch (stream synchronisation before the gather)."""
+    batch_index = {first: index for index, (first, _) in enumerate(batches)}
+
+    def advance(first: int, count: int) -> None:
+        buffer = buffers[(batch_index[first]//world) % 2]
+        for i in range(count):
+            step(first + i, modes[first + i], buffer, i*frame_bytes)
+
+    round_robin_export(world, rank, batches, advance, lambda count, buffer: finish_batch(), emit, gather, buffers, frame_bytes)

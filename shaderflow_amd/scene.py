@@ -33,6 +33,7 @@ from shaderflow_amd.exporting import ExportingHelper
 from shaderflow_amd.ffmpeg import FFmpeg
 from shaderflow_amd.message import ShaderMessage
 from shaderflow_amd.module import ShaderModule, logger
+from shaderflow_amd.parallel import rank_world
 from shaderflow_amd.resolution import Resolution
 from shaderflow_amd.scheduler import Scheduler
 from shaderflow_amd.shader import ShaderProgram
@@ -58,6 +59,11 @@ class ShaderScene(ShaderModule):
     """Shade + resolve in one kernel when final.glsl's taps stay inside the pixel's own supersamples"""
 
     _fused_this_frame: bool = False
+    _skip_render: bool = False
+    shard_warmup = "auto"                                     # plain class attribute: subclasses override it like `life_period`
+    """Frames a rank renders ahead of each of its batches in a multi-GPU frame-loop export so that temporal textures hold
+    their history: "auto" = 2*(deepest temporal - 1) (the history a frame samples, plus iFinal's own delay of
+    temporal - 1 frames, texture.py:253-256), an int, or None for unbounded feedback (Life): render everything before."""
     _initialized: bool = False
 
     @property
@@ -287,11 +293,14 @@ class ShaderScene(ShaderModule):
         buffers: int = 5,
         batch: Optional[bool] = None,
         top_down: Optional[bool] = None,
+        shard: Optional[tuple[int, int]] = None,
     ) -> Optional[Union[Path, bytes]]:
         """Render the scene to `output` (scene.py:493-639). `output` may be a path (raw rgb24 frames, or a video
         when an `ffmpeg` binary exists), "pipe"/"-"/bytes (returns the raw frames), or None with freewheel=True
         (renders without writing). `batch`: None = frame tape when the scene allows it, False = frame loop.
-        `top_down`: write frame rows top-down on the device (None = exactly when an ffmpeg process is the sink)."""
+        `top_down`: write frame rows top-down on the device (None = exactly when an ffmpeg process is the sink).
+        `shard`: (rank, world) to run ONE rank's share of a sharded frame-loop export without a process group (tests,
+        external launchers); with torch.distributed initialised the group's rank and size are used."""
         self.initialize()
         self.exporting = (bool(output))
         self.freewheel = (self.exporting or freewheel)
@@ -323,7 +332,6 @@ class ShaderScene(ShaderModule):
             self.ssaa = ssaa
 
         export = ExportingHelper(self, top_down=top_down)
-        from shaderflow_amd.parallel import rank_world
         if (self.exporting) and rank_world()[0] != 0:
             pass                                             # sharded export: only rank 0 owns the sink (tape.py)
         elif (self.exporting):
@@ -343,6 +351,8 @@ class ShaderScene(ShaderModule):
 
         self.vsync = self.scheduler.new(task=self.next, frequency=self.fps, freewheel=self.freewheel,
                                         frameskip=frameskip, precise=True)
+        if self.exporting and (rank_world()[1] > 1 or shard is not None):
+            return self._sharded_frame_loop(export, turbo, *(shard or rank_world()))
         while (task := self.scheduler.next()):
             if (task is not self.vsync):
                 continue
@@ -352,6 +362,73 @@ class ShaderScene(ShaderModule):
             export.update()
             if (export.finished):
                 return export.finish()
+
+    def _one_frame(self) -> None:
+        """Run the scheduler up to and including the next vsync task (one `next`)"""
+        while (task := self.scheduler.next()):
+            if task is self.vsync:
+                return
+
+    def _sharded_frame_loop(self, export: ExportingHelper, turbo: bool, rank: int, world: int, batch: int = 30):
+        """Multi-GPU export of a frame-loop scene (python logic between frames, layered/temporal textures): every rank steps
+        through all frames so that host state stays in lock step, launches shaders only for its own batches and their
+        warm-up, and rank 0 receives the finished frames in order (parallel.sharded_frame_loop)."""
+        from shaderflow_amd.parallel import FrameGather, frame_modes, shard_batches, sharded_frame_loop
+        total = export.total_frames
+        frame_bytes = self.width*self.height*3
+        batches = shard_batches(0, total, batch)
+        warmup = self.shard_warmup
+        if warmup == "auto":
+            depth = max(m.texture.temporal for m in self.modules if isinstance(m, ShaderProgram))
+            warmup = 2*(depth - 1)
+        modes = frame_modes(batches, world, rank, warmup)
+        context = self.context
+        distributed = rank_world()[1] > 1
+        if distributed:
+            import torch
+            device = torch.device("cuda", context.device)
+            tensors = [torch.zeros(frame_bytes*batch, dtype=torch.uint8, device=device) for _ in range(2)]
+            pointer_of = lambda buffer: buffer.data_ptr()
+            gather = FrameGather(world, rank, frame_bytes*batch, device)
+        else:                                                   # one rank's share, no process group: frames of foreign batches are dropped
+            tensors = [context.alloc(frame_bytes*batch) for _ in range(2)]
+            pointer_of = lambda buffer: buffer
+            gather = None
+
+        def step(frame: int, mode: int, buffer, offset: int) -> None:
+            self._skip_render = (mode == 0)
+            self._one_frame()
+            if mode == 2:
+                context.copy(pointer_of(buffer) + offset, self._final.texture.texture.device_ptr(), frame_bytes)
+
+        def emit(buffer, count: int) -> None:                   # rank 0 of a process group: frames arrive in order
+            for i in range(count):
+                export.pipe_device(pointer_of(buffer) + i*frame_bytes, turbo=turbo)
+                export.update()
+
+        try:
+            if gather is None:
+                # no process group: walk every frame, hand this rank's own batches to the sink
+                for index, (first, count) in enumerate(batches):
+                    for i in range(count):
+                        step(first + i, modes[first + i], tensors[0], i*frame_bytes)
+                    if index % world == rank:
+                        context.synchronize()
+                        for i in range(count):
+                            export.pipe_device(tensors[0] + i*frame_bytes, turbo=False)
+                            export.update()
+                export.frame = total
+            else:
+                sharded_frame_loop(world, rank, batches, modes, step, context.synchronize, emit, gather, tensors, frame_bytes)
+                if rank != 0:
+                    export.frame = total
+            return export.finish()
+        finally:
+            self._skip_render = False
+            context.synchronize()
+            if gather is None:
+                for pointer in tensors:
+                    context.free(pointer)
 
     # module ----------------------------------------------------------------------------------------------------
 

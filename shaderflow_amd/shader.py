@@ -189,29 +189,33 @@ class ShaderProgram(ShaderModule):
     def render(self) -> None:
         if self.program is None:
             self.compile()
+        # host-only frames of a sharded export (parallel.frame_modes mode 0): the temporal matrix still rolls
+        skip = self.SKIP_GPU or self.scene._skip_render
 
         if self.texture.final:
             # shader.py:391-396 — iScreen (RGBA8, linear, clamp) → iFinal (RGB8)
-            if self.SKIP_GPU or self.scene._fused_this_frame:
+            if skip or self.scene._fused_this_frame:
                 return None
             source = self.scene.shader.texture.texture
             N.check(N.lib().sfx_resolve(self.scene.context.handle, source.handle, self.texture.fbo.handle, self.scene.subsample))
             return None
 
-        self.use_pipeline(self.full_pipeline())
+        if not skip:
+            self.use_pipeline(self.full_pipeline())
 
         # Main pass + resolve in one kernel when final.glsl only needs the pixel's own supersamples
         if (self is self.scene.shader) and self.scene._can_fuse(self):
-            if not self.SKIP_GPU:
+            if not skip:
                 N.check(N.lib().sfx_render_resolve(self.program, self.scene._final.texture.fbo.handle,
                                                    int(self.scene.ssaa), self.scene.subsample))
             self.scene._fused_this_frame = True
             self.texture.roll()
             return None
 
-        for layer, box in enumerate(self.texture.row(0)):
-            self.set_uniform("iLayer", layer)
-            self.render_to_fbo(fbo=box.fbo, clear=box.clear, layer=layer)
+        if not skip:
+            for layer, box in enumerate(self.texture.row(0)):
+                self.set_uniform("iLayer", layer)
+                self.render_to_fbo(fbo=box.fbo, clear=box.clear, layer=layer)
         self.texture.roll()
 
     def update(self) -> None:

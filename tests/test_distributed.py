@@ -136,3 +136,74 @@ def test_round_robin_export_single_rank():
                        lambda c, b: log.append(("render", c)), lambda b, c: log.append(("emit", c)), None, buffers, 1)
     assert [e for e in log if e[0] == "emit"] == [("emit", 4), ("emit", 4), ("emit", 2)]
     assert [e for e in log if e[0] == "advance"] == [("advance", 0, 4), ("advance", 4, 4), ("advance", 8, 2)]
+
+
+def test_frame_modes_cover_owned_batches_and_their_warmup():
+    from shaderflow_amd.parallel import frame_modes
+    batches = shard_batches(0, 50, 8)
+    for world in (1, 2, 3):
+        owners = np.zeros(50, int)
+        for rank in range(world):
+            modes = np.array(frame_modes(batches, world, rank, 3))
+            owners += (modes == 2)
+            for index, (first, count) in enumerate(batches):
+                if index % world == rank:
+                    assert (modes[first:first + count] == 2).all()
+                    assert (modes[max(0, first - 3):first] >= 1).all()                 # warm-up rendered (or owned)
+            assert ((modes == 1).sum() <= 3*len(batches))
+        assert (owners == 1).all()                                                     # every frame kept by exactly one rank
+    unbounded = np.array(frame_modes(batches, 2, 1, None))
+    assert (unbounded[:40] >= 1).all() and (unbounded[48:] == 0).all()                 # everything before the rank's last batch
+    assert frame_modes(batches, 1, 0, 5) == [2]*50
+
+
+def _loop_worker(rank: int, world: int, port: int, total: int, batch: int, warmup: int, out):
+    from shaderflow_amd.parallel import frame_modes, sharded_frame_loop
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frame_bytes = 8
+        batches = shard_batches(0, total, batch)
+        modes = frame_modes(batches, world, rank, warmup)
+        buffers = [torch.zeros(batch*frame_bytes, dtype=torch.uint8) for _ in range(2)]
+        gather = FrameGather(world, rank, batch*frame_bytes, torch.device("cpu"))
+        history, walked, emitted = [], [], []
+
+        def step(frame, mode, buffer, offset):
+            walked.append(frame)                                                        # host logic runs for EVERY frame, in order
+            if mode:
+                history.append(frame)
+            if mode == 2:                                                               # a kept frame needs its `warmup` predecessors rendered
+                assert all(k in history for k in range(max(0, frame - warmup), frame)), (rank, frame)
+            if mode == 2:
+                buffer[offset:offset + frame_bytes] = torch.tensor([frame], dtype=torch.int64).view(torch.uint8)
+
+        def emit(buffer, count):
+            emitted.extend(np.frombuffer(buffer[:count*frame_bytes].numpy().tobytes(), np.int64).tolist())
+
+        sharded_frame_loop(world, rank, batches, modes, step, lambda: None, emit, gather, buffers, frame_bytes)
+        assert walked == list(range(total))
+        if rank == 0:
+            out.put(emitted)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("total,batch,warmup", [(50, 8, 3), (23, 4, 6)])
+def test_sharded_frame_loop_over_gloo(total, batch, warmup):
+    """Frame-loop sharding with temporal warm-up: every rank walks all frames, renders its batches + warm-up, rank 0 emits in order"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, world, port, total, batch, warmup, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    emitted = out.get(timeout=90)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert emitted == list(range(total))

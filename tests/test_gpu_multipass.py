@@ -248,3 +248,29 @@ def test_video_scene_uploads_frames_on_time():
         want = O.resolve(O.render("video", u, {0: O.make_texture(frame)}, w, h), w, h, 2)
         assert np.array_equal(got[k], want), (k, lsb_report(got[k], want))
     assert read == 3
+
+
+@pytest.mark.parametrize("name", ["MotionBlur", "Video", "Life"])
+def test_sharded_frame_loop_reproduces_the_single_process_frames(name):
+    """SURVEY §8e for frame-loop scenes: two ranks' shares (run here one after the other, `shard=(rank, 2)`) put together
+    are the single-process export — temporal history through warm-up frames (MotionBlur: 2*(10-1)), host logic on every
+    frame (Video uploads), unbounded feedback by rendering everything before (Life: shard_warmup=None)."""
+    import examples.scenes as scenes
+    w, h, fps, frames, batch = 64, 36, 30.0, 40, 30
+    rng = np.random.default_rng(1)
+    clip = rng.integers(0, 256, (24, 18, 32, 3), dtype=np.uint8)
+
+    def build():
+        base = getattr(scenes, name)
+        attrs = {"clip": (clip, 20.0)} if name == "Video" else ({"shard_warmup": None, "life_period": 2} if name == "Life" else {})
+        np.random.seed(3)
+        return type(name, (base,), attrs)()
+
+    kw = dict(width=w, height=h, fps=fps, ssaa=1, time=frames/fps, output=bytes)
+    whole = frames_of(build().main(**kw), w, h)
+    assert whole.shape[0] == frames
+    parts = [frames_of(build().main(shard=(rank, 2), **kw), w, h) for rank in range(2)]
+    assert parts[0].shape[0] == 30 and parts[1].shape[0] == 10              # batches of 30 frames: [0, 30) and [30, 40)
+    assert np.array_equal(parts[0], whole[:30]), lsb_report(parts[0], whole[:30])
+    assert np.array_equal(parts[1], whole[30:]), lsb_report(parts[1], whole[30:])
+    assert whole[30:].std() > 0
