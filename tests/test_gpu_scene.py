@@ -224,3 +224,34 @@ def test_clock_tape_equals_frame_loop(name, ssaa):
     assert loop.shape == tape.shape == (70, 54, 96, 3)
     assert np.array_equal(loop, tape), lsb_report(tape, loop)
     assert not np.array_equal(tape[0], tape[-1]) or name in ("Mandelbrot", "RayMarch")       # time-dependent scenes move
+
+
+def test_piano_module_writes_its_textures(tmp_path):
+    """ShaderPiano inside a scene: textures of the reference's shapes, written every frame, uniforms in the pipeline; a MIDI
+    file round trip feeds it (the texture CONTENTS are pinned on CPU, tests/test_host_piano.py)"""
+    from examples.scenes import Basic
+    from shaderflow_amd.piano import PianoNote, ShaderPiano
+    from shaderflow_amd.piano.midi import write_midi
+
+    score = [PianoNote(note=60 + k % 12, start=0.05*k, end=0.05*k + 0.3, channel=k % 3, velocity=40 + 5*k) for k in range(16)]
+    midi = write_midi(tmp_path/"score.mid", score)
+
+    class PianoScene(Basic):
+        def build(self):
+            self.piano = ShaderPiano(scene=self)
+            self.piano.load_midi(midi)
+
+    scene = PianoScene()
+    raw = scene.main(width=64, height=36, fps=30, time=0.5, output=bytes)
+    assert frames_of(raw, 64, 36).shape[0] == 15
+    piano = scene.piano
+    assert len(list(piano.notes)) == 16 and piano.global_minimum_note == 60 and piano.global_maximum_note == 71
+    assert piano.keys_texture.size == (128, 1) and piano.roll_texture.size == (256, 128) and piano.roll_texture.components == 4
+    keys = piano.keys_texture.texture.read()[0, :, 0]
+    assert np.array_equal(keys, piano.key_press_dynamics.value.astype(np.float32)) and keys[60:72].max() > 0
+    roll = piano.roll_texture.texture.read()                        # (128 notes, 256 slots, 4), as written
+    assert roll.shape == (128, 256, 4) and roll[60:72, 0, 1].max() > 0 and not roll[:60].any()
+    channels = piano.channel_texture.texture.read()[0, :, 0]
+    assert channels.min() == -1 and set(np.unique(channels[60:72])) <= {-1.0, 0.0, 1.0, 2.0}
+    names = {u.name for u in scene.shader.full_pipeline()}
+    assert {"iPianoDynamic", "iPianoRollTime", "iPianoKeys0x0", "iPianoRoll0x0", "iPianoChan0x0", "iPianoTempo0x0"} <= names
