@@ -154,6 +154,31 @@ def test_visualizer_lds_tile_kernel_within_one_lsb(gpu, volume, repeat):
     assert (got != want).mean() < 0.02, lsb_report(got, want)
 
 
+@pytest.mark.parametrize("ssaa", [1, 2])
+@pytest.mark.parametrize("camera", [dict(iCameraZoom=1.3, iCameraPosition=(0.12, -0.05, 0.0)), dict(iCameraIsometric=0.3, iCameraZoom=0.8),
+                                    dict(iCameraProjection=1, iCameraSeparation=0.08)])
+def test_visualizer_lds_tile_kernel_with_a_moved_camera(gpu, camera, ssaa):
+    """Non-identity cameras take the reduction path for the tap window (the corner-sample shortcut needs iCamera.gluv == gluv)"""
+    w, h = 136, 72
+    u, arrays, params = visualizer_inputs(w, h, seed=23, volume=0.8, bg_size=(120, 68))
+    for key, value in camera.items():
+        cur = getattr(u, key)
+        if hasattr(cur, "__len__"):
+            for i, v in enumerate(value):
+                cur[i] = v
+        else:
+            setattr(u, key, value)
+    u.iSSAA = float(ssaa)
+    screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, threads=8)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    if ssaa == 1:
+        assert_within_lsb(gpu.render(prog, w, h), screen)
+    else:
+        assert_within_lsb(gpu.render_resolve(prog, w, h, ssaa, 2), O.resolve(screen, w, h, 2))
+
+
 def test_visualizer_tile_overflow_falls_back(gpu):
     """A background far larger than the output: the tap window exceeds the LDS tile → generic taps, same result"""
     w, h = 64, 36
