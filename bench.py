@@ -40,8 +40,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 256*4*32*2.4e9    # 256 CU x 4 SIMD32 x 2.4 GHz = 78.6e12 lane-instructions/s (157.3 TFLOP/s FMA)
 # From profiles/r01_rocprofv3_bench_c3_summary.txt (rocprofv3 --pmc, separate passes, same command):
 PROFILE = {"file": "profiles/r01_rocprofv3_bench_c3_summary.txt",
-           "valu_instr_per_supersample": 2423.0,   # SQ_INSTS_VALU / SQ_WAVES of the fused visualizer kernel
-           "hbm_bytes_per_frame": (3386.0 + 1458000.0)*1024/60}   # FETCH_SIZE + WRITE_SIZE (KiB) per 60-frame launch
+           "valu_instr_per_supersample": 2109.0,   # SQ_INSTS_VALU / SQ_WAVES of the fused visualizer kernel
+           "hbm_bytes_per_frame": (3378.2 + 1458000.0)*1024/60}   # FETCH_SIZE + WRITE_SIZE (KiB) per 60-frame launch
 
 
 def parse_args():
@@ -229,7 +229,7 @@ def main() -> None:
                          "unit": "GB/s", "frac": round(achieved/HBM_PEAK_GBS, 4),
                          "traffic": (PROFILE["hbm_bytes_per_frame"]*fpb if c3 else None), "traffic_source": PROFILE["file"],
                          "algorithmic_bytes_per_launch": b_alg*fpb, "launch_ms": round(launch_s*1e3, 3), "frames_per_launch": fpb,
-                         "note": "FP32-VALU bound kernel (81 bilinear taps per supersample, 40 of them summed per texel cell in closed form): the fused kernel writes only the RGB8 frame, "
+                         "note": "FP32-VALU bound kernel (81 bilinear taps per supersample: 40 summed per texel cell in closed form, 40 diagonal ones sharing their coordinate work in groups of four): the fused kernel writes only the RGB8 frame, "
                                  "12.6x less HBM traffic than the two-pass data-flow the algorithmic bytes describe; the binding roof is under valu"},
             "valu": {"bound": "fp32_valu_issue", "achieved": round(lane_ops/1e12, 2), "peak": round(VALU_PEAK_LANE_OPS/1e12, 1), "unit": "T lane-instr/s",
                      "frac": round(lane_ops/VALU_PEAK_LANE_OPS, 4), "taps_per_s": round(samples_per_s*81/1e9, 1), "taps_unit": "G taps/s",
