@@ -8,12 +8,18 @@
  * Pinning status
  *   audio half (sfo_audio.c): PINNED against tests/golden/ fixtures, captured from the reference's own
  *       numpy code by tests/golden/make_golden.py (tests/test_oracle_audio.py).
- *   pixel half (sfo_pixel.c): PARITY UNPINNED — the reference evaluates GLSL inside an OpenGL driver
- *       (moderngl ~=5.12 → system GL ≥ 3.3), which is neither vendored nor runnable here and for which
- *       the reference holds no golden images. The restatement follows the GLSL
- *       sources line by line plus OpenGL 3.3 core §3.8 (sampling) and §2.1.6/§4.1 (unorm conversion),
- *       with the built-in functions fixed by sfo_math.h; closed-form scenes pin the plumbing
- *       (tests/test_oracle_pixel.py).
+ *   pixel half (sfo_pixel.c): PINNED TO 1 LSB against the reference's GLSL run by an independent OpenGL
+ *       implementation. The reference evaluates GLSL inside an OpenGL 3.3 driver (moderngl), which cannot run
+ *       here, and holds no golden images. tests/golden/make_golden_gles.py therefore assembles
+ *       the reference's shader files the way shader.py:190-235 does, adapts them mechanically to GLSL ES 3.00
+ *       and renders them with Google SwiftShader (OpenGL ES 3.0, CPU) — 27 images: every camera projection, the
+ *       visualizer with its radial blur, bars, waveform, the inline demo fragments, raymarch, mandelbrot,
+ *       multipass/motionblur layers, final.glsl, and the bare sampler in every filter/wrap mode. The oracle
+ *       matches all of them within 1 LSB per channel (tests/test_oracle_gles.py), which is as far as two
+ *       conforming GL implementations agree (built-in precision and filter precision are implementation
+ *       choices; sfo_math.h fixes ours). NOT covered by that fixture (integer semantics the all-float ES
+ *       adaptation would change): tetration.frag and life/*.glsl, which rest on known-answer tests
+ *       (tests/test_oracle_pixel.py: Conway patterns, closed forms).
  */
 #ifndef SFO_H
 #define SFO_H

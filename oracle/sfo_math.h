@@ -6,7 +6,7 @@
  *
  * GLSL leaves the precision of sin/cos/atan/pow/exp2/log2 to the driver, and the reference
  * (shaderflow/resources/shaders/include/shaderflow.glsl, fragment/ shaders, examples/basic/shaders/ fragments)
- * pins none of it ("parity unpinned" for the GL half). This file therefore FIXES one
+ * pins none of it. This file therefore FIXES one
  * admissible implementation: every function below is a finite sequence of correctly-rounded
  * binary32 operations (+ - * / sqrtf fmaf floorf rintf and integer bit moves), evaluated in the
  * written order with no contraction (-ffp-contract=off). The HIP device code restates the same

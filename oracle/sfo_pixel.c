@@ -2,8 +2,9 @@
  * ORACLE (test infrastructure, never shipped, never on the product path).
  * Pixel half: CPU restatement of the reference's GLSL (vertex/default.glsl, include/shaderflow.glsl,
  * include/camera.glsl, fragment/{default,missing,final}.glsl, examples/basic/shaders/ fragments) and of
- * the OpenGL 3.3 rules the reference leans on. PARITY UNPINNED: the reference has no golden images
- * and its GL driver cannot run here (see sfo.h). Citations are file:line in /root/reference.
+ * the OpenGL 3.3 rules the reference leans on. PINNED TO 1 LSB against the reference's GLSL executed by an
+ * independent OpenGL implementation (tests/golden/gles.npz, tests/test_oracle_gles.py; see sfo.h); the
+ * reference itself holds no golden images. Citations are file:line in /root/reference.
  *
  * Conventions fixed here (and restated independently by the HIP kernels):
  *   - pixel (i, j) of a (wr, hr) target, origin bottom-left, is shaded at its centre; the varyings

@@ -1,0 +1,105 @@
+"""
+The pixel oracle against the REFERENCE'S GLSL executed by an independent OpenGL implementation (Google SwiftShader,
+OpenGL ES 3.0): tests/golden/gles.npz holds what tests/golden/make_golden_gles.py rendered in the build container from
+the shader files under /root/reference (assembled as shader.py:190-235 does, adapted mechanically to GLSL ES).
+This is what pins the oracle's reading of the GLSL, the GL sampler and the varyings; CPU only.
+
+Tolerance: 1 LSB per channel. Built-in precision (sin, pow, atan) and the sub-texel precision of the bilinear filter
+are implementation choices in OpenGL, so two conforming implementations differ in the last bit of an 8-bit channel;
+the north star's parity bar is that same 1 LSB. One image has a known ill-conditioned term (default.glsl's ring:
+1/circle² next to circle = 0) and is held to 1 LSB on 99.8 % of its values.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from tests.helpers import oracle_textures, visualizer_inputs
+
+G = np.load(Path(__file__).parent/"golden"/"gles.npz")
+CAMERAS = {"plain": {}, "moved": dict(iCameraZoom=1.3, iCameraIsometric=0.2, iCameraPosition=(0.1, -0.05, 0.0)),
+           "stereo": dict(iCameraProjection=1, iCameraSeparation=0.07, iCameraZoom=1.2), "equirect": dict(iCameraProjection=2, iCameraZoom=0.8)}
+
+
+def agree(tag: str, want: np.ndarray, fraction: float = 1.0) -> None:
+    got = G[f"{tag}.image"]
+    assert got.shape == want.shape, (tag, got.shape, want.shape)
+    d = np.abs(got.astype(int) - want.astype(int))
+    within = (d <= 1).mean()
+    assert within >= fraction, f"{tag}: {100*within:.3f}% within 1 LSB (max {d.max()})"
+    assert np.abs(got.astype(float).mean() - want.astype(float).mean()) < 0.25, tag       # no systematic offset
+
+
+@pytest.mark.parametrize("camera", list(CAMERAS))
+def test_default_fragment_every_projection(camera):
+    u = O.default_uniforms(160, 90, iTime=0.75, iTau=0.3, **CAMERAS[camera])
+    agree(f"default.{camera}", O.render("default", u, {}, 160, 90, threads=4), fraction=0.998 if camera == "plain" else 1.0)
+
+
+def test_untextured_fragments():
+    u = O.default_uniforms(96, 54, iTime=3.0, iTau=0.3)
+    agree("missing", O.render("missing", u, {}, 96, 54))
+    agree("shadertoy", O.render("shadertoy", u, {}, 96, 54))
+    agree("multi_child", O.render("multi_child", O.default_uniforms(64, 36), {}, 64, 36))
+    agree("raymarch", O.render("raymarch", O.default_uniforms(160, 90), {}, 160, 90, threads=4))
+    agree("raymarch.moved", O.render("raymarch", O.default_uniforms(160, 90, iCameraPosition=(0.4, 0.2, -1.5), iCameraZoom=0.8), {}, 160, 90, threads=4))
+    agree("mandelbrot", O.render("mandelbrot", O.default_uniforms(160, 90, iQuality=0.2), {}, 160, 90, threads=4))
+
+
+@pytest.mark.parametrize("volume", [0.0, 0.5, 1.2])
+def test_visualizer_with_its_radial_blur(volume):
+    """The benchmark fragment: 91 bilinear taps with float loop counters, rotated bars, nearest spectrogram, linear waveform"""
+    u, arrays, params = visualizer_inputs(160, 90, seed=21, volume=volume, bg_size=(120, 68))
+    agree(f"visualizer.v{volume}", O.render("visualizer", u, oracle_textures(arrays, params), 160, 90, threads=8))
+
+
+def test_audio_texture_fragments():
+    u, arrays, params = visualizer_inputs(128, 72, seed=5)
+    arrays["iSpectrogram"] = arrays["iSpectrogram"]*3
+    for name in ("bars", "waveform"):
+        agree(name, O.render(name, u, oracle_textures(arrays, params), 128, 72, threads=4))
+    u.user[0] = 0.35
+    agree("dynamics", O.render("dynamics", u, oracle_textures(arrays, params), 128, 72))
+
+
+@pytest.mark.parametrize("filter", ["nearest", "linear"])
+@pytest.mark.parametrize("wrap", ["clamp", "repeat"])
+def test_sampler_addressing_and_filtering(filter, wrap):
+    """texture() on a 7x5 RGBA8 grid at coordinates from -0.75 to 1.75: texel addressing, wrap modes, bilinear weights"""
+    texture = O.make_texture(G["sampler.texels"], filter, wrap == "repeat", wrap == "repeat")
+    w, h = 70, 50
+    want = np.zeros((h, w, 4), np.uint8)
+    for j in range(h):
+        for i in range(w):
+            # astuv of the pixel centre (vertex/default.glsl:9-10), then the probe's `astuv*2.5 - 0.75`
+            s = np.float32(((np.float32(i) + np.float32(0.5))/np.float32(w)*np.float32(2) - np.float32(1) + np.float32(1))/np.float32(2))
+            t = np.float32(((np.float32(j) + np.float32(0.5))/np.float32(h)*np.float32(2) - np.float32(1) + np.float32(1))/np.float32(2))
+            c = O.sample(texture, s*np.float32(2.5) - np.float32(0.75), t*np.float32(2.5) - np.float32(0.75))
+            want[j, i] = np.rint(np.clip(c, 0, 1)*255)
+    agree(f"sampler.{filter}.{wrap}", want)
+    if filter == "nearest":
+        assert np.array_equal(G[f"sampler.{filter}.{wrap}.image"], want)                  # no filtering arithmetic: identical
+
+
+def test_layers_history_and_final():
+    w, h = 128, 72
+    background = G["multipass.background"]
+    u = O.default_uniforms(w, h, iLayer=0)
+    layer0 = O.render("multipass", u, {"background": O.make_texture(background)}, w, h, threads=4)
+    agree("multipass.layer0", layer0)
+    u.iLayer = 1
+    # layer 1 samples what GL rendered into iScreen0x0, so feed the oracle the same texels
+    first = G["multipass.layer0.image"]
+    agree("multipass.layer1", O.render("multipass", u, {"background": O.make_texture(background), 0: O.make_texture(first, "linear", False, False)}, w, h, threads=4))
+    history = G["motionblur.history"]
+    u = O.default_uniforms(96, 54, iLayer=1)
+    u.user[0] = len(history)
+    agree("motionblur.layer1", O.render("motionblur", u, {t: O.make_texture(history[t], "linear", False, False) for t in range(len(history))}, 96, 54, threads=4))
+    screen = G["final.screen"]
+    for (fw, fh, sub) in ((64, 36, 2), (64, 36, 1), (128, 72, 2), (32, 18, 4)):
+        want = O.resolve(screen, fw, fh, sub)
+        got = G[f"final.{fw}x{fh}.k{sub}.image"]
+        d = np.abs(got[..., :3].astype(int) - want.astype(int))
+        assert d.max() <= 1, (fw, fh, sub, d.max())
+        assert (got[..., 3] == 255).all()
