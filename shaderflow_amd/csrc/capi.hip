@@ -18,6 +18,7 @@
 #include <string>
 #include <thread>
 #include <unistd.h>
+#include <algorithm>
 #include <vector>
 
 using namespace sf;
@@ -56,6 +57,7 @@ struct Context : Object {
     hipEvent_t events[64] = {};
     hipDeviceProp_t prop;
     float tap_x[81], tap_y[81];
+    std::vector<struct Program*> programs;   // live programs of this context (their sampler slots point at textures)
     int top_down = 0;                // frames leave with rows top-down (sfx_ctx_output_top_down)
 };
 
@@ -208,6 +210,8 @@ extern "C" int sfx_device_read(sfx_handle h, const void* dptr, void* host, size_
 // ---------------------------------------------------------------------------------------------------------
 // Textures
 
+static void forget_texture(struct Texture* t);                      // defined after Program
+
 extern "C" int sfx_texture_create(sfx_handle h, int width, int height, int components, int dtype, sfx_handle* out) {
     CTX_OR_FAIL(c, h);
     if (!out || width < 1 || height < 1 || components < 1 || components > 4) return fail(SFX_E_INVALID, "texture %dx%dx%d", width, height, components);
@@ -269,6 +273,7 @@ extern "C" int sfx_texture_destroy(sfx_handle h) {
     if (!t) return fail(SFX_E_INVALID, "invalid texture handle");
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
+    forget_texture(t);                                              // no program keeps a pointer to it
     hipFree(t->data);
     t->magic = 0;
     delete t;
@@ -311,6 +316,11 @@ struct Program : Object {
     Uniforms u;
     Texture* samplers[TEX_SLOTS];
 };
+
+static void forget_texture(Texture* t) {
+    for (Program* p : t->ctx->programs)
+        for (auto& s : p->samplers) if (s == t) s = nullptr;
+}
 
 struct UniformField { const char* name; size_t offset; int count; bool integer; };
 #define UF(n, c, i) {#n, offsetof(Uniforms, n), c, i}
@@ -379,6 +389,7 @@ extern "C" int sfx_program_lookup(sfx_handle h, const char* source, sfx_handle* 
     p->magic = MAGIC_PROG; p->ctx = c; p->fragment = fragment;
     default_uniforms(p->u);
     for (auto& s : p->samplers) s = nullptr;
+    c->programs.push_back(p);
     *out = handle_of(p);
     return SFX_OK;
 }
@@ -449,6 +460,8 @@ extern "C" int sfx_sampler_bind(sfx_handle h, const char* name, sfx_handle tex, 
 extern "C" int sfx_program_destroy(sfx_handle h) {
     Program* p = get<Program>(h, MAGIC_PROG);
     if (!p) return fail(SFX_E_INVALID, "invalid program handle");
+    auto& live = p->ctx->programs;
+    live.erase(std::remove(live.begin(), live.end(), p), live.end());
     p->magic = 0;
     delete p;
     return SFX_OK;

@@ -5,6 +5,7 @@ libshaderflow_hip here (`sfx_texture_*`, include/shaderflow_hip.h).
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 from typing import Optional
 
 import numpy as np
@@ -21,6 +22,8 @@ class DeviceTexture:
     size: tuple[int, int]
     components: int
     dtype: np.dtype
+    serial: int = field(factory=itertools.count(1).__next__)
+    """Unique per allocation (a handle value can be reused after a release): what sampler-binding caches compare"""
 
     @property
     def nbytes(self) -> int:

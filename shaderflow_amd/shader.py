@@ -114,6 +114,8 @@ class ShaderProgram(ShaderModule):
     # device program -----------------------------------------------------------------------------------
 
     program: Optional[N.Handle] = None
+    _pushed: dict = Factory(dict)
+    """name → (bytes, known) of the value the device program holds: unchanged uniforms and samplers are not sent again"""
     fallback: bool = False
     """True when the fragment was unknown and the `missing` kernel was bound (shader.py:336-340)"""
 
@@ -121,6 +123,7 @@ class ShaderProgram(ShaderModule):
         if self.program is not None and self.program.value:
             N.lib().sfx_program_destroy(self.program)
         self.program = None
+        self._pushed.clear()
 
     def compile(self, _vertex: str = None, _fragment: str = None):
         for variable in self.full_pipeline():
@@ -160,8 +163,13 @@ class ShaderProgram(ShaderModule):
         data = np.ascontiguousarray(np.asarray(value, dtype=np.float64).ravel()[:count].astype(dtype))
         if data.size < count:
             return False
+        raw = (code, data.tobytes())
+        previous = self._pushed.get(name)
+        if previous is not None and previous[0] == raw:
+            return previous[1]
         known = C.c_int(0)
         N.check(N.lib().sfx_uniform_set(self.program, name.encode(), code, data.ctypes.data, C.byref(known)))
+        self._pushed[name] = (raw, bool(known.value))
         return bool(known.value)
 
     def get_uniform(self, name: str) -> Optional[Any]:
@@ -174,7 +182,10 @@ class ShaderProgram(ShaderModule):
             if (variable.type == "sampler2D"):
                 texture = variable.value
                 if isinstance(texture, DeviceTexture) and texture.handle.value:
-                    N.check(N.lib().sfx_sampler_bind(self.program, variable.name.encode(), texture.handle, None))
+                    bound = ("sampler", texture.serial)
+                    if self._pushed.get(variable.name) != bound:
+                        N.check(N.lib().sfx_sampler_bind(self.program, variable.name.encode(), texture.handle, None))
+                        self._pushed[variable.name] = bound
                 _index += 1
                 continue
             if variable.value is None or variable.type not in _UNIFORM_TYPES:

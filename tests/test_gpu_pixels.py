@@ -256,3 +256,18 @@ def test_full_size_properties_4k_ssaa2(gpu):
     img = gpu.render_resolve(bars, w, h, ssaa, 2)
     bin_width = w/115
     assert np.array_equal(img[:, int(10*bin_width) + 3], img[:, int(10*bin_width) + 20])
+
+
+def test_destroyed_texture_is_unbound_not_dangling(gpu):
+    """A program must not keep a pointer to a texture that was destroyed: the render reports the missing sampler instead"""
+    from shaderflow_amd import _native as N
+    import ctypes as C
+    prog, _ = gpu.program("dynamics")
+    gpu.set_uniforms(prog, O.default_uniforms(32, 18))
+    texture = N.Handle()
+    N.check(gpu.lib.sfx_texture_create(gpu.ctx.handle, 8, 8, 3, N.U8, C.byref(texture)))
+    assert gpu.bind(prog, "background", texture)
+    target = gpu.empty(32, 18, 4)
+    assert gpu.lib.sfx_render(prog, target, 0) == N.OK
+    N.check(gpu.lib.sfx_texture_destroy(texture))
+    assert gpu.lib.sfx_render(prog, target, 0) != N.OK and b"background" in gpu.lib.sfx_last_error()
