@@ -12,14 +12,14 @@
  *       implementation. The reference evaluates GLSL inside an OpenGL 3.3 driver (moderngl), which cannot run
  *       here, and holds no golden images. tests/golden/make_golden_gles.py therefore assembles
  *       the reference's shader files the way shader.py:190-235 does, adapts them mechanically to GLSL ES 3.00
- *       and renders them with Google SwiftShader (OpenGL ES 3.0, CPU) — 27 images: every camera projection, the
+ *       and renders them with Google SwiftShader (OpenGL ES 3.0, CPU) — 33 images: every camera projection, the
  *       visualizer with its radial blur, bars, waveform, the inline demo fragments, raymarch, mandelbrot,
- *       multipass/motionblur layers, final.glsl, and the bare sampler in every filter/wrap mode. The oracle
- *       matches all of them within 1 LSB per channel (tests/test_oracle_gles.py), which is as far as two
- *       conforming GL implementations agree (built-in precision and filter precision are implementation
- *       choices; sfo_math.h fixes ours). NOT covered by that fixture (integer semantics the all-float ES
- *       adaptation would change): tetration.frag and life/*.glsl, which rest on known-answer tests
- *       (tests/test_oracle_pixel.py: Conway patterns, closed forms).
+ *       tetration, life (simulation with its integer types, visuals), multipass/motionblur layers, final.glsl,
+ *       and the bare sampler in every filter/wrap mode. The oracle matches them within 1 LSB per channel
+ *       (tests/test_oracle_gles.py), which is as far as two conforming GL implementations agree (built-in
+ *       precision and filter precision are implementation choices; sfo_math.h fixes ours). Two stated
+ *       exceptions: the chaotic boundary of tetration (0.4 % of the values) and texelFetch outside the texture
+ *       (undefined in GL: SwiftShader clamps, this oracle reads zero like robust-access desktop drivers).
  */
 #ifndef SFO_H
 #define SFO_H

@@ -17,8 +17,9 @@ order, built-ins, the camera chain), the GL sampler (texel addressing, wrap mode
 conversion) and the rasteriser's varyings — against a real GLSL compiler and rasteriser. What it cannot pin to
 the bit: `sin/cos/pow/atan` precision and the sub-texel precision of the bilinear filter are implementation
 choices (SwiftShader filters with 8 fractional bits), so the comparison is "within a few LSB", stated in the test.
-Fragments whose meaning depends on integer arithmetic (`tetration`: `it / MAX_STEPS`; `life/*`: int arrays,
-texelFetch) are left out — the all-float adaptation would change them.
+Integer semantics that survive: a division between two names declared `int` becomes `trunc(a / b)` (tetration.frag's
+`it / MAX_STEPS`). life/simulation.glsl (int arrays, `%`, ivec2, texelFetch) is compiled WITH its integers and without
+the prelude it does not use (`typed_content` below: only float() around the values assigned to colour components).
 """
 from __future__ import annotations
 
@@ -83,6 +84,9 @@ def to_es(source: str) -> str:
         out += text[pos:open_at] + "(@@INT@@(" + text[open_at + 1:close_at] + "))"
         pos = close_at + 1
     text = out + text[pos:]
+    # integer division between two int variables keeps its meaning once they are floats: a / b → trunc(a / b)
+    integers = set(re.findall(r"\bint\s+(\w+)\s*(?:=|;|,)", text))
+    text = re.sub(r"\b(\w+)\s*/\s*(\w+)\b", lambda m: f"trunc({m.group(1)} / {m.group(2)})" if {m.group(1), m.group(2)} <= integers else m.group(0), text)
     text = re.sub(r"\bint\s*\(", "trunc(", text)
     text = text.replace("@@INT@@(", "int(")
     text = re.sub(r"\bivec([234])\b", r"vec\1", text)
@@ -143,6 +147,15 @@ def history_defines(name: str, temporal: int, layers: int) -> str:
             lines += [f"    if (temporal == {t} && layer == {l})", f"        return texture({name}{t}x{l}, astuv);"]
     lines += ["    return vec4(0.0);", "}"]
     return "\n".join(lines) + "\n"
+
+
+def typed_content(fragment_text: str, uniforms: str) -> str:
+    """A fragment that keeps its integer types: comments dropped, scalar colour-component assignments wrapped in float()"""
+    text = re.sub(r"/\*.*?\*/", "", fragment_text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r"(fragColor\.[rgba]\s*=\s*)([^;]+);", r"\1float(\2);", text)
+    varyings = "out vec4 fragColor;\n" + "".join(f"in vec2 {v};\n" for v in VARYINGS)
+    return HEADER + uniforms + varyings + text
 
 
 def build(fragment_text: str, samplers: list[str], extra: str = "") -> tuple[str, str]:
@@ -250,6 +263,30 @@ def main() -> None:
     final = (SHADERS/"fragment/final.glsl").read_text().replace("uniform int iSubsample;", "")
     for (fw, fh, sub) in ((64, 36, 2), (64, 36, 1), (128, 72, 2), (32, 18, 4)):
         run(f"final.{fw}x{fh}.k{sub}", final, O.default_uniforms(fw, fh), fw, fh, {"iScreen": screen}, {"iScreen": (True, False, False)}, iSubsample=sub)
+
+    # --- integer semantics: tetration (int division), Conway's life (texelFetch, int arrays, %), its visuals ------------------
+    run("tetration", (REF/"examples/fractals/shaders/tetration.frag").read_text(), O.default_uniforms(160, 90), 160, 90, {}, {})
+    run("tetration.zoomed", (REF/"examples/fractals/shaders/tetration.frag").read_text(),
+        O.default_uniforms(160, 90, iCameraZoom=2.5, iCameraPosition=(-0.7, 0.1, 0.0)), 160, 90, {}, {})
+    lw, lh = 48, 27
+    states = [rng.integers(0, 2, (lh, lw, 1)).astype(np.float32) for _ in range(5)]
+    out["life.states"] = np.stack(states)
+    vertex, _ = build("void main() {}", [])
+    uniforms = "uniform int iFrame;\nuniform int iLifePeriod;\nuniform vec2 iLifeSize;\nuniform sampler2D iLife1x0;\n"
+    simulation = typed_content((EXAMPLES/"life/simulation.glsl").read_text(), uniforms)
+    program = ctx.program(vertex, simulation)
+    ctx.gl.glUseProgram(program)
+    for frame in (0, 6, 7):
+        handle = ctx.texture(states[1], False, True, True)
+        for name, value in (("iFrame", frame), ("iLifePeriod", 6)):
+            ctx.gl.glUniform1i(ctx.gl.glGetUniformLocation(program, name.encode()), value)
+        image = ctx.draw(program, lw, lh, {"iLifeSize": (lw, lh), "iResolution": (lw, lh), "iWantAspect": lw/lh}, {"iLife1x0": handle},
+                         {"vertex_position": QUAD, "vertex_gluv": QUAD})
+        out[f"life_simulation.f{frame}.image"] = image                  # RGBA8 target: the red channel is the cell (0 or 255)
+        print(f"life_simulation.f{frame}          alive {int((image[..., 0] > 127).sum())}")
+    textures = {f"iLife{t}x0": states[t] for t in range(5)}
+    run("life_visuals", (EXAMPLES/"life/visuals.glsl").read_text(), O.default_uniforms(128, 72, iCameraZoom=0.9), 128, 72, textures,
+        {name: (False, True, True) for name in textures})
 
     np.savez_compressed(HERE/"gles.npz", **out)
     print("gles.npz", (HERE/"gles.npz").stat().st_size, "bytes,", len([k for k in out if k.endswith('.image')]), "images")

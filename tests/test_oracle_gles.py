@@ -103,3 +103,34 @@ def test_layers_history_and_final():
         d = np.abs(got[..., :3].astype(int) - want.astype(int))
         assert d.max() <= 1, (fw, fh, sub, d.max())
         assert (got[..., 3] == 255).all()
+
+
+@pytest.mark.parametrize("tag,kw", [("tetration", {}), ("tetration.zoomed", dict(iCameraZoom=2.5, iCameraPosition=(-0.7, 0.1, 0.0)))])
+def test_tetration_integer_division(tag, kw):
+    """`it / MAX_STEPS` is an integer division (value 0 or 1). The iteration is chaotic along the fractal's boundary, where
+    the built-ins' last bits decide between escape and hue: 99.5 % of the values agree to 1 LSB, the rest lies on that boundary."""
+    agree(tag, O.render("tetration", O.default_uniforms(160, 90, **kw), {}, 160, 90, threads=4), fraction=0.995)
+
+
+def test_life_simulation_and_visuals():
+    """life/simulation.glsl compiled WITH its integer types (texelFetch, int arrays, %): the hold branch is identical; the rule
+    branch is identical away from the border. On the border ring the two differ by design: texelFetch outside the texture is
+    undefined in OpenGL — SwiftShader clamps the coordinate, the oracle (and the HIP kernel) read zero like robust-access
+    desktop drivers do (sfo_pixel.c texel_fetch)."""
+    states = G["life.states"]
+    lh, lw = states[1].shape[:2]
+    for frame in (0, 6, 7):
+        u = O.default_uniforms(lw, lh, iFrame=frame)
+        u.user[0], u.user[1], u.user[2] = lw, lh, 6
+        want = O.render_to("life_simulation", u, {1: O.make_texture(states[1], "nearest", True, True)}, lw, lh, 1, np.float32)[..., 0] > 0.5
+        got = G[f"life_simulation.f{frame}.image"][..., 0] > 127
+        if frame % 6:
+            assert np.array_equal(got, want)
+        else:
+            assert np.array_equal(got[1:-1, 1:-1], want[1:-1, 1:-1])
+            clamped = np.pad(states[1][..., 0], 1, mode="edge")
+            near = sum(clamped[1 + dy:1 + dy + lh, 1 + dx:1 + dx + lw] for dx in (-1, 0, 1) for dy in (-1, 0, 1) if (dx, dy) != (0, 0))
+            assert np.array_equal(got, np.where(states[1][..., 0] == 1, (near == 2) | (near == 3), near == 3))     # SwiftShader = clamp-to-edge fetch
+    visuals = O.render("life_visuals", O.default_uniforms(128, 72, iCameraZoom=0.9),
+                       {t: O.make_texture(states[t], "nearest", True, True) for t in range(5)}, 128, 72, threads=4)
+    assert np.array_equal(G["life_visuals.image"], visuals)
