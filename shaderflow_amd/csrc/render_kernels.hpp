@@ -105,7 +105,10 @@ __device__ __forceinline__ void store_target(const RenderArgs& a, long frame, in
 template <int FRAGMENT> struct PlainShader {
     static constexpr int BLOCK_W = 64, BLOCK_H = 4;      // unfused block shape
     static constexpr int MIN_WAVES_PER_SIMD = 1;
-    static constexpr int FUSED_ROWS = 1;                 // output rows per block of the fused kernel (S >= 2)
+#ifndef PLAIN_FUSED_ROWS
+#define PLAIN_FUSED_ROWS 4
+#endif
+    static constexpr int FUSED_ROWS = PLAIN_FUSED_ROWS;  // output rows per block of the fused kernel (S >= 2)
     struct State {};
     struct Shared {};
     __device__ static void pre(const RenderArgs&, const Frag&, bool, State&) {}
