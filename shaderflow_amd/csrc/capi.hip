@@ -553,6 +553,9 @@ static int launch_render(int fragment, const RenderArgs& a, int frames, hipStrea
 #ifndef VIS_FUSED_ROWS
 #define VIS_FUSED_ROWS 1
 #endif
+#ifndef VIS_THREAD_ROWS
+#define VIS_THREAD_ROWS 1
+#endif
 #ifndef VIS_ROWS_SS
 #define VIS_ROWS_SS 10
 #endif
@@ -562,10 +565,11 @@ static int launch_render(int fragment, const RenderArgs& a, int frames, hipStrea
 
 template <class SHADER> static int launch_fused_s(const RenderArgs& a, int ssaa, int frames, hipStream_t s) {
     const int blocks_x = (a.w + 127)/128;
-    const int row_blocks = (a.h + SHADER::FUSED_ROWS - 1)/SHADER::FUSED_ROWS;
+    constexpr int rows = SHADER::FUSED_ROWS*SHADER::THREAD_ROWS, threads = 512*SHADER::THREAD_ROWS;
+    const int row_blocks = (a.h + rows - 1)/rows;
     if (ssaa == 1) hipLaunchKernelGGL((k_render_resolve<SHADER, 1>), dim3(blocks_x*((a.h + 1)/2), 1, frames), dim3(256), 0, s, a);
-    else if (ssaa == 2) hipLaunchKernelGGL((k_render_resolve<SHADER, 2>), dim3(blocks_x*row_blocks, 1, frames), dim3(512), 0, s, a);
-    else if (ssaa == 4) hipLaunchKernelGGL((k_render_resolve<SHADER, 4>), dim3(blocks_x*row_blocks, 1, frames), dim3(512), 0, s, a);
+    else if (ssaa == 2) hipLaunchKernelGGL((k_render_resolve<SHADER, 2>), dim3(blocks_x*row_blocks, 1, frames), dim3(threads), 0, s, a);
+    else if (ssaa == 4) hipLaunchKernelGGL((k_render_resolve<SHADER, 4>), dim3(blocks_x*row_blocks, 1, frames), dim3(threads), 0, s, a);
     else return fail(SFX_E_UNSUPPORTED, "fused ssaa %d", ssaa);
     return SFX_OK;
 }
@@ -610,7 +614,7 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
                 if (ssaa == 1) return launch_fused_s<VisualizerShader<128, 10, 1>>(a, ssaa, frames, s);
                 // four samples per lane need more registers: 6 waves per SIMD without spills beat 8 with (8K 4xSSAA: 55 -> 63 frames/s)
                 if (ssaa == 4) return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, 6, VIS_FUSED_ROWS>>(a, ssaa, frames, s);
-                return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_SS, VIS_FUSED_ROWS>>(a, ssaa, frames, s);
+                return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_SS, VIS_FUSED_ROWS, VIS_THREAD_ROWS>>(a, ssaa, frames, s);
             }
             return launch_fused_s<PlainShader<FRAG_VISUALIZER>>(a, ssaa, frames, s);
         case FRAG_BARS: return launch_fused_s<PlainShader<FRAG_BARS>>(a, ssaa, frames, s);

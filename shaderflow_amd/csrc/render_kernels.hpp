@@ -108,7 +108,8 @@ template <int FRAGMENT> struct PlainShader {
 #ifndef PLAIN_FUSED_ROWS
 #define PLAIN_FUSED_ROWS 4
 #endif
-    static constexpr int FUSED_ROWS = PLAIN_FUSED_ROWS;  // output rows per block of the fused kernel (S >= 2)
+    static constexpr int FUSED_ROWS = PLAIN_FUSED_ROWS;  // output rows a lane group walks in the fused kernel (S >= 2)
+    static constexpr int THREAD_ROWS = 1;                // output rows covered side by side by the block's threads (S >= 2)
     struct State {};
     struct Shared {};
     __device__ static void pre(const RenderArgs&, const Frag&, bool, State&) {}
@@ -256,14 +257,15 @@ __device__ __forceinline__ void store_rgb_row(uint8_t* out_row, int x0, int w, c
 // After shading, every lane of a quad receives the quad's packed RGBA8 texels through DPP quad_perm moves and
 // lane c of the quad resolves colour channel c (lane 3 idles); lane 0 collects the three bytes.
 template <class SHADER, int S>
-__global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_resolve(const RenderArgs a) {
+__global__ __launch_bounds__(512*SHADER::THREAD_ROWS, SHADER::MIN_WAVES_PER_SIMD) void k_render_resolve(const RenderArgs a) {
     constexpr int LANES = (S == 1) ? 1 : 4;
     constexpr int GROUP = (S*S)/LANES;               // supersamples of one pixel owned by one lane: 1, 1, 4
     constexpr int G = (S == 4) ? 2 : 1;              // side of that group
     // Output rows per block: S == 1 packs 2 rows of 128 pixels into its 256 threads; otherwise every quad walks
     // SHADER::FUSED_ROWS vertically adjacent pixels, which amortises the shader's per-block setup (LDS staging)
-    constexpr int ROWS = (S == 1) ? 2 : SHADER::FUSED_ROWS;
-    constexpr int WALK = (S == 1) ? 1 : ROWS;        // pixels a lane group visits one after the other
+    constexpr int TROWS = (S == 1) ? 2 : SHADER::THREAD_ROWS;             // rows covered by different threads
+    constexpr int WALK = (S == 1) ? 1 : SHADER::FUSED_ROWS;               // pixels a lane group visits one after the other
+    constexpr int ROWS = TROWS*WALK;
     constexpr int PER_LANE = GROUP*WALK;
     __shared__ __attribute__((aligned(16))) uint8_t staged[ROWS][384];
 
@@ -274,8 +276,8 @@ __global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_reso
     const int bx = tile % blocks_x, by = tile / blocks_x;
     const int tid = threadIdx.x;
     const int p = tid / LANES, sub = tid % LANES;
-    const int prow = (S == 1) ? (p / 128) : 0;
-    const int px = bx*128 + (p % 128), py0 = by*ROWS + prow;
+    const int prow = p / 128;                        // 0 .. TROWS-1
+    const int px = bx*128 + (p % 128), py0 = by*ROWS + prow*WALK;
 
     __shared__ typename SHADER::Shared shared;
     uint32_t mine[PER_LANE];
@@ -294,7 +296,8 @@ __global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_reso
     SF_TICK(a, 0);                                   // varyings + pre
     // the thread whose LAST sample is the block's top-right valid supersample (thread 0's first one is the bottom-left)
     const int p_last = min(127, a.w - 1 - bx*128);
-    const int corner_tid = (S == 1) ? min(1, a.h - 1 - by*2)*128 + p_last : p_last*LANES + (LANES - 1);
+    const int prow_last = (min(ROWS, a.h - by*ROWS) - 1)/WALK;
+    const int corner_tid = (prow_last*128 + p_last)*LANES + (LANES - 1);
     SHADER::template setup<PER_LANE>(a, tex, f, state, valid, shared, corner_tid);
     SF_TICK(a, 1);                                   // setup (window reduction + LDS staging)
 #pragma unroll
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(512, SHADER::MIN_WAVES_PER_SIMD) void k_render_reso
             const uint32_t channel = resolve_channel_any<S>(block, a.subsample, 8*(sub < 3 ? sub : 0));
             const uint32_t green = quad_lane1(channel), blue = quad_lane2(channel);
             if (valid[r*GROUP] && sub == 0) {
-                uint8_t* s = &staged[r][(p % 128)*3];
+                uint8_t* s = &staged[prow*WALK + r][(p % 128)*3];
                 s[0] = (uint8_t)channel; s[1] = (uint8_t)green; s[2] = (uint8_t)blue;
             }
         }
