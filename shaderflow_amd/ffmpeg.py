@@ -250,6 +250,75 @@ class FFmpeg:
     def available() -> bool:
         return shutil.which("ffmpeg") is not None
 
+    # media probes (ffmpeg.py:1104-1235) ----------------------------------------------------------------------
+    # RIFF/WAVE files are answered from their header by the native reader; anything else needs the ffprobe binary.
+    # A path that does not exist gives None, like the reference.
+
+    @staticmethod
+    def _wav(path: Path):
+        from shaderflow_amd.audio.reader import read_wav
+        if Path(path).suffix.lower() in (".wav", ".wave"):
+            return read_wav(path)
+        return None
+
+    @staticmethod
+    def _probe(path: Path, stream: str, entry: str) -> str:
+        if shutil.which("ffprobe") is None:
+            raise RuntimeError(f"{path}: probing this container needs the ffprobe binary (RIFF/WAVE files do not)")
+        return subprocess.check_output(["ffprobe", "-hide_banner", "-loglevel", "error", "-select_streams", stream,
+                                        "-show_entries", entry, "-of", "default=noprint_wrappers=1:nokey=1", str(path)], text=True).strip()
+
+    @staticmethod
+    def get_audio_samplerate(path: Path, *, stream: int = 0, echo: bool = True) -> Optional[int]:
+        if not (path := Path(path)).exists():
+            return None
+        wav = FFmpeg._wav(path)
+        return wav[1] if wav else int(FFmpeg._probe(path, f"a:{stream}", "stream=sample_rate"))
+
+    @staticmethod
+    def get_audio_channels(path: Path, *, stream: int = 0, echo: bool = True) -> Optional[int]:
+        if not (path := Path(path)).exists():
+            return None
+        wav = FFmpeg._wav(path)
+        return wav[0].shape[1] if wav else int(FFmpeg._probe(path, f"a:{stream}", "stream=channels"))
+
+    @staticmethod
+    def get_audio_duration(path: Path, *, echo: bool = True) -> Optional[float]:
+        if not (path := Path(path)).exists():
+            return None
+        wav = FFmpeg._wav(path)
+        return wav[0].shape[0]/wav[1] if wav else float(FFmpeg._probe(path, "a:0", "format=duration"))
+
+    @staticmethod
+    def get_audio_numpy(path: Path, *, echo: bool = True):
+        """(samples, channels) float32 of the whole file"""
+        if not (path := Path(path)).exists():
+            return None
+        wav = FFmpeg._wav(path)
+        if wav:
+            return wav[0]
+        raise RuntimeError(f"{path}: decoding this container needs an ffmpeg binary; convert it to WAV")
+
+    @staticmethod
+    def get_video_resolution(path: Path, *, echo: bool = True) -> Optional[tuple[int, int]]:
+        if not (path := Path(path)).exists():
+            return None
+        width, height = FFmpeg._probe(path, "v:0", "stream=width,height").split()[:2]
+        return int(width), int(height)
+
+    @staticmethod
+    def get_video_framerate(path: Path, *, precise: bool = False, echo: bool = True) -> Optional[float]:
+        if not (path := Path(path)).exists():
+            return None
+        num, _, den = FFmpeg._probe(path, "v:0", "stream=r_frame_rate").partition("/")
+        return float(num)/float(den or 1)
+
+    @staticmethod
+    def get_video_duration(path: Path, *, echo: bool = True) -> Optional[float]:
+        if not (path := Path(path)).exists():
+            return None
+        return float(FFmpeg._probe(path, "v:0", "format=duration"))
+
 
 def _stage_from_call(kind: str, args: tuple, options: dict) -> Stage:
     """Positional sugar the reference allows: input(path), output(path), filter(content), pcm(format)"""

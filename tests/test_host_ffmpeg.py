@@ -68,3 +68,13 @@ def test_device_vflip_drops_the_filter():
 def test_pcm_dtypes():
     assert pcm_dtype("pcm_f32le") == np.dtype("<f4") and pcm_dtype("pcm_s16be") == np.dtype(">i2")
     assert pcm_dtype("pcm_u8") == np.dtype("u1") and pcm_dtype("pcm_f64le") == np.dtype("<f8")
+
+
+def test_audio_probes_answer_wav_files_natively(tmp_path):
+    from shaderflow_amd.audio.reader import write_wav_f32
+    samples = np.random.default_rng(0).uniform(-1, 1, (4410, 2)).astype(np.float32)
+    path = write_wav_f32(tmp_path/"clip.wav", samples, 22050)
+    assert FFmpeg.get_audio_samplerate(path) == 22050 and FFmpeg.get_audio_channels(path) == 2
+    assert FFmpeg.get_audio_duration(path) == pytest.approx(0.2)
+    assert np.array_equal(FFmpeg.get_audio_numpy(path), samples)
+    assert FFmpeg.get_audio_samplerate(tmp_path/"missing.wav") is None and FFmpeg.get_video_resolution(tmp_path/"missing.mp4") is None
