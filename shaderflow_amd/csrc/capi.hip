@@ -514,19 +514,46 @@ static int check_samplers(int fragment, const RenderArgs& a) {
     return rc;
 }
 
-template <class SHADER> static void launch_render_t(const RenderArgs& a, int frames, hipStream_t s) {
+template <class SHADER> static void launch_render_t(const RenderArgs& a, int frames, hipStream_t s, size_t dynamic_lds = 0) {
     dim3 grid((a.wr + SHADER::BLOCK_W - 1)/SHADER::BLOCK_W, (a.hr + SHADER::BLOCK_H - 1)/SHADER::BLOCK_H, frames), block(SHADER::BLOCK_W, SHADER::BLOCK_H, 1);
-    hipLaunchKernelGGL(k_render<SHADER>, grid, block, 0, s, a);
+    if (dynamic_lds > 48*1024) hipFuncSetAttribute((const void*)k_render<SHADER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_lds);
+    hipLaunchKernelGGL(k_render<SHADER>, grid, block, dynamic_lds, s, a);
 }
+
+// Upper bound of the background window (in texel cells) that a block of `sx` x `sy` shaded samples needs for
+// visualizer.frag's taps — the numbers VisualizerShader::setup derives per block, bounded over the frames of a launch.
+// Texels per sample are zoom^2 * background.height / shaded_height on both axes (visualizer.frag:17, gtexture); on the
+// tape path the per-frame zoom and blur radius live on the device, so their largest values are used (z <= 0.93,
+// intensity <= 0.003). A moved camera scales the footprint by an unknown factor: a generous guess, and the kernel
+// still checks every block (a window that does not fit falls back to the generic taps).
+static void visualizer_window_bound(const RenderArgs& a, int sx, int sy, int& tw, int& th) {
+    const Tex& bg = a.tex[TEX_BACKGROUND];
+    const float zoom2 = a.has_vis ? a.vis.zoom2 : 0.93f*0.93f;
+    const float intensity = a.has_vis ? fabsf(a.vis.intensity) : 0.003f;
+    float density = zoom2*(float)bg.height/(float)a.hr;
+    if (!a.identity_camera) density *= 2.0f*fmaxf(1.0f, fabsf(a.u.iCameraZoom));
+    const float rx = intensity*a.bg_scale_x*(float)bg.width*1.101f + 0.001f, ry = intensity*(float)bg.height*1.101f + 0.001f;
+    tw = (int)floorf((float)(sx - 1)*density + 2.0f*rx) + 2;
+    th = (int)floorf((float)(sy - 1)*density + 2.0f*ry) + 2;
+}
+static const size_t VIS_LDS_LIMIT = 150*1024;                         // leave room for the static shared state of the kernels
 
 static int launch_render(int fragment, const RenderArgs& a, int frames, hipStream_t s) {
     switch (fragment) {
         case FRAG_DEFAULT: launch_render_t<PlainShader<FRAG_DEFAULT>>(a, frames, s); break;
         case FRAG_MISSING: launch_render_t<PlainShader<FRAG_MISSING>>(a, frames, s); break;
-        case FRAG_VISUALIZER:
-            if (visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) launch_render_t<VisualizerShader<128, 10, 1>>(a, frames, s);
+        case FRAG_VISUALIZER: {
+            int tw = 0, th = 0;
+            if (visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) visualizer_window_bound(a, 128, 2, tw, th);
+            if (tw > 0 && tw <= 128 && th <= 10) launch_render_t<VisualizerShader<128, 10, 1>>(a, frames, s);
+            else if (tw > 0 && (size_t)tw*th*48 <= VIS_LDS_LIMIT) {           // a window wider than the fixed tile: tile sized per launch
+                RenderArgs d = a;
+                d.tile_pitch = tw; d.tile_rows = th;
+                launch_render_t<VisualizerShader<0, 0, 1>>(d, frames, s, (size_t)tw*th*48);
+            }
             else launch_render_t<PlainShader<FRAG_VISUALIZER>>(a, frames, s);
             break;
+        }
         case FRAG_BARS: launch_render_t<PlainShader<FRAG_BARS>>(a, frames, s); break;
         case FRAG_WAVEFORM: launch_render_t<PlainShader<FRAG_WAVEFORM>>(a, frames, s); break;
         case FRAG_MULTI_CHILD: launch_render_t<PlainShader<FRAG_MULTI_CHILD>>(a, frames, s); break;
@@ -563,13 +590,18 @@ static int launch_render(int fragment, const RenderArgs& a, int frames, hipStrea
 #define VIS_MIN_WAVES_SS 8
 #endif
 
-template <class SHADER> static int launch_fused_s(const RenderArgs& a, int ssaa, int frames, hipStream_t s) {
+template <class SHADER, int S> static void launch_fused_k(const RenderArgs& a, dim3 grid, dim3 block, size_t dynamic_lds, hipStream_t s) {
+    if (dynamic_lds > 48*1024) hipFuncSetAttribute((const void*)k_render_resolve<SHADER, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_lds);
+    hipLaunchKernelGGL((k_render_resolve<SHADER, S>), grid, block, dynamic_lds, s, a);
+}
+
+template <class SHADER> static int launch_fused_s(const RenderArgs& a, int ssaa, int frames, hipStream_t s, size_t dynamic_lds = 0) {
     const int blocks_x = (a.w + 127)/128;
     constexpr int rows = SHADER::FUSED_ROWS*SHADER::THREAD_ROWS, threads = 512*SHADER::THREAD_ROWS;
     const int row_blocks = (a.h + rows - 1)/rows;
-    if (ssaa == 1) hipLaunchKernelGGL((k_render_resolve<SHADER, 1>), dim3(blocks_x*((a.h + 1)/2), 1, frames), dim3(256), 0, s, a);
-    else if (ssaa == 2) hipLaunchKernelGGL((k_render_resolve<SHADER, 2>), dim3(blocks_x*row_blocks, 1, frames), dim3(threads), 0, s, a);
-    else if (ssaa == 4) hipLaunchKernelGGL((k_render_resolve<SHADER, 4>), dim3(blocks_x*row_blocks, 1, frames), dim3(threads), 0, s, a);
+    if (ssaa == 1) launch_fused_k<SHADER, 1>(a, dim3(blocks_x*((a.h + 1)/2), 1, frames), dim3(256), dynamic_lds, s);
+    else if (ssaa == 2) launch_fused_k<SHADER, 2>(a, dim3(blocks_x*row_blocks, 1, frames), dim3(threads), dynamic_lds, s);
+    else if (ssaa == 4) launch_fused_k<SHADER, 4>(a, dim3(blocks_x*row_blocks, 1, frames), dim3(threads), dynamic_lds, s);
     else return fail(SFX_E_UNSUPPORTED, "fused ssaa %d", ssaa);
     return SFX_OK;
 }
@@ -611,10 +643,22 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
         case FRAG_MISSING: return launch_fused_s<PlainShader<FRAG_MISSING>>(a, ssaa, frames, s);
         case FRAG_VISUALIZER:
             if (!force_generic && visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) {
-                if (ssaa == 1) return launch_fused_s<VisualizerShader<128, 10, 1>>(a, ssaa, frames, s);
-                // four samples per lane need more registers: 6 waves per SIMD without spills beat 8 with (8K 4xSSAA: 55 -> 63 frames/s)
-                if (ssaa == 4) return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, 6, VIS_FUSED_ROWS>>(a, ssaa, frames, s);
-                return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_SS, VIS_FUSED_ROWS, VIS_THREAD_ROWS>>(a, ssaa, frames, s);
+                // the block shades 128*ssaa x rows*ssaa samples (S == 1: 128 x 2 pixels); pick the fixed tile when its window fits
+                int tw = 0, th = 0;
+                visualizer_window_bound(a, 128*ssaa, (ssaa == 1 ? 2 : VIS_FUSED_ROWS*VIS_THREAD_ROWS)*ssaa, tw, th);
+                if (ssaa == 1 && tw <= 128 && th <= 10) return launch_fused_s<VisualizerShader<128, 10, 1>>(a, ssaa, frames, s);
+                if (ssaa != 1 && tw <= VIS_PITCH_SS && th <= VIS_ROWS_SS) {
+                    // four samples per lane need more registers: 6 waves per SIMD without spills beat 8 with (8K 4xSSAA: 55 -> 63 frames/s)
+                    if (ssaa == 4) return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, 6, VIS_FUSED_ROWS>>(a, ssaa, frames, s);
+                    return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_SS, VIS_FUSED_ROWS, VIS_THREAD_ROWS>>(a, ssaa, frames, s);
+                }
+                if ((size_t)tw*th*48 <= VIS_LDS_LIMIT) {
+                    // denser backgrounds (1080p output at 2x SSAA over a 1080-row background: 0.43 texel per sample): the tile is
+                    // sized per launch in dynamic LDS; fewer blocks fit a CU, which is still several times the generic taps
+                    RenderArgs d = a;
+                    d.tile_pitch = tw; d.tile_rows = th;
+                    return launch_fused_s<VisualizerShader<0, 0, 4, VIS_FUSED_ROWS, VIS_THREAD_ROWS>>(d, ssaa, frames, s, (size_t)tw*th*48);
+                }
             }
             return launch_fused_s<PlainShader<FRAG_VISUALIZER>>(a, ssaa, frames, s);
         case FRAG_BARS: return launch_fused_s<PlainShader<FRAG_BARS>>(a, ssaa, frames, s);

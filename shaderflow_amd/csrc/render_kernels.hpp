@@ -41,6 +41,7 @@ struct RenderArgs {
     int identity_camera;             // glsl.hpp camera_is_identity(u): iCamera.gluv == gluv exactly
     float aspect;                    // iResolution.x/iResolution.y (iAspectRatio, shaderflow.glsl:16), divided once on the host
     float bg_scale_x;                // background.height/background.width (gtexture, shaderflow.glsl:166-167), divided once on the host
+    int tile_pitch, tile_rows;       // geometry of the LDS tile when it is a launch parameter (VisualizerShader<0, …>)
     int top_down;                    // K9: write the RGB8 frame rows top-down (the encoder's `vflip`, exporting.py:103, done here)
 #ifdef SF_SECTION_TIMERS
     unsigned long long* timers;      // profiling builds (tools/variants.sh): per-section shader-clock sums, see SF_TICK

@@ -52,12 +52,24 @@ struct VisualizerShader {
         VisualizerPre pre;
         float xc, yc;                // centre tap in texel space (u*w - 0.5, v*h - 0.5)
     };
+    // TILE_PITCH == 0: the tile geometry is a launch parameter (RenderArgs::tile_pitch/tile_rows) and the cells live in
+    // dynamic LDS — for output/background combinations whose window does not fit the fixed tile (capi launch_fused)
+    static constexpr bool DYNAMIC_TILE = (TILE_PITCH == 0);
     struct Shared {
-        float4 tile[TILE_ROWS*TILE_PITCH*3];   // 48-byte cells {Ar Ag Ab Br} {Bg Bb Cr Cg} {Cb Dr Dg Db}
+        float4 cells[DYNAMIC_TILE ? 1 : TILE_ROWS*TILE_PITCH*3];   // 48-byte cells {Ar Ag Ab Br} {Bg Bb Cr Cg} {Cb Dr Dg Db}
         float red[5][16];
         VisualizerConsts consts;
         int x0, y0, tw, th, ok;
     };
+    __device__ __forceinline__ static float4* tile_of(Shared& sh) {
+        if constexpr (DYNAMIC_TILE) { extern __shared__ __attribute__((aligned(16))) float4 sf_dynamic_tile[]; return sf_dynamic_tile; }
+        else return sh.cells;
+    }
+    __device__ __forceinline__ static const float4* tile_of(const Shared& sh) { return tile_of(const_cast<Shared&>(sh)); }
+    __device__ __forceinline__ static int pitch_of(const RenderArgs& a) { if constexpr (DYNAMIC_TILE) return a.tile_pitch; else return TILE_PITCH; }
+    __device__ __forceinline__ static int rows_of(const RenderArgs& a) { if constexpr (DYNAMIC_TILE) return a.tile_rows; else return TILE_ROWS; }
+    // bytes between tile rows, as the float the offset arithmetic uses (a literal for the fixed tile)
+    __device__ __forceinline__ static float row_bytes(const RenderArgs& a) { if constexpr (DYNAMIC_TILE) return (float)(a.tile_pitch*48); else return (float)(TILE_PITCH*48); }
 
     __device__ static VisualizerConsts frame_consts(const RenderArgs& a, const Frag& f) {
         if (a.vis_consts) return a.vis_consts[a.frame0 + blockIdx.z];
@@ -117,7 +129,7 @@ struct VisualizerShader {
                 x0 = (int)floorf(x_lo - rx); y0 = (int)floorf(y_lo - ry);
                 tw = (int)floorf(x_hi + rx) - x0 + 1;
                 th = (int)floorf(y_hi + ry) - y0 + 1;
-                ok = (tw <= TILE_PITCH) && (th <= TILE_ROWS);
+                ok = (tw <= pitch_of(a)) && (th <= rows_of(a));
             }
             if (tid == 0) { sh.x0 = x0; sh.y0 = y0; sh.ok = ok; sh.consts = c; }      // read by run() after the staging barrier
         } else {
@@ -143,7 +155,7 @@ struct VisualizerShader {
                 x0 = (int)floorf(m[0] - rx); y0 = (int)floorf(m[2] - ry);
                 tw = (int)floorf(-m[1] + rx) - x0 + 1;                // cells [x0, x0+tw) hold every tap's floor()
                 th = (int)floorf(-m[3] + ry) - y0 + 1;
-                ok = (tw <= TILE_PITCH) && (th <= TILE_ROWS);
+                ok = (tw <= pitch_of(a)) && (th <= rows_of(a));
             } else if (n_bad == 0 && !(m[0] < INFINITY)) {
                 ok = 2;                                               // nothing to blur in this block
             }
@@ -161,8 +173,14 @@ struct VisualizerShader {
         // one thread per cell of the TILE_PITCH-wide grid (constant divisor); a texel is fetched with ONE unaligned
         // 4-byte load (the allocation is padded, capi sfx_texture_create) and unpacked with v_cvt_f32_ubyteN
         typedef uint32_t unaligned_u32 __attribute__((aligned(1)));
-        for (int idx = tid; idx < TILE_PITCH*th; idx += nthreads) {
-            const int ty = idx / TILE_PITCH, tx = idx - ty*TILE_PITCH;
+        const int pitch = pitch_of(a);
+        float4* const tile = tile_of(sh);
+        // fixed tile: one thread per cell of the pitch-wide grid (constant divisor); dynamic tile: waves take rows, lanes columns
+        const int idx_end = DYNAMIC_TILE ? th*((tw + 63) & ~63) : pitch*th, row_span = DYNAMIC_TILE ? ((tw + 63) & ~63) : pitch;
+        for (int idx = tid; idx < idx_end; idx += nthreads) {
+            int ty, tx;
+            if constexpr (DYNAMIC_TILE) { ty = idx / row_span; tx = idx - ty*row_span; }      // row_span is a multiple of 64: a wave stays in one row
+            else { ty = idx / TILE_PITCH; tx = idx - ty*TILE_PITCH; }
             if (tx >= tw) continue;
             const int j0 = wrap_texel(y0 + ty, bg.height, bg.repeat_y), j1 = wrap_texel(y0 + ty + 1, bg.height, bg.repeat_y);
             const int i0 = wrap_texel(x0 + tx, bg.width, bg.repeat_x), i1 = wrap_texel(x0 + tx + 1, bg.width, bg.repeat_x);
@@ -182,7 +200,7 @@ struct VisualizerShader {
                 q1 = make_float4(g10 - g00, b10 - b00, r01 - r00, g01 - g00);
                 q2 = make_float4(b01 - b00, (r00 - r10) - (r01 - r11), (g00 - g10) - (g01 - g11), (b00 - b10) - (b01 - b11));
             }
-            float4* cell = sh.tile + (ty*TILE_PITCH + tx)*3;
+            float4* cell = tile + (ty*pitch + tx)*3;
             cell[0] = q0; cell[1] = q1; cell[2] = q2;
         }
         SF_TICK(a, 5);                               // staging (loads + conversion + LDS writes)
@@ -206,12 +224,12 @@ struct VisualizerShader {
         r = fmaf(axy, q2.y, r); g = fmaf(axy, q2.z, g); b = fmaf(axy, q2.w, b);
     }
 
-    __device__ __forceinline__ static void tap(const float4* tile, float x, float y, float& r, float& g, float& b) {
+    __device__ __forceinline__ static void tap(const float4* tile, float rowb, float x, float y, float& r, float& g, float& b) {
         const float ax = __builtin_amdgcn_fractf(x), ay = __builtin_amdgcn_fractf(y);
         // byte offset of the cell, in float arithmetic (exact: < 2^24) so that only ONE conversion is needed:
         // (floor(y)*PITCH + floor(x))*48; x, y >= 0 inside the staged window. (Carrying the offset along with the
         // position — one more add, two fewer ops — was measured: 32 fewer VALU per wave, same time.)
-        const float cell = fmaf(y - ay, (float)(TILE_PITCH*48), (x - ax)*48.0f);
+        const float cell = fmaf(y - ay, rowb, (x - ax)*48.0f);
         const float4* p = (const float4*)((const char*)tile + (unsigned)cell);
         const float4 q0 = p[0], q1 = p[1], q2 = p[2];
         const float axy = ax*ay;
@@ -229,36 +247,12 @@ struct VisualizerShader {
     // steps that stay inside the cell. A tap within rounding distance of a cell boundary may be counted on either
     // side: the bilinear surface is continuous there, so the sum moves by ~1e-7. At most 1 + ceil(9|s|) runs are
     // needed (the loop bound is wave-uniform); the tail loop only runs if rounding split a run.
+    // One run of one axis direction: state (m = position of the next tap, left = taps left).
     template <bool ALONG_X>
-    __device__ __forceinline__ static void runs_axis(const float4* tile, float m, float s, float f, float fixed_offset, float& r, float& g, float& b) {
-        const float inv = fminf(__builtin_amdgcn_rcpf(fabsf(s)), 1.0e6f);          // s == 0: every tap in the first cell
-        const float k1 = (s > 0.0f) ? -inv : inv, k0 = (s > 0.0f) ? inv : 0.0f;     // t = k0 + a*k1
-        const float hs = 0.5f*s;
-        const int bound = __builtin_amdgcn_readfirstlane(1 + (int)ceilf(9.0f*fabsf(s) + 1.0e-3f));
-        float left = 10.0f;
-        for (int it = 0; it < bound || __any(left > 0.0f); it++) {
-            const float a = __builtin_amdgcn_fractf(m);
-            const float cell = fmaf(m - a, ALONG_X ? 48.0f : (float)(TILE_PITCH*48), fixed_offset);
-            const float4* p = (const float4*)((const char*)tile + (unsigned)cell);
-            const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-            const float n = fminf(floorf(fmaf(a, k1, k0)) + 1.0f, left);
-            left = left - n;
-            const float sum = n*(a + fmaf(n, hs, -hs));
-            const float wx = ALONG_X ? sum : n*f, wy = ALONG_X ? n*f : sum, wxy = sum*f;
-            r = fmaf(n, q0.x, r);    g = fmaf(n, q0.y, g);    b = fmaf(n, q0.z, b);
-            r = fmaf(wx, q0.w, r);   g = fmaf(wx, q1.x, g);   b = fmaf(wx, q1.y, b);
-            r = fmaf(wy, q1.z, r);   g = fmaf(wy, q1.w, g);   b = fmaf(wy, q2.x, b);
-            r = fmaf(wxy, q2.y, r);  g = fmaf(wxy, q2.z, g);  b = fmaf(wxy, q2.w, b);
-            m = fmaf(n, s, m);
-        }
-    }
-
-    // One run of one axis direction: state (m = position of the next tap, left = taps left); see runs_axis.
-    template <bool ALONG_X>
-    __device__ __forceinline__ static void one_run(const float4* tile, float& m, float& left, float s, float k0, float k1, float hs,
+    __device__ __forceinline__ static void one_run(const float4* tile, float rowb, float& m, float& left, float s, float k0, float k1, float hs,
                                                    float f, float fixed_offset, float weight, float& r, float& g, float& b) {
         const float a = __builtin_amdgcn_fractf(m);
-        const float cell = fmaf(m - a, ALONG_X ? 48.0f : (float)(TILE_PITCH*48), fixed_offset);
+        const float cell = fmaf(m - a, ALONG_X ? 48.0f : rowb, fixed_offset);
         const float4* p = (const float4*)((const char*)tile + (unsigned)cell);
         const float4 q0 = p[0], q1 = p[1], q2 = p[2];
         const float n = fminf(floorf(fmaf(a, k1, k0)) + 1.0f, left);
@@ -276,7 +270,7 @@ struct VisualizerShader {
     // The four axis-aligned directions together: every loop iteration advances each of them by one run, which gives the
     // scheduler four independent dependency chains and one loop test. `step` > 0 is the common |step| (texels per tap),
     // `first` the offset of the first tap; direction 0 (+x) carries weight 2 (direction 8 == direction 0).
-    __device__ __forceinline__ static void runs_axes(const float4* tile, float xr, float yr, float first, float step, float fx, float fy,
+    __device__ __forceinline__ static void runs_axes(const float4* tile, float rowb, float xr, float yr, float first, float step, float fx, float fy,
                                                      float row_offset, float column_offset, float& r, float& g, float& b) {
         const float inv = fminf(__builtin_amdgcn_rcpf(step), 1.0e6f);
         const float hs = 0.5f*step;
@@ -284,10 +278,10 @@ struct VisualizerShader {
         float m0 = xr + first, m1 = yr + first, m2 = xr - first, m3 = yr - first;
         float l0 = 10.0f, l1 = 10.0f, l2 = 10.0f, l3 = 10.0f;
         for (int it = 0; it < bound || __any((l0 + l1) + (l2 + l3) > 0.0f); it++) {
-            one_run<true>(tile, m0, l0, step, inv, -inv, hs, fy, row_offset, 2.0f, r, g, b);
-            one_run<false>(tile, m1, l1, step, inv, -inv, hs, fx, column_offset, 1.0f, r, g, b);
-            one_run<true>(tile, m2, l2, -step, 0.0f, inv, -hs, fy, row_offset, 1.0f, r, g, b);
-            one_run<false>(tile, m3, l3, -step, 0.0f, inv, -hs, fx, column_offset, 1.0f, r, g, b);
+            one_run<true>(tile, rowb, m0, l0, step, inv, -inv, hs, fy, row_offset, 2.0f, r, g, b);
+            one_run<false>(tile, rowb, m1, l1, step, inv, -inv, hs, fx, column_offset, 1.0f, r, g, b);
+            one_run<true>(tile, rowb, m2, l2, -step, 0.0f, inv, -hs, fy, row_offset, 1.0f, r, g, b);
+            one_run<false>(tile, rowb, m3, l3, -step, 0.0f, inv, -hs, fx, column_offset, 1.0f, r, g, b);
         }
     }
 
@@ -301,24 +295,17 @@ struct VisualizerShader {
         // Directions 0/4 and 2/6 run along a texel row / column: their cross-axis displacement is |cos(k*TAU/4)| <= 2e-7
         // of the radius (< 1e-6 texel), which is dropped so that the fixed coordinate is decomposed once per direction.
         const float fy = __builtin_amdgcn_fractf(yr), fx = __builtin_amdgcn_fractf(xr);
-        const float row_offset = (yr - fy)*(float)(TILE_PITCH*48), column_offset = (xr - fx)*48.0f;
-#ifdef VIS_AXIS_SEQUENTIAL
-        // axis-aligned directions: closed-form runs; direction 0 counts twice (direction 8 == direction 0)
-        runs_axis<true>(sh.tile, fmaf(a.tap_x[0], ax, xr), (a.tap_x[1] - a.tap_x[0])*ax, fy, row_offset, r, g, b);
-        r = r*2.0f; g = g*2.0f; b = b*2.0f;
-        runs_axis<false>(sh.tile, fmaf(a.tap_y[20], ay, yr), (a.tap_y[21] - a.tap_y[20])*ay, fx, column_offset, r, g, b);
-        runs_axis<true>(sh.tile, fmaf(a.tap_x[40], ax, xr), (a.tap_x[41] - a.tap_x[40])*ax, fy, row_offset, r, g, b);
-        runs_axis<false>(sh.tile, fmaf(a.tap_y[60], ay, yr), (a.tap_y[61] - a.tap_y[60])*ay, fx, column_offset, r, g, b);
-#else
+        const float4* const tile = tile_of(sh);
+        const float rowb = row_bytes(a);
+        const float row_offset = (yr - fy)*rowb, column_offset = (xr - fx)*48.0f;
         // axis-aligned directions: closed-form runs, the four directions interleaved (the two axes have the same texel
         // scale up to 1 ulp, see below)
-        runs_axes(sh.tile, xr, yr, a.tap_x[0]*ax, (a.tap_x[1] - a.tap_x[0])*ax, fx, fy, row_offset, column_offset, r, g, b);
-#endif
+        runs_axes(tile, rowb, xr, yr, a.tap_x[0]*ax, (a.tap_x[1] - a.tap_x[0])*ax, fx, fy, row_offset, column_offset, r, g, b);
         // The four diagonal directions walk (+-k*s, +-k*s) from the centre (|cos| and |sin| of 45 degrees agree to 1 ulp,
         // and so do the texel scales of the two axes: differences below 1e-6 texel are dropped): at every walk step
         // the four taps share two x and two y coordinates, so two fractions and two cell offsets per axis serve all four.
         {
-            constexpr float ROW = (float)(TILE_PITCH*48);
+            const float ROW = rowb;
             const float step = (a.tap_x[11] - a.tap_x[10])*ax, first = a.tap_x[10]*ax;      // direction 1 = 45 degrees: both positive
             float xp = xr + first, xm = xr - first, yp = yr + first, ym = yr - first;
 #ifndef VIS_DIAG_UNROLL
@@ -330,14 +317,14 @@ struct VisualizerShader {
                 const float ayp = __builtin_amdgcn_fractf(yp), aym = __builtin_amdgcn_fractf(ym);
                 const float cxp = (xp - axp)*48.0f, cxm = (xm - axm)*48.0f;
                 const float ryp = (yp - ayp)*ROW, rym = (ym - aym)*ROW;
-                tap_at(sh.tile, cxp + ryp, axp, ayp, r, g, b);       // 45
-                tap_at(sh.tile, cxm + ryp, axm, ayp, r, g, b);       // 135
-                tap_at(sh.tile, cxm + rym, axm, aym, r, g, b);       // 225
-                tap_at(sh.tile, cxp + rym, axp, aym, r, g, b);       // 315
+                tap_at(tile, cxp + ryp, axp, ayp, r, g, b);       // 45
+                tap_at(tile, cxm + ryp, axm, ayp, r, g, b);       // 135
+                tap_at(tile, cxm + rym, axm, aym, r, g, b);       // 225
+                tap_at(tile, cxp + rym, axp, aym, r, g, b);       // 315
                 xp = xp + step; xm = xm - step; yp = yp + step; ym = ym - step;
             }
         }
-        tap(sh.tile, xr, yr, r, g, b);                               // centre tap (:19)
+        tap(tile, rowb, xr, yr, r, g, b);                            // centre tap (:19)
         // (sum/255)/(quality*directions) (:32) as one multiplication: part of this path's re-association (≤ 1 ulp)
         const float norm = 1.0f/(255.0f*10.0f*8.0f);
         return {r*norm, g*norm, b*norm, 91.0f/80.0f};
