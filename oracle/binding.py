@@ -63,7 +63,7 @@ FRAGMENTS = dict(default=0, missing=1, visualizer=2, bars=3, waveform=4, multi_c
                  video=14, raymarch=15, mandelbrot=16, tetration=17)
 TEX_SLOTS = dict(background=0, iSpectrogram=1, iWaveform=2, child=3)
 TEX_HISTORY, TEX_HISTORY_DEPTH, TEX_SLOT_COUNT = 4, 12, 16
-DTYPES = {np.dtype(np.uint8): 0, np.dtype(np.float32): 1, np.dtype(np.uint16): 2}
+DTYPES = {np.dtype(np.uint8): 0, np.dtype(np.float32): 1, np.dtype(np.uint16): 2, np.dtype(np.float16): 3}
 MATH_FN = dict(sin=0, cos=1, atan2=2, atan=3, log2=4, exp2=5, pow=6, exp=7, mod=8, smoothstep=9, mix=10, sqrt=11, log=12)
 
 _lib = None

@@ -44,6 +44,35 @@ static inline int wrap_index(int i, int size, int repeat) {
     return (i < 0) ? 0 : ((i >= size) ? size - 1 : i);                    /* CLAMP_TO_EDGE */
 }
 
+/* IEEE binary16 <-> binary32 (numpy float16 textures, texture.py:28-38), written out: gcc 11 has no _Float16 on x86 */
+static inline float half_to_float(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exponent = (h >> 10) & 0x1Fu, mantissa = h & 0x3FFu, bits;
+    if (exponent == 0) {
+        if (mantissa == 0) bits = sign;
+        else {                                                              /* subnormal: renormalise */
+            int shift = 0;
+            while (!(mantissa & 0x400u)) { mantissa <<= 1; shift++; }
+            bits = sign | ((uint32_t)(113 - shift) << 23) | ((mantissa & 0x3FFu) << 13);
+        }
+    } else if (exponent == 31) bits = sign | 0x7F800000u | (mantissa << 13);
+    else bits = sign | ((exponent + 112u) << 23) | (mantissa << 13);
+    float f; memcpy(&f, &bits, 4); return f;
+}
+static inline uint16_t float_to_half(float f) {                            /* round to nearest even */
+    uint32_t bits; memcpy(&bits, &f, 4);
+    uint32_t sign = (bits >> 16) & 0x8000u, magnitude = bits & 0x7FFFFFFFu;
+    if (magnitude >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((magnitude > 0x7F800000u) ? 0x200u : 0u));
+    if (magnitude >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);        /* rounds to infinity */
+    if (magnitude < 0x33000001u) return (uint16_t)sign;                     /* rounds to zero */
+    int exponent = (int)(magnitude >> 23) - 127;
+    uint32_t mantissa = (magnitude & 0x7FFFFFu) | 0x800000u;
+    int shift = (exponent < -14) ? (-14 - exponent + 13) : 13;              /* subnormal halves lose more bits */
+    uint32_t kept = mantissa >> shift, rest = mantissa & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rest > half || (rest == half && (kept & 1u))) kept++;
+    if (exponent < -14) return (uint16_t)(sign | kept);                     /* kept may carry into the smallest normal: same bits */
+    return (uint16_t)(sign | (((uint32_t)(exponent + 15) << 10) + (kept - 0x400u)));
+}
+
 static inline v4 fetch_texel(const sfo_texture* t, int i, int j) {
     v4 c = V4(0.0f, 0.0f, 0.0f, 1.0f);
     float* out = &c.x;
@@ -51,6 +80,7 @@ static inline v4 fetch_texel(const sfo_texture* t, int i, int j) {
     for (int k = 0; k < t->components && k < 4; k++) {
         if (t->dtype == SFO_U8) out[k] = (float)((const uint8_t*)t->data)[base + k]/255.0f;
         else if (t->dtype == SFO_U16) out[k] = (float)((const uint16_t*)t->data)[base + k]/65535.0f;
+        else if (t->dtype == SFO_F16) out[k] = half_to_float(((const uint16_t*)t->data)[base + k]);
         else out[k] = ((const float*)t->data)[base + k];
     }
     return c;
@@ -686,6 +716,7 @@ static void render_rows(const job_t* jb) {
             const int n = jb->out_components;
             for (int k = 0; k < n; k++) {
                 if (jb->out_dtype == SFO_F32) ((float*)jb->out)[((int64_t)j*jb->wr + i)*n + k] = channel[k];
+                else if (jb->out_dtype == SFO_F16) ((uint16_t*)jb->out)[((int64_t)j*jb->wr + i)*n + k] = float_to_half(channel[k]);
                 else jb->out[((int64_t)j*jb->wr + i)*n + k] = to_unorm8(channel[k]);
             }
         }

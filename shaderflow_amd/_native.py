@@ -143,7 +143,7 @@ def as_ptr(array: np.ndarray, ctype):
     return array.ctypes.data_as(C.POINTER(ctype))
 
 
-NUMPY_DTYPES = {np.dtype(np.uint8): U8, np.dtype(np.float32): F32, np.dtype(np.uint16): U16}
+NUMPY_DTYPES = {np.dtype(np.uint8): U8, np.dtype(np.float32): F32, np.dtype(np.uint16): U16, np.dtype(np.float16): F16}
 
 
 class Context:

@@ -215,7 +215,7 @@ static void forget_texture(struct Texture* t);                      // defined a
 extern "C" int sfx_texture_create(sfx_handle h, int width, int height, int components, int dtype, sfx_handle* out) {
     CTX_OR_FAIL(c, h);
     if (!out || width < 1 || height < 1 || components < 1 || components > 4) return fail(SFX_E_INVALID, "texture %dx%dx%d", width, height, components);
-    if (dtype != SFX_U8 && dtype != SFX_F32 && dtype != SFX_U16) return fail(SFX_E_UNSUPPORTED, "texture dtype %d", dtype);
+    if (dtype != SFX_U8 && dtype != SFX_F32 && dtype != SFX_U16 && dtype != SFX_F16) return fail(SFX_E_UNSUPPORTED, "texture dtype %d", dtype);
     if (width > 65536 || height > 65536) return fail(SFX_E_TOO_LARGE, "texture size too large for this context: (%d, %d) > 65536", width, height);
     USE_DEVICE(c);
     Texture* t = new Texture();
@@ -687,7 +687,7 @@ extern "C" int sfx_render(sfx_handle h, sfx_handle target, int layer) {
     Texture* t = get<Texture>(target, MAGIC_TEX);
     if (!p || !t) return fail(SFX_E_INVALID, "invalid program or target handle");
     if (p->fragment == FRAG_FINAL) return fail(SFX_E_INVALID, "the final program is driven by sfx_resolve / sfx_render_resolve");
-    if (t->dtype != SFX_U8 && t->dtype != SFX_F32) return fail(SFX_E_UNSUPPORTED, "render target dtype %d", t->dtype);
+    if (t->dtype != SFX_U8 && t->dtype != SFX_F32 && t->dtype != SFX_F16) return fail(SFX_E_UNSUPPORTED, "render target dtype %d", t->dtype);
     USE_DEVICE(p->ctx);
     RenderArgs a;
     fill_args(p, a);

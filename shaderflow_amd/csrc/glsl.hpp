@@ -92,6 +92,12 @@ SF_HD vec4 texel(const Tex& t, int i, int j) {
         if (n > 1) c.y = (float)p[1]/65535.0f;
         if (n > 2) c.z = (float)p[2]/65535.0f;
         if (n > 3) c.w = (float)p[3]/65535.0f;
+    } else if (t.dtype == DT_F16) {                               // numpy float16 = IEEE binary16 ("f2", texture.py:28-38)
+        const _Float16* p = (const _Float16*)t.data + base;
+        c.x = (float)p[0];
+        if (n > 1) c.y = (float)p[1];
+        if (n > 2) c.z = (float)p[2];
+        if (n > 3) c.w = (float)p[3];
     }
     return c;
 }

@@ -90,6 +90,12 @@ __device__ __forceinline__ void store_target(const RenderArgs& a, long frame, in
         p[0] = (uint8_t)unorm8(c.x);
         if (n > 1) p[1] = (uint8_t)unorm8(c.y);
         if (n > 2) p[2] = (uint8_t)unorm8(c.z);
+    } else if (a.out_dtype == DT_F16) {                          // round to nearest even, as a GL half-float attachment stores
+        _Float16* p = (_Float16*)base + pix*n;
+        p[0] = (_Float16)c.x;
+        if (n > 1) p[1] = (_Float16)c.y;
+        if (n > 2) p[2] = (_Float16)c.z;
+        if (n > 3) p[3] = (_Float16)c.w;
     } else {
         float* p = (float*)base + pix*n;
         p[0] = c.x;

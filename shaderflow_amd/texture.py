@@ -182,7 +182,7 @@ class ShaderTexture(ShaderModule):
         if max(width, height) > limit:
             raise Exception(f"Texture size too large for this context: {(width, height)} > {limit}")
         if self.dtype not in N.NUMPY_DTYPES:
-            raise TypeError(f"Texture dtype {self.dtype} has no device format (uint8, uint16, float32)")
+            raise TypeError(f"Texture dtype {self.dtype} has no device format (uint8, uint16, float16, float32)")
         self._reshape_matrix()
         for (_, _, box) in self.boxes:
             box.release()

@@ -271,3 +271,20 @@ def test_destroyed_texture_is_unbound_not_dangling(gpu):
     assert gpu.lib.sfx_render(prog, target, 0) == N.OK
     N.check(gpu.lib.sfx_texture_destroy(texture))
     assert gpu.lib.sfx_render(prog, target, 0) != N.OK and b"background" in gpu.lib.sfx_last_error()
+
+
+def test_float16_textures_and_render_targets_bit_exact(gpu):
+    """numpy float16 textures ("f2", texture.py:28-38): sampled (nearest and linear) and used as a render target"""
+    rng = np.random.default_rng(8)
+    data = (rng.standard_normal((27, 48, 3))*3).astype(np.float16)
+    w, h = 96, 54
+    u = O.default_uniforms(w, h, iCameraZoom=0.8)
+    for filter in ("nearest", "linear"):
+        want = O.render("video", u, {0: O.make_texture(data, filter, True, True)}, w, h)
+        prog, _ = gpu.program("video")
+        gpu.set_uniforms(prog, u)
+        assert gpu.bind(prog, "iVideo", gpu.texture(data, filter, True, True))
+        assert np.array_equal(gpu.render(prog, w, h), want)
+    wide = O.render_to("video", u, {0: O.make_texture(data, "linear", True, True)}, w, h, 4, np.float16)
+    got = gpu.render(prog, w, h, comps=4, dtype=np.float16)
+    assert np.array_equal(got.view(np.uint16), wide.view(np.uint16))

@@ -260,3 +260,26 @@ def test_tetration_and_video_are_well_formed():
 def test_log_matches_libm():
     x = np.exp(np.random.default_rng(3).uniform(-20, 20, 2000)).astype(np.float32)
     assert np.allclose(O.math("log", x), np.log(x.astype(np.float64)), rtol=0, atol=4e-6*20)
+
+
+def test_float16_textures_and_targets_follow_numpy():
+    """numpy float16 is a texture format of the reference (texture.py:28-38 "f2"): reads widen exactly, writes round to nearest even"""
+    values = np.arange(65536, dtype=np.uint16).view(np.float16).reshape(256, 256, 1)
+    finite = np.isfinite(values[..., 0])
+    tex = O.make_texture(values, "nearest", False, False)
+    got = np.array([[O.sample(tex, (i + 0.5)/256, (j + 0.5)/256)[0] for i in range(0, 256, 5)] for j in range(0, 256, 3)], np.float32)
+    want = values[0:256:3, 0:256:5, 0].astype(np.float32)
+    keep = finite[0:256:3, 0:256:5]
+    assert np.array_equal(got[keep], want[keep]) and np.isnan(got[~keep & np.isnan(want)]).all()
+    u = O.default_uniforms(96, 54, iTime=1.3)
+    for fragment in ("shadertoy", "default"):
+        wide = O.render_to(fragment, u, {}, 96, 54, 4, np.float32)
+        half = O.render_to(fragment, u, {}, 96, 54, 4, np.float16)
+        assert np.array_equal(half, wide.astype(np.float16))
+    rng = np.random.default_rng(0)
+    magnitudes = (np.exp(rng.uniform(-30, 12, 20000))*rng.choice([-1, 1], 20000)).astype(np.float32)   # normals, subnormals, overflow
+    probe = O.make_texture(magnitudes.reshape(100, 200, 1), "nearest", False, False)
+    u = O.default_uniforms(200, 100)
+    rendered = O.render_to("video", u, {0: probe}, 200, 100, 1, np.float16)[..., 0]                      # video.frag copies the texel (identity camera)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(rendered, magnitudes.reshape(100, 200).astype(np.float16))
