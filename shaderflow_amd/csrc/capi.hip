@@ -583,6 +583,9 @@ static int launch_render(int fragment, const RenderArgs& a, int frames, hipStrea
 #ifndef VIS_THREAD_ROWS
 #define VIS_THREAD_ROWS 1
 #endif
+#ifndef VIS_BLOCK_PX
+#define VIS_BLOCK_PX 128
+#endif
 #ifndef VIS_ROWS_SS
 #define VIS_ROWS_SS 10
 #endif
@@ -596,10 +599,10 @@ template <class SHADER, int S> static void launch_fused_k(const RenderArgs& a, d
 }
 
 template <class SHADER> static int launch_fused_s(const RenderArgs& a, int ssaa, int frames, hipStream_t s, size_t dynamic_lds = 0) {
-    const int blocks_x = (a.w + 127)/128;
-    constexpr int rows = SHADER::FUSED_ROWS*SHADER::THREAD_ROWS, threads = 512*SHADER::THREAD_ROWS;
+    constexpr int rows = SHADER::FUSED_ROWS*SHADER::THREAD_ROWS, threads = 4*SHADER::BLOCK_PX*SHADER::THREAD_ROWS;
+    const int blocks_x = (a.w + SHADER::BLOCK_PX - 1)/SHADER::BLOCK_PX;          // S >= 2; S == 1 always covers 128 x 2 pixels
     const int row_blocks = (a.h + rows - 1)/rows;
-    if (ssaa == 1) launch_fused_k<SHADER, 1>(a, dim3(blocks_x*((a.h + 1)/2), 1, frames), dim3(256), dynamic_lds, s);
+    if (ssaa == 1) launch_fused_k<SHADER, 1>(a, dim3(((a.w + 127)/128)*((a.h + 1)/2), 1, frames), dim3(256), dynamic_lds, s);
     else if (ssaa == 2) launch_fused_k<SHADER, 2>(a, dim3(blocks_x*row_blocks, 1, frames), dim3(threads), dynamic_lds, s);
     else if (ssaa == 4) launch_fused_k<SHADER, 4>(a, dim3(blocks_x*row_blocks, 1, frames), dim3(threads), dynamic_lds, s);
     else return fail(SFX_E_UNSUPPORTED, "fused ssaa %d", ssaa);
@@ -645,19 +648,36 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
             if (!force_generic && visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) {
                 // the block shades 128*ssaa x rows*ssaa samples (S == 1: 128 x 2 pixels); pick the fixed tile when its window fits
                 int tw = 0, th = 0;
-                visualizer_window_bound(a, 128*ssaa, (ssaa == 1 ? 2 : VIS_FUSED_ROWS*VIS_THREAD_ROWS)*ssaa, tw, th);
+                visualizer_window_bound(a, (ssaa == 1 ? 128 : VIS_BLOCK_PX)*ssaa, (ssaa == 1 ? 2 : VIS_FUSED_ROWS*VIS_THREAD_ROWS)*ssaa, tw, th);
                 if (ssaa == 1 && tw <= 128 && th <= 10) return launch_fused_s<VisualizerShader<128, 10, 1>>(a, ssaa, frames, s);
                 if (ssaa != 1 && tw <= VIS_PITCH_SS && th <= VIS_ROWS_SS) {
                     // four samples per lane need more registers: 6 waves per SIMD without spills beat 8 with (8K 4xSSAA: 55 -> 63 frames/s)
                     if (ssaa == 4) return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, 6, VIS_FUSED_ROWS>>(a, ssaa, frames, s);
-                    return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_SS, VIS_FUSED_ROWS, VIS_THREAD_ROWS>>(a, ssaa, frames, s);
+                    return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_SS, VIS_FUSED_ROWS, VIS_THREAD_ROWS, VIS_BLOCK_PX>>(a, ssaa, frames, s);
                 }
-                if ((size_t)tw*th*48 <= VIS_LDS_LIMIT) {
-                    // denser backgrounds (1080p output at 2x SSAA over a 1080-row background: 0.43 texel per sample): the tile is
-                    // sized per launch in dynamic LDS; fewer blocks fit a CU, which is still several times the generic taps
+                if (ssaa != 1) {
+                    // denser backgrounds (1080p output at 2x SSAA over a 1080-row background: 0.43 texel per sample; backgrounds
+                    // larger than the output): the tile is sized per launch in dynamic LDS, and the block narrows from 128 to 64
+                    // or 32 pixels until its window leaves room for at least two blocks per CU
+                    const int rows = VIS_FUSED_ROWS*VIS_THREAD_ROWS*ssaa;
+                    int best_px = 0, best_tw = 0, best_th = 0;
+                    for (int px : {128, 64, 32}) {
+                        visualizer_window_bound(a, px*ssaa, rows, tw, th);
+                        const size_t lds = (size_t)tw*th*48;
+                        if (lds <= VIS_LDS_LIMIT) { best_px = px; best_tw = tw; best_th = th; if (lds <= 64*1024) break; }
+                    }
+                    if (best_px) {
+                        RenderArgs d = a;
+                        d.tile_pitch = best_tw; d.tile_rows = best_th;
+                        const size_t lds = (size_t)best_tw*best_th*48;
+                        if (best_px == 128) return launch_fused_s<VisualizerShader<0, 0, 4, VIS_FUSED_ROWS, VIS_THREAD_ROWS, 128>>(d, ssaa, frames, s, lds);
+                        if (best_px == 64) return launch_fused_s<VisualizerShader<0, 0, 4, VIS_FUSED_ROWS, VIS_THREAD_ROWS, 64>>(d, ssaa, frames, s, lds);
+                        return launch_fused_s<VisualizerShader<0, 0, 4, VIS_FUSED_ROWS, VIS_THREAD_ROWS, 32>>(d, ssaa, frames, s, lds);
+                    }
+                } else if ((size_t)tw*th*48 <= VIS_LDS_LIMIT) {
                     RenderArgs d = a;
                     d.tile_pitch = tw; d.tile_rows = th;
-                    return launch_fused_s<VisualizerShader<0, 0, 4, VIS_FUSED_ROWS, VIS_THREAD_ROWS>>(d, ssaa, frames, s, (size_t)tw*th*48);
+                    return launch_fused_s<VisualizerShader<0, 0, 4>>(d, ssaa, frames, s, (size_t)tw*th*48);
                 }
             }
             return launch_fused_s<PlainShader<FRAG_VISUALIZER>>(a, ssaa, frames, s);

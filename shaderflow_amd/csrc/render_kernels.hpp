@@ -117,6 +117,7 @@ template <int FRAGMENT> struct PlainShader {
 #endif
     static constexpr int FUSED_ROWS = PLAIN_FUSED_ROWS;  // output rows a lane group walks in the fused kernel (S >= 2)
     static constexpr int THREAD_ROWS = 1;                // output rows covered side by side by the block's threads (S >= 2)
+    static constexpr int BLOCK_PX = 128;                 // output pixels of one row per block of the fused kernel (S >= 2)
     struct State {};
     struct Shared {};
     __device__ static void pre(const RenderArgs&, const Frag&, bool, State&) {}
@@ -246,8 +247,8 @@ __device__ __forceinline__ int xcd_band_order(int b, int nblocks) {
 }
 
 // Writes one row segment of 128 RGB8 pixels (384 B) staged in LDS with 16-byte stores
-__device__ __forceinline__ void store_rgb_row(uint8_t* out_row, int x0, int w, const uint8_t* staged, int tid, int nthreads) {
-    const int npix = (w - x0 < 128) ? (w - x0) : 128;
+__device__ __forceinline__ void store_rgb_row(uint8_t* out_row, int x0, int w, const uint8_t* staged, int tid, int nthreads, int block_px) {
+    const int npix = (w - x0 < block_px) ? (w - x0) : block_px;
     const int nbytes = npix*3;
     uint8_t* dst = out_row + (long)x0*3;
     if ((nbytes & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
@@ -264,7 +265,7 @@ __device__ __forceinline__ void store_rgb_row(uint8_t* out_row, int x0, int w, c
 // After shading, every lane of a quad receives the quad's packed RGBA8 texels through DPP quad_perm moves and
 // lane c of the quad resolves colour channel c (lane 3 idles); lane 0 collects the three bytes.
 template <class SHADER, int S>
-__global__ __launch_bounds__(512*SHADER::THREAD_ROWS, SHADER::MIN_WAVES_PER_SIMD) void k_render_resolve(const RenderArgs a) {
+__global__ __launch_bounds__(4*SHADER::BLOCK_PX*SHADER::THREAD_ROWS, SHADER::MIN_WAVES_PER_SIMD) void k_render_resolve(const RenderArgs a) {
     constexpr int LANES = (S == 1) ? 1 : 4;
     constexpr int GROUP = (S*S)/LANES;               // supersamples of one pixel owned by one lane: 1, 1, 4
     constexpr int G = (S == 4) ? 2 : 1;              // side of that group
@@ -274,17 +275,18 @@ __global__ __launch_bounds__(512*SHADER::THREAD_ROWS, SHADER::MIN_WAVES_PER_SIMD
     constexpr int WALK = (S == 1) ? 1 : SHADER::FUSED_ROWS;               // pixels a lane group visits one after the other
     constexpr int ROWS = TROWS*WALK;
     constexpr int PER_LANE = GROUP*WALK;
-    __shared__ __attribute__((aligned(16))) uint8_t staged[ROWS][384];
+    constexpr int BPX = (S == 1) ? 128 : SHADER::BLOCK_PX;               // output pixels of a row per block (multiple of 16)
+    __shared__ __attribute__((aligned(16))) uint8_t staged[ROWS][BPX*3];
 
     Uniforms u; Tex tex[TEX_HISTORY];
     frame_view(a, blockIdx.z, u, tex);
-    const int blocks_x = (a.w + 127)/128;
+    const int blocks_x = (a.w + BPX - 1)/BPX;
     const int tile = xcd_band_order(blockIdx.x, gridDim.x);
     const int bx = tile % blocks_x, by = tile / blocks_x;
     const int tid = threadIdx.x;
     const int p = tid / LANES, sub = tid % LANES;
-    const int prow = p / 128;                        // 0 .. TROWS-1
-    const int px = bx*128 + (p % 128), py0 = by*ROWS + prow*WALK;
+    const int prow = p / BPX;                        // 0 .. TROWS-1
+    const int px = bx*BPX + (p % BPX), py0 = by*ROWS + prow*WALK;
 
     __shared__ typename SHADER::Shared shared;
     uint32_t mine[PER_LANE];
@@ -302,9 +304,9 @@ __global__ __launch_bounds__(512*SHADER::THREAD_ROWS, SHADER::MIN_WAVES_PER_SIMD
     }
     SF_TICK(a, 0);                                   // varyings + pre
     // the thread whose LAST sample is the block's top-right valid supersample (thread 0's first one is the bottom-left)
-    const int p_last = min(127, a.w - 1 - bx*128);
+    const int p_last = min(BPX - 1, a.w - 1 - bx*BPX);
     const int prow_last = (min(ROWS, a.h - by*ROWS) - 1)/WALK;
-    const int corner_tid = (prow_last*128 + p_last)*LANES + (LANES - 1);
+    const int corner_tid = (prow_last*BPX + p_last)*LANES + (LANES - 1);
     SHADER::template setup<PER_LANE>(a, tex, f, state, valid, shared, corner_tid);
     SF_TICK(a, 1);                                   // setup (window reduction + LDS staging)
 #pragma unroll
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(512*SHADER::THREAD_ROWS, SHADER::MIN_WAVES_PER_SIMD
     if constexpr (S == 1) {
         const uint32_t block[1] = {mine[0]};
         if (valid[0]) {
-            uint8_t* s = &staged[prow][(p % 128)*3];
+            uint8_t* s = &staged[prow][(p % BPX)*3];
             s[0] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 0);
             s[1] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 8);
             s[2] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 16);
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(512*SHADER::THREAD_ROWS, SHADER::MIN_WAVES_PER_SIMD
             const uint32_t channel = resolve_channel_any<S>(block, a.subsample, 8*(sub < 3 ? sub : 0));
             const uint32_t green = quad_lane1(channel), blue = quad_lane2(channel);
             if (valid[r*GROUP] && sub == 0) {
-                uint8_t* s = &staged[prow*WALK + r][(p % 128)*3];
+                uint8_t* s = &staged[prow*WALK + r][(p % BPX)*3];
                 s[0] = (uint8_t)channel; s[1] = (uint8_t)green; s[2] = (uint8_t)blue;
             }
         }
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(512*SHADER::THREAD_ROWS, SHADER::MIN_WAVES_PER_SIMD
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         const int y = by*ROWS + r;
-        if (y < a.h) store_rgb_row(frame + (long)(a.top_down ? a.h - 1 - y : y)*a.w*3, bx*128, a.w, staged[r], tid, blockDim.x);
+        if (y < a.h) store_rgb_row(frame + (long)(a.top_down ? a.h - 1 - y : y)*a.w*3, bx*BPX, a.w, staged[r], tid, blockDim.x, BPX);
     }
     SF_TICK(a, 3);                                   // resolve + store
 }

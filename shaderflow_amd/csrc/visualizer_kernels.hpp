@@ -41,8 +41,9 @@ __global__ void k_visualizer_consts(const FrameDyn* __restrict__ dyn, int frame0
 
 // TILE_PITCH: cells per tile row (48 B each): 128 covers a 128-pixel block without supersampling, 80 is enough when
 // the block's 128 pixels are 2x or 4x supersampled (the window is then ~64 cells wide) and lets more blocks share a CU.
-template <int TILE_PITCH, int TILE_ROWS, int MIN_WAVES, int ROWS_PER_BLOCK = 1, int THREAD_ROWS_PER_BLOCK = 1>
+template <int TILE_PITCH, int TILE_ROWS, int MIN_WAVES, int ROWS_PER_BLOCK = 1, int THREAD_ROWS_PER_BLOCK = 1, int BLOCK_PIXELS = 128>
 struct VisualizerShader {
+    static constexpr int BLOCK_PX = BLOCK_PIXELS;        // output pixels of a row per block of the fused kernel (S >= 2)
     static constexpr int FUSED_ROWS = ROWS_PER_BLOCK;    // rows a lane group walks; one LDS window serves FUSED_ROWS*THREAD_ROWS output rows
     static constexpr int THREAD_ROWS = THREAD_ROWS_PER_BLOCK;
     static constexpr int BLOCK_W = 128, BLOCK_H = 2;     // unfused block shape (render_kernels.hpp k_render)

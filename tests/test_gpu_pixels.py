@@ -179,6 +179,19 @@ def test_visualizer_lds_tile_kernel_with_a_moved_camera(gpu, camera, ssaa):
         assert_within_lsb(gpu.render_resolve(prog, w, h, ssaa, 2), O.resolve(screen, w, h, 2))
 
 
+@pytest.mark.parametrize("bg_size,ssaa", [((160, 90), 2), ((320, 180), 2), ((640, 360), 2), ((320, 180), 4)])
+def test_visualizer_dense_backgrounds_use_a_tile_sized_per_launch(gpu, bg_size, ssaa):
+    """Backgrounds with more texels per shaded sample than the fixed tile holds: dynamic-LDS tile, narrower blocks as needed"""
+    w, h = 200, 48
+    u, arrays, params = visualizer_inputs(w, h, seed=61, volume=0.9, bg_size=bg_size)
+    u.iSSAA = float(ssaa)
+    screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, threads=8)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    assert_within_lsb(gpu.render_resolve(prog, w, h, ssaa, 2), O.resolve(screen, w, h, 2))
+
+
 def test_visualizer_tile_overflow_falls_back(gpu):
     """A background far larger than the output: the tap window exceeds the LDS tile → generic taps, same result"""
     w, h = 64, 36
