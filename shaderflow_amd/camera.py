@@ -161,6 +161,23 @@ class ShaderCamera(ShaderModule):
         self.rotation.target = target/np.linalg.norm(target)
         return self
 
+    def rotate2d(self, degrees: float = 0.0):
+        """Turn the UP vector around FORWARD by a plane angle (camera.py:220-223)"""
+        target = Algebra.rotate_vector(self.zenith.value, Algebra.quaternion(self.forward_target, degrees))
+        return self.align(self.up_target, target)
+
+    def apply_zoom(self, value: float) -> None:
+        """Zooming in then out by the same amount returns to the same value (camera.py:280-285)"""
+        if (value > 0):
+            self.zoom.target *= (1 + value)
+        else:
+            self.zoom.target /= (1 - value)
+
+    def update(self):
+        """The headless part of camera.py:240-278: spherical mode keeps the horizon level; key and mouse motion is interactive"""
+        if self.mode == CameraMode.Spherical:
+            self.align(self.right_target, self.zenith.target, 90)
+
     def align(self, A, B, degrees: float = 0.0):
         A, B = DynamicNumber.extract(A, B)
         return self.rotate(Algebra.unit_vector(np.cross(A, B)), Algebra.angle(A, B) - degrees)
@@ -193,8 +210,21 @@ class ShaderCamera(ShaderModule):
     def backward(self): return (-1)*self.forward
 
     @property
+    def left_target(self): return (-1)*self.right_target
+    @property
+    def down_target(self): return (-1)*self.up_target
+    @property
+    def backward_target(self): return (-1)*self.forward_target
+
+    @property
     def x(self) -> float: return self.position.value[0]
+    @x.setter
+    def x(self, value: float): self.position.target[0] = value
     @property
     def y(self) -> float: return self.position.value[1]
+    @y.setter
+    def y(self, value: float): self.position.target[1] = value
     @property
     def z(self) -> float: return self.position.value[2]
+    @z.setter
+    def z(self, value: float): self.position.target[2] = value

@@ -255,3 +255,54 @@ def test_piano_module_writes_its_textures(tmp_path):
     assert channels.min() == -1 and set(np.unique(channels[60:72])) <= {-1.0, 0.0, 1.0, 2.0}
     names = {u.name for u in scene.shader.full_pipeline()}
     assert {"iPianoDynamic", "iPianoRollTime", "iPianoKeys0x0", "iPianoRoll0x0", "iPianoChan0x0", "iPianoTempo0x0"} <= names
+
+
+def test_scripted_camera_motion_matches_oracle():
+    """A scene that drives the camera from update() (move, zoom, rotate2d, projection): every frame equals the oracle rendered
+    with the uniforms the pipeline emitted for that frame (camera.py:196-235 → camera.glsl)"""
+    from examples.scenes import Basic
+    from shaderflow_amd.camera import CameraProjection
+    from shaderflow_amd.module import ShaderModule
+
+    snapshots = []
+
+    class Snapshot(ShaderModule):
+        def update(self):
+            snapshots.append({v.name: np.array(v.value, dtype=np.float64).copy() for v in self.scene.shader.full_pipeline() if v.type != "sampler2D" and v.value is not None})
+
+    class Moving(Basic):
+        def build(self):
+            Snapshot(scene=self)
+
+        def update(self):
+            self.camera.move(np.array([0.02, -0.01, 0.0]))
+            self.camera.apply_zoom(0.05)
+            self.camera.rotate2d(3.0)
+            if self.frame_count == 3:
+                self.camera.projection = CameraProjection.Stereoscopic
+            self.frame_count += 1
+        frame_count = 0
+
+    w, h = 96, 54
+    scene = Moving()
+    raw = scene.main(width=w, height=h, fps=30, time=0.2, output=bytes)
+    got = frames_of(raw, w, h)
+    assert got.shape[0] == 6 and len(snapshots) == 6
+    assert scene.camera.zoom.target == pytest.approx(1.05**6) and scene.camera.x == pytest.approx(scene.camera.position.value[0])
+    for k, snap in enumerate(snapshots):
+        u = O.default_uniforms(w, h)
+        for name, value in snap.items():
+            if hasattr(u, name):
+                cur = getattr(u, name)
+                if hasattr(cur, "__len__"):
+                    for i in range(len(cur)):
+                        cur[i] = float(value.ravel()[i])
+                else:
+                    setattr(u, name, type(cur)(value.ravel()[0]))
+        want = O.resolve(O.render("default", u, {}, w, h, threads=4), w, h, 2)
+        assert np.array_equal(got[k], want), (k, lsb_report(got[k], want))
+    assert not np.array_equal(got[0], got[5])
+    assert snapshots[5]["iCameraProjection"] == 1 and snapshots[2]["iCameraProjection"] == 0
+    scene.camera.x = 0.5
+    assert scene.camera.position.target[0] == 0.5
+    assert np.allclose(scene.camera.left_target, -scene.camera.right_target) and np.allclose(scene.camera.backward_target, -scene.camera.forward_target)
