@@ -306,3 +306,25 @@ def test_scripted_camera_motion_matches_oracle():
     scene.camera.x = 0.5
     assert scene.camera.position.target[0] == 0.5
     assert np.allclose(scene.camera.left_target, -scene.camera.right_target) and np.allclose(scene.camera.backward_target, -scene.camera.forward_target)
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root/"bench.py"), "--steps", "2", "--warmup", "1", "--frames-per-step", "3",
+                          "--width", "384", "--height", "216", "--cpu-rows", "8"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [line for line in out.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1
+    record = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in record, key
+    assert record["n_gpus"] == 1 and record["steps"] == 2 and record["warmup"] == 1 and record["unit"] == "frames/s"
+    assert record["value"] > 0 and record["higher_is_better"] is True and record["scaling"] == "weak" and record["vs_baseline"] is None
+    assert "workload" in record["config"] and "model" not in record["config"]
+    assert set(record["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and record["roofline"]["bound"] in ("hbm", "mfma")
+    assert set(record["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and record["cpu_baseline"]["kind"] in ("port", "reference")
