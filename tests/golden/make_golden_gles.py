@@ -288,6 +288,35 @@ def main() -> None:
     run("life_visuals", (EXAMPLES/"life/visuals.glsl").read_text(), O.default_uniforms(128, 72, iCameraZoom=0.9), 128, 72, textures,
         {name: (False, True, True) for name in textures})
 
+    # --- end to end: the reference's numpy audio state (pipeline.npz, captured from its own code) through its own GLSL:
+    #     visualizer.frag at 2x SSAA, then final.glsl — the frames the reference would hand to the encoder ----------------------
+    from shaderflow_amd import synth
+    P = np.load(HERE/"pipeline.npz")
+    fps, frames = float(P["meta"][0]), int(P["meta"][2])
+    w, h, ssaa, runtime = 192, 108, 2, frames/fps
+    image = synth.background_image(240, 135, seed=7)
+    bins = int(P["bins"][0])
+    out["frames.index"] = np.array([1, 10, 40, 99])
+    out["frames.size"] = np.array([w, h, ssaa])
+    vertex, fragment = build((EXAMPLES/"visualizer.frag").read_text(), ["background", "iSpectrogram", "iWaveform"])
+    visualizer = ctx.program(vertex, fragment)
+    vertex, fragment = build((SHADERS/"fragment/final.glsl").read_text().replace("uniform int iSubsample;", ""), ["iScreen"])
+    final = ctx.program(vertex, fragment)
+    background = ctx.texture(np.flipud(image), True, True, True)                                  # from_numpy flips (texture.py:327-335)
+    for k in out["frames.index"]:
+        t = float(P["time"][k])
+        u = O.default_uniforms(w, h, iTime=t, iTau=(t/runtime) % 1.0, iDuration=runtime, iSSAA=float(ssaa), iFramerate=fps, iFrame=round(t*fps),
+                               iAudioVolume=float(P["vol_value"][k]), iAudioVolumeIntegral=float(P["vol_integral"][k]), iAudioSTD=float(P["std_value"][k]),
+                               iSpectrogramLength=1, iSpectrogramBins=bins, iWaveformLength=180)
+        spectrogram = ctx.texture(np.ascontiguousarray(P["spec_value"][k]).reshape(bins, 1, 2), False, True, False)   # spectrogram.py:306 texel order
+        waveform = ctx.texture(np.ascontiguousarray(P["wave_row"][k]).reshape(1, 180, 2), True, False, False)
+        screen = ctx.draw(visualizer, w*ssaa, h*ssaa, uniform_values(u), {"background": background, "iSpectrogram": spectrogram, "iWaveform": waveform},
+                          {"vertex_position": QUAD, "vertex_gluv": QUAD})
+        frame = ctx.draw(final, w, h, uniform_values(O.default_uniforms(w, h), iSubsample=2), {"iScreen": ctx.texture(screen, True, False, False)},
+                         {"vertex_position": QUAD, "vertex_gluv": QUAD})
+        out[f"frames.{k}"] = frame[..., :3].copy()
+        print(f"frame {k:3d} t={t:.4f} volume {float(P['vol_value'][k]):.4f} mean {frame[..., :3].mean():.1f}")
+
     np.savez_compressed(HERE/"gles.npz", **out)
     print("gles.npz", (HERE/"gles.npz").stat().st_size, "bytes,", len([k for k in out if k.endswith('.image')]), "images")
 

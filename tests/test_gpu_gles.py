@@ -105,3 +105,26 @@ def test_life(gpu):
     for t in range(5):
         assert gpu.bind(prog, f"iLife{t}x0", gpu.texture(states[t], "nearest", True, True))
     assert np.array_equal(gpu.render(prog, 128, 72), G["life_visuals.image"])
+
+
+@pytest.mark.parametrize("batch", [None, False])
+def test_end_to_end_export_against_the_reference_pipeline(batch):
+    """The north star's parity statement, end to end and with no oracle in between: the product exports the Visualizer scene from
+    PCM (STFT, filterbank, DynamicNumbers, waveform and loudness on the device; fused fragment + resolve), and the frames are
+    compared with what the REFERENCE's own numpy audio code (pipeline.npz) fed through the REFERENCE's own GLSL (SwiftShader:
+    visualizer.frag at 2x SSAA, then final.glsl) produced. Bound: 2 LSB (1 between GL implementations + 1 of the tiled kernel),
+    with at least 99.9 % of the values within 1."""
+    from examples.scenes import Visualizer, make
+    from shaderflow_amd import synth
+    from tests.helpers import i16_to_f32
+    P = np.load(Path(__file__).parent/"golden"/"pipeline.npz")
+    fps, samplerate, frames = float(P["meta"][0]), int(P["meta"][1]), int(P["meta"][2])
+    w, h, ssaa = (int(v) for v in G["frames.size"])
+    scene = make(Visualizer, audio=(i16_to_f32(P["pcm_i16"]), samplerate), background=synth.background_image(240, 135, seed=7))
+    raw = scene.main(width=w, height=h, fps=fps, ssaa=ssaa, subsample=2, time=frames/fps, output=bytes, batch=batch)
+    got = np.frombuffer(raw, np.uint8).reshape(-1, h, w, 3)
+    assert got.shape[0] == frames
+    for k in G["frames.index"]:
+        want = G[f"frames.{k}"]
+        d = np.abs(got[k].astype(int) - want.astype(int))
+        assert d.max() <= 2 and (d <= 1).mean() >= 0.999, (int(k), d.max(), (d <= 1).mean())

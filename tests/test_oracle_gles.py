@@ -134,3 +134,27 @@ def test_life_simulation_and_visuals():
     visuals = O.render("life_visuals", O.default_uniforms(128, 72, iCameraZoom=0.9),
                        {t: O.make_texture(states[t], "nearest", True, True) for t in range(5)}, 128, 72, threads=4)
     assert np.array_equal(G["life_visuals.image"], visuals)
+
+
+def test_end_to_end_frames_from_the_reference_audio_state():
+    """The whole per-frame path of the reference on real inputs: its numpy audio state for a 1.5 s clip (pipeline.npz, captured
+    from its own code) drives its own GLSL — visualizer.frag at 2x SSAA, then final.glsl — on SwiftShader; the oracle, fed the
+    same audio state, produces the same RGB8 frames within 1 LSB."""
+    from shaderflow_amd import synth
+    P = np.load(Path(__file__).parent/"golden"/"pipeline.npz")
+    fps, frames = float(P["meta"][0]), int(P["meta"][2])
+    w, h, ssaa = (int(v) for v in G["frames.size"])
+    runtime, bins = frames/fps, int(P["bins"][0])
+    background = O.make_texture(np.flipud(synth.background_image(240, 135, seed=7)))
+    for k in G["frames.index"]:
+        t = float(P["time"][k])
+        u = O.default_uniforms(w, h, iTime=t, iTau=(t/runtime) % 1.0, iDuration=runtime, iSSAA=float(ssaa), iFramerate=fps, iFrame=round(t*fps),
+                               iAudioVolume=float(P["vol_value"][k]), iAudioVolumeIntegral=float(P["vol_integral"][k]), iAudioSTD=float(P["std_value"][k]),
+                               iSpectrogramLength=1, iSpectrogramBins=bins, iWaveformLength=180)
+        textures = {"background": background,
+                    "iSpectrogram": O.make_texture(np.ascontiguousarray(P["spec_value"][k]).reshape(bins, 1, 2), "nearest", True, False),
+                    "iWaveform": O.make_texture(np.ascontiguousarray(P["wave_row"][k]).reshape(1, 180, 2), "linear", False, False)}
+        want = O.resolve(O.render("visualizer", u, textures, w*ssaa, h*ssaa, threads=8), w, h, 2, threads=4)
+        got = G[f"frames.{k}"]
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert d.max() <= 1, (int(k), d.max(), (d > 1).sum())
