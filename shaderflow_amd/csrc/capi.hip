@@ -1185,8 +1185,10 @@ extern "C" int sfx_clock_tape_create(sfx_handle hc, int max_frames, sfx_handle* 
     t->magic = MAGIC_TAPE; t->plan = nullptr; t->audio = nullptr; t->ctx = c; t->max_frames = max_frames; t->n = 0;
     t->d_tell = nullptr; t->d_power = t->d_targets = t->d_columns = t->d_rows = t->d_loudness = t->d_state = nullptr;
     t->d_scalars = nullptr; t->d_coeff = nullptr; t->d_vol = t->d_std = nullptr; t->d_clock = nullptr;
-    HIP_TRY(hipMalloc(&t->d_dyn, sizeof(FrameDyn)*max_frames));
-    HIP_TRY(hipMalloc(&t->d_vis, sizeof(VisualizerConsts)*max_frames));
+    if (hipMalloc(&t->d_dyn, sizeof(FrameDyn)*max_frames) != hipSuccess || hipMalloc(&t->d_vis, sizeof(VisualizerConsts)*max_frames) != hipSuccess) {
+        sfx_tape_destroy(handle_of(t));
+        return fail(SFX_E_HIP, "clock tape of %d frames: out of device memory", max_frames);
+    }
     *out = handle_of(t);
     return SFX_OK;
 }
@@ -1203,20 +1205,27 @@ extern "C" int sfx_tape_create(sfx_handle hp, sfx_handle ha, const sfx_tape_desc
     t->n = p->bins*p->channels;
     const size_t F = max_frames;
     const int pts = desc->points > 0 ? desc->points : 1;
-    HIP_TRY(hipMalloc(&t->d_tell, sizeof(long)*F));
-    HIP_TRY(hipMalloc(&t->d_power, sizeof(float)*F*p->channels*p->fft_bins));
-    HIP_TRY(hipMalloc(&t->d_targets, sizeof(float)*F*t->n));
-    HIP_TRY(hipMalloc(&t->d_columns, sizeof(float)*F*t->n));
-    HIP_TRY(hipMalloc(&t->d_rows, sizeof(float)*F*pts*a->channels));
-    HIP_TRY(hipMalloc(&t->d_loudness, sizeof(float)*F*2));
-    HIP_TRY(hipMalloc(&t->d_state, sizeof(float)*3*t->n));
-    HIP_TRY(hipMalloc(&t->d_scalars, sizeof(ScalarState)*2));
-    HIP_TRY(hipMalloc(&t->d_dyn, sizeof(FrameDyn)*F));
-    HIP_TRY(hipMalloc(&t->d_coeff, sizeof(DynCoeffF32)*F));
-    HIP_TRY(hipMalloc(&t->d_vol, sizeof(DynCoeffF64)*F));
-    HIP_TRY(hipMalloc(&t->d_std, sizeof(DynCoeffF64)*F));
-    HIP_TRY(hipMalloc(&t->d_clock, sizeof(FrameClock)*F));
-    HIP_TRY(hipMalloc(&t->d_vis, sizeof(VisualizerConsts)*F));
+    t->d_tell = nullptr; t->d_power = t->d_targets = t->d_columns = t->d_rows = t->d_loudness = t->d_state = nullptr;
+    t->d_scalars = nullptr; t->d_dyn = nullptr; t->d_coeff = nullptr; t->d_vol = t->d_std = nullptr; t->d_clock = nullptr; t->d_vis = nullptr;
+    const bool allocated =
+        hipMalloc(&t->d_tell, sizeof(long)*F) == hipSuccess &&
+        hipMalloc(&t->d_power, sizeof(float)*F*p->channels*p->fft_bins) == hipSuccess &&
+        hipMalloc(&t->d_targets, sizeof(float)*F*t->n) == hipSuccess &&
+        hipMalloc(&t->d_columns, sizeof(float)*F*t->n) == hipSuccess &&
+        hipMalloc(&t->d_rows, sizeof(float)*F*pts*a->channels) == hipSuccess &&
+        hipMalloc(&t->d_loudness, sizeof(float)*F*2) == hipSuccess &&
+        hipMalloc(&t->d_state, sizeof(float)*3*t->n) == hipSuccess &&
+        hipMalloc(&t->d_scalars, sizeof(ScalarState)*2) == hipSuccess &&
+        hipMalloc(&t->d_dyn, sizeof(FrameDyn)*F) == hipSuccess &&
+        hipMalloc(&t->d_coeff, sizeof(DynCoeffF32)*F) == hipSuccess &&
+        hipMalloc(&t->d_vol, sizeof(DynCoeffF64)*F) == hipSuccess &&
+        hipMalloc(&t->d_std, sizeof(DynCoeffF64)*F) == hipSuccess &&
+        hipMalloc(&t->d_clock, sizeof(FrameClock)*F) == hipSuccess &&
+        hipMalloc(&t->d_vis, sizeof(VisualizerConsts)*F) == hipSuccess;
+    if (!allocated) {
+        sfx_tape_destroy(handle_of(t));                             // frees what was allocated (hipFree(nullptr) is a no-op)
+        return fail(SFX_E_HIP, "tape of %d frames: out of device memory", max_frames);
+    }
     *out = handle_of(t);
     return sfx_tape_reset(*out);
 }
