@@ -59,6 +59,26 @@ def read_wav(path: Path) -> tuple[np.ndarray, int]:
     return np.ascontiguousarray(pcm[:frames*channels].reshape(frames, channels)), int(samplerate)
 
 
+def decode_audio(path: Path) -> tuple[np.ndarray, int]:
+    """(samples float32 (n, channels), samplerate) of any audio file: RIFF/WAVE natively, other containers through an `ffmpeg`
+    binary as the reference does (pcm_f32le over a pipe, ffmpeg.py:1294-1301; samplerate and channels from ffprobe)"""
+    raw = Path(path)
+    with open(raw, "rb") as file:
+        magic = file.read(12)
+    if magic[:4] == b"RIFF" and magic[8:12] == b"WAVE":
+        return read_wav(raw)
+    import shutil
+    import subprocess
+    if not (shutil.which("ffmpeg") and shutil.which("ffprobe")):
+        raise ValueError(f"{path}: not a RIFF/WAVE file and no ffmpeg/ffprobe binary to decode it with (convert it to WAV first)")
+    from shaderflow_amd.ffmpeg import FFmpeg
+    samplerate, channels = FFmpeg.get_audio_samplerate(raw), FFmpeg.get_audio_channels(raw)
+    command = FFmpeg().quiet().input(path=raw).pcm("pcm_f32le").no_video().output("-").command
+    data = subprocess.run(command, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    pcm = np.frombuffer(data[:len(data)//(4*channels)*(4*channels)], "<f4")
+    return np.ascontiguousarray(pcm.reshape(-1, channels)), int(samplerate)
+
+
 def write_wav_f32(path: Path, samples: np.ndarray, samplerate: int) -> Path:
     """(n, channels) float32 → IEEE-float WAV (what the synthetic clips are stored as)"""
     samples = np.ascontiguousarray(samples, "<f4")
@@ -83,7 +103,7 @@ class BrokenAudioReader:
 
     def load(self) -> "BrokenAudioReader":
         if self.samples is None:
-            self.samples, self.samplerate = read_wav(self.path)
+            self.samples, self.samplerate = decode_audio(self.path)
         self.samples = np.ascontiguousarray(self.samples, np.float32)
         self.channels = self.samples.shape[1]
         return self

@@ -78,3 +78,38 @@ def test_audio_probes_answer_wav_files_natively(tmp_path):
     assert FFmpeg.get_audio_duration(path) == pytest.approx(0.2)
     assert np.array_equal(FFmpeg.get_audio_numpy(path), samples)
     assert FFmpeg.get_audio_samplerate(tmp_path/"missing.wav") is None and FFmpeg.get_video_resolution(tmp_path/"missing.mp4") is None
+
+
+FAKE_DECODER = """#!/usr/bin/env python3
+import sys
+src = sys.argv[sys.argv.index('-i') + 1]
+assert 'pcm_f32le' in sys.argv and '-' in sys.argv
+sys.stdout.buffer.write(open(src, 'rb').read()[4:])
+"""
+FAKE_PROBE = """#!/usr/bin/env python3
+import sys
+print('2' if 'stream=channels' in sys.argv else '32000')
+"""
+
+
+def test_non_wav_audio_goes_through_the_ffmpeg_binary(tmp_path, monkeypatch):
+    """Containers other than RIFF/WAVE are decoded like the reference does (ffmpeg.py:1294-1301): pcm_f32le on a pipe, format from
+    ffprobe; stand-in binaries here"""
+    import os
+    from shaderflow_amd.audio.reader import BrokenAudioReader, decode_audio
+    samples = np.random.default_rng(1).uniform(-1, 1, (3000, 2)).astype(np.float32)
+    (tmp_path/"song.flac").write_bytes(b"fLaC" + samples.tobytes())                 # not a real FLAC: the stand-in decoder strips the tag
+    bindir = tmp_path/"bin"
+    bindir.mkdir()
+    (bindir/"ffmpeg").write_text(FAKE_DECODER)
+    (bindir/"ffprobe").write_text(FAKE_PROBE)
+    for tool in ("ffmpeg", "ffprobe"):
+        (bindir/tool).chmod(0o755)
+    monkeypatch.setenv("PATH", "/nonexistent")
+    with pytest.raises(ValueError, match="no ffmpeg"):
+        decode_audio(tmp_path/"song.flac")
+    monkeypatch.setenv("PATH", f"{bindir}{os.pathsep}/usr/bin{os.pathsep}/bin")
+    decoded, samplerate = decode_audio(tmp_path/"song.flac")
+    assert samplerate == 32000 and np.array_equal(decoded, samples)
+    reader = BrokenAudioReader(path=tmp_path/"song.flac").load()
+    assert reader.channels == 2 and reader.samplerate == 32000
