@@ -166,6 +166,11 @@ class ExportingHelper:
         if self.ring is not None and self.frame > 0:
             N.check(N.lib().sfx_ring_stream_wait(self.ring, (self.frame - 1) % self.slots))
 
+    def drain(self) -> None:
+        """Every queued frame has left its device buffer and reached the sink (gathered buffers are reused right after)"""
+        if self.ring is not None and self.ring.value:
+            N.check(N.lib().sfx_ring_pipe_sync(self.ring, -1))
+
     def pipe_device(self, device_ptr: int, turbo: bool = True, fence: Optional[int] = None) -> None:
         """Same, for a frame that lives in a raw device buffer (frame tape batches)"""
         if (self.fileno is None) or (self.ring is None):

@@ -37,19 +37,28 @@ def shard_batches(first: int, last: int, batch: int) -> list[tuple[int, int]]:
 
 
 class FrameGather:
-    """Two-slot asynchronous gather of equally sized byte buffers to rank 0"""
+    """Two-slot asynchronous gather of equally sized byte buffers to rank 0.
+
+    RCCL ("nccl") gathers device buffers directly. The gloo backend has no device gather, so device buffers are staged
+    through host memory there (tests with several processes on one GPU, CPU-only process groups)."""
 
     def __init__(self, world: int, rank: int, nbytes: int, device, slots: int = 2):
         import torch
+        import torch.distributed as dist
         self.world, self.rank, self.nbytes = world, rank, nbytes
+        self.device = torch.device(device)
+        self.staged = (dist.get_backend() == "gloo") and (self.device.type != "cpu")
+        where = torch.device("cpu") if self.staged else self.device
         self.pending: list = [None]*slots
         self.received: list[Optional[list]] = [None]*slots
         if rank == 0:
-            self.received = [[torch.empty(nbytes, dtype=torch.uint8, device=device) for _ in range(world)] for _ in range(slots)]
+            self.received = [[torch.empty(nbytes, dtype=torch.uint8, device=where) for _ in range(world)] for _ in range(slots)]
 
     def start(self, slot: int, tensor) -> None:
         import torch.distributed as dist
         self.wait(slot)
+        if self.staged:
+            tensor = tensor.cpu()
         self.pending[slot] = dist.gather(tensor, gather_list=self.received[slot] if self.rank == 0 else None, dst=0, async_op=True)
 
     def wait(self, slot: int) -> None:
@@ -63,8 +72,10 @@ class FrameGather:
             self.wait(slot)
 
     def frames(self, slot: int) -> list:
-        """Rank 0: the `world` buffers of the last completed gather of `slot`, in rank order"""
+        """Rank 0: the `world` buffers of the last completed gather of `slot`, in rank order (on the gather's device)"""
         self.wait(slot)
+        if self.staged and self.received[slot] is not None:
+            return [buffer.to(self.device) for buffer in self.received[slot]]
         return self.received[slot]
 
 

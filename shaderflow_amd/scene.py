@@ -405,6 +405,7 @@ class ShaderScene(ShaderModule):
             for i in range(count):
                 export.pipe_device(pointer_of(buffer) + i*frame_bytes, turbo=turbo)
                 export.update()
+            export.drain()                                      # the gathered buffer is overwritten by a later gather
 
         try:
             if gather is None:

@@ -249,8 +249,11 @@ class FrameTape:
                     self.render(count, buffer.data_ptr())
                     context.synchronize()                       # the context's stream is not torch's: order before the gather
 
-                round_robin_export(world, rank, batches, self.build, render,
-                                   lambda buffer, count: emit_frames(buffer.data_ptr(), count), gather, buffers, frame_bytes)
+                def emit(buffer, count):                        # rank 0: `buffer` is a gathered batch, overwritten by a later gather
+                    emit_frames(buffer.data_ptr(), count)
+                    export.drain()
+
+                round_robin_export(world, rank, batches, self.build, render, emit, gather, buffers, frame_bytes)
                 if rank != 0:
                     export.frame = total
             scene.time, scene.dt, scene.rdt = self.times[-1], self.dts[-1], self.dts[-1]      # clock of the last frame

@@ -1,0 +1,60 @@
+"""
+The sharded export with real renders: two processes of one `gloo` process group share the test GPU (RCCL does not allow two
+ranks on one device; FrameGather stages device buffers through host memory under gloo) and run the product's own
+multi-rank code paths — the tape's round-robin batches (tape.py) and the frame loop with temporal warm-up (scene.py) —
+end to end; rank 0's output must be the single-process export, byte for byte.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(name: str):
+    import examples.scenes as scenes
+    from shaderflow_amd import synth
+    if name == "Visualizer":
+        return scenes.make(scenes.Visualizer, audio=(synth.sweep_clip(3.0, 44100), 44100), background=synth.background_image(160, 90, seed=2))
+    return scenes.make(getattr(scenes, name), background=synth.background_image(120, 68, seed=4))
+
+
+KW = {"Visualizer": dict(width=96, height=54, fps=60.0, ssaa=2, time=130/60), "MotionBlur": dict(width=64, height=36, fps=30.0, ssaa=1, time=70/30)}
+
+
+def _rank(rank: int, world: int, port: int, name: str, path: str):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _build(name).main(output=path, **KW[name])
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("name", ["Visualizer", "MotionBlur"])
+def test_two_ranks_on_one_gpu_reproduce_the_single_process_export(tmp_path, name):
+    whole = _build(name).main(output=bytes, **KW[name])
+    path = str(tmp_path/"sharded.rgb")
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, name, path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    sharded = open(path, "rb").read()
+    assert len(sharded) == len(whole)
+    assert sharded == whole, f"{np.count_nonzero(np.frombuffer(sharded, np.uint8) != np.frombuffer(whole, np.uint8))} bytes differ"
