@@ -112,12 +112,18 @@ def main() -> None:
     import numpy as np
     import torch                                                  # before the HIP library: one HIP runtime per process
 
+    local_rank %= max(1, torch.cuda.device_count())               # more ranks than devices only happens in the gloo test below
     torch.cuda.set_device(local_rank)
     distributed = world > 1 or os.environ.get("SHADERFLOW_FORCE_DIST") == "1"     # the env var exercises the RCCL path on one GPU
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL ("nccl") is the backend; SHADERFLOW_DIST_BACKEND=gloo lets tests run several ranks on ONE device (RCCL refuses that)
+        backend = os.environ.get("SHADERFLOW_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from examples.scenes import MusicBars, Visualizer, make
     from shaderflow_amd import _native as N

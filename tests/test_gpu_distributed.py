@@ -58,3 +58,26 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_export(tmp_path, name
     sharded = open(path, "rb").read()
     assert len(sharded) == len(whole)
     assert sharded == whole, f"{np.count_nonzero(np.frombuffer(sharded, np.uint8) != np.frombuffer(whole, np.uint8))} bytes differ"
+
+
+@pytest.mark.timeout(400)
+def test_bench_with_two_ranks_prints_one_line_for_the_whole_job():
+    """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one rank per GPU), here with two ranks on the one
+    test GPU over gloo: barrier + max-over-ranks timing, the gather to rank 0, ONE JSON line from rank 0 with the aggregate"""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, SHADERFLOW_DIST_BACKEND="gloo")
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), str(root/"bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--frames-per-step", "4", "--width", "384", "--height", "216"]
+    out = subprocess.run(command, capture_output=True, text=True, timeout=360, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [line for line in out.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    record = json.loads(lines[0])
+    assert record["n_gpus"] == 2 and record["steps"] == 2 and record["scaling"] == "weak"
+    assert record["config"]["global_frames_per_step"] == 8 and record["value"] > 0
+    assert "cpu_baseline" not in record                                       # rank 0 at N = 1 only
