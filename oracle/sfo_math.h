@@ -38,6 +38,14 @@ static inline float sfo_floor(float x) { return floorf(x); }
 static inline float sfo_fract(float x) { return x - floorf(x); }
 static inline float sfo_mod(float x, float y) { return x - y*floorf(x/y); }          /* GLSL 8.3 */
 static inline float sfo_mix(float a, float b, float t) { return a*(1.0f - t) + b*t; }   /* GLSL 8.3 */
+/* GLSL int(float) on arbitrary values: C leaves NaN and out-of-range conversions undefined (x86 yields INT_MIN, GPUs 0 or
+ * saturation); the rule of both implementations is the GPU's: NaN -> 0, saturate */
+static inline int32_t sfo_to_int(float x) {
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return INT32_MAX;
+    if (x <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)x;
+}
 static inline float sfo_smoothstep(float e0, float e1, float x) {
     float t = sfo_clamp((x - e0)/(e1 - e0), 0.0f, 1.0f);
     return t*t*(3.0f - 2.0f*t);

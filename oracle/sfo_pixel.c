@@ -185,7 +185,7 @@ static v3 hsv2rgb(float h, float s, float v) {
     float x = c*(1.0f - sfo_abs(sfo_mod(h/(SFO_PI/3.0f), 2.0f) - 1.0f));
     float m = v - c;
     v3 rgb;
-    switch ((int)floorf(6.0f*(h/(2.0f*SFO_PI)))) {
+    switch (sfo_to_int(floorf(6.0f*(h/(2.0f*SFO_PI))))) {
         case 0: rgb = V3(c, x, 0.0f); break;
         case 1: rgb = V3(x, c, 0.0f); break;
         case 2: rgb = V3(0.0f, c, x); break;
@@ -545,8 +545,8 @@ static v4 frag_life_simulation(const frag_in* f) {
         out.w = 1.0f;
         return out;
     }
-    int pixel_x = (int)(f->astuv.x*f->u->user[0]);
-    int pixel_y = (int)(f->astuv.y*f->u->user[1]);
+    int pixel_x = sfo_to_int(f->astuv.x*f->u->user[0]);
+    int pixel_y = sfo_to_int(f->astuv.y*f->u->user[1]);
     int near = 0, current = 0;
     for (int x = -1; x <= 1; x++)
         for (int y = -1; y <= 1; y++) {
@@ -633,7 +633,7 @@ static v4 frag_mandelbrot(const frag_in* f) {
     if (!cam.out_of_bounds) {
         float zx = cam.gluv.x - 0.5f, zy = cam.gluv.y - 0.0f;
         float cx = zx, cy = zy;
-        int quality = (int)(1000.0f*f->u->iQuality);
+        int quality = sfo_to_int(1000.0f*f->u->iQuality);
         int iter = 0;
         for (; iter < quality; iter++) {
             if (sfo_sqrt(zx*zx + zy*zy) > 3.0f) break;

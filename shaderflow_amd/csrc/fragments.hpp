@@ -315,7 +315,7 @@ SF_HD vec4 frag_life_simulation(const Frag& f) {
         col.x = texture(previous, f.astuv).x;
         return col;
     }
-    const int px = (int)(f.astuv.x*f.u->user[USER_LIFE_SIZE]), py = (int)(f.astuv.y*f.u->user[USER_LIFE_SIZE + 1]);   // :32
+    const int px = sf::to_int(f.astuv.x*f.u->user[USER_LIFE_SIZE]), py = sf::to_int(f.astuv.y*f.u->user[USER_LIFE_SIZE + 1]);   // :32
     int near = 0, current = 0;
     for (int x = -1; x <= 1; x++) {
         for (int y = -1; y <= 1; y++) {
@@ -397,7 +397,7 @@ SF_HD vec4 frag_mandelbrot(const Frag& f) {
     } else {
         vec2 z = cam.gluv - vec2{0.5f, 0.0f};
         const vec2 c = z;
-        const int quality = (int)(1000.0f*f.u->iQuality);
+        const int quality = sf::to_int(1000.0f*f.u->iQuality);
         int iter = 0;
         for (; iter < quality; iter++) {
             if (length(z) > 3.0f) break;

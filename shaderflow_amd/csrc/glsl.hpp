@@ -251,7 +251,7 @@ SF_HD vec3 hsv2rgb(float h, float s, float v) {                                 
     float x = c*(1.0f - sf::abs(sf::mod(h/(PI/3.0f), 2.0f) - 1.0f));
     float m = v - c;
     vec3 rgb;
-    switch ((int)::floorf(6.0f*(h/(2.0f*PI)))) {
+    switch (sf::to_int(::floorf(6.0f*(h/(2.0f*PI))))) {
         case 0: rgb = {c, x, 0.0f}; break;
         case 1: rgb = {x, c, 0.0f}; break;
         case 2: rgb = {0.0f, c, x}; break;

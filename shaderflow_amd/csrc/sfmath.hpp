@@ -51,6 +51,14 @@ SF_HD float mod(float x, float y) { return x - y*::floorf(x/y); }
 SF_HD float mix(float a, float b, float t) { return a*(1.0f - t) + b*t; }
 SF_HD float sign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 SF_HD float sqrt(float x) { return ::sqrtf(x); }
+// GLSL int(float) where the value can be anything (NaN out of a diverging iteration, huge products): C leaves those
+// conversions undefined and CPUs and GPUs disagree, so both implementations fix the GPU's rule: NaN -> 0, saturate
+SF_HD int to_int(float x) {
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return -2147483647 - 1;
+    return (int)x;
+}
 SF_HD float smoothstep(float e0, float e1, float x) {
     float t = sf::clamp((x - e0)/(e1 - e0), 0.0f, 1.0f);
     return t*t*(3.0f - 2.0f*t);

@@ -1,0 +1,82 @@
+"""
+Seeded differential runs of the HIP kernels against the oracle over odd sizes, cameras, volumes, background shapes and SSAA pairs
+— partial blocks, tiles of every kind (fixed, per-launch, narrowed blocks, generic fallback), wrap modes. Bounds as everywhere:
+generic kernels bit-exact, the tiled visualizer and the fused resolve within 1 LSB.
+"""
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from tests.helpers import Gpu, gpu_bind_all, lsb_report, oracle_textures, visualizer_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    g = Gpu()
+    yield g
+    g.close()
+
+
+def random_camera(rng):
+    if rng.random() < 0.5:
+        return {}
+    return dict(iCameraProjection=int(rng.integers(0, 3)), iCameraZoom=float(rng.uniform(0.6, 1.8)), iCameraIsometric=float(rng.uniform(0, 0.4)),
+                iCameraPosition=(float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.2, 0.2)), 0.0), iCameraSeparation=float(rng.uniform(0.02, 0.1)))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_visualizer_random_configurations(gpu, seed):
+    rng = np.random.default_rng(1000 + seed)
+    w, h = int(rng.integers(17, 260)), int(rng.integers(9, 120))
+    ssaa, subsample = [(1, 1), (2, 2), (2, 1), (4, 2), (4, 4), (1, 2), (3, 2)][seed % 7]
+    bg_size = (int(rng.integers(8, 400)), int(rng.integers(8, 260)))
+    u, arrays, params = visualizer_inputs(w, h, seed=seed, volume=float(rng.choice([0.0, 0.2, 0.7, 1.1, 2.0])), bg_size=bg_size,
+                                          time=float(rng.uniform(0, 30)), std=float(rng.uniform(0, 0.5)))
+    params["background"] = ("linear", bool(rng.integers(0, 2)), bool(rng.integers(0, 2)))
+    for key, value in random_camera(rng).items():
+        cur = getattr(u, key)
+        if hasattr(cur, "__len__"):
+            for i, v in enumerate(value):
+                cur[i] = v
+        else:
+            setattr(u, key, value)
+    u.iSSAA = float(ssaa)
+    screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, threads=8)
+    want = O.resolve(screen, w, h, subsample, threads=4)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    from shaderflow_amd import _native as N
+    if N.lib().sfx_fused_supported(ssaa*1000, subsample):
+        got = gpu.render_resolve(prog, w, h, ssaa, subsample)
+    else:
+        shaded = gpu.render(prog, w*ssaa, h*ssaa)
+        d = np.abs(shaded.astype(int) - screen.astype(int))
+        assert d.max() <= 1, lsb_report(shaded, screen)
+        got = gpu.resolve(screen, w, h, subsample)
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1, (seed, (w, h, ssaa, subsample, bg_size), lsb_report(got, want))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_generic_fragments_random_configurations(gpu, seed):
+    rng = np.random.default_rng(2000 + seed)
+    name = ["default", "bars", "waveform", "shadertoy", "raymarch", "mandelbrot", "missing", "tetration"][seed % 8]
+    w, h = int(rng.integers(5, 300)), int(rng.integers(3, 150))
+    u, arrays, params = visualizer_inputs(w, h, seed=seed, time=float(rng.uniform(0, 20)))
+    for key, value in random_camera(rng).items():
+        cur = getattr(u, key)
+        if hasattr(cur, "__len__"):
+            for i, v in enumerate(value):
+                cur[i] = v
+        else:
+            setattr(u, key, value)
+    u.iQuality = float(rng.uniform(0.05, 0.3))
+    want = O.render(name, u, oracle_textures(arrays, params), w, h, threads=8)
+    prog, _ = gpu.program(name)
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, {k: v for k, v in arrays.items() if k != "background"}, params)
+    got = gpu.render(prog, w, h)
+    assert np.array_equal(got, want), (name, (w, h), lsb_report(got, want))
