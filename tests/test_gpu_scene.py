@@ -328,3 +328,22 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert "workload" in record["config"] and "model" not in record["config"]
     assert set(record["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and record["roofline"]["bound"] in ("hbm", "mfma")
     assert set(record["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and record["cpu_baseline"]["kind"] in ("port", "reference")
+
+
+@pytest.mark.parametrize("samplerate,fps,seconds", [(48000, 30.0, 0.4), (22050, 50.0, 0.3), (32000, 24.0, 0.5)])
+def test_visualizer_other_sample_rates_and_frame_rates(samplerate, fps, seconds):
+    """The chunk arithmetic, window schedule, filterbank and DynamicNumber coefficients all depend on (samplerate, fps): the tape and
+    the frame loop against the oracle's audio + pixel pipeline for rates other than 44.1 kHz / 60 fps"""
+    from examples.scenes import Visualizer, make
+    w, h, ssaa = 112, 64, 2
+    rng = np.random.default_rng(int(samplerate + fps))
+    t = np.arange(int(samplerate*(seconds + 0.2)))/samplerate
+    pcm = np.stack([0.6*np.sin(2*np.pi*(200 + 900*t)*t), 0.5*np.sin(2*np.pi*330*t) + 0.1*rng.standard_normal(len(t))], axis=1).astype(np.float32)
+    background = synth.background_image(128, 72, seed=9)
+    frames = round(seconds*fps)
+    want = oracle_visualizer_frames(pcm, samplerate, background, w, h, ssaa, 2, fps, frames, seconds)
+    for batch in (None, False):
+        raw = make(Visualizer, audio=(pcm, samplerate), background=background).main(width=w, height=h, fps=fps, ssaa=ssaa, time=seconds, output=bytes, batch=batch)
+        got = frames_of(raw, w, h)
+        assert got.shape == want.shape
+        mostly_within_one_lsb(got, want)
