@@ -1161,6 +1161,7 @@ struct Tape : Object {
     float* d_state; ScalarState* d_scalars; FrameDyn* d_dyn;
     DynCoeffF32* d_coeff; DynCoeffF64 *d_vol, *d_std; FrameClock* d_clock;
     VisualizerConsts* d_vis;
+    float* d_bars = nullptr;         // sqrt(column/1000) of every frame of the batch (visualizer.frag:45)
     void* d_screen = nullptr; size_t screen_bytes = 0;   // iScreen scratch of the two-pass path (frames of a batch)
 };
 
@@ -1221,7 +1222,8 @@ extern "C" int sfx_tape_create(sfx_handle hp, sfx_handle ha, const sfx_tape_desc
         hipMalloc(&t->d_vol, sizeof(DynCoeffF64)*F) == hipSuccess &&
         hipMalloc(&t->d_std, sizeof(DynCoeffF64)*F) == hipSuccess &&
         hipMalloc(&t->d_clock, sizeof(FrameClock)*F) == hipSuccess &&
-        hipMalloc(&t->d_vis, sizeof(VisualizerConsts)*F) == hipSuccess;
+        hipMalloc(&t->d_vis, sizeof(VisualizerConsts)*F) == hipSuccess &&
+        hipMalloc(&t->d_bars, sizeof(float)*F*t->n) == hipSuccess;
     if (!allocated) {
         sfx_tape_destroy(handle_of(t));                             // frees what was allocated (hipFree(nullptr) is a no-op)
         return fail(SFX_E_HIP, "tape of %d frames: out of device memory", max_frames);
@@ -1297,7 +1299,7 @@ extern "C" int sfx_tape_destroy(sfx_handle h) {
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
     hipFree(t->d_tell); hipFree(t->d_power); hipFree(t->d_targets); hipFree(t->d_columns); hipFree(t->d_rows); hipFree(t->d_loudness);
-    hipFree(t->d_state); hipFree(t->d_scalars); hipFree(t->d_dyn); hipFree(t->d_coeff); hipFree(t->d_vol); hipFree(t->d_std); hipFree(t->d_clock); hipFree(t->d_vis); hipFree(t->d_screen);
+    hipFree(t->d_state); hipFree(t->d_scalars); hipFree(t->d_dyn); hipFree(t->d_coeff); hipFree(t->d_vol); hipFree(t->d_std); hipFree(t->d_clock); hipFree(t->d_vis); hipFree(t->d_bars); hipFree(t->d_screen);
     t->magic = 0;
     delete t;
     return SFX_OK;
@@ -1348,6 +1350,12 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
     if (p->fragment == FRAG_VISUALIZER) {
         hipLaunchKernelGGL(k_visualizer_consts, dim3((nframes + 63)/64), dim3(64), 0, p->ctx->stream, t->d_dyn, frame0, nframes, t->d_vis);
         a.vis_consts = t->d_vis;
+        if (t->plan && a.tex[TEX_SPECTROGRAM].components == 2 && a.tex[TEX_SPECTROGRAM].filter == FILTER_NEAREST) {
+            const long count = (long)nframes*t->n;
+            hipLaunchKernelGGL(k_visualizer_bars, dim3((unsigned)((count + 255)/256)), dim3(256), 0, p->ctx->stream,
+                               t->d_columns + (long)frame0*t->n, count, t->d_bars + (long)frame0*t->n);
+            a.tape_bars = t->d_bars;
+        }
     }
     if (fused) {
         if ((rc = launch_fused(p->fragment, a, ssaa, nframes, p->ctx->stream))) return rc;

@@ -166,7 +166,7 @@ template <> struct ColourMath<true> {
 #endif
 
 template <bool COLOUR_ONLY_FAST = false>
-SF_HD vec4 visualizer_post(const Frag& f, const VisualizerPre& p, const VisualizerConsts& c, vec4 col) {
+SF_HD vec4 visualizer_post(const Frag& f, const VisualizerPre& p, const VisualizerConsts& c, vec4 col, const float* bars = nullptr) {
     using CM = ColourMath<COLOUR_ONLY_FAST>;
     const vec3 space = vec3{1.0f, 11.0f, 26.0f}/255.0f;                                        // :9
     col = col*(1.0f + c.flash*CM::pow6(sf::clamp(CM::length(f.agluv) - 0.3f, 0.0f, 1.0f)));   // :36
@@ -176,8 +176,17 @@ SF_HD vec4 visualizer_post(const Frag& f, const VisualizerPre& p, const Visualiz
     const float radius = 0.17f;
 
     float circle = sf::abs(atan1n(music_uv));                                                  // :44
-    vec2 s = texture_xy(f.tex[TEX_SPECTROGRAM], vec2{0.0f, circle});
-    vec2 freq = {sf::sqrt(s.x/1000.0f), sf::sqrt(s.y/1000.0f)};                               // :45
+    vec2 freq;
+    if (bars) {
+        // the nearest texel texture() would pick in the one-column RG32F spectrogram (glsl.hpp texture_xy: u = 0, clamp in y),
+        // read from the per-frame table of sqrt(texel/1000) (k_visualizer_bars): the same bits, evaluated once per texel
+        const Tex& sp = f.tex[TEX_SPECTROGRAM];
+        const int j = wrap_texel((int)::floorf(circle*(float)sp.height), sp.height, sp.repeat_y);
+        freq = {bars[2*j], bars[2*j + 1]};
+    } else {
+        vec2 s = texture_xy(f.tex[TEX_SPECTROGRAM], vec2{0.0f, circle});
+        freq = {sf::sqrt(s.x/1000.0f), sf::sqrt(s.y/1000.0f)};                                // :45
+    }
     freq = freq*(0.05f + 3.0f*sf::smoothstep(0.0f, 2.0f, circle));                            // :46
 
     float len = length(music_uv);

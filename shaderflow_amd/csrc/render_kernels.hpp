@@ -30,6 +30,7 @@ struct RenderArgs {
     // tape (batched export) mode: per-frame uniforms and audio textures come from device memory
     const FrameDyn* dyn;
     const float* tape_spectrogram; long spectrogram_stride;   // floats per frame
+    const float* tape_bars;          // sqrt(column/1000) per frame (k_visualizer_bars), same stride; visualizer only
     const float* tape_waveform; long waveform_stride;
     int frame0;
     // radial-blur tap table of visualizer.frag:26-31 (unit displacements cos/sin(angle)*walk)

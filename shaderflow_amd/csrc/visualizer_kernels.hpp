@@ -39,6 +39,14 @@ __global__ void k_visualizer_consts(const FrameDyn* __restrict__ dyn, int frame0
     out[frame0 + k] = visualizer_consts(d.iTime, d.iAudioVolume, d.iAudioSTD);
 }
 
+// Bar heights per spectrogram texel: visualizer.frag:45 takes sqrt(texel/1000) of the column texel a fragment looks up; the
+// value depends on the texel only, so the tape path evaluates it once per (frame, bin, channel) — the same IEEE division
+// and square root, hoisted out of the 33 M fragments of a frame.
+__global__ void k_visualizer_bars(const float* __restrict__ columns, long n, float* __restrict__ bars) {
+    const long k = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (k < n) bars[k] = sf::sqrt(columns[k]/1000.0f);
+}
+
 // TILE_PITCH: cells per tile row (48 B each): 128 covers a 128-pixel block without supersampling, 80 is enough when
 // the block's 128 pixels are 2x or 4x supersampled (the window is then ~64 cells wide) and lets more blocks share a CU.
 template <int TILE_PITCH, int TILE_ROWS, int MIN_WAVES, int ROWS_PER_BLOCK = 1, int THREAD_ROWS_PER_BLOCK = 1, int BLOCK_PIXELS = 128>
@@ -349,7 +357,7 @@ struct VisualizerShader {
         return blurred;
 #else
 #ifndef VIS_EXACT_POST
-        return visualizer_post<true>(f, s.pre, c, blurred);
+        return visualizer_post<true>(f, s.pre, c, blurred, a.tape_bars ? a.tape_bars + (long)(a.frame0 + blockIdx.z)*a.spectrogram_stride : nullptr);
 #else
         return visualizer_post<false>(f, s.pre, c, blurred);
 #endif

@@ -12,7 +12,7 @@ from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob("gpurun_out/pmcq/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"].split("(")[0][-60:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[r["Kernel_Name"].split("(")[0][-90:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     if "render" not in k: continue
     waves = sum(cs.get("SQ_WAVES", [1]))/max(1, len(cs.get("SQ_WAVES", [1])))
