@@ -347,3 +347,44 @@ def test_visualizer_other_sample_rates_and_frame_rates(samplerate, fps, seconds)
         got = frames_of(raw, w, h)
         assert got.shape == want.shape
         mostly_within_one_lsb(got, want)
+
+
+def test_host_api_odds_and_ends(tmp_path):
+    """Pieces of the reference API surface that scenes use: scale/ratio in main (scene.py:493-561 + resolution.py), textures that
+    track the scene at a factor, temporal writes/clears, swapping a fragment between exports, time given as an expression"""
+    from examples.scenes import Basic
+    from shaderflow_amd.shader import ShaderProgram
+    from shaderflow_amd.texture import ShaderTexture
+
+    scene = Basic()
+    raw = scene.main(width=128, height=72, scale=0.5, fps=30, time="2/30", output=bytes)               # time strings are evaluated (scene.py:560)
+    assert scene.resolution == (64, 36) and len(raw) == 2*64*36*3
+    raw = Basic().main(height=90, ratio="16:9", fps=30, time=1/30, output=bytes)
+    assert len(raw) == 160*90*3
+
+    scene = Basic()
+    scene.initialize()                                                                                  # modules need the scene's context (scene.py:128-195)
+    half = ShaderProgram(scene=scene, name="half")
+    half.texture.track = 0.5                                                                            # half the render resolution
+    probe = ShaderTexture(scene=scene, name="probe", temporal=3, width=4, height=2, components=1, dtype=np.float32)
+    scene.main(width=64, height=36, ssaa=2, fps=30, time=1/30, freewheel=True)
+    assert half.texture.size == (64, 36) and scene.shader.texture.size == (128, 72) and scene._final.texture.size == (64, 36)
+    data = np.arange(8, dtype=np.float32).reshape(2, 4, 1)
+    probe.write(data, temporal=2)
+    assert probe.is_empty(0) and not probe.is_empty(2) and np.array_equal(probe.matrix[2][0].texture.read(), data)
+    probe.roll()
+    assert np.array_equal(probe.matrix[0][0].texture.read(), data)                                      # deque.rotate(1): the last row comes first
+    probe.clear(0)
+    assert not probe.matrix[0][0].texture.read().any() and not probe.is_empty(0)
+    probe.temporal = 2                                                                                  # shrinking re-allocates and keeps full writes of equal size
+    assert len(probe.matrix) == 2
+
+    scene = Basic()
+    first = frames_of(scene.main(width=64, height=36, fps=30, time=1/30, output=bytes), 64, 36)
+    assert scene.shader.kernel == "default"
+    scene.shader.fragment = "shadertoy"                                                                 # hot swap (shader.py:299-306): compiled on the next export
+    second = frames_of(scene.main(width=64, height=36, fps=30, time=1/30, output=bytes), 64, 36)
+    assert scene.shader.kernel == "shadertoy" and not np.array_equal(first, second)
+    scene.shader.fragment = "void main() { fragColor = vec4(0.2); }"
+    scene.main(width=64, height=36, fps=30, time=1/30, freewheel=True)
+    assert scene.shader.kernel == "missing" and scene.shader.fallback
