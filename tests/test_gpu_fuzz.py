@@ -80,3 +80,39 @@ def test_generic_fragments_random_configurations(gpu, seed):
     gpu_bind_all(gpu, prog, {k: v for k, v in arrays.items() if k != "background"}, params)
     got = gpu.render(prog, w, h)
     assert np.array_equal(got, want), (name, (w, h), lsb_report(got, want))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_sampler_formats_filters_and_wraps(gpu, seed):
+    """texture() through video.frag on textures of every format (u8, u16, f16, f32), 1-4 components, both filters and wrap modes,
+    odd sizes, moved cameras: bit-exact against the oracle"""
+    rng = np.random.default_rng(3000 + seed)
+    dtype = [np.uint8, np.uint16, np.float16, np.float32][seed % 4]
+    components = int(rng.integers(1, 5))
+    tw, th = int(rng.integers(1, 40)), int(rng.integers(1, 30))
+    if dtype in (np.uint8, np.uint16):
+        data = rng.integers(0, np.iinfo(dtype).max + 1, (th, tw, components)).astype(dtype)
+    else:
+        data = rng.uniform(-0.5, 1.5, (th, tw, components)).astype(dtype)
+    filter, rx, ry = ("linear" if seed % 3 else "nearest"), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    w, h = int(rng.integers(3, 200)), int(rng.integers(3, 120))
+    u = O.default_uniforms(w, h, iCameraZoom=float(rng.uniform(0.5, 2.5)), iCameraPosition=(float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), 0.0))
+    want = O.render("video", u, {0: O.make_texture(data, filter, rx, ry)}, w, h, threads=4)
+    prog, _ = gpu.program("video")
+    gpu.set_uniforms(prog, u)
+    assert gpu.bind(prog, "iVideo", gpu.texture(data, filter, rx, ry))
+    got = gpu.render(prog, w, h)
+    assert np.array_equal(got, want), ((dtype.__name__, components, (tw, th), filter, rx, ry), lsb_report(got, want))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_resolve_random_sizes(gpu, seed):
+    rng = np.random.default_rng(4000 + seed)
+    w, h = int(rng.integers(2, 150)), int(rng.integers(2, 90))
+    factor = float(rng.choice([1.0, 1.25, 1.5, 2.0, 3.0, 4.0]))
+    wr, hr = int(w*factor), int(h*factor)
+    subsample = int(rng.integers(1, 5))
+    screen = rng.integers(0, 256, (hr, wr, 4), dtype=np.uint8)
+    want = O.resolve(screen, w, h, subsample, threads=4)
+    got = gpu.resolve(screen, w, h, subsample)
+    assert np.array_equal(got, want), ((w, h, factor, subsample), lsb_report(got, want))
