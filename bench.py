@@ -197,6 +197,10 @@ def main() -> None:
         tape.render(fpb, buffers[i].data_ptr())
     torch.cuda.synchronize()
     N.check(N.lib().sfx_tape_reset(tape.handle))
+    if gather is not None:
+        # same for the communicator: RCCL opens its peer-to-peer channels on the first gather (also with --warmup 0)
+        gather.start(0, buffers[0][:piece*frame_bytes])
+        gather.wait_all()
 
     for i in range(args.warmup):
         step(i, None)
