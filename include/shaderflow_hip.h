@@ -98,6 +98,21 @@ int sfx_texture_destroy(sfx_handle tex);
  * is accepted in place of the source. */
 
 int sfx_program_lookup(sfx_handle ctx, const char* source, sfx_handle* program, int* fallback);
+
+/* Fragments outside the registry — the other half of opengl.program(vs, fs) (shader.py:313-349). The host translates the
+ * GLSL to HIP C++ and compiles it to a gfx950 code object (shaderflow_amd/glsl2hip.py; hipcc --genco against
+ * csrc/jit_runtime.hpp); this call loads it. `bindings` name what the host may set on it: a uniform lives at floats
+ * [slot, slot + count) of the program's scene-defined uniform block (integer: stored as int32 bits), a sampler at texture
+ * slot `slot`. The program then behaves like any other (sfx_uniform_set, sfx_sampler_bind, sfx_render, sfx_render_resolve,
+ * sfx_render_tape). Fails with SFX_E_INVALID if the code object was compiled against other kernel headers than this library. */
+typedef struct sfx_binding {
+    const char* name;
+    int sampler;        /* 1: sampler2D, 0: uniform */
+    int slot;
+    int count;          /* uniform: number of 32-bit values (1-4); sampler: 1 */
+    int integer;        /* uniform: int/bool/uint rather than float */
+} sfx_binding;
+int sfx_program_load(sfx_handle ctx, const void* code_object, size_t nbytes, const sfx_binding* bindings, int nbindings, sfx_handle* program);
 const char* sfx_program_name(sfx_handle program);
 /* returns SFX_OK whether or not the program reads `name` (inactive uniforms are ignored, shader.py:356-357);
  * *known (may be NULL) tells which */

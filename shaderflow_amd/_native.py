@@ -42,6 +42,11 @@ class FrameClock(C.Structure):
     _fields_ = [("iTime", C.c_float), ("iTau", C.c_float), ("iSpectrogramOffset", C.c_float), ("iFrame", C.c_int32)]
 
 
+class Binding(C.Structure):
+    """sfx_binding (include/shaderflow_hip.h): a uniform or sampler name of a loaded program"""
+    _fields_ = [("name", C.c_char_p), ("sampler", C.c_int), ("slot", C.c_int), ("count", C.c_int), ("integer", C.c_int)]
+
+
 class TapeDesc(C.Structure):
     _fields_ = [("points", C.c_int32), ("chunk_size", C.c_int32), ("reducer", C.c_int32), ("volume_window", C.c_int32),
                 ("use_mfma", C.c_int32), ("volume_integrate", C.c_int32), ("std_integrate", C.c_int32),
@@ -67,6 +72,7 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_texture_device_ptr": (C.c_int, [Handle, P(C.c_void_p), P(C.c_size_t)]),
     "sfx_texture_destroy": (C.c_int, [Handle]),
     "sfx_program_lookup": (C.c_int, [Handle, C.c_char_p, P(Handle), P(C.c_int)]),
+    "sfx_program_load": (C.c_int, [Handle, C.c_void_p, C.c_size_t, P(Binding), C.c_int, P(Handle)]),
     "sfx_program_name": (C.c_char_p, [Handle]),
     "sfx_uniform_set": (C.c_int, [Handle, C.c_char_p, C.c_int, C.c_void_p, P(C.c_int)]),
     "sfx_sampler_bind": (C.c_int, [Handle, C.c_char_p, Handle, P(C.c_int)]),

@@ -291,7 +291,7 @@ static const char* const g_fragment_names[] = {"default", "missing", "visualizer
                                                "multi_main", "shadertoy", "dynamics", "audio", "multipass", "motionblur",
                                                "life_simulation", "life_visuals", "video", "raymarch", "mandelbrot", "tetration"};
 static_assert(sizeof(g_fragment_names)/sizeof(g_fragment_names[0]) == FRAG_COUNT, "one name per fragment");
-enum { FRAG_FINAL = 100 };
+enum { FRAG_FINAL = 100, FRAG_JIT = 101 };
 
 static int fragment_by_name(const char* name) {
     for (int k = 0; k < FRAG_COUNT; k++) if (!strcmp(name, g_fragment_names[k])) return k;
@@ -310,11 +310,16 @@ static uint64_t normalised_hash(const char* src) {
     return h;
 }
 
+struct JitBinding { std::string name; bool sampler; int slot, count; bool integer; };
 struct Program : Object {
     Context* ctx;
     int fragment;
     Uniforms u;
     Texture* samplers[TEX_SLOTS];
+    // FRAG_JIT: a code object built by the host from a translated fragment (sfx_program_load)
+    hipModule_t module = nullptr;
+    hipFunction_t fn_render = nullptr, fn_fused[3] = {nullptr, nullptr, nullptr};     // ssaa 1, 2, 4
+    std::vector<JitBinding> bindings;
 };
 
 static void forget_texture(Texture* t) {
@@ -394,9 +399,47 @@ extern "C" int sfx_program_lookup(sfx_handle h, const char* source, sfx_handle* 
     return SFX_OK;
 }
 
+// A fragment translated and compiled by the host (shaderflow_amd/glsl2hip.py → hipcc --genco) — what `opengl.program(vs, fs)`
+// (shader.py:324) is for fragments outside the registry. The code object exports the kernels of csrc/jit_runtime.hpp
+// (SF_JIT_ENTRY_POINTS) and the size of the RenderArgs it was compiled against.
+extern "C" int sfx_program_load(sfx_handle h, const void* code_object, size_t nbytes, const sfx_binding* bindings, int nbindings, sfx_handle* out) {
+    CTX_OR_FAIL(c, h);
+    if (!code_object || !nbytes || !out || (nbindings > 0 && !bindings)) return fail(SFX_E_INVALID, "null code object, bindings or output");
+    USE_DEVICE(c);
+    Program* p = new Program();
+    p->magic = MAGIC_PROG; p->ctx = c; p->fragment = FRAG_JIT;
+    default_uniforms(p->u);
+    for (auto& s : p->samplers) s = nullptr;
+    // (the runtime's sticky last error is cleared: launch_status() must not report this failure for a later launch)
+    auto bail = [&](int code, const char* what, hipError_t e) { if (p->module) hipModuleUnload(p->module); delete p; (void)hipGetLastError(); return fail(code, "%s: %s", what, hipGetErrorString(e)); };
+    hipError_t e = hipModuleLoadData(&p->module, code_object);
+    if (e != hipSuccess) { p->module = nullptr; return bail(SFX_E_HIP, "hipModuleLoadData", e); }
+    static const char* const fused_names[3] = {"sfx_jit_fused_1", "sfx_jit_fused_2", "sfx_jit_fused_4"};
+    if ((e = hipModuleGetFunction(&p->fn_render, p->module, "sfx_jit_render")) != hipSuccess) return bail(SFX_E_INVALID, "code object has no sfx_jit_render", e);
+    for (int k = 0; k < 3; k++)
+        if ((e = hipModuleGetFunction(&p->fn_fused[k], p->module, fused_names[k])) != hipSuccess) return bail(SFX_E_INVALID, "code object lacks a fused entry point", e);
+    hipDeviceptr_t layout = nullptr; size_t layout_bytes = 0; unsigned compiled_size = 0;
+    if ((e = hipModuleGetGlobal(&layout, &layout_bytes, p->module, "sfx_jit_layout")) != hipSuccess) return bail(SFX_E_INVALID, "code object has no sfx_jit_layout", e);
+    if ((e = hipMemcpy(&compiled_size, layout, sizeof compiled_size, hipMemcpyDeviceToHost)) != hipSuccess) return bail(SFX_E_HIP, "reading sfx_jit_layout", e);
+    if (compiled_size != sizeof(RenderArgs)) {
+        hipModuleUnload(p->module); delete p;
+        return fail(SFX_E_INVALID, "code object was compiled against another version of the kernel headers (RenderArgs %u bytes, library %zu)", compiled_size, sizeof(RenderArgs));
+    }
+    for (int k = 0; k < nbindings; k++) {
+        const sfx_binding& b = bindings[k];
+        const int limit = b.sampler ? TEX_SLOTS : USER_SLOTS;
+        if (!b.name || b.slot < 0 || b.count < 1 || b.slot + (b.sampler ? 1 : b.count) > limit) { hipModuleUnload(p->module); delete p; return fail(SFX_E_INVALID, "binding %d is out of range", k); }
+        p->bindings.push_back({b.name, b.sampler != 0, b.slot, b.count, b.integer != 0});
+    }
+    c->programs.push_back(p);
+    *out = handle_of(p);
+    return SFX_OK;
+}
+
 extern "C" const char* sfx_program_name(sfx_handle h) {
     Program* p = get<Program>(h, MAGIC_PROG);
     if (!p) return "";
+    if (p->fragment == FRAG_JIT) return "translated";
     return p->fragment == FRAG_FINAL ? "final" : g_fragment_names[p->fragment];
 }
 
@@ -419,6 +462,8 @@ extern "C" int sfx_uniform_set(sfx_handle h, const char* name, int type, const v
         if (!strcmp(f.name, name)) { store((char*)&p->u + f.offset, f.count, f.integer); return SFX_OK; }
     for (const auto& uu : g_user_uniforms)
         if (uu.fragment == p->fragment && !strcmp(uu.name, name)) { store((char*)&p->u.user[uu.slot], uu.count, false); return SFX_OK; }
+    for (const auto& b : p->bindings)
+        if (!b.sampler && b.name == name) { store((char*)&p->u.user[b.slot], b.count, b.integer); return SFX_OK; }
     return SFX_OK;                                                  // inactive uniform: ignored like program.get(name, None)
 }
 
@@ -451,7 +496,9 @@ extern "C" int sfx_sampler_bind(sfx_handle h, const char* name, sfx_handle tex, 
     Texture* t = get<Texture>(tex, MAGIC_TEX);
     if (!p || !name) return fail(SFX_E_INVALID, "invalid program handle or name");
     if (tex && !t) return fail(SFX_E_INVALID, "invalid texture handle");
-    const int slot = sampler_slot(p->fragment, name);
+    int slot = -1;
+    if (p->fragment == FRAG_JIT) { for (const auto& b : p->bindings) if (b.sampler && b.name == name) slot = b.slot; }
+    else slot = sampler_slot(p->fragment, name);
     if (known) *known = (slot >= 0);
     if (slot >= 0) p->samplers[slot] = t;
     return SFX_OK;
@@ -462,6 +509,7 @@ extern "C" int sfx_program_destroy(sfx_handle h) {
     if (!p) return fail(SFX_E_INVALID, "invalid program handle");
     auto& live = p->ctx->programs;
     live.erase(std::remove(live.begin(), live.end(), p), live.end());
+    if (p->module) { hipSetDevice(p->ctx->device); hipStreamSynchronize(p->ctx->stream); hipModuleUnload(p->module); }
     p->magic = 0;
     delete p;
     return SFX_OK;
@@ -697,6 +745,28 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
     }
 }
 
+// A loaded program runs the generic kernels of its own code object (PlainShader geometry, jit_runtime.hpp)
+static int launch_jit(hipFunction_t fn, const RenderArgs& a, dim3 grid, dim3 block, hipStream_t s) {
+    size_t size = sizeof(RenderArgs);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, (void*)&a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    const hipError_t e = hipModuleLaunchKernel(fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, 0, s, nullptr, config);
+    return e == hipSuccess ? SFX_OK : fail(SFX_E_HIP, "hipModuleLaunchKernel: %s", hipGetErrorString(e));
+}
+static int launch_render_p(const Program* p, const RenderArgs& a, int frames, hipStream_t s) {
+    if (p->fragment != FRAG_JIT) return launch_render(p->fragment, a, frames, s);
+    using P = PlainShader<FRAG_DEFAULT>;
+    return launch_jit(p->fn_render, a, dim3((a.wr + P::BLOCK_W - 1)/P::BLOCK_W, (a.hr + P::BLOCK_H - 1)/P::BLOCK_H, frames), dim3(P::BLOCK_W, P::BLOCK_H, 1), s);
+}
+static int launch_fused_p(const Program* p, const RenderArgs& a, int ssaa, int frames, hipStream_t s) {
+    if (p->fragment != FRAG_JIT) return launch_fused(p->fragment, a, ssaa, frames, s);
+    using P = PlainShader<FRAG_DEFAULT>;
+    if (ssaa == 1) return launch_jit(p->fn_fused[0], a, dim3(((a.w + 127)/128)*((a.h + 1)/2), 1, frames), dim3(256), s);
+    if (ssaa != 2 && ssaa != 4) return fail(SFX_E_UNSUPPORTED, "fused ssaa %d", ssaa);
+    constexpr int rows = P::FUSED_ROWS*P::THREAD_ROWS, threads = 4*P::BLOCK_PX*P::THREAD_ROWS;
+    const int blocks_x = (a.w + P::BLOCK_PX - 1)/P::BLOCK_PX, row_blocks = (a.h + rows - 1)/rows;
+    return launch_jit(p->fn_fused[ssaa == 2 ? 1 : 2], a, dim3(blocks_x*row_blocks, 1, frames), dim3(threads), s);
+}
+
 static int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SFX_OK : fail(SFX_E_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -716,7 +786,7 @@ extern "C" int sfx_render(sfx_handle h, sfx_handle target, int layer) {
     a.out = t->data; a.out_components = t->components; a.out_dtype = t->dtype; a.out_frame_stride = 0;
     int rc = check_samplers(p->fragment, a);
     if (rc) return rc;
-    if ((rc = launch_render(p->fragment, a, 1, p->ctx->stream))) return rc;
+    if ((rc = launch_render_p(p, a, 1, p->ctx->stream))) return rc;
     return launch_status();
 }
 
@@ -757,7 +827,7 @@ extern "C" int sfx_render_resolve(sfx_handle h, sfx_handle final_tex, int ssaa, 
     a.out = t->data; a.out_frame_stride = 0;
     int rc = check_samplers(p->fragment, a);
     if (rc) return rc;
-    if ((rc = launch_fused(p->fragment, a, ssaa, 1, p->ctx->stream))) return rc;
+    if ((rc = launch_fused_p(p, a, ssaa, 1, p->ctx->stream))) return rc;
     return launch_status();
 }
 
@@ -1358,7 +1428,7 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
         }
     }
     if (fused) {
-        if ((rc = launch_fused(p->fragment, a, ssaa, nframes, p->ctx->stream))) return rc;
+        if ((rc = launch_fused_p(p, a, ssaa, nframes, p->ctx->stream))) return rc;
         return launch_status();
     }
     // two passes, batched: the fragment into an RGBA8 iScreen scratch per frame, then final.glsl (shader.py:388-405)
@@ -1370,7 +1440,7 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
         t->screen_bytes = screen_frame*nframes;
     }
     a.out = t->d_screen; a.out_frame_stride = (long)screen_frame; a.out_components = 4; a.out_dtype = DT_U8;
-    if ((rc = launch_render(p->fragment, a, nframes, p->ctx->stream))) return rc;
+    if ((rc = launch_render_p(p, a, nframes, p->ctx->stream))) return rc;
     ResolveArgs r;
     r.screen = Tex{t->d_screen, a.wr, a.hr, 4, DT_U8, FILTER_LINEAR, 0, 0};      // iScreen: linear, repeat(False) (scene.py:192-194)
     r.w = width; r.h = height; r.subsample = subsample; r.out = (uint8_t*)device_out;

@@ -172,6 +172,7 @@ SF_HD uint32_t pack_rgba8(vec4 c) { return unorm8(c.x) | (unorm8(c.y) << 8) | (u
 // scene.py:687-703, camera.py:196-201 (+ its ShaderDynamics :147-185), audio/module.py:413-421,
 // spectrogram.py:313-320, waveform.py:89-90. Host fills it by name (capi: sfx_uniform_set).
 
+constexpr int USER_SLOTS = 64;
 struct Uniforms {
     float iTime, iTau, iDuration, iDeltatime;
     float iResolution[2];
@@ -187,7 +188,7 @@ struct Uniforms {
     int iSpectrogramLength, iSpectrogramBins, iSpectrogramSmooth, iSpectrogramScroll;
     float iSpectrogramOffset, iSpectrogramMin, iSpectrogramMax;
     int iWaveformLength;
-    float user[16];
+    float user[USER_SLOTS];        // scene-defined uniforms: fixed slots for the restated fragments (fragments.hpp), in declaration order for translated ones
 };
 
 // Sampler slots: four named textures, then the temporal history of the texture a fragment reads by

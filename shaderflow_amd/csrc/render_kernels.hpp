@@ -127,8 +127,10 @@ template <int FRAGMENT> struct PlainShader {
 };
 
 // ---- K6: generic unfused render --------------------------------------------------------------------
+// (the bodies are functions so that the code object of a run-time translated fragment can wrap them in kernels with
+// C names, jit_runtime.hpp)
 template <class SHADER>
-__global__ __launch_bounds__(256) void k_render(const RenderArgs a) {
+__device__ __forceinline__ void render_body(const RenderArgs& a) {
     __shared__ typename SHADER::Shared shared;
     const int i = blockIdx.x*SHADER::BLOCK_W + threadIdx.x;
     const int j = blockIdx.y*SHADER::BLOCK_H + threadIdx.y;
@@ -146,6 +148,8 @@ __global__ __launch_bounds__(256) void k_render(const RenderArgs a) {
     SHADER::template setup<1>(a, tex, f, state, valid, shared, j_last*SHADER::BLOCK_W + i_last);
     if (inside) store_target(a, blockIdx.z, i, j, SHADER::run(a, f, state[0], shared));
 }
+template <class SHADER>
+__global__ __launch_bounds__(256) void k_render(const RenderArgs a) { render_body<SHADER>(a); }
 
 // ---- K8: final.glsl as a pass ------------------------------------------------------------------------
 struct ResolveArgs {
@@ -266,7 +270,7 @@ __device__ __forceinline__ void store_rgb_row(uint8_t* out_row, int x0, int w, c
 // After shading, every lane of a quad receives the quad's packed RGBA8 texels through DPP quad_perm moves and
 // lane c of the quad resolves colour channel c (lane 3 idles); lane 0 collects the three bytes.
 template <class SHADER, int S>
-__global__ __launch_bounds__(4*SHADER::BLOCK_PX*SHADER::THREAD_ROWS, SHADER::MIN_WAVES_PER_SIMD) void k_render_resolve(const RenderArgs a) {
+__device__ __forceinline__ void render_resolve_body(const RenderArgs& a) {
     constexpr int LANES = (S == 1) ? 1 : 4;
     constexpr int GROUP = (S*S)/LANES;               // supersamples of one pixel owned by one lane: 1, 1, 4
     constexpr int G = (S == 4) ? 2 : 1;              // side of that group
@@ -363,6 +367,10 @@ __global__ __launch_bounds__(4*SHADER::BLOCK_PX*SHADER::THREAD_ROWS, SHADER::MIN
         if (y < a.h) store_rgb_row(frame + (long)(a.top_down ? a.h - 1 - y : y)*a.w*3, bx*BPX, a.w, staged[r], tid, blockDim.x, BPX);
     }
     SF_TICK(a, 3);                                   // resolve + store
+}
+template <class SHADER, int S>
+__global__ __launch_bounds__(4*SHADER::BLOCK_PX*SHADER::THREAD_ROWS, SHADER::MIN_WAVES_PER_SIMD) void k_render_resolve(const RenderArgs a) {
+    render_resolve_body<SHADER, S>(a);
 }
 
 }  // namespace sf

@@ -1,0 +1,557 @@
+"""
+glsl2hip — fragments that are not in the kernel registry: GLSL 3.30 → HIP C++ → gfx950 code object.
+
+The reference gives the assembled GLSL to the OpenGL driver (shader.py:190-239 builds the text, :313-349 compiles it
+with `opengl.program`, falling back to `missing.glsl` on errors). Without a driver the same job is done in two steps:
+
+1. `translate()` rewrites the fragment token by token into the body of a C++ struct that derives from
+   `sf::rt::FragmentBase` (csrc/jit_runtime.hpp): globals and uniforms become members, functions become member
+   functions, `main` becomes `main_`. GLSL and C++ share almost all of their expression and statement syntax; the
+   header supplies the vector types (with swizzles), the built-in functions on the deterministic binary32 routines of
+   csrc/sfmath.hpp and the reference's prelude, so what is rewritten is small:
+     * floating literals get an `f` suffix (C++ would compute in double),
+     * `in/out/inout` parameter qualifiers become values and references, precision/layout/interpolation qualifiers go,
+     * `uniform`/`in`/`out` declarations go (the members exist already), prototypes go,
+     * `int(x)`/`uint(x)` become `to_int(x)`/`to_uint(x)` (defined results for NaN and overflow),
+     * array constructors `T[n](…)` become `{…}`, `T[n] name` becomes `T name[n]`,
+     * `const` scalars with literal initialisers become `static constexpr` (array bounds),
+     * `discard` sets a flag and returns, identifiers that are C++ keywords get a trailing underscore.
+2. `compile()` runs hipcc (`--genco`, the flags of csrc/Makefile) and caches the code object by content hash;
+   libshaderflow_hip loads it with `sfx_program_load`.
+
+What is not supported raises `TranslationError` (the caller logs it and binds the `missing` kernel, like the reference
+does for a GLSL compile error): geometry beyond one fullscreen quad, `discard` outside `main`, arrays as function
+arguments or return values, more than 16 samplers or 64 uniform floats, non-square matrices.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import re
+import subprocess
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Iterable, Optional
+
+CSRC = Path(__file__).resolve().parent/"csrc"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
+         "-fno-slp-vectorize", "-fno-gpu-flush-denormals-to-zero", "-Wno-unused-value", "-Wno-deprecated-copy", "-Wno-parentheses"]
+
+USER_SLOTS = 64          # csrc/glsl.hpp USER_SLOTS
+TEX_SLOTS = 16           # csrc/glsl.hpp TEX_SLOTS
+FIXED_SAMPLER_SLOTS = {"iSpectrogram": 1, "iWaveform": 2}      # the slots the tape patches per frame (render_kernels.hpp frame_view)
+
+
+class TranslationError(Exception):
+    pass
+
+
+class CompileError(Exception):
+    pass
+
+
+@dataclass
+class Binding:
+    """One name the host sets on the program: a uniform (`slot` = first float of csrc Uniforms.user) or a sampler (`slot` = texture slot)"""
+    name: str
+    type: str
+    slot: int
+    count: int = 1
+    integer: bool = False
+
+    @property
+    def sampler(self) -> bool:
+        return self.type == "sampler2D"
+
+
+@dataclass
+class Translation:
+    cpp: str
+    bindings: list[Binding] = field(default_factory=list)
+
+    @property
+    def key(self) -> str:
+        return hashlib.sha256((self.cpp + runtime_fingerprint()).encode()).hexdigest()[:24]
+
+
+# ---- tokens -----------------------------------------------------------------------------------------------------------
+
+_TOKEN = re.compile(r"""
+    (?P<comment>//[^\n]*|/\*.*?\*/)
+  | (?P<pp>(?<![^\n])[ \t]*\#(?:[^\n\\]|\\.|\\\n)*)
+  | (?P<number>0[xX][0-9a-fA-F]+[uU]?|(?:\d+\.\d*|\.\d+|\d+)(?:[eE][+-]?\d+)?(?:lf|LF|[fFuU])?)
+  | (?P<ident>[A-Za-z_]\w*)
+  | (?P<op><<=|>>=|\+\+|--|<<|>>|<=|>=|==|!=|&&|\|\||\^\^|[-+*/%&|^]=|[-+*/%<>=!&|^~?:;,.(){}\[\]])
+  | (?P<ws>\s+)
+""", re.X | re.S)
+
+_CPP_ONLY_KEYWORDS = {
+    "new", "delete", "operator", "private", "protected", "friend", "virtual", "explicit", "mutable", "try", "catch", "throw",
+    "typename", "auto", "register", "signed", "char", "wchar_t", "char8_t", "char16_t", "char32_t", "and", "or", "not", "xor", "bitand",
+    "bitor", "compl", "and_eq", "or_eq", "xor_eq", "not_eq", "nullptr", "constexpr", "consteval", "constinit", "decltype", "noexcept",
+    "static_assert", "thread_local", "alignas", "alignof", "concept", "requires", "co_await", "co_return", "co_yield", "export",
+    "import", "module", "final", "override", "asm", "typeid", "dynamic_cast", "static_cast", "reinterpret_cast", "const_cast",
+}
+_DROPPED_QUALIFIERS = {"highp", "mediump", "lowp", "flat", "smooth", "noperspective", "centroid", "invariant", "precise"}
+_TYPES = {"void", "float", "int", "uint", "bool", "vec2", "vec3", "vec4", "ivec2", "ivec3", "ivec4", "uvec2", "uvec3", "uvec4",
+          "bvec2", "bvec3", "bvec4", "mat2", "mat3", "mat4", "mat2x2", "mat3x3", "mat4x4", "sampler2D"}
+_UNIFORM_COUNTS = {"float": (1, False), "int": (1, True), "bool": (1, True), "uint": (1, True), "vec2": (2, False), "vec3": (3, False),
+                   "vec4": (4, False), "ivec2": (2, True), "ivec3": (3, True), "ivec4": (4, True)}
+# members of sf::rt::FragmentBase (jit_runtime.hpp): uniforms and varyings that exist for every fragment
+BUILTIN_MEMBERS = {
+    "fragCoord", "stxy", "glxy", "stuv", "astuv", "gluv", "agluv", "gl_FragCoord", "fragColor", "instance",
+    "iTime", "iTau", "iDuration", "iFrametime", "iDeltatime", "iCycle", "iAspectRatio", "iWidth", "iHeight", "iResolution", "iMouse",
+    "iWantAspect", "iQuality", "iSSAA", "iFramerate", "iFrame", "iLayer", "iSubsample", "iRealtime", "iRendering", "iMouseInside",
+    "iMouse1", "iMouse2", "iCameraMode", "iCameraProjection", "iCameraRight", "iCameraUpward", "iCameraForward", "iCameraPosition",
+    "iCameraZenith", "iCameraSeparation", "iCameraZoom", "iCameraIsometric", "iCameraFocalLength", "iCameraOrbital", "iCameraDolly",
+    "iAudioVolume", "iAudioVolumeIntegral", "iAudioSTD", "iSpectrogramLength", "iSpectrogramBins", "iSpectrogramScroll",
+    "iWaveformLength", "iSpectrogramSmooth", "iSpectrogramOffset", "iSpectrogramMin", "iSpectrogramMax",
+}
+
+
+@dataclass
+class Tok:
+    kind: str
+    text: str
+
+
+def tokenize(source: str) -> list[Tok]:
+    tokens, position = [], 0
+    while position < len(source):
+        match = _TOKEN.match(source, position)
+        if match is None:
+            raise TranslationError(f"unexpected character {source[position]!r} at offset {position}")
+        tokens.append(Tok(match.lastgroup, match.group()))
+        position = match.end()
+    return tokens
+
+
+def _float_literal(text: str) -> str:
+    if text[:2] in ("0x", "0X") or text[-1] in "uU":
+        return text
+    if text.endswith(("lf", "LF")):
+        text = text[:-2]
+    if text[-1] in "fF":
+        return text
+    if ("." in text) or ("e" in text) or ("E" in text):
+        return text + ("f" if "." in text or "e" in text.lower() else "")
+    return text
+
+
+def _matching(tokens: list[Tok], start: int, open_: str, close: str) -> int:
+    """index of the token closing the bracket opened at `start`"""
+    depth = 0
+    for k in range(start, len(tokens)):
+        if tokens[k].kind == "op":
+            if tokens[k].text == open_:
+                depth += 1
+            elif tokens[k].text == close:
+                depth -= 1
+                if depth == 0:
+                    return k
+    raise TranslationError(f"unbalanced {open_!r}")
+
+
+def _significant(tokens: list[Tok], start: int, step: int = 1) -> int:
+    """next index from `start` (inclusive) in direction `step` that is not whitespace or a comment; len(tokens) / -1 if none"""
+    k = start
+    while 0 <= k < len(tokens) and tokens[k].kind in ("ws", "comment"):
+        k += step
+    return k
+
+
+# ---- token-level rewrites that apply everywhere --------------------------------------------------------------------------
+
+def _rewrite_tokens(tokens: list[Tok], structs: set[str]) -> list[Tok]:
+    out: list[Tok] = []
+    k = 0
+    types = _TYPES | structs
+    while k < len(tokens):
+        t = tokens[k]
+        if t.kind == "comment":
+            out.append(Tok("ws", "\n"*t.text.count("\n") or " "))
+        elif t.kind == "number":
+            out.append(Tok("number", _float_literal(t.text)))
+        elif t.kind == "ident":
+            nxt = _significant(tokens, k + 1)
+            following = tokens[nxt].text if nxt < len(tokens) else ""
+            if t.text in _DROPPED_QUALIFIERS:
+                pass
+            elif t.text == "layout" and following == "(":
+                k = _matching(tokens, nxt, "(", ")")
+            elif t.text in _CPP_ONLY_KEYWORDS:
+                out.append(Tok("ident", t.text + "_"))
+            elif t.text == "main":
+                out.append(Tok("ident", "main_"))
+            elif t.text in ("int", "uint") and following == "(":
+                out.append(Tok("ident", "to_" + t.text))
+            elif t.text in types and following == "[":
+                # `T[n](a, b)` array constructor → `{a, b}`;  `T[n] name` → `T name[n]`
+                close = _matching(tokens, nxt, "[", "]")
+                after = _significant(tokens, close + 1)
+                if after < len(tokens) and tokens[after].text == "(":
+                    end = _matching(tokens, after, "(", ")")
+                    inner = _rewrite_tokens(tokens[after + 1:end], structs)
+                    out.append(Tok("op", "{")); out.extend(inner); out.append(Tok("op", "}"))
+                    k = end
+                elif after < len(tokens) and tokens[after].kind == "ident":
+                    out.append(t); out.append(Tok("ws", " ")); out.append(Tok("ident", tokens[after].text))
+                    out.extend(_rewrite_tokens(tokens[nxt:close + 1], structs))
+                    k = after
+                else:
+                    out.append(t)
+            else:
+                out.append(t)
+        else:
+            out.append(t)
+        k += 1
+    return out
+
+
+def _text(tokens: Iterable[Tok]) -> str:
+    return "".join(t.text for t in tokens)
+
+
+# ---- function heads ---------------------------------------------------------------------------------------------------
+
+def _rewrite_parameters(tokens: list[Tok]) -> list[Tok]:
+    """`in T a, out T b, inout T c, const in T d` → `T a, T& b, T& c, const T d`"""
+    out: list[Tok] = []
+    reference = False
+    k = 0
+    while k < len(tokens):
+        t = tokens[k]
+        if t.kind == "ident" and t.text in ("out", "inout"):
+            reference = True
+        elif t.kind == "ident" and t.text == "in":
+            pass
+        elif t.kind == "ident" and reference and t.text != "const":
+            nxt = _significant(tokens, k + 1)
+            if nxt < len(tokens) and tokens[nxt].text == "[":
+                raise TranslationError("array parameters with out/inout qualifiers are not supported")
+            out.append(t); out.append(Tok("op", "&"))
+            reference = False
+        else:
+            if t.kind == "op" and t.text == "[":
+                raise TranslationError("array parameters are not supported")
+            out.append(t)
+        k += 1
+    return out
+
+
+# ---- the global scope -------------------------------------------------------------------------------------------------
+
+_CONSTANT_TOKENS = re.compile(r"^[-+*/%()\s\d.eEfFuUxXa-fA-F<>&|^~!?:]*$")
+
+
+def _count_initialisers(tokens: list[Tok]) -> int:
+    """number of top-level elements of the brace list starting at tokens[0] == '{'"""
+    end = _matching(tokens, 0, "{", "}")
+    depth, count, any_token = 0, 0, False
+    for t in tokens[1:end]:
+        if t.kind == "op" and t.text in "([{":
+            depth += 1
+        elif t.kind == "op" and t.text in ")]}":
+            depth -= 1
+        elif t.kind == "op" and t.text == "," and depth == 0:
+            count += 1
+        if t.kind not in ("ws",):
+            any_token = True
+    return count + 1 if any_token else 0
+
+
+class _Translator:
+    def __init__(self, source: str, uniforms: list[tuple[str, str]]):
+        self.source = source
+        self.pipeline = list(uniforms)
+        self.body: list[str] = []
+        self.structs: set[str] = set()
+        self.constants: set[str] = set()
+        self.declared_uniforms: list[tuple[str, str, str]] = []     # (type, name, default text)
+        self.macros: list[str] = []
+        self.identifiers: set[str] = set()
+
+    # a statement of the global scope that ends in ';'
+    def declaration(self, tokens: list[Tok]) -> str:
+        first = _significant(tokens, 0)
+        if first >= len(tokens):
+            return _text(tokens)
+        words = [t.text for t in tokens if t.kind == "ident"]
+        head = tokens[first].text
+        if head == "precision":
+            return ""
+        qualifiers = set()
+        k = first
+        while k < len(tokens) and (tokens[k].kind in ("ws",) or (tokens[k].kind == "ident" and tokens[k].text in ("uniform", "in", "out", "varying", "attribute", "const"))):
+            if tokens[k].kind == "ident":
+                qualifiers.add(tokens[k].text)
+            k += 1
+        rest = tokens[k:]
+        if "uniform" in qualifiers:
+            type_index = _significant(rest, 0)
+            type_ = rest[type_index].text
+            names = _text(rest[type_index + 1:-1])
+            for part in self._split_commas(names):
+                name, _, default = part.partition("=")
+                if "[" in name:
+                    raise TranslationError(f"uniform arrays are not supported: {part.strip()}")
+                self.declared_uniforms.append((type_, name.strip(), default.strip()))
+            return ""
+        if qualifiers & {"in", "out", "varying", "attribute"}:
+            type_index = _significant(rest, 0)
+            names = [n.strip() for n in self._split_commas(_text(rest[type_index + 1:-1]))]
+            unknown = [n for n in names if n.split("[")[0].strip() not in BUILTIN_MEMBERS]
+            return (f"\n{rest[type_index].text} {', '.join(unknown)};" if unknown else "")
+        # prototype: `T name(params);` without an initialiser
+        texts = [t.text for t in tokens if t.kind not in ("ws",)]
+        if "=" not in texts and "(" in texts and texts[-2] == ")" and len(words) >= 2:
+            return ""
+        if head == "struct":
+            return self.struct(tokens)
+        text = _text(tokens)
+        if "const" in qualifiers:
+            type_index = _significant(rest, 0)
+            type_ = rest[type_index].text
+            if type_ in ("int", "float", "bool", "uint") and "[" not in texts:
+                parts = self._split_commas(_text(rest[type_index + 1:-1]))
+                constant = True
+                for part in parts:
+                    name, _, init = part.partition("=")
+                    probe = re.sub(r"\b(?:%s|true|false)\b" % "|".join(sorted(self.constants) or ["__none__"]), "1", init)
+                    probe = re.sub(r"\bto_u?int\b|\bfloat\b|\bbool\b", "", probe)
+                    constant = constant and bool(init.strip()) and bool(_CONSTANT_TOKENS.match(probe))
+                if constant:
+                    for part in parts:
+                        self.constants.add(part.partition("=")[0].strip())
+                    return f"\nstatic constexpr {type_} {', '.join(p.strip() for p in parts)};"
+        # members cannot deduce an array bound from their initialiser: write it out
+        match = re.search(r"\[\s*\]\s*=\s*\{", text)
+        if match:
+            brace = next(i for i, t in enumerate(tokens) if t.kind == "op" and t.text == "{")
+            text = text[:match.start()] + f"[{_count_initialisers(tokens[brace:])}] = {{" + text[match.end():]
+        return text
+
+    @staticmethod
+    def _split_commas(text: str) -> list[str]:
+        parts, depth, current = [], 0, ""
+        for ch in text:
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            if ch == "," and depth == 0:
+                parts.append(current); current = ""
+            else:
+                current += ch
+        if current.strip():
+            parts.append(current)
+        return parts
+
+    def struct(self, tokens: list[Tok]) -> str:
+        return _text(tokens)
+
+    def function(self, head: list[Tok], body: list[Tok]) -> str:
+        open_ = next(i for i, t in enumerate(head) if t.kind == "op" and t.text == "(")
+        close = _matching(head, open_, "(", ")")
+        before = head[:open_]
+        return_type = next((t.text for t in before if t.kind == "ident"), "void")
+        parameters = _rewrite_parameters(head[open_ + 1:close])
+        if _text(parameters).strip() == "void":
+            parameters = []
+        body_text = self.function_body(body, return_type)
+        return "\nSF_HD " + _text(before).lstrip() + "(" + _text(parameters) + ")" + _text(head[close + 1:]) + body_text
+
+    def function_body(self, body: list[Tok], return_type: str) -> str:
+        out = []
+        for t in body:
+            if t.kind == "ident" and t.text == "discard":
+                if return_type != "void":
+                    raise TranslationError("`discard` inside a function that returns a value is not supported")
+                out.append("{ discarded_ = true; return; }")
+            elif t.kind == "pp":
+                out.append("\n" + self.preprocessor(t.text).strip("\n") + "\n")
+            else:
+                out.append(t.text)
+        return "".join(out)
+
+    def preprocessor(self, text: str) -> str:
+        stripped = text.strip()
+        directive = re.match(r"#\s*(\w+)", stripped)
+        name = directive.group(1) if directive else ""
+        if name in ("version", "extension", "pragma", "line", "include"):
+            return ""
+        if name == "define":
+            match = re.match(r"(\s*#\s*define\s+)(\w+)(.*)$", text, re.S)
+            if match:
+                self.macros.append(match.group(2))
+                rewritten = _text(_rewrite_tokens(tokenize(match.group(3)), self.structs))
+                return match.group(1) + (match.group(2) + "_" if match.group(2) in _CPP_ONLY_KEYWORDS else match.group(2)) + rewritten
+        return text
+
+    def run(self) -> Translation:
+        raw = tokenize(self.source)
+        # names the fragment can reach: those of its code, and those of the macros it reaches (a texture's `#define name
+        # name0x0` must not make the sampler active unless `name` is used)
+        self.identifiers = {t.text for t in raw if t.kind == "ident"}
+        macros: dict[str, set[str]] = {}
+        for t in raw:
+            if t.kind == "pp":
+                define = re.match(r"\s*#\s*define\s+(\w+)(?:\([^)]*\))?(.*)$", t.text, re.S)
+                if define:
+                    macros.setdefault(define.group(1), set()).update(re.findall(r"[A-Za-z_]\w*", define.group(2)))
+                else:
+                    self.identifiers |= set(re.findall(r"[A-Za-z_]\w*", t.text))
+        grown = True
+        while grown:
+            grown = False
+            for name, names in macros.items():
+                if name in self.identifiers and not names <= self.identifiers:
+                    self.identifiers |= names
+                    grown = True
+        # struct names first: they are types for the array rewrites
+        for k, t in enumerate(raw):
+            if t.kind == "ident" and t.text == "struct":
+                nxt = _significant(raw, k + 1)
+                if nxt < len(raw) and raw[nxt].kind == "ident":
+                    self.structs.add(raw[nxt].text)
+        tokens = _rewrite_tokens(raw, self.structs)
+        k, statement = 0, []
+        while k < len(tokens):
+            t = tokens[k]
+            if t.kind == "pp":
+                self.body.append(_text(statement)); statement = []
+                self.body.append("\n" + self.preprocessor(t.text).strip("\n") + "\n")
+            elif t.kind == "op" and t.text == ";":
+                statement.append(t)
+                self.body.append(self.declaration(statement)); statement = []
+            elif t.kind == "op" and t.text == "{":
+                end = _matching(tokens, k, "{", "}")
+                texts = [s.text for s in statement if s.kind != "ws"]
+                if "=" in texts:                                   # brace initialiser of a global: part of the statement
+                    statement.extend(tokens[k:end + 1])
+                elif texts and texts[0] == "struct":               # struct definition (up to its ';')
+                    statement.extend(tokens[k:end + 1])
+                elif "(" in texts:                                 # function definition
+                    self.body.append(self.function(statement, tokens[k:end + 1])); statement = []
+                else:
+                    raise TranslationError(f"unexpected block after {_text(statement).strip()!r}")
+                k = end
+            else:
+                statement.append(t)
+            k += 1
+        if _text(statement).strip():
+            raise TranslationError(f"unterminated declaration: {_text(statement).strip()[:60]!r}")
+        return self.assemble()
+
+    def assemble(self) -> Translation:
+        bindings: list[Binding] = []
+        members: list[str] = []
+        loads: list[str] = []
+        seen: set[str] = set()
+        next_float = 0
+        free_samplers = [s for s in range(TEX_SLOTS) if s not in FIXED_SAMPLER_SLOTS.values()]
+        wanted = [(type_, name, "") for (type_, name) in self.pipeline] + self.declared_uniforms
+        declared_names = {name for (_, name, _) in self.declared_uniforms}
+        for (type_, name, default) in wanted:
+            if name in seen or name in BUILTIN_MEMBERS:
+                continue
+            if name not in self.identifiers and name not in declared_names:
+                continue                                           # inactive uniform: the driver would have removed it as well
+            seen.add(name)
+            if type_ == "sampler2D":
+                if name in FIXED_SAMPLER_SLOTS:
+                    slot = FIXED_SAMPLER_SLOTS[name]
+                elif free_samplers:
+                    slot = free_samplers.pop(0)
+                else:
+                    raise TranslationError(f"more than {TEX_SLOTS} samplers")
+                bindings.append(Binding(name, type_, slot))
+                members.append(f"    sampler2D {name};")
+                loads.append(f"{name} = sampler_({slot});")
+                continue
+            if type_ not in _UNIFORM_COUNTS:
+                raise TranslationError(f"uniform {name}: type {type_} is not supported")
+            count, integer = _UNIFORM_COUNTS[type_]
+            if next_float + count > USER_SLOTS:
+                raise TranslationError(f"more than {USER_SLOTS} floats of uniforms")
+            getter = "user_int_" if integer else "user_"
+            values = ", ".join(f"{getter}({next_float + i})" for i in range(count))
+            members.append(f"    {type_} {name};")
+            if type_ == "bool":
+                loads.append(f"{name} = user_int_({next_float}) != 0;")
+            elif type_ == "uint":
+                loads.append(f"{name} = (uint)user_int_({next_float});")
+            elif count == 1:
+                loads.append(f"{name} = {values};")
+            else:
+                loads.append(f"{name} = {type_}({values});")
+            bindings.append(Binding(name, type_, next_float, count, integer))
+            next_float += count
+        code = "".join(self.body)
+        undefs = "".join(f"#undef {m}\n" for m in dict.fromkeys(self.macros))
+        cpp = ("// generated by shaderflow_amd/glsl2hip.py from a GLSL fragment\n"
+               "#include \"jit_runtime.hpp\"\n"
+               "namespace sf { namespace rt {\n"
+               "struct Fragment : FragmentBase {\n" + "\n".join(members) + "\n"
+               "    SF_HD void load_user_() { " + " ".join(loads) + " }\n"
+               "// ---- translated fragment ----\n" + code + "\n"
+               "// ---- end of translated fragment ----\n"
+               "};\n"
+               "}}\n" + undefs +
+               "SF_JIT_ENTRY_POINTS(sf::rt::Fragment)\n")
+        return Translation(cpp, bindings)
+
+
+def translate(source: str, uniforms: Iterable[tuple[str, str]] = ()) -> Translation:
+    """GLSL fragment text (defines + includes + content, without the `uniform` declarations the engine generates) and the
+    pipeline's `(type, name)` pairs → C++ translation unit + the bindings of its uniforms and samplers"""
+    return _Translator(source, list(uniforms)).run()
+
+
+# ---- compile ----------------------------------------------------------------------------------------------------------
+
+_fingerprint: Optional[str] = None
+
+
+def runtime_fingerprint() -> str:
+    """Hash of the headers a code object is compiled against (its RenderArgs layout must match the library's)"""
+    global _fingerprint
+    if _fingerprint is None:
+        digest = hashlib.sha256()
+        for name in ("sfmath.hpp", "glsl.hpp", "fragments.hpp", "render_kernels.hpp", "jit_runtime.hpp", "jit_swizzles.inc"):
+            digest.update((CSRC/name).read_bytes())
+        digest.update(" ".join(FLAGS).encode())
+        _fingerprint = digest.hexdigest()
+    return _fingerprint
+
+
+def cache_directory() -> Path:
+    root = os.environ.get("SHADERFLOW_JIT_CACHE")
+    if root:
+        return Path(root)
+    return Path(os.environ.get("XDG_CACHE_HOME", Path.home()/".cache"))/"shaderflow_amd"/"jit"
+
+
+def compile(translation: Translation, *, cache: Optional[Path] = None, timeout: float = 300.0) -> bytes:
+    """Translation → gfx950 code object (bytes), through the on-disk cache"""
+    cache = Path(cache) if cache else cache_directory()
+    cache.mkdir(parents=True, exist_ok=True)
+    target = cache/f"{translation.key}.hsaco"
+    if target.exists():
+        return target.read_bytes()
+    unit = cache/f"{translation.key}.hip"
+    unit.write_text(translation.cpp)
+    temporary = cache/f"{translation.key}.{os.getpid()}.tmp"
+    command = [HIPCC, *FLAGS, f"-I{CSRC}", "--genco", str(unit), "-o", str(temporary)]
+    try:
+        done = subprocess.run(command, capture_output=True, text=True, timeout=timeout)
+    except FileNotFoundError as error:
+        raise CompileError(f"hipcc not found ({HIPCC}): fragments outside the registry need the ROCm compiler at run time") from error
+    except subprocess.TimeoutExpired as error:
+        raise CompileError(f"hipcc timed out after {timeout:.0f} s") from error
+    if done.returncode != 0 or not temporary.exists():
+        temporary.unlink(missing_ok=True)
+        raise CompileError(f"hipcc failed ({unit}):\n{done.stderr[-4000:]}")
+    os.replace(temporary, target)
+    return target.read_bytes()

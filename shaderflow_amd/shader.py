@@ -132,10 +132,56 @@ class ShaderProgram(ShaderModule):
         source = _fragment or self.fragment
         handle, fallback = N.Handle(), C.c_int(0)
         N.check(N.lib().sfx_program_lookup(self.scene.context.handle, source.encode("utf-8"), C.byref(handle), C.byref(fallback)))
-        self.program, self.fallback = handle, bool(fallback.value)
+        self.program, self.fallback, self.translated = handle, bool(fallback.value), False
+        if self.fallback and self.translate:
+            try:
+                self._load_translated(source)
+            except Exception as error:                       # shader.py:326-340: report, keep rendering with missing.glsl
+                from shaderflow_amd.glsl2hip import CompileError, TranslationError
+                if not isinstance(error, (TranslationError, CompileError, N.NativeError)):
+                    raise
+                self.compile_error = str(error)
+                self.log_error(f"Fragment could not be translated: {error}")
         if self.fallback:
-            self.log_error("Fragment is not in the kernel registry, loading missing texture shader")
+            self.log_error("Fragment is neither in the kernel registry nor translatable, loading missing texture shader")
         return self
+
+    translate: bool = os.environ.get("SHADERFLOW_TRANSLATE", "1") != "0"
+    """Fragments that are not in the registry are translated to HIP and compiled at run time (glsl2hip.py)"""
+    translated: bool = False
+    compile_error: str = ""
+
+    def assembled_fragment(self, content: str) -> str:
+        """What the reference hands to the GLSL compiler after the declarations and the prelude (shader.py:214-233): every
+        module's defines and includes, then the content. A module's helper functions are only included when the content
+        names them (they would otherwise make every box of every texture an active sampler)."""
+        parts: list[str] = []
+        for module in self.scene.modules:
+            lines = [line for line in module.defines() if line]
+            parts.extend(line for line in lines if line.lstrip().startswith("#"))
+            helpers = [line for line in lines if not line.lstrip().startswith("#")]
+            if helpers:
+                import re
+                names = re.findall(r"\b(\w+)\s*\(", helpers[0])
+                if any(re.search(rf"\b{re.escape(name)}\b", content) for name in names):
+                    parts.extend(helpers)
+            for include in filter(None, module.includes()):
+                parts.append(include.read_text() if isinstance(include, Path) else str(include))
+        parts.append(content)
+        return "\n".join(parts)
+
+    def _load_translated(self, content: str) -> None:
+        from shaderflow_amd import glsl2hip
+        variables = [(variable.type, variable.name) for variable in self.full_pipeline()]
+        translation = glsl2hip.translate(self.assembled_fragment(content), variables)
+        code = glsl2hip.compile(translation)
+        keep = [binding.name.encode() for binding in translation.bindings]
+        table = (N.Binding*max(1, len(keep)))(*[N.Binding(name, int(binding.sampler), binding.slot, binding.count, int(binding.integer))
+                                                for name, binding in zip(keep, translation.bindings)])
+        handle = N.Handle()
+        N.check(N.lib().sfx_program_load(self.scene.context.handle, code, len(code), table, len(keep), C.byref(handle)))
+        self.release_program()
+        self.program, self.fallback, self.translated = handle, False, True
 
     @property
     def kernel(self) -> str:

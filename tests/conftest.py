@@ -1,4 +1,5 @@
 """pytest configuration: registers the `gpu` marker; `-m "not gpu"` runs on CPU only."""
+import os
 import sys
 from pathlib import Path
 
@@ -9,6 +10,8 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 GOLDEN = ROOT/"tests"/"golden"
+# code objects of run-time translated fragments stay inside the repository (build/ is git-ignored and travels to the GPU box)
+os.environ.setdefault("SHADERFLOW_JIT_CACHE", str(ROOT/"build"/"jit"))
 
 
 def pytest_configure(config):

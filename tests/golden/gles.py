@@ -50,7 +50,7 @@ class Context:
         gl.glGetString.restype = C.c_char_p
         gl.glGetUniformLocation.argtypes = [C.c_uint, C.c_char_p]
         gl.glGetAttribLocation.argtypes = [C.c_uint, C.c_char_p]
-        for name in ("glUniform1f", "glUniform2f", "glUniform3f"):
+        for name in ("glUniform1f", "glUniform2f", "glUniform3f", "glUniform4f"):
             getattr(gl, name).argtypes = [C.c_int] + [C.c_float]*int(name[9])
         gl.glVertexAttribPointer.argtypes = [C.c_uint, C.c_int, C.c_uint, C.c_ubyte, C.c_int, C.c_void_p]
         gl.glBufferData.argtypes = [C.c_uint, C.c_ssize_t, C.c_void_p, C.c_uint]
@@ -115,9 +115,10 @@ class Context:
         return handle.value
 
     # draw -------------------------------------------------------------------------------------------------
-    def draw(self, program: int, width: int, height: int, uniforms: dict, textures: dict, attributes: dict) -> np.ndarray:
+    def draw(self, program: int, width: int, height: int, uniforms: dict, textures: dict, attributes: dict, integers: dict = None) -> np.ndarray:
         """Fullscreen triangle strip into an RGBA8 target; returns (h, w, 4) uint8, row 0 = bottom.
-        uniforms: name → float or tuple of floats; textures: name → texture handle; attributes: name → (4, k) float32"""
+        uniforms: name → float or tuple of floats; textures: name → texture handle; attributes: name → (4, k) float32;
+        integers: name → int for uniforms declared int/bool"""
         gl = self.gl
         target, fbo = C.c_uint(), C.c_uint()
         gl.glGenTextures(1, C.byref(target))
@@ -135,6 +136,10 @@ class Context:
                 continue
             values = [float(v) for v in (value if hasattr(value, "__len__") else [value])]
             getattr(gl, f"glUniform{len(values)}f")(location, *values)
+        for name, value in (integers or {}).items():
+            location = gl.glGetUniformLocation(program, name.encode())
+            if location >= 0:
+                gl.glUniform1i(location, int(value))
         for unit, (name, handle) in enumerate(textures.items()):
             location = gl.glGetUniformLocation(program, name.encode())
             if location < 0:

@@ -52,12 +52,8 @@ def _matching_paren(text: str, start: int) -> int:
     raise ValueError("unbalanced parentheses")
 
 
-def to_es(source: str) -> str:
-    """GLSL 3.30 text → GLSL ES 3.00 text in which every scalar is a float (see the module docstring)"""
-    text = re.sub(r"/\*.*?\*/", "", source, flags=re.S)
-    text = re.sub(r"//[^\n]*", "", text)
-    text = re.sub(r"^\s*#version[^\n]*\n", "", text, flags=re.M)
-    # GLSL ES has no `##`: function-like macros that paste tokens (camera.glsl GetCamera) are expanded here
+def expand_pasting_macros(text: str) -> str:
+    """GLSL ES has no `##`: function-like macros that paste tokens (camera.glsl GetCamera) are expanded and removed"""
     for define in re.finditer(r"^[ \t]*#define[ \t]+(\w+)\((\w+)\)((?:[^\n]*\\\n)*[^\n]*##(?:[^\n]*\\\n)*[^\n]*)\n", text, flags=re.M):
         macro, parameter, body = define.group(1), define.group(2), define.group(3).replace("\\\n", "\n")
         text = text.replace(define.group(0), "")
@@ -66,6 +62,15 @@ def to_es(source: str) -> str:
             pasted = re.sub(rf"\b{parameter}\s*##\s*(\w+)", lambda m: argument + m.group(1), body)
             return re.sub(rf"\b{parameter}\b", argument, pasted)
         text = re.sub(rf"\b{macro}\(([^()]*)\)", expand, text)
+    return text
+
+
+def to_es(source: str) -> str:
+    """GLSL 3.30 text → GLSL ES 3.00 text in which every scalar is a float (see the module docstring)"""
+    text = re.sub(r"/\*.*?\*/", "", source, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r"^\s*#version[^\n]*\n", "", text, flags=re.M)
+    text = expand_pasting_macros(text)
     text = re.sub(r"\bsample\b", "sample_", text)                # reserved in GLSL ES 3.00, an ordinary name in 3.30
     keep: list[str] = []
 

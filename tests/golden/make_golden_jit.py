@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""
+Golden images for run-time translated fragments (shaderflow_amd/glsl2hip.py): the fragments of tests/golden/jit/*.glsl —
+written for this repository — rendered by the same independent OpenGL ES implementation as make_golden_gles.py, with the
+reference's prelude in front of them (read from /root/reference when this script runs, adapted by `to_es`, never stored).
+The fragments are valid GLSL 3.30 and GLSL ES 3.00 at once (explicit float literals, typed integers), so their own text
+is compiled as it is; `march.glsl` expands the reference's GetCamera macro and therefore goes through `to_es` whole.
+
+Stores the inputs and the RGBA8 images in jit.npz. The GPU tests translate the same texts with glsl2hip, load them with
+sfx_program_load and compare.
+
+usage: python tests/golden/make_golden_jit.py
+"""
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(HERE.parent.parent))
+
+import make_golden_gles as M  # noqa: E402
+from gles import Context  # noqa: E402
+from oracle import binding as O  # noqa: E402
+
+FRAGMENTS = HERE/"jit"
+
+# name → (width, height, oracle-uniform overrides, float uniforms, int uniforms, whole text through to_es)
+CASES = {
+    "waves": (160, 90, dict(iTime=1.75), {}, {}, False),
+    "march": (160, 90, dict(iTime=0.5, iCameraPosition=(0.2, 0.1, -0.5), iCameraZoom=0.9), {}, {}, True),
+    "march.stereo": (160, 90, dict(iCameraProjection=1, iCameraSeparation=0.1), {}, {}, True),
+    "cells": (128, 72, dict(iFrame=37), {}, {}, False),
+    "polar": (160, 90, dict(iTime=0.3), dict(iSpin=0.8, iScale=1.4, iCentre=(0.15, -0.1), iTint=(0.9, 1.0, 0.8, 0.95)), dict(iRings=6, iInvert=0), False),
+    "polar.inverted": (96, 54, dict(), dict(iSpin=2.5, iScale=0.7, iCentre=(-0.3, 0.2), iTint=(1.0, 0.7, 0.9, 1.0)), dict(iRings=3, iInvert=1), False),
+}
+
+
+def background(seed: int = 11, size=(48, 32)) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (size[1], size[0], 3), dtype=np.uint8)
+
+
+def build(name: str, samplers: list[str], whole: bool) -> tuple[str, str]:
+    content = (FRAGMENTS/f"{name.split('.')[0]}.glsl").read_text()
+    prelude = (M.SHADERS/"include/shaderflow.glsl").read_text() + "\n" + (M.SHADERS/"include/camera.glsl").read_text() + "\n"
+    vertex = M.HEADER + M.declarations("vertex", samplers) + M.to_es(prelude + (M.SHADERS/"vertex/default.glsl").read_text())
+    if whole:
+        fragment = M.HEADER + M.declarations("fragment", samplers) + M.to_es(prelude + content)
+    else:
+        fragment = M.HEADER + M.declarations("fragment", samplers) + M.to_es(prelude) + content
+    return vertex, fragment
+
+
+def main() -> None:
+    ctx = Context()
+    print(ctx.version)
+    out: dict[str, np.ndarray] = {"background": background()}
+    for name, (w, h, overrides, floats, integers, whole) in CASES.items():
+        u = O.default_uniforms(w, h, **overrides)
+        vertex, fragment = build(name, ["background"], whole)
+        program = ctx.program(vertex, fragment)
+        texture = ctx.texture(out["background"], True, True, True)
+        image = ctx.draw(program, w, h, M.uniform_values(u, **floats), {"background": texture},
+                         {"vertex_position": M.QUAD, "vertex_gluv": M.QUAD}, integers=integers)
+        out[f"{name}.image"] = image
+        print(f"{name:18s} {w}x{h} mean {image[..., :3].mean():6.1f}")
+    out["cases"] = np.array(json.dumps({name: dict(width=w, height=h, uniforms=overrides, floats=floats, integers=integers)
+                                        for name, (w, h, overrides, floats, integers, _) in CASES.items()}))
+    np.savez_compressed(HERE/"jit.npz", **out)
+    print("wrote", HERE/"jit.npz")
+
+
+if __name__ == "__main__":
+    main()

@@ -385,6 +385,9 @@ def test_host_api_odds_and_ends(tmp_path):
     scene.shader.fragment = "shadertoy"                                                                 # hot swap (shader.py:299-306): compiled on the next export
     second = frames_of(scene.main(width=64, height=36, fps=30, time=1/30, output=bytes), 64, 36)
     assert scene.shader.kernel == "shadertoy" and not np.array_equal(first, second)
-    scene.shader.fragment = "void main() { fragColor = vec4(0.2); }"
+    scene.shader.fragment = "void main() { fragColor = vec4(0.2); }"                                     # not in the registry: translated and compiled
+    third = frames_of(scene.main(width=64, height=36, fps=30, time=1/30, output=bytes), 64, 36)
+    assert scene.shader.kernel == "translated" and not scene.shader.fallback and (third == 51).all()
+    scene.shader.fragment = "void main() { fragColor = undeclared_function(stuv); }"                    # a compile error: missing.glsl (shader.py:323-340)
     scene.main(width=64, height=36, fps=30, time=1/30, freewheel=True)
-    assert scene.shader.kernel == "missing" and scene.shader.fallback
+    assert scene.shader.kernel == "missing" and scene.shader.fallback and "undeclared_function" in scene.shader.compile_error

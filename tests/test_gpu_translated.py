@@ -1,0 +1,195 @@
+"""
+Fragments outside the registry on the GPU: GLSL text → glsl2hip.translate → hipcc → sfx_program_load → the generic kernels.
+
+Checked against (1) an independent OpenGL implementation's rendering of the same GLSL (tests/golden/jit.npz, made by
+tests/golden/make_golden_jit.py), (2) the restated kernels where a fragment exists in both forms, (3) closed forms through
+a whole scene. The fragments are this repository's own (tests/golden/jit/*.glsl).
+"""
+import ctypes as C
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from shaderflow_amd import _native as N
+from shaderflow_amd import glsl2hip
+from tests.helpers import Gpu, lsb_report
+
+pytestmark = pytest.mark.gpu
+HERE = Path(__file__).parent
+G = np.load(HERE/"golden"/"jit.npz")
+CASES = json.loads(str(G["cases"]))
+CACHE = HERE.parent/"build"/"jit"
+
+
+@pytest.fixture()
+def gpu():
+    g = Gpu()
+    yield g
+    g.close()
+
+
+def load(gpu: Gpu, text: str, variables=()) -> tuple[N.Handle, glsl2hip.Translation]:
+    translation = glsl2hip.translate(text, variables)
+    code = glsl2hip.compile(translation, cache=CACHE)
+    names = [b.name.encode() for b in translation.bindings]
+    table = (N.Binding*max(1, len(names)))(*[N.Binding(n, int(b.sampler), b.slot, b.count, int(b.integer)) for n, b in zip(names, translation.bindings)])
+    handle = N.Handle()
+    N.check(gpu.lib.sfx_program_load(gpu.ctx.handle, code, len(code), table, len(names), C.byref(handle)))
+    return handle, translation
+
+
+def render_case(gpu: Gpu, name: str) -> np.ndarray:
+    case = CASES[name]
+    text = (HERE/"golden"/"jit"/f"{name.split('.')[0]}.glsl").read_text()
+    prog, _ = load(gpu, text, [("sampler2D", "background")])
+    overrides = {k: (tuple(v) if isinstance(v, list) else v) for k, v in case["uniforms"].items()}
+    gpu.set_uniforms(prog, O.default_uniforms(case["width"], case["height"], **overrides))
+    for key, value in case["floats"].items():
+        assert gpu.set_values(prog, key, value), key
+    for key, value in case["integers"].items():
+        assert gpu.set_values(prog, key, value, integer=True), key
+    gpu.bind(prog, "background", gpu.texture(G["background"], "linear", True, True))
+    image = gpu.render(prog, case["width"], case["height"])
+    N.check(gpu.lib.sfx_program_destroy(prog))
+    return image
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_translated_fragment_against_an_opengl_implementation(gpu, name):
+    got = render_case(gpu, name)
+    want = G[f"{name}.image"]
+    d = np.abs(got.astype(int) - want.astype(int))
+    print(name, lsb_report(got, want))
+    assert d.max() <= 1 and (d == 0).mean() >= 0.98, lsb_report(got, want)
+
+
+GRADIENT = """
+void main() {
+    fragColor = vec4(stuv.x, 1 - stuv.x, iTime/2, 1);
+}
+"""
+
+
+def test_fused_resolve_of_a_translated_fragment_equals_render_then_resolve(gpu):
+    """sfx_render_resolve on a loaded program (its own code object's fused kernels) against sfx_render + sfx_resolve"""
+    text = (HERE/"golden"/"jit"/"waves.glsl").read_text()
+    prog, _ = load(gpu, text, [("sampler2D", "background")])
+    gpu.bind(prog, "background", gpu.texture(G["background"], "linear", True, True))
+    for (ssaa, subsample) in ((1, 1), (2, 2), (2, 1), (4, 4), (4, 2)):
+        w, h = 100, 58
+        u = O.default_uniforms(w, h, iTime=0.4, iSSAA=float(ssaa))
+        gpu.set_uniforms(prog, u)
+        fused = gpu.render_resolve(prog, w, h, ssaa, subsample)
+        screen = gpu.render(prog, w*ssaa, h*ssaa)
+        two_pass = gpu.resolve(screen, w, h, subsample)
+        d = np.abs(fused.astype(int) - two_pass.astype(int))
+        assert d.max() <= 1, ((ssaa, subsample), lsb_report(fused, two_pass))
+    N.check(gpu.lib.sfx_program_destroy(prog))
+
+
+def test_implicit_conversions_compute_what_the_explicit_text_computes(gpu):
+    """GLSL 3.30 converts int to float implicitly (§4.1.10); the translation must give the same bits as the text that spells the floats out"""
+    loose = """
+    const int N = 3;
+    float falloff(float x, int power) { float r = 1; for (int i = 0; i < power; i++) r *= x; return r; }
+    void main() {
+        vec3 c = vec3(1, 11, 26)/255;
+        vec2 p = gluv*2 - 1/2;
+        c += max(p.x, 0) + clamp(p.y, 0, 1) + pow(abs(p.x), 2) + mix(0, 1, stuv.y) + smoothstep(0, 2, length(p)) + step(1, p.x);
+        c *= 1 - 0.25*falloff(stuv.x, N);
+        c.rg += mod(p, 2)/4;
+        float k = 3;
+        c.b += k/4 + float(N)/8 + N/2;
+        fragColor = vec4(c/(1 + c), 1);
+    }"""
+    strict = """
+    const int N = 3;
+    float falloff(float x, int power) { float r = 1.0; for (int i = 0; i < power; i++) r *= x; return r; }
+    void main() {
+        vec3 c = vec3(1.0, 11.0, 26.0)/255.0;
+        vec2 p = gluv*2.0 - float(1/2);
+        c += max(p.x, 0.0) + clamp(p.y, 0.0, 1.0) + pow(abs(p.x), 2.0) + mix(0.0, 1.0, stuv.y) + smoothstep(0.0, 2.0, length(p)) + step(1.0, p.x);
+        c *= 1.0 - 0.25*falloff(stuv.x, N);
+        c.rg += mod(p, 2.0)/4.0;
+        float k = 3.0;
+        c.b += k/4.0 + float(N)/8.0 + float(N/2);
+        fragColor = vec4(c/(1.0 + c), 1.0);
+    }"""
+    images = []
+    for text in (loose, strict):
+        prog, _ = load(gpu, text)
+        gpu.set_uniforms(prog, O.default_uniforms(96, 54))
+        images.append(gpu.render(prog, 96, 54, comps=4, dtype=np.float32))
+        N.check(gpu.lib.sfx_program_destroy(prog))
+    assert np.array_equal(images[0], images[1]) and images[0].std() > 0.01
+
+
+def test_translated_gradient_is_the_closed_form(gpu):
+    prog, _ = load(gpu, GRADIENT)
+    w, h = 64, 8
+    gpu.set_uniforms(prog, O.default_uniforms(w, h, iTime=1.0))
+    got = gpu.render(prog, w, h, comps=4, dtype=np.float32)
+    x = ((np.arange(w, dtype=np.float32) + np.float32(0.5))/np.float32(w)).astype(np.float32)
+    aspect = np.float32(w)/np.float32(h)
+    stuv_x = ((((x*np.float32(2) - np.float32(1))*aspect) + np.float32(1))/np.float32(2)).astype(np.float32)
+    assert np.array_equal(got[3, :, 0], stuv_x) and np.array_equal(got[3, :, 1], np.float32(1) - stuv_x)
+    assert (got[..., 2] == 0.5).all() and (got[..., 3] == 1).all()
+    N.check(gpu.lib.sfx_program_destroy(prog))
+
+
+def test_a_code_object_built_against_other_headers_is_refused(gpu):
+    translation = glsl2hip.translate(GRADIENT)
+    code = bytearray(glsl2hip.compile(translation, cache=CACHE))
+    handle = N.Handle()
+    with pytest.raises(N.NativeError):
+        N.check(gpu.lib.sfx_program_load(gpu.ctx.handle, bytes(code[:4096]), 4096, None, 0, C.byref(handle)))      # truncated: not a code object
+
+
+def test_scene_with_its_own_fragment_through_the_frame_tape(gpu):
+    """A stock scene with a fragment of its own batches through the clock tape (iTime/iFrame per frame on the device) like a registry
+    fragment does: same bytes as the frame loop, fused and two-pass"""
+    from shaderflow_amd import ShaderScene
+    from shaderflow_amd.tape import FrameTape
+
+    class Pulse(ShaderScene):
+        def build(self):
+            super().build()
+            self.shader.fragment = "void main() { vec2 p = gluv*rotate2d(iTime); fragColor = vec4(0.5 + 0.5*sin(4.0*p.x + iTime), fract(float(iFrame)/16.0), stuv.y, 1.0); }"
+
+    assert FrameTape.applicable(Pulse())
+    for ssaa in (1, 2):
+        kw = dict(width=96, height=54, fps=60, time=70/60, ssaa=ssaa, output=bytes)
+        loop = np.frombuffer(Pulse().main(batch=False, **kw), np.uint8).reshape(70, 54, 96, 3)
+        scene = Pulse()
+        tape = np.frombuffer(scene.main(batch=None, **kw), np.uint8).reshape(70, 54, 96, 3)
+        assert scene.shader.kernel == "translated"
+        assert np.array_equal(loop, tape), lsb_report(tape, loop)
+        assert [int(f[0, 0, 1]) for f in tape[:4]] == [int(np.rint(np.float32(k)/np.float32(16)*255)) for k in range(4)]
+
+
+def test_scene_with_its_own_fragment_and_uniforms(gpu):
+    """A scene whose fragment and uniforms exist nowhere in the registry (frame loop: its pipeline is python): the frames are the
+    closed form of the fragment"""
+    from shaderflow_amd import ShaderScene
+    from shaderflow_amd.variable import Uniform
+
+    class Custom(ShaderScene):
+        def build(self):
+            super().build()
+            self.shader.fragment = "void main() { fragColor = vec4(iLevel*stuv.x, iShade.g, float(iFrame)/8.0, 1.0); }"
+
+        def pipeline(self):
+            yield from ShaderScene.pipeline(self)
+            yield Uniform("float", "iLevel", 0.5)
+            yield Uniform("vec3", "iShade", (0.1, 0.6, 0.3))
+
+    scene = Custom()
+    raw = scene.main(width=64, height=36, fps=30, time=4/30, output=bytes)
+    frames = np.frombuffer(raw, np.uint8).reshape(-1, 36, 64, 3)
+    assert scene.shader.kernel == "translated" and len(frames) == 4
+    assert (frames[..., 1] == 153).all()                                       # 0.6*255
+    assert [int(f[0, 0, 2]) for f in frames] == [int(np.rint(np.float32(k)/np.float32(8)*255)) for k in range(4)]
+    assert frames[0, 0, -1, 0] > frames[0, 0, 0, 0]
