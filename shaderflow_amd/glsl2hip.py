@@ -79,7 +79,7 @@ class Translation:
 
 _TOKEN = re.compile(r"""
     (?P<comment>//[^\n]*|/\*.*?\*/)
-  | (?P<pp>(?<![^\n])[ \t]*\#(?:[^\n\\]|\\.|\\\n)*)
+  | (?P<pp>\#(?:[^\n\\]|\\.|\\\n)*)
   | (?P<number>0[xX][0-9a-fA-F]+[uU]?|(?:\d+\.\d*|\.\d+|\d+)(?:[eE][+-]?\d+)?(?:lf|LF|[fFuU])?)
   | (?P<ident>[A-Za-z_]\w*)
   | (?P<op><<=|>>=|\+\+|--|<<|>>|<=|>=|==|!=|&&|\|\||\^\^|[-+*/%&|^]=|[-+*/%<>=!&|^~?:;,.(){}\[\]])
@@ -120,7 +120,7 @@ def tokenize(source: str) -> list[Tok]:
     tokens, position = [], 0
     while position < len(source):
         match = _TOKEN.match(source, position)
-        if match is None:
+        if match is None or (match.lastgroup == "pp" and source[source.rfind("\n", 0, position) + 1:position].strip()):
             raise TranslationError(f"unexpected character {source[position]!r} at offset {position}")
         tokens.append(Tok(match.lastgroup, match.group()))
         position = match.end()

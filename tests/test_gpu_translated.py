@@ -159,7 +159,9 @@ def test_scene_with_its_own_fragment_through_the_frame_tape(gpu):
             super().build()
             self.shader.fragment = "void main() { vec2 p = gluv*rotate2d(iTime); fragColor = vec4(0.5 + 0.5*sin(4.0*p.x + iTime), fract(float(iFrame)/16.0), stuv.y, 1.0); }"
 
-    assert FrameTape.applicable(Pulse())
+    probe = Pulse()
+    probe.initialize()
+    assert FrameTape.applicable(probe)
     for ssaa in (1, 2):
         kw = dict(width=96, height=54, fps=60, time=70/60, ssaa=ssaa, output=bytes)
         loop = np.frombuffer(Pulse().main(batch=False, **kw), np.uint8).reshape(70, 54, 96, 3)

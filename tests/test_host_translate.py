@@ -1,0 +1,188 @@
+"""
+glsl2hip on the CPU: what the translator rewrites (and what it refuses), the bindings it hands to sfx_program_load, that its
+output compiles for gfx950 (hipcc cross-compiles without a GPU), and the GLSL semantics of csrc/jit_runtime.hpp executed on
+the host. The rendering of translated fragments is checked on the GPU (tests/test_gpu_translated.py).
+"""
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+
+from shaderflow_amd import glsl2hip as G
+
+ROOT = Path(__file__).resolve().parent.parent
+FRAGMENTS = ROOT/"tests"/"golden"/"jit"
+CACHE = ROOT/"build"/"jit"
+
+
+def body(cpp: str) -> str:
+    return cpp.split("// ---- translated fragment ----")[1].split("// ---- end of translated fragment ----")[0]
+
+
+def test_floating_literals_get_a_suffix_and_integers_do_not():
+    out = body(G.translate("void main() { float a = 1.0 + .5 + 2. + 1e-4 + 3E5 + 7 + 0x1F + 2u + 1.5f + 4.0lf; }").cpp)
+    assert "1.0f + .5f + 2.f + 1e-4f + 3E5f + 7 + 0x1F + 2u + 1.5f + 4.0f" in out
+    assert G.translate("void main() { vec2 v1 = gluv; float b = v1.x*2.5; }").cpp.count("v1.x*2.5f") == 1     # `v1.x`: not a literal
+
+
+def test_parameter_qualifiers_become_values_and_references():
+    out = body(G.translate("void f(in float a, out vec3 b, inout float c, const in vec2 d) { b = vec3(a); c += d.x; }\nvoid main() {}").cpp)
+    head = re.sub(r"\s+", " ", out.split("{")[0])
+    assert "SF_HD void f( float a, vec3& b, float& c, const vec2 d)" in head.replace("  ", " ")
+    assert "SF_HD void main_()" in out
+    with pytest.raises(G.TranslationError):
+        G.translate("void f(out float a[3]) {}\nvoid main() {}")
+
+
+def test_declarations_of_the_engine_go_and_globals_become_members():
+    source = """#version 330
+    precision highp float;
+    uniform float iLevel;
+    uniform vec3 iShade = vec3(1);
+    in vec2 stuv;
+    layout(location = 0) out vec4 fragColor;
+    in vec2 extra_varying;
+    float helper(float x);
+    float counter = 0;
+    const float GAIN = 2.0*1.5;
+    const int N = 3;
+    const float SCALED = GAIN*N;
+    const vec2 CORNER = vec2(1, 0);
+    const float ROOT = sqrt(2.0);
+    float helper(float x) { return x*GAIN; }
+    void main() { fragColor = vec4(helper(iLevel)); }"""
+    translation = G.translate(source)
+    out = body(translation.cpp)
+    assert "#version" not in out and "precision" not in out and "uniform" not in out and "layout" not in out
+    assert "vec2 extra_varying;" in out and "in vec2" not in out
+    assert out.count("helper") == 2                                             # the prototype is gone: definition and call remain
+    assert "static constexpr float GAIN = 2.0f*1.5f;" in out and "static constexpr int N = 3;" in out and "static constexpr float SCALED = GAIN*N;" in out
+    assert "const vec2 CORNER = vec2(1, 0);" in out and "static constexpr vec2" not in out
+    assert "const float ROOT = sqrt(2.0f);" in out                             # a call: not a constant expression for C++
+    assert "float counter = 0;" in out
+    names = {(b.name, b.type, b.slot, b.count) for b in translation.bindings}
+    assert names == {("iLevel", "float", 0, 1), ("iShade", "vec3", 1, 3)}
+    assert "iLevel = user_(0);" in translation.cpp and "iShade = vec3(user_(1), user_(2), user_(3));" in translation.cpp
+
+
+def test_bindings_follow_the_pipeline_and_skip_what_the_fragment_does_not_read():
+    source = """#define background background0x0
+    #define iScreen iScreen0x1
+    #define iScreen1 iScreen1x1
+    void main() { fragColor = texture(background, astuv)*iGain + texture(iSpectrogram, vec2(0, 0)) + float(iCount) + (iFlag ? 1 : 0) + iTime; }"""
+    pipeline = [("float", "iTime"), ("sampler2D", "background0x0"), ("sampler2D", "iScreen0x1"), ("sampler2D", "iScreen1x1"), ("sampler2D", "iSpectrogram"),
+                ("float", "iGain"), ("int", "iCount"), ("bool", "iFlag"), ("vec4", "iUnused"), ("sampler2D", "iWaveform")]
+    translation = G.translate(source, pipeline)
+    by_name = {b.name: b for b in translation.bindings}
+    assert set(by_name) == {"background0x0", "iSpectrogram", "iGain", "iCount", "iFlag"}      # iScreen*: defined but not reached; iTime: built in
+    assert by_name["iSpectrogram"].slot == 1 and by_name["background0x0"].slot == 0 and by_name["background0x0"].sampler
+    assert (by_name["iGain"].slot, by_name["iCount"].slot, by_name["iFlag"].slot) == (0, 1, 2)
+    assert by_name["iCount"].integer and by_name["iFlag"].integer and not by_name["iGain"].integer
+    assert "iCount = user_int_(1);" in translation.cpp and "iFlag = user_int_(2) != 0;" in translation.cpp
+    assert translation.cpp.rstrip().endswith("SF_JIT_ENTRY_POINTS(sf::rt::Fragment)") and "#undef background" in translation.cpp
+    with pytest.raises(G.TranslationError):
+        G.translate("void main() { fragColor = vec4(0); }" + "".join(f" // s{k}" for k in range(1)), [("mat3", "iMatrix")] if False else [])\
+            if False else G.translate("uniform mat3 iMatrix;\nvoid main() { fragColor = vec4(iMatrix[0], 1); }")
+    with pytest.raises(G.TranslationError):
+        G.translate("void main() { fragColor = " + " + ".join(f"texture(s{k}, stuv)" for k in range(17)) + "; }", [("sampler2D", f"s{k}") for k in range(17)])
+
+
+def test_arrays_casts_keywords_and_discard():
+    source = """
+    const float WEIGHTS[] = float[](0.25, 0.5, 0.25);
+    vec3[2] PAIR = vec3[2](vec3(0), vec3(1));
+    struct Ray { vec3 origin; vec3 direction; };
+    float new = 1.0;
+    void main() {
+        float taps[3] = float[3](1.0, 2.0, 3.0);
+        int index = int(fragCoord.x) % 3;
+        uint bits = uint(index) << 2u;
+        Ray ray = Ray(vec3(0), vec3(0, 0, 1));
+        bool not = false;
+        if (taps[index] > 2.5 || not) discard;
+        fragColor = vec4(WEIGHTS[index]*new + float(bits), PAIR[1].xy, ray.direction.z);
+    }"""
+    out = body(G.translate(source).cpp)
+    assert "const float WEIGHTS[3] = {0.25f, 0.5f, 0.25f};" in out
+    assert re.search(r"vec3 PAIR\[2\] = \{vec3\(0\), vec3\(1\)\};", out)
+    assert "float taps[3] = {1.0f, 2.0f, 3.0f};" in out
+    assert "to_int(fragCoord.x) % 3" in out and "to_uint(index) << 2u" in out and "float(bits)" in out
+    assert "float new_ = 1.0f;" in out and "bool not_ = false;" in out and "WEIGHTS[index]*new_" in out
+    assert "{ discarded_ = true; return; }" in out
+    assert "Ray ray = Ray(vec3(0), vec3(0, 0, 1));" in out                     # C++20 initialises the aggregate from parentheses
+    with pytest.raises(G.TranslationError):
+        G.translate("float f() { discard; return 1.0; }\nvoid main() {}")
+    with pytest.raises(G.TranslationError):
+        G.translate("void main() { fragColor = vec4(0); ")
+
+
+def test_macros_are_rewritten_too_and_removed_afterwards():
+    translation = G.translate("#define HALF 0.5\n#define scale(x) ((x)*2.0)\n#if 1\nvoid main() { fragColor = vec4(scale(HALF)); }\n#endif\n")
+    assert "#define HALF 0.5f" in translation.cpp and "#define scale(x) ((x)*2.0f)" in translation.cpp
+    assert "#undef HALF" in translation.cpp and "#undef scale" in translation.cpp and "#if 1" in translation.cpp
+
+
+@pytest.mark.parametrize("name", sorted(p.stem for p in FRAGMENTS.glob("*.glsl")))
+def test_repository_fragments_translate(name):
+    translation = G.translate((FRAGMENTS/f"{name}.glsl").read_text(), [("sampler2D", "background")])
+    assert "SF_HD void main_()" in translation.cpp
+    assert translation.key == G.translate((FRAGMENTS/f"{name}.glsl").read_text(), [("sampler2D", "background")]).key
+
+
+def test_translation_compiles_for_gfx950_and_exports_the_entry_points():
+    translation = G.translate((FRAGMENTS/"polar.glsl").read_text())
+    code = G.compile(translation, cache=CACHE)
+    assert code.startswith((b"__CLANG_OFFLOAD_BUNDLE__", b"\x7fELF")) and b"gfx950" in code
+    for symbol in (b"sfx_jit_render", b"sfx_jit_fused_1", b"sfx_jit_fused_2", b"sfx_jit_fused_4", b"sfx_jit_layout"):
+        assert symbol in code, symbol
+    assert (CACHE/f"{translation.key}.hsaco").exists()                         # second call: served from the cache
+    assert G.compile(translation, cache=CACHE) == code
+
+
+def test_compile_errors_carry_the_compiler_message():
+    translation = G.translate("void main() { fragColor = undeclared_function(stuv); }")
+    with pytest.raises(G.CompileError) as error:
+        G.compile(translation, cache=CACHE)
+    assert "undeclared_function" in str(error.value)
+
+
+def test_runtime_header_semantics_on_the_host(tmp_path):
+    """tests/jit_runtime_check.hip: swizzles, constructors, implicit conversions, matrix products and the prelude, run on the CPU"""
+    binary = tmp_path/"jit_runtime_check"
+    build = subprocess.run([G.HIPCC, "--offload-arch=gfx950", "-std=c++20", "-ffp-contract=off", "-O1", f"-I{G.CSRC}",
+                            str(ROOT/"tests"/"jit_runtime_check.hip"), "-o", str(binary)], capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([str(binary)], capture_output=True, text=True, timeout=60)
+    assert run.returncode == 0 and "all checks passed" in run.stdout, run.stdout + run.stderr
+
+
+REFERENCE = Path("/root/reference")
+
+
+@pytest.mark.skipif(not REFERENCE.exists(), reason="the reference checkout is only present in the build container")
+def test_every_fragment_of_the_reference_translates_and_a_few_compile(tmp_path):
+    """Real-world GLSL in the reference's own style (implicit conversions, float loop counters, macros, switch, texelFetch, structs):
+    every fragment it ships goes through the translator; a cross-section is compiled for gfx950. Read in place, nothing is stored."""
+    files = sorted((REFERENCE/"examples").rglob("*.frag")) + sorted((REFERENCE/"examples").rglob("*.glsl")) \
+        + sorted((REFERENCE/"shaderflow"/"resources"/"shaders"/"fragment").glob("*.glsl"))
+    assert len(files) >= 14
+    samplers = ["background", "iSpectrogram", "iWaveform", "child", "iVideo"] + [f"iScreen{t}x{l}" for t in range(4) for l in range(2)] + [f"iLife{t}x0" for t in range(5)]
+    pipeline = [("sampler2D", name) for name in samplers] + [("float", "iShaderDynamics"), ("int", "iScreenTemporal"), ("int", "iScreenLayers"),
+                                                              ("vec2", "iScreenSize"), ("vec2", "iLifeSize"), ("int", "iLifePeriod"), ("int", "iLifeTemporal")]
+    # what ShaderTexture.defines() injects for the history textures (texture.py:349-363)
+    defines = [f"#define iScreen{t or ''} iScreen{t}x1" for t in range(4)] + [f"#define iLife{t or ''} iLife{t}x0" for t in range(5)]
+    defines.append("vec4 iScreenTexture(int temporal, int layer, vec2 astuv) {")
+    for t in range(4):
+        for layer in range(2):
+            defines += [f"    if (temporal == {t} && layer == {layer})", f"        return texture(iScreen{t}x{layer}, astuv);"]
+    defines += ["    return vec4(0.0);", "}"]
+    compiled = 0
+    for path in files:
+        translation = G.translate("\n".join(defines) + "\n" + path.read_text(), pipeline)
+        assert "SF_HD void main_()" in translation.cpp, path.name
+        if path.name in ("visualizer.frag", "motionblur.frag", "simulation.glsl", "tetration.frag"):
+            # (a scratch cache: nothing derived from the reference's text stays in the tree that travels to the GPU box)
+            assert G.compile(translation, cache=tmp_path).startswith((b"__CLANG_OFFLOAD_BUNDLE__", b"\x7fELF")), path.name
+            compiled += 1
+    assert compiled == 4
