@@ -675,8 +675,49 @@ template <class FRAGMENT> struct JitShader : PlainShader<FRAG_DEFAULT> {
 
 }  // namespace sf
 
+// Host-side execution of a translated fragment, for tests only (tests/test_host_translate.py builds the translation unit as a
+// shared library with -DSF_JIT_HOST and compares its pixels with the parity oracle; no product path defines SF_JIT_HOST).
+#ifdef SF_JIT_HOST
+#include "uniform_table.hpp"
+extern "C" {
+inline size_t sfx_jit_host_uniforms_size() { return sizeof(sf::Uniforms); }
+inline size_t sfx_jit_host_textures_size() { return sizeof(sf::Tex)*sf::TEX_SLOTS; }
+inline void sfx_jit_host_defaults(sf::Uniforms* u) { sf::default_uniforms(*u); }
+inline int sfx_jit_host_uniform(sf::Uniforms* u, const char* name, const float* values, int count) {
+    for (const auto& f : sf::g_uniform_fields) {
+        if (strcmp(f.name, name)) continue;
+        for (int k = 0; k < count && k < f.count; k++) {
+            if (f.integer) ((int*)((char*)u + f.offset))[k] = (int)values[k];
+            else ((float*)((char*)u + f.offset))[k] = values[k];
+        }
+        return 1;
+    }
+    return 0;
+}
+inline void sfx_jit_host_user(sf::Uniforms* u, int slot, const void* words, int count) { memcpy(&u->user[slot], words, 4*(size_t)count); }
+inline void sfx_jit_host_texture(sf::Tex* textures, int slot, const void* data, int width, int height, int components, int dtype, int filter, int repeat_x, int repeat_y) {
+    textures[slot] = sf::Tex{data, width, height, components, dtype, filter, repeat_x, repeat_y};
+}
+}
+#define SF_JIT_HOST_POINTS(FRAGMENT) \
+    extern "C" void sfx_jit_host_render(const sf::Uniforms* u, const sf::Tex* textures, int wr, int hr, unsigned* rgba8) { \
+        sf::RenderArgs a{}; \
+        const float aspect = u->iResolution[0]/u->iResolution[1]; \
+        for (int j = 0; j < hr; j++) for (int i = 0; i < wr; i++) { \
+            sf::Frag f; f.u = u; f.tex = textures; f.history = textures + sf::TEX_HISTORY; \
+            sf::make_varyings(f, i, j, wr, hr, aspect); \
+            rgba8[(size_t)j*wr + i] = sf::pack_rgba8(sf::JitShader<FRAGMENT>::run(a, f, {}, {})); \
+        } \
+    } \
+    extern "C" void* sfx_jit_host_keep[] = {(void*)sfx_jit_host_uniforms_size, (void*)sfx_jit_host_textures_size, (void*)sfx_jit_host_defaults, \
+                                            (void*)sfx_jit_host_uniform, (void*)sfx_jit_host_user, (void*)sfx_jit_host_texture};
+#else
+#define SF_JIT_HOST_POINTS(FRAGMENT)
+#endif
+
 // Entry points of a code object (capi: sfx_program_load looks them up by these names)
 #define SF_JIT_ENTRY_POINTS(FRAGMENT) \
+    SF_JIT_HOST_POINTS(FRAGMENT) \
     extern "C" __device__ __attribute__((used)) const unsigned sfx_jit_layout = (unsigned)sizeof(sf::RenderArgs); \
     extern "C" __global__ __launch_bounds__(256) void sfx_jit_render(const sf::RenderArgs a) { sf::render_body<sf::JitShader<FRAGMENT>>(a); } \
     extern "C" __global__ __launch_bounds__(256) void sfx_jit_fused_1(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT>, 1>(a); } \

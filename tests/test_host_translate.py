@@ -186,3 +186,69 @@ def test_every_fragment_of_the_reference_translates_and_a_few_compile(tmp_path):
             assert G.compile(translation, cache=tmp_path).startswith((b"__CLANG_OFFLOAD_BUNDLE__", b"\x7fELF")), path.name
             compiled += 1
     assert compiled == 4
+
+
+# ---- translated fragments executed on the host ---------------------------------------------------------------------------
+
+def test_translated_fragments_on_the_host_match_the_opengl_goldens():
+    """The repository's own fragments, translated and run on the CPU, against their OpenGL ES renderings (tests/golden/jit.npz)"""
+    import json
+
+    import numpy as np
+
+    from oracle import binding as O
+    from tests.jit_host import HostFragment
+    golden = np.load(ROOT/"tests"/"golden"/"jit.npz")
+    cases = json.loads(str(golden["cases"]))
+    for name in ("waves", "cells", "polar"):
+        case = cases[name]
+        host = HostFragment(G.translate((FRAGMENTS/f"{name}.glsl").read_text(), [("sampler2D", "background")]), CACHE)
+        overrides = {k: (tuple(v) if isinstance(v, list) else v) for k, v in case["uniforms"].items()}
+        host.set_uniforms(O.default_uniforms(case["width"], case["height"], **overrides))
+        for key, value in {**case["floats"], **case["integers"]}.items():
+            host.set(key, value)
+        host.bind("background", golden["background"])
+        got = host.render(case["width"], case["height"])
+        d = np.abs(got.astype(int) - golden[f"{name}.image"].astype(int))
+        assert d.max() <= 1 and (d == 0).mean() >= 0.98, (name, int(d.max()), float((d == 0).mean()))
+
+
+REFERENCE_CASES = {
+    # oracle fragment name → (file under /root/reference, textures it samples)
+    "default": ("shaderflow/resources/shaders/fragment/default.glsl", ()),
+    "shadertoy": ("examples/basic/shaders/shadertoy.frag", ()),
+    "raymarch": ("examples/basic/shaders/raymarch.frag", ()),
+    "tetration": ("examples/fractals/shaders/tetration.frag", ()),
+    "mandelbrot": ("examples/fractals/shaders/mandelbrot.frag", ()),
+    "bars": ("examples/basic/shaders/bars.frag", ("iSpectrogram",)),
+    "waveform": ("examples/basic/shaders/waveform.frag", ("iWaveform",)),
+    "visualizer": ("examples/basic/shaders/visualizer.frag", ("background", "iSpectrogram", "iWaveform")),
+}
+
+
+@pytest.mark.skipif(not REFERENCE.exists(), reason="the reference checkout is only present in the build container")
+@pytest.mark.parametrize("name", list(REFERENCE_CASES))
+def test_mechanical_translation_of_the_reference_equals_the_restatement(name, tmp_path):
+    """Two independent derivations of the same pixels: the oracle restates the reference's fragments by hand (and the HIP kernels are
+    bit-exact against it on the GPU); here the reference's GLSL text itself goes through the translator and runs on the CPU. Both must
+    give the same bytes: they share sfmath's operations, and neither re-associates what the GLSL spells out."""
+    import numpy as np
+
+    from oracle import binding as O
+    from tests.helpers import oracle_textures, visualizer_inputs
+    from tests.jit_host import HostFragment
+    path, samplers = REFERENCE_CASES[name]
+    w, h = 96, 54
+    u, arrays, params = visualizer_inputs(w, h, seed=9)
+    u.iTau = 0.3
+    translation = G.translate((REFERENCE/path).read_text(), [("sampler2D", s) for s in ("background", "iSpectrogram", "iWaveform")])
+    host = HostFragment(translation, tmp_path)
+    host.set_uniforms(u)
+    for sampler in samplers:
+        assert host.bind(sampler, arrays[sampler], *params[sampler])
+    got = host.render(w, h)
+    want = O.render(name, u, oracle_textures({k: arrays[k] for k in samplers}, params), w, h, threads=4)
+    d = np.abs(got.astype(int) - want.astype(int))
+    exact = float((d == 0).mean())
+    print(f"{name}: max {d.max()} LSB, {exact*100:.3f}% exact")
+    assert np.array_equal(got, want), (int(d.max()), exact)                       # observed: identical bytes, tetration's chaotic boundary included
