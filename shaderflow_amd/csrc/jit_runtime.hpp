@@ -669,6 +669,7 @@ template <class FRAGMENT> struct JitShader : PlainShader<FRAG_DEFAULT> {
         s.load_(f);
         s.load_user_();
         s.main_();
+        if (s.discarded_) return {0.0f, 0.0f, 0.0f, 0.0f};        // `discard`: the target keeps its cleared value (no previous content in a fused target)
         return {s.fragColor.x, s.fragColor.y, s.fragColor.z, s.fragColor.w};
     }
 };

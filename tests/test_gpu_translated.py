@@ -195,3 +195,49 @@ def test_scene_with_its_own_fragment_and_uniforms(gpu):
     assert (frames[..., 1] == 153).all()                                       # 0.6*255
     assert [int(f[0, 0, 2]) for f in frames] == [int(np.rint(np.float32(k)/np.float32(8)*255)) for k in range(4)]
     assert frames[0, 0, -1, 0] > frames[0, 0, 0, 0]
+
+
+def test_scenes_with_several_translated_programs_layers_and_history(gpu):
+    """What the reference's MultiShader and Multipass/MotionBlur scenes do, with fragments of this repository: a second program whose
+    texture is sampled by name, a layered target, and a temporal history read back — frames follow the closed forms"""
+    from shaderflow_amd import ShaderProgram, ShaderScene
+
+    class TwoPrograms(ShaderScene):
+        def build(self):
+            super().build()
+            self.child = ShaderProgram(scene=self, name="child")
+            self.child.fragment = "void main() { fragColor = vec4(astuv.x, 0.25, 0.5, 1.0); }"
+            self.shader.fragment = "void main() { fragColor = vec4(texture(child, astuv).rgb*vec3(1.0, 2.0, 0.5), 1.0); if (astuv.y > 0.75) discard; }"
+
+    frames = np.frombuffer(TwoPrograms().main(width=64, height=32, fps=30, time=2/30, output=bytes), np.uint8).reshape(2, 32, 64, 3)
+    # rows of `output=bytes` are GL's, bottom-up: the top quarter was discarded (final.glsl at ssaa 1, subsample 2 blends the rows next to the edge)
+    kept = frames[0][:23]
+    assert (frames[0][25:] == 0).all()
+    assert (kept[..., 1] == 128).all() and (kept[..., 2] == 64).all() and kept[0, -1, 0] > 250 and kept[0, 0, 0] < 4
+
+    class Feedback(ShaderScene):
+        """layer 0 draws a bar that moves with the frame number, layer 1 averages it with what layer 1 showed one frame ago"""
+        def build(self):
+            super().build()
+            self.shader.texture.layers = 2
+            self.shader.texture.temporal = 2
+            self.shader.fragment = (
+                "void main() {\n"
+                "    if (iLayer == 0) { fragColor = vec4(vec3(step(float(iFrame)/4.0, astuv.x)), 1.0); return; }\n"
+                "    vec4 now = texture(iScreen0x0, astuv);\n"
+                "    vec4 before = iScreenTexture(1, 1, astuv);\n"
+                "    fragColor = vec4(0.5*now.rgb + 0.5*before.rgb, 1.0);\n"
+                "}\n")
+
+    scene = Feedback()
+    frames = np.frombuffer(scene.main(width=64, height=32, fps=30, time=6/30, subsample=1, output=bytes), np.uint8).reshape(6, 32, 64, 3)   # subsample 1: final.glsl is a copy
+    assert scene.shader.kernel == "translated"
+    # iFinal shows the frame rendered temporal-1 = 1 frame earlier (DESIGN.md "Layered and temporal targets"); the first is black
+    assert (frames[0] == 0).all()
+    row = frames[:, 16, :, 0].astype(int)
+    expected_previous = np.zeros(64)
+    for k in range(5):                                                          # frame k of the render loop is shown as output k+1
+        bar = ((np.arange(64) + 0.5)/64 >= k/4.0).astype(float)
+        value = 0.5*bar + 0.5*expected_previous
+        assert np.abs(row[k + 1] - np.rint(value*255)).max() <= 1, k
+        expected_previous = np.rint(value*255)/255
