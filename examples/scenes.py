@@ -4,6 +4,7 @@ names, same module construction, same parameters — with two differences forced
 fragments are named by their registry entry instead of a path into the reference's examples/basic/shaders/, and
 assets are synthetic (shaderflow_amd.synth) because the originals are downloads (demo.py:16-49).
 With the reference checked out, its own demo.py runs unchanged after `shaderflow_amd.install_alias()`.
+`Plasma` is not from the reference: it shows a user-written fragment going through the run-time translator.
 """
 from __future__ import annotations
 
@@ -185,6 +186,34 @@ class Video(ShaderScene):
             frames, fps = self.clip if self.clip is not None else (synth.background_image(64, 36)[None].repeat(4, 0), 30.0)
             self.video = ShaderVideo(scene=self, frames=frames, fps=fps)
         self.shader.fragment = "video"
+
+
+class Plasma(ShaderScene):
+    """A scene with a fragment of its own (not one of the reference's): the GLSL below is translated to HIP C++, compiled
+    with hipcc on first use and cached (shaderflow_amd/glsl2hip.py). Scene-defined uniforms come from `pipeline()` like in the
+    reference; being a stock scene otherwise, it batches through the clock tape."""
+    FRAGMENT = """
+        // sum of rotating plane waves, coloured through the prelude's hsv2rgb
+        #define WAVES 5
+        float wave(vec2 p, float k) {
+            vec2 direction = vec2(cos(k*1.3), sin(k*1.3));
+            return sin(dot(direction, p)*(3.0 + k) + iTime*(0.6 + 0.2*k));
+        }
+        void main() {
+            GetCamera(iCamera);
+            vec2 p = iCamera.gluv*rotate2d(0.1*iTime);
+            float sum = 0;
+            for (int k = 0; k < WAVES; k++)
+                sum += wave(p, float(k))/WAVES;
+            vec3 colour = hsv2rgb(vec3(TAU*fract(0.5*sum + 0.05*iTime), 0.75, 0.6 + 0.4*sum));
+            colour *= 1 - 0.3*smoothstep(0.5, 1.5, length(iCamera.gluv));
+            fragColor = vec4(colour, 1);
+        }
+    """
+
+    def build(self):
+        super().build()
+        self.shader.fragment = self.FRAGMENT
 
 
 def make(cls, audio=None, background=None, **fields):

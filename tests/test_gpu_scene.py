@@ -208,7 +208,7 @@ def test_encoder_handoff_top_down_rows_and_command(tmp_path, monkeypatch, batch)
     assert np.array_equal(frames_of(flipped, w, h), want[:, ::-1])
 
 
-@pytest.mark.parametrize("name,ssaa", [("Basic", 1), ("Basic", 2), ("ShaderToy", 2), ("Mandelbrot", 1), ("RayMarch", 2)])
+@pytest.mark.parametrize("name,ssaa", [("Basic", 1), ("Basic", 2), ("ShaderToy", 2), ("Mandelbrot", 1), ("RayMarch", 2), ("Plasma", 2)])
 def test_clock_tape_equals_frame_loop(name, ssaa):
     """Scenes without audio modules batch through a clock-only tape (iTime/iTau/iFrame per frame on the device):
     the same kernels with the same uniform values, so the frames are identical to the python frame loop's"""
