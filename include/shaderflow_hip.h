@@ -44,7 +44,8 @@ enum { SFX_WINDOW_HANNING = 0, SFX_WINDOW_HANN_POISSON = 1, SFX_WINDOW_NONE = 2 
 enum { SFX_REDUCER_AVERAGE = 0, SFX_REDUCER_RMS = 1, SFX_REDUCER_STD = 2 };          /* waveform.py:14-22 */
 
 /* GLSL uniform types accepted by sfx_uniform_set (variable.py:12-23) */
-enum { SFX_T_FLOAT = 0, SFX_T_INT = 1, SFX_T_BOOL = 2, SFX_T_VEC2 = 3, SFX_T_VEC3 = 4, SFX_T_VEC4 = 5 };
+enum { SFX_T_FLOAT = 0, SFX_T_INT = 1, SFX_T_BOOL = 2, SFX_T_VEC2 = 3, SFX_T_VEC3 = 4, SFX_T_VEC4 = 5,
+       SFX_T_MAT2 = 6, SFX_T_MAT3 = 7, SFX_T_MAT4 = 8 /* column major, 4/9/16 floats; loaded programs only */ };
 
 const char* sfx_last_error(void);
 const char* sfx_version(void);

@@ -17,7 +17,7 @@ LIBRARY = PACKAGE/"libshaderflow_hip.so"
 OK = 0
 U8, F32, U16, F16 = 0, 1, 2, 3
 NEAREST, LINEAR = 0, 1
-T_FLOAT, T_INT, T_BOOL, T_VEC2, T_VEC3, T_VEC4 = range(6)
+T_FLOAT, T_INT, T_BOOL, T_VEC2, T_VEC3, T_VEC4, T_MAT2, T_MAT3, T_MAT4 = range(9)
 TAPE_SPECTROGRAM, TAPE_WAVEFORM, TAPE_UNIFORMS, TAPE_TARGETS, TAPE_LOUDNESS = range(5)
 E_UNSUPPORTED = -4
 

@@ -422,8 +422,8 @@ extern "C" const char* sfx_program_name(sfx_handle h) {
 extern "C" int sfx_uniform_set(sfx_handle h, const char* name, int type, const void* value, int* known) {
     Program* p = get<Program>(h, MAGIC_PROG);
     if (!p || !name || !value) return fail(SFX_E_INVALID, "invalid program handle, name or value");
-    const int counts[] = {1, 1, 1, 2, 3, 4};
-    if (type < 0 || type > SFX_T_VEC4) return fail(SFX_E_INVALID, "uniform type %d", type);
+    const int counts[] = {1, 1, 1, 2, 3, 4, 4, 9, 16};
+    if (type < 0 || type > SFX_T_MAT4) return fail(SFX_E_INVALID, "uniform type %d", type);
     const bool src_int = (type == SFX_T_INT || type == SFX_T_BOOL);
     if (known) *known = 0;
     auto store = [&](char* dst, int count, bool dst_int) {

@@ -20,8 +20,8 @@ with `opengl.program`, falling back to `missing.glsl` on errors). Without a driv
    libshaderflow_hip loads it with `sfx_program_load`.
 
 What is not supported raises `TranslationError` (the caller logs it and binds the `missing` kernel, like the reference
-does for a GLSL compile error): geometry beyond one fullscreen quad, `discard` outside `main`, arrays as function
-arguments or return values, more than 16 samplers or 64 uniform floats, non-square matrices.
+does for a GLSL compile error): geometry beyond one fullscreen quad, arrays as function
+return values, uniform arrays, more than 16 samplers or 64 uniform floats, non-square matrices.
 """
 from __future__ import annotations
 
@@ -97,7 +97,8 @@ _DROPPED_QUALIFIERS = {"highp", "mediump", "lowp", "flat", "smooth", "noperspect
 _TYPES = {"void", "float", "int", "uint", "bool", "vec2", "vec3", "vec4", "ivec2", "ivec3", "ivec4", "uvec2", "uvec3", "uvec4",
           "bvec2", "bvec3", "bvec4", "mat2", "mat3", "mat4", "mat2x2", "mat3x3", "mat4x4", "sampler2D"}
 _UNIFORM_COUNTS = {"float": (1, False), "int": (1, True), "bool": (1, True), "uint": (1, True), "vec2": (2, False), "vec3": (3, False),
-                   "vec4": (4, False), "ivec2": (2, True), "ivec3": (3, True), "ivec4": (4, True)}
+                   "vec4": (4, False), "ivec2": (2, True), "ivec3": (3, True), "ivec4": (4, True),
+                   "mat2": (4, False), "mat3": (9, False), "mat4": (16, False)}
 # members of sf::rt::FragmentBase (jit_runtime.hpp): uniforms and varyings that exist for every fragment
 BUILTIN_MEMBERS = {
     "fragCoord", "stxy", "glxy", "stuv", "astuv", "gluv", "agluv", "gl_FragCoord", "fragColor", "instance",
@@ -216,27 +217,42 @@ def _text(tokens: Iterable[Tok]) -> str:
 # ---- function heads ---------------------------------------------------------------------------------------------------
 
 def _rewrite_parameters(tokens: list[Tok]) -> list[Tok]:
-    """`in T a, out T b, inout T c, const in T d` → `T a, T& b, T& c, const T d`"""
+    """`in T a, out T b, inout T c, const in T d, T e[3], out T f[3]` → `T a, T& b, T& c, const T d, const T (&e)[3], T (&f)[3]`
+    (an `in` array is a copy in GLSL; here it is a view that cannot be written, which a compiler error reports if a fragment does)"""
     out: list[Tok] = []
-    reference = False
-    k = 0
-    while k < len(tokens):
-        t = tokens[k]
-        if t.kind == "ident" and t.text in ("out", "inout"):
-            reference = True
-        elif t.kind == "ident" and t.text == "in":
-            pass
-        elif t.kind == "ident" and reference and t.text != "const":
-            nxt = _significant(tokens, k + 1)
-            if nxt < len(tokens) and tokens[nxt].text == "[":
-                raise TranslationError("array parameters with out/inout qualifiers are not supported")
-            out.append(t); out.append(Tok("op", "&"))
-            reference = False
+    parameter: list[Tok] = []
+
+    def flush() -> None:
+        words = [t for t in parameter if t.kind not in ("ws", "comment")]
+        if not words:
+            return
+        reference = any(t.kind == "ident" and t.text in ("out", "inout") for t in words)
+        constant = any(t.kind == "ident" and t.text == "const" for t in words)
+        core = [t for t in words if not (t.kind == "ident" and t.text in ("in", "out", "inout", "const"))]
+        bracket = next((i for i, t in enumerate(core) if t.kind == "op" and t.text == "["), None)
+        if bracket is None:
+            type_, rest = core[0], core[1:]
+            text = ("const " if constant and not reference else "") + type_.text + ("&" if reference else "") + " " + _text(rest)
         else:
-            if t.kind == "op" and t.text == "[":
-                raise TranslationError("array parameters are not supported")
-            out.append(t)
-        k += 1
+            if bracket < 2:
+                raise TranslationError(f"unnamed array parameter: {_text(parameter).strip()!r}")
+            type_, name, bounds = core[0], core[bracket - 1], core[bracket:]
+            text = ("" if reference else "const ") + f"{type_.text} (&{name.text}){_text(bounds)}"
+        if out:
+            out.append(Tok("op", ", "))
+        out.append(Tok("ident", text))
+
+    depth = 0
+    for t in tokens:
+        if t.kind == "op" and t.text in "([":
+            depth += 1
+        elif t.kind == "op" and t.text in ")]":
+            depth -= 1
+        if t.kind == "op" and t.text == "," and depth == 0:
+            flush(); parameter = []
+        else:
+            parameter.append(t)
+    flush()
     return out
 
 
@@ -366,9 +382,8 @@ class _Translator:
         out = []
         for t in body:
             if t.kind == "ident" and t.text == "discard":
-                if return_type != "void":
-                    raise TranslationError("`discard` inside a function that returns a value is not supported")
-                out.append("{ discarded_ = true; return; }")
+                # the invocation ends in GLSL; here the flag makes the result transparent whatever the callers still compute
+                out.append("{ discarded_ = true; return; }" if return_type == "void" else "{ discarded_ = true; return {}; }")
             elif t.kind == "pp":
                 out.append("\n" + self.preprocessor(t.text).strip("\n") + "\n")
             else:

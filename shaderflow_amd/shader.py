@@ -28,7 +28,8 @@ from shaderflow_amd.texture import DeviceTexture, ShaderTexture
 from shaderflow_amd.variable import FlatVariable, InVariable, OutVariable, ShaderVariable
 
 _UNIFORM_TYPES = {"float": (N.T_FLOAT, np.float32, 1), "int": (N.T_INT, np.int32, 1), "bool": (N.T_BOOL, np.int32, 1),
-                  "vec2": (N.T_VEC2, np.float32, 2), "vec3": (N.T_VEC3, np.float32, 3), "vec4": (N.T_VEC4, np.float32, 4)}
+                  "vec2": (N.T_VEC2, np.float32, 2), "vec3": (N.T_VEC3, np.float32, 3), "vec4": (N.T_VEC4, np.float32, 4),
+                  "mat2": (N.T_MAT2, np.float32, 4), "mat3": (N.T_MAT3, np.float32, 9), "mat4": (N.T_MAT4, np.float32, 16)}
 
 
 @define(eq=False, slots=False)

@@ -241,3 +241,33 @@ def test_scenes_with_several_translated_programs_layers_and_history(gpu):
         value = 0.5*bar + 0.5*expected_previous
         assert np.abs(row[k + 1] - np.rint(value*255)).max() <= 1, k
         expected_previous = np.rint(value*255)/255
+
+
+def test_array_parameters_matrix_uniforms_and_discard_in_a_function(gpu):
+    text = """
+    uniform mat2 iTurn;
+    uniform mat3 iMix;
+    float total(float values[3]) { return values[0] + values[1] + values[2]; }
+    void fill(out float values[3], float seed) { for (int i = 0; i < 3; i++) values[i] = seed*float(i + 1); }
+    float keep(vec2 p) { if (p.x > 0.5) discard; return 0.25; }
+    void main() {
+        float values[3];
+        fill(values, 0.1);
+        vec2 p = iTurn*vec2(1.0, 0.0);
+        vec3 c = iMix*vec3(1.0, 2.0, 3.0);
+        fragColor = vec4(total(values), p.y, c.z/32.0, keep(astuv));
+    }"""
+    prog, translation = load(gpu, text)
+    gpu.set_uniforms(prog, O.default_uniforms(32, 8))
+    turn = np.array([0.0, 1.0, -1.0, 0.0], np.float32)                            # columns (0, 1) and (-1, 0): a quarter turn
+    mix = np.arange(1, 10, dtype=np.float32)                                      # columns (1,2,3) (4,5,6) (7,8,9)
+    for name, code, values in (("iTurn", N.T_MAT2, turn), ("iMix", N.T_MAT3, mix)):
+        known = C.c_int()
+        N.check(gpu.lib.sfx_uniform_set(prog, name.encode(), code, values.ctypes.data, C.byref(known)))
+        assert known.value
+    got = gpu.render(prog, 32, 8, comps=4, dtype=np.float32)
+    left, right = got[:, :16], got[:, 16:]
+    assert np.allclose(left[..., 0], 0.6, atol=1e-6) and (left[..., 1] == 1.0).all() and (left[..., 3] == 0.25).all()
+    assert (left[..., 2] == np.float32(3 + 12 + 27)/np.float32(32)).all()        # row 2 of iMix times (1, 2, 3)
+    assert (right == 0).all()                                                     # discarded inside keep()
+    N.check(gpu.lib.sfx_program_destroy(prog))
