@@ -710,6 +710,16 @@ inline void sfx_jit_host_texture(sf::Tex* textures, int slot, const void* data, 
             rgba8[(size_t)j*wr + i] = sf::pack_rgba8(sf::JitShader<FRAGMENT>::run(a, f, {}, {})); \
         } \
     } \
+    extern "C" void sfx_jit_host_render_float(const sf::Uniforms* u, const sf::Tex* textures, int wr, int hr, float* rgba) { \
+        sf::RenderArgs a{}; \
+        const float aspect = u->iResolution[0]/u->iResolution[1]; \
+        for (int j = 0; j < hr; j++) for (int i = 0; i < wr; i++) { \
+            sf::Frag f; f.u = u; f.tex = textures; f.history = textures + sf::TEX_HISTORY; \
+            sf::make_varyings(f, i, j, wr, hr, aspect); \
+            const sf::vec4 c = sf::JitShader<FRAGMENT>::run(a, f, {}, {}); \
+            float* p = rgba + ((size_t)j*wr + i)*4; p[0] = c.x; p[1] = c.y; p[2] = c.z; p[3] = c.w; \
+        } \
+    } \
     extern "C" void* sfx_jit_host_keep[] = {(void*)sfx_jit_host_uniforms_size, (void*)sfx_jit_host_textures_size, (void*)sfx_jit_host_defaults, \
                                             (void*)sfx_jit_host_uniform, (void*)sfx_jit_host_user, (void*)sfx_jit_host_texture};
 #else

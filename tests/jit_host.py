@@ -68,3 +68,9 @@ class HostFragment:
         out = np.zeros((height, width, 4), np.uint8)
         self.lib.sfx_jit_host_render(self.uniforms, self.textures, width, height, out.ctypes.data_as(C.c_void_p))
         return out
+
+    def render_float(self, width: int, height: int) -> np.ndarray:
+        """the fragment's output before any target conversion: (h, w, 4) float32"""
+        out = np.zeros((height, width, 4), np.float32)
+        self.lib.sfx_jit_host_render_float(self.uniforms, self.textures, width, height, out.ctypes.data_as(C.c_void_p))
+        return out

@@ -217,6 +217,7 @@ def test_translated_fragments_on_the_host_match_the_opengl_goldens():
 REFERENCE_CASES = {
     # oracle fragment name → (file under /root/reference, textures it samples)
     "default": ("shaderflow/resources/shaders/fragment/default.glsl", ()),
+    "missing": ("shaderflow/resources/shaders/fragment/missing.glsl", ()),
     "shadertoy": ("examples/basic/shaders/shadertoy.frag", ()),
     "raymarch": ("examples/basic/shaders/raymarch.frag", ()),
     "tetration": ("examples/fractals/shaders/tetration.frag", ()),
@@ -253,3 +254,87 @@ def test_mechanical_translation_of_the_reference_equals_the_restatement(name, tm
     exact = float((d == 0).mean())
     print(f"{name}: max {d.max()} LSB, {exact*100:.3f}% exact")
     assert np.array_equal(got, want), (int(d.max()), exact)                       # observed: identical bytes, tetration's chaotic boundary included
+
+
+def _history_defines(name: str, temporal: int, layers: int) -> str:
+    """what ShaderTexture.defines() injects (texture.py:349-363): plain names for the last layer and the <name>Texture selector"""
+    lines = [f"#define {name}{t or ''} {name}{t}x{layers - 1}" for t in range(temporal)]
+    lines.append(f"vec4 {name}Texture(int temporal, int layer, vec2 astuv) {{")
+    for t in range(temporal):
+        for layer in range(layers):
+            lines += [f"    if (temporal == {t} && layer == {layer})", f"        return texture({name}{t}x{layer}, astuv);"]
+    return "\n".join(lines + ["    return vec4(0.0);", "}"]) + "\n"
+
+
+@pytest.mark.skipif(not REFERENCE.exists(), reason="the reference checkout is only present in the build container")
+def test_mechanical_translation_of_the_layered_and_temporal_fragments(tmp_path):
+    """multipass (both layers), motionblur (history sum through iScreenTexture), life (float state, texelFetch, int arrays, `%`) and
+    video: the translated GLSL against the oracle, byte for byte — with the sampler names and helper functions the engine generates"""
+    import numpy as np
+
+    from oracle import binding as O
+    from tests.jit_host import HostFragment
+    shaders = REFERENCE/"examples"/"basic"/"shaders"
+    rng = np.random.default_rng(3)
+    w, h = 96, 54
+
+    # multipass: layer 0 draws the background, layer 1 reads layer 0 as iScreen0x0 (texture.py:346-347)
+    background = rng.integers(0, 256, (40, 64, 3), dtype=np.uint8)
+    text = _history_defines("iScreen", 1, 2) + (shaders/"multipass.frag").read_text()
+    host = HostFragment(G.translate(text, [("sampler2D", n) for n in ("background", "iScreen0x0", "iScreen0x1")]), tmp_path)
+    u = O.default_uniforms(w, h, iLayer=0)
+    host.set_uniforms(u)
+    assert host.bind("background", background)
+    layer0 = host.render(w, h)
+    want0 = O.render("multipass", u, {"background": O.make_texture(background)}, w, h, threads=4)
+    assert np.array_equal(layer0, want0)
+    u.iLayer = 1
+    host.set_uniforms(u)
+    assert host.bind("iScreen0x0", want0, "linear", False, False)
+    want1 = O.render("multipass", u, {"background": O.make_texture(background), 0: O.make_texture(want0, "linear", False, False)}, w, h, threads=4)
+    assert np.array_equal(host.render(w, h), want1)
+
+    # motionblur: iScreenTemporal frames of history, layer 1 sums them
+    temporal = 4
+    history = [rng.integers(0, 256, (h, w, 4), dtype=np.uint8) for _ in range(temporal)]
+    text = _history_defines("iScreen", temporal, 2) + (shaders/"motionblur.frag").read_text()
+    pipeline = [("sampler2D", f"iScreen{t}x{layer}") for t in range(temporal) for layer in range(2)] + [("int", "iScreenTemporal"), ("sampler2D", "background")]
+    host = HostFragment(G.translate(text, pipeline), tmp_path)
+    u = O.default_uniforms(w, h, iLayer=1)
+    u.user[0] = float(temporal)
+    host.set_uniforms(u)
+    host.set("iScreenTemporal", temporal)
+    for t in range(temporal):
+        assert host.bind(f"iScreen{t}x0", history[t], "linear", False, False)
+    want = O.render("motionblur", u, {t: O.make_texture(history[t], "linear", False, False) for t in range(temporal)}, w, h, threads=4)
+    assert np.array_equal(host.render(w, h), want)
+
+    # life: the simulation renders a float state from the state one frame back; the visuals read five frames
+    state = rng.integers(0, 2, (27, 48, 1)).astype(np.float32)
+    text = _history_defines("iLife", 5, 1) + (shaders/"life"/"simulation.glsl").read_text()
+    pipeline = [("sampler2D", f"iLife{t}x0") for t in range(5)] + [("vec2", "iLifeSize"), ("int", "iLifePeriod")]
+    host = HostFragment(G.translate(text, pipeline), tmp_path)
+    for frame in (0, 7):
+        u = O.default_uniforms(48, 27, iFrame=frame)
+        u.user[0], u.user[1], u.user[2] = 48, 27, 6
+        host.set_uniforms(u)
+        host.set("iLifeSize", (48, 27)); host.set("iLifePeriod", 6)
+        assert host.bind("iLife1x0", state, "nearest", True, True)
+        want = O.render_to("life_simulation", u, {1: O.make_texture(state, "nearest", True, True)}, 48, 27, 1, np.float32, threads=4)
+        assert np.array_equal(host.render_float(48, 27)[..., :1], want), frame
+    states = [rng.integers(0, 2, (27, 48, 1)).astype(np.float32) for _ in range(5)]
+    text = _history_defines("iLife", 5, 1) + (shaders/"life"/"visuals.glsl").read_text()
+    host = HostFragment(G.translate(text, pipeline), tmp_path)
+    u = O.default_uniforms(w, h, iCameraZoom=0.9)
+    host.set_uniforms(u)
+    for t in range(5):
+        assert host.bind(f"iLife{t}x0", states[t], "nearest", True, True)
+    want = O.render("life_visuals", u, {t: O.make_texture(states[t], "nearest", True, True) for t in range(5)}, w, h, threads=4)
+    assert np.array_equal(host.render(w, h), want)
+
+    # video: one texture named after its module (video.py:57-66)
+    frame = rng.integers(0, 256, (36, 64, 3), dtype=np.uint8)
+    host = HostFragment(G.translate("#define iVideo iVideo0x0\n" + (shaders/"video.frag").read_text(), [("sampler2D", "iVideo0x0")]), tmp_path)
+    host.set_uniforms(u)
+    assert host.bind("iVideo0x0", frame)
+    assert np.array_equal(host.render(w, h), O.render("video", u, {0: O.make_texture(frame)}, w, h, threads=4))
