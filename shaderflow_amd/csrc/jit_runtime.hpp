@@ -27,22 +27,26 @@ struct vec2; struct vec3; struct vec4;
 // ---- swizzles ---------------------------------------------------------------------------------------------------------
 // A swizzle is a member of the vector's anonymous union (same storage): reading converts it to a vector of the selected
 // components, writing assigns them (GLSL requires distinct components for that; not checked).
-template <class V, int P, int... I>
-struct Swz {
-    float d[P];
+template <class T, class V, int P, int... I>
+struct SwzT {
+    T d[P];
     SF_HD operator V() const { return V(d[I]...); }
-    SF_HD Swz& operator=(const V& v) { int k = 0; ((d[I] = v.d[k++]), ...); return *this; }
-    SF_HD Swz& operator=(const Swz& o) { const V v = o; return *this = v; }
-    SF_HD Swz& operator+=(const V& v) { const V me = *this; return *this = me + v; }
-    SF_HD Swz& operator-=(const V& v) { const V me = *this; return *this = me - v; }
-    SF_HD Swz& operator*=(const V& v) { const V me = *this; return *this = me*v; }
-    SF_HD Swz& operator/=(const V& v) { const V me = *this; return *this = me/v; }
-    SF_HD Swz& operator+=(float s) { const V me = *this; return *this = me + s; }
-    SF_HD Swz& operator-=(float s) { const V me = *this; return *this = me - s; }
-    SF_HD Swz& operator*=(float s) { const V me = *this; return *this = me*s; }
-    SF_HD Swz& operator/=(float s) { const V me = *this; return *this = me/s; }
-    SF_HD float operator[](int k) const { const int index[] = {I...}; return d[index[k]]; }
+    SF_HD SwzT& operator=(const V& v) { int k = 0; ((d[I] = v.d[k++]), ...); return *this; }
+    SF_HD SwzT& operator=(const SwzT& o) { const V v = o; return *this = v; }
+    // `v.xy op= x` for anything `vec2 op x` is defined for (vectors, scalars, matrices)
+    template <class X> SF_HD SwzT& operator+=(const X& x) { const V me = *this; return *this = me + x; }
+    template <class X> SF_HD SwzT& operator-=(const X& x) { const V me = *this; return *this = me - x; }
+    template <class X> SF_HD SwzT& operator*=(const X& x) { const V me = *this; return *this = me*x; }
+    template <class X> SF_HD SwzT& operator/=(const X& x) { const V me = *this; return *this = me/x; }
+    template <class X> SF_HD SwzT& operator%=(const X& x) { const V me = *this; return *this = me % x; }
+    template <class X> SF_HD SwzT& operator&=(const X& x) { const V me = *this; return *this = me & x; }
+    template <class X> SF_HD SwzT& operator|=(const X& x) { const V me = *this; return *this = me | x; }
+    template <class X> SF_HD SwzT& operator^=(const X& x) { const V me = *this; return *this = me ^ x; }
+    template <class X> SF_HD SwzT& operator<<=(const X& x) { const V me = *this; return *this = me << x; }
+    template <class X> SF_HD SwzT& operator>>=(const X& x) { const V me = *this; return *this = me >> x; }
+    SF_HD T operator[](int k) const { const int index[] = {I...}; return d[index[k]]; }
 };
+template <class V, int P, int... I> using Swz = SwzT<float, V, P, I...>;
 
 #define SF_RT_COMMON(V, N) \
     SF_HD V& operator=(const V& o) { for (int k = 0; k < N; k++) d[k] = o.d[k]; return *this; } \
@@ -58,29 +62,38 @@ struct Swz {
     SF_HD V& operator*=(float s) { for (int k = 0; k < N; k++) d[k] = d[k]*s; return *this; } \
     SF_HD V& operator/=(float s) { for (int k = 0; k < N; k++) d[k] = d[k]/s; return *this; }
 
-struct ivec2 {
-    int x, y;
-    SF_HD ivec2() : x(0), y(0) {}
-    SF_HD explicit ivec2(int s) : x(s), y(s) {}
-    SF_HD ivec2(int a, int b) : x(a), y(b) {}
-    SF_HD explicit ivec2(const vec2& v);
-    SF_HD int& operator[](int k) { return k ? y : x; }
-    SF_HD int operator[](int k) const { return k ? y : x; }
-};
-struct ivec3 {
-    int x, y, z;
-    SF_HD ivec3() : x(0), y(0), z(0) {}
-    SF_HD explicit ivec3(int s) : x(s), y(s), z(s) {}
-    SF_HD ivec3(int a, int b, int c) : x(a), y(b), z(c) {}
-    SF_HD explicit ivec3(const vec3& v);
-};
-struct ivec4 {
-    int x, y, z, w;
-    SF_HD ivec4() : x(0), y(0), z(0), w(0) {}
-    SF_HD explicit ivec4(int s) : x(s), y(s), z(s), w(s) {}
-    SF_HD ivec4(int a, int b, int c, int e) : x(a), y(b), z(c), w(e) {}
-    SF_HD explicit ivec4(const vec4& v);
-};
+// integer vectors: same shape as the float ones (names, array and swizzles in one union), for int and for uint
+struct ivec2; struct ivec3; struct ivec4; struct uvec2; struct uvec3; struct uvec4;
+#define SF_RT_T int
+#define SF_RT_V2 ivec2
+#define SF_RT_V3 ivec3
+#define SF_RT_V4 ivec4
+#define SF_RT_O2 uvec2
+#define SF_RT_O3 uvec3
+#define SF_RT_O4 uvec4
+#include "jit_intvec.inc"
+#undef SF_RT_T
+#undef SF_RT_V2
+#undef SF_RT_V3
+#undef SF_RT_V4
+#undef SF_RT_O2
+#undef SF_RT_O3
+#undef SF_RT_O4
+#define SF_RT_T uint
+#define SF_RT_V2 uvec2
+#define SF_RT_V3 uvec3
+#define SF_RT_V4 uvec4
+#define SF_RT_O2 ivec2
+#define SF_RT_O3 ivec3
+#define SF_RT_O4 ivec4
+#include "jit_intvec.inc"
+#undef SF_RT_T
+#undef SF_RT_V2
+#undef SF_RT_V3
+#undef SF_RT_V4
+#undef SF_RT_O2
+#undef SF_RT_O3
+#undef SF_RT_O4
 struct bvec2 { bool x, y; };
 struct bvec3 { bool x, y, z; };
 struct bvec4 { bool x, y, z, w; };
@@ -102,7 +115,8 @@ struct vec2 {
     SF_HD vec2() { x = 0.0f; y = 0.0f; }
     SF_HD explicit vec2(float v) { x = v; y = v; }
     SF_HD vec2(float a, float b) { x = a; y = b; }
-    SF_HD vec2(const ivec2& v) { x = (float)v.x; y = (float)v.y; }      // GLSL converts ivec to vec implicitly (§4.1.10)
+    SF_HD vec2(const ivec2& v) { x = (float)v.x; y = (float)v.y; }      // GLSL converts ivec/uvec to vec implicitly (§4.1.10)
+    SF_HD vec2(const uvec2& v) { x = (float)v.x; y = (float)v.y; }
     SF_HD explicit vec2(const vec3& v);
     SF_HD explicit vec2(const vec4& v);
     SF_RT_COMMON(vec2, 2)
@@ -127,6 +141,7 @@ struct vec3 {
     SF_HD vec3(const vec2& a, float c) { x = a.x; y = a.y; z = c; }
     SF_HD vec3(float a, const vec2& b) { x = a; y = b.x; z = b.y; }
     SF_HD vec3(const ivec3& v) { x = (float)v.x; y = (float)v.y; z = (float)v.z; }
+    SF_HD vec3(const uvec3& v) { x = (float)v.x; y = (float)v.y; z = (float)v.z; }
     SF_HD explicit vec3(const vec4& v);
     SF_RT_COMMON(vec3, 3)
 };
@@ -154,6 +169,7 @@ struct vec4 {
     SF_HD vec4(float a, const vec2& u, float e) { x = a; y = u.x; z = u.y; w = e; }
     SF_HD vec4(float a, float b, const vec2& u) { x = a; y = b; z = u.x; w = u.y; }
     SF_HD vec4(const ivec4& v) { x = (float)v.x; y = (float)v.y; z = (float)v.z; w = (float)v.w; }
+    SF_HD vec4(const uvec4& v) { x = (float)v.x; y = (float)v.y; z = (float)v.z; w = (float)v.w; }
     SF_RT_COMMON(vec4, 4)
 };
 SF_HD vec2::vec2(const vec3& v) { x = v.x; y = v.y; }
@@ -169,22 +185,34 @@ SF_HD uint to_uint(float x) { return (x != x || x <= 0.0f) ? 0u : ((x >= 4294967
 SF_HD uint to_uint(int x) { return (uint)x; }
 SF_HD uint to_uint(uint x) { return x; }
 SF_HD uint to_uint(bool x) { return x ? 1u : 0u; }
-SF_HD ivec2::ivec2(const vec2& v) : x(sf::to_int(v.x)), y(sf::to_int(v.y)) {}
-SF_HD ivec3::ivec3(const vec3& v) : x(sf::to_int(v.x)), y(sf::to_int(v.y)), z(sf::to_int(v.z)) {}
-SF_HD ivec4::ivec4(const vec4& v) : x(sf::to_int(v.x)), y(sf::to_int(v.y)), z(sf::to_int(v.z)), w(sf::to_int(v.w)) {}
+SF_HD ivec2::ivec2(const vec2& v) { x = sf::to_int(v.x); y = sf::to_int(v.y); }
+SF_HD ivec3::ivec3(const vec3& v) { x = sf::to_int(v.x); y = sf::to_int(v.y); z = sf::to_int(v.z); }
+SF_HD ivec4::ivec4(const vec4& v) { x = sf::to_int(v.x); y = sf::to_int(v.y); z = sf::to_int(v.z); w = sf::to_int(v.w); }
+SF_HD uvec2::uvec2(const vec2& v) { x = to_uint(v.x); y = to_uint(v.y); }
+SF_HD uvec3::uvec3(const vec3& v) { x = to_uint(v.x); y = to_uint(v.y); z = to_uint(v.z); }
+SF_HD uvec4::uvec4(const vec4& v) { x = to_uint(v.x); y = to_uint(v.y); z = to_uint(v.z); w = to_uint(v.w); }
+SF_HD ivec2::ivec2(const uvec2& v) { x = (int)v.x; y = (int)v.y; }
+SF_HD ivec3::ivec3(const uvec3& v) { x = (int)v.x; y = (int)v.y; z = (int)v.z; }
+SF_HD ivec4::ivec4(const uvec4& v) { x = (int)v.x; y = (int)v.y; z = (int)v.z; w = (int)v.w; }
+SF_HD uvec2::uvec2(const ivec2& v) { x = (uint)v.x; y = (uint)v.y; }
+SF_HD uvec3::uvec3(const ivec3& v) { x = (uint)v.x; y = (uint)v.y; z = (uint)v.z; }
+SF_HD uvec4::uvec4(const ivec4& v) { x = (uint)v.x; y = (uint)v.y; z = (uint)v.z; w = (uint)v.w; }
 
-SF_HD ivec2 operator+(ivec2 a, ivec2 b) { return {a.x + b.x, a.y + b.y}; }
-SF_HD ivec2 operator-(ivec2 a, ivec2 b) { return {a.x - b.x, a.y - b.y}; }
-SF_HD ivec2 operator*(ivec2 a, ivec2 b) { return {a.x*b.x, a.y*b.y}; }
-SF_HD ivec2 operator/(ivec2 a, ivec2 b) { return {a.x/b.x, a.y/b.y}; }
-SF_HD ivec2 operator%(ivec2 a, ivec2 b) { return {a.x % b.x, a.y % b.y}; }
-SF_HD ivec2 operator+(ivec2 a, int s) { return {a.x + s, a.y + s}; }
-SF_HD ivec2 operator-(ivec2 a, int s) { return {a.x - s, a.y - s}; }
-SF_HD ivec2 operator*(ivec2 a, int s) { return {a.x*s, a.y*s}; }
-SF_HD ivec2 operator/(ivec2 a, int s) { return {a.x/s, a.y/s}; }
-SF_HD ivec2 operator%(ivec2 a, int s) { return {a.x % s, a.y % s}; }
-SF_HD bool operator==(ivec2 a, ivec2 b) { return a.x == b.x && a.y == b.y; }
-SF_HD bool operator!=(ivec2 a, ivec2 b) { return !(a == b); }
+#define SF_RT_INT_OP(V, T, N, op) \
+    SF_HD V operator op(const V& a, const V& b) { V r; for (int k = 0; k < N; k++) r.d[k] = a.d[k] op b.d[k]; return r; } \
+    SF_HD V operator op(const V& a, T s) { V r; for (int k = 0; k < N; k++) r.d[k] = a.d[k] op s; return r; } \
+    SF_HD V operator op(T s, const V& a) { V r; for (int k = 0; k < N; k++) r.d[k] = s op a.d[k]; return r; } \
+    SF_HD V& operator op##=(V& a, const V& b) { for (int k = 0; k < N; k++) a.d[k] = a.d[k] op b.d[k]; return a; } \
+    SF_HD V& operator op##=(V& a, T s) { for (int k = 0; k < N; k++) a.d[k] = a.d[k] op s; return a; }
+#define SF_RT_INT_OPS(V, T, N) \
+    SF_RT_INT_OP(V, T, N, +) SF_RT_INT_OP(V, T, N, -) SF_RT_INT_OP(V, T, N, *) SF_RT_INT_OP(V, T, N, /) SF_RT_INT_OP(V, T, N, %) \
+    SF_RT_INT_OP(V, T, N, &) SF_RT_INT_OP(V, T, N, |) SF_RT_INT_OP(V, T, N, ^) SF_RT_INT_OP(V, T, N, <<) SF_RT_INT_OP(V, T, N, >>) \
+    SF_HD V operator-(const V& a) { V r; for (int k = 0; k < N; k++) r.d[k] = (T)(0 - a.d[k]); return r; } \
+    SF_HD V operator~(const V& a) { V r; for (int k = 0; k < N; k++) r.d[k] = ~a.d[k]; return r; } \
+    SF_HD bool operator==(const V& a, const V& b) { bool e = true; for (int k = 0; k < N; k++) e = e && (a.d[k] == b.d[k]); return e; } \
+    SF_HD bool operator!=(const V& a, const V& b) { return !(a == b); }
+SF_RT_INT_OPS(ivec2, int, 2) SF_RT_INT_OPS(ivec3, int, 3) SF_RT_INT_OPS(ivec4, int, 4)
+SF_RT_INT_OPS(uvec2, uint, 2) SF_RT_INT_OPS(uvec3, uint, 3) SF_RT_INT_OPS(uvec4, uint, 4)
 
 #define SF_RT_ARITH(V, N) \
     SF_HD V operator+(const V& a, const V& b) { V r; for (int k = 0; k < N; k++) r.d[k] = a.d[k] + b.d[k]; return r; } \
@@ -254,6 +282,19 @@ SF_HD int floatBitsToInt(float x) { return (int)f2u(x); }
 SF_HD uint floatBitsToUint(float x) { return f2u(x); }
 SF_HD float intBitsToFloat(int x) { return u2f((uint32_t)x); }
 SF_HD float uintBitsToFloat(uint x) { return u2f(x); }
+
+SF_HD ivec2 floatBitsToInt(const vec2& v) { return ivec2(floatBitsToInt(v.x), floatBitsToInt(v.y)); }
+SF_HD ivec3 floatBitsToInt(const vec3& v) { return ivec3(floatBitsToInt(v.x), floatBitsToInt(v.y), floatBitsToInt(v.z)); }
+SF_HD ivec4 floatBitsToInt(const vec4& v) { return ivec4(floatBitsToInt(v.x), floatBitsToInt(v.y), floatBitsToInt(v.z), floatBitsToInt(v.w)); }
+SF_HD uvec2 floatBitsToUint(const vec2& v) { return uvec2(f2u(v.x), f2u(v.y)); }
+SF_HD uvec3 floatBitsToUint(const vec3& v) { return uvec3(f2u(v.x), f2u(v.y), f2u(v.z)); }
+SF_HD uvec4 floatBitsToUint(const vec4& v) { return uvec4(f2u(v.x), f2u(v.y), f2u(v.z), f2u(v.w)); }
+SF_HD vec2 intBitsToFloat(const ivec2& v) { return vec2(intBitsToFloat(v.x), intBitsToFloat(v.y)); }
+SF_HD vec3 intBitsToFloat(const ivec3& v) { return vec3(intBitsToFloat(v.x), intBitsToFloat(v.y), intBitsToFloat(v.z)); }
+SF_HD vec4 intBitsToFloat(const ivec4& v) { return vec4(intBitsToFloat(v.x), intBitsToFloat(v.y), intBitsToFloat(v.z), intBitsToFloat(v.w)); }
+SF_HD vec2 uintBitsToFloat(const uvec2& v) { return vec2(u2f(v.x), u2f(v.y)); }
+SF_HD vec3 uintBitsToFloat(const uvec3& v) { return vec3(u2f(v.x), u2f(v.y), u2f(v.z)); }
+SF_HD vec4 uintBitsToFloat(const uvec4& v) { return vec4(u2f(v.x), u2f(v.y), u2f(v.z), u2f(v.w)); }
 
 // integer forms: exact-match templates, so that (float, int) arguments pick the float overloads like GLSL does
 #define SF_RT_INTS(A, B) typename std::enable_if<std::is_integral<A>::value && std::is_integral<B>::value && !std::is_same<A, bool>::value, int>::type
@@ -337,6 +378,11 @@ struct matn {
     SF_HD matn(A... values) { const float v[] = {(float)values...}; for (int j = 0; j < N; j++) for (int i = 0; i < N; i++) c[j].d[i] = v[j*N + i]; }
     template <class... A, typename std::enable_if<sizeof...(A) == N && (std::is_convertible<A, V>::value && ...) && !(std::is_arithmetic<A>::value || ...), int>::type = 0>
     SF_HD matn(const A&... columns) { const V v[] = {V(columns)...}; for (int j = 0; j < N; j++) c[j] = v[j]; }
+    // from a matrix of another size (§5.4.2): the common block is copied, the rest is the identity
+    template <class W, int M, typename std::enable_if<M != N, int>::type = 0>
+    SF_HD explicit matn(const matn<W, M>& o) {
+        for (int j = 0; j < N; j++) for (int i = 0; i < N; i++) c[j].d[i] = (i < M && j < M) ? o.c[j].d[i] : ((i == j) ? 1.0f : 0.0f);
+    }
     SF_HD V& operator[](int j) { return c[j]; }
     SF_HD const V& operator[](int j) const { return c[j]; }
     SF_HD matn& operator*=(const matn& o) { *this = *this*o; return *this; }

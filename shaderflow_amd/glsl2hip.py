@@ -98,6 +98,7 @@ _TYPES = {"void", "float", "int", "uint", "bool", "vec2", "vec3", "vec4", "ivec2
           "bvec2", "bvec3", "bvec4", "mat2", "mat3", "mat4", "mat2x2", "mat3x3", "mat4x4", "sampler2D"}
 _UNIFORM_COUNTS = {"float": (1, False), "int": (1, True), "bool": (1, True), "uint": (1, True), "vec2": (2, False), "vec3": (3, False),
                    "vec4": (4, False), "ivec2": (2, True), "ivec3": (3, True), "ivec4": (4, True),
+                   "uvec2": (2, True), "uvec3": (3, True), "uvec4": (4, True),
                    "mat2": (4, False), "mat3": (9, False), "mat4": (16, False)}
 # members of sf::rt::FragmentBase (jit_runtime.hpp): uniforms and varyings that exist for every fragment
 BUILTIN_MEMBERS = {
@@ -534,7 +535,7 @@ def runtime_fingerprint() -> str:
     global _fingerprint
     if _fingerprint is None:
         digest = hashlib.sha256()
-        for name in ("sfmath.hpp", "glsl.hpp", "fragments.hpp", "render_kernels.hpp", "jit_runtime.hpp", "jit_swizzles.inc"):
+        for name in ("sfmath.hpp", "glsl.hpp", "fragments.hpp", "render_kernels.hpp", "jit_runtime.hpp", "jit_swizzles.inc", "jit_intvec.inc"):
             digest.update((CSRC/name).read_bytes())
         digest.update(" ".join(FLAGS).encode())
         _fingerprint = digest.hexdigest()

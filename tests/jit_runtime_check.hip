@@ -57,6 +57,25 @@ int run_checks() {
     vec2 q(1.0f, 0.0f);
     q *= rotate2d(0.0f);
     CHECK(q == vec2(1.0f, 0.0f));
+    CHECK(mat3(s4)[2] == vec3(0.0f, 0.0f, 2.0f) && mat4(m)[1] == vec4(3.0f, 4.0f, 0.0f, 0.0f) && mat4(m)[3] == vec4(0.0f, 0.0f, 0.0f, 1.0f));
+    vec3 turned(1.0f, 0.0f, 5.0f);
+    turned.xy *= mat2(0.0f, 1.0f, -1.0f, 0.0f);                      // v*m: dot products with the columns
+    CHECK(turned == vec3(0.0f, -1.0f, 5.0f));
+    // integer vectors: unsigned wrap-around, shifts, swizzles, conversions
+    uvec3 h = uvec3(1u, 2u, 3u)*1664525u + 1013904223u;
+    h.x += h.y*h.z;
+    h ^= h >> 16u;
+    h = h.yzx + uvec3(4294967295u);                                  // wraps: minus one
+    CHECK(h.x == ((2u*1664525u + 1013904223u) ^ ((2u*1664525u + 1013904223u) >> 16u)) - 1u);
+    ivec3 n = ivec3(7, -3, 2) % 4;
+    CHECK(n == ivec3(3, -3, 2) && (ivec3(8, 8, 8) >> 2) == ivec3(2) && (ivec2(5, 6) & 3) == ivec2(1, 2) && -ivec2(1, 2) == ivec2(-1, -2));
+    ivec4 q4(ivec2(1, 2), ivec2(3, 4));
+    q4.wx = q4.xw;
+    CHECK(q4 == ivec4(4, 2, 3, 1) && q4.zy == ivec2(3, 2));
+    CHECK(vec3(uvec3(1u, 2u, 3u)) == vec3(1.0f, 2.0f, 3.0f) && uvec2(vec2(3.9f, -1.0f)) == uvec2(3u, 0u) && ivec2(uvec2(7u, 8u)) == ivec2(7, 8));
+    vec3 normalised = vec3(uvec3(4294967295u, 0u, 2147483648u))*(1.0f/4294967296.0f);
+    CHECK(normalised.x == 1.0f && normalised.y == 0.0f && normalised.z == 0.5f);
+    CHECK(floatBitsToUint(vec2(1.0f, -2.0f)) == uvec2(0x3f800000u, 0xc0000000u) && uintBitsToFloat(uvec2(0x3f800000u, 0x40000000u)) == vec2(1.0f, 2.0f));
     // relational
     CHECK(any(lessThan(vec3(1.0f, 2.0f, 3.0f), vec3(2.0f))) && !all(lessThan(vec3(1.0f, 2.0f, 3.0f), vec3(2.0f))) && all(not_(equal(vec2(1.0f), vec2(2.0f)))));
     // prelude
