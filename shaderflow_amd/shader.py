@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import re
 from collections.abc import Iterable
 from pathlib import Path
 from typing import Any, Optional, Union
@@ -30,6 +31,48 @@ from shaderflow_amd.variable import FlatVariable, InVariable, OutVariable, Shade
 _UNIFORM_TYPES = {"float": (N.T_FLOAT, np.float32, 1), "int": (N.T_INT, np.int32, 1), "bool": (N.T_BOOL, np.int32, 1),
                   "vec2": (N.T_VEC2, np.float32, 2), "vec3": (N.T_VEC3, np.float32, 3), "vec4": (N.T_VEC4, np.float32, 4),
                   "mat2": (N.T_MAT2, np.float32, 4), "mat3": (N.T_MAT3, np.float32, 9), "mat4": (N.T_MAT4, np.float32, 16)}
+
+
+@define
+class ShaderDumper:
+    """What the reference does with a fragment its driver rejects (shader.py:36-97): the texts and the error go to the
+    user's log directory, the first error is shown with its surrounding lines. Here the compiler is hipcc and there are
+    two texts: the assembled GLSL and its translation (line numbers in the error are the translation's)."""
+    shader: "ShaderProgram"
+    error: str
+    fragment: str
+    translation: str = ""
+    context: int = 5
+
+    _parser = re.compile(r"^[^\n:]*\.hip:(\d+):(\d+): error: (.*)$", re.MULTILINE)
+
+    @staticmethod
+    def directory() -> Path:
+        from shaderflow_amd import glsl2hip
+        return Path(os.environ.get("SHADERFLOW_LOG_DIR", glsl2hip.cache_directory().parent/"logs"))
+
+    def excerpt(self) -> str:
+        """the lines of the translation around the first compiler error, the faulty one marked"""
+        match = self._parser.search(self.error)
+        if match is None or not self.translation:
+            return ""
+        lines, lineno = self.translation.splitlines(), int(match.group(1))
+        first, last = max(0, lineno - self.context - 1), min(len(lines), lineno + self.context)
+        body = [f"({n + 1:3d}) {'>' if n + 1 == lineno else '|'} {lines[n]}" for n in range(first, last)]
+        return "\n".join([f"Module #{self.shader.uuid}, line {lineno}: {match.group(3)}", *body])
+
+    def dump(self) -> Path:
+        directory = self.directory()
+        directory.mkdir(parents=True, exist_ok=True)
+        self.shader.log_error(f"Dumping shaders to {directory}")
+        (directory/f"{self.shader.uuid}.frag").write_text(self.fragment, encoding="utf-8")
+        if self.translation:
+            (directory/f"{self.shader.uuid}.hip").write_text(self.translation, encoding="utf-8")
+        (directory/f"{self.shader.uuid}-error.md").write_text(self.error, encoding="utf-8")
+        excerpt = self.excerpt()
+        if excerpt:
+            self.shader.log_error(excerpt)
+        return directory
 
 
 @define(eq=False, slots=False)
@@ -142,7 +185,8 @@ class ShaderProgram(ShaderModule):
                 if not isinstance(error, (TranslationError, CompileError, N.NativeError)):
                     raise
                 self.compile_error = str(error)
-                self.log_error(f"Fragment could not be translated: {error}")
+                self.log_error(f"Fragment could not be translated: {str(error).splitlines()[0]}")
+                ShaderDumper(shader=self, error=str(error), fragment=self.assembled_fragment(source), translation=self._translation_text).dump()
         if self.fallback:
             self.log_error("Fragment is neither in the kernel registry nor translatable, loading missing texture shader")
         return self
@@ -151,6 +195,7 @@ class ShaderProgram(ShaderModule):
     """Fragments that are not in the registry are translated to HIP and compiled at run time (glsl2hip.py)"""
     translated: bool = False
     compile_error: str = ""
+    _translation_text: str = ""
 
     def assembled_fragment(self, content: str) -> str:
         """What the reference hands to the GLSL compiler after the declarations and the prelude (shader.py:214-233): every
@@ -162,7 +207,6 @@ class ShaderProgram(ShaderModule):
             parts.extend(line for line in lines if line.lstrip().startswith("#"))
             helpers = [line for line in lines if not line.lstrip().startswith("#")]
             if helpers:
-                import re
                 names = re.findall(r"\b(\w+)\s*\(", helpers[0])
                 if any(re.search(rf"\b{re.escape(name)}\b", content) for name in names):
                     parts.extend(helpers)
@@ -174,7 +218,9 @@ class ShaderProgram(ShaderModule):
     def _load_translated(self, content: str) -> None:
         from shaderflow_amd import glsl2hip
         variables = [(variable.type, variable.name) for variable in self.full_pipeline()]
+        self._translation_text = ""
         translation = glsl2hip.translate(self.assembled_fragment(content), variables)
+        self._translation_text = translation.cpp
         code = glsl2hip.compile(translation)
         keep = [binding.name.encode() for binding in translation.bindings]
         table = (N.Binding*max(1, len(keep)))(*[N.Binding(name, int(binding.sampler), binding.slot, binding.count, int(binding.integer))

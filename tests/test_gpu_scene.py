@@ -391,3 +391,7 @@ def test_host_api_odds_and_ends(tmp_path):
     scene.shader.fragment = "void main() { fragColor = undeclared_function(stuv); }"                    # a compile error: missing.glsl (shader.py:323-340)
     scene.main(width=64, height=36, fps=30, time=1/30, freewheel=True)
     assert scene.shader.kernel == "missing" and scene.shader.fallback and "undeclared_function" in scene.shader.compile_error
+    from shaderflow_amd.shader import ShaderDumper                                                      # the texts and the error are dumped (shader.py:68-73)
+    dumped = ShaderDumper.directory()
+    assert "undeclared_function" in (dumped/f"{scene.shader.uuid}.frag").read_text() and (dumped/f"{scene.shader.uuid}.hip").exists()
+    assert "error" in (dumped/f"{scene.shader.uuid}-error.md").read_text()
