@@ -131,9 +131,12 @@ def main() -> None:
     from shaderflow_amd.parallel import FrameGather
     from shaderflow_amd.tape import FrameTape
 
-    # everything of this rank runs on torch's current stream so that RCCL and torch.cuda.synchronize() order with it
-    stream = torch.cuda.current_stream().cuda_stream
-    context = N.Context(local_rank, stream)
+    # Everything of this rank runs on ONE stream, which is also torch's current stream: RCCL orders a gather after the work
+    # already queued on the current stream, and a later render waits for the gather it must not overtake. (torch's default
+    # stream has the handle 0, for which the context would create a stream of its own that nothing orders with — so a real one.)
+    render_stream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(render_stream)
+    context = N.Context(local_rank, render_stream.cuda_stream)
 
     w, h, s, fpb = args.width, args.height, args.ssaa, args.frames_per_step
     pcm = synth.sweep_clip(args.seconds, 44100)
@@ -255,10 +258,19 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, pcm, background)
-        print(json.dumps(result))
+    else:
+        result = None
 
+    # The JSON line is the LAST line on stdout: libraries that write through C stdio (RCCL prints a version banner that stays in
+    # its buffer until exit) are flushed first, on every rank, before rank 0 prints.
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
+    if result is not None:
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
