@@ -168,7 +168,7 @@ def main() -> None:
     # the end of the timed region (the gather of a piece overlaps the render of the next one); N = 1 renders the batch at once
     parts = next(p for p in (4, 3, 2, 1) if fpb % p == 0) if distributed else 1
     piece = fpb//parts
-    gather = FrameGather(world, rank, piece*frame_bytes, torch.device("cuda", local_rank), slots=2*parts) if distributed else None
+    gather = FrameGather(world, rank, piece*frame_bytes, torch.device("cuda", local_rank), slots=2*parts, host_wait=False) if distributed else None
 
     def step(index: int, timed_slot: int | None):
         first = (index*fpb) % max(1, (min(frames_needed, clip_frames) - fpb + 1))

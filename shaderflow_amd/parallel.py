@@ -42,9 +42,14 @@ class FrameGather:
     RCCL ("nccl") gathers device buffers directly. The gloo backend has no device gather, so device buffers are staged
     through host memory there (tests with several processes on one GPU, CPU-only process groups)."""
 
-    def __init__(self, world: int, rank: int, nbytes: int, device, slots: int = 2):
+    def __init__(self, world: int, rank: int, nbytes: int, device, slots: int = 2, host_wait: bool = True):
+        """`host_wait`: `wait()` returns when the gather HAS finished. RCCL's own wait only makes torch's current stream wait,
+        which orders nothing for callers whose kernels and copies run on another stream (the export paths: the context's
+        stream and the read-out ring's copy stream) — they could overwrite a buffer still being sent, or read one still being
+        received. Callers that run everything on torch's current stream (bench.py) pass False and stay asynchronous."""
         import torch
         import torch.distributed as dist
+        self.host_wait = host_wait
         self.world, self.rank, self.nbytes = world, rank, nbytes
         self.device = torch.device(device)
         self.staged = (dist.get_backend() == "gloo") and (self.device.type != "cpu")
@@ -65,6 +70,9 @@ class FrameGather:
         work = self.pending[slot]
         if work is not None:
             work.wait()
+            if self.host_wait and not self.staged and self.device.type != "cpu":
+                import torch
+                torch.cuda.current_stream(self.device).synchronize()
             self.pending[slot] = None
 
     def wait_all(self) -> None:
