@@ -388,6 +388,7 @@ class ShaderScene(ShaderModule):
             import torch
             device = torch.device("cuda", context.device)
             tensors = [torch.zeros(frame_bytes*batch, dtype=torch.uint8, device=device) for _ in range(2)]
+            torch.cuda.synchronize(device)                  # the fill runs on torch's stream, the renders on the context's
             pointer_of = lambda buffer: buffer.data_ptr()
             gather = FrameGather(world, rank, frame_bytes*batch, device)
         else:                                                   # one rank's share, no process group: frames of foreign batches are dropped

@@ -243,6 +243,7 @@ class FrameTape:
                 import torch
                 device = torch.device("cuda", context.device)
                 buffers = [torch.zeros(frame_bytes*self.batch, dtype=torch.uint8, device=device) for _ in range(2)]
+                torch.cuda.synchronize(device)                  # the fill runs on torch's stream, the renders on the context's
                 gather = FrameGather(world, rank, frame_bytes*self.batch, device)
 
                 def render(count, buffer):
