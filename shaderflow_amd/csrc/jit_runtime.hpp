@@ -117,6 +117,7 @@ struct vec2 {
     SF_HD vec2(float a, float b) { x = a; y = b; }
     SF_HD vec2(const ivec2& v) { x = (float)v.x; y = (float)v.y; }      // GLSL converts ivec/uvec to vec implicitly (§4.1.10)
     SF_HD vec2(const uvec2& v) { x = (float)v.x; y = (float)v.y; }
+    SF_HD explicit vec2(const bvec2& v) { x = v.x ? 1.0f : 0.0f; y = v.y ? 1.0f : 0.0f; }
     SF_HD explicit vec2(const vec3& v);
     SF_HD explicit vec2(const vec4& v);
     SF_RT_COMMON(vec2, 2)
@@ -142,6 +143,7 @@ struct vec3 {
     SF_HD vec3(float a, const vec2& b) { x = a; y = b.x; z = b.y; }
     SF_HD vec3(const ivec3& v) { x = (float)v.x; y = (float)v.y; z = (float)v.z; }
     SF_HD vec3(const uvec3& v) { x = (float)v.x; y = (float)v.y; z = (float)v.z; }
+    SF_HD explicit vec3(const bvec3& v) { x = v.x ? 1.0f : 0.0f; y = v.y ? 1.0f : 0.0f; z = v.z ? 1.0f : 0.0f; }
     SF_HD explicit vec3(const vec4& v);
     SF_RT_COMMON(vec3, 3)
 };
@@ -170,6 +172,7 @@ struct vec4 {
     SF_HD vec4(float a, float b, const vec2& u) { x = a; y = b; z = u.x; w = u.y; }
     SF_HD vec4(const ivec4& v) { x = (float)v.x; y = (float)v.y; z = (float)v.z; w = (float)v.w; }
     SF_HD vec4(const uvec4& v) { x = (float)v.x; y = (float)v.y; z = (float)v.z; w = (float)v.w; }
+    SF_HD explicit vec4(const bvec4& v) { x = v.x ? 1.0f : 0.0f; y = v.y ? 1.0f : 0.0f; z = v.z ? 1.0f : 0.0f; w = v.w ? 1.0f : 0.0f; }
     SF_RT_COMMON(vec4, 4)
 };
 SF_HD vec2::vec2(const vec3& v) { x = v.x; y = v.y; }
@@ -352,10 +355,11 @@ SF_RT_MAP3(vec4, 4)
 SF_HD vec3 cross(const vec3& a, const vec3& b) { return vec3(a.y*b.z - b.y*a.z, a.z*b.x - b.z*a.x, a.x*b.y - b.x*a.y); }
 
 // vector relational functions (§8.6)
-#define SF_RT_REL(name, op) \
-    SF_HD bvec2 name(const vec2& a, const vec2& b) { return {a.x op b.x, a.y op b.y}; } \
-    SF_HD bvec3 name(const vec3& a, const vec3& b) { return {a.x op b.x, a.y op b.y, a.z op b.z}; } \
-    SF_HD bvec4 name(const vec4& a, const vec4& b) { return {a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w}; }
+#define SF_RT_REL3(name, op, V2, V3, V4) \
+    SF_HD bvec2 name(const V2& a, const V2& b) { return {a.x op b.x, a.y op b.y}; } \
+    SF_HD bvec3 name(const V3& a, const V3& b) { return {a.x op b.x, a.y op b.y, a.z op b.z}; } \
+    SF_HD bvec4 name(const V4& a, const V4& b) { return {a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w}; }
+#define SF_RT_REL(name, op) SF_RT_REL3(name, op, vec2, vec3, vec4) SF_RT_REL3(name, op, ivec2, ivec3, ivec4) SF_RT_REL3(name, op, uvec2, uvec3, uvec4)
 SF_RT_REL(lessThan, <) SF_RT_REL(lessThanEqual, <=) SF_RT_REL(greaterThan, >) SF_RT_REL(greaterThanEqual, >=)
 SF_RT_REL(equal, ==) SF_RT_REL(notEqual, !=)
 SF_HD bool any(bvec2 b) { return b.x || b.y; }
