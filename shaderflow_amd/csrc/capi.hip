@@ -321,6 +321,7 @@ struct Program : Object {
     hipModule_t module = nullptr;
     hipFunction_t fn_render = nullptr, fn_fused[3] = {nullptr, nullptr, nullptr};     // ssaa 1, 2, 4
     std::vector<JitBinding> bindings;
+    unsigned flags = 0;                                             // sfx_jit_flags of the code object: 1 = takes screen-space derivatives
 };
 
 static void forget_texture(Texture* t) {
@@ -401,6 +402,9 @@ extern "C" int sfx_program_load(sfx_handle h, const void* code_object, size_t nb
         hipModuleUnload(p->module); delete p;
         return fail(SFX_E_INVALID, "code object was compiled against another version of the kernel headers (RenderArgs %u bytes, library %zu)", compiled_size, sizeof(RenderArgs));
     }
+    if (hipModuleGetGlobal(&layout, &layout_bytes, p->module, "sfx_jit_flags") == hipSuccess) {
+        if ((e = hipMemcpy(&p->flags, layout, sizeof p->flags, hipMemcpyDeviceToHost)) != hipSuccess) return bail(SFX_E_HIP, "reading sfx_jit_flags", e);
+    } else (void)hipGetLastError();
     for (int k = 0; k < nbindings; k++) {
         const sfx_binding& b = bindings[k];
         const int limit = b.sampler ? TEX_SLOTS : USER_SLOTS;
@@ -410,6 +414,11 @@ extern "C" int sfx_program_load(sfx_handle h, const void* code_object, size_t nb
     c->programs.push_back(p);
     *out = handle_of(p);
     return SFX_OK;
+}
+
+extern "C" int sfx_program_fusable(sfx_handle h) {
+    Program* p = get<Program>(h, MAGIC_PROG);
+    return (p && p->fragment != FRAG_FINAL && !(p->flags & 1u)) ? 1 : 0;
 }
 
 extern "C" const char* sfx_program_name(sfx_handle h) {
@@ -796,6 +805,7 @@ extern "C" int sfx_render_resolve(sfx_handle h, sfx_handle final_tex, int ssaa, 
     if (t->dtype != SFX_U8 || t->components != 3) return fail(SFX_E_UNSUPPORTED, "fused target must be RGB8 (iFinal, scene.py:188-189)");
     if (subsample < 1) subsample = 1;
     if (!fused_supported(ssaa, subsample)) return fail(SFX_E_UNSUPPORTED, "final.glsl footprint for ssaa=%d subsample=%d leaves the pixel's block: use sfx_render + sfx_resolve", ssaa, subsample);
+    if (p->flags & 1u) return fail(SFX_E_UNSUPPORTED, "the fragment takes screen-space derivatives, which the fused kernels' lane layout does not provide: use sfx_render + sfx_resolve");
     USE_DEVICE(p->ctx);
     RenderArgs a;
     fill_args(p, a);
@@ -1360,7 +1370,7 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
     if (frame0 < 0 || nframes < 1 || frame0 + nframes > t->max_frames) return fail(SFX_E_INVALID, "frames [%d, %d) outside the tape", frame0, frame0 + nframes);
     if (subsample < 1) subsample = 1;
     if (ssaa_x1000 < 10) return fail(SFX_E_INVALID, "ssaa %d/1000", ssaa_x1000);
-    const bool fused = (ssaa_x1000 % 1000 == 0) && fused_supported(ssaa_x1000/1000, subsample);
+    const bool fused = (ssaa_x1000 % 1000 == 0) && fused_supported(ssaa_x1000/1000, subsample) && !(p->flags & 1u);
     const int ssaa = ssaa_x1000/1000;
     USE_DEVICE(p->ctx);
     RenderArgs a;

@@ -354,6 +354,21 @@ SF_RT_MAP3(vec3, 3)
 SF_RT_MAP3(vec4, 4)
 SF_HD vec3 cross(const vec3& a, const vec3& b) { return vec3(a.y*b.z - b.y*a.z, a.z*b.x - b.z*a.x, a.x*b.y - b.x*a.y); }
 
+// screen-space derivatives (§8.8): differences inside the 2 x 2 quad the unfused kernel lays out for fragments that use them
+// (render_kernels.hpp, QUADS) — the "fine" form: each row and column of the quad has its own difference. The host build used
+// by the CPU tests has no neighbours and returns zero.
+template <int CTRL> SF_HD float quad_value(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, true));
+#else
+    return v;
+#endif
+}
+SF_HD float dFdx(float v) { return quad_value<0xF5>(v) - quad_value<0xA0>(v); }      // quad_perm (1,1,3,3) - (0,0,2,2)
+SF_HD float dFdy(float v) { return quad_value<0xEE>(v) - quad_value<0x44>(v); }      // quad_perm (2,3,2,3) - (0,1,0,1)
+SF_HD float fwidth(float v) { return sf::abs(dFdx(v)) + sf::abs(dFdy(v)); }
+SF_RT_MAP1(dFdx) SF_RT_MAP1(dFdy) SF_RT_MAP1(fwidth)
+
 // vector relational functions (§8.6)
 #define SF_RT_REL3(name, op, V2, V3, V4) \
     SF_HD bvec2 name(const V2& a, const V2& b) { return {a.x op b.x, a.y op b.y}; } \
@@ -713,7 +728,8 @@ struct FragmentBase {
 
 // The shader policy of a translated fragment: FRAGMENT is the generated struct (derives from rt::FragmentBase, has
 // load_user_() and main_()).
-template <class FRAGMENT> struct JitShader : PlainShader<FRAG_DEFAULT> {
+template <class FRAGMENT, bool DERIVATIVES = false> struct JitShader : PlainShader<FRAG_DEFAULT> {
+    static constexpr bool QUADS = DERIVATIVES;
     SF_HD static vec4 run(const RenderArgs&, const Frag& f, const State&, const Shared&) {
         FRAGMENT s;
         s.load_(f);
@@ -777,10 +793,13 @@ inline void sfx_jit_host_texture(sf::Tex* textures, int slot, const void* data, 
 #endif
 
 // Entry points of a code object (capi: sfx_program_load looks them up by these names)
+// SF_JIT_DERIVATIVES (0/1, defined by the translator before this macro): the fragment calls dFdx/dFdy/fwidth — the unfused kernel
+// uses the quad layout and the library keeps the program off the fused kernels (their lanes are not quads for every SSAA factor).
 #define SF_JIT_ENTRY_POINTS(FRAGMENT) \
     SF_JIT_HOST_POINTS(FRAGMENT) \
     extern "C" __device__ __attribute__((used)) const unsigned sfx_jit_layout = (unsigned)sizeof(sf::RenderArgs); \
-    extern "C" __global__ __launch_bounds__(256) void sfx_jit_render(const sf::RenderArgs a) { sf::render_body<sf::JitShader<FRAGMENT>>(a); } \
+    extern "C" __device__ __attribute__((used)) const unsigned sfx_jit_flags = (SF_JIT_DERIVATIVES ? 1u : 0u); \
+    extern "C" __global__ __launch_bounds__(256) void sfx_jit_render(const sf::RenderArgs a) { sf::render_body<sf::JitShader<FRAGMENT, (SF_JIT_DERIVATIVES != 0)>>(a); } \
     extern "C" __global__ __launch_bounds__(256) void sfx_jit_fused_1(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT>, 1>(a); } \
     extern "C" __global__ __launch_bounds__(512) void sfx_jit_fused_2(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT>, 2>(a); } \
     extern "C" __global__ __launch_bounds__(512) void sfx_jit_fused_4(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT>, 4>(a); }

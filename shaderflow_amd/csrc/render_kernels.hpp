@@ -129,11 +129,25 @@ template <int FRAGMENT> struct PlainShader {
 // ---- K6: generic unfused render --------------------------------------------------------------------
 // (the bodies are functions so that the code object of a run-time translated fragment can wrap them in kernels with
 // C names, jit_runtime.hpp)
+// Shaders that take screen-space derivatives (translated fragments calling dFdx/dFdy/fwidth) declare `QUADS = true`: the
+// lanes of a wave then cover 32 x 2 pixels as sixteen 2 x 2 quads in consecutive lanes (lane bit 0 = x, bit 1 = y inside the
+// quad), every lane of a quad is shaded whether or not its pixel exists, and a derivative is a DPP quad_perm difference.
+template <class S, class = void> struct shader_uses_quads { static constexpr bool value = false; };
+template <class S> struct shader_uses_quads<S, decltype((void)S::QUADS)> { static constexpr bool value = S::QUADS; };
+
 template <class SHADER>
 __device__ __forceinline__ void render_body(const RenderArgs& a) {
     __shared__ typename SHADER::Shared shared;
-    const int i = blockIdx.x*SHADER::BLOCK_W + threadIdx.x;
-    const int j = blockIdx.y*SHADER::BLOCK_H + threadIdx.y;
+    constexpr bool QUADS = shader_uses_quads<SHADER>::value;
+    int lx = threadIdx.x, ly = threadIdx.y;
+    if constexpr (QUADS) {
+        static_assert(SHADER::BLOCK_W == 64 && SHADER::BLOCK_H == 4, "the quad layout is written for 64 x 4 blocks");
+        const int tid = ly*64 + lx, wave = tid >> 6, lane = tid & 63;
+        lx = (((lane >> 2) << 1) | (lane & 1)) + 32*(wave & 1);
+        ly = ((lane >> 1) & 1) + 2*(wave >> 1);
+    }
+    const int i = blockIdx.x*SHADER::BLOCK_W + lx;
+    const int j = blockIdx.y*SHADER::BLOCK_H + ly;
     Uniforms u; Tex tex[TEX_HISTORY];
     frame_view(a, blockIdx.z, u, tex);
     const bool inside = (i < a.wr) && (j < a.hr);
@@ -146,7 +160,12 @@ __device__ __forceinline__ void render_body(const RenderArgs& a) {
     const int i_last = min((int)(blockIdx.x + 1)*SHADER::BLOCK_W, a.wr) - 1 - (int)blockIdx.x*SHADER::BLOCK_W;
     const int j_last = min((int)(blockIdx.y + 1)*SHADER::BLOCK_H, a.hr) - 1 - (int)blockIdx.y*SHADER::BLOCK_H;
     SHADER::template setup<1>(a, tex, f, state, valid, shared, j_last*SHADER::BLOCK_W + i_last);
-    if (inside) store_target(a, blockIdx.z, i, j, SHADER::run(a, f, state[0], shared));
+    if constexpr (QUADS) {
+        const vec4 colour = SHADER::run(a, f, state[0], shared);      // helper lanes run too: their values feed the neighbours' differences
+        if (inside) store_target(a, blockIdx.z, i, j, colour);
+    } else {
+        if (inside) store_target(a, blockIdx.z, i, j, SHADER::run(a, f, state[0], shared));
+    }
 }
 template <class SHADER>
 __global__ __launch_bounds__(256) void k_render(const RenderArgs a) { render_body<SHADER>(a); }

@@ -515,6 +515,7 @@ class _Translator:
                "// ---- end of translated fragment ----\n"
                "};\n"
                "}}\n" + undefs +
+               f"#define SF_JIT_DERIVATIVES {int(bool(self.identifiers & {'dFdx', 'dFdy', 'fwidth'}))}\n"
                "SF_JIT_ENTRY_POINTS(sf::rt::Fragment)\n")
         return Translation(cpp, bindings)
 

@@ -118,6 +118,12 @@ def test_arrays_casts_keywords_and_discard():
         G.translate("void main() { fragColor = vec4(0); ")
 
 
+def test_fragments_that_take_derivatives_ask_for_the_quad_layout():
+    assert "#define SF_JIT_DERIVATIVES 1" in G.translate("void main() { fragColor = vec4(fwidth(stuv.x)); }").cpp
+    assert "#define SF_JIT_DERIVATIVES 1" in G.translate("#define slope(v) dFdx(v)\nvoid main() { fragColor = vec4(slope(stuv.x)); }").cpp
+    assert "#define SF_JIT_DERIVATIVES 0" in G.translate("void main() { fragColor = vec4(stuv.x); }").cpp
+
+
 def test_macros_are_rewritten_too_and_removed_afterwards():
     translation = G.translate("#define HALF 0.5\n#define scale(x) ((x)*2.0)\n#if 1\nvoid main() { fragColor = vec4(scale(HALF)); }\n#endif\n")
     assert "#define HALF 0.5f" in translation.cpp and "#define scale(x) ((x)*2.0f)" in translation.cpp
