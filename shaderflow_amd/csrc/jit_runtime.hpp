@@ -179,6 +179,12 @@ SF_HD vec2::vec2(const vec3& v) { x = v.x; y = v.y; }
 SF_HD vec2::vec2(const vec4& v) { x = v.x; y = v.y; }
 SF_HD vec3::vec3(const vec4& v) { x = v.x; y = v.y; z = v.z; }
 
+// `.length()` of arrays and vectors (the translator writes length_of(name))
+template <class T, int N> SF_HD constexpr int length_of(const T (&)[N]) { return N; }
+SF_HD constexpr int length_of(const vec2&) { return 2; }
+SF_HD constexpr int length_of(const vec3&) { return 3; }
+SF_HD constexpr int length_of(const vec4&) { return 4; }
+
 // GLSL int(x)/uint(x)/float(x)/bool(x) constructors (§5.4.1); NaN and out-of-range values convert by sfmath's rule
 SF_HD int to_int(float x) { return sf::to_int(x); }
 SF_HD int to_int(int x) { return x; }

@@ -165,6 +165,15 @@ def _significant(tokens: list[Tok], start: int, step: int = 1) -> int:
 
 # ---- token-level rewrites that apply everywhere --------------------------------------------------------------------------
 
+def _is_length_call(tokens: list[Tok], dot: int) -> bool:
+    name = _significant(tokens, dot + 1)
+    if name >= len(tokens) or tokens[name].text != "length":
+        return False
+    open_ = _significant(tokens, name + 1)
+    close = _significant(tokens, open_ + 1) if open_ < len(tokens) else len(tokens)
+    return open_ < len(tokens) and tokens[open_].text == "(" and close < len(tokens) and tokens[close].text == ")"
+
+
 def _rewrite_tokens(tokens: list[Tok], structs: set[str]) -> list[Tok]:
     out: list[Tok] = []
     k = 0
@@ -175,6 +184,13 @@ def _rewrite_tokens(tokens: list[Tok], structs: set[str]) -> list[Tok]:
             out.append(Tok("ws", "\n"*t.text.count("\n") or " "))
         elif t.kind == "number":
             out.append(Tok("number", _float_literal(t.text)))
+        elif t.kind == "op" and t.text == "^^":                       # logical exclusive or (§5.9): on bools that is `!=`
+            out.append(Tok("op", "!="))
+        elif t.kind == "op" and t.text == "." and _is_length_call(tokens, k) and out and out[-1].kind == "ident":
+            # `name.length()` of an array or vector (§4.1.9, §5.5) → length_of(name) (jit_runtime.hpp)
+            name = out.pop()
+            out.append(Tok("ident", f"length_of({name.text})"))
+            k = _matching(tokens, _significant(tokens, _significant(tokens, k + 1) + 1), "(", ")")
         elif t.kind == "ident":
             nxt = _significant(tokens, k + 1)
             following = tokens[nxt].text if nxt < len(tokens) else ""

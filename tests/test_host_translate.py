@@ -118,6 +118,13 @@ def test_arrays_casts_keywords_and_discard():
         G.translate("void main() { fragColor = vec4(0); ")
 
 
+def test_operators_and_methods_c_plus_plus_does_not_have():
+    out = body(G.translate("const float W[3] = float[3](1.0, 2.0, 3.0);\nvoid main() { bool a = stuv.x > 0.5 ^^ stuv.y > 0.5; float s = 0.0;\n"
+                           "for (int i = 0; i < W.length(); i++) s += W[i]; fragColor = vec4(a ? s : float(fragColor.length ( ))); }").cpp)
+    assert "stuv.x > 0.5f != stuv.y > 0.5f" in out and "i < length_of(W);" in out and "float(length_of(fragColor))" in out
+    assert "length(p)" in body(G.translate("void main() { vec2 p = stuv; fragColor = vec4(length(p)); }").cpp)          # the function is left alone
+
+
 def test_fragments_that_take_derivatives_ask_for_the_quad_layout():
     assert "#define SF_JIT_DERIVATIVES 1" in G.translate("void main() { fragColor = vec4(fwidth(stuv.x)); }").cpp
     assert "#define SF_JIT_DERIVATIVES 1" in G.translate("#define slope(v) dFdx(v)\nvoid main() { fragColor = vec4(slope(stuv.x)); }").cpp
