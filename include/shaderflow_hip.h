@@ -115,9 +115,10 @@ typedef struct sfx_binding {
 } sfx_binding;
 int sfx_program_load(sfx_handle ctx, const void* code_object, size_t nbytes, const sfx_binding* bindings, int nbindings, sfx_handle* program);
 const char* sfx_program_name(sfx_handle program);
-/* 1 when sfx_render_resolve / the fused branch of sfx_render_tape can run the program, 0 when it needs sfx_render + sfx_resolve
- * (a translated fragment that calls dFdx/dFdy/fwidth: only the unfused kernel lays its lanes out as 2x2 quads) */
-int sfx_program_fusable(sfx_handle program);
+/* 1 when sfx_render_resolve / the fused branch of sfx_render_tape can run the program at this SSAA factor, 0 when it needs
+ * sfx_render + sfx_resolve (a translated fragment that calls dFdx/dFdy/fwidth needs its 2x2 neighbours in the lanes of a quad:
+ * the unfused kernel lays them out so, the fused kernel does for ssaa == 2 only) */
+int sfx_program_fusable(sfx_handle program, int ssaa);
 /* returns SFX_OK whether or not the program reads `name` (inactive uniforms are ignored, shader.py:356-357);
  * *known (may be NULL) tells which */
 int sfx_uniform_set(sfx_handle program, const char* name, int type, const void* value, int* known);

@@ -74,7 +74,7 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_program_lookup": (C.c_int, [Handle, C.c_char_p, P(Handle), P(C.c_int)]),
     "sfx_program_load": (C.c_int, [Handle, C.c_void_p, C.c_size_t, P(Binding), C.c_int, P(Handle)]),
     "sfx_program_name": (C.c_char_p, [Handle]),
-    "sfx_program_fusable": (C.c_int, [Handle]),
+    "sfx_program_fusable": (C.c_int, [Handle, C.c_int]),
     "sfx_uniform_set": (C.c_int, [Handle, C.c_char_p, C.c_int, C.c_void_p, P(C.c_int)]),
     "sfx_sampler_bind": (C.c_int, [Handle, C.c_char_p, Handle, P(C.c_int)]),
     "sfx_program_destroy": (C.c_int, [Handle]),

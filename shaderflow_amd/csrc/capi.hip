@@ -416,9 +416,12 @@ extern "C" int sfx_program_load(sfx_handle h, const void* code_object, size_t nb
     return SFX_OK;
 }
 
-extern "C" int sfx_program_fusable(sfx_handle h) {
+// A fragment that takes derivatives needs its 2x2 neighbours in the lanes of a DPP quad. The fused kernel has that layout for
+// ssaa == 2 only (the four supersamples of a pixel are the four lanes of a quad, x in bit 0, y in bit 1).
+static bool fusable(const Program* p, int ssaa) { return !(p->flags & 1u) || ssaa == 2; }
+extern "C" int sfx_program_fusable(sfx_handle h, int ssaa) {
     Program* p = get<Program>(h, MAGIC_PROG);
-    return (p && p->fragment != FRAG_FINAL && !(p->flags & 1u)) ? 1 : 0;
+    return (p && p->fragment != FRAG_FINAL && fusable(p, ssaa)) ? 1 : 0;
 }
 
 extern "C" const char* sfx_program_name(sfx_handle h) {
@@ -805,7 +808,7 @@ extern "C" int sfx_render_resolve(sfx_handle h, sfx_handle final_tex, int ssaa, 
     if (t->dtype != SFX_U8 || t->components != 3) return fail(SFX_E_UNSUPPORTED, "fused target must be RGB8 (iFinal, scene.py:188-189)");
     if (subsample < 1) subsample = 1;
     if (!fused_supported(ssaa, subsample)) return fail(SFX_E_UNSUPPORTED, "final.glsl footprint for ssaa=%d subsample=%d leaves the pixel's block: use sfx_render + sfx_resolve", ssaa, subsample);
-    if (p->flags & 1u) return fail(SFX_E_UNSUPPORTED, "the fragment takes screen-space derivatives, which the fused kernels' lane layout does not provide: use sfx_render + sfx_resolve");
+    if (!fusable(p, ssaa)) return fail(SFX_E_UNSUPPORTED, "the fragment takes screen-space derivatives, which the fused kernel's lane layout provides for ssaa 2 only: use sfx_render + sfx_resolve");
     USE_DEVICE(p->ctx);
     RenderArgs a;
     fill_args(p, a);
@@ -1370,7 +1373,7 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
     if (frame0 < 0 || nframes < 1 || frame0 + nframes > t->max_frames) return fail(SFX_E_INVALID, "frames [%d, %d) outside the tape", frame0, frame0 + nframes);
     if (subsample < 1) subsample = 1;
     if (ssaa_x1000 < 10) return fail(SFX_E_INVALID, "ssaa %d/1000", ssaa_x1000);
-    const bool fused = (ssaa_x1000 % 1000 == 0) && fused_supported(ssaa_x1000/1000, subsample) && !(p->flags & 1u);
+    const bool fused = (ssaa_x1000 % 1000 == 0) && fused_supported(ssaa_x1000/1000, subsample) && fusable(p, ssaa_x1000/1000);
     const int ssaa = ssaa_x1000/1000;
     USE_DEVICE(p->ctx);
     RenderArgs a;

@@ -800,12 +800,13 @@ inline void sfx_jit_host_texture(sf::Tex* textures, int slot, const void* data, 
 
 // Entry points of a code object (capi: sfx_program_load looks them up by these names)
 // SF_JIT_DERIVATIVES (0/1, defined by the translator before this macro): the fragment calls dFdx/dFdy/fwidth — the unfused kernel
-// uses the quad layout and the library keeps the program off the fused kernels (their lanes are not quads for every SSAA factor).
+// uses the quad layout and the library keeps the program off the fused kernels except at ssaa 2, where the four supersamples of
+// a pixel already are the four lanes of a quad (all valid or all invalid together).
 #define SF_JIT_ENTRY_POINTS(FRAGMENT) \
     SF_JIT_HOST_POINTS(FRAGMENT) \
     extern "C" __device__ __attribute__((used)) const unsigned sfx_jit_layout = (unsigned)sizeof(sf::RenderArgs); \
     extern "C" __device__ __attribute__((used)) const unsigned sfx_jit_flags = (SF_JIT_DERIVATIVES ? 1u : 0u); \
     extern "C" __global__ __launch_bounds__(256) void sfx_jit_render(const sf::RenderArgs a) { sf::render_body<sf::JitShader<FRAGMENT, (SF_JIT_DERIVATIVES != 0)>>(a); } \
     extern "C" __global__ __launch_bounds__(256) void sfx_jit_fused_1(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT>, 1>(a); } \
-    extern "C" __global__ __launch_bounds__(512) void sfx_jit_fused_2(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT>, 2>(a); } \
+    extern "C" __global__ __launch_bounds__(512) void sfx_jit_fused_2(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT, (SF_JIT_DERIVATIVES != 0)>, 2>(a); } \
     extern "C" __global__ __launch_bounds__(512) void sfx_jit_fused_4(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT>, 4>(a); }

@@ -254,7 +254,7 @@ class ShaderScene(ShaderModule):
             self.fuse and (program.texture.temporal == 1) and (program.texture.layers == 1)
             and (final.components == 3) and (final.dtype == np.dtype(np.uint8))
             and N.lib().sfx_fused_supported(int(round(self.ssaa*1000)), self.subsample)
-            and (program.program is None or N.lib().sfx_program_fusable(program.program))
+            and (program.program is None or N.lib().sfx_program_fusable(program.program, int(self.ssaa)))
             and not any(isinstance(m, ShaderProgram) and m not in (program, self._final) and "iScreen" in m.fragment for m in self.modules)
         )
 

@@ -274,19 +274,23 @@ def test_array_parameters_matrix_uniforms_and_discard_in_a_function(gpu):
     N.check(gpu.lib.sfx_program_destroy(prog))
 
 
-def test_derivatives_keep_a_program_off_the_fused_kernels(gpu):
-    """dFdx/dFdy/fwidth need the quad layout of the unfused kernel: the program says so, the fused entry point refuses, and a scene
-    renders it in two passes — tape and frame loop alike — with the same bytes"""
+def test_derivatives_and_the_fused_kernels(gpu):
+    """dFdx/dFdy/fwidth need 2x2 neighbours in the lanes of a quad: the unfused kernel lays them out so, the fused kernel has that
+    layout at ssaa 2 only — the program says so, the other factors are refused, and scenes render either way with the same bytes
+    from tape and frame loop"""
     from shaderflow_amd import ShaderScene
     text = (HERE/"golden"/"jit"/"edges.glsl").read_text()
     prog, _ = load(gpu, text)
-    assert gpu.lib.sfx_program_fusable(prog) == 0
-    gpu.set_uniforms(prog, O.default_uniforms(64, 36))
+    assert [gpu.lib.sfx_program_fusable(prog, ssaa) for ssaa in (1, 2, 4)] == [0, 1, 0]
+    gpu.set_uniforms(prog, O.default_uniforms(64, 36, iSSAA=2.0))
     final = gpu.empty(64, 36, 3)
-    assert gpu.lib.sfx_render_resolve(prog, final, 2, 2) == N.E_UNSUPPORTED
+    assert gpu.lib.sfx_render_resolve(prog, final, 1, 1) == N.E_UNSUPPORTED and gpu.lib.sfx_render_resolve(prog, final, 4, 2) == N.E_UNSUPPORTED
+    fused = gpu.render_resolve(prog, 64, 36, 2, 2)                               # ssaa 2: the supersamples of a pixel are a quad
+    two_pass = gpu.resolve(gpu.render(prog, 128, 72), 64, 36, 2)
+    assert np.abs(fused.astype(int) - two_pass.astype(int)).max() <= 1 and fused.std() > 10
     N.check(gpu.lib.sfx_program_destroy(prog))
     plain, _ = load(gpu, GRADIENT)
-    assert gpu.lib.sfx_program_fusable(plain) == 1
+    assert [gpu.lib.sfx_program_fusable(plain, ssaa) for ssaa in (1, 2, 4)] == [1, 1, 1]
     N.check(gpu.lib.sfx_program_destroy(plain))
 
     class Edges(ShaderScene):
@@ -294,10 +298,11 @@ def test_derivatives_keep_a_program_off_the_fused_kernels(gpu):
             super().build()
             self.shader.fragment = text
 
-    kw = dict(width=96, height=54, fps=30, time=3/30, ssaa=2, output=bytes)
-    loop = np.frombuffer(Edges().main(batch=False, **kw), np.uint8).reshape(3, 54, 96, 3)
-    tape = np.frombuffer(Edges().main(batch=None, **kw), np.uint8).reshape(3, 54, 96, 3)
-    assert np.array_equal(loop, tape) and loop.std() > 10
+    for ssaa in (1, 2):                                                          # two passes, fused
+        kw = dict(width=96, height=54, fps=30, time=3/30, ssaa=ssaa, output=bytes)
+        loop = np.frombuffer(Edges().main(batch=False, **kw), np.uint8).reshape(3, 54, 96, 3)
+        tape = np.frombuffer(Edges().main(batch=None, **kw), np.uint8).reshape(3, 54, 96, 3)
+        assert np.array_equal(loop, tape) and loop.std() > 10
     # against the golden at the scene's render resolution would need the resolve; the ring is there and anti-aliased:
     centre_row = loop[0, 27].astype(int)
     assert len(np.unique(centre_row[:, 0])) > 4
