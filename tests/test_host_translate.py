@@ -258,15 +258,25 @@ def test_mechanical_translation_of_the_reference_equals_the_restatement(name, tm
     u.iTau = 0.3
     translation = G.translate((REFERENCE/path).read_text(), [("sampler2D", s) for s in ("background", "iSpectrogram", "iWaveform")])
     host = HostFragment(translation, tmp_path)
-    host.set_uniforms(u)
     for sampler in samplers:
         assert host.bind(sampler, arrays[sampler], *params[sampler])
-    got = host.render(w, h)
-    want = O.render(name, u, oracle_textures({k: arrays[k] for k in samplers}, params), w, h, threads=4)
-    d = np.abs(got.astype(int) - want.astype(int))
-    exact = float((d == 0).mean())
-    print(f"{name}: max {d.max()} LSB, {exact*100:.3f}% exact")
-    assert np.array_equal(got, want), (int(d.max()), exact)                       # observed: identical bytes, tetration's chaotic boundary included
+    textures = oracle_textures({k: arrays[k] for k in samplers}, params)
+    # the same code object under every camera projection, a moved camera, another time and a louder signal
+    settings = [dict(), dict(iCameraProjection=1, iCameraSeparation=0.08, iCameraZoom=1.2), dict(iCameraProjection=2, iCameraZoom=0.7),
+                dict(iCameraPosition=(0.3, -0.2, -0.4), iCameraZoom=0.8, iCameraIsometric=0.3, iTime=7.25, iAudioVolume=1.4, iAudioSTD=0.6)]
+    for setting in settings:
+        for key, value in setting.items():
+            if hasattr(value, "__len__"):
+                for k, component in enumerate(value):
+                    getattr(u, key)[k] = component
+            else:
+                setattr(u, key, value)
+        host.set_uniforms(u)
+        got = host.render(w, h)
+        want = O.render(name, u, textures, w, h, threads=4)
+        d = np.abs(got.astype(int) - want.astype(int))
+        # observed: identical bytes, tetration's chaotic boundary included
+        assert np.array_equal(got, want), (name, setting, int(d.max()), float((d == 0).mean()))
 
 
 def _history_defines(name: str, temporal: int, layers: int) -> str:
