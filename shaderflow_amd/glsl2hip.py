@@ -36,7 +36,8 @@ from typing import Iterable, Optional
 CSRC = Path(__file__).resolve().parent/"csrc"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
-         "-fno-slp-vectorize", "-fno-gpu-flush-denormals-to-zero", "-Wno-unused-value", "-Wno-deprecated-copy", "-Wno-parentheses"]
+         "-fno-slp-vectorize", "-fno-gpu-flush-denormals-to-zero", "-fwrapv",      # GLSL integers wrap (§4.1.3); C++ leaves signed overflow undefined
+         "-Wno-unused-value", "-Wno-deprecated-copy", "-Wno-parentheses"]
 
 USER_SLOTS = 64          # csrc/glsl.hpp USER_SLOTS
 TEX_SLOTS = 16           # csrc/glsl.hpp TEX_SLOTS

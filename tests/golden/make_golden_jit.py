@@ -37,6 +37,7 @@ CASES = {
     "cells": (128, 72, dict(iFrame=37), {}, {}, False),
     "hash": (128, 72, dict(iFrame=5), {}, {}, False),
     "builtins": (192, 128, dict(), {}, {}, False),
+    "materials": (160, 90, dict(iTime=2.5), {}, {}, False),
     "edges": (160, 90, dict(), {}, {}, False),
     "edges.odd": (97, 55, dict(), {}, {}, False),
     "polar": (160, 90, dict(iTime=0.3), dict(iSpin=0.8, iScale=1.4, iCentre=(0.15, -0.1), iTint=(0.9, 1.0, 0.8, 0.95)), dict(iRings=6, iInvert=0), False),

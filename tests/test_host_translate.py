@@ -214,7 +214,7 @@ def test_translated_fragments_on_the_host_match_the_opengl_goldens():
     from tests.jit_host import HostFragment
     golden = np.load(ROOT/"tests"/"golden"/"jit.npz")
     cases = json.loads(str(golden["cases"]))
-    for name in ("waves", "cells", "hash", "builtins", "polar"):
+    for name in ("waves", "cells", "hash", "builtins", "materials", "polar"):
         case = cases[name]
         host = HostFragment(G.translate((FRAGMENTS/f"{name}.glsl").read_text(), [("sampler2D", "background")]), CACHE)
         overrides = {k: (tuple(v) if isinstance(v, list) else v) for k, v in case["uniforms"].items()}
