@@ -375,6 +375,17 @@ SF_HD float dFdy(float v) { return quad_value<0xEE>(v) - quad_value<0x44>(v); } 
 SF_HD float fwidth(float v) { return sf::abs(dFdx(v)) + sf::abs(dFdy(v)); }
 SF_RT_MAP1(dFdx) SF_RT_MAP1(dFdy) SF_RT_MAP1(fwidth)
 
+// mix with a boolean selector (§8.3: components of b where the selector is true) and modf
+template <class B, typename std::enable_if<std::is_same<B, bool>::value, int>::type = 0>
+SF_HD float mix(float a, float b, B t) { return t ? b : a; }              // exactly bool: mix(a, b, 1) stays the float form
+SF_HD vec2 mix(const vec2& a, const vec2& b, const bvec2& t) { return vec2(t.x ? b.x : a.x, t.y ? b.y : a.y); }
+SF_HD vec3 mix(const vec3& a, const vec3& b, const bvec3& t) { return vec3(t.x ? b.x : a.x, t.y ? b.y : a.y, t.z ? b.z : a.z); }
+SF_HD vec4 mix(const vec4& a, const vec4& b, const bvec4& t) { return vec4(t.x ? b.x : a.x, t.y ? b.y : a.y, t.z ? b.z : a.z, t.w ? b.w : a.w); }
+SF_HD float modf(float x, float& whole) { whole = ::truncf(x); return x - whole; }
+SF_HD vec2 modf(const vec2& x, vec2& whole) { whole = trunc(x); return x - whole; }
+SF_HD vec3 modf(const vec3& x, vec3& whole) { whole = trunc(x); return x - whole; }
+SF_HD vec4 modf(const vec4& x, vec4& whole) { whole = trunc(x); return x - whole; }
+
 // vector relational functions (§8.6)
 #define SF_RT_REL3(name, op, V2, V3, V4) \
     SF_HD bvec2 name(const V2& a, const V2& b) { return {a.x op b.x, a.y op b.y}; } \

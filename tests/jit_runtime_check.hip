@@ -78,6 +78,9 @@ int run_checks() {
     CHECK(floatBitsToUint(vec2(1.0f, -2.0f)) == uvec2(0x3f800000u, 0xc0000000u) && uintBitsToFloat(uvec2(0x3f800000u, 0x40000000u)) == vec2(1.0f, 2.0f));
     // relational
     CHECK(any(lessThan(vec3(1.0f, 2.0f, 3.0f), vec3(2.0f))) && !all(lessThan(vec3(1.0f, 2.0f, 3.0f), vec3(2.0f))) && all(not_(equal(vec2(1.0f), vec2(2.0f)))));
+    vec2 whole;
+    CHECK(modf(vec2(2.75f, -1.5f), whole) == vec2(0.75f, -0.5f) && whole == vec2(2.0f, -1.0f));
+    CHECK(mix(vec3(1.0f), vec3(2.0f), lessThan(vec3(0.0f, 1.0f, 2.0f), vec3(1.0f))) == vec3(2.0f, 1.0f, 1.0f) && mix(1.0f, 2.0f, true) == 2.0f && mix(1.0f, 3.0f, 1) == 3.0f && mix(0, 1, 0.25f) == 0.25f);
     // prelude
     CHECK(stuv2gluv(vec2(0.5f)) == vec2(0.0f) && gluv2stuv(vec2(1.0f)) == vec2(1.0f) && zoom(vec2(1.0f), 2.0f) == vec2(4.0f));
     CHECK(sdSphere(vec3(0.0f), vec3(0.0f, 0.0f, 2.0f), 0.5f) == 1.5f && sdUnion(1.0f, 2.0f) == 1.0f && isBlackKey(1) && isWhiteKey(0.0f));
