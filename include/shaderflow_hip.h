@@ -92,7 +92,7 @@ int sfx_texture_destroy(sfx_handle tex);
 /* Programs — replace opengl.program(vs, fs) (shader.py:324), program[name].value = v (shader.py:353-360),
  * sampler binding (shader.py:377-386) and fbo.use(); vao.render() (shader.py:367-375, 388-405).
  *
- * There is no GLSL compiler: `source` (the USER part of the fragment, shader.py:229-235) is normalised
+ * The library itself has no GLSL compiler: `source` (the USER part of the fragment, shader.py:229-235) is normalised
  * (comments and whitespace stripped) and looked up in the registry of fragments restated as HIP kernels.
  * `*fallback` is set to 1 when it is unknown and the `missing.glsl` kernel was bound instead — the
  * reference's compile-error behaviour (shader.py:323-340). A registry name ("visualizer", "default" …)

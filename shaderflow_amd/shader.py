@@ -3,9 +3,10 @@ ShaderProgram: a fragment program that renders a fullscreen quad into its own Sh
 
 Host mirror of the reference's shaderflow/shader.py:99-425. What moderngl/OpenGL did there is done here by
 libshaderflow_hip: `compile()` resolves the fragment source through the registry of fragments restated as HIP
-kernels (`sfx_program_lookup`; unknown sources get the `missing` kernel — the reference's compile-error fallback,
-shader.py:323-340), `use_pipeline()` pushes every Uniform by name and binds samplers, `render()` draws each
-layer (`sfx_render`) and rolls the temporal matrix. The scene's `iFinal` program (texture.final) is the SSAA
+kernels (`sfx_program_lookup`); a source that is not there is translated to HIP C++, compiled and loaded
+(`glsl2hip.py`, `sfx_program_load`), and one that fails to translate or compile gets the `missing` kernel — the
+reference's compile-error fallback, shader.py:323-340. `use_pipeline()` pushes every Uniform by name and binds
+samplers, `render()` draws each layer (`sfx_render`) and rolls the temporal matrix. The scene's `iFinal` program (texture.final) is the SSAA
 resolve (shader.py:391-396): `sfx_resolve`, or fused with the main pass (`sfx_render_resolve`) when
 final.glsl's footprint stays inside the output pixel's own supersample block.
 """

@@ -245,7 +245,7 @@ class ShaderTexture(ShaderModule):
         return f"{self.name}{temporal}x{layer}"
 
     def defines(self) -> Iterable[str]:
-        """The GLSL helper text the reference injects for this texture; informational (nothing compiles GLSL here)"""
+        """The GLSL helper text the reference injects for this texture (texture.py:349-363); goes in front of fragments that are translated"""
         if not self.name:
             return
         last = self.layers - 1
