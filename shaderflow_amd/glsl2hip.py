@@ -186,6 +186,22 @@ def _rewrite_tokens(tokens: list[Tok], structs: set[str]) -> list[Tok]:
         elif t.kind == "number":
             out.append(Tok("number", _float_literal(t.text)))
         elif t.kind == "op" and t.text == "^^":                       # logical exclusive or (§5.9): on bools that is `!=`
+            # `!=` binds tighter than `&&`, `^^` looser: refuse the one spelling where that would change the meaning silently
+            for step in (-1, 1):
+                depth, j = 0, k + step
+                while 0 <= j < len(tokens):
+                    text = tokens[j].text if tokens[j].kind == "op" else ""
+                    if text in ("(", "[") if step == 1 else text in (")", "]"):
+                        depth += 1
+                    elif text in (")", "]") if step == 1 else text in ("(", "["):
+                        if depth == 0:
+                            break
+                        depth -= 1
+                    elif depth == 0 and text in (";", ",", "?", ":", "=", "||", "{", "}"):
+                        break
+                    elif depth == 0 and text == "&&":
+                        raise TranslationError("`&&` next to `^^` without parentheses: write (a && b) ^^ c")
+                    j += step
             out.append(Tok("op", "!="))
         elif t.kind == "op" and t.text == "." and _is_length_call(tokens, k) and out and out[-1].kind == "ident":
             # `name.length()` of an array or vector (§4.1.9, §5.5) → length_of(name) (jit_runtime.hpp)

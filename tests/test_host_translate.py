@@ -123,6 +123,9 @@ def test_operators_and_methods_c_plus_plus_does_not_have():
                            "for (int i = 0; i < W.length(); i++) s += W[i]; fragColor = vec4(a ? s : float(fragColor.length ( ))); }").cpp)
     assert "stuv.x > 0.5f != stuv.y > 0.5f" in out and "i < length_of(W);" in out and "float(length_of(fragColor))" in out
     assert "length(p)" in body(G.translate("void main() { vec2 p = stuv; fragColor = vec4(length(p)); }").cpp)          # the function is left alone
+    assert "(a && b) != c" in G.translate("void main() { bool a = true, b = false, c = true; fragColor = vec4(float((a && b) ^^ c)); }").cpp
+    with pytest.raises(G.TranslationError):                                        # C++ has no operator between && and ||
+        G.translate("void main() { bool a = true, b = false, c = true; fragColor = vec4(float(a && b ^^ c)); }")
 
 
 def test_fragments_that_take_derivatives_ask_for_the_quad_layout():
