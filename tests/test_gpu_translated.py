@@ -306,3 +306,31 @@ def test_derivatives_and_the_fused_kernels(gpu):
     # against the golden at the scene's render resolution would need the resolve; the ring is there and anti-aliased:
     centre_row = loop[0, 27].astype(int)
     assert len(np.unique(centre_row[:, 0])) > 4
+
+
+@pytest.mark.parametrize("name", ["waves", "march", "cells", "hash", "builtins", "materials", "polar"])
+def test_device_and_host_builds_of_a_translation_agree_bit_for_bit(gpu, name):
+    """One translation unit, two targets: the gfx950 code object and the x86 host build of the same header (tests/jit_host.py). Every
+    operation is a correctly rounded binary32 operation on both (no contraction, IEEE division and square root, denormals kept), so the
+    float outputs must be identical — this ties the GPU to the CPU checks of tests/test_host_translate.py (oracle, OpenGL goldens)."""
+    from tests.jit_host import HostFragment
+    case = CASES[name]
+    w, h = case["width"], case["height"]
+    text = (HERE/"golden"/"jit"/f"{name}.glsl").read_text()
+    prog, translation = load(gpu, text, [("sampler2D", "background")])
+    host = HostFragment(translation, CACHE)
+    overrides = {k: (tuple(v) if isinstance(v, list) else v) for k, v in case["uniforms"].items()}
+    u = O.default_uniforms(w, h, iTime=1.375, iCameraZoom=0.9, **{k: v for k, v in overrides.items() if k not in ("iTime", "iCameraZoom")})
+    gpu.set_uniforms(prog, u)
+    host.set_uniforms(u)
+    for key, value in case["floats"].items():
+        gpu.set_values(prog, key, value); host.set(key, value)
+    for key, value in case["integers"].items():
+        gpu.set_values(prog, key, value, integer=True); host.set(key, value)
+    gpu.bind(prog, "background", gpu.texture(G["background"], "linear", True, True))
+    host.bind("background", G["background"], "linear", True, True)
+    got = gpu.render(prog, w, h, comps=4, dtype=np.float32)
+    want = host.render_float(w, h)
+    N.check(gpu.lib.sfx_program_destroy(prog))
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), f"{int((~same).sum())} of {same.size} floats differ; first at {np.argwhere(~same)[0].tolist()}: {got[~same][0]!r} vs {want[~same][0]!r}"
