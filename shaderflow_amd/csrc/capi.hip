@@ -628,6 +628,9 @@ static int launch_render(int fragment, const RenderArgs& a, int frames, hipStrea
 #ifndef VIS_MIN_WAVES_SS
 #define VIS_MIN_WAVES_SS 8
 #endif
+#ifndef VIS_MIN_WAVES_S4
+#define VIS_MIN_WAVES_S4 6
+#endif
 
 template <class SHADER, int S> static void launch_fused_k(const RenderArgs& a, dim3 grid, dim3 block, size_t dynamic_lds, hipStream_t s) {
     if (dynamic_lds > 48*1024) hipFuncSetAttribute((const void*)k_render_resolve<SHADER, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_lds);
@@ -688,7 +691,7 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
                 if (ssaa == 1 && tw <= 128 && th <= 10) return launch_fused_s<VisualizerShader<128, 10, 1>>(a, ssaa, frames, s);
                 if (ssaa != 1 && tw <= VIS_PITCH_SS && th <= VIS_ROWS_SS) {
                     // four samples per lane need more registers: 6 waves per SIMD without spills beat 8 with (8K 4xSSAA: 55 -> 63 frames/s)
-                    if (ssaa == 4) return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, 6, VIS_FUSED_ROWS>>(a, ssaa, frames, s);
+                    if (ssaa == 4) return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_S4, VIS_FUSED_ROWS>>(a, ssaa, frames, s);
                     return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_SS, VIS_FUSED_ROWS, VIS_THREAD_ROWS, VIS_BLOCK_PX>>(a, ssaa, frames, s);
                 }
                 if (ssaa != 1) {
