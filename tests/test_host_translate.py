@@ -178,9 +178,10 @@ REFERENCE = Path("/root/reference")
 
 
 @pytest.mark.skipif(not REFERENCE.exists(), reason="the reference checkout is only present in the build container")
-def test_every_fragment_of_the_reference_translates_and_a_few_compile(tmp_path):
+def test_every_fragment_of_the_reference_translates():
     """Real-world GLSL in the reference's own style (implicit conversions, float loop counters, macros, switch, texelFetch, structs):
-    every fragment it ships goes through the translator; a cross-section is compiled for gfx950. Read in place, nothing is stored."""
+    every fragment it ships goes through the translator (fourteen of them are also compiled, run and compared with the oracle by the
+    test_mechanical_translation_* tests below). Read in place, nothing is stored."""
     files = sorted((REFERENCE/"examples").rglob("*.frag")) + sorted((REFERENCE/"examples").rglob("*.glsl")) \
         + sorted((REFERENCE/"shaderflow"/"resources"/"shaders"/"fragment").glob("*.glsl"))
     assert len(files) >= 14
@@ -194,15 +195,9 @@ def test_every_fragment_of_the_reference_translates_and_a_few_compile(tmp_path):
         for layer in range(2):
             defines += [f"    if (temporal == {t} && layer == {layer})", f"        return texture(iScreen{t}x{layer}, astuv);"]
     defines += ["    return vec4(0.0);", "}"]
-    compiled = 0
     for path in files:
         translation = G.translate("\n".join(defines) + "\n" + path.read_text(), pipeline)
         assert "SF_HD void main_()" in translation.cpp, path.name
-        if path.name in ("visualizer.frag", "motionblur.frag", "simulation.glsl", "tetration.frag"):
-            # (a scratch cache: nothing derived from the reference's text stays in the tree that travels to the GPU box)
-            assert G.compile(translation, cache=tmp_path).startswith((b"__CLANG_OFFLOAD_BUNDLE__", b"\x7fELF")), path.name
-            compiled += 1
-    assert compiled == 4
 
 
 # ---- translated fragments executed on the host ---------------------------------------------------------------------------
