@@ -580,7 +580,13 @@ static int launch_render(int fragment, const RenderArgs& a, int frames, hipStrea
         case FRAG_MISSING: launch_render_t<PlainShader<FRAG_MISSING>>(a, frames, s); break;
         case FRAG_VISUALIZER: {
             int tw = 0, th = 0;
-            if (visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) visualizer_window_bound(a, 128, 2, tw, th);
+            if (visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) {
+                // first choice: 64 x 8 samples per block over a 64 x 15 tile — three 512-thread blocks per CU and two staged cells per
+                // sample, against two 256-thread blocks and five cells for the 128 x 2 shape (1080p without SSAA: 8.4 -> see DESIGN §7)
+                visualizer_window_bound(a, 64, 8, tw, th);
+                if (tw > 0 && tw <= 64 && th <= 15) { launch_render_t<VisualizerShader<64, 15, 6, 1, 1, 128, 64, 8>>(a, frames, s); break; }
+                visualizer_window_bound(a, 128, 2, tw, th);
+            }
             if (tw > 0 && tw <= 128 && th <= 10) launch_render_t<VisualizerShader<128, 10, 1>>(a, frames, s);
             else if (tw > 0 && (size_t)tw*th*48 <= VIS_LDS_LIMIT) {           // a window wider than the fixed tile: tile sized per launch
                 RenderArgs d = a;

@@ -74,7 +74,13 @@ SF_HD vec4 texel(const Tex& t, int i, int j) {
     vec4 c = {0.0f, 0.0f, 0.0f, 1.0f};
     const long base = ((long)j*t.width + i)*t.components;
     const int n = t.components;
-    if (t.dtype == DT_U8) {
+    if (t.dtype == DT_U8 && n == 4) {                              // RGBA8 (iScreen, history textures): one aligned 32-bit load
+        const uint32_t w = ((const uint32_t*)t.data)[(long)j*t.width + i];
+        c.x = unorm8_to_float((float)(w & 255u));
+        c.y = unorm8_to_float((float)((w >> 8) & 255u));
+        c.z = unorm8_to_float((float)((w >> 16) & 255u));
+        c.w = unorm8_to_float((float)(w >> 24));
+    } else if (t.dtype == DT_U8) {
         const uint8_t* p = (const uint8_t*)t.data + base;
         c.x = unorm8_to_float((float)p[0]);
         if (n > 1) c.y = unorm8_to_float((float)p[1]);

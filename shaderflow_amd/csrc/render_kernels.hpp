@@ -168,7 +168,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a) {
     }
 }
 template <class SHADER>
-__global__ __launch_bounds__(256) void k_render(const RenderArgs a) { render_body<SHADER>(a); }
+__global__ __launch_bounds__(SHADER::BLOCK_W*SHADER::BLOCK_H, SHADER::MIN_WAVES_PER_SIMD) void k_render(const RenderArgs a) { render_body<SHADER>(a); }
 
 // ---- K8: final.glsl as a pass ------------------------------------------------------------------------
 struct ResolveArgs {

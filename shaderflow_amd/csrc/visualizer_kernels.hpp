@@ -49,12 +49,15 @@ __global__ void k_visualizer_bars(const float* __restrict__ columns, long n, flo
 
 // TILE_PITCH: cells per tile row (48 B each): 128 covers a 128-pixel block without supersampling, 80 is enough when
 // the block's 128 pixels are 2x or 4x supersampled (the window is then ~64 cells wide) and lets more blocks share a CU.
-template <int TILE_PITCH, int TILE_ROWS, int MIN_WAVES, int ROWS_PER_BLOCK = 1, int THREAD_ROWS_PER_BLOCK = 1, int BLOCK_PIXELS = 128>
+// UNFUSED_W x UNFUSED_H: the block of the unfused kernel. 128 x 2 samples need a 128 x 10 tile (61 KB: two blocks per CU, five
+// staged cells per sample); 64 x 8 samples need 64 x 15 cells (46 KB: three blocks of 512 threads, two cells per sample).
+template <int TILE_PITCH, int TILE_ROWS, int MIN_WAVES, int ROWS_PER_BLOCK = 1, int THREAD_ROWS_PER_BLOCK = 1, int BLOCK_PIXELS = 128,
+          int UNFUSED_W = 128, int UNFUSED_H = 2>
 struct VisualizerShader {
     static constexpr int BLOCK_PX = BLOCK_PIXELS;        // output pixels of a row per block of the fused kernel (S >= 2)
     static constexpr int FUSED_ROWS = ROWS_PER_BLOCK;    // rows a lane group walks; one LDS window serves FUSED_ROWS*THREAD_ROWS output rows
     static constexpr int THREAD_ROWS = THREAD_ROWS_PER_BLOCK;
-    static constexpr int BLOCK_W = 128, BLOCK_H = 2;     // unfused block shape (render_kernels.hpp k_render)
+    static constexpr int BLOCK_W = UNFUSED_W, BLOCK_H = UNFUSED_H;     // unfused block shape (render_kernels.hpp k_render)
     static constexpr int MIN_WAVES_PER_SIMD = MIN_WAVES;
 
     struct State {
