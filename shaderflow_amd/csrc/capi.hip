@@ -585,6 +585,14 @@ static int launch_render(int fragment, const RenderArgs& a, int frames, hipStrea
                 // sample, against two 256-thread blocks and five cells for the 128 x 2 shape (1080p without SSAA: 8.4 -> see DESIGN §7)
                 visualizer_window_bound(a, 64, 8, tw, th);
                 if (tw > 0 && tw <= 64 && th <= 15) { launch_render_t<VisualizerShader<64, 15, 6, 1, 1, 128, 64, 8>>(a, frames, s); break; }
+                // sparser outputs (720p over a 1080-row background: 1.3 texels per sample): the same block shape over a tile sized per
+                // launch, as long as two blocks share a CU — the 128 x 2 shape would need a 174 x 11 window there (one 256-thread block per CU)
+                if (tw > 0 && (size_t)tw*th*48 <= 76*1024) {
+                    RenderArgs d = a;
+                    d.tile_pitch = tw; d.tile_rows = th;
+                    launch_render_t<VisualizerShader<0, 0, 4, 1, 1, 128, 64, 8>>(d, frames, s, (size_t)tw*th*48);
+                    break;
+                }
                 visualizer_window_bound(a, 128, 2, tw, th);
             }
             if (tw > 0 && tw <= 128 && th <= 10) launch_render_t<VisualizerShader<128, 10, 1>>(a, frames, s);
