@@ -708,6 +708,14 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
                     if (ssaa == 4) return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_S4, VIS_FUSED_ROWS>>(a, ssaa, frames, s);
                     return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_SS, VIS_FUSED_ROWS, VIS_THREAD_ROWS, VIS_BLOCK_PX>>(a, ssaa, frames, s);
                 }
+                if (ssaa == 2) {
+                    // 0.43 texel per sample (1080p output at 2x SSAA over a 1080-row background): 64 pixels x 2 rows per block see a
+                    // 63 x 10 window — a 64 x 11 tile (33 KB) keeps four 512-thread blocks on a CU, where the tile sized per launch
+                    // below holds two
+                    int tw2 = 0, th2 = 0;
+                    visualizer_window_bound(a, 64*2, 2*2, tw2, th2);
+                    if (tw2 <= 64 && th2 <= 11) return launch_fused_s<VisualizerShader<64, 11, 8, 1, 2, 64>>(a, ssaa, frames, s);
+                }
                 if (ssaa != 1) {
                     // denser backgrounds (1080p output at 2x SSAA over a 1080-row background: 0.43 texel per sample; backgrounds
                     // larger than the output): the tile is sized per launch in dynamic LDS, and the block narrows from 128 to 64
