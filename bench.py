@@ -55,7 +55,7 @@ def parse_args():
     p.add_argument("--frames-per-step", type=int, default=60)
     p.add_argument("--seconds", type=float, default=60.0, help="length of the synthetic clip")
     p.add_argument("--scene", choices=("visualizer", "bars"), default="visualizer",
-                   help="visualizer = the metric's scene; bars = MusicBars (a light, HBM-write-bound fragment)")
+                   help="visualizer = the metric's scene; bars = MusicBars (a light fragment: 170 VALU instructions per supersample, still issue-bound)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-rows", type=int, default=0, help="output rows of the CPU baseline band (0 = auto, ~15 s)")
     return p.parse_args()
