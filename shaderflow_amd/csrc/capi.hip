@@ -716,6 +716,12 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
                     visualizer_window_bound(a, 64*2, 2*2, tw2, th2);
                     if (tw2 <= 64 && th2 <= 11) return launch_fused_s<VisualizerShader<64, 11, 8, 1, 2, 64>>(a, ssaa, frames, s);
                 }
+                if (ssaa == 4) {
+                    // the same for 4x SSAA at 0.2-0.3 texel per sample (1080p / 720p outputs): 32 pixels x 4 rows per block, a 56 x 14 tile (37 KB)
+                    int tw4 = 0, th4 = 0;
+                    visualizer_window_bound(a, 32*4, 4*4, tw4, th4);
+                    if (tw4 <= 56 && th4 <= 14) return launch_fused_s<VisualizerShader<56, 14, VIS_MIN_WAVES_S4, 1, 4, 32>>(a, ssaa, frames, s);
+                }
                 if (ssaa != 1) {
                     // denser backgrounds (1080p output at 2x SSAA over a 1080-row background: 0.43 texel per sample; backgrounds
                     // larger than the output): the tile is sized per launch in dynamic LDS, and the block narrows from 128 to 64
