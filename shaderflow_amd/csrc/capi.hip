@@ -523,6 +523,25 @@ static void fill_args(const Program* p, RenderArgs& a) {
     a.top_down = p->ctx->top_down;
 }
 
+// RN(1/n) if glsl.hpp pixel_centre(i, n, RN(1/n)) equals the IEEE quotient (i + 0.5)/n for every pixel index of an n-pixel axis,
+// else 0 (the kernels then divide). Checked exhaustively, once per extent.
+static float pixel_centre_reciprocal(int n) {
+    static std::mutex lock;
+    static std::vector<std::pair<int, float>> known;
+    if (n < 1) return 0.0f;
+    std::lock_guard<std::mutex> guard(lock);
+    for (const auto& k : known) if (k.first == n) return k.second;
+    const float inv = 1.0f/(float)n;
+    bool same = true;
+    for (int i = 0; i < n && same; i++) {
+        const float exact = ((float)i + 0.5f)/(float)n, fast = pixel_centre(i, n, inv);
+        same = (f2u(exact) == f2u(fast));
+    }
+    known.push_back({n, same ? inv : 0.0f});
+    return known.back().second;
+}
+static void set_pixel_centres(RenderArgs& a) { a.inv_wr = pixel_centre_reciprocal(a.wr); a.inv_hr = pixel_centre_reciprocal(a.hr); }
+
 static bool needs(const RenderArgs& a, int slot) { return a.tex[slot].data != nullptr || (slot == TEX_SPECTROGRAM && a.tape_spectrogram) || (slot == TEX_WAVEFORM && a.tape_waveform); }
 
 static int check_samplers(int fragment, const RenderArgs& a) {
@@ -803,6 +822,7 @@ extern "C" int sfx_render(sfx_handle h, sfx_handle target, int layer) {
     a.u.iLayer = layer;                                             // shader.py:402
     a.wr = t->width; a.hr = t->height; a.w = t->width; a.h = t->height;
     a.out = t->data; a.out_components = t->components; a.out_dtype = t->dtype; a.out_frame_stride = 0;
+    set_pixel_centres(a);
     int rc = check_samplers(p->fragment, a);
     if (rc) return rc;
     if ((rc = launch_render_p(p, a, 1, p->ctx->stream))) return rc;
@@ -845,6 +865,7 @@ extern "C" int sfx_render_resolve(sfx_handle h, sfx_handle final_tex, int ssaa, 
     fill_args(p, a);
     a.w = t->width; a.h = t->height; a.wr = t->width*ssaa; a.hr = t->height*ssaa; a.subsample = subsample;
     a.out = t->data; a.out_frame_stride = 0;
+    set_pixel_centres(a);
     int rc = check_samplers(p->fragment, a);
     if (rc) return rc;
     if ((rc = launch_fused_p(p, a, ssaa, 1, p->ctx->stream))) return rc;
@@ -1411,6 +1432,7 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
     fill_args(p, a);
     a.w = width; a.h = height; a.subsample = subsample;
     a.wr = (int)((double)width*ssaa_x1000/1000.0); a.hr = (int)((double)height*ssaa_x1000/1000.0);   // scene.py:372-375
+    set_pixel_centres(a);
     a.out = device_out; a.out_frame_stride = (long)width*height*3;
     a.dyn = t->d_dyn; a.frame0 = frame0;
     if (t->plan) {

@@ -220,12 +220,21 @@ struct Frag {
 SF_HD vec2 gluv2stuv(vec2 g) { return (g + 1.0f)/2.0f; }          // shaderflow.glsl:95
 SF_HD vec2 stuv2gluv(vec2 s) { return (s*2.0f) - 1.0f; }          // shaderflow.glsl:91
 
+// (i + 0.5)/n, the pixel centre of vertex/default.glsl's interpolation. `inv` != 0 is RN(1/n) from a host that has checked, for
+// EVERY i in [0, n), that the Newton-corrected product below equals the IEEE quotient bit for bit (capi: pixel_centre_reciprocal):
+// three plain operations instead of the division sequence, same bits. `inv` == 0: the division.
+SF_HD float pixel_centre(int i, int n, float inv) {
+    const float c = (float)i + 0.5f;
+    if (inv != 0.0f) { const float q = c*inv; return fmaf(fmaf(-q, (float)n, c), inv, q); }
+    return c/(float)n;
+}
+
 // `aspect` = iResolution.x/iResolution.y, the same IEEE division done once by the caller
-SF_HD void make_varyings(Frag& f, int i, int j, int wr, int hr, float aspect) {
+SF_HD void make_varyings(Frag& f, int i, int j, int wr, int hr, float aspect, float inv_wr = 0.0f, float inv_hr = 0.0f) {
     const Uniforms& u = *f.u;
     vec2 res = {u.iResolution[0], u.iResolution[1]};
     f.aspect = aspect;
-    vec2 centre = {((float)i + 0.5f)/(float)wr, ((float)j + 0.5f)/(float)hr};
+    vec2 centre = {pixel_centre(i, wr, inv_wr), pixel_centre(j, hr, inv_hr)};
     f.agluv = centre*2.0f - 1.0f;
     f.gluv = f.agluv*vec2{f.aspect, 1.0f};                         // agluv2gluv, shaderflow.glsl:99
     f.astuv = gluv2stuv(f.agluv);

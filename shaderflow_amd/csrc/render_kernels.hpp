@@ -44,6 +44,7 @@ struct RenderArgs {
     float bg_scale_x;                // background.height/background.width (gtexture, shaderflow.glsl:166-167), divided once on the host
     int tile_pitch, tile_rows;       // geometry of the LDS tile when it is a launch parameter (VisualizerShader<0, …>)
     int top_down;                    // K9: write the RGB8 frame rows top-down (the encoder's `vflip`, exporting.py:103, done here)
+    float inv_wr, inv_hr;            // RN(1/wr), RN(1/hr) when the host verified glsl.hpp pixel_centre() for them, else 0
 #ifdef SF_SECTION_TIMERS
     unsigned long long* timers;      // profiling builds (tools/variants.sh): per-section shader-clock sums, see SF_TICK
 #endif
@@ -152,7 +153,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a) {
     frame_view(a, blockIdx.z, u, tex);
     const bool inside = (i < a.wr) && (j < a.hr);
     Frag f; f.u = &u; f.tex = tex; f.history = a.tex + TEX_HISTORY;
-    make_varyings(f, i, j, a.wr, a.hr, a.aspect);
+    make_varyings(f, i, j, a.wr, a.hr, a.aspect, a.inv_wr, a.inv_hr);
     typename SHADER::State state[1];
     const bool valid[1] = {inside};
     SHADER::pre(a, f, inside, state[0]);
@@ -323,7 +324,7 @@ __device__ __forceinline__ void render_resolve_body(const RenderArgs& a) {
         const int r = n / GROUP, m = n % GROUP;
         const int gx = (sub & 1)*G + (m % G), gy = (sub >> 1)*G + (m / G);       // position inside the S x S block
         valid[n] = (px < a.w) && (py0 + r < a.h);
-        make_varyings(f, px*S + gx, (py0 + r)*S + gy, a.wr, a.hr, a.aspect);
+        make_varyings(f, px*S + gx, (py0 + r)*S + gy, a.wr, a.hr, a.aspect, a.inv_wr, a.inv_hr);
         SHADER::pre(a, f, valid[n], state[n]);
     }
     SF_TICK(a, 0);                                   // varyings + pre
@@ -340,7 +341,7 @@ __device__ __forceinline__ void render_resolve_body(const RenderArgs& a) {
             if constexpr (PER_LANE > 1) {            // with one sample per lane the varyings of pass 1 are still live
                 const int r = n / GROUP, m = n % GROUP;
                 const int gx = (sub & 1)*G + (m % G), gy = (sub >> 1)*G + (m / G);
-                make_varyings(f, px*S + gx, (py0 + r)*S + gy, a.wr, a.hr, a.aspect);
+                make_varyings(f, px*S + gx, (py0 + r)*S + gy, a.wr, a.hr, a.aspect, a.inv_wr, a.inv_hr);
             }
             q = pack_rgba8(SHADER::run(a, f, state[n], shared));
         }
