@@ -540,7 +540,11 @@ static float pixel_centre_reciprocal(int n) {
     known.push_back({n, same ? inv : 0.0f});
     return known.back().second;
 }
+#ifdef SF_NO_FAST_CENTRE                                         // A/B builds (tools/variants.sh)
+static void set_pixel_centres(RenderArgs& a) { a.inv_wr = 0.0f; a.inv_hr = 0.0f; }
+#else
 static void set_pixel_centres(RenderArgs& a) { a.inv_wr = pixel_centre_reciprocal(a.wr); a.inv_hr = pixel_centre_reciprocal(a.hr); }
+#endif
 
 static bool needs(const RenderArgs& a, int slot) { return a.tex[slot].data != nullptr || (slot == TEX_SPECTROGRAM && a.tape_spectrogram) || (slot == TEX_WAVEFORM && a.tape_waveform); }
 

@@ -136,6 +136,10 @@ template <int FRAGMENT> struct PlainShader {
 template <class S, class = void> struct shader_uses_quads { static constexpr bool value = false; };
 template <class S> struct shader_uses_quads<S, decltype((void)S::QUADS)> { static constexpr bool value = S::QUADS; };
 
+// Shaders may opt out of the verified-reciprocal pixel centres (glsl.hpp pixel_centre) at compile time: `FAST_CENTRES = false`
+template <class S, class = void> struct shader_fast_centres { static constexpr bool value = true; };
+template <class S> struct shader_fast_centres<S, decltype((void)S::FAST_CENTRES)> { static constexpr bool value = S::FAST_CENTRES; };
+
 template <class SHADER>
 __device__ __forceinline__ void render_body(const RenderArgs& a) {
     __shared__ typename SHADER::Shared shared;
@@ -153,7 +157,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a) {
     frame_view(a, blockIdx.z, u, tex);
     const bool inside = (i < a.wr) && (j < a.hr);
     Frag f; f.u = &u; f.tex = tex; f.history = a.tex + TEX_HISTORY;
-    make_varyings(f, i, j, a.wr, a.hr, a.aspect, a.inv_wr, a.inv_hr);
+    make_varyings(f, i, j, a.wr, a.hr, a.aspect, shader_fast_centres<SHADER>::value ? a.inv_wr : 0.0f, shader_fast_centres<SHADER>::value ? a.inv_hr : 0.0f);
     typename SHADER::State state[1];
     const bool valid[1] = {inside};
     SHADER::pre(a, f, inside, state[0]);
@@ -324,7 +328,7 @@ __device__ __forceinline__ void render_resolve_body(const RenderArgs& a) {
         const int r = n / GROUP, m = n % GROUP;
         const int gx = (sub & 1)*G + (m % G), gy = (sub >> 1)*G + (m / G);       // position inside the S x S block
         valid[n] = (px < a.w) && (py0 + r < a.h);
-        make_varyings(f, px*S + gx, (py0 + r)*S + gy, a.wr, a.hr, a.aspect, a.inv_wr, a.inv_hr);
+        make_varyings(f, px*S + gx, (py0 + r)*S + gy, a.wr, a.hr, a.aspect, shader_fast_centres<SHADER>::value ? a.inv_wr : 0.0f, shader_fast_centres<SHADER>::value ? a.inv_hr : 0.0f);
         SHADER::pre(a, f, valid[n], state[n]);
     }
     SF_TICK(a, 0);                                   // varyings + pre
@@ -341,7 +345,7 @@ __device__ __forceinline__ void render_resolve_body(const RenderArgs& a) {
             if constexpr (PER_LANE > 1) {            // with one sample per lane the varyings of pass 1 are still live
                 const int r = n / GROUP, m = n % GROUP;
                 const int gx = (sub & 1)*G + (m % G), gy = (sub >> 1)*G + (m / G);
-                make_varyings(f, px*S + gx, (py0 + r)*S + gy, a.wr, a.hr, a.aspect, a.inv_wr, a.inv_hr);
+                make_varyings(f, px*S + gx, (py0 + r)*S + gy, a.wr, a.hr, a.aspect, shader_fast_centres<SHADER>::value ? a.inv_wr : 0.0f, shader_fast_centres<SHADER>::value ? a.inv_hr : 0.0f);
             }
             q = pack_rgba8(SHADER::run(a, f, state[n], shared));
         }

@@ -59,6 +59,9 @@ struct VisualizerShader {
     static constexpr int THREAD_ROWS = THREAD_ROWS_PER_BLOCK;
     static constexpr int BLOCK_W = UNFUSED_W, BLOCK_H = UNFUSED_H;     // unfused block shape (render_kernels.hpp k_render)
     static constexpr int MIN_WAVES_PER_SIMD = MIN_WAVES;
+    // this kernel runs at its issue and dependency limits: the division's latency is hidden and the shorter sequence of
+    // glsl.hpp pixel_centre() gains nothing here (A/B on one box: -0.4 %), so it keeps the division
+    static constexpr bool FAST_CENTRES = false;
 
     struct State {
         VisualizerPre pre;
