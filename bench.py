@@ -40,8 +40,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 256*4*32*2.4e9    # 256 CU x 4 SIMD32 x 2.4 GHz = 78.6e12 lane-instructions/s (157.3 TFLOP/s FMA)
 # From profiles/r01_rocprofv3_bench_c3_summary.txt (rocprofv3 --pmc, separate passes, same command):
 PROFILE = {"file": "profiles/r01_rocprofv3_bench_c3_summary.txt",
-           "valu_instr_per_supersample": 2118.0,   # SQ_INSTS_VALU / SQ_WAVES of the fused visualizer kernel
-           "hbm_bytes_per_frame": (3484.4 + 1458000.0)*1024/60}   # FETCH_SIZE + WRITE_SIZE (KiB) per 60-frame launch
+           "valu_instr_per_supersample": 2120.0,   # SQ_INSTS_VALU / SQ_WAVES of the fused visualizer kernel
+           "hbm_bytes_per_frame": (3415.4 + 1458000.0)*1024/60}   # FETCH_SIZE + WRITE_SIZE (KiB) per 60-frame launch
 
 
 def parse_args():
