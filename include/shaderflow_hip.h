@@ -49,6 +49,13 @@ enum { SFX_T_FLOAT = 0, SFX_T_INT = 1, SFX_T_BOOL = 2, SFX_T_VEC2 = 3, SFX_T_VEC
 
 const char* sfx_last_error(void);
 const char* sfx_version(void);
+/* Fingerprint of the kernel-argument layout (member offsets + build switches) the library was built with. Code objects of
+ * run-time translated fragments carry the fingerprint of the headers THEY were compiled against; sfx_program_load refuses a
+ * mismatch, and hosts key their code-object caches with it. */
+uint64_t sfx_abi_layout(void);
+/* Name of the kernel instance the calling thread's last sfx_render / sfx_render_resolve / sfx_render_tape launched for the
+ * fragment, e.g. "k_render_resolve<VisualizerShader<80, 10, 8, 1, 1, 128, 128, 2>, 2>": tests and profiles tie results to it. */
+const char* sfx_last_kernel(void);
 
 /* ------------------------------------------------------------------------------------------------ */
 /* Context — replaces window/GL-context creation (scene.py:145-157) and GL_MAX_VIEWPORT_DIMS (texture.py:251) */
@@ -165,6 +172,10 @@ int sfx_audio_destroy(sfx_handle audio);
 /* The filterbank is built by the host exactly as spectrogram.py:194-224 does and handed over as CSR. */
 int sfx_stft_plan(sfx_handle ctx, int fft_n, int window, int bins, int channels,
                   const int32_t* indptr, const int32_t* indices, const float* data, sfx_handle* plan);
+/* FourierMagnitude (spectrogram.py:20-26): what `fft()` makes of the complex bins. Power (the default) = (x*conj(x)).real,
+ * Amplitude = np.abs(x); both evaluated in float64 and cast to float32 like the reference (:169-171). */
+enum { SFX_MAGNITUDE_POWER = 0, SFX_MAGNITUDE_AMPLITUDE = 1 };
+int sfx_stft_plan_magnitude(sfx_handle plan, int magnitude);
 int sfx_stft_plan_destroy(sfx_handle plan);
 
 /* Per-frame entry points (the faithful frame loop: results come back to the host like numpy arrays).
@@ -197,11 +208,28 @@ typedef struct {
     int32_t iFrame;
 } sfx_frame_clock;
 
+/* DynamicNumber.next on its own (dynamics.py:197-250; SURVEY.md §8b "dynamics_scan"): the float32 array system of
+ * ShaderSpectrogram (spectrogram.py:287-290, 304-307) walked over `nframes` targets. Host arrays: targets and values
+ * [nframes][n]; coeff[frame] = the python scalars of that frame (dt == 0: the frame is skipped, :210-211); state =
+ * value | derivative | previous (n floats each), read and written back. The early-out `max|target - value| < precision`
+ * (:222-225) freezes the whole system for the frame, exactly as the reference does. n <= 2048. */
+int sfx_dynamics_scan(sfx_handle ctx, int nframes, int n, const float* targets, const sfx_dyn_coeff_f32* coeff,
+                      float precision, float* state, float* values);
+/* The same for `nsystems` independent float64 scalar systems (volume, std: audio/module.py:413-421; the camera's:
+ * camera.py:147-185). targets [nframes][nsystems], coeff [nsystems][nframes], state [nsystems][4] = value, derivative,
+ * previous, integral (in/out), out [nframes][nsystems][3] = value, integral, derivative. */
+int sfx_dynamics_scan_f64(sfx_handle ctx, int nframes, int nsystems, const double* targets, const sfx_dyn_coeff_f64* coeff,
+                          double precision, int integrate, double* state, double* out);
+
 typedef struct {
     int32_t points, chunk_size, reducer;     /* ShaderWaveform (0 points: no waveform)              */
     int32_t volume_window;                   /* int(0.1*samplerate), audio/module.py:457            */
     int32_t use_mfma;
     int32_t volume_integrate, std_integrate; /* ShaderDynamics.integrate (audio/module.py:413-421)  */
+    int32_t length_samples;                  /* ShaderSpectrogram.length_samples = width of its texture (spectrogram.py:272-274);
+                                              * <= 1: one column (length = 0). > 1: the scrolling texture — column (k+1) % width is
+                                              * rewritten by frame k (:303, 308-311) and every tape frame samples the texture as it
+                                              * was when that frame was drawn */
     double precision;                        /* DynamicNumber.precision, dynamics.py:147            */
 } sfx_tape_desc;
 

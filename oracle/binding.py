@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
         L.sfo_reader.argtypes = [P(C.c_double), C.c_int, C.c_int, C.c_int, C.c_int64, P(C.c_int32), P(C.c_int64)]
         L.sfo_window.argtypes = [C.c_int, C.c_int, P(C.c_double)]
         L.sfo_fft_power.argtypes = [P(C.c_float), C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, P(C.c_float)]
+        L.sfo_fft_amplitude.argtypes = L.sfo_fft_power.argtypes
         L.sfo_filterbank.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double,
                                      P(C.c_int32), P(C.c_int32), P(C.c_float), C.c_int]
         L.sfo_filterbank.restype = C.c_int
@@ -129,12 +130,13 @@ def window(kind: int, n: int) -> np.ndarray:
     return out
 
 
-def fft_power(pcm: np.ndarray, tell: int, fft_n: int = 12, window_kind: int = 0) -> np.ndarray:
-    """pcm: planar (channels, total) float32"""
+def fft_power(pcm: np.ndarray, tell: int, fft_n: int = 12, window_kind: int = 0, amplitude: bool = False) -> np.ndarray:
+    """pcm: planar (channels, total) float32; amplitude: FourierMagnitude.Amplitude instead of .Power"""
     pcm = np.ascontiguousarray(pcm, np.float32)
     channels, total = pcm.shape
     out = np.zeros((channels, (1 << fft_n)//2 + 1), np.float32)
-    lib().sfo_fft_power(_p(pcm, C.c_float), total, channels, tell, fft_n, window_kind, _p(out, C.c_float))
+    fn = lib().sfo_fft_amplitude if amplitude else lib().sfo_fft_power
+    fn(_p(pcm, C.c_float), total, channels, tell, fft_n, window_kind, _p(out, C.c_float))
     return out
 
 

@@ -58,6 +58,8 @@ void sfo_window(int kind, int n, double* out);
  * before the start. out: (channels, n/2+1) float32 power. */
 void sfo_fft_power(const float* pcm, int64_t total, int channels, int64_t tell,
                    int fft_n, int window_kind, float* out);
+void sfo_fft_amplitude(const float* pcm, int64_t total, int channels, int64_t tell,
+                       int fft_n, int window_kind, float* out);
 
 /* spectrogram.py:186-224 (+ scales :73-87, kernels :44-70). Returns nnz (or -needed if cap is too
  * small). CSR of the (bins, fft_bins) float32 matrix. */

@@ -108,8 +108,8 @@ static inline float stream_sample(const float* pcm, int64_t total, int c, int64_
     return (idx < 0 || idx >= total) ? 0.0f : pcm[(int64_t)c*total + idx];
 }
 
-void sfo_fft_power(const float* pcm, int64_t total, int channels, int64_t tell,
-                   int fft_n, int window_kind, float* out) {
+static void fft_magnitude(const float* pcm, int64_t total, int channels, int64_t tell,
+                          int fft_n, int window_kind, int amplitude, float* out) {
     const int n = 1 << fft_n;
     const int bins = n/2 + 1;
     double* win = (double*)malloc(sizeof(double)*n);
@@ -123,10 +123,19 @@ void sfo_fft_power(const float* pcm, int64_t total, int channels, int64_t tell,
             im[i] = 0.0;
         }
         fft_radix2(re, im, n);
-        for (int k = 0; k < bins; k++)                          /* spectrogram.py:25-26 then .astype(f32) */
-            out[(int64_t)c*bins + k] = (float)(re[k]*re[k] + im[k]*im[k]);
+        for (int k = 0; k < bins; k++)                          /* spectrogram.py:22-26 then .astype(f32) */
+            out[(int64_t)c*bins + k] = amplitude ? (float)hypot(re[k], im[k]) : (float)(re[k]*re[k] + im[k]*im[k]);
     }
     free(win); free(re); free(im);
+}
+
+void sfo_fft_power(const float* pcm, int64_t total, int channels, int64_t tell,
+                   int fft_n, int window_kind, float* out) {      /* FourierMagnitude.Power, spectrogram.py:25-26 */
+    fft_magnitude(pcm, total, channels, tell, fft_n, window_kind, 0, out);
+}
+void sfo_fft_amplitude(const float* pcm, int64_t total, int channels, int64_t tell,
+                       int fft_n, int window_kind, float* out) {  /* FourierMagnitude.Amplitude = np.abs, spectrogram.py:22-23 */
+    fft_magnitude(pcm, total, channels, tell, fft_n, window_kind, 1, out);
 }
 
 /* ---------------------------------------------------------------------------------------------- */

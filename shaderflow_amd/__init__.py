@@ -12,6 +12,9 @@ There is no CPU fallback: importing works anywhere, creating a scene needs the b
 """
 from __future__ import annotations
 
+import importlib
+import importlib.machinery
+import importlib.util
 import logging
 import sys
 from pathlib import Path
@@ -39,17 +42,43 @@ class _Directories:
 
 directories = _Directories()
 
-_SUBMODULES = ("variable", "message", "module", "scheduler", "resolution", "dynamics", "texture", "shader",
-               "camera", "exporting", "scene", "tape", "device", "parallel", "synth", "audio", "audio.module", "audio.spectrogram", "audio.waveform",
-               "audio.reader", "piano", "piano.notes")
+class _AliasFinder:
+    """Resolves `<alias>` and every `<alias>.<sub>` to THE module object of `shaderflow_amd[.<sub>]` — one object under two
+    names, so `shaderflow.video.ShaderVideo is shaderflow_amd.video.ShaderVideo` for every submodule, present and future
+    (a static list would let a forgotten one be imported a second time as a distinct module)"""
+
+    def __init__(self, alias: str):
+        self.alias = alias
+
+    def _real(self, fullname: str):
+        if fullname == self.alias or fullname.startswith(self.alias + "."):
+            return __name__ + fullname[len(self.alias):]
+        return None
+
+    def find_spec(self, fullname, path=None, target=None):
+        real = self._real(fullname)
+        if real is None:
+            return None
+        try:
+            found = importlib.util.find_spec(real)
+        except (ImportError, ValueError):
+            found = None
+        if found is None:
+            return None
+        return importlib.machinery.ModuleSpec(fullname, self, is_package=found.submodule_search_locations is not None)
+
+    def create_module(self, spec):
+        return importlib.import_module(self._real(spec.name))
+
+    def exec_module(self, module) -> None:
+        pass                                                  # already executed under its own name
 
 
 def install_alias(name: str = "shaderflow") -> None:
     """Make `import shaderflow`, `from shaderflow.scene import ShaderScene`, … resolve to this package"""
-    import importlib
     sys.modules[name] = sys.modules[__name__]
-    for sub in _SUBMODULES:
-        sys.modules[f"{name}.{sub}"] = importlib.import_module(f"{__name__}.{sub}")
+    if not any(isinstance(finder, _AliasFinder) and finder.alias == name for finder in sys.meta_path):
+        sys.meta_path.insert(0, _AliasFinder(name))
 
 
 def __getattr__(attr: str):

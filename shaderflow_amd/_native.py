@@ -50,7 +50,7 @@ class Binding(C.Structure):
 class TapeDesc(C.Structure):
     _fields_ = [("points", C.c_int32), ("chunk_size", C.c_int32), ("reducer", C.c_int32), ("volume_window", C.c_int32),
                 ("use_mfma", C.c_int32), ("volume_integrate", C.c_int32), ("std_integrate", C.c_int32),
-                ("precision", C.c_double)]
+                ("length_samples", C.c_int32), ("precision", C.c_double)]
 
 
 # name → (restype, argtypes); every symbol declared in include/shaderflow_hip.h
@@ -58,6 +58,8 @@ P = C.POINTER
 PROTOTYPES: dict[str, tuple] = {
     "sfx_last_error": (C.c_char_p, []),
     "sfx_version": (C.c_char_p, []),
+    "sfx_abi_layout": (C.c_uint64, []),
+    "sfx_last_kernel": (C.c_char_p, []),
     "sfx_ctx_create": (C.c_int, [C.c_int, C.c_void_p, P(Handle)]),
     "sfx_ctx_info": (C.c_int, [Handle, P(CtxInfo)]),
     "sfx_ctx_synchronize": (C.c_int, [Handle]),
@@ -95,11 +97,14 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_audio_upload": (C.c_int, [Handle, P(C.c_float), C.c_int64, C.c_int, C.c_int, P(Handle)]),
     "sfx_audio_destroy": (C.c_int, [Handle]),
     "sfx_stft_plan": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_int32), P(C.c_int32), P(C.c_float), P(Handle)]),
+    "sfx_stft_plan_magnitude": (C.c_int, [Handle, C.c_int]),
     "sfx_stft_plan_destroy": (C.c_int, [Handle]),
     "sfx_stft_power": (C.c_int, [Handle, Handle, P(C.c_int64), C.c_int, P(C.c_float)]),
     "sfx_spectrogram_targets": (C.c_int, [Handle, Handle, P(C.c_int64), C.c_int, C.c_int, P(C.c_float)]),
     "sfx_waveform_rows": (C.c_int, [Handle, P(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]),
     "sfx_volume_std": (C.c_int, [Handle, P(C.c_int64), C.c_int, C.c_int, P(C.c_float)]),
+    "sfx_dynamics_scan": (C.c_int, [Handle, C.c_int, C.c_int, P(C.c_float), P(DynCoeffF32), C.c_float, P(C.c_float), P(C.c_float)]),
+    "sfx_dynamics_scan_f64": (C.c_int, [Handle, C.c_int, C.c_int, P(C.c_double), P(DynCoeffF64), C.c_double, C.c_int, P(C.c_double), P(C.c_double)]),
     "sfx_tape_create": (C.c_int, [Handle, Handle, P(TapeDesc), C.c_int, P(Handle)]),
     "sfx_clock_tape_create": (C.c_int, [Handle, C.c_int, P(Handle)]),
     "sfx_tape_reset": (C.c_int, [Handle]),

@@ -6,8 +6,8 @@ SpectrogramWindow) and the filterbank construction (`spectrogram_frequencies`, `
 stay numpy/scipy code — they run once per configuration and define WHAT is computed. Device side: the per-frame
 STFT (`window*frame → radix-2 FFT in float64 → |X|² → float32`, :155-171) and the filterbank product
 (:175-176) are HIP kernels reached through an `sfx_stft_plan`. Options the kernels implement: the three windows,
-`FourierMagnitude.Power`, any scale/interpolation (they only shape the CSR matrix). `sample_rateio != 1`
-(third-party `samplerate` resampler, :158-167) and `FourierMagnitude.Amplitude` raise NotImplementedError.
+`FourierMagnitude.Power` and `.Amplitude`, any scale/interpolation (they only shape the CSR matrix). `sample_rateio != 1`
+(third-party `samplerate` resampler, :158-167: un-vendored, not importable here) raises NotImplementedError.
 """
 from __future__ import annotations
 
@@ -157,11 +157,12 @@ class BrokenSpectrogram:
         """The sfx_stft_plan of the current configuration (rebuilt when it changes)"""
         if self.sample_rateio != 1:
             raise NotImplementedError("sample_rateio != 1 needs the third-party 'samplerate' resampler, which has no device path")
-        if self.magnitude is not FourierMagnitude.Power:
-            raise NotImplementedError("only FourierMagnitude.Power has a device kernel")
+        if self.magnitude not in (FourierMagnitude.Power, FourierMagnitude.Amplitude):
+            raise NotImplementedError("custom magnitudes have no device kernel (FourierMagnitude.Power, .Amplitude)")
         if self.window not in _WINDOW_CODES:
             raise NotImplementedError("custom windows have no device kernel (hanning, hann_poisson_window, none)")
-        key = (hash(self), self.audio.channels, self.audio.samplerate, _WINDOW_CODES[self.window])
+        amplitude = (self.magnitude is FourierMagnitude.Amplitude)
+        key = (hash(self), self.audio.channels, self.audio.samplerate, _WINDOW_CODES[self.window], amplitude)
         if self._plan is None or self._plan_key != key:
             self.release_plan()
             matrix = self.spectrogram_matrix()
@@ -172,6 +173,7 @@ class BrokenSpectrogram:
             N.check(N.lib().sfx_stft_plan(self._context().handle, self.fft_n, _WINDOW_CODES[self.window], self.spectrogram_bins,
                                           self.audio.channels, N.as_ptr(indptr, C.c_int32), N.as_ptr(indices, C.c_int32),
                                           N.as_ptr(data, C.c_float), C.byref(handle)))
+            N.check(N.lib().sfx_stft_plan_magnitude(handle, int(amplitude)))
             self._plan, self._plan_key = handle, key
         return self._plan
 

@@ -27,7 +27,7 @@ __device__ __forceinline__ float stream_at(const float* pcm, long total, int c, 
 // twiddle[k] = exp(-2*pi*i*k/N), k < N/2, and window[n] are float64 tables built by the host.
 __global__ __launch_bounds__(256) void k_stft_power(const float* __restrict__ pcm, long total, const long* __restrict__ tell,
                                                     int fft_n, const double* __restrict__ window,
-                                                    const double2* __restrict__ twiddle, float* __restrict__ power) {
+                                                    const double2* __restrict__ twiddle, float* __restrict__ power, int amplitude) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2* z = (double2*)smem;
     const int N = 1 << fft_n, M = N >> 1, logM = fft_n - 1;
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void k_stft_power(const float* __restrict__ pc
         const double orr = 0.5*(a.y + b.y), oi = -0.5*(a.x - b.x);  // O = -i(Z[k] - conj(Z[M-k]))/2
         double2 w = (k < M) ? twiddle[k] : make_double2(-1.0, 0.0);
         const double xr = er + (orr*w.x - oi*w.y), xi = ei + (orr*w.y + oi*w.x);
-        out[k] = (float)(xr*xr + xi*xi);                            // FourierMagnitude.Power, spectrogram.py:25-26
+        // FourierMagnitude.Power = (x*conj(x)).real, spectrogram.py:25-26; .Amplitude = np.abs(x) = hypot in float64, :22-23
+        out[k] = amplitude ? (float)::hypot(xr, xi) : (float)(xr*xr + xi*xi);
     }
 }
 
@@ -305,6 +306,49 @@ __global__ __launch_bounds__(1024) void k_dynamics_scan(int nframes, int n /* bi
         const int i = threadIdx.x + e*1024;
         if (i < n) { state[i] = value[e]; state[n + i] = deriv[e]; state[2*n + i] = prev[e]; }
     }
+}
+
+// ---- scrolling spectrogram texture (spectrogram.py:298-311) -------------------------------------------------
+// ShaderSpectrogram keeps a texture of `width` = length*fps columns and overwrites column (offset+1) % width every frame.
+// A batch renders its frames concurrently, so every frame gets the texture AS IT WAS when that frame was drawn:
+// scroll[f][bin][col][channel] = the column the most recent frame k' <= k with (k'+1) % width == col wrote (zeros before
+// any did), k = first_frame + f. `ring` holds the smoothed columns of the last `ring_frames` >= width frames by
+// absolute frame index modulo ring_frames.
+__global__ void k_spectrogram_ring_store(const float* __restrict__ columns, int nframes, int n, long first_frame, int ring_frames,
+                                         float* __restrict__ ring) {
+    const long t = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (t >= (long)nframes*n) return;
+    const long f = t / n, e = t % n;
+    ring[((first_frame + f) % ring_frames)*n + e] = columns[t];
+}
+__global__ void k_spectrogram_scroll(const float* __restrict__ ring, int ring_frames, long first_frame, int nframes,
+                                     int bins, int channels, int width, float* __restrict__ scroll) {
+    const long t = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    const long per_frame = (long)bins*width*channels;
+    if (t >= per_frame*nframes) return;
+    const long f = t / per_frame; long r = t % per_frame;
+    const int bin = (int)(r / ((long)width*channels)); r %= (long)width*channels;
+    const int col = (int)(r / channels), ch = (int)(r % channels);
+    const long k = first_frame + f;
+    const long age = (((k + 1 - col) % width) + width) % width;          // frames since column `col` was written
+    const long writer = k - age;
+    scroll[t] = (writer >= 0) ? ring[((writer % ring_frames)*bins + bin)*channels + ch] : 0.0f;
+}
+
+// Scalar float64 systems alone (volume, std, the camera's nine systems — dynamics.py:197-250 with python floats): one thread per
+// system walks the frames; out[frame][system] = {value, integral, derivative}.
+__global__ void k_dynamics_scan_f64(int nframes, int nsystems, const double* __restrict__ targets /* [frame][system] */,
+                                    const DynCoeffF64* __restrict__ coeff /* [system][frame] */, double precision, int integrate,
+                                    ScalarState* __restrict__ state, double* __restrict__ out) {
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= nsystems) return;
+    ScalarState s = state[k];
+    for (int f = 0; f < nframes; f++) {
+        scalar_step(s, targets[(long)f*nsystems + k], coeff[(long)k*nframes + f], precision, integrate);
+        double* o = out + ((long)f*nsystems + k)*3;
+        o[0] = s.value; o[1] = s.integral; o[2] = s.derivative;
+    }
+    state[k] = s;
 }
 
 }  // namespace sf

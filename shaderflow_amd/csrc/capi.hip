@@ -6,6 +6,7 @@
 
 #include "audio_kernels.hpp"
 #include "visualizer_kernels.hpp"
+#include "visualizer_fast.hpp"
 #include "uniform_table.hpp"
 
 #include <atomic>
@@ -28,6 +29,7 @@ using namespace sf;
 // Errors and handles
 
 static thread_local std::string g_error;
+static thread_local std::string g_last_kernel;   // which render kernel instance the last launch on this thread picked (sfx_last_kernel)
 
 static int fail(int code, const char* fmt, ...) {
     char buf[1024];
@@ -38,7 +40,9 @@ static int fail(int code, const char* fmt, ...) {
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(SFX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
 extern "C" const char* sfx_last_error(void) { return g_error.c_str(); }
-extern "C" const char* sfx_version(void) { return "shaderflow_hip 0.1 (gfx950)"; }
+extern "C" const char* sfx_version(void) { return "shaderflow_hip 0.2 (gfx950)"; }
+// (defined after the kernel headers) fingerprint of the kernel-argument layout this library was built with
+extern "C" uint64_t sfx_abi_layout(void);
 
 enum : uint32_t { MAGIC_CTX = 0x53465843, MAGIC_TEX = 0x53465854, MAGIC_PROG = 0x53465850, MAGIC_RING = 0x53465852,
                   MAGIC_AUDIO = 0x53465841, MAGIC_PLAN = 0x5346584c, MAGIC_TAPE = 0x53465854 + 0x100 };
@@ -60,7 +64,11 @@ struct Context : Object {
     float tap_x[81], tap_y[81];
     std::vector<struct Program*> programs;   // live programs of this context (their sampler slots point at textures)
     int top_down = 0;                // frames leave with rows top-down (sfx_ctx_output_top_down)
+    // per-frame column/row tables of the fast visualizer kernel (visualizer_fast.hpp), grown on demand
+    void* vis_tables = nullptr; size_t vis_tables_bytes = 0;
+    float* vis_bars = nullptr; size_t vis_bars_count = 0;          // sqrt(texel/1000) of a bound spectrogram (single launches)
 };
+static thread_local Context* g_launch_ctx = nullptr;               // the context whose program is being launched (scratch owner)
 
 struct Texture : Object {
     Context* ctx;
@@ -156,6 +164,7 @@ extern "C" int sfx_ctx_destroy(sfx_handle h) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (auto& e : c->events) hipEventDestroy(e);
+    hipFree(c->vis_tables); hipFree(c->vis_bars);
     if (c->own_stream) hipStreamDestroy(c->stream);
     c->magic = 0;
     delete c;
@@ -379,6 +388,8 @@ extern "C" int sfx_program_lookup(sfx_handle h, const char* source, sfx_handle* 
 // A fragment translated and compiled by the host (shaderflow_amd/glsl2hip.py → hipcc --genco) — what `opengl.program(vs, fs)`
 // (shader.py:324) is for fragments outside the registry. The code object exports the kernels of csrc/jit_runtime.hpp
 // (SF_JIT_ENTRY_POINTS) and the size of the RenderArgs it was compiled against.
+extern "C" uint64_t sfx_abi_layout(void) { return render_args_layout(); }
+
 extern "C" int sfx_program_load(sfx_handle h, const void* code_object, size_t nbytes, const sfx_binding* bindings, int nbindings, sfx_handle* out) {
     CTX_OR_FAIL(c, h);
     if (!code_object || !nbytes || !out || (nbindings > 0 && !bindings)) return fail(SFX_E_INVALID, "null code object, bindings or output");
@@ -395,12 +406,13 @@ extern "C" int sfx_program_load(sfx_handle h, const void* code_object, size_t nb
     if ((e = hipModuleGetFunction(&p->fn_render, p->module, "sfx_jit_render")) != hipSuccess) return bail(SFX_E_INVALID, "code object has no sfx_jit_render", e);
     for (int k = 0; k < 3; k++)
         if ((e = hipModuleGetFunction(&p->fn_fused[k], p->module, fused_names[k])) != hipSuccess) return bail(SFX_E_INVALID, "code object lacks a fused entry point", e);
-    hipDeviceptr_t layout = nullptr; size_t layout_bytes = 0; unsigned compiled_size = 0;
+    hipDeviceptr_t layout = nullptr; size_t layout_bytes = 0; unsigned long long compiled_layout = 0;
     if ((e = hipModuleGetGlobal(&layout, &layout_bytes, p->module, "sfx_jit_layout")) != hipSuccess) return bail(SFX_E_INVALID, "code object has no sfx_jit_layout", e);
-    if ((e = hipMemcpy(&compiled_size, layout, sizeof compiled_size, hipMemcpyDeviceToHost)) != hipSuccess) return bail(SFX_E_HIP, "reading sfx_jit_layout", e);
-    if (compiled_size != sizeof(RenderArgs)) {
+    if (layout_bytes != sizeof compiled_layout) { hipModuleUnload(p->module); delete p; return fail(SFX_E_INVALID, "code object predates the layout fingerprint (sfx_jit_layout is %zu bytes): recompile the fragment", layout_bytes); }
+    if ((e = hipMemcpy(&compiled_layout, layout, sizeof compiled_layout, hipMemcpyDeviceToHost)) != hipSuccess) return bail(SFX_E_HIP, "reading sfx_jit_layout", e);
+    if (compiled_layout != render_args_layout()) {
         hipModuleUnload(p->module); delete p;
-        return fail(SFX_E_INVALID, "code object was compiled against another version of the kernel headers (RenderArgs %u bytes, library %zu)", compiled_size, sizeof(RenderArgs));
+        return fail(SFX_E_INVALID, "code object was compiled against another version or build of the kernel headers (argument layout %016llx, library %016llx)", compiled_layout, render_args_layout());
     }
     if (hipModuleGetGlobal(&layout, &layout_bytes, p->module, "sfx_jit_flags") == hipSuccess) {
         if ((e = hipMemcpy(&p->flags, layout, sizeof p->flags, hipMemcpyDeviceToHost)) != hipSuccess) return bail(SFX_E_HIP, "reading sfx_jit_flags", e);
@@ -573,7 +585,20 @@ static int check_samplers(int fragment, const RenderArgs& a) {
     return rc;
 }
 
+// "k_render<…>" / "k_render_resolve<…, S>" of the instance a launch picked, from the compiler's spelling of the enclosing template
+static void note_kernel(const char* pretty, const char* kernel, int ssaa = 0) {
+    std::string text(pretty);
+    const size_t at = text.find("SHADER = ");
+    std::string shader = at == std::string::npos ? text : text.substr(at + 9);
+    const size_t end = shader.find_first_of(";]");
+    if (end != std::string::npos) shader.resize(end);
+    for (size_t k; (k = shader.find("sf::")) != std::string::npos; ) shader.erase(k, 4);
+    g_last_kernel = std::string(kernel) + "<" + shader + (ssaa ? ", " + std::to_string(ssaa) : std::string()) + ">";
+}
+extern "C" const char* sfx_last_kernel(void) { return g_last_kernel.c_str(); }
+
 template <class SHADER> static void launch_render_t(const RenderArgs& a, int frames, hipStream_t s, size_t dynamic_lds = 0) {
+    note_kernel(__PRETTY_FUNCTION__, "k_render");
     dim3 grid((a.wr + SHADER::BLOCK_W - 1)/SHADER::BLOCK_W, (a.hr + SHADER::BLOCK_H - 1)/SHADER::BLOCK_H, frames), block(SHADER::BLOCK_W, SHADER::BLOCK_H, 1);
     if (dynamic_lds > 48*1024) hipFuncSetAttribute((const void*)k_render<SHADER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_lds);
     hipLaunchKernelGGL(k_render<SHADER>, grid, block, dynamic_lds, s, a);
@@ -670,6 +695,7 @@ static int launch_render(int fragment, const RenderArgs& a, int frames, hipStrea
 #endif
 
 template <class SHADER, int S> static void launch_fused_k(const RenderArgs& a, dim3 grid, dim3 block, size_t dynamic_lds, hipStream_t s) {
+    note_kernel(__PRETTY_FUNCTION__, "k_render_resolve", S);
     if (dynamic_lds > 48*1024) hipFuncSetAttribute((const void*)k_render_resolve<SHADER, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_lds);
     hipLaunchKernelGGL((k_render_resolve<SHADER, S>), grid, block, dynamic_lds, s, a);
 }
@@ -683,6 +709,67 @@ template <class SHADER> static int launch_fused_s(const RenderArgs& a, int ssaa,
     else if (ssaa == 4) launch_fused_k<SHADER, 4>(a, dim3(blocks_x*row_blocks, 1, frames), dim3(threads), dynamic_lds, s);
     else return fail(SFX_E_UNSUPPORTED, "fused ssaa %d", ssaa);
     return SFX_OK;
+}
+
+// ---- the fast visualizer path (visualizer_fast.hpp) -----------------------------------------------------------------------
+// Identity camera, unorm8 bilinear background, 2x SSAA, the window of a 128-pixel block inside the fixed tile, and a blur whose
+// axis lines fit their slots at the largest radius the launch can see. Returns 1 when it launched, 0 when the configuration is
+// not its own (the caller then takes VisualizerShader), < 0 on errors.
+#ifndef VIS_FAST
+#define VIS_FAST 1
+#endif
+#ifndef VIS_FAST_PITCH
+#define VIS_FAST_PITCH 80
+#endif
+static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hipStream_t s) {
+    constexpr int PITCH = VIS_FAST_PITCH, ROWS = 10, BLOCK_PX = 128;
+    Context* ctx = g_launch_ctx;
+    if (!VIS_FAST || !ctx || ssaa != 2 || !a0.identity_camera || !visualizer_tile_applicable(a0.tex[TEX_BACKGROUND])) return 0;
+    if (getenv("SHADERFLOW_VIS_FAST") && atoi(getenv("SHADERFLOW_VIS_FAST")) == 0) return 0;      // A/B switch for measurements
+    const Tex& bg = a0.tex[TEX_BACKGROUND];
+    const Tex& sp = a0.tex[TEX_SPECTROGRAM];
+    RenderArgs a = a0;
+    if (!a.tape_bars) {
+        // a bound one-column RG32F spectrogram: the bar heights per texel into the context's scratch (k_visualizer_bars)
+        if (a.dyn || a.tape_spectrogram || !sp.data || sp.dtype != DT_F32 || sp.components != 2 || sp.width != 1 || sp.filter != FILTER_NEAREST) return 0;
+        const size_t count = (size_t)sp.height*2;
+        if (ctx->vis_bars_count < count) {
+            hipStreamSynchronize(s);
+            hipFree(ctx->vis_bars); ctx->vis_bars = nullptr; ctx->vis_bars_count = 0;
+            if (hipMalloc(&ctx->vis_bars, sizeof(float)*count) != hipSuccess) return fail(SFX_E_HIP, "visualizer bar table: out of device memory");
+            ctx->vis_bars_count = count;
+        }
+        hipLaunchKernelGGL(k_visualizer_bars, dim3((unsigned)((count + 255)/256)), dim3(256), 0, s, (const float*)sp.data, (long)count, ctx->vis_bars);
+        a.tape_bars = ctx->vis_bars; a.spectrogram_stride = 0;
+    } else if (sp.width != 1 || sp.components != 2) return 0;
+    // window and line bounds at the largest blur radius of the launch (visualizer_window_bound's conventions)
+    int tw = 0, th = 0;
+    visualizer_window_bound(a, BLOCK_PX*2, 2, tw, th);
+    const float intensity = a.has_vis ? fabsf(a.vis.intensity) : 0.003f;
+    const float ax = intensity*a.bg_scale_x*(float)bg.width;
+    const float reach_line = (fabsf(a.tap_x[0]) + 9.0f*fabsf(a.tap_x[1] - a.tap_x[0]))*ax;
+    if (tw > PITCH || th > ROWS || !(2.0f*reach_line + 1.0e-3f < (float)(VIS_LINE_CELLS - 1))) return 0;
+
+    VisTables t;
+    t.blocks_x = (a.w + BLOCK_PX - 1)/BLOCK_PX; t.blocks_y = a.h;
+    t.block_columns = BLOCK_PX*2; t.block_rows = 2; t.tile_pitch = PITCH; t.tile_rows = ROWS;
+    const size_t entries = (size_t)frames*((size_t)a.wr + a.hr)*VIS_ENTRY_QUADS*sizeof(float4);
+    const size_t blocks = (size_t)frames*((size_t)t.blocks_x + t.blocks_y)*sizeof(int4);
+    if (ctx->vis_tables_bytes < entries + blocks) {
+        hipStreamSynchronize(s);
+        hipFree(ctx->vis_tables); ctx->vis_tables = nullptr; ctx->vis_tables_bytes = 0;
+        if (hipMalloc(&ctx->vis_tables, entries + blocks) != hipSuccess) return fail(SFX_E_HIP, "visualizer tables of %d frames: out of device memory", frames);
+        ctx->vis_tables_bytes = entries + blocks;
+    }
+    t.columns = (float4*)ctx->vis_tables;
+    t.rows = t.columns + (size_t)frames*a.wr*VIS_ENTRY_QUADS;
+    t.block_x = (int4*)(t.rows + (size_t)frames*a.hr*VIS_ENTRY_QUADS);
+    t.block_y = t.block_x + (size_t)frames*t.blocks_x;
+    hipLaunchKernelGGL(k_visualizer_axis<0>, dim3((a.wr + 127)/128, frames), dim3(128), 0, s, a, t);
+    hipLaunchKernelGGL(k_visualizer_axis<1>, dim3((a.hr + 127)/128, frames), dim3(128), 0, s, a, t);
+    g_last_kernel = "k_visualizer_fast<" + std::to_string(PITCH) + ", " + std::to_string(ROWS) + ", " + std::to_string(BLOCK_PX) + ", 8>";
+    hipLaunchKernelGGL((k_visualizer_fast<PITCH, ROWS, BLOCK_PX, 8>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(4*BLOCK_PX), 0, s, a, t);
+    return 1;
 }
 
 #ifdef SF_SECTION_TIMERS
@@ -721,6 +808,10 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
         case FRAG_DEFAULT: return launch_fused_s<PlainShader<FRAG_DEFAULT>>(a, ssaa, frames, s);
         case FRAG_MISSING: return launch_fused_s<PlainShader<FRAG_MISSING>>(a, ssaa, frames, s);
         case FRAG_VISUALIZER:
+            if (!force_generic) {
+                const int fast = launch_visualizer_fast(a, ssaa, frames, s);
+                if (fast != 0) return fast < 0 ? fast : SFX_OK;
+            }
             if (!force_generic && visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) {
                 // the block shades 128*ssaa x rows*ssaa samples (S == 1: 128 x 2 pixels); pick the fixed tile when its window fits
                 int tw = 0, th = 0;
@@ -800,6 +891,7 @@ static int launch_render_p(const Program* p, const RenderArgs& a, int frames, hi
     return launch_jit(p->fn_render, a, dim3((a.wr + P::BLOCK_W - 1)/P::BLOCK_W, (a.hr + P::BLOCK_H - 1)/P::BLOCK_H, frames), dim3(P::BLOCK_W, P::BLOCK_H, 1), s);
 }
 static int launch_fused_p(const Program* p, const RenderArgs& a, int ssaa, int frames, hipStream_t s) {
+    g_launch_ctx = p->ctx;
     if (p->fragment != FRAG_JIT) return launch_fused(p->fragment, a, ssaa, frames, s);
     using P = PlainShader<FRAG_DEFAULT>;
     if (ssaa == 1) return launch_jit(p->fn_fused[0], a, dim3(((a.w + 127)/128)*((a.h + 1)/2), 1, frames), dim3(256), s);
@@ -1083,6 +1175,7 @@ extern "C" int sfx_audio_destroy(sfx_handle h) {
 struct Plan : Object {
     Context* ctx;
     int fft_n, window, bins, channels, fft_bins, nnz;
+    int amplitude = 0;               // FourierMagnitude: 0 Power, 1 Amplitude (spectrogram.py:20-26)
     double* d_window = nullptr; double2* d_twiddle = nullptr;
     int *d_indptr = nullptr, *d_indices = nullptr; float* d_data = nullptr;
     float* d_dense = nullptr; int2* d_band = nullptr; int k_pad = 0, row_tiles = 0;
@@ -1161,6 +1254,14 @@ extern "C" int sfx_stft_plan(sfx_handle h, int fft_n, int window, int bins, int 
     return SFX_OK;
 }
 
+extern "C" int sfx_stft_plan_magnitude(sfx_handle h, int magnitude) {
+    Plan* p = get<Plan>(h, MAGIC_PLAN);
+    if (!p) return fail(SFX_E_INVALID, "invalid plan handle");
+    if (magnitude != SFX_MAGNITUDE_POWER && magnitude != SFX_MAGNITUDE_AMPLITUDE) return fail(SFX_E_INVALID, "magnitude %d", magnitude);
+    p->amplitude = (magnitude == SFX_MAGNITUDE_AMPLITUDE);
+    return SFX_OK;
+}
+
 extern "C" int sfx_stft_plan_destroy(sfx_handle h) {
     Plan* p = get<Plan>(h, MAGIC_PLAN);
     if (!p) return fail(SFX_E_INVALID, "invalid plan handle");
@@ -1184,7 +1285,7 @@ static int check_audio(const Plan* p, const Audio* a) {
 static void launch_stft(const Plan* p, const Audio* a, const long* d_tell, int frames, float* d_power, hipStream_t s) {
     const int N = 1 << p->fft_n;
     hipLaunchKernelGGL(k_stft_power, dim3(frames, p->channels), dim3(256), (N/2)*sizeof(double2), s,
-                       a->pcm, a->samples, d_tell, p->fft_n, p->d_window, p->d_twiddle, d_power);
+                       a->pcm, a->samples, d_tell, p->fft_n, p->d_window, p->d_twiddle, d_power, p->amplitude);
 }
 static void launch_filterbank(const Plan* p, int frames, int use_mfma, const float* d_power, float* d_out, hipStream_t s) {
     const int ncols = frames*p->channels;
@@ -1265,6 +1366,65 @@ extern "C" int sfx_volume_std(sfx_handle ha, const int64_t* tell, int nframes, i
     return rc;
 }
 
+// DynamicNumber.next over a run of frames, on its own (SURVEY.md §8b last row; dynamics.py:197-250). Host arrays in and out.
+extern "C" int sfx_dynamics_scan(sfx_handle h, int nframes, int n, const float* targets, const sfx_dyn_coeff_f32* coeff,
+                                 float precision, float* state, float* values) {
+    CTX_OR_FAIL(c, h);
+    if (nframes < 1 || n < 1 || !targets || !coeff || !state || !values) return fail(SFX_E_INVALID, "dynamics scan: null array or nothing to do");
+    if (n > 2048) return fail(SFX_E_UNSUPPORTED, "dynamics scan handles up to 2048 values per system, got %d", n);
+    USE_DEVICE(c);
+    hipStream_t s = c->stream;
+    float *d_targets = nullptr, *d_state = nullptr, *d_values = nullptr; DynCoeffF32* d_coeff = nullptr;
+    const size_t frame_bytes = sizeof(float)*(size_t)nframes*n;
+    const bool ok = hipMalloc(&d_targets, frame_bytes) == hipSuccess && hipMalloc(&d_values, frame_bytes) == hipSuccess &&
+                    hipMalloc(&d_state, sizeof(float)*3*n) == hipSuccess && hipMalloc(&d_coeff, sizeof(DynCoeffF32)*nframes) == hipSuccess;
+    int rc = ok ? SFX_OK : fail(SFX_E_HIP, "dynamics scan of %d frames x %d values: out of device memory", nframes, n);
+    if (!rc) {
+        hipMemcpyAsync(d_targets, targets, frame_bytes, hipMemcpyHostToDevice, s);
+        hipMemcpyAsync(d_state, state, sizeof(float)*3*n, hipMemcpyHostToDevice, s);
+        hipMemcpyAsync(d_coeff, coeff, sizeof(DynCoeffF32)*nframes, hipMemcpyHostToDevice, s);
+        hipLaunchKernelGGL(k_dynamics_scan, dim3(1), dim3(1024), 0, s, nframes, n, d_targets, d_coeff, precision, d_state, d_values,
+                           (const float*)nullptr, (const DynCoeffF64*)nullptr, (const DynCoeffF64*)nullptr, 0.0, 0, 0,
+                           (ScalarState*)nullptr, (const FrameClock*)nullptr, (FrameDyn*)nullptr);
+        rc = launch_status();
+    }
+    if (!rc) {
+        hipMemcpyAsync(values, d_values, frame_bytes, hipMemcpyDeviceToHost, s);
+        hipMemcpyAsync(state, d_state, sizeof(float)*3*n, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) rc = fail(SFX_E_HIP, "dynamics scan: stream synchronisation failed");
+    }
+    hipFree(d_targets); hipFree(d_values); hipFree(d_state); hipFree(d_coeff);
+    return rc;
+}
+
+extern "C" int sfx_dynamics_scan_f64(sfx_handle h, int nframes, int nsystems, const double* targets, const sfx_dyn_coeff_f64* coeff,
+                                     double precision, int integrate, double* state, double* out) {
+    CTX_OR_FAIL(c, h);
+    if (nframes < 1 || nsystems < 1 || !targets || !coeff || !state || !out) return fail(SFX_E_INVALID, "dynamics scan: null array or nothing to do");
+    static_assert(sizeof(ScalarState) == 4*sizeof(double), "state = value, derivative, previous, integral");
+    USE_DEVICE(c);
+    hipStream_t s = c->stream;
+    double *d_targets = nullptr, *d_out = nullptr; ScalarState* d_state = nullptr; DynCoeffF64* d_coeff = nullptr;
+    const size_t count = (size_t)nframes*nsystems;
+    const bool ok = hipMalloc(&d_targets, sizeof(double)*count) == hipSuccess && hipMalloc(&d_out, sizeof(double)*3*count) == hipSuccess &&
+                    hipMalloc(&d_state, sizeof(ScalarState)*nsystems) == hipSuccess && hipMalloc(&d_coeff, sizeof(DynCoeffF64)*count) == hipSuccess;
+    int rc = ok ? SFX_OK : fail(SFX_E_HIP, "dynamics scan of %d frames x %d systems: out of device memory", nframes, nsystems);
+    if (!rc) {
+        hipMemcpyAsync(d_targets, targets, sizeof(double)*count, hipMemcpyHostToDevice, s);
+        hipMemcpyAsync(d_state, state, sizeof(ScalarState)*nsystems, hipMemcpyHostToDevice, s);
+        hipMemcpyAsync(d_coeff, coeff, sizeof(DynCoeffF64)*count, hipMemcpyHostToDevice, s);
+        hipLaunchKernelGGL(k_dynamics_scan_f64, dim3((nsystems + 63)/64), dim3(64), 0, s, nframes, nsystems, d_targets, d_coeff, precision, integrate, d_state, d_out);
+        rc = launch_status();
+    }
+    if (!rc) {
+        hipMemcpyAsync(out, d_out, sizeof(double)*3*count, hipMemcpyDeviceToHost, s);
+        hipMemcpyAsync(state, d_state, sizeof(ScalarState)*nsystems, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) rc = fail(SFX_E_HIP, "dynamics scan: stream synchronisation failed");
+    }
+    hipFree(d_targets); hipFree(d_out); hipFree(d_state); hipFree(d_coeff);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Tape
 
@@ -1278,6 +1438,9 @@ struct Tape : Object {
     VisualizerConsts* d_vis;
     float* d_bars = nullptr;         // sqrt(column/1000) of every frame of the batch (visualizer.frag:45)
     void* d_screen = nullptr; size_t screen_bytes = 0;   // iScreen scratch of the two-pass path (frames of a batch)
+    // scrolling spectrogram (length_samples > 1, spectrogram.py:298-311): ring of the last columns, per-frame texture states
+    int width = 1, ring_frames = 0; long frames_done = 0;
+    float* d_ring = nullptr; float* d_scroll = nullptr;
 };
 
 extern "C" int sfx_tape_reset(sfx_handle h) {
@@ -1287,6 +1450,7 @@ extern "C" int sfx_tape_reset(sfx_handle h) {
     USE_DEVICE(t->ctx);
     HIP_TRY(hipMemsetAsync(t->d_state, 0, sizeof(float)*3*t->n, t->ctx->stream));
     HIP_TRY(hipMemsetAsync(t->d_scalars, 0, sizeof(ScalarState)*2, t->ctx->stream));
+    t->frames_done = 0;                                             // the scrolling texture starts empty again
     return SFX_OK;
 }
 
@@ -1339,7 +1503,14 @@ extern "C" int sfx_tape_create(sfx_handle hp, sfx_handle ha, const sfx_tape_desc
         hipMalloc(&t->d_clock, sizeof(FrameClock)*F) == hipSuccess &&
         hipMalloc(&t->d_vis, sizeof(VisualizerConsts)*F) == hipSuccess &&
         hipMalloc(&t->d_bars, sizeof(float)*F*t->n) == hipSuccess;
-    if (!allocated) {
+    t->width = desc->length_samples > 1 ? desc->length_samples : 1;
+    bool scroll_ok = true;
+    if (allocated && t->width > 1) {
+        t->ring_frames = t->width + max_frames;
+        scroll_ok = hipMalloc(&t->d_ring, sizeof(float)*(size_t)t->ring_frames*t->n) == hipSuccess &&
+                    hipMalloc(&t->d_scroll, sizeof(float)*F*t->n*t->width) == hipSuccess;
+    }
+    if (!allocated || !scroll_ok) {
         sfx_tape_destroy(handle_of(t));                             // frees what was allocated (hipFree(nullptr) is a no-op)
         return fail(SFX_E_HIP, "tape of %d frames: out of device memory", max_frames);
     }
@@ -1383,6 +1554,14 @@ extern "C" int sfx_tape_build(sfx_handle h, int nframes, const int64_t* tell, co
     hipLaunchKernelGGL(k_dynamics_scan, dim3(1), dim3(1024), 0, s, nframes, t->n, t->d_targets, t->d_coeff, (float)t->desc.precision,
                        t->d_state, t->d_columns, t->d_loudness, t->d_vol, t->d_std, t->desc.precision,
                        t->desc.volume_integrate, t->desc.std_integrate, t->d_scalars, t->d_clock, t->d_dyn);
+    if (t->width > 1) {
+        const long count = (long)nframes*t->n;
+        hipLaunchKernelGGL(k_spectrogram_ring_store, dim3((unsigned)((count + 255)/256)), dim3(256), 0, s, t->d_columns, nframes, t->n, t->frames_done, t->ring_frames, t->d_ring);
+        const long texels = count*t->width;
+        hipLaunchKernelGGL(k_spectrogram_scroll, dim3((unsigned)((texels + 255)/256)), dim3(256), 0, s, t->d_ring, t->ring_frames, t->frames_done, nframes,
+                           p->bins, p->channels, t->width, t->d_scroll);
+    }
+    t->frames_done += nframes;
     return launch_status();
 }
 
@@ -1414,7 +1593,7 @@ extern "C" int sfx_tape_destroy(sfx_handle h) {
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
     hipFree(t->d_tell); hipFree(t->d_power); hipFree(t->d_targets); hipFree(t->d_columns); hipFree(t->d_rows); hipFree(t->d_loudness);
-    hipFree(t->d_state); hipFree(t->d_scalars); hipFree(t->d_dyn); hipFree(t->d_coeff); hipFree(t->d_vol); hipFree(t->d_std); hipFree(t->d_clock); hipFree(t->d_vis); hipFree(t->d_bars); hipFree(t->d_screen);
+    hipFree(t->d_state); hipFree(t->d_scalars); hipFree(t->d_dyn); hipFree(t->d_coeff); hipFree(t->d_vol); hipFree(t->d_std); hipFree(t->d_clock); hipFree(t->d_vis); hipFree(t->d_bars); hipFree(t->d_screen); hipFree(t->d_ring); hipFree(t->d_scroll);
     t->magic = 0;
     delete t;
     return SFX_OK;
@@ -1442,13 +1621,16 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
     if (t->plan) {
     // iSpectrogram: width 1 (length=0 scenes), height bins, RG32F (spectrogram.py:298-311); the bound texture's
     // sampler state is kept, only its storage is redirected to the tape column of the frame
-    a.tape_spectrogram = t->d_columns; a.spectrogram_stride = t->n;
+    // (length > 0: the texture is `width` columns wide and every frame of the batch gets its own state of it, k_spectrogram_scroll)
+    const bool scrolling = (t->width > 1);
+    a.tape_spectrogram = scrolling ? t->d_scroll : t->d_columns; a.spectrogram_stride = (long)t->n*t->width;
     if (!a.tex[TEX_SPECTROGRAM].data) {
         Tex& s = a.tex[TEX_SPECTROGRAM];
-        s.width = 1; s.height = t->plan->bins; s.components = t->plan->channels; s.dtype = DT_F32; s.filter = FILTER_NEAREST; s.repeat_x = 1; s.repeat_y = 0;
+        s.width = t->width; s.height = t->plan->bins; s.components = t->plan->channels; s.dtype = DT_F32; s.filter = FILTER_NEAREST; s.repeat_x = 1; s.repeat_y = 0;
     }
-    if (a.tex[TEX_SPECTROGRAM].width != 1 || a.tex[TEX_SPECTROGRAM].height != t->plan->bins || a.tex[TEX_SPECTROGRAM].components != t->plan->channels)
-        return fail(SFX_E_UNSUPPORTED, "tape rendering supports a 1-column iSpectrogram (length=0); use the per-frame path for scrolling spectrograms");
+    if (a.tex[TEX_SPECTROGRAM].width != t->width || a.tex[TEX_SPECTROGRAM].height != t->plan->bins || a.tex[TEX_SPECTROGRAM].components != t->plan->channels)
+        return fail(SFX_E_INVALID, "the bound iSpectrogram is %d x %d x %d, the tape was created for %d x %d x %d (length_samples x bins x channels)",
+                    a.tex[TEX_SPECTROGRAM].width, a.tex[TEX_SPECTROGRAM].height, a.tex[TEX_SPECTROGRAM].components, t->width, t->plan->bins, t->plan->channels);
     if (t->desc.points > 0) {
         a.tape_waveform = t->d_rows; a.waveform_stride = (long)t->desc.points*t->audio->channels;
         if (!a.tex[TEX_WAVEFORM].data) {
@@ -1457,7 +1639,7 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
         }
     }
     // placeholders so that texel() sees a non-null base before frame_view() redirects it
-    a.tex[TEX_SPECTROGRAM].data = t->d_columns;
+    a.tex[TEX_SPECTROGRAM].data = a.tape_spectrogram;
     if (t->desc.points > 0) a.tex[TEX_WAVEFORM].data = t->d_rows;
     }
     int rc = check_samplers(p->fragment, a);
@@ -1466,7 +1648,7 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
     if (p->fragment == FRAG_VISUALIZER) {
         hipLaunchKernelGGL(k_visualizer_consts, dim3((nframes + 63)/64), dim3(64), 0, p->ctx->stream, t->d_dyn, frame0, nframes, t->d_vis);
         a.vis_consts = t->d_vis;
-        if (t->plan && a.tex[TEX_SPECTROGRAM].components == 2 && a.tex[TEX_SPECTROGRAM].filter == FILTER_NEAREST) {
+        if (t->plan && t->width == 1 && a.tex[TEX_SPECTROGRAM].components == 2 && a.tex[TEX_SPECTROGRAM].filter == FILTER_NEAREST) {
             const long count = (long)nframes*t->n;
             hipLaunchKernelGGL(k_visualizer_bars, dim3((unsigned)((count + 255)/256)), dim3(256), 0, p->ctx->stream,
                                t->d_columns + (long)frame0*t->n, count, t->d_bars + (long)frame0*t->n);

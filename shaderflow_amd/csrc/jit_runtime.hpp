@@ -815,7 +815,7 @@ inline void sfx_jit_host_texture(sf::Tex* textures, int slot, const void* data, 
 // a pixel already are the four lanes of a quad (all valid or all invalid together).
 #define SF_JIT_ENTRY_POINTS(FRAGMENT) \
     SF_JIT_HOST_POINTS(FRAGMENT) \
-    extern "C" __device__ __attribute__((used)) const unsigned sfx_jit_layout = (unsigned)sizeof(sf::RenderArgs); \
+    extern "C" __device__ __attribute__((used)) const unsigned long long sfx_jit_layout = sf::render_args_layout(); \
     extern "C" __device__ __attribute__((used)) const unsigned sfx_jit_flags = (SF_JIT_DERIVATIVES ? 1u : 0u); \
     extern "C" __global__ __launch_bounds__(256) void sfx_jit_render(const sf::RenderArgs a) { sf::render_body<sf::JitShader<FRAGMENT, (SF_JIT_DERIVATIVES != 0)>>(a); } \
     extern "C" __global__ __launch_bounds__(256) void sfx_jit_fused_1(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT>, 1>(a); } \

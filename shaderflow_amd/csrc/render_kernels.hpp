@@ -50,6 +50,31 @@ struct RenderArgs {
 #endif
 };
 
+// Fingerprint of the kernel-argument layout: the offsets of RenderArgs' members and the sizes of the blocks inside it, plus the
+// build switches that change it. The library exports it (sfx_abi_layout) and every code object of a translated fragment carries
+// the value it was compiled with (sfx_jit_layout): a same-size change — two members swapped — is refused at load time too.
+constexpr unsigned long long layout_mix(unsigned long long h, unsigned long long v) { return (h ^ v)*1099511628211ull; }
+constexpr unsigned long long render_args_layout() {
+    unsigned long long h = 1469598103934665603ull;
+#define SF_LAYOUT_MEMBER(m) h = layout_mix(h, (unsigned long long)__builtin_offsetof(RenderArgs, m))
+    SF_LAYOUT_MEMBER(u); SF_LAYOUT_MEMBER(tex); SF_LAYOUT_MEMBER(wr); SF_LAYOUT_MEMBER(hr); SF_LAYOUT_MEMBER(w); SF_LAYOUT_MEMBER(h);
+    SF_LAYOUT_MEMBER(subsample); SF_LAYOUT_MEMBER(out_components); SF_LAYOUT_MEMBER(out_dtype); SF_LAYOUT_MEMBER(out);
+    SF_LAYOUT_MEMBER(out_frame_stride); SF_LAYOUT_MEMBER(dyn); SF_LAYOUT_MEMBER(tape_spectrogram); SF_LAYOUT_MEMBER(spectrogram_stride);
+    SF_LAYOUT_MEMBER(tape_bars); SF_LAYOUT_MEMBER(tape_waveform); SF_LAYOUT_MEMBER(waveform_stride); SF_LAYOUT_MEMBER(frame0);
+    SF_LAYOUT_MEMBER(tap_x); SF_LAYOUT_MEMBER(tap_y); SF_LAYOUT_MEMBER(vis_consts); SF_LAYOUT_MEMBER(vis); SF_LAYOUT_MEMBER(has_vis);
+    SF_LAYOUT_MEMBER(identity_camera); SF_LAYOUT_MEMBER(aspect); SF_LAYOUT_MEMBER(bg_scale_x); SF_LAYOUT_MEMBER(tile_pitch);
+    SF_LAYOUT_MEMBER(tile_rows); SF_LAYOUT_MEMBER(top_down); SF_LAYOUT_MEMBER(inv_wr); SF_LAYOUT_MEMBER(inv_hr);
+#undef SF_LAYOUT_MEMBER
+    h = layout_mix(h, sizeof(RenderArgs)); h = layout_mix(h, sizeof(Uniforms)); h = layout_mix(h, sizeof(Tex));
+    h = layout_mix(h, sizeof(FrameDyn)); h = layout_mix(h, sizeof(VisualizerConsts));
+    h = layout_mix(h, (unsigned long long)__builtin_offsetof(Uniforms, user)); h = layout_mix(h, (unsigned long long)__builtin_offsetof(Uniforms, iAudioVolume));
+    h = layout_mix(h, TEX_SLOTS); h = layout_mix(h, USER_SLOTS);
+#ifdef SF_SECTION_TIMERS
+    h = layout_mix(h, 0x74696d657273ull);
+#endif
+    return h;
+}
+
 // Section timers of profiling builds: every wave adds the shader-clock cycles it spent since its previous mark to
 // timers[section]; compiled out otherwise.
 #ifdef SF_SECTION_TIMERS

@@ -1,0 +1,358 @@
+// visualizer_fast.hpp — visualizer.frag (examples/basic/shaders/visualizer.frag:6-74) under the freshly built camera, with
+// everything that depends on the sample COLUMN only or on the sample ROW only evaluated once per frame instead of once per
+// supersample (k_visualizer_axis → per-frame tables in HBM, L2-resident), and the fused fragment + resolve kernel reduced to
+// what really is two-dimensional: the diagonal blur taps, the polar bar lookup and the final colour arithmetic.
+//
+// Under the identity camera (glsl.hpp camera_is_identity) iCamera.gluv == gluv, so for a W x H sample grid
+//   * gluv.x, agluv.x, astuv.x, the background coordinate of the centre tap, the waveform tap texture(iWaveform, (astuv.x, 0)),
+//     the vignette factor of x and `|gluv.x| > iWantAspect` take W distinct values per frame,
+//   * gluv.y, …, `1 ∓ gluv.y` take H distinct values per frame,
+// against W*H = 33.2 M supersamples at 4K 2xSSAA. The tables hold, per column (row):
+//   q0 = { r, frac(r), byte offset of cell floor(r) inside the block's LDS tile, byte offset of the line's first cell }
+//   q1 = { rot_c*u | -rot_s*u (col) or rot_s*u | rot_c*u (row), u*u, agluv*agluv }     (u = gluv.x or gluv.y)
+//   q2 = { log2(astuv*(1-astuv)), waveform.x*0.2 | 1-gluv.y, waveform.y*0.2 | 1+gluv.y, out of bounds }
+//   q3..q6 = the AXIS LINE: the blur's taps along this axis (visualizer.frag:26-31, directions 0 and 180 degrees plus the
+//            centre tap for a row of texels, 90 and 270 degrees for a column) summed per texel cell in closed form — for each
+//            of the VIS_LINE_CELLS consecutive cells the line can touch: n = sum of tap weights, s = sum of weight*fraction.
+//            A run of taps inside one cell sums to n*A + s*B' + (n*f)*C' + (s*f)*D (visualizer_kernels.hpp one_run), so the
+//            20 + 1 taps of a line cost 8 cell fetches and 8*15 operations per supersample instead of 21 taps.
+// `r` = the centre tap in texel units RELATIVE to the window of background cells the sample's block stages in LDS, so the
+// tables are specific to the block geometry (BLOCK_COLUMNS x BLOCK_ROWS samples) they were built for.
+//
+// Bit-level contract: every term that decides a branch or a nearest-texel index — out of bounds, the polar angle and its bin,
+// the bar height, both lengths compared with it, the waveform strips — is the generic chain's sequence of operations (same
+// bits as fragments.hpp visualizer_post), merely evaluated where its inputs are known. Colour-only terms use the hardware's
+// log/exp/sqrt (1 ulp), as VisualizerShader does. The blur is VisualizerShader's (re-associated sums, <= 1e-6 relative).
+#pragma once
+
+#include "visualizer_kernels.hpp"
+
+namespace sf {
+
+constexpr int VIS_LINE_CELLS = 8;        // cells an axis line may touch: floor(2*radius) + 2 with radius <= 3.24 texels
+constexpr int VIS_ENTRY_QUADS = 7;       // float4s per table entry
+
+struct VisTables {
+    float4* columns;                     // [frame][wr][VIS_ENTRY_QUADS]
+    float4* rows;                        // [frame][hr][VIS_ENTRY_QUADS]
+    int4* block_x;                       // [frame][blocks_x] = { x0, tw, fits, 0 }: window of background cells of a block column
+    int4* block_y;                       // [frame][blocks_y] = { y0, th, fits, 0 }
+    int blocks_x, blocks_y;              // blocks per row / column of the sample grid
+    int block_columns, block_rows;       // samples per block along x / y
+    int tile_pitch, tile_rows;           // LDS tile the offsets are computed for (cells)
+};
+
+// One axis of the sample grid: thread k builds the entry of column (AXIS == 0) or row (AXIS == 1) k of frame blockIdx.y.
+template <int AXIS>
+__global__ __launch_bounds__(128) void k_visualizer_axis(const RenderArgs a, const VisTables t) {
+    const int k = blockIdx.x*128 + threadIdx.x;
+    const int n = AXIS == 0 ? a.wr : a.hr;
+    if (k >= n) return;
+    const int frame = blockIdx.y;
+    Uniforms u; Tex tex[TEX_HISTORY];
+    frame_view(a, frame, u, tex);
+    const VisualizerConsts c = a.vis_consts ? a.vis_consts[a.frame0 + frame] : (a.has_vis ? a.vis : visualizer_consts(u.iTime, u.iAudioVolume, u.iAudioSTD));
+    const Tex& bg = tex[TEX_BACKGROUND];
+    const float size = AXIS == 0 ? (float)bg.width : (float)bg.height;
+    const float scale = AXIS == 0 ? a.bg_scale_x : 1.0f;              // gtexture's (height/width, 1), shaderflow.glsl:166-167
+    const float aspect = AXIS == 0 ? a.aspect : 1.0f;                  // agluv2gluv, shaderflow.glsl:99
+    const float offset = AXIS == 0 ? c.off_x : c.off_y;
+
+    // vertex/default.glsl:1-17 and visualizer.frag:17-18 for ONE coordinate: the operations of make_varyings / visualizer_pre /
+    // VisualizerShader::pre in the same order
+    auto centre_tap = [&](int index, float& ag, float& g, float& as) {
+        const float centre = ((float)index + 0.5f)/(float)n;
+        ag = centre*2.0f - 1.0f;
+        g = ag*aspect;
+        as = (ag + 1.0f)/2.0f;
+        const float bgc = (((g + 1.0f)/2.0f) - 0.5f)*c.zoom2 + 0.5f + offset;        // zoom(gluv2stuv(uv), z, 0.5) + offset
+        const float st = ((((bgc*2.0f) - 1.0f)*scale) + 1.0f)/2.0f;                    // gluv2stuv(stuv2gluv(bg)*scale)
+        return st*size - 0.5f;
+    };
+    float ag, g, as;
+    const float centre = centre_tap(k, ag, g, as);
+
+    // the window of the block this column/row belongs to: VisualizerShader::setup 1a (two corner samples bound all of them)
+    const int per_block = AXIS == 0 ? t.block_columns : t.block_rows;
+    const int block = k / per_block;
+    const int first_index = block*per_block, last_index = min(first_index + per_block, n) - 1;
+    float dummy0, dummy1, dummy2;
+    const float c_first = centre_tap(first_index, dummy0, dummy1, dummy2), c_last = centre_tap(last_index, dummy0, dummy1, dummy2);
+    const float lo = fminf(c_first, c_last), hi = fmaxf(c_first, c_last);
+    const float texels = fabsf(c.intensity*scale*size);               // blur radius in texels (glsl.hpp gtexture)
+    const float reach = texels*1.101f + 0.001f;
+    const int limit = AXIS == 0 ? t.tile_pitch : t.tile_rows;
+    int origin = 0, extent = 0, fits = 0;
+    if ((c.intensity == c.intensity) && fabsf(lo) < 1e8f && fabsf(hi) < 1e8f && reach < 64.0f) {
+        origin = (int)floorf(lo - reach);
+        extent = (int)floorf(hi + reach) - origin + 1;
+        // the line's cells must exist in the staged window even when the music is silent
+        if (extent < VIS_LINE_CELLS) extent = VIS_LINE_CELLS;
+        fits = (extent <= limit) ? 1 : 0;
+    }
+    // the axis line: weights per texel cell, in tile-local coordinates
+    const float r = centre - (float)origin;
+    const float ax = c.intensity*a.bg_scale_x*(float)bg.width;        // texels per unit displacement, as VisualizerShader::blur_tile uses it for both axes
+    const float first = a.tap_x[0]*ax, step = (a.tap_x[1] - a.tap_x[0])*ax;
+    const float reach_line = fabsf(first) + 9.0f*fabsf(step);
+    // a line touches at most floor(2*reach) + 2 consecutive cells: a property of the frame, so every column and row of a block
+    // agrees on it and the block's flag needs no voting
+    if (!(2.0f*reach_line + 1.0e-3f < (float)(VIS_LINE_CELLS - 1))) fits = 0;
+    if (k == first_index) (AXIS == 0 ? t.block_x : t.block_y)[(long)frame*(AXIS == 0 ? t.blocks_x : t.blocks_y) + block] = make_int4(origin, extent, fits, 0);
+    const float cell_r = floorf(r), frac_r = r - cell_r;
+    // slot 0 of the line: the leftmost cell it can touch, pulled back so that all VIS_LINE_CELLS slots lie inside the window
+    int start = (int)floorf(r - reach_line);
+    start = max(0, min(start, extent - VIS_LINE_CELLS));
+    float wn[VIS_LINE_CELLS], ws[VIS_LINE_CELLS];
+#pragma unroll
+    for (int s = 0; s < VIS_LINE_CELLS; s++) { wn[s] = 0.0f; ws[s] = 0.0f; }
+    auto tap = [&](float position, float weight) {
+        const float cell = floorf(position);
+        const float fraction = position - cell;
+        const int slot = (int)cell - start;                           // 0 <= slot < VIS_LINE_CELLS whenever `fits`
+#pragma unroll
+        for (int s = 0; s < VIS_LINE_CELLS; s++)
+            if (s == slot) { wn[s] = wn[s] + weight; ws[s] = fmaf(weight, fraction, ws[s]); }
+    };
+    if (AXIS == 0) tap(r, 1.0f);                                      // the centre tap (visualizer.frag:19) rides on the row of texels
+    for (int j = 0; j < 10; j++) {
+        const float d = fmaf((float)j, step, first);
+        tap(r + d, AXIS == 0 ? 2.0f : 1.0f);                          // direction 0 is direction 8 as well (float loop counter, :26)
+        tap(r - d, 1.0f);
+    }
+
+    float4* e = (AXIS == 0 ? t.columns : t.rows) + ((long)frame*n + k)*VIS_ENTRY_QUADS;
+    const int cell_bytes = AXIS == 0 ? 48 : t.tile_pitch*48;
+    e[0] = make_float4(r, frac_r, __int_as_float((int)cell_r*cell_bytes), __int_as_float(start*cell_bytes));
+    if (AXIS == 0) {
+        // rotate2d(-PI/2)*uv (visualizer.frag:39): x' = rot_c*x + rot_s*y, y' = (-rot_s)*x + rot_c*y — the products of x
+        e[1] = make_float4(c.rot_c*g, (-c.rot_s)*g, g*g, ag*ag);
+        const Tex& wave = tex[TEX_WAVEFORM];
+        const vec2 w = texture_xy(wave, vec2{as, 0.0f});                                       // :71
+        e[2] = make_float4(__builtin_amdgcn_logf(as*(1.0f - as)), 0.2f*w.x, 0.2f*w.y, __int_as_float((sf::abs(g) > u.iWantAspect) ? 1 : 0));
+    } else {
+        e[1] = make_float4(c.rot_s*g, c.rot_c*g, g*g, ag*ag);
+        e[2] = make_float4(__builtin_amdgcn_logf(as*(1.0f - as)), 1.0f - g, 1.0f + g, 0.0f);   // :72-73 compare these with the waveform
+    }
+    e[3] = make_float4(wn[0], ws[0], wn[1], ws[1]);
+    e[4] = make_float4(wn[2], ws[2], wn[3], ws[3]);
+    e[5] = make_float4(wn[4], ws[4], wn[5], ws[5]);
+    e[6] = make_float4(wn[6], ws[6], wn[7], ws[7]);
+}
+
+// ---- the fused kernel ------------------------------------------------------------------------------------------------------
+// S == 2: a quad of lanes per output pixel, one supersample each (render_kernels.hpp render_resolve_body's layout and epilogue).
+template <int TILE_PITCH, int TILE_ROWS, int BLOCK_PX>
+struct VisualizerFast {
+    static constexpr int S = 2;
+    static constexpr int THREADS = 4*BLOCK_PX;
+    struct Shared {
+        float4 cells[TILE_ROWS*TILE_PITCH*3];
+        float4 row_entries[S][VIS_ENTRY_QUADS];
+        uint8_t staged[BLOCK_PX*3 + 16];
+    };
+
+    __device__ __forceinline__ static void cell_sum(const char* p, int offset, float wa, float wx, float wy, float wxy, float& r, float& g, float& b) {
+        const float4* q = (const float4*)(p + offset);
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+        r = fmaf(wa, q0.x, r);   g = fmaf(wa, q0.y, g);   b = fmaf(wa, q0.z, b);
+        r = fmaf(wx, q0.w, r);   g = fmaf(wx, q1.x, g);   b = fmaf(wx, q1.y, b);
+        r = fmaf(wy, q1.z, r);   g = fmaf(wy, q1.w, g);   b = fmaf(wy, q2.x, b);
+        r = fmaf(wxy, q2.y, r);  g = fmaf(wxy, q2.z, g);  b = fmaf(wxy, q2.w, b);
+    }
+
+    // The blur without the LDS window (a block whose window does not fit the tile, or a radius beyond the line slots — backgrounds
+    // much larger than the output): the 91 taps of visualizer.frag:19-31 as bilinear fetches from global memory, in the same texel
+    // coordinates and difference form as the tiled taps. A compact loop: its registers must not weigh on the fast path.
+    __device__ static void blur_direct(const RenderArgs& a, const Tex& bg, float x, float y, float intensity, float& r, float& g, float& b) {
+        const float ax = intensity*a.bg_scale_x*(float)bg.width, ay = intensity*(float)bg.height;
+        const uint8_t* data = (const uint8_t*)bg.data;
+        const int comps = bg.components;
+        typedef uint32_t unaligned_u32 __attribute__((aligned(1)));
+#pragma unroll 1
+        for (int k = 0; k <= 80; k++) {
+            const float weight = (k < 10) ? 2.0f : 1.0f;                  // direction 0 is direction 8 as well
+            const float tx = fmaf(a.tap_x[k], ax, x), ty = fmaf(a.tap_y[k], ay, y);
+            const float cx = floorf(tx), cy = floorf(ty);
+            const float fx = tx - cx, fy = ty - cy;
+            const int i0 = wrap_texel((int)cx, bg.width, bg.repeat_x), i1 = wrap_texel((int)cx + 1, bg.width, bg.repeat_x);
+            const int j0 = wrap_texel((int)cy, bg.height, bg.repeat_y), j1 = wrap_texel((int)cy + 1, bg.height, bg.repeat_y);
+            const uint32_t row0 = (uint32_t)j0*(uint32_t)bg.width, row1 = (uint32_t)j1*(uint32_t)bg.width;
+            const uint32_t w00 = *(const unaligned_u32*)(data + (size_t)(row0 + i0)*comps), w10 = *(const unaligned_u32*)(data + (size_t)(row0 + i1)*comps);
+            const uint32_t w01 = *(const unaligned_u32*)(data + (size_t)(row1 + i0)*comps), w11 = *(const unaligned_u32*)(data + (size_t)(row1 + i1)*comps);
+            const float wx = weight*fx, wy = weight*fy, wxy = wx*fy;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float t00 = (float)((w00 >> (8*ch)) & 255u), t10 = (float)((w10 >> (8*ch)) & 255u);
+                const float t01 = (float)((w01 >> (8*ch)) & 255u), t11 = (float)((w11 >> (8*ch)) & 255u);
+                float& acc = ch == 0 ? r : (ch == 1 ? g : b);
+                acc = fmaf(weight, t00, acc);
+                acc = fmaf(wx, t10 - t00, acc);
+                acc = fmaf(wy, t01 - t00, acc);
+                acc = fmaf(wxy, (t00 - t10) - (t01 - t11), acc);
+            }
+        }
+    }
+
+    __device__ static void run(const RenderArgs& a, const VisTables& t) {
+        __shared__ __attribute__((aligned(16))) Shared sh;
+        const int frame = blockIdx.z;
+        const int tile_index = xcd_band_order(blockIdx.x, gridDim.x);
+        const int bx = tile_index % t.blocks_x, by = tile_index / t.blocks_x;
+        const int tid = threadIdx.x;
+        const int p = tid >> 2, sub = tid & 3;
+        const int px = bx*BLOCK_PX + p, py = by;
+        const bool valid = (px < a.w) && (py < a.h);
+        const int i = min(px, a.w - 1)*S + (sub & 1), j = py*S + (sub >> 1);
+
+        const int4 wx = t.block_x[(long)frame*t.blocks_x + bx], wy = t.block_y[(long)frame*t.blocks_y + by];
+        const Tex& bg = a.tex[TEX_BACKGROUND];
+        const VisualizerConsts c = a.vis_consts ? a.vis_consts[a.frame0 + frame] : a.vis;
+
+        // column entry: global (L1/L2 resident: 4320 sample rows read each column's entry)
+        const float4* ce = t.columns + ((long)frame*a.wr + i)*VIS_ENTRY_QUADS;
+
+        // stage the window (VisualizerShader::setup step 2) and the block's two row entries
+        if (wx.z && wy.z) {
+            const int x0 = wx.x, y0 = wy.x, tw = wx.y, th = wy.y;
+            const uint8_t* data = (const uint8_t*)bg.data;
+            const int comps = bg.components;
+            typedef uint32_t unaligned_u32 __attribute__((aligned(1)));
+            for (int idx = tid; idx < TILE_PITCH*th; idx += THREADS) {
+                const int ty = idx / TILE_PITCH, tx = idx - ty*TILE_PITCH;
+                if (tx >= tw) continue;
+                const int j0 = wrap_texel(y0 + ty, bg.height, bg.repeat_y), j1 = wrap_texel(y0 + ty + 1, bg.height, bg.repeat_y);
+                const int i0 = wrap_texel(x0 + tx, bg.width, bg.repeat_x), i1 = wrap_texel(x0 + tx + 1, bg.width, bg.repeat_x);
+                const uint32_t row0 = (uint32_t)j0*(uint32_t)bg.width, row1 = (uint32_t)j1*(uint32_t)bg.width;
+                const uint32_t w00 = *(const unaligned_u32*)(data + (size_t)(row0 + i0)*comps);
+                const uint32_t w10 = *(const unaligned_u32*)(data + (size_t)(row0 + i1)*comps);
+                const uint32_t w01 = *(const unaligned_u32*)(data + (size_t)(row1 + i0)*comps);
+                const uint32_t w11 = *(const unaligned_u32*)(data + (size_t)(row1 + i1)*comps);
+                const float r00 = (float)(w00 & 255u), g00 = (float)((w00 >> 8) & 255u), b00 = (float)((w00 >> 16) & 255u);
+                const float r10 = (float)(w10 & 255u), g10 = (float)((w10 >> 8) & 255u), b10 = (float)((w10 >> 16) & 255u);
+                const float r01 = (float)(w01 & 255u), g01 = (float)((w01 >> 8) & 255u), b01 = (float)((w01 >> 16) & 255u);
+                const float r11 = (float)(w11 & 255u), g11 = (float)((w11 >> 8) & 255u), b11 = (float)((w11 >> 16) & 255u);
+                float4* cell = sh.cells + (ty*TILE_PITCH + tx)*3;
+                cell[0] = make_float4(r00, g00, b00, r10 - r00);
+                cell[1] = make_float4(g10 - g00, b10 - b00, r01 - r00, g01 - g00);
+                cell[2] = make_float4(b01 - b00, (r00 - r10) - (r01 - r11), (g00 - g10) - (g01 - g11), (b00 - b10) - (b01 - b11));
+            }
+            if (tid < S*VIS_ENTRY_QUADS) {
+                const int row = tid / VIS_ENTRY_QUADS, quad = tid - row*VIS_ENTRY_QUADS;
+                const int jr = min(by*S + row, a.hr - 1);
+                sh.row_entries[row][quad] = t.rows[((long)frame*a.hr + jr)*VIS_ENTRY_QUADS + quad];
+            }
+        }
+        __syncthreads();
+        const float4* re = sh.row_entries[sub >> 1];
+        const float4 r0 = re[0], c0 = ce[0];
+
+        uint32_t texel = 0;
+        if (valid) {
+            float r = 0.0f, g = 0.0f, b = 0.0f;
+            const char* tile = (const char*)sh.cells;
+            const float xr = c0.x, fx = c0.y, yr = r0.x, fy = r0.y;
+            if (!(wx.z && wy.z)) {
+                blur_direct(a, bg, xr + (float)wx.x, yr + (float)wy.x, c.intensity, r, g, b);
+            } else {
+            // the row of texels through the sample (directions 0, 180 degrees and the centre tap): moving axis x, fixed fraction fy
+            {
+                const char* line = tile + (__float_as_int(c0.w) + __float_as_int(r0.z));
+                const float4 c3 = ce[3], c4 = ce[4], c5 = ce[5], c6 = ce[6];
+                const float n[8] = {c3.x, c3.z, c4.x, c4.z, c5.x, c5.z, c6.x, c6.z}, s[8] = {c3.y, c3.w, c4.y, c4.w, c5.y, c5.w, c6.y, c6.w};
+#pragma unroll
+                for (int k = 0; k < VIS_LINE_CELLS; k++) cell_sum(line, k*48, n[k], s[k], n[k]*fy, s[k]*fy, r, g, b);
+            }
+            // the column of texels (90 and 270 degrees): moving axis y, fixed fraction fx
+            {
+                const char* line = tile + (__float_as_int(r0.w) + __float_as_int(c0.z));
+                const float4 l3 = re[3], l4 = re[4], l5 = re[5], l6 = re[6];
+                const float n[8] = {l3.x, l3.z, l4.x, l4.z, l5.x, l5.z, l6.x, l6.z}, s[8] = {l3.y, l3.w, l4.y, l4.w, l5.y, l5.w, l6.y, l6.w};
+#pragma unroll
+                for (int k = 0; k < VIS_LINE_CELLS; k++) cell_sum(line, k*TILE_PITCH*48, n[k], n[k]*fx, s[k], s[k]*fx, r, g, b);
+            }
+            // the four diagonal directions (VisualizerShader::blur_tile): at every walk step the four taps (+-k*s, +-k*s) share two
+            // x and two y coordinates
+            {
+                const float ax = c.intensity*a.bg_scale_x*(float)bg.width;
+                const float step = (a.tap_x[11] - a.tap_x[10])*ax, first = a.tap_x[10]*ax;
+                const float ROW = (float)(TILE_PITCH*48);
+                const float4* cells = sh.cells;
+                float xp = xr + first, xm = xr - first, yp = yr + first, ym = yr - first;
+                using V = VisualizerShader<TILE_PITCH, TILE_ROWS, 8>;
+#pragma unroll 1
+                for (int w = 0; w < 10; w++) {
+                    const float axp = __builtin_amdgcn_fractf(xp), axm = __builtin_amdgcn_fractf(xm);
+                    const float ayp = __builtin_amdgcn_fractf(yp), aym = __builtin_amdgcn_fractf(ym);
+                    const float cxp = (xp - axp)*48.0f, cxm = (xm - axm)*48.0f;
+                    const float ryp = (yp - ayp)*ROW, rym = (ym - aym)*ROW;
+                    V::tap_at(cells, cxp + ryp, axp, ayp, r, g, b);
+                    V::tap_at(cells, cxm + ryp, axm, ayp, r, g, b);
+                    V::tap_at(cells, cxm + rym, axm, aym, r, g, b);
+                    V::tap_at(cells, cxp + rym, axp, aym, r, g, b);
+                    xp = xp + step; xm = xm - step; yp = yp + step; ym = ym - step;
+                }
+            }
+            }
+            const float norm = 1.0f/(255.0f*10.0f*8.0f);              // (sum/255)/(quality*directions), visualizer.frag:32
+            vec3 col = {r*norm, g*norm, b*norm};
+            const vec3 space = vec3{1.0f, 11.0f, 26.0f}/255.0f;                                        // :9
+
+            // ---- visualizer.frag:36-73 (fragments.hpp visualizer_post<true>) on the separable terms ----
+            const float4 c1 = ce[1], c2 = ce[2], r1 = re[1], r2 = re[2];
+            {
+                const float la = __builtin_amdgcn_sqrtf(c1.w + r1.w);                                   // length(agluv), colour only
+                const float cl = sf::clamp(la - 0.3f, 0.0f, 1.0f);
+                const float c2l = cl*cl;
+                col = col*(1.0f + c.flash*(c2l*c2l*c2l));                                               // :36
+            }
+            const vec2 music_uv = vec2{c1.x + r1.x, c1.y + r1.y}*c.shrink;                              // :39-40
+            const float radius = 0.17f;
+            const float circle = sf::abs(atan1n(music_uv));                                             // :44
+            const Tex& sp = a.tex[TEX_SPECTROGRAM];
+            const float* bars = a.tape_bars + (long)(a.frame0 + frame)*a.spectrogram_stride;
+            const int bin = wrap_texel((int)::floorf(circle*(float)sp.height), sp.height, sp.repeat_y);
+            vec2 freq = {bars[2*bin], bars[2*bin + 1]};                                                 // sqrt(texel/1000), :45
+            freq = freq*(0.05f + 3.0f*sf::smoothstep(0.0f, 2.0f, circle));                              // :46
+            const float len = length(music_uv);
+            if (len < radius) {                                                                         // :49-50
+                col = col*0.5f;
+            } else {
+                const float bar = (music_uv.y < 0.0f) ? freq.x : freq.y;                                // :52
+                const float rr = radius + 0.5f*bar;
+                if (len < rr) col = mix(col, vec3{1.0f, 1.0f, 1.0f}, sf::smoothstep(0.0f, 1.0f, 0.5f + bar));   // :56
+                else col = col*ColourMath<true>::pow((len - rr)*0.5f, 0.05f);                           // :58
+            }
+            {
+                const float lp = __builtin_amdgcn_sqrtf(c1.z + r1.z)*0.05f;                             // length(uv)/20, colour only
+                col = mix(col, space, sf::smoothstep(0.0f, 1.0f, lp));                                  // :62
+            }
+            // pow(vig.x*vig.y*20, e) = exp2(e*(log2(ax(1-ax)) + log2(ay(1-ay)) + log2(20))), :65-66
+            col = col*__builtin_amdgcn_exp2f(c.vig_exp*((c2.x + r2.x) + 4.321928095f));
+            if (r2.y < c2.y) col = col*0.8f;                                                            // :72
+            if (r2.z < c2.z) col = col*0.8f;                                                            // :73
+            if (__float_as_int(c2.w) != 0) col = space;                                                 // :11-14
+            texel = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16);
+        }
+
+        // final.glsl over the pixel's 2x2 block (render_resolve_body): lane c of the quad resolves channel c
+        const uint32_t l0 = quad_lane0(texel), l1 = quad_lane1(texel), l2 = quad_lane2(texel), l3 = quad_lane3(texel);
+        const uint32_t block[4] = {l0, l1, l2, l3};
+        const uint32_t channel = resolve_channel_any<2>(block, a.subsample, 8*(sub < 3 ? sub : 0));
+        const uint32_t green = quad_lane1(channel), blue = quad_lane2(channel);
+        if (valid && sub == 0) {
+            uint8_t* s = &sh.staged[p*3];
+            s[0] = (uint8_t)channel; s[1] = (uint8_t)green; s[2] = (uint8_t)blue;
+        }
+        __syncthreads();
+        uint8_t* out = (uint8_t*)a.out + (long)frame*a.out_frame_stride;
+        if (py < a.h) store_rgb_row(out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3, bx*BLOCK_PX, a.w, sh.staged, tid, THREADS, BLOCK_PX);
+    }
+};
+
+template <int TILE_PITCH, int TILE_ROWS, int BLOCK_PX, int MIN_WAVES>
+__global__ __launch_bounds__(4*BLOCK_PX, MIN_WAVES) void k_visualizer_fast(const RenderArgs a, const VisTables t) {
+    VisualizerFast<TILE_PITCH, TILE_ROWS, BLOCK_PX>::run(a, t);
+}
+
+}  // namespace sf

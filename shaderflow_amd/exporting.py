@@ -114,10 +114,17 @@ class ExportingHelper:
         for module in self.scene.modules:
             module.ffhook(self.ffmpeg)
 
-    def popen(self) -> None:
+    def popen(self, open_sink: bool = True) -> None:
+        """`open_sink=False`: a rank of a sharded export that renders frames but does not own the sink — it still has to write
+        its rows in the order the sink wants"""
         self.scene.context.output_top_down(bool(self.top_down))
+        if not open_sink:
+            return
         if self.kind == "path-ffmpeg":
-            self.process = self.ffmpeg.popen(stdin=subprocess.PIPE, stderr=subprocess.PIPE)
+            # the encoder's own output goes to temporary files, never to a pipe nobody drains (the reference hands ffmpeg
+            # file-backed pipes for the same reason, exporting.py:131-132): a chatty encoder cannot stall the export
+            self._encoder_log = tempfile.TemporaryFile(mode="w+b")
+            self.process = self.ffmpeg.popen(stdin=subprocess.PIPE, stdout=self._encoder_log, stderr=self._encoder_log)
             self.fileno = self.process.stdin.fileno()
         elif self.kind == "path-raw":
             self.file = open(self.path, "wb")
@@ -142,8 +149,16 @@ class ExportingHelper:
 
     def _check_encoder(self) -> None:
         if (self.process is not None) and (self.process.poll() is not None):
-            raise RuntimeError("FFmpeg process closed unexpectedly with traceback:\n"
-                               f"{self.process.stderr.read().decode('utf-8', 'replace')}")
+            raise RuntimeError("FFmpeg process closed unexpectedly with traceback:\n" + self.encoder_output())
+
+    def encoder_output(self) -> str:
+        """What the encoder process has printed so far (stdout and stderr share one temporary file)"""
+        log = getattr(self, "_encoder_log", None)
+        if log is None:
+            return ""
+        log.flush()
+        log.seek(0)
+        return log.read().decode("utf-8", "replace")
 
     def pipe(self, turbo: bool = False) -> None:
         """Queue the frame that was just rendered (exporting.py:151-174)"""
@@ -192,14 +207,18 @@ class ExportingHelper:
         self.scene.context.synchronize()
         self.release_buffers()
         self.scene.context.output_top_down(False)
-        if self.kind == "path-ffmpeg":
+        if self.process is not None:
             self.process.stdin.close()
-            self.process.wait()
+            if self.process.wait() != 0:                      # the reference only waits (exporting.py:186-187); say what went wrong
+                logger.error(f"FFmpeg exited with status {self.process.returncode}:\n" + self.encoder_output())
             output = self.path
+        elif self.kind == "path-ffmpeg":
+            output = self.path                                # a rank that does not own the sink
         elif self.kind == "path-raw":
-            self.file.close()
+            if self.file is not None:
+                self.file.close()
             output = self.path
-        elif self.kind == "pipe":
+        elif self.kind == "pipe" and self.file is not None:
             self.file.seek(0)
             output = self.file.read()
             self.file.close()

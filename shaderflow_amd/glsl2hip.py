@@ -60,6 +60,8 @@ class Binding:
     slot: int
     count: int = 1
     integer: bool = False
+    default: Optional[tuple] = None      # the initialiser of `uniform T name = …;` (GLSL 3.30 §4.3.5): what the program reads until the host sets the uniform
+    array: Optional[str] = None          # element `name[i]` of the uniform array `array` (GL exposes array elements under these names too)
 
     @property
     def sampler(self) -> bool:
@@ -318,6 +320,7 @@ class _Translator:
         self.body: list[str] = []
         self.structs: set[str] = set()
         self.constants: set[str] = set()
+        self.constant_values: dict[str, int] = {}                    # `const int N = 3;` → array sizes of uniform declarations
         self.declared_uniforms: list[tuple[str, str, str]] = []     # (type, name, default text)
         self.macros: list[str] = []
         self.identifiers: set[str] = set()
@@ -344,8 +347,6 @@ class _Translator:
             names = _text(rest[type_index + 1:-1])
             for part in self._split_commas(names):
                 name, _, default = part.partition("=")
-                if "[" in name:
-                    raise TranslationError(f"uniform arrays are not supported: {part.strip()}")
                 self.declared_uniforms.append((type_, name.strip(), default.strip()))
             return ""
         if qualifiers & {"in", "out", "varying", "attribute"}:
@@ -374,6 +375,8 @@ class _Translator:
                 if constant:
                     for part in parts:
                         self.constants.add(part.partition("=")[0].strip())
+                        if type_ == "int" and part.partition("=")[2].strip().isdigit():
+                            self.constant_values[part.partition("=")[0].strip()] = int(part.partition("=")[2])
                     return f"\nstatic constexpr {type_} {', '.join(p.strip() for p in parts)};"
         # members cannot deduce an array bound from their initialiser: write it out
         match = re.search(r"\[\s*\]\s*=\s*\{", text)
@@ -493,6 +496,14 @@ class _Translator:
             raise TranslationError(f"unterminated declaration: {_text(statement).strip()[:60]!r}")
         return self.assemble()
 
+    def _array_length(self, text: str) -> int:
+        if text.isdigit():
+            return int(text)
+        value = self.constant_values.get(text)
+        if value is None:
+            raise TranslationError(f"array size '{text}' is not an integer literal or a literal `const int`")
+        return int(value)
+
     def assemble(self) -> Translation:
         bindings: list[Binding] = []
         members: list[str] = []
@@ -519,24 +530,43 @@ class _Translator:
                 members.append(f"    sampler2D {name};")
                 loads.append(f"{name} = sampler_({slot});")
                 continue
+            length = None                                          # `uniform T name[N]`: N elements, bound as name[0] … name[N-1]
+            array = re.fullmatch(r"(\w+)\s*\[\s*(\w+)\s*\]", name)
+            if array:
+                name = array.group(1)
+                length = self._array_length(array.group(2))
+            elif "[" in name:
+                raise TranslationError(f"uniform {name}: only one-dimensional arrays with a literal or constant size are supported")
             if type_ not in _UNIFORM_COUNTS:
                 raise TranslationError(f"uniform {name}: type {type_} is not supported")
             count, integer = _UNIFORM_COUNTS[type_]
-            if next_float + count > USER_SLOTS:
+            if next_float + count*(length or 1) > USER_SLOTS:
                 raise TranslationError(f"more than {USER_SLOTS} floats of uniforms")
-            getter = "user_int_" if integer else "user_"
-            values = ", ".join(f"{getter}({next_float + i})" for i in range(count))
-            members.append(f"    {type_} {name};")
-            if type_ == "bool":
-                loads.append(f"{name} = user_int_({next_float}) != 0;")
-            elif type_ == "uint":
-                loads.append(f"{name} = (uint)user_int_({next_float});")
-            elif count == 1:
-                loads.append(f"{name} = {values};")
+            defaults = _constant_initialiser(type_, count, length, default, name) if default else None
+
+            def load(target: str, first: int) -> str:
+                getter = "user_int_" if integer else "user_"
+                values = ", ".join(f"{getter}({first + i})" for i in range(count))
+                if type_ == "bool":
+                    return f"{target} = user_int_({first}) != 0;"
+                if type_ == "uint":
+                    return f"{target} = (uint)user_int_({first});"
+                if count == 1:
+                    return f"{target} = {values};"
+                return f"{target} = {type_}({values});"
+
+            if length is None:
+                members.append(f"    {type_} {name};")
+                loads.append(load(name, next_float))
+                bindings.append(Binding(name, type_, next_float, count, integer, default=defaults[0] if defaults else None))
+                next_float += count
             else:
-                loads.append(f"{name} = {type_}({values});")
-            bindings.append(Binding(name, type_, next_float, count, integer))
-            next_float += count
+                members.append(f"    {type_} {name}[{length}];")
+                for index in range(length):
+                    loads.append(load(f"{name}[{index}]", next_float))
+                    bindings.append(Binding(f"{name}[{index}]", type_, next_float, count, integer,
+                                            default=defaults[index] if defaults else None, array=name))
+                    next_float += count
         code = "".join(self.body)
         undefs = "".join(f"#undef {m}\n" for m in dict.fromkeys(self.macros))
         cpp = ("// generated by shaderflow_amd/glsl2hip.py from a GLSL fragment\n"
@@ -551,6 +581,76 @@ class _Translator:
                f"#define SF_JIT_DERIVATIVES {int(bool(self.identifiers & {'dFdx', 'dFdy', 'fwidth'}))}\n"
                "SF_JIT_ENTRY_POINTS(sf::rt::Fragment)\n")
         return Translation(cpp, bindings)
+
+
+_SCALAR_OF = {"float": float, "int": int, "uint": int, "bool": bool}
+
+
+def _constant_scalar(text: str, name: str) -> float:
+    """A literal arithmetic expression of a uniform initialiser → its value (`-0.5`, `2.0*3.0`, `1e-3`, `true`, `3u`)"""
+    import ast
+    cleaned = re.sub(r"(?<=[0-9.])(?:lf|LF|[fFuU])\b", "", text.strip())
+    cleaned = re.sub(r"\btrue\b", "1", re.sub(r"\bfalse\b", "0", cleaned))
+    cleaned = re.sub(r"\b(?:float|int|uint|bool)\s*\(", "(", cleaned)
+    try:
+        tree = ast.parse(cleaned, mode="eval")
+    except SyntaxError:
+        raise TranslationError(f"uniform {name}: initialiser '{text}' is not a literal constant expression") from None
+    allowed = (ast.Expression, ast.BinOp, ast.UnaryOp, ast.Constant, ast.Add, ast.Sub, ast.Mult, ast.Div, ast.USub, ast.UAdd)
+    if not all(isinstance(node, allowed) for node in ast.walk(tree)):
+        raise TranslationError(f"uniform {name}: initialiser '{text}' is not a literal constant expression")
+    import builtins                                            # this module defines its own compile()
+    return float(eval(builtins.compile(tree, "<initialiser>", "eval"), {"__builtins__": {}}))
+
+
+def _split_arguments(text: str) -> list[str]:
+    parts, depth, current = [], 0, ""
+    for ch in text:
+        if ch in "([":
+            depth += 1
+        elif ch in ")]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(current)
+            current = ""
+        else:
+            current += ch
+    if current.strip():
+        parts.append(current)
+    return parts
+
+
+def _constant_value(type_: str, count: int, text: str, name: str) -> tuple:
+    """`T(…)` or a scalar expression → `count` numbers (vector constructors splat a single argument, matrices put it on the diagonal)"""
+    text = text.strip()
+    constructor = re.fullmatch(rf"{type_}\s*\((.*)\)", text, re.S)
+    if count == 1:
+        return (_constant_scalar(constructor.group(1) if constructor else text, name),)
+    if not constructor:
+        raise TranslationError(f"uniform {name}: initialiser '{text}' must be a {type_}(…) constructor of literals")
+    arguments = [_constant_scalar(a, name) for a in _split_arguments(constructor.group(1))]
+    if len(arguments) == 1:
+        if type_.startswith("mat"):
+            side = int(type_[3])
+            return tuple(arguments[0] if (k % (side + 1) == 0) else 0.0 for k in range(count))
+        return tuple(arguments*count)
+    if len(arguments) != count:
+        raise TranslationError(f"uniform {name}: {type_} initialiser with {len(arguments)} components")
+    return tuple(arguments)
+
+
+def _constant_initialiser(type_: str, count: int, length: Optional[int], text: str, name: str) -> list[tuple]:
+    """The initialiser of a uniform declaration as one tuple per element (one element for a non-array)"""
+    if length is None:
+        return [_constant_value(type_, count, text, name)]
+    # (array constructors reach this point already rewritten to C++ brace lists)
+    array = re.fullmatch(rf"{type_}\s*\[\s*\w*\s*\]\s*\((.*)\)", text.strip(), re.S) or re.fullmatch(r"\{(.*)\}", text.strip(), re.S)
+    if not array:
+        raise TranslationError(f"uniform {name}: an array initialiser must be written {type_}[](…)")
+    elements = _split_arguments(array.group(1))
+    if len(elements) != length:
+        raise TranslationError(f"uniform {name}: {len(elements)} initialisers for {length} elements")
+    return [_constant_value(type_, count, element, name) for element in elements]
 
 
 def translate(source: str, uniforms: Iterable[tuple[str, str]] = ()) -> Translation:
@@ -569,9 +669,17 @@ def runtime_fingerprint() -> str:
     global _fingerprint
     if _fingerprint is None:
         digest = hashlib.sha256()
-        for name in ("sfmath.hpp", "glsl.hpp", "fragments.hpp", "render_kernels.hpp", "jit_runtime.hpp", "jit_swizzles.inc", "jit_intvec.inc"):
+        for name in ("sfmath.hpp", "glsl.hpp", "fragments.hpp", "render_kernels.hpp", "jit_runtime.hpp", "jit_swizzles.inc", "jit_intvec.inc",
+                     "uniform_table.hpp"):
             digest.update((CSRC/name).read_bytes())
         digest.update(" ".join(FLAGS).encode())
+        # …and the layout the LOADED library was built with (a variant library built with other switches, or headers edited since it
+        # was built, must not pick up code objects cached for another layout; sfx_program_load checks the same value)
+        try:
+            from shaderflow_amd import _native
+            digest.update(str(_native.lib().sfx_abi_layout()).encode())
+        except Exception:                                      # no library yet (host-only translation tests): headers alone
+            pass
         _fingerprint = digest.hexdigest()
     return _fingerprint
 

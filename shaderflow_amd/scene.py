@@ -333,15 +333,17 @@ class ShaderScene(ShaderModule):
             self.ssaa = ssaa
 
         export = ExportingHelper(self, top_down=top_down)
-        if (self.exporting) and rank_world()[0] != 0:
-            pass                                             # sharded export: only rank 0 owns the sink (tape.py)
-        elif (self.exporting):
+        if (self.exporting):
+            # Every rank of a sharded export resolves the sink the same way — its kind decides the row order the kernels write
+            # (exporting.py:94-118) — but only rank 0 opens it and owns the read-out ring (tape.py, _sharded_frame_loop)
+            owner = (rank_world()[0] == 0)
             export.ffmpeg_clean()
             export.ffmpeg_sizes(width=_width, height=_height)
             export.ffmpeg_output(output)
-            export.make_buffers(buffers)
+            if owner:
+                export.make_buffers(buffers)
             export.ffhook()
-            export.popen()
+            export.popen(open_sink=owner)
         if (self.freewheel):
             export.open_bar()
 

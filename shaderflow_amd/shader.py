@@ -169,6 +169,7 @@ class ShaderProgram(ShaderModule):
             N.lib().sfx_program_destroy(self.program)
         self.program = None
         self._pushed.clear()
+        self._uniform_arrays = {}
 
     def compile(self, _vertex: str = None, _fragment: str = None):
         for variable in self.full_pipeline():
@@ -197,6 +198,7 @@ class ShaderProgram(ShaderModule):
     translated: bool = False
     compile_error: str = ""
     _translation_text: str = ""
+    _uniform_arrays: dict = Factory(dict)
 
     def assembled_fragment(self, content: str) -> str:
         """What the reference hands to the GLSL compiler after the declarations and the prelude (shader.py:214-233): every
@@ -230,6 +232,15 @@ class ShaderProgram(ShaderModule):
         N.check(N.lib().sfx_program_load(self.scene.context.handle, code, len(code), table, len(keep), C.byref(handle)))
         self.release_program()
         self.program, self.fallback, self.translated = handle, False, True
+        # uniform arrays are set through their elements (`name[i]`, as GL names them); initialisers of `uniform T x = …;`
+        # declarations are what the program reads until the host sets the uniform (GLSL 3.30 §4.3.5)
+        self._uniform_arrays = {}
+        for binding in translation.bindings:
+            if binding.array:
+                kind, length = self._uniform_arrays.get(binding.array, (binding.type, 0))
+                self._uniform_arrays[binding.array] = (kind, length + 1)
+            if binding.default is not None:
+                self._push(binding.name, binding.default, binding.type)
 
     @property
     def kernel(self) -> str:
@@ -244,6 +255,10 @@ class ShaderProgram(ShaderModule):
         self._push(name, value)
 
     def _push(self, name: str, value: Any, type: Optional[str] = None) -> bool:
+        if name in self._uniform_arrays:                              # `uniform T name[N]` of a translated fragment: element by element
+            kind, length = self._uniform_arrays[name]
+            elements = np.asarray(value, dtype=np.float64).reshape(length, -1)
+            return all([self._push(f"{name}[{index}]", elements[index], kind) for index in range(length)])
         if type is None:
             array = np.asarray(value)
             count = array.size

@@ -15,6 +15,7 @@ anything else runs through the frame loop (`ShaderScene.next`), which produces t
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import TYPE_CHECKING, Optional
 
 import numpy as np
@@ -56,6 +57,7 @@ def _coefficients_f32(system, dts) -> np.ndarray:
 
 class FrameTape:
     BATCH = 60
+    SCROLL_BYTES = 8 << 30           # per-frame states of a scrolling spectrogram texture that one batch may hold
 
     @staticmethod
     def applicable(scene: "ShaderScene") -> bool:
@@ -86,13 +88,20 @@ class FrameTape:
         audio = audios[0]
         if audio.native is None or any(m.audio is not audio for m in (*spectrograms, *waveforms)):
             return False
-        if spectrograms[0].length_samples != 1 or spectrograms[0].spectrogram_bins*audio.channels > 2048:
+        if spectrograms[0].spectrogram_bins*audio.channels > 2048:
+            return False                                          # the scan kernel walks up to 2048 values per frame
+        # a scrolling spectrogram (length > 0) keeps one state of its texture per frame of a batch in HBM (sfx_tape_desc.length_samples)
+        if spectrograms[0].length_samples*spectrograms[0].spectrogram_bins*audio.channels*4*FrameTape.BATCH > FrameTape.SCROLL_BYTES:
             return False
         return True                                               # any (ssaa, subsample): fused when possible, else two passes
 
-    def __init__(self, scene: "ShaderScene", batch: Optional[int] = None, use_mfma: bool = True):
+    def __init__(self, scene: "ShaderScene", batch: Optional[int] = None, use_mfma: Optional[bool] = None):
         self.scene = scene
         self.batch = int(batch or self.BATCH)
+        # filterbank product: CSR rows in scipy's summation order (bit-exact against the reference's `M.dot`, the default) or the
+        # dense banded GEMM on v_mfma_f32_32x32x2_f32 (2e-6 relative: another summation order); SHADERFLOW_FILTERBANK=mfma|csr
+        if use_mfma is None:
+            use_mfma = os.environ.get("SHADERFLOW_FILTERBANK", "csr").lower() == "mfma"
         self.use_mfma = bool(use_mfma)
         self.audio: Optional[ShaderAudio] = next((m for m in scene.modules if isinstance(m, ShaderAudio)), None)
         self.spectrogram: Optional[ShaderSpectrogram] = next((m for m in scene.modules if isinstance(m, ShaderSpectrogram)), None)
@@ -134,6 +143,7 @@ class FrameTape:
             volume_window=int(0.1*audio.samplerate),
             use_mfma=int(self.use_mfma),
             volume_integrate=int(audio.volume.integrate), std_integrate=int(audio.std.integrate),
+            length_samples=int(spec.length_samples),
             precision=float(spec.dynamics.precision),
         )
         handle = N.Handle()

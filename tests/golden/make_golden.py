@@ -73,6 +73,7 @@ import shaderflow.ffmpeg as ref_ffmpeg                                    # noqa
 from shaderflow.audio.module import BrokenAudio, root_mean_square         # noqa: E402
 from shaderflow.audio.spectrogram import (                                # noqa: E402
     BrokenSpectrogram,
+    FourierMagnitude,
     SpectrogramInterpolation,
     SpectrogramScale,
     SpectrogramWindow,
@@ -250,6 +251,40 @@ def capture_fft() -> dict:
         out[f"power_noise_{wname}"] = spec.fft()
     out["window_hanning_4096"] = SpectrogramWindow.hanning(4096)
     out["window_hann_poisson_4096"] = SpectrogramWindow.hann_poisson_window(4096)
+    return out
+
+# 2b. FourierMagnitude.Amplitude (spectrogram.py:22-23) on inputs of fft.npz
+
+def capture_options() -> dict:
+    out = {}
+    inputs = np.load(HERE/"fft.npz")
+    for name in ("sine1k", "noise", "impulse"):
+        audio = make_audio()
+        audio.add_data(inputs[f"in_{name}"])
+        spec = BrokenSpectrogram(audio=audio, magnitude=FourierMagnitude.Amplitude)
+        out[f"amplitude_{name}"] = spec.fft()
+    audio = make_audio()
+    audio.add_data(inputs["in_noise_long"])
+    out["amplitude_noise_n10"] = BrokenSpectrogram(audio=audio, fft_n=10, magnitude=FourierMagnitude.Amplitude).fft()
+
+    # DynamicNumber, float32 (2, 24) array like ShaderSpectrogram's (spectrogram.py:287-290): a target held long enough for the whole
+    # array to come within `precision`, so that the early-out (dynamics.py:222-225) freezes value/derivative/previous, then released
+    rng = np.random.default_rng(23)
+    frames = 420
+    targets = np.empty((frames, 2, 24), np.float32)
+    targets[:8] = (np.abs(rng.standard_normal((8, 2, 24)))*3).astype(np.float32)
+    targets[8:400] = targets[7]
+    targets[400:] = (np.abs(rng.standard_normal((20, 2, 24)))*3).astype(np.float32)
+    dts = np.full(frames, 1/60); dts[0] = 0.0
+    system = DynamicNumber(frequency=4, zeta=1, response=0, dtype=np.float32)
+    system.set(np.zeros((2, 24), np.float32))
+    values, derivatives = [], []
+    for k in range(frames):
+        system.target = targets[k]
+        system.next(dt=abs(float(dts[k])))
+        values.append(np.array(system.value, copy=True)); derivatives.append(np.array(system.derivative, copy=True))
+    out["hold_targets"], out["hold_dts"] = targets, dts
+    out["hold_values"], out["hold_derivatives"] = np.asarray(values), np.asarray(derivatives)
     return out
 
 # ----------------------------------------------------------------------------------------------- #
@@ -501,11 +536,14 @@ def main() -> None:
     for name, fn in (
         ("clock", capture_clock),
         ("fft", capture_fft),
+        ("options", capture_options),
         ("filterbank", capture_filterbank),
         ("dynamics", capture_dynamics),
         ("pipeline", capture_pipeline),
         ("resolution", capture_resolution),
     ):
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue                                                        # `make_golden.py options` regenerates one fixture
         data = fn()
         path = HERE/f"{name}.npz"
         np.savez_compressed(path, **data)

@@ -37,6 +37,9 @@ class HostFragment:
         self.textures = C.create_string_buffer(self.lib.sfx_jit_host_textures_size())
         self.lib.sfx_jit_host_defaults(self.uniforms)
         self._keep: list[np.ndarray] = []
+        for binding in translation.bindings:                 # what ShaderProgram._load_translated does with `uniform T x = …;`
+            if binding.default is not None:
+                self.set(binding.name, binding.default)
 
     def set_uniforms(self, u: O.Uniforms) -> None:
         """every built-in field of an oracle uniform block, by name"""
@@ -49,6 +52,11 @@ class HostFragment:
 
     def set(self, name: str, value) -> None:
         """a scene-defined uniform, through the translation's bindings"""
+        elements = [b for b in self.translation.bindings if b.array == name]
+        if elements:                                         # a uniform array: element by element (ShaderProgram._push)
+            for index, row in enumerate(np.asarray(value, np.float64).reshape(len(elements), -1)):
+                self.set(f"{name}[{index}]", row)
+            return
         binding = next(b for b in self.translation.bindings if b.name == name and not b.sampler)
         words = np.atleast_1d(np.asarray(value, np.int32 if binding.integer else np.float32))
         assert words.size == binding.count, (name, words.size, binding.count)

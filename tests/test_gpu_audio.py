@@ -74,6 +74,22 @@ def test_stft_power_against_reference_vectors(gpu, golden, name):
     close(got, O.fft_power(pcm, pcm.shape[1]))
 
 
+@pytest.mark.parametrize("name", ["sine1k", "noise", "impulse"])
+def test_stft_amplitude_against_reference_vectors(gpu, golden, name):
+    """FourierMagnitude.Amplitude = np.abs(rfft) (spectrogram.py:22-23) on the device vs the imported reference's vectors"""
+    g, o = golden("fft"), golden("options")
+    pcm = g[f"in_{name}"]
+    audio = Audio(gpu, pcm.T)
+    plan = audio.plan(12, 0, *trivial_csr(), 4)
+    N.check(gpu.lib.sfx_stft_plan_magnitude(plan, 1))
+    got = audio.power(plan, [pcm.shape[1]], 12)[0]
+    close(got, o[f"amplitude_{name}"])
+    close(got, O.fft_power(pcm, pcm.shape[1], amplitude=True))
+    N.check(gpu.lib.sfx_stft_plan_magnitude(plan, 0))
+    close(audio.power(plan, [pcm.shape[1]], 12)[0], g[f"power_{name}"])
+    assert gpu.lib.sfx_stft_plan_magnitude(plan, 7) != 0
+
+
 def test_stft_sizes_windows_and_start_of_stream(gpu, golden):
     g = golden("fft")
     pcm = g["in_noise_long"]
@@ -178,18 +194,83 @@ def test_frame_tape_against_reference_pipeline(gpu, golden, mfma):
     gpu.lib.sfx_tape_destroy(tape)
 
 
-def test_dynamics_scan_bit_exact_on_golden_targets(gpu, golden):
-    """K3 alone: feeding the reference's own float32 targets must reproduce its trajectory bit for bit,
-    including the converged stretch where the early-out freezes the state (dynamics.py:222-225)"""
+def _coeff_table(freq, zeta, resp, dts, dtype):
     from shaderflow_amd.dynamics import dynamics_coefficients
+    wide = np.zeros((len(dts), 4), np.float64)
+    for k, dt in enumerate(dts):
+        dt = abs(float(dt))
+        if dt:
+            k1, k2, k3, _ = dynamics_coefficients(freq, zeta, resp, dt)
+            wide[k] = (dt, k1, k2, k3)
+    return np.ascontiguousarray(wide.astype(dtype))       # python scalars → float32 the way numpy rounds them for a float32 array
+
+
+def test_dynamics_scan_bit_exact_on_golden_targets(gpu, golden):
+    """K3 alone through sfx_dynamics_scan: the DEVICE, fed the reference's own float32 targets, reproduces the reference's
+    trajectory bit for bit — including frame 0 (dt = 0) and the converged stretch where the early-out freezes the whole
+    system (dynamics.py:210-211, 222-225). Run in two calls to cover the state hand-over between batches."""
     g = golden("dynamics")
-    targets = g["spec_targets"].reshape(len(g["spec_dts"]), -1)      # (frames, 230) in the (2,115) memory order
-    frames = targets.shape[0]
+    frames = len(g["spec_dts"])
+    targets = np.ascontiguousarray(g["spec_targets"].reshape(frames, -1))      # (frames, 230) in the (2,115) memory order
+    want = g["spec_values"].reshape(frames, -1)
+    f, z, r, _ = g["spec_params"]
+    coeff = _coeff_table(f, z, r, g["spec_dts"], np.float32)
+    state = np.zeros(3*230, np.float32)
+    got = np.zeros_like(targets)
+    for first, count in ((0, 47), (47, frames - 47)):
+        N.check(gpu.lib.sfx_dynamics_scan(gpu.ctx.handle, count, 230, N.as_ptr(targets[first:], C.c_float),
+                                          C.cast(coeff[first:].ctypes.data, C.POINTER(N.DynCoeffF32)), np.float32(1e-6),
+                                          N.as_ptr(state, C.c_float), N.as_ptr(got[first:], C.c_float)))
+    assert np.array_equal(got, want)
+    assert np.array_equal(state[:230], want[-1])
+    assert np.array_equal(state[230:460], g["spec_derivatives"].reshape(frames, -1)[-1])
+    # The early-out (dynamics.py:222-225): options.npz holds a target for 392 frames — the reference's state freezes from frame 69
+    # to frame 399 (max|target - value| < 1e-6 over the WHOLE array) and moves again when the target is released. A device scan that
+    # froze one frame late, or per element, would differ in the bits of every later frame.
+    o = golden("options")
+    hold_targets = np.ascontiguousarray(o["hold_targets"].reshape(len(o["hold_dts"]), -1))
+    hold_want = o["hold_values"].reshape(hold_targets.shape)
+    n = hold_targets.shape[1]
+    frozen = [k for k in range(1, len(hold_want)) if k > 8 and np.array_equal(hold_want[k], hold_want[k - 1])]
+    assert len(frozen) > 300 and frozen[-1] == 399, "the fixture no longer exercises the early-out"
+    hold_coeff = _coeff_table(4, 1, 0, o["hold_dts"], np.float32)
+    hold_state = np.zeros(3*n, np.float32)
+    hold_got = np.zeros_like(hold_targets)
+    for first, count in ((0, 60), (60, 60), (120, len(hold_targets) - 120)):
+        N.check(gpu.lib.sfx_dynamics_scan(gpu.ctx.handle, count, n, N.as_ptr(hold_targets[first:], C.c_float),
+                                          C.cast(hold_coeff[first:].ctypes.data, C.POINTER(N.DynCoeffF32)), np.float32(1e-6),
+                                          N.as_ptr(hold_state, C.c_float), N.as_ptr(hold_got[first:], C.c_float)))
+    assert np.array_equal(hold_got, hold_want)
+    assert np.array_equal(hold_state[n:2*n], o["hold_derivatives"].reshape(hold_targets.shape)[-1])
+    # and the oracle agrees (the checker is itself pinned to the same fixture)
     oracle = O.DynF32(230, 4, 1, 0)
-    want = np.stack([oracle.step(targets[k], float(g["spec_dts"][k])).copy() for k in range(frames)])
-    assert np.array_equal(want, g["spec_values"].reshape(frames, -1))
-    # The tape derives its targets from audio, so the scan kernel is exercised through the oracle equality above
-    # and through test_frame_tape_against_reference_pipeline; here the host coefficient helper is pinned:
+    assert np.array_equal(np.stack([oracle.step(targets[k], float(g["spec_dts"][k])).copy() for k in range(frames)]), want)
+
+
+@pytest.mark.parametrize("tag", ["volume", "std", "resp", "cosh", "idle", "vardt"])
+def test_scalar_dynamics_scan_bit_exact(gpu, golden, tag):
+    """The float64 scalar systems (both integrator branches, response/velocity term, integrate, early-out, variable dt)
+    on the device vs the reference's trajectories: value, integral and derivative bit for bit"""
+    g = golden("dynamics")
+    dts = g[f"{tag}_dts"]
+    frames = len(dts)
+    f, z, r, integrate = g[f"{tag}_params"]
+    targets = np.ascontiguousarray(g[f"{tag}_targets"].astype(np.float64).reshape(frames, 1))
+    coeff = _coeff_table(f, z, r, dts, np.float64)
+    start = 0.25 if tag == "idle" else 0.0
+    state = np.array([[start, 0.0, start, 0.0]], np.float64)            # value, derivative, previous, integral
+    out = np.zeros((frames, 1, 3), np.float64)
+    N.check(gpu.lib.sfx_dynamics_scan_f64(gpu.ctx.handle, frames, 1, N.as_ptr(targets, C.c_double),
+                                          C.cast(coeff.ctypes.data, C.POINTER(N.DynCoeffF64)), 1e-6, int(integrate),
+                                          N.as_ptr(state, C.c_double), N.as_ptr(out, C.c_double)))
+    assert np.array_equal(out[:, 0, 0], g[f"{tag}_values"])
+    if integrate:
+        assert np.array_equal(out[:, 0, 1], g[f"{tag}_integrals"])
+    assert np.array_equal(out[:, 0, 2], g[f"{tag}_derivatives"])
+
+
+def test_dynamics_coefficients_match_the_oracle():
+    from shaderflow_amd.dynamics import dynamics_coefficients
     for dt in (1/60, 1/30, 0.004):
         for (f, z, r) in ((4, 1, 0), (10, 1, 0), (25, 1.7, -0.5), (3, 0.4, 1.5)):
             k1, k2, k3, branch = dynamics_coefficients(f, z, r, dt)

@@ -31,25 +31,30 @@ def _build(name: str):
 KW = {"Visualizer": dict(width=96, height=54, fps=60.0, ssaa=2, time=130/60), "MotionBlur": dict(width=64, height=36, fps=30.0, ssaa=1, time=70/30)}
 
 
-def _rank(rank: int, world: int, port: int, name: str, path: str):
+def _rank(rank: int, world: int, port: int, name: str, path: str, top_down=None):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        _build(name).main(output=path, **KW[name])
+        _build(name).main(output=path, top_down=top_down, **KW[name])
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("name", ["Visualizer", "MotionBlur"])
-def test_two_ranks_on_one_gpu_reproduce_the_single_process_export(tmp_path, name):
-    whole = _build(name).main(output=bytes, **KW[name])
+@pytest.mark.parametrize("name,top_down", [("Visualizer", None), ("MotionBlur", None), ("Visualizer", True), ("MotionBlur", True)])
+def test_two_ranks_on_one_gpu_reproduce_the_single_process_export(tmp_path, name, top_down):
+    """`top_down=True`: the row order an ffmpeg sink asks for must reach EVERY rank, not only the one that owns the sink
+    (a rank that missed it would deliver its batches upside down)"""
+    whole = _build(name).main(output=bytes, top_down=top_down, **KW[name])
+    if top_down:
+        frames = np.frombuffer(whole, np.uint8).reshape(-1, KW[name]["height"], KW[name]["width"], 3)
+        assert np.array_equal(frames[:, ::-1], np.frombuffer(_build(name).main(output=bytes, **KW[name]), np.uint8).reshape(frames.shape))
     path = str(tmp_path/"sharded.rgb")
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, name, path)) for r in range(2)]
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, name, path, top_down)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

@@ -256,6 +256,7 @@ def test_full_size_properties_4k_ssaa2(gpu):
     gpu.set_uniforms(prog, u)
     gpu_bind_all(gpu, prog, arrays, params)
     a = gpu.render_resolve(prog, w, h, ssaa, 2)
+    assert gpu.lib.sfx_last_kernel().decode().startswith("k_visualizer_fast<"), gpu.lib.sfx_last_kernel()     # the bench's kernel
     b = gpu.render_resolve(prog, w, h, ssaa, 2)
     assert np.array_equal(a, b)
     rows = (1000, 1004)                                           # 4 output rows = 8 supersample rows on the CPU
@@ -269,6 +270,61 @@ def test_full_size_properties_4k_ssaa2(gpu):
     img = gpu.render_resolve(bars, w, h, ssaa, 2)
     bin_width = w/115
     assert np.array_equal(img[:, int(10*bin_width) + 3], img[:, int(10*bin_width) + 20])
+
+
+def _last_kernel(gpu) -> str:
+    return gpu.lib.sfx_last_kernel().decode()
+
+
+def test_full_size_properties_1080p_two_pass(gpu):
+    """BASELINE config 2 at its own size (1920x1080, ssaa 1, subsample 2): the fragment into an RGBA8 iScreen, then final.glsl's 3x3
+    tent as a pass — the pair the fused kernel refuses. Kernel selection depends on the size (window bound of the LDS tile), so the
+    instance is asserted; a band of rows of BOTH passes equals the oracle; two launches give identical frames."""
+    w, h = 1920, 1080
+    u, arrays, params = visualizer_inputs(w, h, seed=52, volume=0.9, bg_size=(1920, 1080))
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    assert gpu.lib.sfx_fused_supported(1000, 2) == 0
+    screen = gpu.empty(w, h, 4)
+    N.check(gpu.lib.sfx_texture_params(screen, 1, 0, 0))
+    N.check(gpu.lib.sfx_render(prog, screen, 0))
+    assert _last_kernel(gpu) == "k_render<VisualizerShader<64, 15, 6, 1, 1, 128, 64, 8>>", _last_kernel(gpu)
+    shaded = gpu.read(screen, w, h, 4)
+    final = gpu.empty(w, h, 3)
+    N.check(gpu.lib.sfx_resolve(gpu.ctx.handle, screen, final, 2))
+    frame = gpu.read(final, w, h, 3)
+    N.check(gpu.lib.sfx_render(prog, screen, 0))
+    N.check(gpu.lib.sfx_resolve(gpu.ctx.handle, screen, final, 2))
+    assert np.array_equal(frame, gpu.read(final, w, h, 3))
+    # the tent reaches one row up and down: shade rows [r0-1, r1+1) on the CPU, compare the resolve of the inner rows
+    for r0, r1 in ((0, 3), (537, 543), (1077, 1080)):
+        lo, hi = max(0, r0 - 1), min(h, r1 + 1)
+        want_screen = O.render("visualizer", u, oracle_textures(arrays, params), w, h, rows=(lo, hi), threads=8)
+        assert_within_lsb(shaded[lo:hi], want_screen[lo:hi])
+        # final.glsl over the DEVICE's own iScreen rows is bit-exact (k_resolve is the generic chain)
+        padded = shaded.copy()
+        want = O.resolve(padded, w, h, 2, rows=(r0, r1), threads=8)
+        assert np.array_equal(frame[r0:r1], want[r0:r1])
+
+
+def test_full_size_properties_8k_ssaa4(gpu):
+    """BASELINE config 4 at its own size (7680x4320, 4x SSAA: 30720x17280 samples, never materialised): the kernel instance, a band
+    of rows against the oracle (16 supersamples per pixel resolved by final.glsl with subsample 2), determinism."""
+    w, h, ssaa = 7680, 4320, 4
+    u, arrays, params = visualizer_inputs(w, h, seed=53, volume=0.9, bg_size=(1920, 1080))
+    u.iSSAA = 4.0
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    a = gpu.render_resolve(prog, w, h, ssaa, 2)
+    assert _last_kernel(gpu) == "k_render_resolve<VisualizerShader<80, 10, 6, 1, 1, 128, 128, 2>, 4>", _last_kernel(gpu)
+    b = gpu.render_resolve(prog, w, h, ssaa, 2)
+    assert np.array_equal(a, b)
+    for rows in ((0, 1), (2159, 2161), (4319, 4320)):
+        screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, rows=(rows[0]*ssaa, rows[1]*ssaa), threads=8)
+        want = O.resolve(screen, w, h, 2, rows=rows, threads=8)
+        assert_within_lsb(a[rows[0]:rows[1]], want[rows[0]:rows[1]])
 
 
 def test_destroyed_texture_is_unbound_not_dangling(gpu):

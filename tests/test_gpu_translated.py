@@ -149,6 +149,94 @@ def test_a_code_object_built_against_other_headers_is_refused(gpu):
         N.check(gpu.lib.sfx_program_load(gpu.ctx.handle, bytes(code[:4096]), 4096, None, 0, C.byref(handle)))      # truncated: not a code object
 
 
+def test_a_code_object_with_another_argument_layout_is_refused(gpu, monkeypatch):
+    """Same size or not: a code object compiled against a RenderArgs whose members sit elsewhere (here: the profiling build's extra
+    member) carries another layout fingerprint and must not be launched with this library's arguments"""
+    translation = glsl2hip.translate(GRADIENT)
+    monkeypatch.setattr(glsl2hip, "FLAGS", [*glsl2hip.FLAGS, "-DSF_SECTION_TIMERS"])
+    monkeypatch.setattr(glsl2hip, "_fingerprint", None)
+    code = glsl2hip.compile(translation, cache=CACHE)
+    monkeypatch.setattr(glsl2hip, "_fingerprint", None)
+    handle = N.Handle()
+    assert gpu.lib.sfx_program_load(gpu.ctx.handle, code, len(code), None, 0, C.byref(handle)) != N.OK
+    assert b"argument layout" in gpu.lib.sfx_last_error()
+
+
+SCROLL = """
+void main() {
+    vec2 uv = vec2(astuv.x + iSpectrogramOffset, astuv.y);
+    vec2 s = sqrt(texture(iSpectrogram, uv).xy)/40.0;
+    fragColor = vec4(s, float(iSpectrogramLength)/64.0, 1);
+}
+"""
+
+
+@pytest.mark.parametrize("smooth", [False, True])
+def test_scrolling_spectrogram_frame_loop_tape_and_replay(gpu, smooth):
+    """ShaderSpectrogram with length > 0 (spectrogram.py:272-274, 298-311): a `length*fps` columns wide texture, one column rewritten
+    per frame at (offset+1) % width, iSpectrogramOffset telling the fragment where. (1) the frame tape — one texture state per frame
+    of a batch, k_spectrogram_scroll — gives the frame loop's bytes across batch boundaries and ring wrap-arounds; (2) the frame loop
+    is what a replay of the reference's update rule on the oracle's audio tape, rendered by the HOST build of the same translation,
+    produces."""
+    from shaderflow_amd import ShaderScene, synth
+    from shaderflow_amd.audio import ShaderAudio
+    from shaderflow_amd.audio.spectrogram import ShaderSpectrogram
+    from shaderflow_amd.piano import PianoNote
+    from shaderflow_amd.tape import FrameTape
+    from tests.jit_host import HostFragment
+
+    pcm, sr = synth.sweep_clip(2.0, 44100), 44100
+    w, h, fps, frames, length = 96, 54, 60.0, 100, 0.5
+    width = int(length*fps)
+
+    class Scroller(ShaderScene):
+        def build(self):
+            super().build()
+            self.audio = ShaderAudio(scene=self, name="iAudio")
+            self.audio.load(samples=pcm, samplerate=sr)
+            self.spectrogram = ShaderSpectrogram(scene=self, audio=self.audio, length=length, smooth=smooth)
+            self.spectrogram.from_notes(start=PianoNote.from_frequency(20), end=PianoNote.from_frequency(14000), piano=True)
+            self.shader.fragment = SCROLL
+
+    probe = Scroller()
+    probe.initialize()
+    assert FrameTape.applicable(probe) and probe.spectrogram.length_samples == width
+    for ssaa in (1, 2):
+        kw = dict(width=w, height=h, fps=fps, time=frames/fps, ssaa=ssaa, output=bytes)
+        loop = np.frombuffer(Scroller().main(batch=False, **kw), np.uint8).reshape(frames, h, w, 3)
+        tape = np.frombuffer(Scroller().main(batch=None, **kw), np.uint8).reshape(frames, h, w, 3)
+        assert np.array_equal(loop, tape), lsb_report(tape, loop)
+        assert loop[-1].std() > 5
+
+    # replay of spectrogram.py:298-311 on the oracle's tape (ssaa 1 → final.glsl's 3x3 tent over the shaded frame)
+    planar = np.ascontiguousarray(pcm.T)
+    times, dts, rdts = O.clock(fps, frames)
+    _, tell = O.reader(rdts, sr, 2, planar.shape[1])
+    fmin, fmax, bins = O.from_notes(O.lib().sfo_note_of_frequency(20.0, 440.0), O.lib().sfo_note_of_frequency(14000.0, 440.0), True)
+    indptr, indices, data = O.filterbank(0, 0, fmin, fmax, bins, 12, sr)
+    spec = O.DynF32(2*bins, 4, 1, 0)
+    texture = np.zeros((bins, width, 2), np.float32)
+    host = HostFragment(glsl2hip.translate(SCROLL, [("sampler2D", "iSpectrogram")]), CACHE)
+    offset = 0
+    kw = dict(width=w, height=h, fps=fps, time=frames/fps, ssaa=1, output=bytes)
+    loop = np.frombuffer(Scroller().main(batch=False, **kw), np.uint8).reshape(frames, h, w, 3)
+    check = {0, 1, width - 2, width - 1, width, 59, 60, 61, frames - 1}
+    for k in range(frames):
+        offset = (offset + 1) % width
+        target = O.csr_dot(indptr, indices, data, O.fft_power(planar, int(tell[k])))
+        texture[:, offset, :] = spec.step(target.ravel(), abs(dts[k])).reshape(bins, 2)
+        if k not in check:
+            continue
+        u = O.default_uniforms(w, h, iTime=times[k], iTau=(times[k]/(frames/fps)) % 1.0, iDuration=frames/fps, iDeltatime=dts[k], iFramerate=fps,
+                               iFrame=round(times[k]*fps), iSubsample=2, iSpectrogramLength=width, iSpectrogramBins=bins, iSpectrogramSmooth=int(smooth),
+                               iSpectrogramOffset=offset/width)
+        host.set_uniforms(u)
+        host.bind("iSpectrogram", texture.copy(), "linear" if smooth else "nearest", True, False)
+        want = O.resolve(host.render(w, h), w, h, 2)
+        d = np.abs(loop[k].astype(int) - want.astype(int))
+        assert (d <= 1).mean() >= 0.999, (k, lsb_report(loop[k], want))
+
+
 def test_scene_with_its_own_fragment_through_the_frame_tape(gpu):
     """A stock scene with a fragment of its own batches through the clock tape (iTime/iFrame per frame on the device) like a registry
     fragment does: same bytes as the frame loop, fused and two-pass"""

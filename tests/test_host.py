@@ -159,6 +159,52 @@ def test_alias_install():
     assert shaderflow.resources.exists() and ShaderScene.__module__ == "shaderflow_amd.scene" and Uniform is not None
 
 
+def test_alias_covers_every_submodule_with_one_module_object():
+    """`shaderflow.<sub>` must be THE module `shaderflow_amd.<sub>` for every submodule (a second import under the alias
+    would duplicate classes: isinstance checks between the two copies fail)"""
+    import importlib
+    import pkgutil
+
+    import shaderflow_amd
+    shaderflow_amd.install_alias()
+    names = [m.name for m in pkgutil.walk_packages(shaderflow_amd.__path__, "shaderflow_amd.") if not m.name.endswith("libshaderflow_hip")]
+    assert {"shaderflow_amd.video", "shaderflow_amd.ffmpeg", "shaderflow_amd.exporting", "shaderflow_amd.piano.module"} <= set(names)
+    for real in names:
+        alias = "shaderflow" + real[len("shaderflow_amd"):]
+        assert importlib.import_module(alias) is importlib.import_module(real), real
+    with pytest.raises(ImportError):
+        importlib.import_module("shaderflow.no_such_module")
+
+
+REFERENCE_DEMO = Path("/root/reference/examples/basic/demo.py")
+
+
+@pytest.mark.skipif(not REFERENCE_DEMO.exists(), reason="the reference checkout is not present on this machine")
+def test_the_references_own_demo_imports_unchanged():
+    """The drop-in claim for examples/basic/demo.py: the reference's own file, read where it lies and executed unchanged under
+    install_alias(), defines its scenes on THIS package's classes (no GPU needed to import and subclass)"""
+    import importlib.util
+
+    import shaderflow_amd
+    shaderflow_amd.install_alias()
+    spec = importlib.util.spec_from_file_location("reference_demo", REFERENCE_DEMO)
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    from shaderflow_amd.scene import ShaderScene
+    scenes = [getattr(demo, n) for n in ("Basic", "ShaderToy", "MultiShader", "Multipass", "MotionBlur", "Dynamics", "Video", "Audio",
+                                         "Waveform", "MusicBars", "Visualizer", "RayMarch", "Life")]
+    assert all(issubclass(scene, ShaderScene) for scene in scenes)
+    assert demo.shaders == REFERENCE_DEMO.parent/"shaders"
+    # the lazy imports inside the scenes' build() methods resolve too (demo.py:134-137, 149-151, 164-166, 178-182, 196-200)
+    from shaderflow.audio import ShaderAudio                          # noqa: F401
+    from shaderflow.audio.spectrogram import ShaderSpectrogram        # noqa: F401
+    from shaderflow.audio.waveform import ShaderWaveform              # noqa: F401
+    from shaderflow.piano import PianoNote                            # noqa: F401
+    from shaderflow.video import ShaderVideo
+    import shaderflow_amd.video
+    assert ShaderVideo is shaderflow_amd.video.ShaderVideo
+
+
 def test_library_exports_every_declared_symbol():
     """include/shaderflow_hip.h ↔ libshaderflow_hip.so ↔ the ctypes prototype table"""
     from shaderflow_amd import _native as N

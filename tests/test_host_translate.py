@@ -84,8 +84,8 @@ def test_bindings_follow_the_pipeline_and_skip_what_the_fragment_does_not_read()
     assert translation.cpp.rstrip().endswith("SF_JIT_ENTRY_POINTS(sf::rt::Fragment)") and "#undef background" in translation.cpp
     matrix = G.translate("uniform mat3 iMatrix;\nvoid main() { fragColor = vec4(iMatrix[0], 1); }")
     assert [(b.name, b.slot, b.count) for b in matrix.bindings] == [("iMatrix", 0, 9)] and "iMatrix = mat3(user_(0), " in matrix.cpp
-    with pytest.raises(G.TranslationError):
-        G.translate("uniform float weights[4];\nvoid main() { fragColor = vec4(weights[0]); }")
+    with pytest.raises(G.TranslationError):                                        # 17 x 4 floats: more than the 64-float uniform block
+        G.translate("uniform vec4 weights[17];\nvoid main() { fragColor = weights[0]; }")
     with pytest.raises(G.TranslationError):
         G.translate("void main() { fragColor = " + " + ".join(f"texture(s{k}, stuv)" for k in range(17)) + "; }", [("sampler2D", f"s{k}") for k in range(17)])
 
@@ -126,6 +126,53 @@ def test_operators_and_methods_c_plus_plus_does_not_have():
     assert "(a && b) != c" in G.translate("void main() { bool a = true, b = false, c = true; fragColor = vec4(float((a && b) ^^ c)); }").cpp
     with pytest.raises(G.TranslationError):                                        # C++ has no operator between && and ||
         G.translate("void main() { bool a = true, b = false, c = true; fragColor = vec4(float(a && b ^^ c)); }")
+
+
+UNIFORM_OPTIONS = """
+const int TAPS = 3;
+uniform float gain = 0.5;
+uniform vec3 tint = vec3(1.0, 0.5, 0.25);
+uniform vec2 both = vec2(2);
+uniform int steps = 3;
+uniform bool enabled = true;
+uniform float weights[TAPS] = float[](0.25, 0.5, 0.125);
+uniform vec2 offsets[2];
+void main() {
+    float total = 0;
+    for (int k = 0; k < TAPS; k++) total += weights[k];
+    fragColor = vec4(tint*gain*both.x, total + offsets[1].y + float(steps) + (enabled ? 0.0625 : 0));
+}
+"""
+
+
+def test_uniform_initialisers_and_uniform_arrays():
+    """GLSL 3.30 §4.3.5: `uniform float gain = 0.5;` reads 0.5 until the host sets it; `uniform T a[N]` is bound element by element"""
+    translation = G.translate(UNIFORM_OPTIONS)
+    by_name = {b.name: b for b in translation.bindings}
+    assert by_name["gain"].default == (0.5,) and by_name["tint"].default == (1.0, 0.5, 0.25) and by_name["both"].default == (2.0, 2.0)
+    assert by_name["steps"].default == (3.0,) and by_name["steps"].integer and by_name["enabled"].default == (1.0,)
+    assert [by_name[f"weights[{k}]"].default for k in range(3)] == [(0.25,), (0.5,), (0.125,)] and by_name["weights[2]"].array == "weights"
+    assert by_name["offsets[1]"].default is None and by_name["offsets[1]"].count == 2 and by_name["offsets[1]"].slot == by_name["offsets[0]"].slot + 2
+    assert "float weights[3];" in translation.cpp and "vec2 offsets[2];" in translation.cpp
+    for bad in ("uniform float g = sqrt(2.0);\nvoid main() {}", "uniform float w[2] = float[](1.0);\nvoid main() {}",
+                "uniform vec3 t = 1.0;\nvoid main() {}", "uniform float m[2][2];\nvoid main() {}"):
+        with pytest.raises(G.TranslationError):
+            G.translate(bad)
+
+
+def test_uniform_initialisers_and_arrays_run_on_the_host():
+    import numpy as np
+
+    from tests.jit_host import HostFragment
+    host = HostFragment(G.translate(UNIFORM_OPTIONS), CACHE)
+    pixel = host.render_float(2, 2)[0, 0]
+    assert np.allclose(pixel, [1.0, 0.5, 0.25, 0.875 + 0.0 + 3.0 + 0.0625])            # initialisers only; offsets[] starts as zeros
+    host.set("gain", 1.0)
+    host.set("offsets", [[0.0, 0.0], [0.0, 8.0]])
+    host.set("weights", [1.0, 2.0, 3.0])
+    host.set("enabled", 0)
+    pixel = host.render_float(2, 2)[0, 0]
+    assert np.allclose(pixel, [2.0, 1.0, 0.5, 6.0 + 8.0 + 3.0])
 
 
 def test_fragments_that_take_derivatives_ask_for_the_quad_layout():

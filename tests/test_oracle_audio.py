@@ -58,6 +58,16 @@ def test_fft_power(golden, name):
     _power_close(O.fft_power(pcm, pcm.shape[1]), g[f"power_{name}"])
 
 
+@pytest.mark.parametrize("name", ["sine1k", "noise", "impulse"])
+def test_fft_amplitude(golden, name):
+    """FourierMagnitude.Amplitude (spectrogram.py:22-23) against vectors of the imported reference (options.npz)"""
+    g, o = golden("fft"), golden("options")
+    pcm = g[f"in_{name}"]
+    _power_close(O.fft_power(pcm, pcm.shape[1], amplitude=True), o[f"amplitude_{name}"])
+    long = g["in_noise_long"]
+    _power_close(O.fft_power(long, long.shape[1], fft_n=10, amplitude=True), o["amplitude_noise_n10"])
+
+
 def test_fft_sizes_and_windows(golden):
     g = golden("fft")
     pcm = g["in_noise_long"]
@@ -167,3 +177,15 @@ def test_waveform_reducers(golden):
     assert tell % 735 == 0
     assert np.allclose(O.waveform_row(pcm, tell, 735, 180, 1), g["wave_rms"], rtol=2e-6, atol=1e-9)
     assert np.allclose(O.waveform_row(pcm, tell, 735, 180, 2), g["wave_std"], rtol=3e-6, atol=1e-9)
+
+
+def test_dynamics_early_out_freezes_the_whole_array(golden):
+    """options.npz: a float32 (2, 24) system whose target is held until max|target - value| < 1e-6 (dynamics.py:222-225), from the
+    imported reference: the oracle freezes and resumes on the same frames, bit for bit"""
+    o = golden("options")
+    targets = o["hold_targets"].reshape(len(o["hold_dts"]), -1)
+    want = o["hold_values"].reshape(targets.shape)
+    system = O.DynF32(targets.shape[1], 4, 1, 0)
+    got = np.stack([system.step(targets[k], float(o["hold_dts"][k])).copy() for k in range(len(targets))])
+    assert np.array_equal(got, want)
+    assert np.array_equal(want[200], want[399]) and not np.array_equal(want[399], want[400])
