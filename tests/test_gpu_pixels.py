@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import binding as O
+from shaderflow_amd import _native as N
 from tests.helpers import Gpu, gpu_bind_all, lsb_report, oracle_textures, visualizer_inputs
 
 pytestmark = pytest.mark.gpu
