@@ -719,7 +719,7 @@ template <class SHADER> static int launch_fused_s(const RenderArgs& a, int ssaa,
 #define VIS_FAST 1
 #endif
 #ifndef VIS_FAST_PITCH
-#define VIS_FAST_PITCH 80
+#define VIS_FAST_PITCH 72
 #endif
 static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hipStream_t s) {
     constexpr int PITCH = VIS_FAST_PITCH, ROWS = 10, BLOCK_PX = 128;
