@@ -160,6 +160,26 @@ int sfx_ring_pipe_sync(sfx_handle ring, int slot);                              
 int sfx_ring_destroy(sfx_handle ring);
 
 /* ------------------------------------------------------------------------------------------------ */
+/* Cross-process frame queue of a sharded export (one process per GPU; no reference equivalent). The sink takes
+ * one byte stream, so one process owns it (rank 0) — but every rank reads its finished frames out over its OWN PCIe link into a
+ * POSIX shared-memory segment (`name` must start with '/'), and a writer thread in rank 0 hands them to the file descriptor in
+ * the order given to sfx_shm_drain. Per rank a ring of `slots` frames; sfx_shm_push blocks while the rank's ring is full.
+ * What turbopipe.pipe/sync (exporting.py:147-171) is to one process, this is to N. */
+int sfx_shm_create(sfx_handle ctx, const char* name, int rank, int world, size_t frame_bytes, int slots, sfx_handle* shm);
+/* The rank's next frame (device memory, complete on the context's stream when this call is made): asynchronous copy, published
+ * to the writer when it has landed. */
+int sfx_shm_push(sfx_handle shm, const void* device_ptr);
+/* Every frame pushed so far has left its device buffer and is visible to the writer. */
+int sfx_shm_flush(sfx_handle shm);
+/* The first `frames` frames this rank pushed have left their device buffers (a batch buffer may be rendered into again). */
+int sfx_shm_wait(sfx_handle shm, int64_t frames);
+/* Rank 0: start the writer. Frames are written to `fd` run by run: counts[k] frames of rank ranks[k], each rank's frames in the
+ * order that rank pushed them. */
+int sfx_shm_drain(sfx_handle shm, int fd, const int32_t* ranks, const int32_t* counts, int runs);
+int sfx_shm_drain_wait(sfx_handle shm);      /* the writer has written every run (or failed: SFX_E_IO) */
+int sfx_shm_destroy(sfx_handle shm);         /* unmaps; rank 0 also unlinks the segment */
+
+/* ------------------------------------------------------------------------------------------------ */
 /* Audio — replaces BrokenAudio's ring (audio/module.py:113-138), np.hanning/np.fft.rfft/csr.dot
  * (spectrogram.py:103,170,176), the waveform reduce (waveform.py:80-87) and RMS/std (audio/module.py:457-458).
  * In export mode the whole file is known, so the "ring" is the PCM itself, resident in HBM: the window
@@ -242,7 +262,8 @@ int sfx_tape_reset(sfx_handle tape);         /* ShaderDynamics.setup → reset (
 int sfx_tape_build(sfx_handle tape, int nframes, const int64_t* tell, const sfx_frame_clock* clock,
                    const sfx_dyn_coeff_f32* spectrogram, const sfx_dyn_coeff_f64* volume,
                    const sfx_dyn_coeff_f64* std);
-enum { SFX_TAPE_SPECTROGRAM = 0, SFX_TAPE_WAVEFORM = 1, SFX_TAPE_UNIFORMS = 2, SFX_TAPE_TARGETS = 3, SFX_TAPE_LOUDNESS = 4 };
+enum { SFX_TAPE_SPECTROGRAM = 0, SFX_TAPE_WAVEFORM = 1, SFX_TAPE_UNIFORMS = 2, SFX_TAPE_TARGETS = 3, SFX_TAPE_LOUDNESS = 4,
+       SFX_TAPE_SCROLL = 5 /* the scrolling texture as each frame sees it: [n][bins][length_samples][channels] f32 */ };
 /* Copies tape content to the host for inspection: SPECTROGRAM [n][bins][channels] f32, WAVEFORM
  * [n][points][channels] f32, UNIFORMS [n][8] f32 (iTime iTau iAudioVolume iAudioVolumeIntegral iAudioSTD
  * iSpectrogramOffset iFrame pad), TARGETS (unsmoothed) [n][bins][channels] f32, LOUDNESS [n][2] f32 */

@@ -18,7 +18,7 @@ OK = 0
 U8, F32, U16, F16 = 0, 1, 2, 3
 NEAREST, LINEAR = 0, 1
 T_FLOAT, T_INT, T_BOOL, T_VEC2, T_VEC3, T_VEC4, T_MAT2, T_MAT3, T_MAT4 = range(9)
-TAPE_SPECTROGRAM, TAPE_WAVEFORM, TAPE_UNIFORMS, TAPE_TARGETS, TAPE_LOUDNESS = range(5)
+TAPE_SPECTROGRAM, TAPE_WAVEFORM, TAPE_UNIFORMS, TAPE_TARGETS, TAPE_LOUDNESS, TAPE_SCROLL = range(6)
 E_UNSUPPORTED = -4
 
 Handle = C.c_uint64
@@ -94,6 +94,13 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_ring_pipe": (C.c_int, [Handle, C.c_int, C.c_int]),
     "sfx_ring_pipe_sync": (C.c_int, [Handle, C.c_int]),
     "sfx_ring_destroy": (C.c_int, [Handle]),
+    "sfx_shm_create": (C.c_int, [Handle, C.c_char_p, C.c_int, C.c_int, C.c_size_t, C.c_int, P(Handle)]),
+    "sfx_shm_push": (C.c_int, [Handle, C.c_void_p]),
+    "sfx_shm_flush": (C.c_int, [Handle]),
+    "sfx_shm_wait": (C.c_int, [Handle, C.c_int64]),
+    "sfx_shm_drain": (C.c_int, [Handle, C.c_int, P(C.c_int32), P(C.c_int32), C.c_int]),
+    "sfx_shm_drain_wait": (C.c_int, [Handle]),
+    "sfx_shm_destroy": (C.c_int, [Handle]),
     "sfx_audio_upload": (C.c_int, [Handle, P(C.c_float), C.c_int64, C.c_int, C.c_int, P(Handle)]),
     "sfx_audio_destroy": (C.c_int, [Handle]),
     "sfx_stft_plan": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_int32), P(C.c_int32), P(C.c_float), P(Handle)]),

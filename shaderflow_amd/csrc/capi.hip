@@ -11,6 +11,7 @@
 
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -45,7 +46,7 @@ extern "C" const char* sfx_version(void) { return "shaderflow_hip 0.2 (gfx950)";
 extern "C" uint64_t sfx_abi_layout(void);
 
 enum : uint32_t { MAGIC_CTX = 0x53465843, MAGIC_TEX = 0x53465854, MAGIC_PROG = 0x53465850, MAGIC_RING = 0x53465852,
-                  MAGIC_AUDIO = 0x53465841, MAGIC_PLAN = 0x5346584c, MAGIC_TAPE = 0x53465854 + 0x100 };
+                  MAGIC_AUDIO = 0x53465841, MAGIC_PLAN = 0x5346584c, MAGIC_TAPE = 0x53465854 + 0x100, MAGIC_SHM = 0x53465853 };
 
 struct Object { uint32_t magic; };
 
@@ -590,7 +591,8 @@ static void note_kernel(const char* pretty, const char* kernel, int ssaa = 0) {
     std::string text(pretty);
     const size_t at = text.find("SHADER = ");
     std::string shader = at == std::string::npos ? text : text.substr(at + 9);
-    const size_t end = shader.find_first_of(";]");
+    size_t end = shader.find(", S = ");                             // "[SHADER = …, S = 2]" / "[SHADER = …]"
+    if (end == std::string::npos) end = shader.find_first_of(";]");
     if (end != std::string::npos) shader.resize(end);
     for (size_t k; (k = shader.find("sf::")) != std::string::npos; ) shader.erase(k, 4);
     g_last_kernel = std::string(kernel) + "<" + shader + (ssaa ? ", " + std::to_string(ssaa) : std::string()) + ">";
@@ -1138,6 +1140,8 @@ extern "C" int sfx_ring_destroy(sfx_handle h) {
     return SFX_OK;
 }
 
+#include "shm_ring.inc"
+
 // ---------------------------------------------------------------------------------------------------------
 // Audio
 
@@ -1579,6 +1583,9 @@ extern "C" int sfx_tape_read(sfx_handle h, int what, int frame0, int nframes, vo
         case SFX_TAPE_UNIFORMS: src = (const char*)t->d_dyn; per = sizeof(FrameDyn); break;
         case SFX_TAPE_TARGETS: src = (const char*)t->d_targets; per = sizeof(float)*t->n; break;
         case SFX_TAPE_LOUDNESS: src = (const char*)t->d_loudness; per = sizeof(float)*2; break;
+        case SFX_TAPE_SCROLL:
+            if (t->width <= 1) return fail(SFX_E_INVALID, "the tape has no scrolling spectrogram (length_samples <= 1)");
+            src = (const char*)t->d_scroll; per = sizeof(float)*t->n*t->width; break;
         default: return fail(SFX_E_INVALID, "tape section %d", what);
     }
     if (nbytes != per*nframes) return fail(SFX_E_INVALID, "tape read of %zu bytes, section needs %zu", nbytes, per*nframes);

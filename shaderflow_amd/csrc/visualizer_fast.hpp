@@ -203,7 +203,7 @@ struct VisualizerFast {
         const int p = tid >> 2, sub = tid & 3;
         const int px = bx*BLOCK_PX + p, py = by;
         const bool valid = (px < a.w) && (py < a.h);
-        const int i = min(px, a.w - 1)*S + (sub & 1), j = py*S + (sub >> 1);
+        const int i = min(px, a.w - 1)*S + (sub & 1);
 
         const int4 wx = t.block_x[(long)frame*t.blocks_x + bx], wy = t.block_y[(long)frame*t.blocks_y + by];
         const Tex& bg = a.tex[TEX_BACKGROUND];

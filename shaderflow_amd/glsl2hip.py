@@ -520,8 +520,10 @@ class _Translator:
                 continue                                           # inactive uniform: the driver would have removed it as well
             seen.add(name)
             if type_ == "sampler2D":
-                if name in FIXED_SAMPLER_SLOTS:
-                    slot = FIXED_SAMPLER_SLOTS[name]
+                # the engine names a texture's newest box `<name>0x0` (texture.py:346-347) and #defines the plain name to it
+                plain = name[:-3] if name.endswith("0x0") else name
+                if plain in FIXED_SAMPLER_SLOTS:
+                    slot = FIXED_SAMPLER_SLOTS[plain]
                 elif free_samplers:
                     slot = free_samplers.pop(0)
                 else:

@@ -1,18 +1,36 @@
 """
-Multi-GPU offline export: contiguous frame ranges per rank + gather of finished frames to the encoding rank.
+Multi-GPU offline export (one process per GPU; the reference is single-process).
 
-The reference is single-process; this is the sharded export of the north star. One process per GPU
-(`torch.distributed`, backend "nccl" = RCCL on ROCm; "gloo" on CPU for the tests). Frames are independent once the
-audio tape is known, except for the DynamicNumber recurrences, which every rank replays from frame 0 on its own
-device (a few kernels over ~1 KB per frame: far cheaper than communicating state and bit-identical by
-construction). The only exchange step is the gather of finished RGB8 frames to rank 0, which owns the encoder
-pipe: `dist.gather` is a group of point-to-point sends, so on MI355X's fully connected xGMI every peer streams
-over its own link to rank 0 (no ring, nothing to bucket). The gather of batch i is asynchronous and overlaps the
-render of batch i+1 (two alternating frame buffers per rank).
+Frames are independent once the audio tape is known, except for the DynamicNumber recurrences, which every rank replays on
+its own device (a few kernels over ~1 KB per frame: far cheaper than communicating state, bit-identical by construction).
+What is left to decide is how the finished RGB8 frames reach the ONE process that owns the sink (rank 0). Two modes
+(`SHADERFLOW_SHARD`, default "host"):
+
+* **device** — the north star's design: every rank renders ONE CONTIGUOUS frame range (`shard_frames`) into HBM — a whole
+  60 s 4K export is 89.6 GB of RGB8, an eighth of it 11.2 GB: resident, not streamed — and sends it chunk by chunk to rank 0
+  (`RangeTransfer`: grouped point-to-point sends = the RCCL gather; on the fully connected xGMI fabric every peer has its own
+  link to rank 0, ≈ 45 GB/s each against 24.9 MB x frames/s per rank: nothing to bucket). The frames then sit in rank 0's HBM;
+  to reach a HOST sink they all cross rank 0's single PCIe link: ceiling ≈ 55 GB/s / 24.9 MB ≈ 2 200 frames/s at 4K whatever N is.
+* **host** — every rank reads its finished frames out over ITS OWN PCIe link into a shared-memory ring and rank 0's native
+  writer thread interleaves them in frame order (`HostDelivery`, csrc/shm_ring.inc): no collective on the data path, ceiling
+  N x min(render, PCIe) until the sink or host memory bandwidth binds. Here batches alternate between the ranks (batch b on
+  rank b % N): the sink consumes in frame order, so with contiguous ranges only one rank's link would be busy at a time unless
+  whole ranges were buffered on the host; alternating batches keep every link busy with two batches of host ring per rank.
+
+torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the tests) provides rendezvous, barriers and the device-mode sends.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
+
+
+def shard_mode() -> str:
+    """How a sharded export delivers frames to the sink's process: "host" (per-rank PCIe + shared memory) or "device" (RCCL)"""
+    mode = os.environ.get("SHADERFLOW_SHARD", "host").strip().lower()
+    if mode not in ("host", "device"):
+        raise ValueError(f"SHADERFLOW_SHARD={mode!r}: expected 'host' or 'device'")
+    return mode
 
 
 def rank_world() -> tuple[int, int]:
@@ -164,3 +182,155 @@ def sharded_frame_loop(world: int, rank: int, batches: list[tuple[int, int]], mo
             step(first + i, modes[first + i], buffer, i*frame_bytes)
 
     round_robin_export(world, rank, batches, advance, lambda count, buffer: finish_batch(), emit, gather, buffers, frame_bytes)
+
+
+# ---- host mode: per-rank read-out into shared memory -------------------------------------------------------------------------
+
+class HostDelivery:
+    """This rank's end of the cross-process frame queue (csrc/shm_ring.inc): `push` frames in the order this rank finishes them;
+    rank 0 also starts the writer, which hands the frames of all ranks to `fileno` in the order `runs` = [(rank, count), …]."""
+
+    def __init__(self, context, world: int, rank: int, frame_bytes: int, slots: int, fileno: Optional[int], runs: list[tuple[int, int]]):
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        from shaderflow_amd import _native as N
+        self.N, self.C = N, C
+        self.rank, self.world, self.frame_bytes, self.pushed = rank, world, frame_bytes, 0
+        name = [f"/shaderflow-{os.getpid()}-{id(self) & 0xffffff:x}"]
+        if world > 1:
+            dist.broadcast_object_list(name, src=0)                 # one segment name for the group
+        self.handle = N.Handle()
+        N.check(N.lib().sfx_shm_create(context.handle, name[0].encode(), rank, world, frame_bytes, slots, C.byref(self.handle)))
+        if rank == 0:
+            ranks = (C.c_int32*max(1, len(runs)))(*[r for r, _ in runs])
+            counts = (C.c_int32*max(1, len(runs)))(*[c for _, c in runs])
+            N.check(N.lib().sfx_shm_drain(self.handle, -1 if fileno is None else fileno, ranks, counts, len(runs) if fileno is not None else 0))
+
+    def push(self, pointer: int, count: int) -> None:
+        for i in range(count):
+            self.N.check(self.N.lib().sfx_shm_push(self.handle, self.C.c_void_p(pointer + i*self.frame_bytes)))
+        self.pushed += count
+
+    def wait(self, frames: int) -> None:
+        """The first `frames` frames pushed by this rank have left their device buffers"""
+        self.N.check(self.N.lib().sfx_shm_wait(self.handle, frames))
+
+    def finish(self) -> None:
+        import torch.distributed as dist
+        try:
+            self.N.check(self.N.lib().sfx_shm_flush(self.handle))
+            if self.rank == 0:
+                self.N.check(self.N.lib().sfx_shm_drain_wait(self.handle))
+        finally:
+            if self.world > 1:
+                dist.barrier()                                      # nobody unmaps while the writer still reads
+            self.N.lib().sfx_shm_destroy(self.handle)
+
+
+def interleaved_runs(world: int, batches: list[tuple[int, int]]) -> list[tuple[int, int]]:
+    """The sink's order for batches alternating between the ranks: (owner, count) per batch"""
+    return [(index % world, count) for index, (_, count) in enumerate(batches)]
+
+
+def interleaved_host_export(world: int, rank: int, batches: list[tuple[int, int]], advance, render, delivery, buffers: list) -> None:
+    """Host mode: batch b is rendered by rank b % world into one of its `buffers` and pushed to the delivery queue; every rank
+    ADVANCES through every batch (recurrences). A buffer is rendered into again only when the frames it held have left it.
+
+        advance(first, count, buffer)   the tape / host state of those frames (all ranks, all batches; `buffer` is None for batches
+                                        of other ranks — frame-loop scenes shade their own frames into it while they step)
+        render(count, buffer)           render them into `buffer` (the owner), asynchronously on the context's stream
+        delivery.push(buffer, count) / delivery.wait(frames)
+    """
+    marks: list[int] = []                                            # frames pushed after each of this rank's batches
+    for index, (first, count) in enumerate(batches):
+        if index % world != rank:
+            advance(first, count, None)
+            continue
+        mine = len(marks)
+        if mine >= len(buffers):
+            delivery.wait(marks[mine - len(buffers)])               # the batch that last lived in this buffer has been copied out
+        buffer = buffers[mine % len(buffers)]
+        advance(first, count, buffer)
+        render(count, buffer)
+        delivery.push(buffer, count)
+        marks.append(delivery.pushed)
+
+
+# ---- device mode: contiguous ranges, resident in HBM, sent to rank 0 ---------------------------------------------------------
+
+class RangeTransfer:
+    """Point-to-point transfer of frame chunks to rank 0 (RCCL send/recv; staged through host memory under gloo, which has no
+    device transport — tests with several processes on one GPU). Rank 0 posts every receive up front, into the places of its
+    resident buffer where the frames belong; a rank's chunks arrive in the order it sends them."""
+
+    def __init__(self, world: int, rank: int, device):
+        import torch
+        import torch.distributed as dist
+        self.world, self.rank = world, rank
+        self.device = torch.device(device)
+        self.staged = (dist.get_backend() == "gloo") and (self.device.type != "cpu")
+        self.works: dict[tuple[int, int], tuple] = {}               # (source rank, chunk) → (work, staging tensor or None, target view)
+        self.sent: list = []
+
+    def expect(self, source: int, chunk: int, view) -> None:
+        """Rank 0: chunk `chunk` of rank `source` lands in `view` (a slice of the resident buffer)"""
+        import torch
+        import torch.distributed as dist
+        stage = torch.empty(view.numel(), dtype=view.dtype) if self.staged else None
+        work = dist.irecv(stage if self.staged else view, src=source)
+        self.works[(source, chunk)] = (work, stage, view)
+
+    def send(self, view) -> None:
+        import torch.distributed as dist
+        tensor = view.cpu() if self.staged else view
+        self.sent.append((dist.isend(tensor, dst=0), tensor))
+
+    def arrived(self, source: int, chunk: int) -> None:
+        """Rank 0: block until that chunk is in place"""
+        work, stage, view = self.works.pop((source, chunk))
+        work.wait()
+        if stage is not None:
+            view.copy_(stage)
+        if self.device.type != "cpu":
+            import torch
+            torch.cuda.current_stream(self.device).synchronize()    # RCCL's wait only orders torch's stream; the read-out ring has its own
+
+    def finish(self) -> None:
+        for work, _ in self.sent:
+            work.wait()
+        self.sent.clear()
+
+
+def contiguous_device_export(world: int, rank: int, total: int, batch: int, frame_bytes: int, advance, render, emit, resident, transfer: "RangeTransfer") -> None:
+    """Device mode: rank r renders frames shard_frames(total, world, r) into `resident` and sends them to rank 0.
+
+        advance(first, count)            tape / host state (a rank replays everything before its range without rendering)
+        render(first, count, view)       render those frames into `view` (a slice of `resident`), complete when it returns
+        emit(view, count)                rank 0: hand `count` frames to the sink
+        resident                         rank 0: uint8 tensor of total*frame_bytes; other ranks: of their own range
+    """
+    ranges = [shard_frames(total, world, r) for r in range(world)]
+    first, last = ranges[rank]
+    if rank == 0:
+        for source in range(1, world):
+            for chunk, (f, c) in enumerate(shard_batches(*ranges[source], batch)):
+                transfer.expect(source, chunk, resident[f*frame_bytes:(f + c)*frame_bytes])
+    for f, c in shard_batches(0, first, batch):
+        advance(f, c)                                               # the recurrences up to this rank's first frame
+    base = 0 if rank == 0 else first
+    for f, c in shard_batches(first, last, batch):
+        advance(f, c)
+        view = resident[(f - base)*frame_bytes:(f - base + c)*frame_bytes]
+        render(f, c, view)
+        if rank == 0:
+            emit(view, c)
+        else:
+            transfer.send(view)
+    if rank == 0:
+        for source in range(1, world):
+            for chunk, (f, c) in enumerate(shard_batches(*ranges[source], batch)):
+                transfer.arrived(source, chunk)
+                emit(resident[f*frame_bytes:(f + c)*frame_bytes], c)
+    transfer.finish()

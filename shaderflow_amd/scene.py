@@ -376,7 +376,8 @@ class ShaderScene(ShaderModule):
         """Multi-GPU export of a frame-loop scene (python logic between frames, layered/temporal textures): every rank steps
         through all frames so that host state stays in lock step, launches shaders only for its own batches and their
         warm-up, and rank 0 receives the finished frames in order (parallel.sharded_frame_loop)."""
-        from shaderflow_amd.parallel import FrameGather, frame_modes, shard_batches, sharded_frame_loop
+        from shaderflow_amd.parallel import (FrameGather, HostDelivery, frame_modes, interleaved_host_export, interleaved_runs, shard_batches,
+                                             shard_mode, sharded_frame_loop)
         total = export.total_frames
         frame_bytes = self.width*self.height*3
         batches = shard_batches(0, total, batch)
@@ -387,6 +388,32 @@ class ShaderScene(ShaderModule):
         modes = frame_modes(batches, world, rank, warmup)
         context = self.context
         distributed = rank_world()[1] > 1
+        if distributed and shard_mode() == "host":
+            # every rank reads the frames of its own batches out over its own PCIe link into shared memory; rank 0's writer thread
+            # hands them to the sink in frame order (parallel.HostDelivery)
+            import os
+            slots = int(os.environ.get("SHADERFLOW_SHM_SLOTS", 0)) or max(4, min(2*batch, (4 << 30)//frame_bytes))
+            delivery = HostDelivery(context, world, rank, frame_bytes, slots, export.fileno if rank == 0 else None, interleaved_runs(world, batches))
+            pointers = [context.alloc(frame_bytes*batch) for _ in range(2)]
+
+            def advance(first: int, count: int, pointer) -> None:
+                for i in range(count):
+                    mode = modes[first + i]
+                    self._skip_render = (mode == 0)
+                    self._one_frame()
+                    if mode == 2:
+                        context.copy(pointer + i*frame_bytes, self._final.texture.texture.device_ptr(), frame_bytes)
+
+            try:
+                interleaved_host_export(world, rank, batches, advance, lambda count, pointer: None, delivery, pointers)
+            finally:
+                self._skip_render = False
+                delivery.finish()
+                context.synchronize()
+                for pointer in pointers:
+                    context.free(pointer)
+            export.frame = total
+            return export.finish()
         if distributed:
             import torch
             device = torch.device("cuda", context.device)

@@ -199,6 +199,7 @@ class FrameTape:
             N.TAPE_SPECTROGRAM: (count, bins, channels), N.TAPE_TARGETS: (count, bins, channels),
             N.TAPE_WAVEFORM: (count, self.waveform._points if self.waveform is not None else 1, channels),
             N.TAPE_UNIFORMS: (count, 8), N.TAPE_LOUDNESS: (count, 2),
+            N.TAPE_SCROLL: (count, bins, self.spectrogram.length_samples if self.spectrogram is not None else 1, channels),
         }
         out = np.zeros(shapes[what], np.float32)
         N.check(N.lib().sfx_tape_read(self.handle, what, first_slot, count, out.ctypes.data, out.nbytes))
@@ -207,9 +208,11 @@ class FrameTape:
     # whole export ---------------------------------------------------------------------------------------------------
 
     def export(self, export: "ExportingHelper", turbo: bool = True):
-        """The whole export. With an initialised torch.distributed process group (one process per GPU) the batches are
-        rendered round-robin by the ranks and gathered to rank 0, which owns the sink (parallel.round_robin_export)."""
-        from shaderflow_amd.parallel import FrameGather, rank_world, round_robin_export, shard_batches
+        """The whole export. With an initialised torch.distributed process group (one process per GPU) the frames are sharded over
+        the ranks and delivered to rank 0, which owns the sink: per-rank read-out into shared memory ("host", the default) or
+        contiguous HBM-resident ranges sent over RCCL ("device") — shaderflow_amd/parallel.py."""
+        from shaderflow_amd.parallel import (HostDelivery, RangeTransfer, contiguous_device_export, interleaved_host_export, interleaved_runs,
+                                             rank_world, shard_batches, shard_frames, shard_mode)
         scene = self.scene
         total = export.total_frames
         rank, world = rank_world()
@@ -249,22 +252,40 @@ class FrameTape:
                     context.synchronize()
                     for pointer in buffers:
                         context.free(pointer)
+            elif shard_mode() == "host":
+                # every rank reads its own batches out over its own PCIe link into shared memory; rank 0's writer thread hands
+                # them to the sink in frame order (parallel.HostDelivery): no collective on the data path
+                slots = int(os.environ.get("SHADERFLOW_SHM_SLOTS", 0)) or max(4, min(2*self.batch, (4 << 30)//frame_bytes))
+                delivery = HostDelivery(context, world, rank, frame_bytes, slots, export.fileno if rank == 0 else None,
+                                        interleaved_runs(world, batches))
+                buffers = [context.alloc(frame_bytes*self.batch) for _ in range(2)]
+                try:
+                    interleaved_host_export(world, rank, batches, lambda first, count, buffer: self.build(first, count), self.render, delivery, buffers)
+                finally:
+                    delivery.finish()
+                    context.synchronize()
+                    for pointer in buffers:
+                        context.free(pointer)
+                export.frame = total
             else:
+                # the north star's layout: one contiguous frame range per rank, resident in HBM, sent to rank 0 over RCCL
                 import torch
                 device = torch.device("cuda", context.device)
-                buffers = [torch.zeros(frame_bytes*self.batch, dtype=torch.uint8, device=device) for _ in range(2)]
+                first, last = shard_frames(total, world, rank)
+                frames_here = total if rank == 0 else (last - first)
+                resident = torch.zeros(max(1, frames_here)*frame_bytes, dtype=torch.uint8, device=device)
                 torch.cuda.synchronize(device)                  # the fill runs on torch's stream, the renders on the context's
-                gather = FrameGather(world, rank, frame_bytes*self.batch, device)
+                transfer = RangeTransfer(world, rank, device)
 
-                def render(count, buffer):
-                    self.render(count, buffer.data_ptr())
-                    context.synchronize()                       # the context's stream is not torch's: order before the gather
+                def render(first_frame, count, view):
+                    self.render(count, view.data_ptr())
+                    context.synchronize()                       # the context's stream is not torch's: complete before the send
 
-                def emit(buffer, count):                        # rank 0: `buffer` is a gathered batch, overwritten by a later gather
-                    emit_frames(buffer.data_ptr(), count)
-                    export.drain()
+                def emit(view, count):
+                    emit_frames(view.data_ptr(), count)
 
-                round_robin_export(world, rank, batches, self.build, render, emit, gather, buffers, frame_bytes)
+                contiguous_device_export(world, rank, total, self.batch, frame_bytes, self.build, render, emit, resident, transfer)
+                export.drain()                                  # `resident` outlives the queued reads
                 if rank != 0:
                     export.frame = total
             scene.time, scene.dt, scene.rdt = self.times[-1], self.dts[-1], self.dts[-1]      # clock of the last frame

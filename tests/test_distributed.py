@@ -207,3 +207,102 @@ def test_sharded_frame_loop_over_gloo(total, batch, warmup):
         p.join(timeout=30)
         assert p.exitcode == 0
     assert emitted == list(range(total))
+
+
+# ---- the two delivery modes of the sharded export (parallel.py) -------------------------------------------------------------------
+
+def _device_mode_worker(rank: int, world: int, port: int, total: int, batch: int, out):
+    """contiguous_device_export over gloo with stand-in renders: rank r renders shard_frames(total, world, r) into a resident buffer,
+    sends it to rank 0 chunk by chunk (RangeTransfer: isend/irecv), rank 0 emits every frame in order"""
+    from shaderflow_amd.parallel import RangeTransfer, contiguous_device_export
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frame_bytes = 8
+        first, last = shard_frames(total, world, rank)
+        resident = torch.zeros((total if rank == 0 else max(1, last - first))*frame_bytes, dtype=torch.uint8)
+        state = {"seen": 0}
+        rendered, emitted = [], []
+
+        def advance(f, c):
+            assert f == state["seen"], (rank, f, state["seen"])                        # the recurrences see every frame up to the range's end, in order
+            state["seen"] += c
+
+        def render(f, c, view):
+            rendered.extend(range(f, f + c))
+            view[:] = torch.arange(f, f + c, dtype=torch.int64).view(torch.uint8)
+
+        def emit(view, c):
+            emitted.extend(np.frombuffer(view.numpy().tobytes(), np.int64).tolist())
+
+        contiguous_device_export(world, rank, total, batch, frame_bytes, advance, render, emit, resident, RangeTransfer(world, rank, torch.device("cpu")))
+        assert rendered == list(range(first, last)) and state["seen"] == last          # ONE contiguous range per rank, nothing beyond it
+        if rank == 0:
+            out.put(emitted)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("total,batch", [(50, 8), (64, 8), (7, 4), (3, 4)])
+def test_contiguous_device_export_over_gloo(total, batch):
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_device_mode_worker, args=(r, world, port, total, batch, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    emitted = out.get(timeout=90)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert emitted == list(range(total))
+
+
+class _RecordingDelivery:
+    """Stand-in for HostDelivery: records what a rank pushes and checks the buffer-reuse fence"""
+
+    def __init__(self):
+        self.pushed, self.frames, self.waited, self.live = 0, [], [], {}
+
+    def push(self, buffer, count):
+        assert id(buffer) not in self.live, "a buffer was rendered into again before its frames were waited for"
+        self.live[id(buffer)] = self.pushed + count
+        self.frames.extend(buffer[:count])
+        self.pushed += count
+
+    def wait(self, frames):
+        self.waited.append(frames)
+        self.live = {key: mark for key, mark in self.live.items() if mark > frames}
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("total,batch", [(50, 8), (16, 8), (5, 8)])
+def test_interleaved_host_export_orders_frames_and_fences_buffers(world, total, batch):
+    """Host mode: batch b on rank b % world, two buffers per rank; the writer's run list reassembles 0..total-1"""
+    from shaderflow_amd.parallel import interleaved_host_export, interleaved_runs
+    batches = shard_batches(0, total, batch)
+    per_rank = []
+    for rank in range(world):
+        delivery, advanced, current = _RecordingDelivery(), [], {}
+        buffers = [[None]*batch, [None]*batch]
+
+        def advance(first, count, buffer, advanced=advanced, current=current):
+            advanced.append((first, count, buffer is not None))
+            current["first"] = first
+
+        def render(count, buffer, current=current):
+            buffer[:count] = range(current["first"], current["first"] + count)
+
+        interleaved_host_export(world, rank, batches, advance, render, delivery, buffers)
+        assert [(f, c) for f, c, _ in advanced] == batches                              # every rank advances through every batch, in order
+        assert [own for _, _, own in advanced] == [index % world == rank for index in range(len(batches))]
+        per_rank.append(delivery.frames)
+    taken, order = [0]*world, []
+    for owner, count in interleaved_runs(world, batches):                               # what rank 0's writer does with the rings
+        order.extend(per_rank[owner][taken[owner]:taken[owner] + count])
+        taken[owner] += count
+    assert order == list(range(total))

@@ -31,9 +31,10 @@ def _build(name: str):
 KW = {"Visualizer": dict(width=96, height=54, fps=60.0, ssaa=2, time=130/60), "MotionBlur": dict(width=64, height=36, fps=30.0, ssaa=1, time=70/30)}
 
 
-def _rank(rank: int, world: int, port: int, name: str, path: str, top_down=None):
+def _rank(rank: int, world: int, port: int, name: str, path: str, top_down=None, mode="host"):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", RANK=str(rank), WORLD_SIZE=str(world), SHADERFLOW_SHARD=mode,
+                      SHADERFLOW_SHM_SLOTS="5")                       # fewer ring slots than a batch: the back-pressure path runs too
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         _build(name).main(output=path, top_down=top_down, **KW[name])
@@ -43,9 +44,13 @@ def _rank(rank: int, world: int, port: int, name: str, path: str, top_down=None)
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("mode", ["host", "device"])
 @pytest.mark.parametrize("name,top_down", [("Visualizer", None), ("MotionBlur", None), ("Visualizer", True), ("MotionBlur", True)])
-def test_two_ranks_on_one_gpu_reproduce_the_single_process_export(tmp_path, name, top_down):
-    """`top_down=True`: the row order an ffmpeg sink asks for must reach EVERY rank, not only the one that owns the sink
+def test_two_ranks_on_one_gpu_reproduce_the_single_process_export(tmp_path, name, top_down, mode):
+    """Both delivery modes of the sharded export (parallel.py): "host" = every rank reads its own batches out into the shared-memory
+    ring and rank 0's writer thread interleaves them; "device" = contiguous HBM-resident ranges sent to rank 0 (tape scenes) /
+    gathered rounds (frame-loop scenes).
+    `top_down=True`: the row order an ffmpeg sink asks for must reach EVERY rank, not only the one that owns the sink
     (a rank that missed it would deliver its batches upside down)"""
     whole = _build(name).main(output=bytes, top_down=top_down, **KW[name])
     if top_down:
@@ -54,7 +59,7 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_export(tmp_path, name
     path = str(tmp_path/"sharded.rgb")
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, name, path, top_down)) for r in range(2)]
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, name, path, top_down, mode)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

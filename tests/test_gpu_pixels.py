@@ -319,7 +319,7 @@ def test_full_size_properties_8k_ssaa4(gpu):
     gpu.set_uniforms(prog, u)
     gpu_bind_all(gpu, prog, arrays, params)
     a = gpu.render_resolve(prog, w, h, ssaa, 2)
-    assert _last_kernel(gpu) == "k_render_resolve<VisualizerShader<80, 10, 6, 1, 1, 128, 128, 2>, 4>", _last_kernel(gpu)
+    assert _last_kernel(gpu) == "k_render_resolve<VisualizerShader<80, 10, 6>, 4>", _last_kernel(gpu)
     b = gpu.render_resolve(prog, w, h, ssaa, 2)
     assert np.array_equal(a, b)
     for rows in ((0, 1), (2159, 2161), (4319, 4320)):

@@ -82,6 +82,10 @@ def test_bindings_follow_the_pipeline_and_skip_what_the_fragment_does_not_read()
     assert by_name["iCount"].integer and by_name["iFlag"].integer and not by_name["iGain"].integer
     assert "iCount = user_int_(1);" in translation.cpp and "iFlag = user_int_(2) != 0;" in translation.cpp
     assert translation.cpp.rstrip().endswith("SF_JIT_ENTRY_POINTS(sf::rt::Fragment)") and "#undef background" in translation.cpp
+    # the names a scene's pipeline really carries: `<name>0x0` boxes behind `#define <name> <name>0x0` keep the tape's slots too
+    real = G.translate("#define iSpectrogram iSpectrogram0x0\n#define iWaveform iWaveform0x0\nvoid main() { fragColor = texture(iSpectrogram, astuv) + texture(iWaveform, astuv); }",
+                       [("sampler2D", "iWaveform0x0"), ("sampler2D", "iSpectrogram0x0")])
+    assert {b.name: b.slot for b in real.bindings} == {"iSpectrogram0x0": 1, "iWaveform0x0": 2}
     matrix = G.translate("uniform mat3 iMatrix;\nvoid main() { fragColor = vec4(iMatrix[0], 1); }")
     assert [(b.name, b.slot, b.count) for b in matrix.bindings] == [("iMatrix", 0, 9)] and "iMatrix = mat3(user_(0), " in matrix.cpp
     with pytest.raises(G.TranslationError):                                        # 17 x 4 floats: more than the 64-float uniform block
