@@ -6,20 +6,28 @@ bench.py — frames/s of the music-visualizer export path on MI355X.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N … bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json metric config, `configs[2]`): Visualizer scene, 3840x2160, 2x SSAA, subsample 2, 60 fps,
-synthetic 60 s 44.1 kHz stereo sine sweep, synthetic 1920x1080 background; inputs resident in HBM before timing.
-One STEP = one batch of 60 frames (1 s of video) through the whole hot path on every rank: STFT of the 60 frames →
-filterbank (MFMA) → DynamicNumber scan → waveform/loudness → 60 fused fragment+SSAA-resolve frames written as
-RGB8 into a device frame buffer; with N > 1 ranks every rank renders its own batch (weak scaling) and the
-finished frames are gathered to rank 0 over RCCL/xGMI (the encoder-side rank of the sharded export), the gather
-of step i overlapping the render of step i+1.
+synthetic 44.1 kHz stereo sine sweep, synthetic 1920x1080 background; inputs resident in HBM before timing.
+One STEP = one batch of 60 frames (1 s of video) through the whole hot path: STFT of the 60 frames → filterbank →
+DynamicNumber scan → waveform/loudness → per-frame column/row tables → 60 fused fragment+SSAA-resolve frames written as
+RGB8 into a device frame buffer.
+
+N > 1 (one rank per GPU, weak scaling): rank r renders ITS OWN contiguous range of the clip — frames
+[r*(W+K)*60, (r+1)*(W+K)*60) — after replaying the DynamicNumber recurrences of everything before it (untimed set-up, as
+in the sharded export's device mode, shaderflow_amd/parallel.py), and every finished step is sent to rank 0 over
+RCCL/xGMI (grouped point-to-point = the gather of the north star), the transfer of step i overlapping the render of
+step i+1. `value` = frames of all ranks / max-over-ranks time: frames resident in rank 0's HBM.
 
 Prints ONE JSON line (rank 0): value = frames/s of the whole job, plus
-  roofline     — the fused fragment kernel: algorithmic bytes per launch (315.2 MB per frame x
-                 frames per launch) over its mean duration, measured with HIP events on the launch stream
-                 inside the timed region, against the 8 TB/s HBM peak; the kernel is FP32-VALU bound,
-                 so the achieved instruction-lane rate is reported next to it under "valu";
-  cpu_baseline — the oracle (kind "port": plain-C restatement of the reference path) on the host cores of this
-                 box over a bounded band of the same frame, rank 0 at N = 1 only.
+  roofline     — the dominant kernel (named by the library: sfx_last_kernel). It is bound by VALU issue and LDS bandwidth, not
+                 by HBM, so `bound` is "valu": achieved = instruction lanes per second from the launch time measured HERE (HIP
+                 events on the launch stream inside the timed region) x the instructions per supersample rocprofv3 counted for
+                 THIS build (profiles/*.json, checked against the library's source fingerprint — stale counters are dropped,
+                 loudly). The HBM view the contract asks for sits beside it under `hbm`: algorithmic bytes over
+                 the same launch time, and `traffic` = measured FETCH_SIZE + WRITE_SIZE per launch from the same profile.
+  cpu_baseline — the oracle (kind "port": plain-C restatement of the reference path) on the host cores of this box, all cores
+                 and one thread, over bands of three frames of the same workload; rank 0 at N = 1 only, BEFORE the timed region.
+  export_host  — the same frames through a real export to /dev/null including the read-out to host memory (N = 1: pinned ring
+                 + writer thread; N > 1: every rank over its own PCIe link into the shared-memory ring, "host" mode).
 """
 from __future__ import annotations
 
@@ -36,12 +44,9 @@ sys.path.insert(0, str(ROOT))
 B_ALG_PER_FRAME = {  # iScreen write + resolve read + iFinal write + read-out read, bytes
     (3840, 2160, 2): 315.2e6, (1920, 1080, 1): 29.0e6, (256, 256, 1): 0.92e6, (7680, 4320, 4): 4445.8e6,
 }
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 256*4*32*2.4e9    # 256 CU x 4 SIMD32 x 2.4 GHz = 78.6e12 lane-instructions/s (157.3 TFLOP/s FMA)
-# From profiles/r01_rocprofv3_bench_c3_summary.txt (rocprofv3 --pmc, separate passes, same command):
-PROFILE = {"file": "profiles/r01_rocprofv3_bench_c3_summary.txt",
-           "valu_instr_per_supersample": 2120.0,   # SQ_INSTS_VALU / SQ_WAVES of the fused visualizer kernel
-           "hbm_bytes_per_frame": (3415.4 + 1458000.0)*1024/60}   # FETCH_SIZE + WRITE_SIZE (KiB) per 60-frame launch
+PROFILE = ROOT/"profiles"/"r02_bench_c3.json"      # written by tools/profile_bench.sh → tools/summarize_profile.py
 
 
 def parse_args():
@@ -53,52 +58,87 @@ def parse_args():
     p.add_argument("--height", type=int, default=2160)
     p.add_argument("--ssaa", type=int, default=2)
     p.add_argument("--frames-per-step", type=int, default=60)
-    p.add_argument("--seconds", type=float, default=60.0, help="length of the synthetic clip")
-    p.add_argument("--scene", choices=("visualizer", "bars"), default="visualizer",
-                   help="visualizer = the metric's scene; bars = MusicBars (a light fragment: 170 VALU instructions per supersample, still issue-bound)")
+    p.add_argument("--seconds", type=float, default=60.0, help="length of the synthetic clip (grown when the ranks need more frames)")
+    p.add_argument("--scene", choices=("visualizer", "bars"), default="visualizer", help="visualizer = the metric's scene; bars = MusicBars (a light fragment)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-rows", type=int, default=0, help="output rows of the CPU baseline band (0 = auto, ~15 s)")
+    p.add_argument("--no-export", action="store_true", help="skip the host-inclusive export measurement")
+    p.add_argument("--cpu-seconds", type=float, default=18.0, help="budget of the CPU baseline (all cores + one thread)")
     return p.parse_args()
 
 
 def cpu_baseline(args, pcm, background) -> dict:
-    """Oracle on the host cores: a band of one frame of the same workload, all cores (row-band threads)."""
+    """Oracle on the host cores: bands of THREE frames of the same workload on all cores, one band on a single thread."""
     import numpy as np
 
     from oracle import binding as O
     w, h, s = args.width, args.height, args.ssaa
     threads = os.cpu_count() or 1
     planar = np.ascontiguousarray(pcm.T)
-    tell = 735*600
-    t0 = time.perf_counter()
     fmin, fmax, bins = O.from_notes(O.lib().sfo_note_of_frequency(20.0, 440.0), O.lib().sfo_note_of_frequency(14000.0, 440.0), True)
     indptr, indices, data = O.filterbank(0, 0, fmin, fmax, bins, 12, 44100)
-    column = O.csr_dot(indptr, indices, data, O.fft_power(planar, tell))
-    row = O.waveform_row(planar, tell, 735, 180)
-    vol, std = O.volume_std(planar, tell, 4410)
-    audio_s = time.perf_counter() - t0
-    u = O.default_uniforms(w, h, iTime=10.0, iTau=10.0/60.0, iDuration=60.0, iSSAA=float(s), iAudioVolume=0.97, iAudioSTD=float(std),
-                           iSpectrogramBins=bins, iSpectrogramLength=1, iWaveformLength=180)
-    tex = {"background": O.make_texture(np.flipud(background), "linear", True, True),
-           "iSpectrogram": O.make_texture(column.reshape(bins, 1, 2), "nearest", True, False),
-           "iWaveform": O.make_texture(row.reshape(1, 180, 2), "linear", False, False)}
+    bg = O.make_texture(np.flipud(background), "linear", True, True)
 
-    def band(rows: int) -> float:
-        y0 = h//2 - rows//2
+    def frame_inputs(k: int):
+        tell = 735*k
+        t0 = time.perf_counter()
+        column = O.csr_dot(indptr, indices, data, O.fft_power(planar, tell))
+        row = O.waveform_row(planar, tell, 735, 180)
+        _, std = O.volume_std(planar, tell, 4410)
+        audio_s = time.perf_counter() - t0
+        u = O.default_uniforms(w, h, iTime=k/60.0, iTau=(k/60.0)/args.seconds, iDuration=args.seconds, iSSAA=float(s), iAudioVolume=0.97, iAudioSTD=float(std),
+                               iSpectrogramBins=bins, iSpectrogramLength=1, iWaveformLength=180)
+        tex = {"background": bg, "iSpectrogram": O.make_texture(column.reshape(bins, 1, 2), "nearest", True, False),
+               "iWaveform": O.make_texture(row.reshape(1, 180, 2), "linear", False, False)}
+        return u, tex, audio_s
+
+    def band(u, tex, y0: int, rows: int, n_threads: int) -> float:
         t = time.perf_counter()
-        screen = O.render("visualizer", u, tex, w*s, h*s, rows=(y0*s, (y0 + rows)*s), threads=threads)
-        O.resolve(screen, w, h, 2, rows=(y0, y0 + rows), threads=threads)
+        screen = O.render("visualizer", u, tex, w*s, h*s, rows=(y0*s, (y0 + rows)*s), threads=n_threads)
+        O.resolve(screen, w, h, 2, rows=(y0, y0 + rows), threads=n_threads)
         return time.perf_counter() - t
 
-    rows = args.cpu_rows
-    if rows <= 0:
-        probe = band(max(2, threads//4))                          # calibrate, then aim at ~15 s
-        rows = int(min(h, max(threads, 15.0/(probe/max(2, threads//4)))))
-    seconds = band(rows)
-    frame_s = seconds*(h/rows) + audio_s
-    return {"value": 1.0/frame_s, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{rows} of {h} output rows of one {w}x{h} {s}xSSAA visualizer frame ({seconds:.1f} s on {threads} threads) "
-                      f"+ one frame of the audio tape ({audio_s*1e3:.1f} ms), scaled to a whole frame"}
+    u, tex, audio_s = frame_inputs(600)
+    probe_rows = max(2, threads//4)
+    probe = band(u, tex, h//2, probe_rows, threads)                # calibrate: seconds per output row on all cores
+    per_row = probe/probe_rows
+    budget_all, budget_one = 0.7*args.cpu_seconds, 0.3*args.cpu_seconds
+    rows_all = int(min(h, max(threads, budget_all/3.0/per_row)))
+    frames = (300, 1500, 2700)                                     # three frames spread over the clip (different audio, zoom, blur radius)
+    seconds_all, audio_all = 0.0, 0.0
+    for k in frames:
+        u, tex, a_s = frame_inputs(k)
+        seconds_all += band(u, tex, (h - rows_all)//2, rows_all, threads)
+        audio_all += a_s
+    frame_s_all = (seconds_all/len(frames))*(h/rows_all) + audio_all/len(frames)
+    rows_one = int(max(1, min(rows_all, budget_one/(per_row*threads))))
+    seconds_one = band(u, tex, (h - rows_one)//2, rows_one, 1)
+    frame_s_one = seconds_one*(h/rows_one) + audio_all/len(frames)
+    return {"value": 1.0/frame_s_all, "unit": "frames/s", "cores": threads, "kind": "port",
+            "single_thread": {"value": 1.0/frame_s_one, "unit": "frames/s", "cores": 1,
+                              "sample": f"{rows_one} of {h} output rows of one frame ({seconds_one:.1f} s), scaled to a whole frame"},
+            "sample": f"{rows_all} of {h} output rows of each of {len(frames)} frames {frames} of the {w}x{h} {s}xSSAA visualizer clip "
+                      f"({seconds_all:.1f} s on {threads} threads) + the audio tape of those frames ({audio_all*1e3:.1f} ms), scaled to whole frames"}
+
+
+def profile_counters(kernel: str) -> dict | None:
+    """Counters rocprofv3 collected for `kernel` with THIS build (tools/profile_bench.sh); None — with a warning — when the profile
+    is missing, names another kernel or was taken from other kernel sources"""
+    from shaderflow_amd._native import source_fingerprint
+    try:
+        record = json.loads(PROFILE.read_text())
+    except (OSError, ValueError):
+        print(f"bench.py: no profile at {PROFILE}: roofline.instructions/traffic are null", file=sys.stderr)
+        return None
+    if record.get("source_fingerprint") != source_fingerprint():
+        print(f"bench.py: {PROFILE.name} was measured on other kernel sources ({record.get('source_fingerprint')} != {source_fingerprint()}): "
+              "its counters are NOT used; re-run tools/profile_bench.sh", file=sys.stderr)
+        return None
+    for name, entry in record.get("kernels", {}).items():
+        if name.replace(" ", "") == kernel.replace(" ", ""):
+            line = record.get("bench_under_tracer") or {}
+            return dict(entry, frames_per_launch=(line.get("roofline") or {}).get("frames_per_launch"))
+    print(f"bench.py: {PROFILE.name} has no counters for '{kernel}' (it holds {list(record.get('kernels', {}))[:4]}…)", file=sys.stderr)
+    return None
 
 
 def main() -> None:
@@ -112,7 +152,7 @@ def main() -> None:
     import numpy as np
     import torch                                                  # before the HIP library: one HIP runtime per process
 
-    local_rank %= max(1, torch.cuda.device_count())               # more ranks than devices only happens in the gloo test below
+    local_rank %= max(1, torch.cuda.device_count())               # more ranks than devices only happens in the gloo test
     torch.cuda.set_device(local_rank)
     distributed = world > 1 or os.environ.get("SHADERFLOW_FORCE_DIST") == "1"     # the env var exercises the RCCL path on one GPU
     if distributed:
@@ -128,62 +168,94 @@ def main() -> None:
     from examples.scenes import MusicBars, Visualizer, make
     from shaderflow_amd import _native as N
     from shaderflow_amd import synth
-    from shaderflow_amd.parallel import FrameGather
+    from shaderflow_amd.message import ShaderMessage
     from shaderflow_amd.tape import FrameTape
 
-    # Everything of this rank runs on ONE stream, which is also torch's current stream: RCCL orders a gather after the work
-    # already queued on the current stream, and a later render waits for the gather it must not overtake. (torch's default
-    # stream has the handle 0, for which the context would create a stream of its own that nothing orders with — so a real one.)
+    w, h, s, fpb = args.width, args.height, args.ssaa, args.frames_per_step
+    total_steps = args.warmup + args.steps
+    frames_per_rank = total_steps*fpb
+    seconds = max(args.seconds, world*frames_per_rank/60.0)       # every rank gets its own contiguous range of the clip
+    pcm = synth.sweep_clip(seconds, 44100)
+    background = synth.background_image(1920, 1080, seed=0)
+    scene_class = Visualizer if args.scene == "visualizer" else MusicBars
+
+    # the CPU baseline first: the timed region (and the driver's GPU sampler) comes after it
+    baseline = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.scene == "visualizer":
+        baseline = cpu_baseline(args, pcm, background)
+
+    # Everything of this rank runs on ONE stream, which is also torch's current stream: RCCL orders a send after the work already
+    # queued on the current stream, and a later render waits for the transfer it must not overtake. (torch's default stream has
+    # the handle 0, for which the context would create a stream of its own that nothing orders with — so a real one.)
     render_stream = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(render_stream)
     context = N.Context(local_rank, render_stream.cuda_stream)
 
-    w, h, s, fpb = args.width, args.height, args.ssaa, args.frames_per_step
-    pcm = synth.sweep_clip(args.seconds, 44100)
-    background = synth.background_image(1920, 1080, seed=0)
-    scene_class = Visualizer if args.scene == "visualizer" else MusicBars
-    scene = make(scene_class, audio=(pcm, 44100), background=(background if args.scene == "visualizer" else None), context=context)
-    scene.initialize()
-    scene.exporting = scene.freewheel = scene.headless = True
-    scene.realtime = False
-    scene.fps, scene.subsample, scene.time = 60.0, 2, 0.0
-    from shaderflow_amd.message import ShaderMessage
-    scene.relay(ShaderMessage.Shader.Compile)
-    scene.resize(width=w, height=h)
-    for module in scene.modules:
-        module.setup()
-    scene.set_duration(args.seconds)
-    scene.ssaa = s
-    total_steps = args.warmup + args.steps
-    frames_needed = total_steps*fpb
-    clip_frames = int(args.seconds*60)
-    tape = FrameTape(scene, batch=fpb).prepare(max(frames_needed, fpb))
+    def build_scene(prepared: bool = True):
+        scene = make(scene_class, audio=(pcm, 44100), background=(background if args.scene == "visualizer" else None), context=context)
+        if not prepared:
+            return scene                                          # scene.main() does the rest itself
+        scene.initialize()
+        scene.exporting = scene.freewheel = scene.headless = True
+        scene.realtime = False
+        scene.fps, scene.subsample, scene.time = 60.0, 2, 0.0
+        scene.relay(ShaderMessage.Shader.Compile)
+        scene.resize(width=w, height=h)
+        for module in scene.modules:
+            module.setup()
+        scene.set_duration(seconds)
+        scene.ssaa = s
+        return scene
+
+    scene = build_scene()
+    first_frame = rank*frames_per_rank                              # this rank's contiguous range: [first_frame, first_frame + frames_per_rank)
+    tape = FrameTape(scene, batch=fpb).prepare(first_frame + frames_per_rank)
     tape.bind_static_uniforms()
-    N.check(N.lib().sfx_tape_reset(tape.handle))
 
     frame_bytes = w*h*3
     # zeros, not empty: the first touch of fresh device memory is paid here, outside the timed region
     buffers = [torch.zeros(fpb*frame_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
-    # N > 1: a step's frames are rendered and gathered in `parts` pieces, so that only the last piece's gather is exposed at
-    # the end of the timed region (the gather of a piece overlaps the render of the next one); N = 1 renders the batch at once
+    # N > 1: a step's frames are rendered and sent in `parts` pieces, so that only the last piece's transfer is exposed at the end
+    # of the timed region (the transfer of a piece overlaps the render of the next one); N = 1 renders the batch at once
     parts = next(p for p in (4, 3, 2, 1) if fpb % p == 0) if distributed else 1
     piece = fpb//parts
-    gather = FrameGather(world, rank, piece*frame_bytes, torch.device("cuda", local_rank), slots=2*parts, host_wait=False) if distributed else None
+    staged = distributed and dist.get_backend() == "gloo"
+    received = None
+    if distributed and rank == 0:
+        # rank 0 keeps the last two steps of every other rank (a real export hands them to the sink: parallel.contiguous_device_export)
+        where = "cpu" if staged else "cuda"
+        received = [[torch.zeros(fpb*frame_bytes, dtype=torch.uint8, device=where) for _ in range(2)] for _ in range(world)]
+    in_flight: list = []
+
+    def transfer(index: int, q: int, view) -> None:
+        """piece q of step `index`: every other rank → rank 0, grouped point-to-point (the RCCL gather)"""
+        if not distributed:
+            return
+        lo, hi = q*piece*frame_bytes, (q + 1)*piece*frame_bytes
+        if rank == 0:
+            ops = [dist.P2POp(dist.irecv, received[source][index % 2][lo:hi], source) for source in range(1, world)]
+        else:
+            ops = [dist.P2POp(dist.isend, view.cpu() if staged else view, 0)]
+        if ops:
+            in_flight.extend(dist.batch_isend_irecv(ops))
+
+    works_per_transfer = (world - 1) if rank == 0 else 1
+
+    def drain(keep_transfers: int = 0) -> None:
+        while len(in_flight) > keep_transfers*works_per_transfer:
+            in_flight.pop(0).wait()
 
     def step(index: int, timed_slot: int | None):
-        first = (index*fpb) % max(1, (min(frames_needed, clip_frames) - fpb + 1))
+        first = first_frame + index*fpb
         target = buffers[index % 2]
         tape.build(first, fpb)
         if timed_slot is not None:
             context.event_record(2*timed_slot)
         for q in range(parts):
-            slot = (index % 2)*parts + q
-            if gather is not None:
-                gather.wait(slot)                                 # the gather that last read this piece of the buffer has finished
+            drain(keep_transfers=2*parts - 1)                     # the transfer that last used this piece of this buffer (two steps ago) is done
             view = target[q*piece*frame_bytes:(q + 1)*piece*frame_bytes]
             tape.render(piece, view.data_ptr(), first_slot=q*piece)
-            if gather is not None:
-                gather.start(slot, view)
+            transfer(index, q, view)
         if timed_slot is not None:
             context.event_record(2*timed_slot + 1)
 
@@ -193,74 +265,106 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Initialisation, not a measured or counted step: first launches load code objects, commit the scratch buffers and
-    # bring the GPU out of its idle power state (observed: a one-off ~70 ms stall otherwise lands in short runs)
+    # Set-up, not a measured or counted step: first launches load code objects, commit scratch buffers and bring the GPU out of its
+    # idle power state; then the recurrences of every frame before this rank's range are replayed (audio kernels only, no render)
     started = time.perf_counter()
     launches = 0
-    while launches < 2 or time.perf_counter() - started < 0.3:    # small configurations finish two launches in a few ms: not enough for the clocks
+    while launches < 2 or time.perf_counter() - started < 0.3:
         tape.build(0, fpb)
         tape.render(fpb, buffers[launches % 2].data_ptr())
         torch.cuda.synchronize()
         launches += 1
     N.check(N.lib().sfx_tape_reset(tape.handle))
-    if gather is not None:
-        # same for the communicator: RCCL opens its peer-to-peer channels on the first gather (also with --warmup 0)
-        gather.start(0, buffers[0][:piece*frame_bytes])
-        gather.wait_all()
+    for f in range(0, first_frame, fpb):
+        tape.build(f, min(fpb, first_frame - f))
+    if distributed:
+        transfer(0, 0, buffers[0][:piece*frame_bytes])            # the communicator opens its peer-to-peer channels on first use
+        drain()
 
     for i in range(args.warmup):
         step(i, None)
-    if gather is not None:
-        gather.wait_all()
+    drain()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, i if i < 32 else None)
-    if gather is not None:
-        gather.wait_all()
+    drain()
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staged else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     kernel_ms = [context.event_elapsed_ms(2*i, 2*i + 1) for i in range(min(args.steps, 32))]
-    launch_s = float(np.mean(kernel_ms))/1e3
+    launch_s = (float(np.mean(kernel_ms))/1e3/parts) if kernel_ms else float("nan")     # one launch = `piece` frames
+    kernel = N.lib().sfx_last_kernel().decode()
     frames_total = world*args.steps*fpb
-    value = frames_total/elapsed
+    value = frames_total/elapsed if elapsed > 0 else float("nan")
+    tape.release()
+
+    # ---- the same frames through a real export, read-out to host memory included (/dev/null sink) ----
+    export = None
+    if not args.no_export:
+        scene2 = build_scene(prepared=False)
+        frames_export = max(fpb, min(world*args.steps*fpb, int(seconds*60)))
+        barrier()
+        t1 = time.perf_counter()
+        scene2.main(width=w, height=h, ssaa=s, fps=60.0, time=frames_export/60.0, output="/dev/null")
+        barrier()
+        took = time.perf_counter() - t1
+        export = {"value": round(frames_export/took, 2), "unit": "frames/s", "frames": frames_export, "seconds": round(took, 3),
+                  "mode": ("pinned ring + writer thread" if world == 1 else f"sharded export, SHADERFLOW_SHARD={os.environ.get('SHADERFLOW_SHARD', 'host')}"),
+                  "note": "whole scene.main(): tape schedule, table set-up, render, read-out over PCIe, write to /dev/null"}
 
     if rank == 0:
-        b_alg = B_ALG_PER_FRAME.get((w, h, s), float(w*s*h*s*8 + w*h*6))
-        achieved = b_alg*fpb/launch_s/1e9
-        samples_per_s = (w*s)*(h*s)*fpb/launch_s
-        lane_ops = samples_per_s*PROFILE["valu_instr_per_supersample"]
         c3 = (w, h, s) == (3840, 2160, 2) and args.scene == "visualizer"
+        b_alg = B_ALG_PER_FRAME.get((w, h, s), float(w*s*h*s*8 + w*h*6))
+        hbm_achieved = b_alg*piece/launch_s/1e9
+        samples_per_s = (w*s)*(h*s)*piece/launch_s
+        counters = profile_counters(kernel) if c3 else None
+        per_sample = traffic = lds_busy = None
+        if counters:
+            cs = counters["counters"]
+            if cs.get("SQ_WAVES"):
+                per_sample = cs.get("SQ_INSTS_VALU", 0.0)/cs["SQ_WAVES"]
+            if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:        # KiB per profiled launch → bytes per launch of `piece` frames
+                profiled_frames = counters.get("frames_per_launch") or fpb
+                traffic = (cs["FETCH_SIZE"] + cs["WRITE_SIZE"])*1024.0*piece/profiled_frames
+            if cs.get("GRBM_GUI_ACTIVE") and cs.get("SQ_LDS_IDX_ACTIVE"):
+                lds_busy = cs["SQ_LDS_IDX_ACTIVE"]/(cs["GRBM_GUI_ACTIVE"]/8.0*256.0)     # LDS-array cycles / (cycles x CUs); GRBM counts per XCD
+        lane_ops = samples_per_s*per_sample if per_sample else None
         result = {
             "metric": "frames/sec at 4K 2xSSAA music-visualizer" if c3 else f"frames/sec {args.scene} {w}x{h} {s}xSSAA",
             "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed/args.steps*1e3, 3),
+            "ms_per_step": round(elapsed/max(1, args.steps)*1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{scene_class.__name__} scene {w}x{h} {s}xSSAA subsample 2, 60 fps, 60 s synthetic stereo sine sweep @44.1 kHz, "
-                                   f"1920x1080 synthetic background; step = {fpb} frames (STFT+filterbank+dynamics tape, fused fragment+resolve)",
+            "config": {"workload": f"{scene_class.__name__} scene {w}x{h} {s}xSSAA subsample 2, 60 fps, {seconds:.0f} s synthetic stereo sine sweep @44.1 kHz, "
+                                   f"1920x1080 synthetic background; step = {fpb} frames (STFT + filterbank + dynamics tape, column/row tables, fused fragment+resolve)",
                        "frames_per_step": fpb, "global_frames_per_step": fpb*world,
-                       "parallelism": f"frame-range sharding x{world}" + (f", RCCL gather to rank 0 in {parts} pieces per step" if distributed else "")},
+                       "parallelism": f"contiguous frame range per rank x{world}" + (f", every step sent to rank 0 over {dist.get_backend()} in {parts} pieces" if distributed else ""),
+                       "ranks": world, "filterbank": "mfma" if tape.use_mfma else "csr"},
             "realtime_factor": round(value/60.0, 2),
-            "roofline": {"bound": "hbm", "kernel": "k_render_resolve<VisualizerShader, 2>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved/HBM_PEAK_GBS, 4),
-                         "traffic": (PROFILE["hbm_bytes_per_frame"]*fpb if c3 else None), "traffic_source": PROFILE["file"],
-                         "algorithmic_bytes_per_launch": b_alg*fpb, "launch_ms": round(launch_s*1e3, 3), "frames_per_launch": fpb, "launches_per_step": parts,
-                         "note": "FP32-VALU bound kernel (81 bilinear taps per supersample: 40 summed per texel cell in closed form, 40 diagonal ones sharing their coordinate work in groups of four): the fused kernel writes only the RGB8 frame, "
-                                 "12.6x less HBM traffic than the two-pass data-flow the algorithmic bytes describe; the binding roof is under valu"},
-            "valu": {"bound": "fp32_valu_issue", "achieved": round(lane_ops/1e12, 2), "peak": round(VALU_PEAK_LANE_OPS/1e12, 1), "unit": "T lane-instr/s",
-                     "frac": round(lane_ops/VALU_PEAK_LANE_OPS, 4), "taps_per_s": round(samples_per_s*81/1e9, 1), "taps_unit": "G taps/s",
-                     "model": f"{PROFILE['valu_instr_per_supersample']:.0f} VALU instructions per supersample (rocprofv3 SQ_INSTS_VALU/SQ_WAVES) at the "
-                              "2-cycle wave64 issue rate of plain f32 ops at 2.4 GHz; non-f32 ops and SGPR-operand ops issue at 4 cycles, so this is a lower bound on VALU busy"},
+            "roofline": {"bound": "valu", "kernel": kernel,
+                         "achieved": round(lane_ops/1e12, 2) if lane_ops else None, "peak": round(VALU_PEAK_LANE_OPS/1e12, 1), "unit": "T lane-instr/s",
+                         "frac": round(lane_ops/VALU_PEAK_LANE_OPS, 4) if lane_ops else None,
+                         "valu_instructions_per_supersample": round(per_sample, 1) if per_sample else None,
+                         "lds_busy": round(lds_busy, 3) if lds_busy else None,
+                         "traffic": traffic, "counters_from": str(PROFILE.relative_to(ROOT)) if counters else None,
+                         "launch_ms": round(launch_s*1e3, 3), "frames_per_launch": piece, "launches_per_step": parts,
+                         "hbm": {"achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved/HBM_PEAK_GBS, 4),
+                                 "algorithmic_bytes_per_launch": b_alg*piece,
+                                 "measured": round(traffic/launch_s/1e9, 1) if traffic else None,
+                                 "note": "algorithmic bytes = the reference's two-pass data-flow (SURVEY.md §8d); the fused kernel writes the RGB8 frame only"},
+                         "note": "the kernel saturates VALU issue AND LDS bandwidth (40 diagonal bilinear taps of 48-byte cells + 16 axis-line cells per supersample); "
+                                 "HBM carries the finished frames and L2-resident tables only"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args, pcm, background)
+        if baseline is not None:
+            result["cpu_baseline"] = baseline
+        if export is not None:
+            result["export_host"] = export
     else:
         result = None
 

@@ -24,6 +24,17 @@ E_UNSUPPORTED = -4
 Handle = C.c_uint64
 
 
+def source_fingerprint() -> str:
+    """sha256 over the kernel sources the library is built from (csrc/): ties profiles under profiles/ to the code they measured"""
+    import hashlib
+    digest = hashlib.sha256()
+    for path in sorted((PACKAGE/"csrc").iterdir()):
+        if path.suffix in (".hip", ".hpp", ".inc") or path.name == "Makefile":
+            digest.update(path.name.encode())
+            digest.update(path.read_bytes())
+    return digest.hexdigest()[:16]
+
+
 class CtxInfo(C.Structure):
     _fields_ = [("device_name", C.c_char*128), ("gcn_arch", C.c_char*64), ("device_id", C.c_int32),
                 ("compute_units", C.c_int32), ("max_texture_dim", C.c_int32), ("wavefront_size", C.c_int32),

@@ -89,5 +89,8 @@ def test_bench_with_two_ranks_prints_one_line_for_the_whole_job():
     assert len(lines) == 1, out.stdout[-2000:]
     record = json.loads(lines[0])
     assert record["n_gpus"] == 2 and record["steps"] == 2 and record["scaling"] == "weak"
-    assert record["config"]["global_frames_per_step"] == 8 and record["value"] > 0
+    assert record["config"]["global_frames_per_step"] == 8 and record["value"] > 0 and record["config"]["ranks"] == 2
     assert "cpu_baseline" not in record                                       # rank 0 at N = 1 only
+    # the second number: the same frames through a real sharded export, read-out to host memory included (host mode)
+    assert record["export_host"]["frames"] == 16 and record["export_host"]["value"] > 0 and "SHADERFLOW_SHARD=host" in record["export_host"]["mode"]
+    assert record["roofline"]["bound"] == "valu" and record["roofline"]["kernel"].startswith("k_") and record["roofline"]["hbm"]["achieved"] > 0

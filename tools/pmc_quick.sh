@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 C=${1:-SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS}; shift || true
-ARGS=${*:---steps 1 --warmup 1 --no-cpu-baseline --frames-per-step 10}
+ARGS=${*:---steps 1 --warmup 1 --no-cpu-baseline --no-export --frames-per-step 10}
 rm -rf gpurun_out/pmcq && mkdir -p gpurun_out/pmcq
 rocprofv3 --kernel-trace --pmc $C -f csv -d gpurun_out/pmcq -o q -- python3 bench.py $ARGS > gpurun_out/pmcq/log.txt 2>&1
 python3 - <<'PY'

@@ -4,7 +4,7 @@
 # usage: tools/profile_bench.sh <tag> [bench args…]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${*:---steps 2 --warmup 1 --no-cpu-baseline}
+ARGS=${*:---steps 2 --warmup 1 --no-cpu-baseline --no-export}
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG

@@ -35,8 +35,33 @@ for counters in sorted(root.glob("pmc_*/**/*counter_collection.csv")):
         for r in csv.DictReader(fh):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for kernel, cs in acc.items():
-    if not any("render" in kernel or "stft" in kernel or "dynamics" in kernel or "filterbank" in kernel for _ in [0]):
+    if not any(word in kernel for word in ("render", "visualizer", "resolve", "stft", "dynamics", "filterbank", "separable")):
         continue
     print(f"\n{kernel}")
     for name, values in sorted(cs.items()):
         print(f"  {name:28s} mean {sum(values)/len(values):18.1f}   dispatches {len(values)}")
+
+
+# machine-readable twin (bench.py reads the dominant kernel's counters from it): <root>.json next to the directory
+import json
+import subprocess
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from shaderflow_amd._native import source_fingerprint                # noqa: E402
+durations = {}
+for stats in sorted(root.glob("trace/**/*kernel_stats.csv")):
+    with open(stats) as fh:
+        for r in csv.DictReader(fh):
+            durations[short(r["Name"])] = {"calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]), "percentage": float(r["Percentage"])}
+bench_line = None
+for log in sorted(root.glob("bench_trace.log")):
+    lines = [l for l in log.read_text().splitlines() if l.startswith("{")]
+    bench_line = json.loads(lines[-1]) if lines else None
+try:
+    head = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=Path(__file__).resolve().parent.parent).stdout.strip()
+except OSError:
+    head = ""
+record = {"source_fingerprint": source_fingerprint(), "git_head": head, "command": " ".join(sys.argv[2:]),
+          "kernels": {kernel: {"duration": durations.get(kernel), "counters": {name: sum(v)/len(v) for name, v in cs.items()}}
+                      for kernel, cs in acc.items()},
+          "durations": durations, "bench_under_tracer": bench_line}
+Path(str(root).rstrip("/") + ".json").write_text(json.dumps(record, indent=1))
