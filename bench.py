@@ -110,7 +110,8 @@ def cpu_baseline(args, pcm, background) -> dict:
         seconds_all += band(u, tex, (h - rows_all)//2, rows_all, threads)
         audio_all += a_s
     frame_s_all = (seconds_all/len(frames))*(h/rows_all) + audio_all/len(frames)
-    rows_one = int(max(1, min(rows_all, budget_one/(per_row*threads))))
+    probe_one = band(u, tex, h//2, 1, 1)                            # one output row on one thread
+    rows_one = int(max(1, min(rows_all, budget_one/max(probe_one, 1e-6))))
     seconds_one = band(u, tex, (h - rows_one)//2, rows_one, 1)
     frame_s_one = seconds_one*(h/rows_one) + audio_all/len(frames)
     return {"value": 1.0/frame_s_all, "unit": "frames/s", "cores": threads, "kind": "port",

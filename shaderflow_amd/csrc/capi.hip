@@ -7,6 +7,7 @@
 #include "audio_kernels.hpp"
 #include "visualizer_kernels.hpp"
 #include "visualizer_fast.hpp"
+#include "separable_fast.hpp"
 #include "uniform_table.hpp"
 
 #include <atomic>
@@ -774,6 +775,33 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
     return 1;
 }
 
+// ---- bars.frag / waveform.frag with per-frame column and row tables (separable_fast.hpp) ---------------------------------------
+// 1 launched, 0 not this path's configuration (the caller takes PlainShader), < 0 error.
+template <int KIND> static int launch_separable(const RenderArgs& a, int ssaa, int frames, hipStream_t s) {
+    Context* ctx = g_launch_ctx;
+    if (!ctx || ssaa != 2) return 0;
+    if (getenv("SHADERFLOW_SEPARABLE") && atoi(getenv("SHADERFLOW_SEPARABLE")) == 0) return 0;        // A/B switch for measurements
+    if (KIND == SEP_BARS) {
+        // a one-column spectrogram picked with nearest filtering: the look-up is a function of the sample column alone
+        const Tex& sp = a.tex[TEX_SPECTROGRAM];
+        if (sp.width != 1 || sp.filter != FILTER_NEAREST) return 0;
+    }
+    const size_t bytes = (size_t)frames*((size_t)a.wr + a.hr)*sizeof(float4);
+    if (ctx->vis_tables_bytes < bytes) {
+        hipStreamSynchronize(s);
+        hipFree(ctx->vis_tables); ctx->vis_tables = nullptr; ctx->vis_tables_bytes = 0;
+        if (hipMalloc(&ctx->vis_tables, bytes) != hipSuccess) return fail(SFX_E_HIP, "column/row tables of %d frames: out of device memory", frames);
+        ctx->vis_tables_bytes = bytes;
+    }
+    SepTables t;
+    t.columns = (float4*)ctx->vis_tables;
+    t.rows = t.columns + (size_t)frames*a.wr;
+    hipLaunchKernelGGL(k_separable_axis<KIND>, dim3((a.wr + a.hr + 255)/256, frames), dim3(256), 0, s, a, t);
+    g_last_kernel = std::string("k_separable_fused<") + (KIND == SEP_BARS ? "bars" : "waveform") + ">";
+    hipLaunchKernelGGL(k_separable_fused<KIND>, dim3((a.w + SEP_PIXELS - 1)/SEP_PIXELS, (a.h + SEP_ROWS - 1)/SEP_ROWS, frames), dim3(SEP_PIXELS), 0, s, a, t);
+    return 1;
+}
+
 #ifdef SF_SECTION_TIMERS
 static int launch_fused_inner(int fragment, const RenderArgs& a, int ssaa, int frames, hipStream_t s, bool force_generic);
 // profiling builds: run the launch with section timers and print the share of wave time per section
@@ -864,8 +892,16 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
                 }
             }
             return launch_fused_s<PlainShader<FRAG_VISUALIZER>>(a, ssaa, frames, s);
-        case FRAG_BARS: return launch_fused_s<PlainShader<FRAG_BARS>>(a, ssaa, frames, s);
-        case FRAG_WAVEFORM: return launch_fused_s<PlainShader<FRAG_WAVEFORM>>(a, ssaa, frames, s);
+        case FRAG_BARS: {
+            const int fast = force_generic ? 0 : launch_separable<SEP_BARS>(a, ssaa, frames, s);
+            if (fast != 0) return fast < 0 ? fast : SFX_OK;
+            return launch_fused_s<PlainShader<FRAG_BARS>>(a, ssaa, frames, s);
+        }
+        case FRAG_WAVEFORM: {
+            const int fast = force_generic ? 0 : launch_separable<SEP_WAVEFORM>(a, ssaa, frames, s);
+            if (fast != 0) return fast < 0 ? fast : SFX_OK;
+            return launch_fused_s<PlainShader<FRAG_WAVEFORM>>(a, ssaa, frames, s);
+        }
         case FRAG_MULTI_CHILD: return launch_fused_s<PlainShader<FRAG_MULTI_CHILD>>(a, ssaa, frames, s);
         case FRAG_MULTI_MAIN: return launch_fused_s<PlainShader<FRAG_MULTI_MAIN>>(a, ssaa, frames, s);
         case FRAG_SHADERTOY: return launch_fused_s<PlainShader<FRAG_SHADERTOY>>(a, ssaa, frames, s);

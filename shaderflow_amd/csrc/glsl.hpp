@@ -167,12 +167,38 @@ SF_HD vec4 texel_fetch(const Tex& t, int i, int j) {
     return texel(t, i, j);
 }
 
+// Colour write to a unorm8 target (OpenGL 3.3 §2.1.6 / §4.1): clamp to [0, 1] (NaN -> 0), scale by 255, round half to even.
+// On the device that is ONE instruction after the multiplication: v_cvt_pk_u8_f32 clamps to [0, 255], rounds to nearest even,
+// maps NaN to 0 and writes the byte into its place of the packed texel — identical to the sequence below for every one of the
+// 2^32 floats (tools/check_cvt_pk_u8.hip, run on gfx950), and clamp(c)*255 == clamp(c*255) bit for bit.
 SF_HD uint32_t unorm8(float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_cvt_pk_u8_f32(c*255.0f, 0u, 0u);
+#else
     c = (c > 0.0f) ? c : 0.0f;
     c = (c < 1.0f) ? c : 1.0f;
     return (uint32_t)::rintf(c*255.0f);
+#endif
 }
-SF_HD uint32_t pack_rgba8(vec4 c) { return unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (unorm8(c.w) << 24); }
+SF_HD uint32_t pack_rgba8(vec4 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t texel = __builtin_amdgcn_cvt_pk_u8_f32(c.x*255.0f, 0u, 0u);
+    texel = __builtin_amdgcn_cvt_pk_u8_f32(c.y*255.0f, 1u, texel);
+    texel = __builtin_amdgcn_cvt_pk_u8_f32(c.z*255.0f, 2u, texel);
+    return __builtin_amdgcn_cvt_pk_u8_f32(c.w*255.0f, 3u, texel);
+#else
+    return unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (unorm8(c.w) << 24);
+#endif
+}
+SF_HD uint32_t pack_rgb8(vec3 c) {                                  // the fused kernels never look at alpha (final.glsl:6-31 takes .rgb)
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t texel = __builtin_amdgcn_cvt_pk_u8_f32(c.x*255.0f, 0u, 0u);
+    texel = __builtin_amdgcn_cvt_pk_u8_f32(c.y*255.0f, 1u, texel);
+    return __builtin_amdgcn_cvt_pk_u8_f32(c.z*255.0f, 2u, texel);
+#else
+    return unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16);
+#endif
+}
 
 // ---- uniforms ----------------------------------------------------------------------------------
 // scene.py:687-703, camera.py:196-201 (+ its ShaderDynamics :147-185), audio/module.py:413-421,

@@ -332,7 +332,7 @@ struct VisualizerFast {
             if (r2.y < c2.y) col = col*0.8f;                                                            // :72
             if (r2.z < c2.z) col = col*0.8f;                                                            // :73
             if (__float_as_int(c2.w) != 0) col = space;                                                 // :11-14
-            texel = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16);
+            texel = pack_rgb8(col);
         }
 
         // final.glsl over the pixel's 2x2 block (render_resolve_body): lane c of the quad resolves channel c
