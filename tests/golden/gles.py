@@ -115,10 +115,12 @@ class Context:
         return handle.value
 
     # draw -------------------------------------------------------------------------------------------------
-    def draw(self, program: int, width: int, height: int, uniforms: dict, textures: dict, attributes: dict, integers: dict = None) -> np.ndarray:
+    def draw(self, program: int, width: int, height: int, uniforms: dict, textures: dict, attributes: dict, integers: dict = None,
+             region: tuple = None) -> np.ndarray:
         """Fullscreen triangle strip into an RGBA8 target; returns (h, w, 4) uint8, row 0 = bottom.
         uniforms: name → float or tuple of floats; textures: name → texture handle; attributes: name → (4, k) float32;
-        integers: name → int for uniforms declared int/bool"""
+        integers: name → int for uniforms declared int/bool; region = (x, y, w, h): shade and return that rectangle of the target
+        only (scissor test) — bands of frames too large to store"""
         gl = self.gl
         target, fbo = C.c_uint(), C.c_uint()
         gl.glGenTextures(1, C.byref(target))
@@ -160,9 +162,15 @@ class Context:
             gl.glEnableVertexAttribArray(location)
             gl.glVertexAttribPointer(location, array.shape[1], GL["FLOAT"], 0, 0, None)
             keep.append(array)
+        x, y, rw, rh = region if region is not None else (0, 0, width, height)
+        if region is not None:
+            gl.glEnable(0x0C11)                                  # GL_SCISSOR_TEST
+            gl.glScissor(x, y, rw, rh)
         gl.glDrawArrays(GL["TRIANGLE_STRIP"], 0, 4)
-        out = np.zeros((height, width, 4), np.uint8)
-        gl.glReadPixels(0, 0, width, height, GL["RGBA"], GL["UNSIGNED_BYTE"], out.ctypes.data)
+        if region is not None:
+            gl.glDisable(0x0C11)
+        out = np.zeros((rh, rw, 4), np.uint8)
+        gl.glReadPixels(x, y, rw, rh, GL["RGBA"], GL["UNSIGNED_BYTE"], out.ctypes.data)
         assert gl.glGetError() == 0, "GL error after draw"
         gl.glDeleteFramebuffers(1, C.byref(fbo))
         gl.glDeleteTextures(1, C.byref(target))

@@ -1,7 +1,9 @@
 """
 The HIP kernels directly against the reference's GLSL as rendered by an independent OpenGL implementation (tests/golden/gles.npz,
-see tests/test_oracle_gles.py): no oracle in between. Generic kernels are held to 1 LSB (what two GL implementations agree to),
-the LDS-tiled visualizer kernel to 2 LSB on at most 0.1 % of the values (its own 1 LSB re-association on top).
+see tests/test_oracle_gles.py): no oracle in between. Every kernel — the LDS-tiled visualizer kernels included — is held to 1 LSB
+per channel, what two GL implementations agree to (measured: profiles/r02_parity_histogram.txt has no value further off at these
+sizes). At the benchmark's own size (gles_4k.npz: bands of a 3840x2160 2xSSAA frame) 0.2 % of the values sit on antialiased
+outlines where the two implementations put a supersample on different sides; the test pins those to the parity oracle.
 """
 from pathlib import Path
 
@@ -47,7 +49,36 @@ def test_visualizer_tiled_kernel(gpu, volume):
     got = gpu.render(prog, 160, 90)
     want = G[f"visualizer.v{volume}.image"]
     d = np.abs(got.astype(int) - want.astype(int))
-    assert d.max() <= 2 and (d <= 1).mean() >= 0.999, (d.max(), (d <= 1).mean())
+    assert d.max() <= 1, (d.max(), np.bincount(d.ravel()))                      # the north star's bound, against the reference's GLSL
+
+
+def test_benchmark_kernel_against_the_reference_glsl_at_4k(gpu):
+    """The kernel bench.py times (k_visualizer_fast: per-frame column/row tables, axis lines, 72x10-cell LDS tile) is only selected
+    at sizes like the benchmark's, so it gets goldens of its own: three bands of four rows of the 3840x2160 2xSSAA frame of
+    test_full_size_properties_4k_ssaa2, rendered from the reference's visualizer.frag + final.glsl by SwiftShader
+    (tests/golden/make_golden_gles_4k.py). >= 99.8 % of the values within 1 LSB; the rest are antialiased outlines of the bars
+    where the two GL implementations put one of the four supersamples on different sides — there the kernel must agree with the
+    parity oracle (the bit-exact chain), which differs from the GLSL rendering at the same places."""
+    from tests.helpers import oracle_textures
+    K = np.load(Path(__file__).parent/"golden"/"gles_4k.npz")
+    w, h, ssaa, seed, volume = int(K["args"][0]), int(K["args"][1]), int(K["args"][2]), int(K["args"][3]), float(K["args"][4])
+    u, arrays, params = visualizer_inputs(w, h, seed=seed, volume=volume, bg_size=(int(K["args"][5]), int(K["args"][6])))
+    u.iSSAA = float(ssaa)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    frame = gpu.render_resolve(prog, w, h, ssaa, 2)
+    assert gpu.lib.sfx_last_kernel().decode().startswith("k_visualizer_fast<"), gpu.lib.sfx_last_kernel()
+    for first, last in K["bands"]:
+        want = K[f"rows{first}.final"]
+        got = frame[first:last]
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert (d <= 1).mean() >= 0.998, (int(first), np.bincount(d.ravel())[:6])
+        screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, rows=(first*ssaa, last*ssaa), threads=8)
+        oracle = O.resolve(screen, w, h, 2, rows=(first, last), threads=8)[first:last]
+        assert np.abs(got.astype(int) - oracle.astype(int)).max() <= 1
+        far = d >= 2
+        assert (np.abs(oracle.astype(int) - want.astype(int))[far] >= 1).all()  # where the kernel is off the GLSL, so is the bit-exact chain
 
 
 def test_audio_fragments_and_raymarch(gpu):
@@ -112,8 +143,7 @@ def test_end_to_end_export_against_the_reference_pipeline(batch):
     """The north star's parity statement, end to end and with no oracle in between: the product exports the Visualizer scene from
     PCM (STFT, filterbank, DynamicNumbers, waveform and loudness on the device; fused fragment + resolve), and the frames are
     compared with what the REFERENCE's own numpy audio code (pipeline.npz) fed through the REFERENCE's own GLSL (SwiftShader:
-    visualizer.frag at 2x SSAA, then final.glsl) produced. Bound: 2 LSB (1 between GL implementations + 1 of the tiled kernel),
-    with at least 99.9 % of the values within 1."""
+    visualizer.frag at 2x SSAA, then final.glsl) produced. Bound: 1 LSB per channel on every value."""
     from examples.scenes import Visualizer, make
     from shaderflow_amd import synth
     from tests.helpers import i16_to_f32
@@ -127,4 +157,4 @@ def test_end_to_end_export_against_the_reference_pipeline(batch):
     for k in G["frames.index"]:
         want = G[f"frames.{k}"]
         d = np.abs(got[k].astype(int) - want.astype(int))
-        assert d.max() <= 2 and (d <= 1).mean() >= 0.999, (int(k), d.max(), (d <= 1).mean())
+        assert d.max() <= 1, (int(k), d.max(), np.bincount(d.ravel()))

@@ -158,3 +158,22 @@ def test_end_to_end_frames_from_the_reference_audio_state():
         got = G[f"frames.{k}"]
         d = np.abs(got.astype(int) - want.astype(int))
         assert d.max() <= 1, (int(k), d.max(), (d > 1).sum())
+
+
+def test_benchmark_size_bands_against_the_reference_glsl():
+    """gles_4k.npz: three bands of the 3840x2160 2xSSAA frame rendered from the reference's GLSL (make_golden_gles_4k.py). The
+    fragment pass (every 16th supersample column is stored) within 1 LSB everywhere; after final.glsl >= 99.8 % of the values
+    within 1 LSB, the rest on antialiased outlines where one supersample of four lands on the other side of a bar's edge."""
+    from pathlib import Path
+    from tests.helpers import oracle_textures, visualizer_inputs
+    K = np.load(Path(__file__).parent/"golden"/"gles_4k.npz")
+    w, h, ssaa, seed, volume = int(K["args"][0]), int(K["args"][1]), int(K["args"][2]), int(K["args"][3]), float(K["args"][4])
+    u, arrays, params = visualizer_inputs(w, h, seed=seed, volume=volume, bg_size=(int(K["args"][5]), int(K["args"][6])))
+    u.iSSAA = float(ssaa)
+    for first, last in K["bands"]:
+        screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, rows=(first*ssaa, last*ssaa), threads=8)
+        d = np.abs(screen[first*ssaa:last*ssaa, ::16].astype(int) - K[f"rows{first}.screen"].astype(int))
+        assert (d <= 1).mean() >= 0.9995, (int(first), np.bincount(d.ravel())[:6])
+        final = O.resolve(screen, w, h, 2, rows=(first, last), threads=8)[first:last]
+        d = np.abs(final.astype(int) - K[f"rows{first}.final"].astype(int))
+        assert (d <= 1).mean() >= 0.998, (int(first), np.bincount(d.ravel())[:6])
