@@ -185,6 +185,12 @@ int sfx_shm_destroy(sfx_handle shm);         /* unmaps; rank 0 also unlinks the 
  * In export mode the whole file is known, so the "ring" is the PCM itself, resident in HBM: the window
  * the reference reads after `tell` samples were appended is stream[tell-n-1 : tell-1], zeros before 0. */
 
+/* PCM ingest without an ffmpeg binary (the reference pipes every file through ffmpeg, ffmpeg.py:1194-1235,
+ * 1240-1333): FLAC streams decoded natively — host code, integer-exact by the format's definition, CRC-checked. `data` is the
+ * whole file. samples = per channel; out = interleaved float32 (integer / 2^(bits-1), like ffmpeg's pcm_f32le). */
+int sfx_flac_info(const void* data, size_t nbytes, int64_t* samples, int* channels, int* samplerate, int* bits);
+int sfx_flac_decode(const void* data, size_t nbytes, float* out, int64_t capacity_floats, int64_t* samples_written);
+
 int sfx_audio_upload(sfx_handle ctx, const float* interleaved, int64_t samples, int channels,
                      int samplerate, sfx_handle* audio);
 int sfx_audio_destroy(sfx_handle audio);

@@ -3,7 +3,8 @@ PCM ingest for the export path.
 
 The reference decodes audio by piping the file through an `ffmpeg` subprocess as pcm_f32le and slices that
 stream with `BrokenAudioReader.stream` (shaderflow/ffmpeg.py:1240-1333). No ffmpeg binary is assumed here: RIFF/WAV
-files (PCM 8/16/24/32-bit, IEEE float 32/64) are parsed natively into the same float32 interleaved samples, and
+files (PCM 8/16/24/32-bit, IEEE float 32/64) and FLAC streams (the library's native decoder, csrc/flac.inc) are read into the
+same float32 interleaved samples, and
 `BrokenAudioReader` keeps the reference's chunk arithmetic — `target += chunk; length = (target - time)*Bps`
 rounded to whole sample blocks, at least one block — because it defines which samples every frame sees
 (frame 0 reads exactly ONE sample, frame 1 reads 734, then 735 per frame at 44.1 kHz / 60 fps).
@@ -59,18 +60,45 @@ def read_wav(path: Path) -> tuple[np.ndarray, int]:
     return np.ascontiguousarray(pcm[:frames*channels].reshape(frames, channels)), int(samplerate)
 
 
+def flac_info(path: Path) -> tuple[int, int, int, int]:
+    """(samples per channel, channels, samplerate, bits) of a FLAC file, from its STREAMINFO block"""
+    import ctypes as C
+
+    from shaderflow_amd import _native as N
+    raw = Path(path).read_bytes()
+    samples, channels, samplerate, bits = C.c_int64(), C.c_int(), C.c_int(), C.c_int()
+    N.check(N.lib().sfx_flac_info(raw, len(raw), C.byref(samples), C.byref(channels), C.byref(samplerate), C.byref(bits)))
+    return samples.value, channels.value, samplerate.value, bits.value
+
+
+def read_flac(path: Path) -> tuple[np.ndarray, int]:
+    """Returns (samples float32 (n, channels), samplerate): the native decoder of the library (csrc/flac.inc)"""
+    import ctypes as C
+
+    from shaderflow_amd import _native as N
+    raw = Path(path).read_bytes()
+    samples, channels, samplerate, bits = C.c_int64(), C.c_int(), C.c_int(), C.c_int()
+    N.check(N.lib().sfx_flac_info(raw, len(raw), C.byref(samples), C.byref(channels), C.byref(samplerate), C.byref(bits)))
+    out = np.zeros((samples.value, channels.value), np.float32)
+    written = C.c_int64()
+    N.check(N.lib().sfx_flac_decode(raw, len(raw), N.as_ptr(out, C.c_float), out.size, C.byref(written)))
+    return out[:written.value], int(samplerate.value)
+
+
 def decode_audio(path: Path) -> tuple[np.ndarray, int]:
-    """(samples float32 (n, channels), samplerate) of any audio file: RIFF/WAVE natively, other containers through an `ffmpeg`
-    binary as the reference does (pcm_f32le over a pipe, ffmpeg.py:1294-1301; samplerate and channels from ffprobe)"""
+    """(samples float32 (n, channels), samplerate) of any audio file: RIFF/WAVE and FLAC natively, other containers through an
+    `ffmpeg` binary as the reference does (pcm_f32le over a pipe, ffmpeg.py:1294-1301; samplerate and channels from ffprobe)"""
     raw = Path(path)
     with open(raw, "rb") as file:
         magic = file.read(12)
     if magic[:4] == b"RIFF" and magic[8:12] == b"WAVE":
         return read_wav(raw)
+    if magic[:4] == b"fLaC":
+        return read_flac(raw)
     import shutil
     import subprocess
     if not (shutil.which("ffmpeg") and shutil.which("ffprobe")):
-        raise ValueError(f"{path}: not a RIFF/WAVE file and no ffmpeg/ffprobe binary to decode it with (convert it to WAV first)")
+        raise ValueError(f"{path}: neither RIFF/WAVE nor FLAC, and no ffmpeg/ffprobe binary to decode it with (convert it to WAV or FLAC first)")
     from shaderflow_amd.ffmpeg import FFmpeg
     samplerate, channels = FFmpeg.get_audio_samplerate(raw), FFmpeg.get_audio_channels(raw)
     command = FFmpeg().quiet().input(path=raw).pcm("pcm_f32le").no_video().output("-").command

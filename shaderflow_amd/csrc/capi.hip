@@ -1177,6 +1177,7 @@ extern "C" int sfx_ring_destroy(sfx_handle h) {
 }
 
 #include "shm_ring.inc"
+#include "flac.inc"
 
 // ---------------------------------------------------------------------------------------------------------
 // Audio

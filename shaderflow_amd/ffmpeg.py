@@ -251,20 +251,25 @@ class FFmpeg:
         return shutil.which("ffmpeg") is not None
 
     # media probes (ffmpeg.py:1104-1235) ----------------------------------------------------------------------
-    # RIFF/WAVE files are answered from their header by the native reader; anything else needs the ffprobe binary.
+    # RIFF/WAVE and FLAC files are answered by the native readers; anything else needs the ffprobe binary.
     # A path that does not exist gives None, like the reference.
 
     @staticmethod
     def _wav(path: Path):
-        from shaderflow_amd.audio.reader import read_wav
-        if Path(path).suffix.lower() in (".wav", ".wave"):
+        """(samples, samplerate) of the containers read natively — RIFF/WAVE and FLAC, by their magic bytes — else None"""
+        from shaderflow_amd.audio.reader import read_flac, read_wav
+        with open(path, "rb") as file:
+            magic = file.read(12)
+        if magic[:4] == b"RIFF" and magic[8:12] == b"WAVE":
             return read_wav(path)
+        if magic[:4] == b"fLaC":
+            return read_flac(path)
         return None
 
     @staticmethod
     def _probe(path: Path, stream: str, entry: str) -> str:
         if shutil.which("ffprobe") is None:
-            raise RuntimeError(f"{path}: probing this container needs the ffprobe binary (RIFF/WAVE files do not)")
+            raise RuntimeError(f"{path}: probing this container needs the ffprobe binary (RIFF/WAVE and FLAC files do not)")
         return subprocess.check_output(["ffprobe", "-hide_banner", "-loglevel", "error", "-select_streams", stream,
                                         "-show_entries", entry, "-of", "default=noprint_wrappers=1:nokey=1", str(path)], text=True).strip()
 
@@ -297,7 +302,7 @@ class FFmpeg:
         wav = FFmpeg._wav(path)
         if wav:
             return wav[0]
-        raise RuntimeError(f"{path}: decoding this container needs an ffmpeg binary; convert it to WAV")
+        raise RuntimeError(f"{path}: decoding this container needs an ffmpeg binary; convert it to WAV or FLAC")
 
     @staticmethod
     def get_video_resolution(path: Path, *, echo: bool = True) -> Optional[tuple[int, int]]:

@@ -399,3 +399,21 @@ def test_host_api_odds_and_ends(tmp_path):
     dumped = ShaderDumper.directory()
     assert "undeclared_function" in (dumped/f"{scene.shader.uuid}.frag").read_text() and (dumped/f"{scene.shader.uuid}.hip").exists()
     assert "error" in (dumped/f"{scene.shader.uuid}-error.md").read_text()
+
+
+def test_flac_and_wav_files_drive_the_same_export(tmp_path):
+    """audio files reach ShaderAudio without an ffmpeg binary — RIFF/WAVE and FLAC through the native readers; the same
+    samples in either container give the same frames, byte for byte"""
+    import struct
+    from examples.scenes import Visualizer, make
+    from tests.flac_encoder import encode
+    pcm, sr = clip(0.4)
+    ints = np.clip(np.rint(pcm*32767.0), -32768, 32767).astype(np.int64)
+    (tmp_path/"clip.flac").write_bytes(encode(ints, sr, 16, blocksize=4096, plan=lambda frame, channels: dict(assignment=10, subframes=[dict(kind="fixed", order=2, partition_order=3)]*2)))
+    data = ints.astype("<i2").tobytes()
+    (tmp_path/"clip.wav").write_bytes(struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(data), b"WAVE", b"fmt ", 16, 1, 2, sr, sr*4, 4, 16, b"data", len(data)) + data)
+    background = synth.background_image(96, 54, seed=3)
+    kw = dict(width=96, height=54, fps=60.0, ssaa=2, time=0.25, output=bytes)
+    from_flac = make(Visualizer, audio=str(tmp_path/"clip.flac"), background=background).main(**kw)
+    from_wav = make(Visualizer, audio=str(tmp_path/"clip.wav"), background=background).main(**kw)
+    assert from_flac == from_wav and frames_of(from_flac, 96, 54).std() > 1
