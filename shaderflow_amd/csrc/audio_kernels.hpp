@@ -88,42 +88,54 @@ __global__ void k_filterbank_csr(const int* __restrict__ indptr, const int* __re
 // non-zeros per row, spectrogram.py:194-224). Exact float32 products, fma chain in k order.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void k_filterbank_mfma(const float* __restrict__ A, int k_pad, const int2* __restrict__ band,
-                                                         int bins, int channels, int fft_bins, int ncols,
-                                                         const float* __restrict__ power, float* __restrict__ out) {
-    __shared__ float As[32][33];
-    __shared__ float Bs[128][33];
-    const int tile_row = blockIdx.y, col0 = blockIdx.x*128;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// One wave per (32 columns, 32-bin row tile, k split): the band of the row tile is cut into FILTERBANK_SPLITS contiguous runs of
+// 32-wide chunks, every wave feeds its chunks straight from global memory (L2-resident: 1 MB of power per 60 frames) into the matrix
+// pipe — lanes 0-31 supply the even k of a chunk, lanes 32-63 the odd ones, as v_mfma_f32_32x32x2_f32 wants them — and writes its
+// 32x32 partial sums; k_filterbank_reduce adds the splits in a fixed order. 4 x 4 x 8 = 128 waves instead of 16 that walked their
+// whole band through LDS (209 µs per 60 frames in round 1).
+constexpr int FILTERBANK_SPLITS = 8;
+
+__global__ __launch_bounds__(64) void k_filterbank_mfma(const float* __restrict__ A, int k_pad, const int2* __restrict__ band,
+                                                        int fft_bins, int ncols, const float* __restrict__ power,
+                                                        float* __restrict__ partial /* [split][row_tiles*32][ncols] */) {
+    const int tile_row = blockIdx.y, col0 = blockIdx.x*32, split = blockIdx.z;
+    const int lane = threadIdx.x & 63, half = lane >> 5, l = lane & 31;
     const int2 kr = band[tile_row];
+    const int chunks = (kr.y - kr.x)/32, per = (chunks + FILTERBANK_SPLITS - 1)/FILTERBANK_SPLITS;
+    const int first = split*per, last = min(chunks, first + per);
     f32x16 acc = {0};
-    for (int kc = kr.x; kc < kr.y; kc += 32) {
-        for (int e = threadIdx.x; e < 32*32; e += 256) {
-            const int r = e >> 5, k = e & 31;
-            As[r][k] = A[(long)(tile_row*32 + r)*k_pad + kc + k];
-        }
-        for (int e = threadIdx.x; e < 128*32; e += 256) {
-            const int cc = e >> 5, k = e & 31;
-            const int col = col0 + cc;
-            Bs[cc][k] = (col < ncols && kc + k < fft_bins) ? power[(long)col*fft_bins + kc + k] : 0.0f;
-        }
-        __syncthreads();
+    const int col = col0 + l;
+    const float* a_row = A + (long)(tile_row*32 + l)*k_pad;
+    const float* b_row = power + (long)min(col, ncols - 1)*fft_bins;
+    for (int c = first; c < last; c++) {
+        const int kc = kr.x + c*32 + half;
+        float a[16], b[16];
 #pragma unroll
-        for (int kk = 0; kk < 32; kk += 2) {
-            const float a = As[lane & 31][kk + (lane >> 5)];
-            const float b = Bs[wave*32 + (lane & 31)][kk + (lane >> 5)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int q = 0; q < 16; q++) {
+            const int k = kc + 2*q;
+            a[q] = a_row[k];                                          // zero padded to k_pad
+            b[q] = (col < ncols && k < fft_bins) ? b_row[k] : 0.0f;
         }
-        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
     }
-    const int col = col0 + wave*32 + (lane & 31);
     if (col < ncols) {
+        float* out = partial + ((long)split*gridDim.y*32)*ncols;
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
-            const int r = tile_row*32 + (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5);
-            if (r < bins) out[((long)(col / channels)*bins + r)*channels + (col % channels)] = acc[reg];
+            const int r = tile_row*32 + (reg & 3) + 8*(reg >> 2) + 4*half;
+            out[(long)r*ncols + col] = acc[reg];
         }
     }
+}
+
+__global__ void k_filterbank_reduce(const float* __restrict__ partial, int rows_pad, int bins, int channels, int ncols, float* __restrict__ out) {
+    const long t = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (t >= (long)ncols*bins) return;
+    const int col = (int)(t / bins), r = (int)(t % bins);
+    float sum = 0.0f;
+    for (int split = 0; split < FILTERBANK_SPLITS; split++) sum = sum + partial[((long)split*rows_pad + r)*ncols + col];
+    out[((long)(col / channels)*bins + r)*channels + (col % channels)] = sum;
 }
 
 // ---- K4 ---------------------------------------------------------------------------------------------------

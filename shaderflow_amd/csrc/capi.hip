@@ -770,8 +770,11 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
     t.block_y = t.block_x + (size_t)frames*t.blocks_x;
     hipLaunchKernelGGL(k_visualizer_axis<0>, dim3((a.wr + 127)/128, frames), dim3(128), 0, s, a, t);
     hipLaunchKernelGGL(k_visualizer_axis<1>, dim3((a.hr + 127)/128, frames), dim3(128), 0, s, a, t);
-    g_last_kernel = "k_visualizer_fast<" + std::to_string(PITCH) + ", " + std::to_string(ROWS) + ", " + std::to_string(BLOCK_PX) + ", 8>";
-    hipLaunchKernelGGL((k_visualizer_fast<PITCH, ROWS, BLOCK_PX, 8>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(4*BLOCK_PX), 0, s, a, t);
+#ifndef VIS_FAST_WAVES
+#define VIS_FAST_WAVES 8
+#endif
+    g_last_kernel = "k_visualizer_fast<" + std::to_string(PITCH) + ", " + std::to_string(ROWS) + ", " + std::to_string(BLOCK_PX) + ", " + std::to_string(VIS_FAST_WAVES) + ">";
+    hipLaunchKernelGGL((k_visualizer_fast<PITCH, ROWS, BLOCK_PX, VIS_FAST_WAVES>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(4*BLOCK_PX), 0, s, a, t);
     return 1;
 }
 
@@ -1222,6 +1225,7 @@ struct Plan : Object {
     float* d_dense = nullptr; int2* d_band = nullptr; int k_pad = 0, row_tiles = 0;
     // scratch that grows on demand
     long* d_tell = nullptr; float* d_power = nullptr; float* d_out = nullptr; int cap_frames = 0;
+    float* d_partial = nullptr; size_t partial_floats = 0;        // k-split partial sums of the MFMA filterbank
 };
 
 static int plan_reserve(Plan* p, int frames) {
@@ -1309,7 +1313,7 @@ extern "C" int sfx_stft_plan_destroy(sfx_handle h) {
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
     hipFree(p->d_window); hipFree(p->d_twiddle); hipFree(p->d_indptr); hipFree(p->d_indices); hipFree(p->d_data);
-    hipFree(p->d_dense); hipFree(p->d_band); hipFree(p->d_tell); hipFree(p->d_power); hipFree(p->d_out);
+    hipFree(p->d_dense); hipFree(p->d_band); hipFree(p->d_tell); hipFree(p->d_power); hipFree(p->d_out); hipFree(p->d_partial);
     p->magic = 0;
     delete p;
     return SFX_OK;
@@ -1328,11 +1332,20 @@ static void launch_stft(const Plan* p, const Audio* a, const long* d_tell, int f
     hipLaunchKernelGGL(k_stft_power, dim3(frames, p->channels), dim3(256), (N/2)*sizeof(double2), s,
                        a->pcm, a->samples, d_tell, p->fft_n, p->d_window, p->d_twiddle, d_power, p->amplitude);
 }
-static void launch_filterbank(const Plan* p, int frames, int use_mfma, const float* d_power, float* d_out, hipStream_t s) {
+static void launch_filterbank(Plan* p, int frames, int use_mfma, const float* d_power, float* d_out, hipStream_t s) {
     const int ncols = frames*p->channels;
+    const size_t partial = (size_t)FILTERBANK_SPLITS*p->row_tiles*32*ncols;
+    if (use_mfma && p->partial_floats < partial) {
+        hipStreamSynchronize(s);
+        hipFree(p->d_partial); p->d_partial = nullptr; p->partial_floats = 0;
+        if (hipMalloc(&p->d_partial, partial*sizeof(float)) == hipSuccess) p->partial_floats = partial;
+        else { (void)hipGetLastError(); use_mfma = 0; }               // out of memory for the scratch: the CSR kernel needs none
+    }
     if (use_mfma) {
-        hipLaunchKernelGGL(k_filterbank_mfma, dim3((ncols + 127)/128, p->row_tiles), dim3(256), 0, s,
-                           p->d_dense, p->k_pad, p->d_band, p->bins, p->channels, p->fft_bins, ncols, d_power, d_out);
+        hipLaunchKernelGGL(k_filterbank_mfma, dim3((ncols + 31)/32, p->row_tiles, FILTERBANK_SPLITS), dim3(64), 0, s,
+                           p->d_dense, p->k_pad, p->d_band, p->fft_bins, ncols, d_power, p->d_partial);
+        const long total = (long)ncols*p->bins;
+        hipLaunchKernelGGL(k_filterbank_reduce, dim3((unsigned)((total + 255)/256)), dim3(256), 0, s, p->d_partial, p->row_tiles*32, p->bins, p->channels, ncols, d_out);
     } else {
         const long total = (long)ncols*p->bins;
         hipLaunchKernelGGL(k_filterbank_csr, dim3((unsigned)((total + 255)/256)), dim3(256), 0, s,
@@ -1579,7 +1592,7 @@ extern "C" int sfx_tape_build(sfx_handle h, int nframes, const int64_t* tell, co
     static_assert(sizeof(sfx_dyn_coeff_f32) == sizeof(DynCoeffF32) && sizeof(sfx_dyn_coeff_f64) == sizeof(DynCoeffF64) && sizeof(sfx_frame_clock) == sizeof(FrameClock), "ABI structs");
     USE_DEVICE(t->ctx);
     hipStream_t s = t->ctx->stream;
-    const Plan* p = t->plan; const Audio* a = t->audio;
+    Plan* p = t->plan; const Audio* a = t->audio;
     HIP_TRY(hipMemcpyAsync(t->d_tell, tell, sizeof(long)*nframes, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(t->d_clock, clock, sizeof(FrameClock)*nframes, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(t->d_coeff, spectrogram, sizeof(DynCoeffF32)*nframes, hipMemcpyHostToDevice, s));

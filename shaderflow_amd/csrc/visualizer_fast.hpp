@@ -280,7 +280,10 @@ struct VisualizerFast {
                 const float4* cells = sh.cells;
                 float xp = xr + first, xm = xr - first, yp = yr + first, ym = yr - first;
                 using V = VisualizerShader<TILE_PITCH, TILE_ROWS, 8>;
-#pragma unroll 1
+#ifndef VIS_FAST_UNROLL
+#define VIS_FAST_UNROLL 1
+#endif
+#pragma unroll VIS_FAST_UNROLL
                 for (int w = 0; w < 10; w++) {
                     const float axp = __builtin_amdgcn_fractf(xp), axm = __builtin_amdgcn_fractf(xm);
                     const float ayp = __builtin_amdgcn_fractf(yp), aym = __builtin_amdgcn_fractf(ym);
