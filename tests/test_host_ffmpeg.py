@@ -93,12 +93,12 @@ print('2' if 'stream=channels' in sys.argv else '32000')
 
 
 def test_non_wav_audio_goes_through_the_ffmpeg_binary(tmp_path, monkeypatch):
-    """Containers other than RIFF/WAVE are decoded like the reference does (ffmpeg.py:1294-1301): pcm_f32le on a pipe, format from
-    ffprobe; stand-in binaries here"""
+    """Containers other than RIFF/WAVE and FLAC (read natively) are decoded like the reference does (ffmpeg.py:1294-1301):
+    pcm_f32le on a pipe, format from ffprobe; stand-in binaries here"""
     import os
     from shaderflow_amd.audio.reader import BrokenAudioReader, decode_audio
     samples = np.random.default_rng(1).uniform(-1, 1, (3000, 2)).astype(np.float32)
-    (tmp_path/"song.flac").write_bytes(b"fLaC" + samples.tobytes())                 # not a real FLAC: the stand-in decoder strips the tag
+    (tmp_path/"song.ogg").write_bytes(b"OggS" + samples.tobytes())                 # not a real stream: the stand-in decoder strips the tag
     bindir = tmp_path/"bin"
     bindir.mkdir()
     (bindir/"ffmpeg").write_text(FAKE_DECODER)
@@ -107,9 +107,9 @@ def test_non_wav_audio_goes_through_the_ffmpeg_binary(tmp_path, monkeypatch):
         (bindir/tool).chmod(0o755)
     monkeypatch.setenv("PATH", "/nonexistent")
     with pytest.raises(ValueError, match="no ffmpeg"):
-        decode_audio(tmp_path/"song.flac")
+        decode_audio(tmp_path/"song.ogg")
     monkeypatch.setenv("PATH", f"{bindir}{os.pathsep}/usr/bin{os.pathsep}/bin")
-    decoded, samplerate = decode_audio(tmp_path/"song.flac")
+    decoded, samplerate = decode_audio(tmp_path/"song.ogg")
     assert samplerate == 32000 and np.array_equal(decoded, samples)
-    reader = BrokenAudioReader(path=tmp_path/"song.flac").load()
+    reader = BrokenAudioReader(path=tmp_path/"song.ogg").load()
     assert reader.channels == 2 and reader.samplerate == 32000
