@@ -753,9 +753,26 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
     const float reach_line = (fabsf(a.tap_x[0]) + 9.0f*fabsf(a.tap_x[1] - a.tap_x[0]))*ax;
     if (tw > PITCH || th > ROWS || !(2.0f*reach_line + 1.0e-3f < (float)(VIS_LINE_CELLS - 1))) return 0;
 
+#ifndef VIS_FAST_WALK
+#define VIS_FAST_WALK 4
+#endif
+    constexpr int WALK = VIS_FAST_WALK;                              // > 0: every lane walks a strip of WALK samples of its column (VisualizerStrip)
+#ifndef VIS_STRIP_ROWS
+#define VIS_STRIP_ROWS (VIS_FAST_WALK <= 4 ? 10 : (VIS_FAST_WALK <= 6 ? 11 : 12))
+#endif
+#ifndef VIS_STRIP_WAVES
+#define VIS_STRIP_WAVES (VIS_FAST_WALK <= 6 ? 8 : 6)
+#endif
+    constexpr int STRIP_ROWS = VIS_STRIP_ROWS;                         // rows of cells: floor((2*WALK - 1)*0.22 + 7.14) + 2 at the largest blur radius
+    bool strip = false;
+    if (WALK > 0) {
+        int sw = 0, sh = 0;
+        visualizer_window_bound(a, BLOCK_PX*2, 2*WALK, sw, sh);
+        strip = sw <= PITCH && sh <= STRIP_ROWS;
+    }
     VisTables t;
-    t.blocks_x = (a.w + BLOCK_PX - 1)/BLOCK_PX; t.blocks_y = a.h;
-    t.block_columns = BLOCK_PX*2; t.block_rows = 2; t.tile_pitch = PITCH; t.tile_rows = ROWS;
+    t.blocks_x = (a.w + BLOCK_PX - 1)/BLOCK_PX; t.blocks_y = strip ? (a.h + WALK - 1)/WALK : a.h;
+    t.block_columns = BLOCK_PX*2; t.block_rows = strip ? 2*WALK : 2; t.tile_pitch = PITCH; t.tile_rows = strip ? STRIP_ROWS : ROWS;
     const size_t entries = (size_t)frames*((size_t)a.wr + a.hr)*VIS_ENTRY_QUADS*sizeof(float4);
     const size_t blocks = (size_t)frames*((size_t)t.blocks_x + t.blocks_y)*sizeof(int4);
     if (ctx->vis_tables_bytes < entries + blocks) {
@@ -773,6 +790,12 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
 #ifndef VIS_FAST_WAVES
 #define VIS_FAST_WAVES 8
 #endif
+    if (strip) {
+        constexpr int W = WALK > 0 ? WALK : 3, SW = VIS_STRIP_WAVES;
+        g_last_kernel = "k_visualizer_strip<" + std::to_string(PITCH) + ", " + std::to_string(STRIP_ROWS) + ", " + std::to_string(BLOCK_PX) + ", " + std::to_string(W) + ", " + std::to_string(SW) + ">";
+        hipLaunchKernelGGL((k_visualizer_strip<PITCH, STRIP_ROWS, BLOCK_PX, W, SW>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(4*BLOCK_PX), 0, s, a, t);
+        return 1;
+    }
     g_last_kernel = "k_visualizer_fast<" + std::to_string(PITCH) + ", " + std::to_string(ROWS) + ", " + std::to_string(BLOCK_PX) + ", " + std::to_string(VIS_FAST_WAVES) + ">";
     hipLaunchKernelGGL((k_visualizer_fast<PITCH, ROWS, BLOCK_PX, VIS_FAST_WAVES>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(4*BLOCK_PX), 0, s, a, t);
     return 1;

@@ -140,6 +140,75 @@ __global__ __launch_bounds__(128) void k_visualizer_axis(const RenderArgs a, con
     e[6] = make_float4(wn[6], ws[6], wn[7], ws[7]);
 }
 
+// visualizer.frag:32-73 (fragments.hpp visualizer_post<true>) on the blur's sums and the separable terms of the tables: c1/c2 the
+// column's q1/q2, r1/r2 the row's. Returns the RGB8 texel iScreen would hold (alpha is never read by final.glsl).
+__device__ __forceinline__ uint32_t visualizer_fast_post(const RenderArgs& a, int frame, const VisualizerConsts& c, float r, float g, float b,
+                                                         const float4 c1, const float4 c2, const float4 r1, const float4 r2) {
+    const float norm = 1.0f/(255.0f*10.0f*8.0f);                      // (sum/255)/(quality*directions), visualizer.frag:32
+    vec3 col = {r*norm, g*norm, b*norm};
+    const vec3 space = vec3{1.0f, 11.0f, 26.0f}/255.0f;                                                // :9
+    {
+        const float la = __builtin_amdgcn_sqrtf(c1.w + r1.w);                                   // length(agluv), colour only
+        const float cl = sf::clamp(la - 0.3f, 0.0f, 1.0f);
+        const float c2l = cl*cl;
+        col = col*(1.0f + c.flash*(c2l*c2l*c2l));                                               // :36
+    }
+    const vec2 music_uv = vec2{c1.x + r1.x, c1.y + r1.y}*c.shrink;                              // :39-40
+    const float radius = 0.17f;
+    const float circle = sf::abs(atan1n(music_uv));                                             // :44
+    const Tex& sp = a.tex[TEX_SPECTROGRAM];
+    const float* bars = a.tape_bars + (long)(a.frame0 + frame)*a.spectrogram_stride;
+    const int bin = wrap_texel((int)::floorf(circle*(float)sp.height), sp.height, sp.repeat_y);
+    vec2 freq = {bars[2*bin], bars[2*bin + 1]};                                                 // sqrt(texel/1000), :45
+    freq = freq*(0.05f + 3.0f*sf::smoothstep(0.0f, 2.0f, circle));                              // :46
+    const float len = length(music_uv);
+    if (len < radius) {                                                                         // :49-50
+        col = col*0.5f;
+    } else {
+        const float bar = (music_uv.y < 0.0f) ? freq.x : freq.y;                                // :52
+        const float rr = radius + 0.5f*bar;
+        if (len < rr) col = mix(col, vec3{1.0f, 1.0f, 1.0f}, sf::smoothstep(0.0f, 1.0f, 0.5f + bar));   // :56
+        else col = col*ColourMath<true>::pow((len - rr)*0.5f, 0.05f);                           // :58
+    }
+    {
+        const float lp = __builtin_amdgcn_sqrtf(c1.z + r1.z)*0.05f;                             // length(uv)/20, colour only
+        col = mix(col, space, sf::smoothstep(0.0f, 1.0f, lp));                                  // :62
+    }
+    // pow(vig.x*vig.y*20, e) = exp2(e*(log2(ax(1-ax)) + log2(ay(1-ay)) + log2(20))), :65-66
+    col = col*__builtin_amdgcn_exp2f(c.vig_exp*((c2.x + r2.x) + 4.321928095f));
+    if (r2.y < c2.y) col = col*0.8f;                                                            // :72
+    if (r2.z < c2.z) col = col*0.8f;                                                            // :73
+    if (__float_as_int(c2.w) != 0) col = space;                                                 // :11-14
+    return pack_rgb8(col);
+}
+
+// Stages the window [x0, x0+tw) x [y0, y0+th) of the background as difference-basis cells (VisualizerShader::setup step 2)
+template <int TILE_PITCH, int THREADS>
+__device__ __forceinline__ void visualizer_fast_stage(const Tex& bg, float4* cells, int x0, int y0, int tw, int th, int tid) {
+    const uint8_t* data = (const uint8_t*)bg.data;
+    const int comps = bg.components;
+    typedef uint32_t unaligned_u32 __attribute__((aligned(1)));
+    for (int idx = tid; idx < TILE_PITCH*th; idx += THREADS) {
+        const int ty = idx / TILE_PITCH, tx = idx - ty*TILE_PITCH;
+        if (tx >= tw) continue;
+        const int j0 = wrap_texel(y0 + ty, bg.height, bg.repeat_y), j1 = wrap_texel(y0 + ty + 1, bg.height, bg.repeat_y);
+        const int i0 = wrap_texel(x0 + tx, bg.width, bg.repeat_x), i1 = wrap_texel(x0 + tx + 1, bg.width, bg.repeat_x);
+        const uint32_t row0 = (uint32_t)j0*(uint32_t)bg.width, row1 = (uint32_t)j1*(uint32_t)bg.width;
+        const uint32_t w00 = *(const unaligned_u32*)(data + (size_t)(row0 + i0)*comps);
+        const uint32_t w10 = *(const unaligned_u32*)(data + (size_t)(row0 + i1)*comps);
+        const uint32_t w01 = *(const unaligned_u32*)(data + (size_t)(row1 + i0)*comps);
+        const uint32_t w11 = *(const unaligned_u32*)(data + (size_t)(row1 + i1)*comps);
+        const float r00 = (float)(w00 & 255u), g00 = (float)((w00 >> 8) & 255u), b00 = (float)((w00 >> 16) & 255u);
+        const float r10 = (float)(w10 & 255u), g10 = (float)((w10 >> 8) & 255u), b10 = (float)((w10 >> 16) & 255u);
+        const float r01 = (float)(w01 & 255u), g01 = (float)((w01 >> 8) & 255u), b01 = (float)((w01 >> 16) & 255u);
+        const float r11 = (float)(w11 & 255u), g11 = (float)((w11 >> 8) & 255u), b11 = (float)((w11 >> 16) & 255u);
+        float4* cell = cells + (ty*TILE_PITCH + tx)*3;
+        cell[0] = make_float4(r00, g00, b00, r10 - r00);
+        cell[1] = make_float4(g10 - g00, b10 - b00, r01 - r00, g01 - g00);
+        cell[2] = make_float4(b01 - b00, (r00 - r10) - (r01 - r11), (g00 - g10) - (g01 - g11), (b00 - b10) - (b01 - b11));
+    }
+}
+
 // ---- the fused kernel ------------------------------------------------------------------------------------------------------
 // S == 2: a quad of lanes per output pixel, one supersample each (render_kernels.hpp render_resolve_body's layout and epilogue).
 template <int TILE_PITCH, int TILE_ROWS, int BLOCK_PX>
@@ -214,29 +283,7 @@ struct VisualizerFast {
 
         // stage the window (VisualizerShader::setup step 2) and the block's two row entries
         if (wx.z && wy.z) {
-            const int x0 = wx.x, y0 = wy.x, tw = wx.y, th = wy.y;
-            const uint8_t* data = (const uint8_t*)bg.data;
-            const int comps = bg.components;
-            typedef uint32_t unaligned_u32 __attribute__((aligned(1)));
-            for (int idx = tid; idx < TILE_PITCH*th; idx += THREADS) {
-                const int ty = idx / TILE_PITCH, tx = idx - ty*TILE_PITCH;
-                if (tx >= tw) continue;
-                const int j0 = wrap_texel(y0 + ty, bg.height, bg.repeat_y), j1 = wrap_texel(y0 + ty + 1, bg.height, bg.repeat_y);
-                const int i0 = wrap_texel(x0 + tx, bg.width, bg.repeat_x), i1 = wrap_texel(x0 + tx + 1, bg.width, bg.repeat_x);
-                const uint32_t row0 = (uint32_t)j0*(uint32_t)bg.width, row1 = (uint32_t)j1*(uint32_t)bg.width;
-                const uint32_t w00 = *(const unaligned_u32*)(data + (size_t)(row0 + i0)*comps);
-                const uint32_t w10 = *(const unaligned_u32*)(data + (size_t)(row0 + i1)*comps);
-                const uint32_t w01 = *(const unaligned_u32*)(data + (size_t)(row1 + i0)*comps);
-                const uint32_t w11 = *(const unaligned_u32*)(data + (size_t)(row1 + i1)*comps);
-                const float r00 = (float)(w00 & 255u), g00 = (float)((w00 >> 8) & 255u), b00 = (float)((w00 >> 16) & 255u);
-                const float r10 = (float)(w10 & 255u), g10 = (float)((w10 >> 8) & 255u), b10 = (float)((w10 >> 16) & 255u);
-                const float r01 = (float)(w01 & 255u), g01 = (float)((w01 >> 8) & 255u), b01 = (float)((w01 >> 16) & 255u);
-                const float r11 = (float)(w11 & 255u), g11 = (float)((w11 >> 8) & 255u), b11 = (float)((w11 >> 16) & 255u);
-                float4* cell = sh.cells + (ty*TILE_PITCH + tx)*3;
-                cell[0] = make_float4(r00, g00, b00, r10 - r00);
-                cell[1] = make_float4(g10 - g00, b10 - b00, r01 - r00, g01 - g00);
-                cell[2] = make_float4(b01 - b00, (r00 - r10) - (r01 - r11), (g00 - g10) - (g01 - g11), (b00 - b10) - (b01 - b11));
-            }
+            visualizer_fast_stage<TILE_PITCH, THREADS>(bg, sh.cells, wx.x, wy.x, wx.y, wy.y, tid);
             if (tid < S*VIS_ENTRY_QUADS) {
                 const int row = tid / VIS_ENTRY_QUADS, quad = tid - row*VIS_ENTRY_QUADS;
                 const int jr = min(by*S + row, a.hr - 1);
@@ -297,45 +344,7 @@ struct VisualizerFast {
                 }
             }
             }
-            const float norm = 1.0f/(255.0f*10.0f*8.0f);              // (sum/255)/(quality*directions), visualizer.frag:32
-            vec3 col = {r*norm, g*norm, b*norm};
-            const vec3 space = vec3{1.0f, 11.0f, 26.0f}/255.0f;                                        // :9
-
-            // ---- visualizer.frag:36-73 (fragments.hpp visualizer_post<true>) on the separable terms ----
-            const float4 c1 = ce[1], c2 = ce[2], r1 = re[1], r2 = re[2];
-            {
-                const float la = __builtin_amdgcn_sqrtf(c1.w + r1.w);                                   // length(agluv), colour only
-                const float cl = sf::clamp(la - 0.3f, 0.0f, 1.0f);
-                const float c2l = cl*cl;
-                col = col*(1.0f + c.flash*(c2l*c2l*c2l));                                               // :36
-            }
-            const vec2 music_uv = vec2{c1.x + r1.x, c1.y + r1.y}*c.shrink;                              // :39-40
-            const float radius = 0.17f;
-            const float circle = sf::abs(atan1n(music_uv));                                             // :44
-            const Tex& sp = a.tex[TEX_SPECTROGRAM];
-            const float* bars = a.tape_bars + (long)(a.frame0 + frame)*a.spectrogram_stride;
-            const int bin = wrap_texel((int)::floorf(circle*(float)sp.height), sp.height, sp.repeat_y);
-            vec2 freq = {bars[2*bin], bars[2*bin + 1]};                                                 // sqrt(texel/1000), :45
-            freq = freq*(0.05f + 3.0f*sf::smoothstep(0.0f, 2.0f, circle));                              // :46
-            const float len = length(music_uv);
-            if (len < radius) {                                                                         // :49-50
-                col = col*0.5f;
-            } else {
-                const float bar = (music_uv.y < 0.0f) ? freq.x : freq.y;                                // :52
-                const float rr = radius + 0.5f*bar;
-                if (len < rr) col = mix(col, vec3{1.0f, 1.0f, 1.0f}, sf::smoothstep(0.0f, 1.0f, 0.5f + bar));   // :56
-                else col = col*ColourMath<true>::pow((len - rr)*0.5f, 0.05f);                           // :58
-            }
-            {
-                const float lp = __builtin_amdgcn_sqrtf(c1.z + r1.z)*0.05f;                             // length(uv)/20, colour only
-                col = mix(col, space, sf::smoothstep(0.0f, 1.0f, lp));                                  // :62
-            }
-            // pow(vig.x*vig.y*20, e) = exp2(e*(log2(ax(1-ax)) + log2(ay(1-ay)) + log2(20))), :65-66
-            col = col*__builtin_amdgcn_exp2f(c.vig_exp*((c2.x + r2.x) + 4.321928095f));
-            if (r2.y < c2.y) col = col*0.8f;                                                            // :72
-            if (r2.z < c2.z) col = col*0.8f;                                                            // :73
-            if (__float_as_int(c2.w) != 0) col = space;                                                 // :11-14
-            texel = pack_rgb8(col);
+            texel = visualizer_fast_post(a, frame, c, r, g, b, ce[1], ce[2], re[1], re[2]);
         }
 
         // final.glsl over the pixel's 2x2 block (render_resolve_body): lane c of the quad resolves channel c
@@ -352,6 +361,217 @@ struct VisualizerFast {
         if (py < a.h) store_rgb_row(out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3, bx*BLOCK_PX, a.w, sh.staged, tid, THREADS, BLOCK_PX);
     }
 };
+
+// ---- the same, with every lane walking a strip of WALK samples of its column ---------------------------------------------------
+// What a supersample shares with the one 0.42 texel above it in the same column:
+//   * the row-line: its per-cell weights (n, s) depend on the column only, and so do its cells as long as the two samples lie in
+//     the same row of texel cells — then the line's sums P = sum(n*A + s*B), Q = sum(n*C + s*D) are the same and the samples
+//     differ by the lerp P + fy*Q alone: 8 cell fetches and 96 multiply-adds once per distinct cell row instead of per sample;
+//   * the column-line's cells: the same column of cells, shifted by at most a cell per sample — fetched once for the strip, each
+//     used by every sample whose 8 slots cover it (the weights differ per row: they come from the row entries);
+//   * the x half of every diagonal tap (fraction and cell column of +-k*s), the column entry, the window staging.
+// For that the LANES OF A WAVE MUST SHARE THEIR ROWS (the questions "same cell row?" and "which slots cover this cell?" are then
+// wave-uniform: scalar branches, no divergence), so the 2 x 2 supersamples of a pixel no longer sit in the four lanes of a quad:
+// wave w holds sub-row (w & 1) of 32 pixels x 2 sub-columns; the RGBA8 texels meet in LDS (over the cells, which are dead by then)
+// and one thread per output pixel resolves all three channels — cheaper than the DPP exchange it replaces.
+template <int TILE_PITCH, int TILE_ROWS, int BLOCK_PX, int WALK>
+struct VisualizerStrip {
+    static constexpr int THREADS = 4*BLOCK_PX;
+    static constexpr int ROWBYTES = TILE_PITCH*48;
+    using Fast = VisualizerFast<TILE_PITCH, TILE_ROWS, BLOCK_PX>;
+    struct Shared {
+        float4 cells[TILE_ROWS*TILE_PITCH*3];                          // later: uint32 texels[WALK][2][2*BLOCK_PX], then the RGB8 rows at STAGED
+        float4 row_entries[2*WALK][VIS_ENTRY_QUADS];
+        float4 ysteps[2*WALK][10];                                     // the y half of the diagonal taps: { frac(y+), frac(y-), row bytes(y+), row bytes(y-) } per (row, walk step)
+    };
+    static constexpr int STAGED = 16384;                               // byte offset of the staged RGB8 rows inside the (dead) cell tile
+    static_assert(sizeof(uint32_t)*WALK*2*2*BLOCK_PX <= STAGED && STAGED + WALK*BLOCK_PX*3 <= sizeof(float4)*TILE_ROWS*TILE_PITCH*3,
+                  "the texel exchange and the staged rows live in the cell tile");
+
+    // one bilinear tap from a staged cell: A + ax*B + ay*C + (ax*ay)*D per channel (VisualizerShader::tap_at with the cell's address)
+    __device__ __forceinline__ static void tap_cell(const char* cell, float ax, float ay, float& r, float& g, float& b) {
+        const float4* p = (const float4*)cell;
+        const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+        const float axy = ax*ay;
+        r = r + q0.x;           g = g + q0.y;           b = b + q0.z;
+        r = fmaf(ax, q0.w, r);  g = fmaf(ax, q1.x, g);  b = fmaf(ax, q1.y, b);
+        r = fmaf(ay, q1.z, r);  g = fmaf(ay, q1.w, g);  b = fmaf(ay, q2.x, b);
+        r = fmaf(axy, q2.y, r); g = fmaf(axy, q2.z, g); b = fmaf(axy, q2.w, b);
+    }
+
+    __device__ static void run(const RenderArgs& a, const VisTables& t) {
+        __shared__ __attribute__((aligned(16))) Shared sh;
+        const int frame = blockIdx.z;
+        const int tile_index = xcd_band_order(blockIdx.x, gridDim.x);
+        const int bx = tile_index % t.blocks_x, by = tile_index / t.blocks_x;
+        const int tid = threadIdx.x;
+        const int wave = tid >> 6, lane = tid & 63;
+        const int sub_row = wave & 1, sub_col = lane & 1;
+        const int p = (wave >> 1)*32 + (lane >> 1);                   // pixel of the block's row segment
+        const int px = bx*BLOCK_PX + p;
+        const int i = (px < a.w ? px : a.w - 1)*2 + sub_col;
+
+        const int4 wx = t.block_x[(long)frame*t.blocks_x + bx], wy = t.block_y[(long)frame*t.blocks_y + by];
+        const bool fits = wx.z && wy.z;
+        const Tex& bg = a.tex[TEX_BACKGROUND];
+        const VisualizerConsts c = a.vis_consts ? a.vis_consts[a.frame0 + frame] : a.vis;
+        const float4* ce = t.columns + ((long)frame*a.wr + i)*VIS_ENTRY_QUADS;
+
+        if (fits) visualizer_fast_stage<TILE_PITCH, THREADS>(bg, sh.cells, wx.x, wy.x, wx.y, wy.y, tid);
+        if (tid < 2*WALK*VIS_ENTRY_QUADS) {
+            const int row = tid / VIS_ENTRY_QUADS, quad = tid - row*VIS_ENTRY_QUADS;
+            const int jr = by*2*WALK + row;
+            sh.row_entries[row][quad] = t.rows[((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*VIS_ENTRY_QUADS + quad];
+        }
+        {
+            // The y half of a diagonal tap — fraction and row of cells of y +- k*s — depends on the sample ROW and the walk step
+            // only: 2*WALK x 10 values per block instead of eight instructions per tap quadruple of every sample
+            const float ax = c.intensity*a.bg_scale_x*(float)bg.width;
+            const float step = (a.tap_x[11] - a.tap_x[10])*ax, first = a.tap_x[10]*ax;
+            if (tid < 2*WALK*10) {
+                const int row = tid / 10, w = tid - row*10;
+                const int jr = by*2*WALK + row;
+                const float yr = t.rows[((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*VIS_ENTRY_QUADS].x;
+                const float d = fmaf((float)w, step, first);
+                const float yp = yr + d, ym = yr - d;
+                const float ayp = __builtin_amdgcn_fractf(yp), aym = __builtin_amdgcn_fractf(ym);
+                sh.ysteps[row][w] = make_float4(ayp, aym, __int_as_float((int)((yp - ayp)*(float)ROWBYTES)), __int_as_float((int)((ym - aym)*(float)ROWBYTES)));
+            }
+        }
+        __syncthreads();
+
+        const float4 c0 = ce[0];
+        const float xr = c0.x, fx = c0.y;
+        const char* tile = (const char*)sh.cells;
+        float acc[WALK][3];
+#pragma unroll
+        for (int r = 0; r < WALK; r++) { acc[r][0] = 0.0f; acc[r][1] = 0.0f; acc[r][2] = 0.0f; }
+        // rows of this wave's samples: pixel row by*WALK + r, sub-row sub_row; `rows` counts the pixel rows that exist
+        const int rows = (a.h - by*WALK < WALK) ? a.h - by*WALK : WALK;
+
+        if (!fits) {
+#pragma unroll
+            for (int r = 0; r < WALK; r++)
+                if (r < rows) Fast::blur_direct(a, bg, xr + (float)wx.x, sh.row_entries[2*r + sub_row][0].x + (float)wy.x, c.intensity, acc[r][0], acc[r][1], acc[r][2]);
+        } else {
+            // ---- the row-lines: P and Q once per distinct row of cells ----
+            {
+                const float4 c3 = ce[3], c4 = ce[4], c5 = ce[5], c6 = ce[6];
+                const float n[8] = {c3.x, c3.z, c4.x, c4.z, c5.x, c5.z, c6.x, c6.z}, s[8] = {c3.y, c3.w, c4.y, c4.w, c5.y, c5.w, c6.y, c6.w};
+                float P[3] = {0.0f, 0.0f, 0.0f}, Q[3] = {0.0f, 0.0f, 0.0f};
+                int previous = -1;
+#pragma unroll
+                for (int r = 0; r < WALK; r++) if (r < rows) {
+                    const float4 r0 = sh.row_entries[2*r + sub_row][0];
+                    const int cell_row = __builtin_amdgcn_readfirstlane(__float_as_int(r0.z));       // the wave's lanes share their rows
+                    if (cell_row != previous) {
+                        previous = cell_row;
+                        const char* line = tile + (__float_as_int(c0.w) + cell_row);
+                        P[0] = P[1] = P[2] = Q[0] = Q[1] = Q[2] = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < VIS_LINE_CELLS; k++) {
+                            const float4* q = (const float4*)(line + k*48);
+                            const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+                            P[0] = fmaf(n[k], q0.x, P[0]); P[1] = fmaf(n[k], q0.y, P[1]); P[2] = fmaf(n[k], q0.z, P[2]);
+                            P[0] = fmaf(s[k], q0.w, P[0]); P[1] = fmaf(s[k], q1.x, P[1]); P[2] = fmaf(s[k], q1.y, P[2]);
+                            Q[0] = fmaf(n[k], q1.z, Q[0]); Q[1] = fmaf(n[k], q1.w, Q[1]); Q[2] = fmaf(n[k], q2.x, Q[2]);
+                            Q[0] = fmaf(s[k], q2.y, Q[0]); Q[1] = fmaf(s[k], q2.z, Q[1]); Q[2] = fmaf(s[k], q2.w, Q[2]);
+                        }
+                    }
+                    acc[r][0] = fmaf(r0.y, Q[0], P[0]); acc[r][1] = fmaf(r0.y, Q[1], P[1]); acc[r][2] = fmaf(r0.y, Q[2], P[2]);
+                }
+            }
+            // ---- the column-lines: the strip's column of cells fetched once, every sample takes the cells its slots cover ----
+            {
+                int start[WALK];
+                int last = 0;
+#pragma unroll
+                for (int r = 0; r < WALK; r++) {
+                    start[r] = __builtin_amdgcn_readfirstlane(__float_as_int(sh.row_entries[2*r + sub_row][0].w))/ROWBYTES;
+                    if (r < rows) last = start[r] + VIS_LINE_CELLS;     // start[] does not decrease with the row
+                }
+                const int first = start[0];
+                const char* column = tile + __float_as_int(c0.z);
+                for (int k = first; k < last; k++) {
+                    const float4* q = (const float4*)(column + k*ROWBYTES);
+                    const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+#pragma unroll
+                    for (int r = 0; r < WALK; r++) {
+                        const int slot = k - start[r];
+                        if (r < rows && slot >= 0 && slot < VIS_LINE_CELLS) {
+                            const float2 w = *(const float2*)((const char*)sh.row_entries[2*r + sub_row] + 48 + slot*8);   // (n, s) of this cell
+                            const float nx = w.x*fx, sx = w.y*fx;
+                            acc[r][0] = fmaf(w.x, q0.x, acc[r][0]); acc[r][1] = fmaf(w.x, q0.y, acc[r][1]); acc[r][2] = fmaf(w.x, q0.z, acc[r][2]);
+                            acc[r][0] = fmaf(nx, q0.w, acc[r][0]);  acc[r][1] = fmaf(nx, q1.x, acc[r][1]);  acc[r][2] = fmaf(nx, q1.y, acc[r][2]);
+                            acc[r][0] = fmaf(w.y, q1.z, acc[r][0]); acc[r][1] = fmaf(w.y, q1.w, acc[r][1]); acc[r][2] = fmaf(w.y, q2.x, acc[r][2]);
+                            acc[r][0] = fmaf(sx, q2.y, acc[r][0]);  acc[r][1] = fmaf(sx, q2.z, acc[r][1]);  acc[r][2] = fmaf(sx, q2.w, acc[r][2]);
+                        }
+                    }
+                }
+            }
+            // ---- the four diagonal directions: the x half of a walk step once for the strip, the y half from the block's table ----
+            {
+                const float ax = c.intensity*a.bg_scale_x*(float)bg.width;
+                const float step = (a.tap_x[11] - a.tap_x[10])*ax, first = a.tap_x[10]*ax;
+                float xp = xr + first, xm = xr - first;
+#pragma unroll 1
+                for (int w = 0; w < 10; w++) {
+                    const float axp = __builtin_amdgcn_fractf(xp), axm = __builtin_amdgcn_fractf(xm);
+                    const int cxp = (int)((xp - axp)*48.0f), cxm = (int)((xm - axm)*48.0f);
+#pragma unroll
+                    for (int r = 0; r < WALK; r++) if (r < rows) {
+                        const float4 y = sh.ysteps[2*r + sub_row][w];                 // wave-uniform address: a broadcast read
+                        const int ryp = __float_as_int(y.z), rym = __float_as_int(y.w);
+                        tap_cell(tile + (cxp + ryp), axp, y.x, acc[r][0], acc[r][1], acc[r][2]);
+                        tap_cell(tile + (cxm + ryp), axm, y.x, acc[r][0], acc[r][1], acc[r][2]);
+                        tap_cell(tile + (cxm + rym), axm, y.y, acc[r][0], acc[r][1], acc[r][2]);
+                        tap_cell(tile + (cxp + rym), axp, y.y, acc[r][0], acc[r][1], acc[r][2]);
+                    }
+                    xp = xp + step; xm = xm - step;
+                }
+            }
+        }
+
+        // ---- visualizer.frag:36-73 per sample, then the texels meet in LDS ----
+        uint32_t texel[WALK];
+        {
+            const float4 c1 = ce[1], c2 = ce[2];
+#pragma unroll
+            for (int r = 0; r < WALK; r++) {
+                texel[r] = 0;
+                if (r < rows) texel[r] = visualizer_fast_post(a, frame, c, acc[r][0], acc[r][1], acc[r][2], c1, c2, sh.row_entries[2*r + sub_row][1], sh.row_entries[2*r + sub_row][2]);
+            }
+        }
+        __syncthreads();                                              // every wave is done with the cells
+        uint32_t* texels = (uint32_t*)sh.cells;                       // [WALK][2][2*BLOCK_PX]
+        uint8_t* staged = (uint8_t*)sh.cells + STAGED;                 // [WALK][BLOCK_PX*3]
+#pragma unroll
+        for (int r = 0; r < WALK; r++) texels[(r*2 + sub_row)*2*BLOCK_PX + 2*p + sub_col] = texel[r];
+        __syncthreads();
+        // final.glsl (render_kernels.hpp resolve_channel_any): one thread per output pixel, texel order y*2 + x
+        for (int e = tid; e < WALK*BLOCK_PX; e += THREADS) {
+            const int r = e / BLOCK_PX, q = e - r*BLOCK_PX;
+            const uint2 lower = *(const uint2*)&texels[(r*2 + 0)*2*BLOCK_PX + 2*q], upper = *(const uint2*)&texels[(r*2 + 1)*2*BLOCK_PX + 2*q];
+            const uint32_t block[4] = {lower.x, lower.y, upper.x, upper.y};
+            uint8_t* s = staged + (r*BLOCK_PX + q)*3;
+            s[0] = (uint8_t)resolve_channel_any<2>(block, a.subsample, 0);
+            s[1] = (uint8_t)resolve_channel_any<2>(block, a.subsample, 8);
+            s[2] = (uint8_t)resolve_channel_any<2>(block, a.subsample, 16);
+        }
+        __syncthreads();
+        uint8_t* out = (uint8_t*)a.out + (long)frame*a.out_frame_stride;
+#pragma unroll
+        for (int r = 0; r < WALK; r++) {
+            const int py = by*WALK + r;
+            if (py < a.h) store_rgb_row(out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3, bx*BLOCK_PX, a.w, staged + r*BLOCK_PX*3, tid, THREADS, BLOCK_PX);
+        }
+    }
+};
+
+template <int TILE_PITCH, int TILE_ROWS, int BLOCK_PX, int WALK, int MIN_WAVES>
+__global__ __launch_bounds__(4*BLOCK_PX, MIN_WAVES) void k_visualizer_strip(const RenderArgs a, const VisTables t) {
+    VisualizerStrip<TILE_PITCH, TILE_ROWS, BLOCK_PX, WALK>::run(a, t);
+}
 
 template <int TILE_PITCH, int TILE_ROWS, int BLOCK_PX, int MIN_WAVES>
 __global__ __launch_bounds__(4*BLOCK_PX, MIN_WAVES) void k_visualizer_fast(const RenderArgs a, const VisTables t) {
