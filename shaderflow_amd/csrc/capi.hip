@@ -714,21 +714,57 @@ template <class SHADER> static int launch_fused_s(const RenderArgs& a, int ssaa,
     return SFX_OK;
 }
 
+// One geometry of the fast path: the tables for it, then the kernel. STRIP_S == 0: k_visualizer_fast (a quad of lanes per pixel,
+// 2x SSAA); otherwise k_visualizer_strip<PITCH, ROWS, STRIP_S, WALK> (lanes walk strips of their column, 2x or 4x SSAA).
+template <int PITCH, int ROWS, int STRIP_S, int WALK, int WAVES>
+static int launch_visualizer_tables_and_kernel(Context* ctx, const RenderArgs& a, int frames, hipStream_t s) {
+    constexpr int COLS = STRIP_S ? 512/STRIP_S : 256;                 // sample columns per block
+    constexpr int BLOCK_ROWS = STRIP_S ? STRIP_S*WALK : 2;            // sample rows per block
+    constexpr int PIXEL_ROWS = STRIP_S ? WALK : 1;
+    VisTables t;
+    t.blocks_x = (a.wr + COLS - 1)/COLS; t.blocks_y = (a.h + PIXEL_ROWS - 1)/PIXEL_ROWS;
+    t.block_columns = COLS; t.block_rows = BLOCK_ROWS; t.tile_pitch = PITCH; t.tile_rows = ROWS;
+    const size_t entries = (size_t)frames*((size_t)a.wr + a.hr)*VIS_ENTRY_QUADS*sizeof(float4);
+    const size_t blocks = (size_t)frames*((size_t)t.blocks_x + t.blocks_y)*sizeof(int4);
+    const size_t ysteps = STRIP_S ? (size_t)frames*a.hr*10*sizeof(float4) : 0;
+    if (ctx->vis_tables_bytes < entries + blocks + ysteps) {
+        hipStreamSynchronize(s);
+        hipFree(ctx->vis_tables); ctx->vis_tables = nullptr; ctx->vis_tables_bytes = 0;
+        if (hipMalloc(&ctx->vis_tables, entries + blocks + ysteps) != hipSuccess) return fail(SFX_E_HIP, "visualizer tables of %d frames: out of device memory", frames);
+        ctx->vis_tables_bytes = entries + blocks + ysteps;
+    }
+    t.columns = (float4*)ctx->vis_tables;
+    t.rows = t.columns + (size_t)frames*a.wr*VIS_ENTRY_QUADS;
+    t.block_x = (int4*)(t.rows + (size_t)frames*a.hr*VIS_ENTRY_QUADS);
+    t.block_y = t.block_x + (size_t)frames*t.blocks_x;
+    t.ysteps = STRIP_S ? (float4*)(t.block_y + (size_t)frames*t.blocks_y) : nullptr;
+    hipLaunchKernelGGL(k_visualizer_axis<0>, dim3((a.wr + 127)/128, frames), dim3(128), 0, s, a, t);
+    hipLaunchKernelGGL(k_visualizer_axis<1>, dim3((a.hr + 127)/128, frames), dim3(128), 0, s, a, t);
+    if constexpr (STRIP_S != 0) {
+        g_last_kernel = "k_visualizer_strip<" + std::to_string(PITCH) + ", " + std::to_string(ROWS) + ", " + std::to_string(STRIP_S) + ", " + std::to_string(WALK) + ", " + std::to_string(WAVES) + ">";
+        hipLaunchKernelGGL((k_visualizer_strip<PITCH, ROWS, STRIP_S, WALK, WAVES>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(512), 0, s, a, t);
+    } else {
+        g_last_kernel = "k_visualizer_fast<" + std::to_string(PITCH) + ", " + std::to_string(ROWS) + ", 128, " + std::to_string(WAVES) + ">";
+        hipLaunchKernelGGL((k_visualizer_fast<PITCH, ROWS, 128, WAVES>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(512), 0, s, a, t);
+    }
+    return 1;
+}
+
 // ---- the fast visualizer path (visualizer_fast.hpp) -----------------------------------------------------------------------
-// Identity camera, unorm8 bilinear background, 2x SSAA, the window of a 128-pixel block inside the fixed tile, and a blur whose
-// axis lines fit their slots at the largest radius the launch can see. Returns 1 when it launched, 0 when the configuration is
-// not its own (the caller then takes VisualizerShader), < 0 on errors.
+// Identity camera, unorm8 bilinear background, 2x or 4x SSAA, the window of a block inside one of the compiled tiles, and a blur
+// whose axis lines fit their slots at the largest radius the launch can see. Returns 1 when it launched, 0 when the configuration
+// is not its own (the caller then takes VisualizerShader), < 0 on errors.
 #ifndef VIS_FAST
 #define VIS_FAST 1
 #endif
-#ifndef VIS_FAST_PITCH
-#define VIS_FAST_PITCH 72
+#ifndef VIS_FAST_WALK
+#define VIS_FAST_WALK 4
 #endif
 static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hipStream_t s) {
-    constexpr int PITCH = VIS_FAST_PITCH, ROWS = 10, BLOCK_PX = 128;
     Context* ctx = g_launch_ctx;
-    if (!VIS_FAST || !ctx || ssaa != 2 || !a0.identity_camera || !visualizer_tile_applicable(a0.tex[TEX_BACKGROUND])) return 0;
-    if (getenv("SHADERFLOW_VIS_FAST") && atoi(getenv("SHADERFLOW_VIS_FAST")) == 0) return 0;      // A/B switch for measurements
+    if (!VIS_FAST || !ctx || (ssaa != 2 && ssaa != 4) || !a0.identity_camera || !visualizer_tile_applicable(a0.tex[TEX_BACKGROUND])) return 0;
+    const char* toggle = getenv("SHADERFLOW_VIS_FAST");              // A/B switch for measurements: 0 = round 1's kernels, 1 = k_visualizer_fast
+    if (toggle && atoi(toggle) == 0) return 0;
     const Tex& bg = a0.tex[TEX_BACKGROUND];
     const Tex& sp = a0.tex[TEX_SPECTROGRAM];
     RenderArgs a = a0;
@@ -745,60 +781,25 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
         hipLaunchKernelGGL(k_visualizer_bars, dim3((unsigned)((count + 255)/256)), dim3(256), 0, s, (const float*)sp.data, (long)count, ctx->vis_bars);
         a.tape_bars = ctx->vis_bars; a.spectrogram_stride = 0;
     } else if (sp.width != 1 || sp.components != 2) return 0;
-    // window and line bounds at the largest blur radius of the launch (visualizer_window_bound's conventions)
-    int tw = 0, th = 0;
-    visualizer_window_bound(a, BLOCK_PX*2, 2, tw, th);
+    // the axis lines must fit their slots at the largest blur radius of the launch (visualizer_window_bound's conventions)
     const float intensity = a.has_vis ? fabsf(a.vis.intensity) : 0.003f;
     const float ax = intensity*a.bg_scale_x*(float)bg.width;
     const float reach_line = (fabsf(a.tap_x[0]) + 9.0f*fabsf(a.tap_x[1] - a.tap_x[0]))*ax;
-    if (tw > PITCH || th > ROWS || !(2.0f*reach_line + 1.0e-3f < (float)(VIS_LINE_CELLS - 1))) return 0;
-
-#ifndef VIS_FAST_WALK
-#define VIS_FAST_WALK 4
-#endif
-    constexpr int WALK = VIS_FAST_WALK;                              // > 0: every lane walks a strip of WALK samples of its column (VisualizerStrip)
-#ifndef VIS_STRIP_ROWS
-#define VIS_STRIP_ROWS (VIS_FAST_WALK <= 4 ? 10 : (VIS_FAST_WALK <= 6 ? 11 : 12))
-#endif
-#ifndef VIS_STRIP_WAVES
-#define VIS_STRIP_WAVES (VIS_FAST_WALK <= 6 ? 8 : 6)
-#endif
-    constexpr int STRIP_ROWS = VIS_STRIP_ROWS;                         // rows of cells: floor((2*WALK - 1)*0.22 + 7.14) + 2 at the largest blur radius
-    bool strip = false;
-    if (WALK > 0) {
-        int sw = 0, sh = 0;
-        visualizer_window_bound(a, BLOCK_PX*2, 2*WALK, sw, sh);
-        strip = sw <= PITCH && sh <= STRIP_ROWS;
+    if (!(2.0f*reach_line + 1.0e-3f < (float)(VIS_LINE_CELLS - 1))) return 0;
+    auto fits = [&](int columns, int rows, int pitch, int tile_rows) {
+        int tw = 0, th = 0;
+        visualizer_window_bound(a, columns, rows, tw, th);
+        return tw <= pitch && th <= tile_rows;
+    };
+    constexpr int WALK = VIS_FAST_WALK;
+    const bool plain = toggle && atoi(toggle) == 1;                   // force the quad-per-pixel kernel
+    if (ssaa == 2) {
+        if (WALK > 0 && !plain && fits(256, 2*WALK, 72, 10)) return launch_visualizer_tables_and_kernel<72, 10, 2, (WALK > 0 ? WALK : 4), 8>(ctx, a, frames, s);
+        if (fits(256, 2, 72, 10)) return launch_visualizer_tables_and_kernel<72, 10, 0, 0, 8>(ctx, a, frames, s);
+    } else if (WALK > 0) {
+        if (fits(128, 4*WALK, 40, 13)) return launch_visualizer_tables_and_kernel<40, 13, 4, (WALK > 0 ? WALK : 4), 8>(ctx, a, frames, s);
     }
-    VisTables t;
-    t.blocks_x = (a.w + BLOCK_PX - 1)/BLOCK_PX; t.blocks_y = strip ? (a.h + WALK - 1)/WALK : a.h;
-    t.block_columns = BLOCK_PX*2; t.block_rows = strip ? 2*WALK : 2; t.tile_pitch = PITCH; t.tile_rows = strip ? STRIP_ROWS : ROWS;
-    const size_t entries = (size_t)frames*((size_t)a.wr + a.hr)*VIS_ENTRY_QUADS*sizeof(float4);
-    const size_t blocks = (size_t)frames*((size_t)t.blocks_x + t.blocks_y)*sizeof(int4);
-    if (ctx->vis_tables_bytes < entries + blocks) {
-        hipStreamSynchronize(s);
-        hipFree(ctx->vis_tables); ctx->vis_tables = nullptr; ctx->vis_tables_bytes = 0;
-        if (hipMalloc(&ctx->vis_tables, entries + blocks) != hipSuccess) return fail(SFX_E_HIP, "visualizer tables of %d frames: out of device memory", frames);
-        ctx->vis_tables_bytes = entries + blocks;
-    }
-    t.columns = (float4*)ctx->vis_tables;
-    t.rows = t.columns + (size_t)frames*a.wr*VIS_ENTRY_QUADS;
-    t.block_x = (int4*)(t.rows + (size_t)frames*a.hr*VIS_ENTRY_QUADS);
-    t.block_y = t.block_x + (size_t)frames*t.blocks_x;
-    hipLaunchKernelGGL(k_visualizer_axis<0>, dim3((a.wr + 127)/128, frames), dim3(128), 0, s, a, t);
-    hipLaunchKernelGGL(k_visualizer_axis<1>, dim3((a.hr + 127)/128, frames), dim3(128), 0, s, a, t);
-#ifndef VIS_FAST_WAVES
-#define VIS_FAST_WAVES 8
-#endif
-    if (strip) {
-        constexpr int W = WALK > 0 ? WALK : 3, SW = VIS_STRIP_WAVES;
-        g_last_kernel = "k_visualizer_strip<" + std::to_string(PITCH) + ", " + std::to_string(STRIP_ROWS) + ", " + std::to_string(BLOCK_PX) + ", " + std::to_string(W) + ", " + std::to_string(SW) + ">";
-        hipLaunchKernelGGL((k_visualizer_strip<PITCH, STRIP_ROWS, BLOCK_PX, W, SW>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(4*BLOCK_PX), 0, s, a, t);
-        return 1;
-    }
-    g_last_kernel = "k_visualizer_fast<" + std::to_string(PITCH) + ", " + std::to_string(ROWS) + ", " + std::to_string(BLOCK_PX) + ", " + std::to_string(VIS_FAST_WAVES) + ">";
-    hipLaunchKernelGGL((k_visualizer_fast<PITCH, ROWS, BLOCK_PX, VIS_FAST_WAVES>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(4*BLOCK_PX), 0, s, a, t);
-    return 1;
+    return 0;
 }
 
 // ---- bars.frag / waveform.frag with per-frame column and row tables (separable_fast.hpp) ---------------------------------------

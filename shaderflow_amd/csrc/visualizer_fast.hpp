@@ -37,6 +37,7 @@ struct VisTables {
     float4* rows;                        // [frame][hr][VIS_ENTRY_QUADS]
     int4* block_x;                       // [frame][blocks_x] = { x0, tw, fits, 0 }: window of background cells of a block column
     int4* block_y;                       // [frame][blocks_y] = { y0, th, fits, 0 }
+    float4* ysteps;                      // [frame][hr][10] = { frac(y+), frac(y-), row bytes(y+), row bytes(y-) } of the diagonal taps' walk steps; may be null
     int blocks_x, blocks_y;              // blocks per row / column of the sample grid
     int block_columns, block_rows;       // samples per block along x / y
     int tile_pitch, tile_rows;           // LDS tile the offsets are computed for (cells)
@@ -133,6 +134,20 @@ __global__ __launch_bounds__(128) void k_visualizer_axis(const RenderArgs a, con
     } else {
         e[1] = make_float4(c.rot_s*g, c.rot_c*g, g*g, ag*ag);
         e[2] = make_float4(__builtin_amdgcn_logf(as*(1.0f - as)), 1.0f - g, 1.0f + g, 0.0f);   // :72-73 compare these with the waveform
+        if (t.ysteps) {
+            // The y half of a diagonal tap — fraction and row of cells of y +- k*s (VisualizerShader::blur_tile's walk) — depends
+            // on the sample ROW and the walk step only: 10 entries per row instead of eight instructions per tap quadruple of
+            // every sample, and wave-uniform for a wave whose lanes share their rows
+            const float dstep = (a.tap_x[11] - a.tap_x[10])*ax, dfirst = a.tap_x[10]*ax;
+            const float row_bytes = (float)(t.tile_pitch*48);
+            float4* ys = t.ysteps + ((long)frame*n + k)*10;
+            for (int w = 0; w < 10; w++) {
+                const float d = fmaf((float)w, dstep, dfirst);
+                const float yp = r + d, ym = r - d;
+                const float ayp = __builtin_amdgcn_fractf(yp), aym = __builtin_amdgcn_fractf(ym);
+                ys[w] = make_float4(ayp, aym, __int_as_float((int)((yp - ayp)*row_bytes)), __int_as_float((int)((ym - aym)*row_bytes)));
+            }
+        }
     }
     e[3] = make_float4(wn[0], ws[0], wn[1], ws[1]);
     e[4] = make_float4(wn[2], ws[2], wn[3], ws[3]);
@@ -363,53 +378,63 @@ struct VisualizerFast {
 };
 
 // ---- the same, with every lane walking a strip of WALK samples of its column ---------------------------------------------------
-// What a supersample shares with the one 0.42 texel above it in the same column:
+// What a supersample shares with the ones right above it in the same column (a quarter of a texel apart at 4K 2xSSAA over a
+// 1080-row background, a sixteenth at 8K 4xSSAA):
 //   * the row-line: its per-cell weights (n, s) depend on the column only, and so do its cells as long as the two samples lie in
 //     the same row of texel cells — then the line's sums P = sum(n*A + s*B), Q = sum(n*C + s*D) are the same and the samples
 //     differ by the lerp P + fy*Q alone: 8 cell fetches and 96 multiply-adds once per distinct cell row instead of per sample;
-//   * the column-line's cells: the same column of cells, shifted by at most a cell per sample — fetched once for the strip, each
-//     used by every sample whose 8 slots cover it (the weights differ per row: they come from the row entries);
-//   * the x half of every diagonal tap (fraction and cell column of +-k*s), the column entry, the window staging.
+//   * the column-line's cells: the same column of cells, shifted by at most a cell per sample — fetched once for the strip and
+//     folded with the column's fraction once (U = A + fx*B, V = C + fx*D), then every sample whose 8 slots cover the cell adds
+//     n*U + s*V with its own row's weights;
+//   * the x half of every diagonal tap: the taps (x +- k*s, y' +- k*s) of all the strip's samples y' have the same two x
+//     coordinates, so wherever two samples' taps land in the same row of cells they read the SAME two cells, and with
+//     U = (A+ax*B)(x+) + (A+ax*B)(x-), V = (C+ax*D)(x+) + (C+ax*D)(x-) folded once per distinct cell row a sample's pair of taps
+//     is U + ay*V: six operations for two taps instead of twenty-six, and the cells are fetched once per distinct row;
+//   * the column entry and the window staging.
 // For that the LANES OF A WAVE MUST SHARE THEIR ROWS (the questions "same cell row?" and "which slots cover this cell?" are then
-// wave-uniform: scalar branches, no divergence), so the 2 x 2 supersamples of a pixel no longer sit in the four lanes of a quad:
-// wave w holds sub-row (w & 1) of 32 pixels x 2 sub-columns; the RGBA8 texels meet in LDS (over the cells, which are dead by then)
-// and one thread per output pixel resolves all three channels — cheaper than the DPP exchange it replaces.
-template <int TILE_PITCH, int TILE_ROWS, int BLOCK_PX, int WALK>
+// wave-uniform: scalar branches on values from scalar loads, no divergence), so the S x S supersamples of a pixel no longer sit in
+// the four lanes of a quad: wave w holds the WALK consecutive sample rows of row group w % S for the 64 sample columns of column
+// group w / S; the RGBA8 texels meet in LDS (over the cells, which are dead by then) and one thread per output pixel resolves all
+// three channels — cheaper than the DPP exchange it replaces.
+template <int TILE_PITCH, int TILE_ROWS, int S, int WALK>
 struct VisualizerStrip {
-    static constexpr int THREADS = 4*BLOCK_PX;
+    // S x S supersamples per pixel (2 or 4). A block is 512 threads = COLS sample columns x S row groups of WALK rows each.
+    static constexpr int THREADS = 512;
+    static constexpr int COLS = THREADS/S;                             // sample columns of a block: 256 (S = 2), 128 (S = 4)
+    static constexpr int BLOCK_PX = COLS/S;                            // output pixels of a row per block: 128, 32
+    static constexpr int RROWS = S*WALK;                               // sample rows of a block
     static constexpr int ROWBYTES = TILE_PITCH*48;
-    using Fast = VisualizerFast<TILE_PITCH, TILE_ROWS, BLOCK_PX>;
+    using Fast = VisualizerFast<TILE_PITCH, TILE_ROWS, 128>;
     struct Shared {
-        float4 cells[TILE_ROWS*TILE_PITCH*3];                          // later: uint32 texels[WALK][2][2*BLOCK_PX], then the RGB8 rows at STAGED
-        float4 row_entries[2*WALK][VIS_ENTRY_QUADS];
-        float4 ysteps[2*WALK][10];                                     // the y half of the diagonal taps: { frac(y+), frac(y-), row bytes(y+), row bytes(y-) } per (row, walk step)
+        float4 cells[TILE_ROWS*TILE_PITCH*3];                          // later: uint32 texels[RROWS][COLS], then the RGB8 rows at STAGED
+        float4 row_entries[RROWS][VIS_ENTRY_QUADS];
     };
-    static constexpr int STAGED = 16384;                               // byte offset of the staged RGB8 rows inside the (dead) cell tile
-    static_assert(sizeof(uint32_t)*WALK*2*2*BLOCK_PX <= STAGED && STAGED + WALK*BLOCK_PX*3 <= sizeof(float4)*TILE_ROWS*TILE_PITCH*3,
-                  "the texel exchange and the staged rows live in the cell tile");
+    static constexpr int STAGED = (int)sizeof(uint32_t)*RROWS*COLS;    // byte offset of the staged RGB8 rows inside the (dead) cell tile, after the texels
+    static_assert(STAGED + WALK*BLOCK_PX*3 <= (int)sizeof(float4)*TILE_ROWS*TILE_PITCH*3, "the texel exchange and the staged rows live in the cell tile");
 
-    // one bilinear tap from a staged cell: A + ax*B + ay*C + (ax*ay)*D per channel (VisualizerShader::tap_at with the cell's address)
-    __device__ __forceinline__ static void tap_cell(const char* cell, float ax, float ay, float& r, float& g, float& b) {
-        const float4* p = (const float4*)cell;
-        const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-        const float axy = ax*ay;
-        r = r + q0.x;           g = g + q0.y;           b = b + q0.z;
-        r = fmaf(ax, q0.w, r);  g = fmaf(ax, q1.x, g);  b = fmaf(ax, q1.y, b);
-        r = fmaf(ay, q1.z, r);  g = fmaf(ay, q1.w, g);  b = fmaf(ay, q2.x, b);
-        r = fmaf(axy, q2.y, r); g = fmaf(axy, q2.z, g); b = fmaf(axy, q2.w, b);
+    // a wave-uniform float that has to sit in a vector register: VALU operations with a scalar operand issue at half rate on gfx950
+    // (tools/ubench_valu.hip), one v_mov per value used three times is cheaper
+    __device__ __forceinline__ static float in_vgpr(float uniform) {
+        float v;
+        asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform));
+        return v;
     }
 
     __device__ static void run(const RenderArgs& a, const VisTables& t) {
         __shared__ __attribute__((aligned(16))) Shared sh;
         const int frame = blockIdx.z;
         const int tile_index = xcd_band_order(blockIdx.x, gridDim.x);
-        const int bx = tile_index % t.blocks_x, by = tile_index / t.blocks_x;
+        // (the division runs on the vector unit: say that its results are the same in every lane)
+        const int bx = __builtin_amdgcn_readfirstlane(tile_index % t.blocks_x), by = __builtin_amdgcn_readfirstlane(tile_index / t.blocks_x);
         const int tid = threadIdx.x;
-        const int wave = tid >> 6, lane = tid & 63;
-        const int sub_row = wave & 1, sub_col = lane & 1;
-        const int p = (wave >> 1)*32 + (lane >> 1);                   // pixel of the block's row segment
-        const int px = bx*BLOCK_PX + p;
-        const int i = (px < a.w ? px : a.w - 1)*2 + sub_col;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const int group = wave % S;                                   // row group of this wave: sample rows group*WALK + r of the block
+        const int column = (wave / S)*64 + lane;                      // sample column inside the block
+        const int i = (bx*COLS + column < a.wr) ? bx*COLS + column : a.wr - 1;
+        const int row0 = group*WALK;                                  // first row of the wave inside the block
+        const int jr0 = by*RROWS + row0;                              // and inside the frame
+        // sample rows of this wave that exist (the frame's height need not be a multiple of the block's)
+        const int rows = (a.hr - jr0 < WALK) ? (a.hr - jr0 < 0 ? 0 : a.hr - jr0) : WALK;
 
         const int4 wx = t.block_x[(long)frame*t.blocks_x + bx], wy = t.block_y[(long)frame*t.blocks_y + by];
         const bool fits = wx.z && wy.z;
@@ -418,25 +443,10 @@ struct VisualizerStrip {
         const float4* ce = t.columns + ((long)frame*a.wr + i)*VIS_ENTRY_QUADS;
 
         if (fits) visualizer_fast_stage<TILE_PITCH, THREADS>(bg, sh.cells, wx.x, wy.x, wx.y, wy.y, tid);
-        if (tid < 2*WALK*VIS_ENTRY_QUADS) {
+        if (tid < RROWS*VIS_ENTRY_QUADS) {
             const int row = tid / VIS_ENTRY_QUADS, quad = tid - row*VIS_ENTRY_QUADS;
-            const int jr = by*2*WALK + row;
+            const int jr = by*RROWS + row;
             sh.row_entries[row][quad] = t.rows[((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*VIS_ENTRY_QUADS + quad];
-        }
-        {
-            // The y half of a diagonal tap — fraction and row of cells of y +- k*s — depends on the sample ROW and the walk step
-            // only: 2*WALK x 10 values per block instead of eight instructions per tap quadruple of every sample
-            const float ax = c.intensity*a.bg_scale_x*(float)bg.width;
-            const float step = (a.tap_x[11] - a.tap_x[10])*ax, first = a.tap_x[10]*ax;
-            if (tid < 2*WALK*10) {
-                const int row = tid / 10, w = tid - row*10;
-                const int jr = by*2*WALK + row;
-                const float yr = t.rows[((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*VIS_ENTRY_QUADS].x;
-                const float d = fmaf((float)w, step, first);
-                const float yp = yr + d, ym = yr - d;
-                const float ayp = __builtin_amdgcn_fractf(yp), aym = __builtin_amdgcn_fractf(ym);
-                sh.ysteps[row][w] = make_float4(ayp, aym, __int_as_float((int)((yp - ayp)*(float)ROWBYTES)), __int_as_float((int)((ym - aym)*(float)ROWBYTES)));
-            }
         }
         __syncthreads();
 
@@ -446,13 +456,11 @@ struct VisualizerStrip {
         float acc[WALK][3];
 #pragma unroll
         for (int r = 0; r < WALK; r++) { acc[r][0] = 0.0f; acc[r][1] = 0.0f; acc[r][2] = 0.0f; }
-        // rows of this wave's samples: pixel row by*WALK + r, sub-row sub_row; `rows` counts the pixel rows that exist
-        const int rows = (a.h - by*WALK < WALK) ? a.h - by*WALK : WALK;
 
         if (!fits) {
 #pragma unroll
             for (int r = 0; r < WALK; r++)
-                if (r < rows) Fast::blur_direct(a, bg, xr + (float)wx.x, sh.row_entries[2*r + sub_row][0].x + (float)wy.x, c.intensity, acc[r][0], acc[r][1], acc[r][2]);
+                if (r < rows) Fast::blur_direct(a, bg, xr + (float)wx.x, sh.row_entries[row0 + r][0].x + (float)wy.x, c.intensity, acc[r][0], acc[r][1], acc[r][2]);
         } else {
             // ---- the row-lines: P and Q once per distinct row of cells ----
             {
@@ -462,7 +470,7 @@ struct VisualizerStrip {
                 int previous = -1;
 #pragma unroll
                 for (int r = 0; r < WALK; r++) if (r < rows) {
-                    const float4 r0 = sh.row_entries[2*r + sub_row][0];
+                    const float4 r0 = sh.row_entries[row0 + r][0];
                     const int cell_row = __builtin_amdgcn_readfirstlane(__float_as_int(r0.z));       // the wave's lanes share their rows
                     if (cell_row != previous) {
                         previous = cell_row;
@@ -481,51 +489,75 @@ struct VisualizerStrip {
                     acc[r][0] = fmaf(r0.y, Q[0], P[0]); acc[r][1] = fmaf(r0.y, Q[1], P[1]); acc[r][2] = fmaf(r0.y, Q[2], P[2]);
                 }
             }
-            // ---- the column-lines: the strip's column of cells fetched once, every sample takes the cells its slots cover ----
+            // ---- the column-lines: the strip's column of cells fetched and folded with fx once, every sample takes the cells its slots cover ----
             {
                 int start[WALK];
                 int last = 0;
 #pragma unroll
                 for (int r = 0; r < WALK; r++) {
-                    start[r] = __builtin_amdgcn_readfirstlane(__float_as_int(sh.row_entries[2*r + sub_row][0].w))/ROWBYTES;
+                    start[r] = __builtin_amdgcn_readfirstlane(__float_as_int(sh.row_entries[row0 + r][0].w))/ROWBYTES;
                     if (r < rows) last = start[r] + VIS_LINE_CELLS;     // start[] does not decrease with the row
                 }
                 const int first = start[0];
-                const char* column = tile + __float_as_int(c0.z);
+                const char* column_cells = tile + __float_as_int(c0.z);
                 for (int k = first; k < last; k++) {
-                    const float4* q = (const float4*)(column + k*ROWBYTES);
+                    const float4* q = (const float4*)(column_cells + k*ROWBYTES);
                     const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+                    const float U0 = fmaf(fx, q0.w, q0.x), U1 = fmaf(fx, q1.x, q0.y), U2 = fmaf(fx, q1.y, q0.z);
+                    const float V0 = fmaf(fx, q2.y, q1.z), V1 = fmaf(fx, q2.z, q1.w), V2 = fmaf(fx, q2.w, q2.x);
 #pragma unroll
                     for (int r = 0; r < WALK; r++) {
                         const int slot = k - start[r];
                         if (r < rows && slot >= 0 && slot < VIS_LINE_CELLS) {
-                            const float2 w = *(const float2*)((const char*)sh.row_entries[2*r + sub_row] + 48 + slot*8);   // (n, s) of this cell
-                            const float nx = w.x*fx, sx = w.y*fx;
-                            acc[r][0] = fmaf(w.x, q0.x, acc[r][0]); acc[r][1] = fmaf(w.x, q0.y, acc[r][1]); acc[r][2] = fmaf(w.x, q0.z, acc[r][2]);
-                            acc[r][0] = fmaf(nx, q0.w, acc[r][0]);  acc[r][1] = fmaf(nx, q1.x, acc[r][1]);  acc[r][2] = fmaf(nx, q1.y, acc[r][2]);
-                            acc[r][0] = fmaf(w.y, q1.z, acc[r][0]); acc[r][1] = fmaf(w.y, q1.w, acc[r][1]); acc[r][2] = fmaf(w.y, q2.x, acc[r][2]);
-                            acc[r][0] = fmaf(sx, q2.y, acc[r][0]);  acc[r][1] = fmaf(sx, q2.z, acc[r][1]);  acc[r][2] = fmaf(sx, q2.w, acc[r][2]);
+                            const float2 w = *(const float2*)((const char*)sh.row_entries[row0 + r] + 48 + slot*8);   // (n, s) of this cell
+                            acc[r][0] = fmaf(w.x, U0, acc[r][0]); acc[r][1] = fmaf(w.x, U1, acc[r][1]); acc[r][2] = fmaf(w.x, U2, acc[r][2]);
+                            acc[r][0] = fmaf(w.y, V0, acc[r][0]); acc[r][1] = fmaf(w.y, V1, acc[r][1]); acc[r][2] = fmaf(w.y, V2, acc[r][2]);
                         }
                     }
                 }
             }
-            // ---- the four diagonal directions: the x half of a walk step once for the strip, the y half from the block's table ----
+            // ---- the four diagonal directions: per walk step the x halves once for the strip; the y halves (fraction and row of
+            //      cells of y +- k*s, k_visualizer_axis<1>'s ysteps) are wave-uniform: scalar loads, scalar branches ----
             {
                 const float ax = c.intensity*a.bg_scale_x*(float)bg.width;
                 const float step = (a.tap_x[11] - a.tap_x[10])*ax, first = a.tap_x[10]*ax;
+                const float4* ysteps[WALK];
+#pragma unroll
+                for (int r = 0; r < WALK; r++) {
+                    const int jr = jr0 + r;
+                    ysteps[r] = t.ysteps + ((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*10;
+                }
                 float xp = xr + first, xm = xr - first;
 #pragma unroll 1
                 for (int w = 0; w < 10; w++) {
                     const float axp = __builtin_amdgcn_fractf(xp), axm = __builtin_amdgcn_fractf(xm);
                     const int cxp = (int)((xp - axp)*48.0f), cxm = (int)((xm - axm)*48.0f);
+                    float4 y[WALK];
 #pragma unroll
-                    for (int r = 0; r < WALK; r++) if (r < rows) {
-                        const float4 y = sh.ysteps[2*r + sub_row][w];                 // wave-uniform address: a broadcast read
-                        const int ryp = __float_as_int(y.z), rym = __float_as_int(y.w);
-                        tap_cell(tile + (cxp + ryp), axp, y.x, acc[r][0], acc[r][1], acc[r][2]);
-                        tap_cell(tile + (cxm + ryp), axm, y.x, acc[r][0], acc[r][1], acc[r][2]);
-                        tap_cell(tile + (cxm + rym), axm, y.y, acc[r][0], acc[r][1], acc[r][2]);
-                        tap_cell(tile + (cxp + rym), axp, y.y, acc[r][0], acc[r][1], acc[r][2]);
+                    for (int r = 0; r < WALK; r++) y[r] = ysteps[r][w];       // { frac(y+), frac(y-), row bytes(y+), row bytes(y-) }
+#pragma unroll
+                    for (int side = 0; side < 2; side++) {
+                        float U0 = 0.0f, U1 = 0.0f, U2 = 0.0f, V0 = 0.0f, V1 = 0.0f, V2 = 0.0f;
+                        int previous = -1;
+#pragma unroll
+                        for (int r = 0; r < WALK; r++) if (r < rows) {
+                            const int cell_row = __float_as_int(side ? y[r].w : y[r].z);
+                            if (cell_row != previous) {
+                                previous = cell_row;
+                                const float4* p = (const float4*)(tile + (cxp + cell_row));
+                                const float4* m = (const float4*)(tile + (cxm + cell_row));
+                                const float4 p0 = p[0], p1 = p[1], p2 = p[2], m0 = m[0], m1 = m[1], m2 = m[2];
+                                U0 = p0.x + m0.x;          U1 = p0.y + m0.y;          U2 = p0.z + m0.z;
+                                U0 = fmaf(axp, p0.w, U0);  U1 = fmaf(axp, p1.x, U1);  U2 = fmaf(axp, p1.y, U2);
+                                U0 = fmaf(axm, m0.w, U0);  U1 = fmaf(axm, m1.x, U1);  U2 = fmaf(axm, m1.y, U2);
+                                V0 = p1.z + m1.z;          V1 = p1.w + m1.w;          V2 = p2.x + m2.x;
+                                V0 = fmaf(axp, p2.y, V0);  V1 = fmaf(axp, p2.z, V1);  V2 = fmaf(axp, p2.w, V2);
+                                V0 = fmaf(axm, m2.y, V0);  V1 = fmaf(axm, m2.z, V1);  V2 = fmaf(axm, m2.w, V2);
+                            }
+                            const float ay = in_vgpr(side ? y[r].y : y[r].x);
+                            acc[r][0] = acc[r][0] + U0;           acc[r][1] = acc[r][1] + U1;           acc[r][2] = acc[r][2] + U2;
+                            acc[r][0] = fmaf(ay, V0, acc[r][0]);  acc[r][1] = fmaf(ay, V1, acc[r][1]);  acc[r][2] = fmaf(ay, V2, acc[r][2]);
+                        }
                     }
                     xp = xp + step; xm = xm - step;
                 }
@@ -539,24 +571,29 @@ struct VisualizerStrip {
 #pragma unroll
             for (int r = 0; r < WALK; r++) {
                 texel[r] = 0;
-                if (r < rows) texel[r] = visualizer_fast_post(a, frame, c, acc[r][0], acc[r][1], acc[r][2], c1, c2, sh.row_entries[2*r + sub_row][1], sh.row_entries[2*r + sub_row][2]);
+                if (r < rows) texel[r] = visualizer_fast_post(a, frame, c, acc[r][0], acc[r][1], acc[r][2], c1, c2, sh.row_entries[row0 + r][1], sh.row_entries[row0 + r][2]);
             }
         }
         __syncthreads();                                              // every wave is done with the cells
-        uint32_t* texels = (uint32_t*)sh.cells;                       // [WALK][2][2*BLOCK_PX]
+        uint32_t* texels = (uint32_t*)sh.cells;                       // [RROWS][COLS]
         uint8_t* staged = (uint8_t*)sh.cells + STAGED;                 // [WALK][BLOCK_PX*3]
 #pragma unroll
-        for (int r = 0; r < WALK; r++) texels[(r*2 + sub_row)*2*BLOCK_PX + 2*p + sub_col] = texel[r];
+        for (int r = 0; r < WALK; r++) texels[(row0 + r)*COLS + column] = texel[r];
         __syncthreads();
-        // final.glsl (render_kernels.hpp resolve_channel_any): one thread per output pixel, texel order y*2 + x
+        // final.glsl (render_kernels.hpp resolve_channel_any): one thread per output pixel, texel order y*S + x
         for (int e = tid; e < WALK*BLOCK_PX; e += THREADS) {
             const int r = e / BLOCK_PX, q = e - r*BLOCK_PX;
-            const uint2 lower = *(const uint2*)&texels[(r*2 + 0)*2*BLOCK_PX + 2*q], upper = *(const uint2*)&texels[(r*2 + 1)*2*BLOCK_PX + 2*q];
-            const uint32_t block[4] = {lower.x, lower.y, upper.x, upper.y};
+            uint32_t block[S*S];
+#pragma unroll
+            for (int y = 0; y < S; y++) {
+                const uint32_t* row = &texels[(S*r + y)*COLS + S*q];
+                if constexpr (S == 2) { const uint2 v = *(const uint2*)row; block[y*2] = v.x; block[y*2 + 1] = v.y; }
+                else { const uint4 v = *(const uint4*)row; block[y*4] = v.x; block[y*4 + 1] = v.y; block[y*4 + 2] = v.z; block[y*4 + 3] = v.w; }
+            }
             uint8_t* s = staged + (r*BLOCK_PX + q)*3;
-            s[0] = (uint8_t)resolve_channel_any<2>(block, a.subsample, 0);
-            s[1] = (uint8_t)resolve_channel_any<2>(block, a.subsample, 8);
-            s[2] = (uint8_t)resolve_channel_any<2>(block, a.subsample, 16);
+            s[0] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 0);
+            s[1] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 8);
+            s[2] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 16);
         }
         __syncthreads();
         uint8_t* out = (uint8_t*)a.out + (long)frame*a.out_frame_stride;
@@ -568,9 +605,9 @@ struct VisualizerStrip {
     }
 };
 
-template <int TILE_PITCH, int TILE_ROWS, int BLOCK_PX, int WALK, int MIN_WAVES>
-__global__ __launch_bounds__(4*BLOCK_PX, MIN_WAVES) void k_visualizer_strip(const RenderArgs a, const VisTables t) {
-    VisualizerStrip<TILE_PITCH, TILE_ROWS, BLOCK_PX, WALK>::run(a, t);
+template <int TILE_PITCH, int TILE_ROWS, int S, int WALK, int MIN_WAVES>
+__global__ __launch_bounds__(512, MIN_WAVES) void k_visualizer_strip(const RenderArgs a, const VisTables t) {
+    VisualizerStrip<TILE_PITCH, TILE_ROWS, S, WALK>::run(a, t);
 }
 
 template <int TILE_PITCH, int TILE_ROWS, int BLOCK_PX, int MIN_WAVES>

@@ -277,6 +277,24 @@ def _last_kernel(gpu) -> str:
     return gpu.lib.sfx_last_kernel().decode()
 
 
+@pytest.mark.parametrize("w,h,volume", [(600, 362, 0.9), (640, 361, 0.0), (520, 363, 1.3)])
+def test_strip_kernel_partial_blocks_whole_frame_against_oracle(gpu, w, h, volume):
+    """The benchmark's kernel (k_visualizer_strip: per-frame column/row tables, lanes walking strips of four samples of their column)
+    on frames whose width is not a multiple of its 128-pixel blocks and whose height is not a multiple of its four rows, loud and
+    silent (blur radius 0: every line weight in one cell): the WHOLE frame against the oracle, and twice for determinism"""
+    ssaa = 2
+    u, arrays, params = visualizer_inputs(w, h, seed=61, volume=volume, bg_size=(384, 216))
+    u.iSSAA = 2.0
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    got = gpu.render_resolve(prog, w, h, ssaa, 2)
+    assert gpu.lib.sfx_last_kernel().decode().startswith("k_visualizer_strip<"), gpu.lib.sfx_last_kernel()
+    assert np.array_equal(got, gpu.render_resolve(prog, w, h, ssaa, 2))
+    screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, threads=8)
+    assert_within_lsb(got, O.resolve(screen, w, h, 2, threads=8))
+
+
 def test_full_size_properties_1080p_two_pass(gpu):
     """BASELINE config 2 at its own size (1920x1080, ssaa 1, subsample 2): the fragment into an RGBA8 iScreen, then final.glsl's 3x3
     tent as a pass — the pair the fused kernel refuses. Kernel selection depends on the size (window bound of the LDS tile), so the
@@ -319,7 +337,7 @@ def test_full_size_properties_8k_ssaa4(gpu):
     gpu.set_uniforms(prog, u)
     gpu_bind_all(gpu, prog, arrays, params)
     a = gpu.render_resolve(prog, w, h, ssaa, 2)
-    assert _last_kernel(gpu) == "k_render_resolve<VisualizerShader<80, 10, 6>, 4>", _last_kernel(gpu)
+    assert _last_kernel(gpu).startswith("k_visualizer_strip<40, 13, 4, "), _last_kernel(gpu)
     b = gpu.render_resolve(prog, w, h, ssaa, 2)
     assert np.array_equal(a, b)
     for rows in ((0, 1), (2159, 2161), (4319, 4320)):
