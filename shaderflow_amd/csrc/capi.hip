@@ -758,7 +758,7 @@ static int launch_visualizer_tables_and_kernel(Context* ctx, const RenderArgs& a
 #define VIS_FAST 1
 #endif
 #ifndef VIS_FAST_WALK
-#define VIS_FAST_WALK 4
+#define VIS_FAST_WALK 8
 #endif
 static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hipStream_t s) {
     Context* ctx = g_launch_ctx;
@@ -791,13 +791,32 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
         visualizer_window_bound(a, columns, rows, tw, th);
         return tw <= pitch && th <= tile_rows;
     };
-    constexpr int WALK = VIS_FAST_WALK;
+    // build knobs of the strip kernel (tools/variants.sh): rows a lane walks at 2x / 4x SSAA, rows of cells of the tiles, resident waves per SIMD
+#ifndef VIS_STRIP_WALK2
+#define VIS_STRIP_WALK2 VIS_FAST_WALK
+#endif
+#ifndef VIS_STRIP_WALK4
+#define VIS_STRIP_WALK4 VIS_FAST_WALK
+#endif
+#ifndef VIS_STRIP_ROWS2
+#define VIS_STRIP_ROWS2 (VIS_STRIP_WALK2 <= 4 ? 10 : (VIS_STRIP_WALK2 <= 6 ? 11 : 12))
+#endif
+#ifndef VIS_STRIP_ROWS4
+#define VIS_STRIP_ROWS4 13
+#endif
+#ifndef VIS_STRIP_WAVES2
+#define VIS_STRIP_WAVES2 8
+#endif
+#ifndef VIS_STRIP_WAVES4
+#define VIS_STRIP_WAVES4 6
+#endif
+    constexpr int WALK2 = VIS_STRIP_WALK2, WALK4 = VIS_STRIP_WALK4;
     const bool plain = toggle && atoi(toggle) == 1;                   // force the quad-per-pixel kernel
     if (ssaa == 2) {
-        if (WALK > 0 && !plain && fits(256, 2*WALK, 72, 10)) return launch_visualizer_tables_and_kernel<72, 10, 2, (WALK > 0 ? WALK : 4), 8>(ctx, a, frames, s);
+        if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*WALK2, 72, VIS_STRIP_ROWS2)) return launch_visualizer_tables_and_kernel<72, VIS_STRIP_ROWS2, 2, WALK2, VIS_STRIP_WAVES2>(ctx, a, frames, s);
         if (fits(256, 2, 72, 10)) return launch_visualizer_tables_and_kernel<72, 10, 0, 0, 8>(ctx, a, frames, s);
-    } else if (WALK > 0) {
-        if (fits(128, 4*WALK, 40, 13)) return launch_visualizer_tables_and_kernel<40, 13, 4, (WALK > 0 ? WALK : 4), 8>(ctx, a, frames, s);
+    } else if (VIS_FAST_WALK > 0) {
+        if (fits(128, 4*WALK4, 40, VIS_STRIP_ROWS4)) return launch_visualizer_tables_and_kernel<40, VIS_STRIP_ROWS4, 4, WALK4, VIS_STRIP_WAVES4>(ctx, a, frames, s);
     }
     return 0;
 }
