@@ -157,6 +157,21 @@ __global__ __launch_bounds__(128) void k_visualizer_axis(const RenderArgs a, con
 
 // visualizer.frag:32-73 (fragments.hpp visualizer_post<true>) on the blur's sums and the separable terms of the tables: c1/c2 the
 // column's q1/q2, r1/r2 the row's. Returns the RGB8 texel iScreen would hold (alpha is never read by final.glsl).
+//
+// The polar part — atan(y, x)/PI -> bin of the spectrogram -> bar height -> two comparisons with length(uv) — decides branches
+// and a nearest-texel index, so it has to be the generic chain's bits: three IEEE divisions and an IEEE square root, 55 of this
+// function's ≈ 190 instructions. They are SPECULATED: the same formulas with v_rcp_f32/v_sqrt_f32 (1 ulp) first, which differ from
+// the exact chain by <= 1.8e-7 in `circle` (tools/check_polar_speculation.py, 4 M points with the reciprocals perturbed by an ulp
+// either way) and by an ulp in `len`; a lane is CERTAIN when circle*height stays height*1e-6 + 2e-6 away from an integer (its bin
+// cannot differ) and len stays 5e-4 away from both radii (no comparison can differ, and pow(len - rr, 0.05), steep near zero,
+// moves by < 0.1 LSB). If any lane of the wave is not, the whole wave evaluates the exact chain as well (1-3 % of the row-waves:
+// those that a bin boundary or the ring crosses within the margin) — wave-uniform, so no lane ever mixes the two.
+#ifndef VIS_SPECULATE
+#define VIS_SPECULATE 1
+#endif
+__device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }   // sf::clamp(x, 0, 1) for every non-NaN x (the sign of a zero is squared away by its users)
+__device__ __forceinline__ float smoothstep01(float t) { t = clamp01(t); return t*t*(3.0f - 2.0f*t); }   // sf::smoothstep(0, 1, t)
+
 __device__ __forceinline__ uint32_t visualizer_fast_post(const RenderArgs& a, int frame, const VisualizerConsts& c, float r, float g, float b,
                                                          const float4 c1, const float4 c2, const float4 r1, const float4 r2) {
     const float norm = 1.0f/(255.0f*10.0f*8.0f);                      // (sum/255)/(quality*directions), visualizer.frag:32
@@ -164,36 +179,68 @@ __device__ __forceinline__ uint32_t visualizer_fast_post(const RenderArgs& a, in
     const vec3 space = vec3{1.0f, 11.0f, 26.0f}/255.0f;                                                // :9
     {
         const float la = __builtin_amdgcn_sqrtf(c1.w + r1.w);                                   // length(agluv), colour only
-        const float cl = sf::clamp(la - 0.3f, 0.0f, 1.0f);
+        const float cl = clamp01(la - 0.3f);
         const float c2l = cl*cl;
         col = col*(1.0f + c.flash*(c2l*c2l*c2l));                                               // :36
     }
     const vec2 music_uv = vec2{c1.x + r1.x, c1.y + r1.y}*c.shrink;                              // :39-40
     const float radius = 0.17f;
-    const float circle = sf::abs(atan1n(music_uv));                                             // :44
     const Tex& sp = a.tex[TEX_SPECTROGRAM];
     const float* bars = a.tape_bars + (long)(a.frame0 + frame)*a.spectrogram_stride;
-    const int bin = wrap_texel((int)::floorf(circle*(float)sp.height), sp.height, sp.repeat_y);
-    vec2 freq = {bars[2*bin], bars[2*bin + 1]};                                                 // sqrt(texel/1000), :45
-    freq = freq*(0.05f + 3.0f*sf::smoothstep(0.0f, 2.0f, circle));                              // :46
-    const float len = length(music_uv);
+    const float height = (float)sp.height;
+    const float square = music_uv.x*music_uv.x + music_uv.y*music_uv.y;
+
+    float circle, len, bar, rr;
+    auto heights = [&](float circle_, float len_) {                                             // :45-46, :52, given the angle
+        const int bin = wrap_texel((int)::floorf(circle_*height), sp.height, sp.repeat_y);
+        const float amplitude = bars[2*bin + ((music_uv.y < 0.0f) ? 0 : 1)];                    // sqrt(texel/1000), the channel :52 picks
+        bar = amplitude*(0.05f + 3.0f*smoothstep01(circle_*0.5f));                              // smoothstep(0, 2, circle): x/2 is exact
+        rr = radius + 0.5f*bar;
+        circle = circle_; len = len_;
+    };
+    bool certain = false;
+    if (VIS_SPECULATE) {
+        const float ax = sf::abs(music_uv.x), ay = sf::abs(music_uv.y);
+        const float hi = __builtin_fmaxf(ax, ay), lo = __builtin_fminf(ax, ay);
+        const float t = lo*__builtin_amdgcn_rcpf(hi);                                           // hi == 0: NaN, never certain
+        const bool upper = t > 0x1.a8279ap-2f;
+        const float u = upper ? (t - 1.0f)*__builtin_amdgcn_rcpf(t + 1.0f) : t;
+        const float z = u*u;
+        float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+        p = fmaf(p, z, 1.99777106478e-1f);
+        p = fmaf(p, z, -3.33329491539e-1f);
+        float angle = (upper ? QUARTER_PI : 0.0f) + fmaf(p*z, u, u);
+        if (ay > ax) angle = HALF_PI - angle;
+        if (music_uv.x < 0.0f) angle = 0x1.921fb6p+1f - angle;                                  // |atan(y, x)|: the sign of y does not matter
+        const float approximate = angle*0x1.45f306p-2f;                                         // /PI
+        heights(approximate, __builtin_amdgcn_sqrtf(square));
+        const float scaled = approximate*height;
+        const float fraction = scaled - ::floorf(scaled);
+        const float margin = fmaf(height, 1.0e-6f, 2.0e-6f);
+        certain = (fraction > margin) && (fraction < 1.0f - margin) && (sf::abs(len - radius) > 5.0e-4f) && (sf::abs(len - rr) > 5.0e-4f);
+    }
+    if (!VIS_SPECULATE || __builtin_amdgcn_ballot_w64(!certain) != 0)
+        heights(sf::abs(atan1n(music_uv)), sf::sqrt(square));                                   // :44 and length(music_uv), the generic chain's bits
+
     if (len < radius) {                                                                         // :49-50
         col = col*0.5f;
     } else {
-        const float bar = (music_uv.y < 0.0f) ? freq.x : freq.y;                                // :52
-        const float rr = radius + 0.5f*bar;
-        if (len < rr) col = mix(col, vec3{1.0f, 1.0f, 1.0f}, sf::smoothstep(0.0f, 1.0f, 0.5f + bar));   // :56
+        if (len < rr) col = mix(col, vec3{1.0f, 1.0f, 1.0f}, smoothstep01(0.5f + bar));         // :56
         else col = col*ColourMath<true>::pow((len - rr)*0.5f, 0.05f);                           // :58
     }
     {
         const float lp = __builtin_amdgcn_sqrtf(c1.z + r1.z)*0.05f;                             // length(uv)/20, colour only
-        col = mix(col, space, sf::smoothstep(0.0f, 1.0f, lp));                                  // :62
+        col = mix(col, space, smoothstep01(lp));                                                // :62
     }
     // pow(vig.x*vig.y*20, e) = exp2(e*(log2(ax(1-ax)) + log2(ay(1-ay)) + log2(20))), :65-66
     col = col*__builtin_amdgcn_exp2f(c.vig_exp*((c2.x + r2.x) + 4.321928095f));
-    if (r2.y < c2.y) col = col*0.8f;                                                            // :72
-    if (r2.z < c2.z) col = col*0.8f;                                                            // :73
-    if (__float_as_int(c2.w) != 0) col = space;                                                 // :11-14
+    // the waveform strips along the top and bottom edges and the bars outside the wanted aspect: most waves have no such lane
+    const bool strip_top = r2.y < c2.y, strip_bottom = r2.z < c2.z, outside = __float_as_int(c2.w) != 0;
+    if (__builtin_amdgcn_ballot_w64(strip_top || strip_bottom || outside) != 0) {
+        if (strip_top) col = col*0.8f;                                                          // :72
+        if (strip_bottom) col = col*0.8f;                                                       // :73
+        if (outside) col = space;                                                               // :11-14
+    }
     return pack_rgb8(col);
 }
 
