@@ -804,6 +804,9 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
 #ifndef VIS_STRIP_ROWS4
 #define VIS_STRIP_ROWS4 13
 #endif
+#ifndef VIS_STRIP_PITCH2
+#define VIS_STRIP_PITCH2 72
+#endif
 #ifndef VIS_STRIP_WAVES2
 #define VIS_STRIP_WAVES2 8
 #endif
@@ -813,10 +816,15 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
     constexpr int WALK2 = VIS_STRIP_WALK2, WALK4 = VIS_STRIP_WALK4;
     const bool plain = toggle && atoi(toggle) == 1;                   // force the quad-per-pixel kernel
     if (ssaa == 2) {
-        if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*WALK2, 72, VIS_STRIP_ROWS2)) return launch_visualizer_tables_and_kernel<72, VIS_STRIP_ROWS2, 2, WALK2, VIS_STRIP_WAVES2>(ctx, a, frames, s);
+        if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*WALK2, VIS_STRIP_PITCH2, VIS_STRIP_ROWS2)) return launch_visualizer_tables_and_kernel<VIS_STRIP_PITCH2, VIS_STRIP_ROWS2, 2, WALK2, VIS_STRIP_WAVES2>(ctx, a, frames, s);
+        // denser outputs (1080p or 1440p at 2x SSAA over a 1080-row background: up to 0.43 texel per sample): strips of four rows
+        // over a 120 x 12 tile, two blocks per CU
+        if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*4, 120, 12)) return launch_visualizer_tables_and_kernel<120, 12, 2, 4, 4>(ctx, a, frames, s);
         if (fits(256, 2, 72, 10)) return launch_visualizer_tables_and_kernel<72, 10, 0, 0, 8>(ctx, a, frames, s);
     } else if (VIS_FAST_WALK > 0) {
         if (fits(128, 4*WALK4, 40, VIS_STRIP_ROWS4)) return launch_visualizer_tables_and_kernel<40, VIS_STRIP_ROWS4, 4, WALK4, VIS_STRIP_WAVES4>(ctx, a, frames, s);
+        // 1080p at 4x SSAA: the same tile with strips of four rows
+        if (WALK4 != 4 && fits(128, 4*4, 40, 13)) return launch_visualizer_tables_and_kernel<40, 13, 4, 4, 8>(ctx, a, frames, s);
     }
     return 0;
 }

@@ -346,6 +346,25 @@ def test_full_size_properties_8k_ssaa4(gpu):
         assert_within_lsb(a[rows[0]:rows[1]], want[rows[0]:rows[1]])
 
 
+@pytest.mark.parametrize("w,h,ssaa,kernel", [(1920, 1080, 2, "k_visualizer_strip<120, 12, 2, 4, "), (2560, 1440, 2, "k_visualizer_strip<120, 12, 2, 4, "),
+                                             (1920, 1080, 4, "k_visualizer_strip<40, 13, 4, 4, ")])
+def test_full_size_properties_dense_outputs(gpu, w, h, ssaa, kernel):
+    """Outputs denser than the benchmark's over the same 1080-row background (up to 0.43 texel per sample): the strip kernel's
+    instances with shorter strips over larger tiles; bands of rows against the oracle, determinism."""
+    u, arrays, params = visualizer_inputs(w, h, seed=59, volume=0.9, bg_size=(1920, 1080))
+    u.iSSAA = float(ssaa)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    a = gpu.render_resolve(prog, w, h, ssaa, 2)
+    assert _last_kernel(gpu).startswith(kernel), _last_kernel(gpu)
+    assert np.array_equal(a, gpu.render_resolve(prog, w, h, ssaa, 2))
+    for rows in ((0, 2), (h//2 - 1, h//2 + 1), (h - 1, h)):
+        screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, rows=(rows[0]*ssaa, rows[1]*ssaa), threads=8)
+        want = O.resolve(screen, w, h, 2, rows=rows, threads=8)
+        assert_within_lsb(a[rows[0]:rows[1]], want[rows[0]:rows[1]])
+
+
 def test_destroyed_texture_is_unbound_not_dangling(gpu):
     """A program must not keep a pointer to a texture that was destroyed: the render reports the missing sampler instead"""
     from shaderflow_amd import _native as N
