@@ -7,6 +7,7 @@
 #include "audio_kernels.hpp"
 #include "visualizer_kernels.hpp"
 #include "visualizer_fast.hpp"
+#include "resolve_fast.hpp"
 #include "separable_fast.hpp"
 #include "uniform_table.hpp"
 
@@ -69,6 +70,7 @@ struct Context : Object {
     // per-frame column/row tables of the fast visualizer kernel (visualizer_fast.hpp), grown on demand
     void* vis_tables = nullptr; size_t vis_tables_bytes = 0;
     float* vis_bars = nullptr; size_t vis_bars_count = 0;          // sqrt(texel/1000) of a bound spectrogram (single launches)
+    void* resolve_tables = nullptr; size_t resolve_tables_bytes = 0;   // column/row tap tables of k_resolve_fast
 };
 static thread_local Context* g_launch_ctx = nullptr;               // the context whose program is being launched (scratch owner)
 
@@ -166,7 +168,7 @@ extern "C" int sfx_ctx_destroy(sfx_handle h) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (auto& e : c->events) hipEventDestroy(e);
-    hipFree(c->vis_tables); hipFree(c->vis_bars);
+    hipFree(c->vis_tables); hipFree(c->vis_bars); hipFree(c->resolve_tables);
     if (c->own_stream) hipStreamDestroy(c->stream);
     c->magic = 0;
     delete c;
@@ -625,12 +627,18 @@ static void visualizer_window_bound(const RenderArgs& a, int sx, int sy, int& tw
 }
 static const size_t VIS_LDS_LIMIT = 150*1024;                         // leave room for the static shared state of the kernels
 
+static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hipStream_t s, bool to_screen);
+
 static int launch_render(int fragment, const RenderArgs& a, int frames, hipStream_t s) {
     switch (fragment) {
         case FRAG_DEFAULT: launch_render_t<PlainShader<FRAG_DEFAULT>>(a, frames, s); break;
         case FRAG_MISSING: launch_render_t<PlainShader<FRAG_MISSING>>(a, frames, s); break;
         case FRAG_VISUALIZER: {
             int tw = 0, th = 0;
+            {
+                const int fast = launch_visualizer_fast(a, 1, frames, s, true);      // identity camera, RGBA8 target, window inside the strip kernel's tile
+                if (fast != 0) return fast < 0 ? fast : SFX_OK;
+            }
             if (visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) {
                 // first choice: 64 x 8 samples per block over a 64 x 15 tile — three 512-thread blocks per CU and two staged cells per
                 // sample, against two 256-thread blocks and five cells for the 128 x 2 shape (1080p without SSAA: 8.4 -> see DESIGN §7)
@@ -715,14 +723,14 @@ template <class SHADER> static int launch_fused_s(const RenderArgs& a, int ssaa,
 }
 
 // One geometry of the fast path: the tables for it, then the kernel. STRIP_S == 0: k_visualizer_fast (a quad of lanes per pixel,
-// 2x SSAA); otherwise k_visualizer_strip<PITCH, ROWS, STRIP_S, WALK> (lanes walk strips of their column, 2x or 4x SSAA).
-template <int PITCH, int ROWS, int STRIP_S, int WALK, int WAVES>
+// 2x SSAA); otherwise k_visualizer_strip<PITCH, ROWS, STRIP_S, WALK, WAVES, CG> (lanes walk strips of their column; 2x or 4x SSAA
+// fused with the resolve, or STRIP_S == 1: the samples to an RGBA8 iScreen).
+template <int PITCH, int ROWS, int STRIP_S, int WALK, int WAVES, int CG = (STRIP_S ? 8/STRIP_S : 4)>
 static int launch_visualizer_tables_and_kernel(Context* ctx, const RenderArgs& a, int frames, hipStream_t s) {
-    constexpr int COLS = STRIP_S ? 512/STRIP_S : 256;                 // sample columns per block
-    constexpr int BLOCK_ROWS = STRIP_S ? STRIP_S*WALK : 2;            // sample rows per block
-    constexpr int PIXEL_ROWS = STRIP_S ? WALK : 1;
+    constexpr int COLS = STRIP_S ? 64*CG : 256;                       // sample columns per block
+    constexpr int BLOCK_ROWS = STRIP_S ? (8/CG)*WALK : 2;             // sample rows per block
     VisTables t;
-    t.blocks_x = (a.wr + COLS - 1)/COLS; t.blocks_y = (a.h + PIXEL_ROWS - 1)/PIXEL_ROWS;
+    t.blocks_x = (a.wr + COLS - 1)/COLS; t.blocks_y = (a.hr + BLOCK_ROWS - 1)/BLOCK_ROWS;
     t.block_columns = COLS; t.block_rows = BLOCK_ROWS; t.tile_pitch = PITCH; t.tile_rows = ROWS;
     const size_t entries = (size_t)frames*((size_t)a.wr + a.hr)*VIS_ENTRY_QUADS*sizeof(float4);
     const size_t blocks = (size_t)frames*((size_t)t.blocks_x + t.blocks_y)*sizeof(int4);
@@ -742,7 +750,7 @@ static int launch_visualizer_tables_and_kernel(Context* ctx, const RenderArgs& a
     hipLaunchKernelGGL(k_visualizer_axis<1>, dim3((a.hr + 127)/128, frames), dim3(128), 0, s, a, t);
     if constexpr (STRIP_S != 0) {
         g_last_kernel = "k_visualizer_strip<" + std::to_string(PITCH) + ", " + std::to_string(ROWS) + ", " + std::to_string(STRIP_S) + ", " + std::to_string(WALK) + ", " + std::to_string(WAVES) + ">";
-        hipLaunchKernelGGL((k_visualizer_strip<PITCH, ROWS, STRIP_S, WALK, WAVES>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(512), 0, s, a, t);
+        hipLaunchKernelGGL((k_visualizer_strip<PITCH, ROWS, STRIP_S, WALK, WAVES, CG>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(512), 0, s, a, t);
     } else {
         g_last_kernel = "k_visualizer_fast<" + std::to_string(PITCH) + ", " + std::to_string(ROWS) + ", 128, " + std::to_string(WAVES) + ">";
         hipLaunchKernelGGL((k_visualizer_fast<PITCH, ROWS, 128, WAVES>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(512), 0, s, a, t);
@@ -760,9 +768,11 @@ static int launch_visualizer_tables_and_kernel(Context* ctx, const RenderArgs& a
 #ifndef VIS_FAST_WALK
 #define VIS_FAST_WALK 8
 #endif
-static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hipStream_t s) {
+static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hipStream_t s, bool to_screen) {
     Context* ctx = g_launch_ctx;
-    if (!VIS_FAST || !ctx || (ssaa != 2 && ssaa != 4) || !a0.identity_camera || !visualizer_tile_applicable(a0.tex[TEX_BACKGROUND])) return 0;
+    // fused: 2x or 4x SSAA into the RGB8 frame; to_screen: the samples themselves into an RGBA8 iScreen (the two-pass configuration)
+    if (to_screen ? (ssaa != 1 || a0.out_dtype != DT_U8 || a0.out_components != 4) : (ssaa != 2 && ssaa != 4)) return 0;
+    if (!VIS_FAST || !ctx || !a0.identity_camera || !visualizer_tile_applicable(a0.tex[TEX_BACKGROUND])) return 0;
     const char* toggle = getenv("SHADERFLOW_VIS_FAST");              // A/B switch for measurements: 0 = round 1's kernels, 1 = k_visualizer_fast
     if (toggle && atoi(toggle) == 0) return 0;
     const Tex& bg = a0.tex[TEX_BACKGROUND];
@@ -815,7 +825,16 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
 #endif
     constexpr int WALK2 = VIS_STRIP_WALK2, WALK4 = VIS_STRIP_WALK4;
     const bool plain = toggle && atoi(toggle) == 1;                   // force the quad-per-pixel kernel
-    if (ssaa == 2) {
+    if (ssaa == 1) {
+        // no SSAA: 0.87 texel per sample at 1080p over a 1080-row background — nothing to share along a strip, but the tables, the
+        // folded tap pairs and the speculated post-processing still apply. 64 columns x 8 rows per block over a 66 x 15 tile
+        // (three blocks per CU), or strips of two rows over 66 x 22 (two)
+#ifndef VIS_STRIP_WALK1
+#define VIS_STRIP_WALK1 2
+#endif
+        if (VIS_STRIP_WALK1 == 2 && fits(64, 16, 66, 22)) return launch_visualizer_tables_and_kernel<66, 22, 1, 2, 4, 1>(ctx, a, frames, s);
+        if (fits(64, 8, 66, 15)) return launch_visualizer_tables_and_kernel<66, 15, 1, 1, 6, 1>(ctx, a, frames, s);
+    } else if (ssaa == 2) {
         if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*WALK2, VIS_STRIP_PITCH2, VIS_STRIP_ROWS2)) return launch_visualizer_tables_and_kernel<VIS_STRIP_PITCH2, VIS_STRIP_ROWS2, 2, WALK2, VIS_STRIP_WAVES2>(ctx, a, frames, s);
         // denser outputs (1080p or 1440p at 2x SSAA over a 1080-row background: up to 0.43 texel per sample): strips of four rows
         // over a 120 x 12 tile, two blocks per CU
@@ -893,7 +912,7 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
         case FRAG_MISSING: return launch_fused_s<PlainShader<FRAG_MISSING>>(a, ssaa, frames, s);
         case FRAG_VISUALIZER:
             if (!force_generic) {
-                const int fast = launch_visualizer_fast(a, ssaa, frames, s);
+                const int fast = launch_visualizer_fast(a, ssaa, frames, s, false);
                 if (fast != 0) return fast < 0 ? fast : SFX_OK;
             }
             if (!force_generic && visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) {
@@ -978,6 +997,7 @@ static int launch_jit(hipFunction_t fn, const RenderArgs& a, dim3 grid, dim3 blo
     return e == hipSuccess ? SFX_OK : fail(SFX_E_HIP, "hipModuleLaunchKernel: %s", hipGetErrorString(e));
 }
 static int launch_render_p(const Program* p, const RenderArgs& a, int frames, hipStream_t s) {
+    g_launch_ctx = p->ctx;
     if (p->fragment != FRAG_JIT) return launch_render(p->fragment, a, frames, s);
     using P = PlainShader<FRAG_DEFAULT>;
     return launch_jit(p->fn_render, a, dim3((a.wr + P::BLOCK_W - 1)/P::BLOCK_W, (a.hr + P::BLOCK_H - 1)/P::BLOCK_H, frames), dim3(P::BLOCK_W, P::BLOCK_H, 1), s);
@@ -1017,6 +1037,42 @@ extern "C" int sfx_render(sfx_handle h, sfx_handle target, int layer) {
     return launch_status();
 }
 
+// final.glsl as a pass: k_resolve_fast (resolve_fast.hpp) for a linear, clamped iScreen and the kernels it is compiled for, else
+// the generic k_resolve. `frames` launches share the tables (they depend on the sizes only).
+#ifndef RESOLVE_FAST
+#define RESOLVE_FAST 1
+#endif
+static int launch_resolve(Context* ctx, const ResolveArgs& a, int frames, hipStream_t s) {
+    const char* toggle = getenv("SHADERFLOW_RESOLVE_FAST");         // A/B switch for measurements
+    const bool fast = RESOLVE_FAST && ctx && !(toggle && atoi(toggle) == 0) && a.screen.filter == FILTER_LINEAR && !a.screen.repeat_x && !a.screen.repeat_y &&
+                      a.subsample >= 1 && a.subsample <= 3 && a.screen.width > 0 && a.screen.height > 0;
+    if (fast) {
+        const size_t bytes = ((size_t)a.w + a.h)*a.subsample*sizeof(int4);
+        if (ctx->resolve_tables_bytes < bytes) {
+            hipStreamSynchronize(s);
+            hipFree(ctx->resolve_tables); ctx->resolve_tables = nullptr; ctx->resolve_tables_bytes = 0;
+            if (hipMalloc(&ctx->resolve_tables, bytes) != hipSuccess) return fail(SFX_E_HIP, "resolve tables: out of device memory");
+            ctx->resolve_tables_bytes = bytes;
+        }
+        int4* columns = (int4*)ctx->resolve_tables; int4* rows = columns + (size_t)a.w*a.subsample;
+        hipLaunchKernelGGL(k_resolve_axis<0>, dim3((a.w + 127)/128), dim3(128), 0, s, a, columns);
+        hipLaunchKernelGGL(k_resolve_axis<1>, dim3((a.h + 127)/128), dim3(128), 0, s, a, rows);
+        const ResolveTables t{columns, rows};
+        const dim3 grid((a.w + 63)/64, (a.h + 3)/4, frames), block(64, 4);
+        // iScreen texels under a block of 64 x 4 pixels, two more per axis for the bilinear neighbours: the LDS window (a block
+        // whose own window is larger — it cannot be — or a launch over the cap reads iScreen directly)
+        const long tw = ((long)64*a.screen.width + a.w - 1)/a.w + 3, th = ((long)4*a.screen.height + a.h - 1)/a.h + 3;
+        const int window = tw*th <= RESOLVE_WINDOW_TEXELS ? (int)(tw*th) : 0;
+        const size_t lds = (size_t)window*sizeof(float4);
+        if (a.subsample == 1) hipLaunchKernelGGL(k_resolve_fast<1>, grid, block, lds, s, a, t, window);
+        else if (a.subsample == 2) hipLaunchKernelGGL(k_resolve_fast<2>, grid, block, lds, s, a, t, window);
+        else hipLaunchKernelGGL(k_resolve_fast<3>, grid, block, lds, s, a, t, window);
+        return SFX_OK;
+    }
+    hipLaunchKernelGGL(k_resolve, dim3((a.w + 63)/64, (a.h + 3)/4, frames), dim3(64, 4), 0, s, a);
+    return SFX_OK;
+}
+
 extern "C" int sfx_resolve(sfx_handle h, sfx_handle src, sfx_handle dst, int subsample) {
     CTX_OR_FAIL(c, h);
     Texture* s = get<Texture>(src, MAGIC_TEX);
@@ -1031,7 +1087,7 @@ extern "C" int sfx_resolve(sfx_handle h, sfx_handle src, sfx_handle dst, int sub
     a.w = d->width; a.h = d->height; a.subsample = subsample < 1 ? 1 : subsample;
     a.out = (uint8_t*)d->data;
     a.screen_frame_stride = 0; a.out_frame_stride = 0; a.top_down = c->top_down;
-    hipLaunchKernelGGL(k_resolve, dim3((a.w + 63)/64, (a.h + 3)/4), dim3(64, 4), 0, c->stream, a);
+    { const int rc = launch_resolve(c, a, 1, c->stream); if (rc) return rc; }
     return launch_status();
 }
 
@@ -1781,6 +1837,6 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
     r.screen = Tex{t->d_screen, a.wr, a.hr, 4, DT_U8, FILTER_LINEAR, 0, 0};      // iScreen: linear, repeat(False) (scene.py:192-194)
     r.w = width; r.h = height; r.subsample = subsample; r.out = (uint8_t*)device_out;
     r.screen_frame_stride = (long)screen_frame; r.out_frame_stride = (long)width*height*3; r.top_down = p->ctx->top_down;
-    hipLaunchKernelGGL(k_resolve, dim3((width + 63)/64, (height + 3)/4, nframes), dim3(64, 4), 0, p->ctx->stream, r);
+    if ((rc = launch_resolve(p->ctx, r, nframes, p->ctx->stream))) return rc;
     return launch_status();
 }

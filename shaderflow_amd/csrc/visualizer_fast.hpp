@@ -172,6 +172,7 @@ __global__ __launch_bounds__(128) void k_visualizer_axis(const RenderArgs a, con
 __device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }   // sf::clamp(x, 0, 1) for every non-NaN x (the sign of a zero is squared away by its users)
 __device__ __forceinline__ float smoothstep01(float t) { t = clamp01(t); return t*t*(3.0f - 2.0f*t); }   // sf::smoothstep(0, 1, t)
 
+template <bool WITH_ALPHA = false>                               // the fused kernels never look at alpha (final.glsl takes .rgb); iScreen holds it
 __device__ __forceinline__ uint32_t visualizer_fast_post(const RenderArgs& a, int frame, const VisualizerConsts& c, float r, float g, float b,
                                                          const float4 c1, const float4 c2, const float4 r1, const float4 r2) {
     const float norm = 1.0f/(255.0f*10.0f*8.0f);                      // (sum/255)/(quality*directions), visualizer.frag:32
@@ -236,12 +237,15 @@ __device__ __forceinline__ uint32_t visualizer_fast_post(const RenderArgs& a, in
     col = col*__builtin_amdgcn_exp2f(c.vig_exp*((c2.x + r2.x) + 4.321928095f));
     // the waveform strips along the top and bottom edges and the bars outside the wanted aspect: most waves have no such lane
     const bool strip_top = r2.y < c2.y, strip_bottom = r2.z < c2.z, outside = __float_as_int(c2.w) != 0;
+    uint32_t alpha = 0xff000000u;                                                               // fragColor.a = 1 (:68)
     if (__builtin_amdgcn_ballot_w64(strip_top || strip_bottom || outside) != 0) {
-        if (strip_top) col = col*0.8f;                                                          // :72
-        if (strip_bottom) col = col*0.8f;                                                       // :73
-        if (outside) col = space;                                                               // :11-14
+        float opacity = 1.0f;
+        if (strip_top) { col = col*0.8f; opacity = opacity*0.8f; }                              // :72 scales the whole vec4
+        if (strip_bottom) { col = col*0.8f; opacity = opacity*0.8f; }                           // :73
+        if (outside) { col = space; opacity = 0.0f; }                                           // :11-14
+        if (WITH_ALPHA) alpha = unorm8(opacity) << 24;
     }
-    return pack_rgb8(col);
+    return WITH_ALPHA ? (pack_rgb8(col) | alpha) : pack_rgb8(col);
 }
 
 // Stages the window [x0, x0+tw) x [y0, y0+th) of the background as difference-basis cells (VisualizerShader::setup step 2)
@@ -443,21 +447,25 @@ struct VisualizerFast {
 // the four lanes of a quad: wave w holds the WALK consecutive sample rows of row group w % S for the 64 sample columns of column
 // group w / S; the RGBA8 texels meet in LDS (over the cells, which are dead by then) and one thread per output pixel resolves all
 // three channels — cheaper than the DPP exchange it replaces.
-template <int TILE_PITCH, int TILE_ROWS, int S, int WALK>
+template <int TILE_PITCH, int TILE_ROWS, int S, int WALK, int COLUMN_GROUPS = 8/S>
 struct VisualizerStrip {
-    // S x S supersamples per pixel (2 or 4). A block is 512 threads = COLS sample columns x S row groups of WALK rows each.
+    // S x S supersamples per pixel (2 or 4), or S == 1: no resolve, the RGBA8 samples go to iScreen (the two-pass configuration).
+    // A block is 512 threads = 8 waves = COLUMN_GROUPS groups of 64 sample columns x ROW_GROUPS groups of WALK consecutive rows.
     static constexpr int THREADS = 512;
-    static constexpr int COLS = THREADS/S;                             // sample columns of a block: 256 (S = 2), 128 (S = 4)
+    static constexpr int ROW_GROUPS = 8/COLUMN_GROUPS;
+    static constexpr int COLS = 64*COLUMN_GROUPS;                      // sample columns of a block: 256 (S = 2), 128 (S = 4), 64 (S = 1)
     static constexpr int BLOCK_PX = COLS/S;                            // output pixels of a row per block: 128, 32
-    static constexpr int RROWS = S*WALK;                               // sample rows of a block
+    static constexpr int RROWS = ROW_GROUPS*WALK;                      // sample rows of a block
+    static constexpr int PIXEL_ROWS = RROWS/S;                         // output rows of a block
     static constexpr int ROWBYTES = TILE_PITCH*48;
+    static_assert(COLUMN_GROUPS*ROW_GROUPS == 8 && RROWS % S == 0 && COLS % S == 0, "block geometry");
     using Fast = VisualizerFast<TILE_PITCH, TILE_ROWS, 128>;
     struct Shared {
         float4 cells[TILE_ROWS*TILE_PITCH*3];                          // later: uint32 texels[RROWS][COLS], then the RGB8 rows at STAGED
         float4 row_entries[RROWS][VIS_ENTRY_QUADS];
     };
     static constexpr int STAGED = (int)sizeof(uint32_t)*RROWS*COLS;    // byte offset of the staged RGB8 rows inside the (dead) cell tile, after the texels
-    static_assert(STAGED + WALK*BLOCK_PX*3 <= (int)sizeof(float4)*TILE_ROWS*TILE_PITCH*3, "the texel exchange and the staged rows live in the cell tile");
+    static_assert(S == 1 || STAGED + PIXEL_ROWS*BLOCK_PX*3 <= (int)sizeof(float4)*TILE_ROWS*TILE_PITCH*3, "the texel exchange and the staged rows live in the cell tile");
 
     // a wave-uniform float that has to sit in a vector register: VALU operations with a scalar operand issue at half rate on gfx950
     // (tools/ubench_valu.hip), one v_mov per value used three times is cheaper
@@ -475,8 +483,8 @@ struct VisualizerStrip {
         const int bx = __builtin_amdgcn_readfirstlane(tile_index % t.blocks_x), by = __builtin_amdgcn_readfirstlane(tile_index / t.blocks_x);
         const int tid = threadIdx.x;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-        const int group = wave % S;                                   // row group of this wave: sample rows group*WALK + r of the block
-        const int column = (wave / S)*64 + lane;                      // sample column inside the block
+        const int group = wave % ROW_GROUPS;                          // row group of this wave: sample rows group*WALK + r of the block
+        const int column = (wave / ROW_GROUPS)*64 + lane;             // sample column inside the block
         const int i = (bx*COLS + column < a.wr) ? bx*COLS + column : a.wr - 1;
         const int row0 = group*WALK;                                  // first row of the wave inside the block
         const int jr0 = by*RROWS + row0;                              // and inside the frame
@@ -618,17 +626,26 @@ struct VisualizerStrip {
 #pragma unroll
             for (int r = 0; r < WALK; r++) {
                 texel[r] = 0;
-                if (r < rows) texel[r] = visualizer_fast_post(a, frame, c, acc[r][0], acc[r][1], acc[r][2], c1, c2, sh.row_entries[row0 + r][1], sh.row_entries[row0 + r][2]);
+                if (r < rows) texel[r] = visualizer_fast_post<S == 1>(a, frame, c, acc[r][0], acc[r][1], acc[r][2], c1, c2, sh.row_entries[row0 + r][1], sh.row_entries[row0 + r][2]);
             }
+        }
+        if constexpr (S == 1) {
+            // the two-pass configuration: iScreen takes the samples as they are (alpha 1, visualizer.frag's fragColor), 64 lanes = 256 B of a row
+            uint32_t* screen = (uint32_t*)((char*)a.out + (long)frame*a.out_frame_stride);
+            const bool inside = bx*COLS + column < a.wr;
+#pragma unroll
+            for (int r = 0; r < WALK; r++)
+                if (r < rows && inside) screen[(long)(jr0 + r)*a.wr + i] = texel[r];
+            return;
         }
         __syncthreads();                                              // every wave is done with the cells
         uint32_t* texels = (uint32_t*)sh.cells;                       // [RROWS][COLS]
-        uint8_t* staged = (uint8_t*)sh.cells + STAGED;                 // [WALK][BLOCK_PX*3]
+        uint8_t* staged = (uint8_t*)sh.cells + STAGED;                 // [PIXEL_ROWS][BLOCK_PX*3]
 #pragma unroll
         for (int r = 0; r < WALK; r++) texels[(row0 + r)*COLS + column] = texel[r];
         __syncthreads();
         // final.glsl (render_kernels.hpp resolve_channel_any): one thread per output pixel, texel order y*S + x
-        for (int e = tid; e < WALK*BLOCK_PX; e += THREADS) {
+        for (int e = tid; e < PIXEL_ROWS*BLOCK_PX; e += THREADS) {
             const int r = e / BLOCK_PX, q = e - r*BLOCK_PX;
             uint32_t block[S*S];
 #pragma unroll
@@ -645,16 +662,16 @@ struct VisualizerStrip {
         __syncthreads();
         uint8_t* out = (uint8_t*)a.out + (long)frame*a.out_frame_stride;
 #pragma unroll
-        for (int r = 0; r < WALK; r++) {
-            const int py = by*WALK + r;
+        for (int r = 0; r < PIXEL_ROWS; r++) {
+            const int py = by*PIXEL_ROWS + r;
             if (py < a.h) store_rgb_row(out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3, bx*BLOCK_PX, a.w, staged + r*BLOCK_PX*3, tid, THREADS, BLOCK_PX);
         }
     }
 };
 
-template <int TILE_PITCH, int TILE_ROWS, int S, int WALK, int MIN_WAVES>
+template <int TILE_PITCH, int TILE_ROWS, int S, int WALK, int MIN_WAVES, int COLUMN_GROUPS = 8/S>
 __global__ __launch_bounds__(512, MIN_WAVES) void k_visualizer_strip(const RenderArgs a, const VisTables t) {
-    VisualizerStrip<TILE_PITCH, TILE_ROWS, S, WALK>::run(a, t);
+    VisualizerStrip<TILE_PITCH, TILE_ROWS, S, WALK, COLUMN_GROUPS>::run(a, t);
 }
 
 template <int TILE_PITCH, int TILE_ROWS, int BLOCK_PX, int MIN_WAVES>

@@ -308,7 +308,7 @@ def test_full_size_properties_1080p_two_pass(gpu):
     screen = gpu.empty(w, h, 4)
     N.check(gpu.lib.sfx_texture_params(screen, 1, 0, 0))
     N.check(gpu.lib.sfx_render(prog, screen, 0))
-    assert _last_kernel(gpu) == "k_render<VisualizerShader<64, 15, 6, 1, 1, 128, 64, 8>>", _last_kernel(gpu)
+    assert _last_kernel(gpu).startswith("k_visualizer_strip<66, 22, 1, 2, "), _last_kernel(gpu)
     shaded = gpu.read(screen, w, h, 4)
     final = gpu.empty(w, h, 3)
     N.check(gpu.lib.sfx_resolve(gpu.ctx.handle, screen, final, 2))
