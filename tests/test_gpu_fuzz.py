@@ -60,6 +60,51 @@ def test_visualizer_random_configurations(gpu, seed):
     assert d.max() <= 1, (seed, (w, h, ssaa, subsample, bg_size), lsb_report(got, want))
 
 
+def _strip_seeds():
+    import os
+    return range(int(os.environ.get("SHADERFLOW_FUZZ_STRIP_SEEDS", 18)))
+
+
+@pytest.mark.parametrize("seed", _strip_seeds())
+def test_strip_kernel_random_configurations(gpu, seed):
+    """The benchmark's kernel family (k_visualizer_strip: identity camera) over random sizes, backgrounds, wrap modes, volumes
+    (blur radius 0 … beyond the line slots), SSAA 2 and 4 fused and no SSAA into an RGBA8 iScreen, bottom-up and top-down rows:
+    whole frames against the oracle within 1 LSB. Whatever the launch picks (a strip instance, the quad kernel, round 1's kernels
+    when no tile fits) has to agree; most of these sizes land on strip instances with partial blocks and partial strips.
+    SHADERFLOW_FUZZ_STRIP_SEEDS=<n> runs more seeds."""
+    from shaderflow_amd import _native as N
+    rng = np.random.default_rng(7000 + seed)
+    ssaa = (2, 4, 1)[seed % 3]
+    w = int(rng.integers(40, 700 if ssaa < 4 else 360))
+    h = int(rng.integers(24, 420 if ssaa < 4 else 200))
+    bg_size = (int(rng.integers(64, 640)), int(rng.integers(36, 360)))
+    u, arrays, params = visualizer_inputs(w, h, seed=seed, volume=float(rng.choice([0.0, 0.1, 0.5, 0.9, 1.4, 2.5])), bg_size=bg_size,
+                                          time=float(rng.uniform(0, 40)), std=float(rng.uniform(0, 0.6)))
+    params["background"] = ("linear", bool(rng.integers(0, 2)), bool(rng.integers(0, 2)))
+    u.iSSAA = float(ssaa)
+    screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, threads=8)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    if ssaa == 1:
+        got, want = gpu.render(prog, w, h), screen
+    else:
+        top_down = bool(rng.integers(0, 2))
+        N.check(gpu.lib.sfx_ctx_output_top_down(gpu.ctx.handle, int(top_down)))
+        try:
+            got = gpu.render_resolve(prog, w, h, ssaa, 2)
+        finally:
+            N.check(gpu.lib.sfx_ctx_output_top_down(gpu.ctx.handle, 0))
+        want = O.resolve(screen, w, h, 2, threads=4)
+        if top_down:
+            want = want[::-1]
+    import os
+    if os.environ.get("SHADERFLOW_FUZZ_VERBOSE"):
+        print(f"\nseed {seed}: {w}x{h} ssaa {ssaa} background {bg_size}: {gpu.lib.sfx_last_kernel().decode()}")
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1, (seed, (w, h, ssaa, bg_size), gpu.lib.sfx_last_kernel().decode(), lsb_report(got, want))
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_generic_fragments_random_configurations(gpu, seed):
     rng = np.random.default_rng(2000 + seed)
