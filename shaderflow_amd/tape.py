@@ -28,6 +28,7 @@ from shaderflow_amd.audio.waveform import ShaderWaveform, WaveformReducer
 from shaderflow_amd.camera import ShaderCamera
 from shaderflow_amd.dynamics import ShaderDynamics, dynamics_coefficients
 from shaderflow_amd.module import ShaderModule
+from shaderflow_amd.piano import PianoNote
 from shaderflow_amd.scheduler import freewheel_clock
 from shaderflow_amd.shader import ShaderProgram
 from shaderflow_amd.texture import ShaderTexture
@@ -83,11 +84,13 @@ class FrameTape:
             return False
         if not (audios or spectrograms or waveforms):
             return True                                           # clock tape: only iTime/iTau/iFrame change between frames
-        if len(audios) != 1 or len(spectrograms) > 1 or len(waveforms) > 1 or not spectrograms:
+        if len(audios) != 1 or len(spectrograms) > 1 or len(waveforms) > 1:
             return False
         audio = audios[0]
         if audio.native is None or any(m.audio is not audio for m in (*spectrograms, *waveforms)):
             return False
+        if not spectrograms:
+            return True                                           # Waveform-like scenes: the tape carries a private spectrogram nobody samples
         if spectrograms[0].spectrogram_bins*audio.channels > 2048:
             return False                                          # the scan kernel walks up to 2048 values per frame
         # a scrolling spectrogram (length > 0) keeps one state of its texture per frame of a batch in HBM (sfx_tape_desc.length_samples)
@@ -106,6 +109,17 @@ class FrameTape:
         self.audio: Optional[ShaderAudio] = next((m for m in scene.modules if isinstance(m, ShaderAudio)), None)
         self.spectrogram: Optional[ShaderSpectrogram] = next((m for m in scene.modules if isinstance(m, ShaderSpectrogram)), None)
         self.waveform: Optional[ShaderWaveform] = next((m for m in scene.modules if isinstance(m, ShaderWaveform)), None)
+        self.private_spectrogram = False
+        if self.audio is not None and self.spectrogram is None:
+            # A scene with audio but no spectrogram module (demo.py's Waveform, or a fragment that reads iAudioVolume only): the native
+            # tape is built around a spectrogram plan, so it gets the smallest one — detached from the scene again, so that no sampler,
+            # uniform or update() of it exists as far as the scene is concerned (20 µs of STFT per 60 frames buys the batched path)
+            registered = len(scene.modules)
+            self.spectrogram = ShaderSpectrogram(scene=scene, audio=self.audio, length=0, name="iTapePrivateSpectrogram")
+            self.spectrogram.fft_n = 8
+            self.spectrogram.from_notes(start=PianoNote.from_frequency(440.0), end=PianoNote.from_frequency(880.0), bins=2)
+            del scene.modules[registered:]
+            self.private_spectrogram = True
         self.handle: Optional[N.Handle] = None
         self.frames = 0
 
@@ -161,7 +175,7 @@ class FrameTape:
         program = self.scene.shader
         if program.program is None:
             program.compile()
-        if self.spectrogram is not None:
+        if self.spectrogram is not None and not self.private_spectrogram:
             self.spectrogram.configure_texture()             # what its first update() would do
         program.use_pipeline(program.full_pipeline())
 

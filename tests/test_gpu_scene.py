@@ -226,6 +226,28 @@ def test_clock_tape_equals_frame_loop(name, ssaa):
     assert not np.array_equal(tape[0], tape[-1]) or name in ("Mandelbrot", "RayMarch")       # time-dependent scenes move
 
 
+@pytest.mark.parametrize("ssaa", [1, 2])
+def test_waveform_scene_tape_equals_frame_loop(ssaa):
+    """demo.py's Waveform scene (audio + waveform, no spectrogram module): the tape carries a private, detached spectrogram plan so
+    that the scene still takes the batched path — same frames as the python frame loop, and the scene's module list, pipeline and
+    fragment are untouched by it"""
+    from examples.scenes import Waveform, make
+    from shaderflow_amd.tape import FrameTape
+    pcm, sr = clip(1.3)
+    probe = make(Waveform, audio=(pcm, sr))
+    probe.initialize()
+    assert FrameTape.applicable(probe)
+    kw = dict(width=160, height=90, fps=60, time=70/60, ssaa=ssaa, output=bytes)              # 70 frames: two batches of the tape
+    loop_scene, tape_scene = make(Waveform, audio=(pcm, sr)), make(Waveform, audio=(pcm, sr))
+    loop = frames_of(loop_scene.main(batch=False, **kw), 160, 90)
+    tape = frames_of(tape_scene.main(batch=None, **kw), 160, 90)
+    assert not any(getattr(m, "name", "") == "iTapePrivateSpectrogram" for m in tape_scene.modules)
+    assert [type(m).__name__ for m in tape_scene.modules] == [type(m).__name__ for m in loop_scene.modules]
+    assert loop.shape == tape.shape == (70, 90, 160, 3)
+    assert np.abs(loop.astype(int) - tape.astype(int)).max() <= 1, lsb_report(tape, loop)
+    assert not np.array_equal(tape[5], tape[40])
+
+
 def test_piano_module_writes_its_textures(tmp_path):
     """ShaderPiano inside a scene: textures of the reference's shapes, written every frame, uniforms in the pipeline; a MIDI
     file round trip feeds it (the texture CONTENTS are pinned on CPU, tests/test_host_piano.py)"""
