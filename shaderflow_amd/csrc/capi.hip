@@ -839,11 +839,15 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
         // denser outputs (1080p or 1440p at 2x SSAA over a 1080-row background: up to 0.43 texel per sample): strips of four rows
         // over a 120 x 12 tile, two blocks per CU
         if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*4, 120, 12)) return launch_visualizer_tables_and_kernel<120, 12, 2, 4, 4>(ctx, a, frames, s);
+        // sparser still (720p at 2x SSAA: 0.65 texel per sample): 128 columns x 8 rows per block, strips of two, 92 x 14 tile
+        if (VIS_FAST_WALK > 0 && !plain && fits(128, 8, 92, 14)) return launch_visualizer_tables_and_kernel<92, 14, 2, 2, 4, 2>(ctx, a, frames, s);
         if (fits(256, 2, 72, 10)) return launch_visualizer_tables_and_kernel<72, 10, 0, 0, 8>(ctx, a, frames, s);
     } else if (VIS_FAST_WALK > 0) {
         if (fits(128, 4*WALK4, 40, VIS_STRIP_ROWS4)) return launch_visualizer_tables_and_kernel<40, VIS_STRIP_ROWS4, 4, WALK4, VIS_STRIP_WAVES4>(ctx, a, frames, s);
         // 1080p at 4x SSAA: the same tile with strips of four rows
         if (WALK4 != 4 && fits(128, 4*4, 40, 13)) return launch_visualizer_tables_and_kernel<40, 13, 4, 4, 8>(ctx, a, frames, s);
+        // 720p at 4x SSAA (0.32 texel per sample)
+        if (fits(128, 4*4, 56, 14)) return launch_visualizer_tables_and_kernel<56, 14, 4, 4, 8>(ctx, a, frames, s);
     }
     return 0;
 }
