@@ -41,4 +41,6 @@ run bars_c3 --scene bars
 run bars_1080p --scene bars --width 1920 --height 1080 --ssaa 2
 run visualizer_c2 --width 1920 --height 1080 --ssaa 1
 run visualizer_c1 --width 256 --height 256 --ssaa 1
+run visualizer_c4 --width 7680 --height 4320 --ssaa 4 --frames-per-step 8
+run visualizer_1080p_2x --width 1920 --height 1080 --ssaa 2
 cat $OUT
