@@ -21,8 +21,10 @@
 //
 // Bit-level contract: every term that decides a branch or a nearest-texel index — out of bounds, the polar angle and its bin,
 // the bar height, both lengths compared with it, the waveform strips — is the generic chain's sequence of operations (same
-// bits as fragments.hpp visualizer_post), merely evaluated where its inputs are known. Colour-only terms use the hardware's
-// log/exp/sqrt (1 ulp), as VisualizerShader does. The blur is VisualizerShader's (re-associated sums, <= 1e-6 relative).
+// bits as fragments.hpp visualizer_post), merely evaluated where its inputs are known — or, for the polar chain, a cheaper
+// evaluation whose error is bounded and which is re-run exactly by the whole wave whenever a lane comes within that bound of a
+// decision (visualizer_fast_post). Colour-only terms use the hardware's log/exp/sqrt (1 ulp), as VisualizerShader does. The
+// blur is VisualizerShader's (re-associated sums, <= 1e-6 relative).
 #pragma once
 
 #include "visualizer_kernels.hpp"
@@ -444,8 +446,8 @@ struct VisualizerFast {
 //   * the column entry and the window staging.
 // For that the LANES OF A WAVE MUST SHARE THEIR ROWS (the questions "same cell row?" and "which slots cover this cell?" are then
 // wave-uniform: scalar branches on values from scalar loads, no divergence), so the S x S supersamples of a pixel no longer sit in
-// the four lanes of a quad: wave w holds the WALK consecutive sample rows of row group w % S for the 64 sample columns of column
-// group w / S; the RGBA8 texels meet in LDS (over the cells, which are dead by then) and one thread per output pixel resolves all
+// the four lanes of a quad: wave w holds the WALK consecutive sample rows of row group w % ROW_GROUPS for the 64 sample columns of
+// column group w / ROW_GROUPS; the RGBA8 texels meet in LDS (over the cells, which are dead by then) and one thread per output pixel resolves all
 // three channels — cheaper than the DPP exchange it replaces.
 template <int TILE_PITCH, int TILE_ROWS, int S, int WALK, int COLUMN_GROUPS = 8/S>
 struct VisualizerStrip {
