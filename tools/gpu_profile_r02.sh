@@ -6,6 +6,7 @@ mkdir -p gpurun_out/r02
 bash tools/profile_bench.sh r02 > gpurun_out/r02/profile_summary_stdout.txt 2>&1
 cp gpurun_out/prof_r02_summary.txt gpurun_out/r02/rocprofv3_bench_c3_summary.txt
 cp gpurun_out/prof_r02.json gpurun_out/r02/bench_c3.json
+cp gpurun_out/prof_r02.json profiles/r02_bench_c3.json      # the final bench line below reads its counters from here (same sources, same box)
 timeout 120 build/ubench_valu > gpurun_out/r02/ubench_valu.txt 2>&1
 timeout 120 build/ubench_mfma_valu > gpurun_out/r02/ubench_mfma_valu.txt 2>&1
 python tools/parity_histogram.py > gpurun_out/r02/parity_histogram.txt 2>&1
