@@ -186,6 +186,21 @@ def sharded_frame_loop(world: int, rank: int, batches: list[tuple[int, int]], mo
 
 # ---- host mode: per-rank read-out into shared memory -------------------------------------------------------------------------
 
+def shm_slots_that_fit(frame_bytes: int, slots: int, world: int, directory: str = "/dev/shm") -> int:
+    """The ring of `world` ranks x `slots` frames lives in a tmpfs segment: writing past what the filesystem can back raises SIGBUS
+    (a container's /dev/shm may be 64 MB), so the ring is cut to half of the free space — or refused, loudly, when not even two
+    frames per rank fit — before anything is mapped"""
+    try:
+        stat = os.statvfs(directory)
+    except OSError:
+        return slots
+    fit = (stat.f_bavail*stat.f_frsize//2)//max(1, frame_bytes*world)
+    if fit < 2:
+        raise RuntimeError(f"{directory} has {stat.f_bavail*stat.f_frsize >> 20} MiB free: the cross-process frame ring needs at least "
+                           f"{(2*frame_bytes*world*2) >> 20} MiB for {world} ranks; use SHADERFLOW_SHARD=device or enlarge it")
+    return int(min(slots, fit))
+
+
 class HostDelivery:
     """This rank's end of the cross-process frame queue (csrc/shm_ring.inc): `push` frames in the order this rank finishes them;
     rank 0 also starts the writer, which hands the frames of all ranks to `fileno` in the order `runs` = [(rank, count), …]."""
@@ -198,9 +213,10 @@ class HostDelivery:
         from shaderflow_amd import _native as N
         self.N, self.C = N, C
         self.rank, self.world, self.frame_bytes, self.pushed = rank, world, frame_bytes, 0
-        name = [f"/shaderflow-{os.getpid()}-{id(self) & 0xffffff:x}"]
+        name = [f"/shaderflow-{os.getpid()}-{id(self) & 0xffffff:x}", shm_slots_that_fit(frame_bytes, slots, world)]
         if world > 1:
-            dist.broadcast_object_list(name, src=0)                 # one segment name for the group
+            dist.broadcast_object_list(name, src=0)                 # one segment name and one ring size for the group
+        slots = int(name[1])
         self.handle = N.Handle()
         N.check(N.lib().sfx_shm_create(context.handle, name[0].encode(), rank, world, frame_bytes, slots, C.byref(self.handle)))
         if rank == 0:

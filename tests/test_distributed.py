@@ -306,3 +306,25 @@ def test_interleaved_host_export_orders_frames_and_fences_buffers(world, total, 
         order.extend(per_rank[owner][taken[owner]:taken[owner] + count])
         taken[owner] += count
     assert order == list(range(total))
+
+
+def test_shm_ring_is_cut_to_the_free_space_of_its_filesystem(tmp_path, monkeypatch):
+    """The cross-process frame ring lives in tmpfs; mapping more than the filesystem can back ends in SIGBUS, so the slot count is
+    cut to half of the free space, and refused with a message when two frames per rank do not fit"""
+    import os
+    from shaderflow_amd import parallel
+
+    class Stat:
+        f_frsize = 4096
+
+        def __init__(self, free_bytes):
+            self.f_bavail = free_bytes//4096
+
+    frame = 3840*2160*3
+    monkeypatch.setattr(os, "statvfs", lambda path: Stat(64 << 30))
+    assert parallel.shm_slots_that_fit(frame, 120, 8) == 120                       # 23.9 GB of ring inside 32 GB
+    monkeypatch.setattr(os, "statvfs", lambda path: Stat(8 << 30))
+    assert parallel.shm_slots_that_fit(frame, 120, 8) == (4 << 30)//(frame*8)      # cut to half of the free space
+    monkeypatch.setattr(os, "statvfs", lambda path: Stat(64 << 20))                # a container's default /dev/shm
+    with pytest.raises(RuntimeError, match="frame ring needs"):
+        parallel.shm_slots_that_fit(frame, 120, 8)
