@@ -462,9 +462,13 @@ struct VisualizerStrip {
     static constexpr int ROWBYTES = TILE_PITCH*48;
     static_assert(COLUMN_GROUPS*ROW_GROUPS == 8 && RROWS % S == 0 && COLS % S == 0, "block geometry");
     using Fast = VisualizerFast<TILE_PITCH, TILE_ROWS, 128>;
+#ifndef VIS_STRIP_YSTEPS_LDS
+#define VIS_STRIP_YSTEPS_LDS 0                                         // 1: the block's ysteps through LDS (broadcast reads + v_readfirstlane) instead of scalar loads
+#endif
     struct Shared {
         float4 cells[TILE_ROWS*TILE_PITCH*3];                          // later: uint32 texels[RROWS][COLS], then the RGB8 rows at STAGED
         float4 row_entries[RROWS][VIS_ENTRY_QUADS];
+        float4 ysteps[VIS_STRIP_YSTEPS_LDS ? RROWS : 1][10];
     };
     static constexpr int STAGED = (int)sizeof(uint32_t)*RROWS*COLS;    // byte offset of the staged RGB8 rows inside the (dead) cell tile, after the texels
     static_assert(S == 1 || STAGED + PIXEL_ROWS*BLOCK_PX*3 <= (int)sizeof(float4)*TILE_ROWS*TILE_PITCH*3, "the texel exchange and the staged rows live in the cell tile");
@@ -504,6 +508,11 @@ struct VisualizerStrip {
             const int row = tid / VIS_ENTRY_QUADS, quad = tid - row*VIS_ENTRY_QUADS;
             const int jr = by*RROWS + row;
             sh.row_entries[row][quad] = t.rows[((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*VIS_ENTRY_QUADS + quad];
+        }
+        if (VIS_STRIP_YSTEPS_LDS && tid < RROWS*10) {
+            const int row = tid / 10, w = tid - row*10;
+            const int jr = by*RROWS + row;
+            sh.ysteps[row][w] = t.ysteps[((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*10 + w];
         }
         __syncthreads();
 
@@ -591,14 +600,14 @@ struct VisualizerStrip {
                     const int cxp = (int)((xp - axp)*48.0f), cxm = (int)((xm - axm)*48.0f);
                     float4 y[WALK];
 #pragma unroll
-                    for (int r = 0; r < WALK; r++) y[r] = ysteps[r][w];       // { frac(y+), frac(y-), row bytes(y+), row bytes(y-) }
+                    for (int r = 0; r < WALK; r++) y[r] = VIS_STRIP_YSTEPS_LDS ? sh.ysteps[row0 + r][w] : ysteps[r][w];   // { frac(y+), frac(y-), row bytes(y+), row bytes(y-) }
 #pragma unroll
                     for (int side = 0; side < 2; side++) {
                         float U0 = 0.0f, U1 = 0.0f, U2 = 0.0f, V0 = 0.0f, V1 = 0.0f, V2 = 0.0f;
                         int previous = -1;
 #pragma unroll
                         for (int r = 0; r < WALK; r++) if (r < rows) {
-                            const int cell_row = __float_as_int(side ? y[r].w : y[r].z);
+                            const int cell_row = VIS_STRIP_YSTEPS_LDS ? __builtin_amdgcn_readfirstlane(__float_as_int(side ? y[r].w : y[r].z)) : __float_as_int(side ? y[r].w : y[r].z);
                             if (cell_row != previous) {
                                 previous = cell_row;
                                 const float4* p = (const float4*)(tile + (cxp + cell_row));
@@ -611,7 +620,7 @@ struct VisualizerStrip {
                                 V0 = fmaf(axp, p2.y, V0);  V1 = fmaf(axp, p2.z, V1);  V2 = fmaf(axp, p2.w, V2);
                                 V0 = fmaf(axm, m2.y, V0);  V1 = fmaf(axm, m2.z, V1);  V2 = fmaf(axm, m2.w, V2);
                             }
-                            const float ay = in_vgpr(side ? y[r].y : y[r].x);
+                            const float ay = VIS_STRIP_YSTEPS_LDS ? (side ? y[r].y : y[r].x) : in_vgpr(side ? y[r].y : y[r].x);
                             acc[r][0] = acc[r][0] + U0;           acc[r][1] = acc[r][1] + U1;           acc[r][2] = acc[r][2] + U2;
                             acc[r][0] = fmaf(ay, V0, acc[r][0]);  acc[r][1] = fmaf(ay, V1, acc[r][1]);  acc[r][2] = fmaf(ay, V2, acc[r][2]);
                         }
