@@ -462,6 +462,9 @@ struct VisualizerStrip {
     static constexpr int ROWBYTES = TILE_PITCH*48;
     static_assert(COLUMN_GROUPS*ROW_GROUPS == 8 && RROWS % S == 0 && COLS % S == 0, "block geometry");
     using Fast = VisualizerFast<TILE_PITCH, TILE_ROWS, 128>;
+#ifndef VIS_STRIP_COLUMN_BRANCHFREE
+#define VIS_STRIP_COLUMN_BRANCHFREE 1                                  // 1: the column-line takes the weights of all rows of a cell at once (zeros for rows whose slots do not cover it)
+#endif
 #ifndef VIS_STRIP_YSTEPS_LDS
 #define VIS_STRIP_YSTEPS_LDS 0                                         // 1: the block's ysteps through LDS (broadcast reads + v_readfirstlane) instead of scalar loads
 #endif
@@ -469,6 +472,7 @@ struct VisualizerStrip {
         float4 cells[TILE_ROWS*TILE_PITCH*3];                          // later: uint32 texels[RROWS][COLS], then the RGB8 rows at STAGED
         float4 row_entries[RROWS][VIS_ENTRY_QUADS];
         float4 ysteps[VIS_STRIP_YSTEPS_LDS ? RROWS : 1][10];
+        float4 zeros;                                                  // weights of a slot that does not exist
     };
     static constexpr int STAGED = (int)sizeof(uint32_t)*RROWS*COLS;    // byte offset of the staged RGB8 rows inside the (dead) cell tile, after the texels
     static_assert(S == 1 || STAGED + PIXEL_ROWS*BLOCK_PX*3 <= (int)sizeof(float4)*TILE_ROWS*TILE_PITCH*3, "the texel exchange and the staged rows live in the cell tile");
@@ -509,6 +513,7 @@ struct VisualizerStrip {
             const int jr = by*RROWS + row;
             sh.row_entries[row][quad] = t.rows[((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*VIS_ENTRY_QUADS + quad];
         }
+        if (tid == 0) sh.zeros = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (VIS_STRIP_YSTEPS_LDS && tid < RROWS*10) {
             const int row = tid / 10, w = tid - row*10;
             const int jr = by*RROWS + row;
@@ -571,6 +576,23 @@ struct VisualizerStrip {
                     const float4 q0 = q[0], q1 = q[1], q2 = q[2];
                     const float U0 = fmaf(fx, q0.w, q0.x), U1 = fmaf(fx, q1.x, q0.y), U2 = fmaf(fx, q1.y, q0.z);
                     const float V0 = fmaf(fx, q2.y, q1.z), V1 = fmaf(fx, q2.z, q1.w), V2 = fmaf(fx, q2.w, q2.x);
+                    if (VIS_STRIP_COLUMN_BRANCHFREE) {
+                        float2 weights[WALK];
+#pragma unroll
+                        for (int r = 0; r < WALK; r++) {
+                            const int slot = k - start[r];
+                            const bool covered = r < rows && slot >= 0 && slot < VIS_LINE_CELLS;
+                            const char* source = covered ? (const char*)sh.row_entries[row0 + r] + 48 + slot*8 : (const char*)&sh.zeros;
+                            weights[r] = *(const float2*)source;
+                        }
+#pragma unroll
+                        for (int r = 0; r < WALK; r++) {
+                            const float2 w = weights[r];
+                            acc[r][0] = fmaf(w.x, U0, acc[r][0]); acc[r][1] = fmaf(w.x, U1, acc[r][1]); acc[r][2] = fmaf(w.x, U2, acc[r][2]);
+                            acc[r][0] = fmaf(w.y, V0, acc[r][0]); acc[r][1] = fmaf(w.y, V1, acc[r][1]); acc[r][2] = fmaf(w.y, V2, acc[r][2]);
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int r = 0; r < WALK; r++) {
                         const int slot = k - start[r];
@@ -601,28 +623,38 @@ struct VisualizerStrip {
                     float4 y[WALK];
 #pragma unroll
                     for (int r = 0; r < WALK; r++) y[r] = VIS_STRIP_YSTEPS_LDS ? sh.ysteps[row0 + r][w] : ysteps[r][w];   // { frac(y+), frac(y-), row bytes(y+), row bytes(y-) }
+#ifndef VIS_STRIP_SIDES_TOGETHER
+#define VIS_STRIP_SIDES_TOGETHER 1                                     // 1: both y sides of a walk step advance row by row together (their first cells are fetched at once)
+#endif
+                    float U[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}}, V[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+                    int previous[2] = {-1, -1};
+                    auto advance = [&](int r, int side) {
+                        const int cell_row = VIS_STRIP_YSTEPS_LDS ? __builtin_amdgcn_readfirstlane(__float_as_int(side ? y[r].w : y[r].z)) : __float_as_int(side ? y[r].w : y[r].z);
+                        if (cell_row != previous[side]) {
+                            previous[side] = cell_row;
+                            const float4* p = (const float4*)(tile + (cxp + cell_row));
+                            const float4* m = (const float4*)(tile + (cxm + cell_row));
+                            const float4 p0 = p[0], p1 = p[1], p2 = p[2], m0 = m[0], m1 = m[1], m2 = m[2];
+                            float* u = U[side]; float* v = V[side];
+                            u[0] = p0.x + m0.x;          u[1] = p0.y + m0.y;          u[2] = p0.z + m0.z;
+                            u[0] = fmaf(axp, p0.w, u[0]);  u[1] = fmaf(axp, p1.x, u[1]);  u[2] = fmaf(axp, p1.y, u[2]);
+                            u[0] = fmaf(axm, m0.w, u[0]);  u[1] = fmaf(axm, m1.x, u[1]);  u[2] = fmaf(axm, m1.y, u[2]);
+                            v[0] = p1.z + m1.z;          v[1] = p1.w + m1.w;          v[2] = p2.x + m2.x;
+                            v[0] = fmaf(axp, p2.y, v[0]);  v[1] = fmaf(axp, p2.z, v[1]);  v[2] = fmaf(axp, p2.w, v[2]);
+                            v[0] = fmaf(axm, m2.y, v[0]);  v[1] = fmaf(axm, m2.z, v[1]);  v[2] = fmaf(axm, m2.w, v[2]);
+                        }
+                        const float ay = VIS_STRIP_YSTEPS_LDS ? (side ? y[r].y : y[r].x) : in_vgpr(side ? y[r].y : y[r].x);
+                        acc[r][0] = acc[r][0] + U[side][0];           acc[r][1] = acc[r][1] + U[side][1];           acc[r][2] = acc[r][2] + U[side][2];
+                        acc[r][0] = fmaf(ay, V[side][0], acc[r][0]);  acc[r][1] = fmaf(ay, V[side][1], acc[r][1]);  acc[r][2] = fmaf(ay, V[side][2], acc[r][2]);
+                    };
+                    if (VIS_STRIP_SIDES_TOGETHER) {
 #pragma unroll
-                    for (int side = 0; side < 2; side++) {
-                        float U0 = 0.0f, U1 = 0.0f, U2 = 0.0f, V0 = 0.0f, V1 = 0.0f, V2 = 0.0f;
-                        int previous = -1;
+                        for (int r = 0; r < WALK; r++) if (r < rows) { advance(r, 0); advance(r, 1); }
+                    } else {
 #pragma unroll
-                        for (int r = 0; r < WALK; r++) if (r < rows) {
-                            const int cell_row = VIS_STRIP_YSTEPS_LDS ? __builtin_amdgcn_readfirstlane(__float_as_int(side ? y[r].w : y[r].z)) : __float_as_int(side ? y[r].w : y[r].z);
-                            if (cell_row != previous) {
-                                previous = cell_row;
-                                const float4* p = (const float4*)(tile + (cxp + cell_row));
-                                const float4* m = (const float4*)(tile + (cxm + cell_row));
-                                const float4 p0 = p[0], p1 = p[1], p2 = p[2], m0 = m[0], m1 = m[1], m2 = m[2];
-                                U0 = p0.x + m0.x;          U1 = p0.y + m0.y;          U2 = p0.z + m0.z;
-                                U0 = fmaf(axp, p0.w, U0);  U1 = fmaf(axp, p1.x, U1);  U2 = fmaf(axp, p1.y, U2);
-                                U0 = fmaf(axm, m0.w, U0);  U1 = fmaf(axm, m1.x, U1);  U2 = fmaf(axm, m1.y, U2);
-                                V0 = p1.z + m1.z;          V1 = p1.w + m1.w;          V2 = p2.x + m2.x;
-                                V0 = fmaf(axp, p2.y, V0);  V1 = fmaf(axp, p2.z, V1);  V2 = fmaf(axp, p2.w, V2);
-                                V0 = fmaf(axm, m2.y, V0);  V1 = fmaf(axm, m2.z, V1);  V2 = fmaf(axm, m2.w, V2);
-                            }
-                            const float ay = VIS_STRIP_YSTEPS_LDS ? (side ? y[r].y : y[r].x) : in_vgpr(side ? y[r].y : y[r].x);
-                            acc[r][0] = acc[r][0] + U0;           acc[r][1] = acc[r][1] + U1;           acc[r][2] = acc[r][2] + U2;
-                            acc[r][0] = fmaf(ay, V0, acc[r][0]);  acc[r][1] = fmaf(ay, V1, acc[r][1]);  acc[r][2] = fmaf(ay, V2, acc[r][2]);
+                        for (int side = 0; side < 2; side++) {
+#pragma unroll
+                            for (int r = 0; r < WALK; r++) if (r < rows) advance(r, side);
                         }
                     }
                     xp = xp + step; xm = xm - step;
