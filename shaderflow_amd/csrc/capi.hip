@@ -803,7 +803,7 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
     };
     // build knobs of the strip kernel (tools/variants.sh): rows a lane walks at 2x / 4x SSAA, rows of cells of the tiles, resident waves per SIMD
 #ifndef VIS_STRIP_WALK2
-#define VIS_STRIP_WALK2 VIS_FAST_WALK
+#define VIS_STRIP_WALK2 (VIS_FAST_WALK == 8 ? 9 : VIS_FAST_WALK)     // nine rows: the longest strip that stays inside 64 VGPRs (ten spill), +2 % over eight
 #endif
 #ifndef VIS_STRIP_WALK4
 #define VIS_STRIP_WALK4 VIS_FAST_WALK

@@ -616,7 +616,10 @@ struct VisualizerStrip {
                     ysteps[r] = t.ysteps + ((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*10;
                 }
                 float xp = xr + first, xm = xr - first;
-#pragma unroll 1
+#ifndef VIS_STRIP_DIAG_UNROLL
+#define VIS_STRIP_DIAG_UNROLL 1
+#endif
+#pragma unroll VIS_STRIP_DIAG_UNROLL
                 for (int w = 0; w < 10; w++) {
                     const float axp = __builtin_amdgcn_fractf(xp), axm = __builtin_amdgcn_fractf(xm);
                     const int cxp = (int)((xp - axp)*48.0f), cxm = (int)((xm - axm)*48.0f);
