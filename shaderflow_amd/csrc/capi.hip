@@ -806,7 +806,7 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
 #define VIS_STRIP_WALK2 (VIS_FAST_WALK == 8 ? 9 : VIS_FAST_WALK)     // nine rows: the longest strip that stays inside 64 VGPRs (ten spill), +2 % over eight
 #endif
 #ifndef VIS_STRIP_WALK4
-#define VIS_STRIP_WALK4 VIS_FAST_WALK
+#define VIS_STRIP_WALK4 (VIS_FAST_WALK == 8 ? 10 : VIS_FAST_WALK)
 #endif
 #ifndef VIS_STRIP_ROWS2
 #define VIS_STRIP_ROWS2 (VIS_STRIP_WALK2 <= 4 ? 10 : (VIS_STRIP_WALK2 <= 6 ? 11 : 12))
@@ -836,9 +836,15 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
         if (fits(64, 8, 66, 15)) return launch_visualizer_tables_and_kernel<66, 15, 1, 1, 6, 1>(ctx, a, frames, s);
     } else if (ssaa == 2) {
         if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*WALK2, VIS_STRIP_PITCH2, VIS_STRIP_ROWS2)) return launch_visualizer_tables_and_kernel<VIS_STRIP_PITCH2, VIS_STRIP_ROWS2, 2, WALK2, VIS_STRIP_WAVES2>(ctx, a, frames, s);
-        // denser outputs (1080p or 1440p at 2x SSAA over a 1080-row background: up to 0.43 texel per sample): strips of four rows
-        // over a 120 x 12 tile, two blocks per CU
-        if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*4, 120, 12)) return launch_visualizer_tables_and_kernel<120, 12, 2, 4, 4>(ctx, a, frames, s);
+        // denser outputs (1080p or 1440p at 2x SSAA over a 1080-row background: up to 0.43 texel per sample): strips of six rows
+        // over a 120 x 13 tile, two blocks per CU
+#ifndef VIS_DENSE_WALK
+#define VIS_DENSE_WALK 6                                              // the longest strip whose 120-cell-wide tile still leaves two blocks per CU
+#endif
+#ifndef VIS_DENSE_ROWS
+#define VIS_DENSE_ROWS 13
+#endif
+        if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*VIS_DENSE_WALK, 120, VIS_DENSE_ROWS)) return launch_visualizer_tables_and_kernel<120, VIS_DENSE_ROWS, 2, VIS_DENSE_WALK, 4>(ctx, a, frames, s);
         // sparser still (720p at 2x SSAA: 0.65 texel per sample): 128 columns x 8 rows per block, strips of two, 92 x 14 tile
         if (VIS_FAST_WALK > 0 && !plain && fits(128, 8, 92, 14)) return launch_visualizer_tables_and_kernel<92, 14, 2, 2, 4, 2>(ctx, a, frames, s);
         if (fits(256, 2, 72, 10)) return launch_visualizer_tables_and_kernel<72, 10, 0, 0, 8>(ctx, a, frames, s);

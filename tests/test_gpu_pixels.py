@@ -346,7 +346,7 @@ def test_full_size_properties_8k_ssaa4(gpu):
         assert_within_lsb(a[rows[0]:rows[1]], want[rows[0]:rows[1]])
 
 
-@pytest.mark.parametrize("w,h,ssaa,kernel", [(1920, 1080, 2, "k_visualizer_strip<120, 12, 2, 4, "), (2560, 1440, 2, "k_visualizer_strip<120, 12, 2, 4, "),
+@pytest.mark.parametrize("w,h,ssaa,kernel", [(1920, 1080, 2, "k_visualizer_strip<120, 13, 2, 6, "), (2560, 1440, 2, "k_visualizer_strip<120, 13, 2, 6, "),
                                              (1920, 1080, 4, "k_visualizer_strip<40, 13, 4, 4, "), (1280, 720, 2, "k_visualizer_strip<92, 14, 2, 2, "),
                                              (1280, 720, 4, "k_visualizer_strip<56, 14, 4, 4, ")])
 def test_full_size_properties_dense_outputs(gpu, w, h, ssaa, kernel):
