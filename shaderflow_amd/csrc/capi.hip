@@ -845,15 +845,33 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
 #define VIS_DENSE_ROWS 13
 #endif
         if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*VIS_DENSE_WALK, 120, VIS_DENSE_ROWS)) return launch_visualizer_tables_and_kernel<120, VIS_DENSE_ROWS, 2, VIS_DENSE_WALK, 4>(ctx, a, frames, s);
-        // sparser still (720p at 2x SSAA: 0.65 texel per sample): 128 columns x 8 rows per block, strips of two, 92 x 14 tile
-        if (VIS_FAST_WALK > 0 && !plain && fits(128, 8, 92, 14)) return launch_visualizer_tables_and_kernel<92, 14, 2, 2, 4, 2>(ctx, a, frames, s);
+        // sparser still (720p at 2x SSAA: 0.65 texel per sample): 128 columns x 12 rows per block, strips of three, 92 x 16 tile
+#ifndef VIS_SPARSE_WALK
+#define VIS_SPARSE_WALK 3
+#endif
+#ifndef VIS_SPARSE_ROWS
+#define VIS_SPARSE_ROWS 16
+#endif
+        if (VIS_FAST_WALK > 0 && !plain && fits(128, 4*VIS_SPARSE_WALK, 92, VIS_SPARSE_ROWS)) return launch_visualizer_tables_and_kernel<92, VIS_SPARSE_ROWS, 2, VIS_SPARSE_WALK, 4, 2>(ctx, a, frames, s);
         if (fits(256, 2, 72, 10)) return launch_visualizer_tables_and_kernel<72, 10, 0, 0, 8>(ctx, a, frames, s);
     } else if (VIS_FAST_WALK > 0) {
         if (fits(128, 4*WALK4, 40, VIS_STRIP_ROWS4)) return launch_visualizer_tables_and_kernel<40, VIS_STRIP_ROWS4, 4, WALK4, VIS_STRIP_WAVES4>(ctx, a, frames, s);
-        // 1080p at 4x SSAA: the same tile with strips of four rows
-        if (WALK4 != 4 && fits(128, 4*4, 40, 13)) return launch_visualizer_tables_and_kernel<40, 13, 4, 4, 8>(ctx, a, frames, s);
+        // 1080p at 4x SSAA: the same tile width with strips of six rows
+#ifndef VIS_MID4_WALK
+#define VIS_MID4_WALK 6
+#endif
+#ifndef VIS_MID4_ROWS
+#define VIS_MID4_ROWS 14
+#endif
+#ifndef VIS_SPARSE4_WALK
+#define VIS_SPARSE4_WALK 6
+#endif
+#ifndef VIS_SPARSE4_ROWS
+#define VIS_SPARSE4_ROWS 16
+#endif
+        if (WALK4 != VIS_MID4_WALK && fits(128, 4*VIS_MID4_WALK, 40, VIS_MID4_ROWS)) return launch_visualizer_tables_and_kernel<40, VIS_MID4_ROWS, 4, VIS_MID4_WALK, 8>(ctx, a, frames, s);
         // 720p at 4x SSAA (0.32 texel per sample)
-        if (fits(128, 4*4, 56, 14)) return launch_visualizer_tables_and_kernel<56, 14, 4, 4, 8>(ctx, a, frames, s);
+        if (fits(128, 4*VIS_SPARSE4_WALK, 56, VIS_SPARSE4_ROWS)) return launch_visualizer_tables_and_kernel<56, VIS_SPARSE4_ROWS, 4, VIS_SPARSE4_WALK, 8>(ctx, a, frames, s);
     }
     return 0;
 }

@@ -347,8 +347,8 @@ def test_full_size_properties_8k_ssaa4(gpu):
 
 
 @pytest.mark.parametrize("w,h,ssaa,kernel", [(1920, 1080, 2, "k_visualizer_strip<120, 13, 2, 6, "), (2560, 1440, 2, "k_visualizer_strip<120, 13, 2, 6, "),
-                                             (1920, 1080, 4, "k_visualizer_strip<40, 13, 4, 4, "), (1280, 720, 2, "k_visualizer_strip<92, 14, 2, 2, "),
-                                             (1280, 720, 4, "k_visualizer_strip<56, 14, 4, 4, ")])
+                                             (1920, 1080, 4, "k_visualizer_strip<40, 14, 4, 6, "), (1280, 720, 2, "k_visualizer_strip<92, 16, 2, 3, "),
+                                             (1280, 720, 4, "k_visualizer_strip<56, 16, 4, 6, ")])
 def test_full_size_properties_dense_outputs(gpu, w, h, ssaa, kernel):
     """Outputs denser than the benchmark's over the same 1080-row background (up to 0.43 texel per sample): the strip kernel's
     instances with shorter strips over larger tiles; bands of rows against the oracle, determinism."""
