@@ -244,7 +244,16 @@ __device__ __forceinline__ void scalar_step(ScalarState& s, double target, const
     if (integrate) s.integral += (s.value*c.dt);                      // :248-249
 }
 
-__global__ __launch_bounds__(1024) void k_dynamics_scan(int nframes, int n /* bins*channels */,
+// THREADS x PER >= n values. One wave (THREADS == 64, up to 256 values: the 115-bin stereo spectrogram of the benchmark) needs no
+// barrier at all — the early-out's maximum is a wave reduction; larger states take 1024 threads and two barriers per frame. The
+// frame loop is latency bound (a batch is 60 dependent steps of a few hundred values), so the next frame's targets and
+// coefficients are requested before the current frame is worked on, and the float64 volume/std systems live in registers for the
+// whole batch instead of a global round trip per frame (117 -> see DESIGN §7 µs per 60 frames).
+// KEEPER_WAVE: the float64 volume/std systems and the uniforms of a frame are stepped by lane 0 of an extra wave of their own — both
+// halves are chains of dependent operations (IEEE divisions in float32 here, in float64 there) that a single wave would run one after
+// the other; they share nothing, so no barrier is needed between them.
+template <int THREADS, int PER, bool KEEPER_WAVE = false>
+__global__ __launch_bounds__(THREADS + (KEEPER_WAVE ? 64 : 0)) void k_dynamics_scan(int nframes, int n /* bins*channels */,
                                                         const float* __restrict__ targets,     // [frame][n]
                                                         const DynCoeffF32* __restrict__ coeff,
                                                         float precision,
@@ -255,36 +264,67 @@ __global__ __launch_bounds__(1024) void k_dynamics_scan(int nframes, int n /* bi
                                                         double scalar_precision, int vol_integrate, int std_integrate,
                                                         ScalarState* __restrict__ scalars,     // [2]
                                                         const FrameClock* __restrict__ clock, FrameDyn* __restrict__ dyn) {
-    __shared__ float red[16];
-    __shared__ int skip;
-    constexpr int PER = 2;                                            // up to 2048 elements
-    float value[PER], deriv[PER], prev[PER];
+    constexpr int WAVES = THREADS/64;
+    if (KEEPER_WAVE && threadIdx.x >= THREADS) n = 0;                 // the keeper's wave holds no values
+    __shared__ float red[WAVES > 1 ? WAVES : 1];
+    __shared__ int skip_shared;
+    float value[PER], deriv[PER], prev[PER], target[PER], upcoming[PER];
+#pragma unroll
     for (int e = 0; e < PER; e++) {
-        const int i = threadIdx.x + e*1024;
+        const int i = threadIdx.x + e*THREADS;
         value[e] = (i < n) ? state[i] : 0.0f;
         deriv[e] = (i < n) ? state[n + i] : 0.0f;
         prev[e] = (i < n) ? state[2*n + i] : 0.0f;
+        upcoming[e] = (i < n && nframes > 0) ? targets[i] : 0.0f;
     }
+    const bool keeper = threadIdx.x == (KEEPER_WAVE ? THREADS : 0) && dyn;   // the thread that steps the float64 systems and writes the uniforms
+    ScalarState v{}, s{};
+    if (keeper) { v = scalars[0]; s = scalars[1]; }
+    DynCoeffF32 c_next = nframes > 0 ? coeff[0] : DynCoeffF32{};
+    // the keeper's per-frame inputs, requested one frame ahead as well
+    FrameClock clock_next{}; float loud_next[2] = {0.0f, 0.0f}; DynCoeffF64 vol_next{}, std_next{};
+    auto keeper_fetch = [&](int f) {
+        clock_next = clock[f];
+        if (loudness) { loud_next[0] = loudness[2*f]; loud_next[1] = loudness[2*f + 1]; vol_next = vol_coeff[f]; std_next = std_coeff[f]; }
+    };
+    if (keeper && nframes > 0) keeper_fetch(0);
     for (int f = 0; f < nframes; f++) {
-        const DynCoeffF32 c = coeff[f];
-        float target[PER];
+        const DynCoeffF32 c = c_next;
+        const FrameClock clock_now = clock_next; const float loud_now[2] = {loud_next[0], loud_next[1]}; const DynCoeffF64 vol_now = vol_next, std_now = std_next;
+        if (keeper && f + 1 < nframes) keeper_fetch(f + 1);
         float worst = 0.0f;
+#pragma unroll
         for (int e = 0; e < PER; e++) {
-            const int i = threadIdx.x + e*1024;
-            target[e] = (i < n) ? targets[(long)f*n + i] : 0.0f;
+            const int i = threadIdx.x + e*THREADS;
+            target[e] = upcoming[e];
             if (i < n) worst = fmaxf(worst, fabsf(target[e] - value[e]));
+        }
+        if (f + 1 < nframes) {                                        // in flight while this frame is worked on
+            c_next = coeff[f + 1];
+#pragma unroll
+            for (int e = 0; e < PER; e++) {
+                const int i = threadIdx.x + e*THREADS;
+                upcoming[e] = (i < n) ? targets[(long)(f + 1)*n + i] : 0.0f;
+            }
         }
         if (c.dt != 0.0f) {
             for (int m = 32; m >= 1; m >>= 1) worst = fmaxf(worst, __shfl_xor(worst, m));
-            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = worst;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                float w = red[0];
-                for (int k = 1; k < 16; k++) w = fmaxf(w, red[k]);
-                skip = (w < precision) ? 1 : 0;                       // np.abs(target - value).max() < precision
+            bool skip;
+            if constexpr (WAVES == 1) {
+                skip = worst < precision;                             // np.abs(target - value).max() < precision
+            } else {
+                if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = worst;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    float w = red[0];
+                    for (int k = 1; k < WAVES; k++) w = fmaxf(w, red[k]);
+                    skip_shared = (w < precision) ? 1 : 0;
+                }
+                __syncthreads();
+                skip = skip_shared != 0;
             }
-            __syncthreads();
             if (!skip) {
+#pragma unroll
                 for (int e = 0; e < PER; e++) {
                     const float velocity = (target[e] - prev[e])/c.dt;
                     prev[e] = target[e];
@@ -293,29 +333,30 @@ __global__ __launch_bounds__(1024) void k_dynamics_scan(int nframes, int n /* bi
                     deriv[e] = deriv[e] + (accel*c.dt);
                 }
             }
-            __syncthreads();
+            if constexpr (WAVES > 1) __syncthreads();
         }
+#pragma unroll
         for (int e = 0; e < PER; e++) {
-            const int i = threadIdx.x + e*1024;
+            const int i = threadIdx.x + e*THREADS;
             if (i < n) columns[(long)f*n + i] = value[e];
         }
-        if (threadIdx.x == 0 && dyn) {
-            ScalarState v = scalars[0], s = scalars[1];
+        if (keeper) {
             if (loudness) {
-                scalar_step(v, (double)loudness[2*f], vol_coeff[f], scalar_precision, vol_integrate);
-                scalar_step(s, (double)loudness[2*f + 1], std_coeff[f], scalar_precision, std_integrate);
+                scalar_step(v, (double)loud_now[0], vol_now, scalar_precision, vol_integrate);
+                scalar_step(s, (double)loud_now[1], std_now, scalar_precision, std_integrate);
             }
-            scalars[0] = v; scalars[1] = s;
             FrameDyn d;
-            d.iTime = clock[f].iTime; d.iTau = clock[f].iTau; d.iFrame = clock[f].iFrame;
-            d.iSpectrogramOffset = clock[f].iSpectrogramOffset;
+            d.iTime = clock_now.iTime; d.iTau = clock_now.iTau; d.iFrame = clock_now.iFrame;
+            d.iSpectrogramOffset = clock_now.iSpectrogramOffset;
             d.iAudioVolume = (float)v.value; d.iAudioVolumeIntegral = (float)v.integral; d.iAudioSTD = (float)s.value;
             d.pad = 0;
             dyn[f] = d;
         }
     }
+    if (keeper) { scalars[0] = v; scalars[1] = s; }
+#pragma unroll
     for (int e = 0; e < PER; e++) {
-        const int i = threadIdx.x + e*1024;
+        const int i = threadIdx.x + e*THREADS;
         if (i < n) { state[i] = value[e]; state[n + i] = deriv[e]; state[2*n + i] = prev[e]; }
     }
 }

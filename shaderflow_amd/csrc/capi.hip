@@ -1461,6 +1461,12 @@ static int check_audio(const Plan* p, const Audio* a) {
     return SFX_OK;
 }
 
+// K3: one wave for up to 256 values plus one for the float64 systems (no barriers), 1024 threads for up to 2048
+template <class... Args> static void launch_dynamics_scan(hipStream_t s, int nframes, int n, Args... args) {
+    if (n <= 256) hipLaunchKernelGGL((k_dynamics_scan<64, 4, true>), dim3(1), dim3(128), 0, s, nframes, n, args...);
+    else hipLaunchKernelGGL((k_dynamics_scan<1024, 2>), dim3(1), dim3(1024), 0, s, nframes, n, args...);
+}
+
 // device-side launches shared by the per-frame entry points and the tape
 static void launch_stft(const Plan* p, const Audio* a, const long* d_tell, int frames, float* d_power, hipStream_t s) {
     const int N = 1 << p->fft_n;
@@ -1572,9 +1578,9 @@ extern "C" int sfx_dynamics_scan(sfx_handle h, int nframes, int n, const float* 
         hipMemcpyAsync(d_targets, targets, frame_bytes, hipMemcpyHostToDevice, s);
         hipMemcpyAsync(d_state, state, sizeof(float)*3*n, hipMemcpyHostToDevice, s);
         hipMemcpyAsync(d_coeff, coeff, sizeof(DynCoeffF32)*nframes, hipMemcpyHostToDevice, s);
-        hipLaunchKernelGGL(k_dynamics_scan, dim3(1), dim3(1024), 0, s, nframes, n, d_targets, d_coeff, precision, d_state, d_values,
-                           (const float*)nullptr, (const DynCoeffF64*)nullptr, (const DynCoeffF64*)nullptr, 0.0, 0, 0,
-                           (ScalarState*)nullptr, (const FrameClock*)nullptr, (FrameDyn*)nullptr);
+        launch_dynamics_scan(s, nframes, n, d_targets, d_coeff, precision, d_state, d_values,
+                             (const float*)nullptr, (const DynCoeffF64*)nullptr, (const DynCoeffF64*)nullptr, 0.0, 0, 0,
+                             (ScalarState*)nullptr, (const FrameClock*)nullptr, (FrameDyn*)nullptr);
         rc = launch_status();
     }
     if (!rc) {
@@ -1740,9 +1746,9 @@ extern "C" int sfx_tape_build(sfx_handle h, int nframes, const int64_t* tell, co
         hipLaunchKernelGGL(k_waveform_rows, dim3((t->desc.points*a->channels + 3)/4, nframes), dim3(256), 0, s,
                            a->pcm, a->samples, a->channels, t->d_tell, t->desc.chunk_size, t->desc.points, t->desc.reducer, t->d_rows);
     hipLaunchKernelGGL(k_volume_std, dim3(nframes), dim3(256), 0, s, a->pcm, a->samples, a->channels, t->d_tell, t->desc.volume_window, t->d_loudness);
-    hipLaunchKernelGGL(k_dynamics_scan, dim3(1), dim3(1024), 0, s, nframes, t->n, t->d_targets, t->d_coeff, (float)t->desc.precision,
-                       t->d_state, t->d_columns, t->d_loudness, t->d_vol, t->d_std, t->desc.precision,
-                       t->desc.volume_integrate, t->desc.std_integrate, t->d_scalars, t->d_clock, t->d_dyn);
+    launch_dynamics_scan(s, nframes, t->n, t->d_targets, t->d_coeff, (float)t->desc.precision,
+                         t->d_state, t->d_columns, t->d_loudness, t->d_vol, t->d_std, t->desc.precision,
+                         t->desc.volume_integrate, t->desc.std_integrate, t->d_scalars, t->d_clock, t->d_dyn);
     if (t->width > 1) {
         const long count = (long)nframes*t->n;
         hipLaunchKernelGGL(k_spectrogram_ring_store, dim3((unsigned)((count + 255)/256)), dim3(256), 0, s, t->d_columns, nframes, t->n, t->frames_done, t->ring_frames, t->d_ring);
