@@ -150,6 +150,8 @@ def main() -> None:
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    # the host driver of this pool supports dmabuf IPC only: without this RCCL's cross-process buffers fail (hipIpcGetMemHandle)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch                                                  # before the HIP library: one HIP runtime per process
 

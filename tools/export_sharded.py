@@ -27,6 +27,7 @@ def main():
     p.add_argument("--output", default="/dev/null")
     args = p.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC (RCCL across processes on this pool)
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
