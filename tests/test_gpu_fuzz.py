@@ -90,12 +90,13 @@ def test_strip_kernel_random_configurations(gpu, seed):
         got, want = gpu.render(prog, w, h), screen
     else:
         top_down = bool(rng.integers(0, 2))
+        subsample = int(rng.choice([s for s in (1, 2, 4) if N.lib().sfx_fused_supported(ssaa*1000, s)]))       # final.glsl's kernel
         N.check(gpu.lib.sfx_ctx_output_top_down(gpu.ctx.handle, int(top_down)))
         try:
-            got = gpu.render_resolve(prog, w, h, ssaa, 2)
+            got = gpu.render_resolve(prog, w, h, ssaa, subsample)
         finally:
             N.check(gpu.lib.sfx_ctx_output_top_down(gpu.ctx.handle, 0))
-        want = O.resolve(screen, w, h, 2, threads=4)
+        want = O.resolve(screen, w, h, subsample, threads=4)
         if top_down:
             want = want[::-1]
     import os
