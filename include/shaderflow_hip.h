@@ -154,6 +154,10 @@ int sfx_ring_read_device_async(sfx_handle ring, const void* device_ptr, int slot
 int sfx_ring_fence(sfx_handle ring, int which /* 0 or 1 */);
 int sfx_ring_read_fenced_async(sfx_handle ring, const void* device_ptr, int slot, int which);
 int sfx_ring_stream_wait(sfx_handle ring, int slot);
+/* `count` consecutive frames of a batch (first at device_ptr, `stride` bytes apart) read against fence `which` (< 0: against the
+ * render stream as it is now) into slots first_slot, first_slot + 1, … (modulo the ring) and queued for `fd` in that order:
+ * the loop of read_into + turbopipe.pipe over a batch (exporting.py:151-174) in one call. */
+int sfx_ring_pipe_frames(sfx_handle ring, const void* device_ptr, size_t stride, int count, int first_slot, int which, int fd);
 int sfx_ring_sync(sfx_handle ring, int slot, void** host_ptr);                      /* buffer.read() */
 int sfx_ring_pipe(sfx_handle ring, int slot, int fd);                               /* turbopipe.pipe */
 int sfx_ring_pipe_sync(sfx_handle ring, int slot);                                  /* turbopipe.sync; slot < 0: all */

@@ -100,6 +100,7 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_ring_read_device_async": (C.c_int, [Handle, C.c_void_p, C.c_int]),
     "sfx_ring_fence": (C.c_int, [Handle, C.c_int]),
     "sfx_ring_read_fenced_async": (C.c_int, [Handle, C.c_void_p, C.c_int, C.c_int]),
+    "sfx_ring_pipe_frames": (C.c_int, [Handle, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sfx_ring_stream_wait": (C.c_int, [Handle, C.c_int]),
     "sfx_ring_sync": (C.c_int, [Handle, C.c_int, P(C.c_void_p)]),
     "sfx_ring_pipe": (C.c_int, [Handle, C.c_int, C.c_int]),

@@ -1289,6 +1289,19 @@ extern "C" int sfx_ring_pipe(sfx_handle h, int slot, int fd) {
     return SFX_OK;
 }
 
+extern "C" int sfx_ring_pipe_frames(sfx_handle h, const void* dptr, size_t stride, int count, int first_slot, int which, int fd) {
+    Ring* r = get<Ring>(h, MAGIC_RING);
+    if (!r || !dptr || count < 0 || first_slot < 0 || which > 1 || fd < 0) return fail(SFX_E_INVALID, "invalid ring handle, pointer, count, slot, fence or fd");
+    for (int k = 0; k < count; k++) {
+        const int slot = (first_slot + k) % r->slots;
+        const void* frame = (const char*)dptr + (size_t)k*stride;
+        int rc = which < 0 ? sfx_ring_read_device_async(h, frame, slot) : sfx_ring_read_fenced_async(h, frame, slot, which);
+        if (!rc) rc = sfx_ring_pipe(h, slot, fd);
+        if (rc) return rc;
+    }
+    return SFX_OK;
+}
+
 extern "C" int sfx_ring_pipe_sync(sfx_handle h, int slot) {
     Ring* r = get<Ring>(h, MAGIC_RING);
     if (!r || slot >= r->slots) return fail(SFX_E_INVALID, "invalid ring handle or slot");

@@ -200,6 +200,18 @@ class ExportingHelper:
         if not turbo:
             N.check(N.lib().sfx_ring_pipe_sync(self.ring, slot))
 
+    def pipe_device_frames(self, device_ptr: int, stride: int, count: int, turbo: bool = True, fence: Optional[int] = None) -> None:
+        """`count` consecutive frames of a batch in one native call (the per-frame python loop costs more than the frames themselves
+        when they are small); with a progress relay, or without turbo, frame by frame as before"""
+        if self.relay is not None or not turbo or self.fileno is None or self.ring is None:
+            for i in range(count):
+                self.pipe_device(device_ptr + i*stride, turbo=turbo, fence=fence)
+                self.update()
+            return
+        self._check_encoder()
+        N.check(N.lib().sfx_ring_pipe_frames(self.ring, C.c_void_p(device_ptr), stride, count, self.frame % self.slots, -1 if fence is None else fence, self.fileno))
+        self.frame += count
+
     # finish ---------------------------------------------------------------------------------------------------------
 
     def finish(self):

@@ -238,9 +238,7 @@ class FrameTape:
         batches = shard_batches(0, total, self.batch)
 
         def emit_frames(pointer: int, count: int, fence: Optional[int] = None) -> None:
-            for i in range(count):
-                export.pipe_device(pointer + i*frame_bytes, turbo=turbo, fence=fence)
-                export.update()
+            export.pipe_device_frames(pointer, frame_bytes, count, turbo=turbo, fence=fence)
 
         try:
             if world == 1:
