@@ -232,3 +232,13 @@ def test_product_never_imports_the_oracle():
         if path.suffix in (".py", ".hpp", ".hip", ".h") and path.is_file():
             text = path.read_text()
             assert "oracle" not in text.replace("parity oracle", "").replace("CPU oracle", "").replace("the oracle", ""), path
+
+
+def test_written_out_freewheel_clock_equals_the_scheduler_task():
+    """scheduler.freewheel_clock writes SchedulerTask.next's float64 operations out (no object per frame) and keeps the longest
+    sequence per rate: bit-identical to stepping a real SchedulerTask, for prefixes and for rates whose period is not a binary fraction"""
+    from shaderflow_amd.scheduler import freewheel_clock, freewheel_clock_by_task
+    for fps, frames, speed in ((60.0, 3600, 1.0), (60.0, 100, 1.0), (30, 777, 1.0), (59.94, 2000, 0.5), (24, 100, 2.0), (144.0, 1500, 1.0), (60.0, 4000, 1.0)):
+        want = freewheel_clock_by_task(fps, frames, speed)
+        got = freewheel_clock(fps, frames, speed)
+        assert all(list(g) == list(w) for g, w in zip(got, want)), (fps, frames, speed)
