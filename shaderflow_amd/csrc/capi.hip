@@ -1153,7 +1153,9 @@ struct Ring : Object {
     int slots;
     std::vector<void*> host;
     std::vector<hipEvent_t> copied;
-    hipStream_t copy_stream;
+    hipStream_t copy_streams[2] = {nullptr, nullptr};              // frames alternate between two copy streams: 55 instead of 51.5 GB/s (tools/ubench_d2h.hip)
+    int copy_stream_count = 2;
+    hipStream_t copy_stream_of(int slot) const { return copy_streams[copy_stream_count > 1 ? (slot & 1) : 0]; }
     hipEvent_t produced;
     hipEvent_t fences[2];
     // writer
@@ -1200,7 +1202,8 @@ extern "C" int sfx_ring_create(sfx_handle h, size_t frame_bytes, int slots, sfx_
     Ring* r = new Ring();
     r->magic = MAGIC_RING; r->ctx = c; r->frame_bytes = frame_bytes; r->slots = slots;
     r->host.resize(slots); r->copied.resize(slots); r->pending.assign(slots, 0);
-    HIP_TRY(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking));
+    if (const char* n = getenv("SHADERFLOW_COPY_STREAMS")) r->copy_stream_count = atoi(n) == 1 ? 1 : 2;   // A/B switch for measurements
+    for (int k = 0; k < r->copy_stream_count; k++) HIP_TRY(hipStreamCreateWithFlags(&r->copy_streams[k], hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&r->produced, hipEventDisableTiming));
     for (auto& f : r->fences) HIP_TRY(hipEventCreateWithFlags(&f, hipEventDisableTiming));
     for (int k = 0; k < slots; k++) {
@@ -1225,9 +1228,9 @@ extern "C" int sfx_ring_read_device_async(sfx_handle h, const void* dptr, int sl
     int rc = ring_wait_slot(r, slot);                               // turbopipe.sync(buffer) before reuse
     if (rc) return rc;
     HIP_TRY(hipEventRecord(r->produced, r->ctx->stream));           // the frame is complete on the render stream…
-    HIP_TRY(hipStreamWaitEvent(r->copy_stream, r->produced, 0));    // …before the copy engine reads it
-    HIP_TRY(hipMemcpyAsync(r->host[slot], dptr, r->frame_bytes, hipMemcpyDeviceToHost, r->copy_stream));
-    HIP_TRY(hipEventRecord(r->copied[slot], r->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(r->copy_stream_of(slot), r->produced, 0));    // …before the copy engine reads it
+    HIP_TRY(hipMemcpyAsync(r->host[slot], dptr, r->frame_bytes, hipMemcpyDeviceToHost, r->copy_stream_of(slot)));
+    HIP_TRY(hipEventRecord(r->copied[slot], r->copy_stream_of(slot)));
     return SFX_OK;
 }
 
@@ -1245,9 +1248,9 @@ extern "C" int sfx_ring_read_fenced_async(sfx_handle h, const void* dptr, int sl
     USE_DEVICE(r->ctx);
     int rc = ring_wait_slot(r, slot);
     if (rc) return rc;
-    HIP_TRY(hipStreamWaitEvent(r->copy_stream, r->fences[which], 0));
-    HIP_TRY(hipMemcpyAsync(r->host[slot], dptr, r->frame_bytes, hipMemcpyDeviceToHost, r->copy_stream));
-    HIP_TRY(hipEventRecord(r->copied[slot], r->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(r->copy_stream_of(slot), r->fences[which], 0));
+    HIP_TRY(hipMemcpyAsync(r->host[slot], dptr, r->frame_bytes, hipMemcpyDeviceToHost, r->copy_stream_of(slot)));
+    HIP_TRY(hipEventRecord(r->copied[slot], r->copy_stream_of(slot)));
     return SFX_OK;
 }
 
@@ -1317,11 +1320,11 @@ extern "C" int sfx_ring_destroy(sfx_handle h) {
     r->wake.notify_all();
     if (r->writer.joinable()) r->writer.join();
     hipSetDevice(r->ctx->device);
-    hipStreamSynchronize(r->copy_stream);
+    for (int k = 0; k < r->copy_stream_count; k++) hipStreamSynchronize(r->copy_streams[k]);
     for (int k = 0; k < r->slots; k++) { hipHostFree(r->host[k]); hipEventDestroy(r->copied[k]); }
     hipEventDestroy(r->produced);
     for (auto& f : r->fences) hipEventDestroy(f);
-    hipStreamDestroy(r->copy_stream);
+    for (int k = 0; k < r->copy_stream_count; k++) hipStreamDestroy(r->copy_streams[k]);
     r->magic = 0;
     delete r;
     return SFX_OK;
