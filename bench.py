@@ -59,7 +59,8 @@ def parse_args():
     p.add_argument("--ssaa", type=int, default=2)
     p.add_argument("--frames-per-step", type=int, default=60)
     p.add_argument("--seconds", type=float, default=60.0, help="length of the synthetic clip (grown when the ranks need more frames)")
-    p.add_argument("--scene", choices=("visualizer", "bars"), default="visualizer", help="visualizer = the metric's scene; bars = MusicBars (a light fragment)")
+    p.add_argument("--scene", choices=("visualizer", "bars", "waveform", "basic"), default="visualizer",
+                   help="visualizer = the metric's scene; bars = MusicBars, waveform = Waveform, basic = Basic (default.glsl): light fragments")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-export", action="store_true", help="skip the host-inclusive export measurement")
     p.add_argument("--cpu-seconds", type=float, default=18.0, help="budget of the CPU baseline (all cores + one thread)")
@@ -168,7 +169,7 @@ def main() -> None:
         else:
             dist.init_process_group(backend)
 
-    from examples.scenes import MusicBars, Visualizer, make
+    from examples.scenes import Basic, MusicBars, Visualizer, Waveform, make
     from shaderflow_amd import _native as N
     from shaderflow_amd import synth
     from shaderflow_amd.message import ShaderMessage
@@ -180,7 +181,7 @@ def main() -> None:
     seconds = max(args.seconds, world*frames_per_rank/60.0)       # every rank gets its own contiguous range of the clip
     pcm = synth.sweep_clip(seconds, 44100)
     background = synth.background_image(1920, 1080, seed=0)
-    scene_class = Visualizer if args.scene == "visualizer" else MusicBars
+    scene_class = {"visualizer": Visualizer, "bars": MusicBars, "waveform": Waveform, "basic": Basic}[args.scene]
 
     # the CPU baseline first: the timed region (and the driver's GPU sampler) comes after it
     baseline = None
@@ -195,7 +196,7 @@ def main() -> None:
     context = N.Context(local_rank, render_stream.cuda_stream)
 
     def build_scene(prepared: bool = True):
-        scene = make(scene_class, audio=(pcm, 44100), background=(background if args.scene == "visualizer" else None), context=context)
+        scene = make(scene_class, audio=(None if args.scene == "basic" else (pcm, 44100)), background=(background if args.scene == "visualizer" else None), context=context)
         if not prepared:
             return scene                                          # scene.main() does the rest itself
         scene.initialize()

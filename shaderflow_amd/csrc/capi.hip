@@ -882,6 +882,7 @@ template <int KIND> static int launch_separable(const RenderArgs& a, int ssaa, i
     Context* ctx = g_launch_ctx;
     if (!ctx || ssaa != 2) return 0;
     if (getenv("SHADERFLOW_SEPARABLE") && atoi(getenv("SHADERFLOW_SEPARABLE")) == 0) return 0;        // A/B switch for measurements
+    if (KIND == SEP_DEFAULT && !a.identity_camera) return 0;             // default.glsl reads iCamera.gluv: separable under the identity camera only
     if (KIND == SEP_BARS) {
         // a one-column spectrogram picked with nearest filtering: the look-up is a function of the sample column alone
         const Tex& sp = a.tex[TEX_SPECTROGRAM];
@@ -898,7 +899,7 @@ template <int KIND> static int launch_separable(const RenderArgs& a, int ssaa, i
     t.columns = (float4*)ctx->vis_tables;
     t.rows = t.columns + (size_t)frames*a.wr;
     hipLaunchKernelGGL(k_separable_axis<KIND>, dim3((a.wr + a.hr + 255)/256, frames), dim3(256), 0, s, a, t);
-    g_last_kernel = std::string("k_separable_fused<") + (KIND == SEP_BARS ? "bars" : "waveform") + ">";
+    g_last_kernel = std::string("k_separable_fused<") + (KIND == SEP_BARS ? "bars" : (KIND == SEP_WAVEFORM ? "waveform" : "default")) + ">";
     hipLaunchKernelGGL(k_separable_fused<KIND>, dim3((a.w + SEP_PIXELS - 1)/SEP_PIXELS, (a.h + SEP_ROWS - 1)/SEP_ROWS, frames), dim3(SEP_PIXELS), 0, s, a, t);
     return 1;
 }
@@ -936,7 +937,12 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
 #endif
                              ) {
     switch (fragment) {
-        case FRAG_DEFAULT: return launch_fused_s<PlainShader<FRAG_DEFAULT>>(a, ssaa, frames, s);
+        case FRAG_DEFAULT:
+            if (!force_generic) {
+                const int fast = launch_separable<SEP_DEFAULT>(a, ssaa, frames, s);
+                if (fast != 0) return fast < 0 ? fast : SFX_OK;
+            }
+            return launch_fused_s<PlainShader<FRAG_DEFAULT>>(a, ssaa, frames, s);
         case FRAG_MISSING: return launch_fused_s<PlainShader<FRAG_MISSING>>(a, ssaa, frames, s);
         case FRAG_VISUALIZER:
             if (!force_generic) {

@@ -10,13 +10,21 @@
 // RGBA8 quantisation and final.glsl's resolve. One thread per OUTPUT pixel shades its 2 x 2 supersamples from two column and
 // two row entries and walks SEP_ROWS rows with the column entries in registers; rows leave through LDS as 16-byte stores.
 // What bounds it then is issue of the resolve arithmetic and the HBM write of the RGB8 frame (24.9 MB at 4K).
+//
+// default.glsl (resources/shaders/fragment/default.glsl:1-48, the fragment of a scene that sets none) is two-dimensional — a hue
+// wheel by polar angle, a ring by radius — but under the identity camera its coordinate work is not: gluv.x, the checkerboard's
+// floor(uv.x*4), log2(astuv.x(1-astuv.x)) of the vignette (which factorises like the visualizer's) and `out of bounds` per column,
+// the same per row. None of its two-dimensional terms decides anything a viewer could see — the hue is continuous in the angle,
+// and the one branch on the radius (`circle < 0`) flips where the ring's 1/circle^2 glow has long saturated the pixel — so they
+// use v_rcp/v_sqrt/v_log/v_exp and the arctangent polynomial without the IEEE divisions: within 1 LSB of the generic chain like
+// every fused kernel (tests/test_gpu_pixels.py), at a third of its instructions.
 #pragma once
 
 #include "render_kernels.hpp"
 
 namespace sf {
 
-enum : int { SEP_BARS = 0, SEP_WAVEFORM = 1 };
+enum : int { SEP_BARS = 0, SEP_WAVEFORM = 1, SEP_DEFAULT = 2 };
 constexpr int SEP_ROWS = 4, SEP_PIXELS = 256;
 
 struct SepTables {
@@ -49,6 +57,10 @@ __global__ __launch_bounds__(256) void k_separable_axis(const RenderArgs a, cons
         } else {
             e = make_float4(as, 1.0f - as, 0.0f, 0.0f);
         }
+    } else if (KIND == SEP_DEFAULT) {
+        // { gluv, parity of floor(uv*grid/2) (default.glsl:4-8, grid = 8), log2(astuv*(1 - astuv)) (:41-43), out of bounds (camera.glsl:83) }
+        const int parity = (int)::floorf(g*8.0f/2.0f) & 1;
+        e = make_float4(g, __int_as_float(parity), __builtin_amdgcn_logf(as*(1.0f - as)), __int_as_float((column && sf::abs(g) > u.iWantAspect) ? 1 : 0));
     } else {
         if (column) {
             const vec2 w = texture_xy(tex[TEX_WAVEFORM], vec2{as, 0.0f});                                          // waveform.frag:6
@@ -58,6 +70,40 @@ __global__ __launch_bounds__(256) void k_separable_axis(const RenderArgs a, cons
         }
     }
     (column ? t.columns + (long)frame*a.wr : t.rows + (long)frame*a.hr)[index] = e;
+}
+
+// default.glsl:10-47 for one sample from its column and row entries; `hue_shift` = 2*TAU*iTau - PI/4 (:22), per frame
+__device__ __forceinline__ uint32_t default_texel(const float4 c, const float4 r, float hue_shift) {
+    const float ux = c.x, uy = r.x;
+    // :19 atan2(uv) in [0, 2 pi): sfmath.hpp's polynomial on min/max with hardware reciprocals (the hue is continuous in it)
+    const float ax = sf::abs(ux), ay = sf::abs(uy);
+    const float hi = __builtin_fmaxf(ax, ay), lo = __builtin_fminf(ax, ay);
+    const float t = (hi == 0.0f) ? 0.0f : lo*__builtin_amdgcn_rcpf(hi);
+    const bool upper = t > 0x1.a8279ap-2f;
+    const float u = upper ? (t - 1.0f)*__builtin_amdgcn_rcpf(t + 1.0f) : t;
+    const float z = u*u;
+    float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = fmaf(p, z, 1.99777106478e-1f);
+    p = fmaf(p, z, -3.33329491539e-1f);
+    float angle = (upper ? QUARTER_PI : 0.0f) + fmaf(p*z, u, u);
+    if (ay > ax) angle = HALF_PI - angle;
+    if (ux < 0.0f) angle = PI - angle;
+    if (uy < 0.0f) angle = TAU - angle;
+    // :22 hsv2rgb(angle + shift, 1, 1) + 0.3: the hue wheel in its continuous form
+    float h = angle + hue_shift;
+    h = h - TAU*::floorf(h*(1.0f/TAU));
+    const float k = h*(3.0f/PI);
+    const float red = clamp01(sf::abs(k - 3.0f) - 1.0f), green = clamp01(2.0f - sf::abs(k - 2.0f)), blue = clamp01(2.0f - sf::abs(k - 4.0f));
+    // :25-26 the ring
+    const float circle = fmaf(1.333f, __builtin_amdgcn_sqrtf(ux*ux + uy*uy), -1.0f);
+    const float width = 2.0e-4f*sf::abs(__builtin_amdgcn_rcpf(circle*circle));
+    // :29-33 the disc or the checkerboard
+    const float base = (circle < 0.0f) ? 0.18f : (((__float_as_int(c.y) ^ __float_as_int(r.y)) & 1) ? 0.22f : 0.20f);
+    // :41-43 vignette: pow(50*ax(1-ax)*ay(1-ay), 0.1) clamped
+    const float vignette = clamp01(__builtin_amdgcn_exp2f(0.1f*((c.z + r.z) + 5.643856190f)));
+    vec3 col = {fmaf(width, 0.3f + red, base)*vignette, fmaf(width, 0.3f + green, base)*vignette, fmaf(width, 0.3f + blue, base)*vignette};
+    if (__float_as_int(c.w) != 0) col = vec3{0.15f, 0.15f, 0.15f};                               // :14-16
+    return pack_rgb8(col);
 }
 
 template <int KIND> __device__ __forceinline__ uint32_t separable_texel(const float4 c, const float4 r) {
@@ -86,13 +132,22 @@ __global__ __launch_bounds__(SEP_PIXELS) void k_separable_fused(const RenderArgs
     const float4* rows = t.rows + (long)frame*a.hr;
     const int i0 = (2*px < a.wr) ? 2*px : a.wr - 1, i1 = (2*px + 1 < a.wr) ? 2*px + 1 : a.wr - 1;
     const float4 c0 = columns[i0], c1 = columns[i1];
+    const float tau = a.dyn ? a.dyn[a.frame0 + frame].iTau : a.u.iTau;
+    const float hue_shift = (2.0f*TAU*tau) - (PI/4.0f);               // default.glsl:22, the generic chain's operations
+    (void)hue_shift;
 #pragma unroll
     for (int r = 0; r < SEP_ROWS; r++) {
         const int py = blockIdx.y*SEP_ROWS + r;
         if (py >= a.h) break;
         const float4 r0 = rows[2*py], r1 = rows[2*py + 1];            // block-uniform: scalar loads
-        const uint32_t block[4] = {separable_texel<KIND>(c0, r0), separable_texel<KIND>(c1, r0),
-                                   separable_texel<KIND>(c0, r1), separable_texel<KIND>(c1, r1)};      // texel order y*2 + x (render_kernels.hpp)
+        uint32_t block[4];                                             // texel order y*2 + x (render_kernels.hpp)
+        if constexpr (KIND == SEP_DEFAULT) {
+            block[0] = default_texel(c0, r0, hue_shift); block[1] = default_texel(c1, r0, hue_shift);
+            block[2] = default_texel(c0, r1, hue_shift); block[3] = default_texel(c1, r1, hue_shift);
+        } else {
+            block[0] = separable_texel<KIND>(c0, r0); block[1] = separable_texel<KIND>(c1, r0);
+            block[2] = separable_texel<KIND>(c0, r1); block[3] = separable_texel<KIND>(c1, r1);
+        }
         uint8_t* s = &staged[r][tid*3];
         s[0] = (uint8_t)resolve_channel_any<2>(block, a.subsample, 0);
         s[1] = (uint8_t)resolve_channel_any<2>(block, a.subsample, 8);

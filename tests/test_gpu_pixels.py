@@ -220,6 +220,24 @@ def test_fused_render_resolve_within_one_lsb(gpu, name, ssaa, subsample):
     assert_within_lsb(got, want)
 
 
+@pytest.mark.parametrize("w,h,tau", [(136, 40, 0.0), (75, 75, 0.31), (301, 169, 0.77), (640, 360, 0.5)])
+def test_default_fragment_separable_kernel_within_one_lsb(gpu, w, h, tau):
+    """default.glsl at 2x SSAA under the identity camera runs k_separable_fused<default> (per-column / per-row tables, hardware
+    reciprocals and logarithms for its colour-only polar terms): whole frames against the oracle, odd sizes included (a sample lands
+    on gluv = (0, 0)), several iTau (the hue shift), both final.glsl kernels the fused path serves"""
+    u, arrays, params = visualizer_inputs(w, h, seed=3)
+    u.iSSAA = 2.0
+    u.iTau = tau
+    prog, _ = gpu.program("default")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    screen = O.render("default", u, oracle_textures(arrays, params), w*2, h*2, threads=8)
+    for subsample in (2, 1):
+        got = gpu.render_resolve(prog, w, h, 2, subsample)
+        assert _last_kernel(gpu) == "k_separable_fused<default>", _last_kernel(gpu)
+        assert_within_lsb(got, O.resolve(screen, w, h, subsample))
+
+
 def test_fused_matches_two_pass_on_device(gpu):
     """Same device, same inputs: sfx_render + sfx_resolve vs sfx_render_resolve"""
     from shaderflow_amd import _native as N

@@ -38,6 +38,8 @@ print()
 PY
 }
 run bars_c3 --scene bars
+run waveform_c3 --scene waveform
+run basic_c3 --scene basic
 run bars_1080p --scene bars --width 1920 --height 1080 --ssaa 2
 run visualizer_c2 --width 1920 --height 1080 --ssaa 1
 run visualizer_c1 --width 256 --height 256 --ssaa 1
