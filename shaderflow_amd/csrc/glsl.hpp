@@ -60,13 +60,12 @@ SF_HD int wrap_texel(int i, int size, int repeat) {
     return (i < 0) ? 0 : ((i >= size) ? size - 1 : i);
 }
 
-// c/255.0f for an integer-valued 0 <= c <= 255 without the IEEE division sequence: one Newton correction of
-// c*RN(1/255) is the correctly rounded quotient for EVERY finite float (exhaustive: tools/check_divconst.c), so the
-// result is bit-identical to `c/255.0f` (the parity oracle writes the division).
+// c/255.0f for an integer-valued 0 <= c <= 255 (a texel byte) without the IEEE division sequence: 1/255 split into its float
+// and the float of the remainder, c*hi + c*lo with ONE rounding of the sum — the correctly rounded quotient for all 256 bytes
+// (tools/check_unorm8.py does the exact rational arithmetic), so the result is bit-identical to `c/255.0f` (the parity oracle
+// writes the division). Two operations per component; every RGBA8 tap of the generic sampler converts sixteen of them.
 SF_HD float unorm8_to_float(float c) {
-    const float r = 1.0f/255.0f;
-    const float q = c*r;
-    return fmaf(fmaf(-q, 255.0f, c), r, q);
+    return fmaf(c, 0x1.010102p-8f, c*-0x1.fdfdfep-33f);
 }
 
 SF_HD vec4 texel(const Tex& t, int i, int j) {
