@@ -79,6 +79,14 @@ SF_HD vec4 texel(const Tex& t, int i, int j) {
         c.y = unorm8_to_float((float)((w >> 8) & 255u));
         c.z = unorm8_to_float((float)((w >> 16) & 255u));
         c.w = unorm8_to_float((float)(w >> 24));
+#if defined(__HIP_DEVICE_COMPILE__)
+    } else if (t.dtype == DT_U8 && n == 3) {                          // RGB8 (backgrounds, video frames): one unaligned 32-bit load, the fourth byte ignored
+        typedef uint32_t unaligned_u32 __attribute__((aligned(1)));  // (device allocations are padded: the last texel's extra byte exists)
+        const uint32_t w = *(const unaligned_u32*)((const uint8_t*)t.data + base);
+        c.x = unorm8_to_float((float)(w & 255u));
+        c.y = unorm8_to_float((float)((w >> 8) & 255u));
+        c.z = unorm8_to_float((float)((w >> 16) & 255u));
+#endif
     } else if (t.dtype == DT_U8) {
         const uint8_t* p = (const uint8_t*)t.data + base;
         c.x = unorm8_to_float((float)p[0]);
