@@ -71,10 +71,11 @@ SF_HD float unorm8_to_float(float c) {
 SF_HD vec4 texel(const Tex& t, int i, int j) {
     // written without a local array: a dynamically indexed float[4] would be promoted to LDS
     vec4 c = {0.0f, 0.0f, 0.0f, 1.0f};
-    const long base = ((long)j*t.width + i)*t.components;
+    const uint32_t index = (uint32_t)j*(uint32_t)t.width + (uint32_t)i;      // texel index: 0 <= i < width, 0 <= j < height (callers wrap first); < 2^32 texels
     const int n = t.components;
+    const size_t base = (size_t)index*(size_t)n;
     if (t.dtype == DT_U8 && n == 4) {                              // RGBA8 (iScreen, history textures): one aligned 32-bit load
-        const uint32_t w = ((const uint32_t*)t.data)[(long)j*t.width + i];
+        const uint32_t w = ((const uint32_t*)t.data)[index];
         c.x = unorm8_to_float((float)(w & 255u));
         c.y = unorm8_to_float((float)((w >> 8) & 255u));
         c.z = unorm8_to_float((float)((w >> 16) & 255u));
