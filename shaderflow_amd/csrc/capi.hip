@@ -535,6 +535,7 @@ static void fill_args(const Program* p, RenderArgs& a) {
     a.vis_consts = nullptr;
     a.aspect = p->u.iResolution[0]/p->u.iResolution[1];
     a.identity_camera = camera_is_identity(p->u) ? 1 : 0;
+    a.axis_camera = camera_is_axis_aligned(p->u) ? 1 : 0;
     a.bg_scale_x = a.tex[TEX_BACKGROUND].data ? (float)a.tex[TEX_BACKGROUND].height/(float)a.tex[TEX_BACKGROUND].width : 1.0f;
     a.top_down = p->ctx->top_down;
 }
@@ -620,10 +621,20 @@ static void visualizer_window_bound(const RenderArgs& a, int sx, int sy, int& tw
     const float zoom2 = a.has_vis ? a.vis.zoom2 : 0.93f*0.93f;
     const float intensity = a.has_vis ? fabsf(a.vis.intensity) : 0.003f;
     float density = zoom2*(float)bg.height/(float)a.hr;
-    if (!a.identity_camera) density *= 2.0f*fmaxf(1.0f, fabsf(a.u.iCameraZoom));
+    float density_x = density, density_y = density;
+    if (a.axis_camera && !a.identity_camera) {
+        // a zoomed / panned camera: iCamera.gluv is an affine function of gluv per axis (glsl.hpp camera_along_axis): its slopes
+        bool behind = false;
+        const float sx_ = (camera_along_axis<0>(a.u, 1.0f, a.aspect, behind) - camera_along_axis<0>(a.u, -1.0f, a.aspect, behind))/2.0f;
+        const float sy_ = (camera_along_axis<1>(a.u, 1.0f, a.aspect, behind) - camera_along_axis<1>(a.u, -1.0f, a.aspect, behind))/2.0f;
+        density_x *= fabsf(sx_)*1.001f; density_y *= fabsf(sy_)*1.001f;
+        if (!(density_x == density_x) || !(density_y == density_y)) { density_x = density_y = 1e9f; }
+    } else if (!a.identity_camera) {
+        density_x = density_y = density*2.0f*fmaxf(1.0f, fabsf(a.u.iCameraZoom));
+    }
     const float rx = intensity*a.bg_scale_x*(float)bg.width*1.101f + 0.001f, ry = intensity*(float)bg.height*1.101f + 0.001f;
-    tw = (int)floorf((float)(sx - 1)*density + 2.0f*rx) + 2;
-    th = (int)floorf((float)(sy - 1)*density + 2.0f*ry) + 2;
+    tw = (int)floorf(fminf((float)(sx - 1)*density_x + 2.0f*rx, 1e6f)) + 2;
+    th = (int)floorf(fminf((float)(sy - 1)*density_y + 2.0f*ry, 1e6f)) + 2;
 }
 static const size_t VIS_LDS_LIMIT = 150*1024;                         // leave room for the static shared state of the kernels
 
@@ -772,7 +783,7 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
     Context* ctx = g_launch_ctx;
     // fused: 2x or 4x SSAA into the RGB8 frame; to_screen: the samples themselves into an RGBA8 iScreen (the two-pass configuration)
     if (to_screen ? (ssaa != 1 || a0.out_dtype != DT_U8 || a0.out_components != 4) : (ssaa != 2 && ssaa != 4)) return 0;
-    if (!VIS_FAST || !ctx || !a0.identity_camera || !visualizer_tile_applicable(a0.tex[TEX_BACKGROUND])) return 0;
+    if (!VIS_FAST || !ctx || !(a0.identity_camera || a0.axis_camera) || !visualizer_tile_applicable(a0.tex[TEX_BACKGROUND])) return 0;
     const char* toggle = getenv("SHADERFLOW_VIS_FAST");              // A/B switch for measurements: 0 = round 1's kernels, 1 = k_visualizer_fast
     if (toggle && atoi(toggle) == 0) return 0;
     const Tex& bg = a0.tex[TEX_BACKGROUND];

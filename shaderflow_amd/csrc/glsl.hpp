@@ -352,6 +352,16 @@ SF_HD bool camera_is_identity(const Uniforms& u) {
         && u.iCameraOrbital == 0.0f && u.iCameraDolly == 0.0f;
 }
 
+// A perspective camera whose basis is the untouched one (right = x, up = y, forward = z — any position, zoom, isometric factor,
+// focal length, orbital and dolly distance): every product of the ray construction that mixes the two screen coordinates is a
+// product with an exact 0, so iCamera.gluv.x is a function of gluv.x alone and iCamera.gluv.y of gluv.y alone (up to the sign of a
+// zero), and `t` of CameraRay2D is the same for every fragment. camera_along_axis() evaluates get_camera for one coordinate.
+SF_HD bool camera_is_axis_aligned(const Uniforms& u) {
+    return u.iCameraProjection == 0
+        && u.iCameraRight[0] == 1.0f && u.iCameraRight[1] == 0.0f && u.iCameraRight[2] == 0.0f
+        && u.iCameraUpward[0] == 0.0f && u.iCameraUpward[1] == 1.0f && u.iCameraUpward[2] == 0.0f
+        && u.iCameraForward[0] == 0.0f && u.iCameraForward[1] == 0.0f && u.iCameraForward[2] == 1.0f;
+}
 SF_HD Camera get_camera(const Frag& f) {                           // GetCamera :132-155 → CameraProject :93-130
     const Uniforms& u = *f.u;
     Camera c;
@@ -401,6 +411,20 @@ SF_HD Camera get_camera(const Frag& f) {                           // GetCamera 
     c.stxy = res*c.astuv;
     c.glxy = c.stxy - res/2.0f;
     return c;
+}
+
+// iCamera.gluv's component along AXIS (0: x, 1: y) of the fragments whose gluv component along that axis is `g`, and whether the
+// camera's plane lies behind it (t < 0, the same for all fragments) — for camera_is_axis_aligned() cameras
+template <int AXIS> SF_HD float camera_along_axis(const Uniforms& u, float g, float aspect, bool& behind) {
+    Frag f{};
+    f.u = &u; f.aspect = aspect;
+    f.gluv = AXIS == 0 ? vec2{g, 0.0f} : vec2{0.0f, g};
+    f.agluv = f.gluv/vec2{aspect, 1.0f};
+    const Camera c = get_camera(f);
+    // get_camera's out_of_bounds is (t < 0) || |gluv.x| > iWantAspect: with gluv.x = 0 it is the first term alone
+    Frag probe = f; probe.gluv = vec2{0.0f, 0.0f}; probe.agluv = vec2{0.0f, 0.0f};
+    behind = get_camera(probe).out_of_bounds;
+    return AXIS == 0 ? c.gluv.x : c.gluv.y;
 }
 
 }  // namespace sf

@@ -40,6 +40,7 @@ struct RenderArgs {
     VisualizerConsts vis;
     int has_vis;
     int identity_camera;             // glsl.hpp camera_is_identity(u): iCamera.gluv == gluv exactly
+    int axis_camera;                 // glsl.hpp camera_is_axis_aligned(u): iCamera.gluv.x is a function of gluv.x alone, .y of gluv.y (zoom, pan, dolly: no rotation)
     float aspect;                    // iResolution.x/iResolution.y (iAspectRatio, shaderflow.glsl:16), divided once on the host
     float bg_scale_x;                // background.height/background.width (gtexture, shaderflow.glsl:166-167), divided once on the host
     int tile_pitch, tile_rows;       // geometry of the LDS tile when it is a launch parameter (VisualizerShader<0, …>)
@@ -62,7 +63,7 @@ constexpr unsigned long long render_args_layout() {
     SF_LAYOUT_MEMBER(out_frame_stride); SF_LAYOUT_MEMBER(dyn); SF_LAYOUT_MEMBER(tape_spectrogram); SF_LAYOUT_MEMBER(spectrogram_stride);
     SF_LAYOUT_MEMBER(tape_bars); SF_LAYOUT_MEMBER(tape_waveform); SF_LAYOUT_MEMBER(waveform_stride); SF_LAYOUT_MEMBER(frame0);
     SF_LAYOUT_MEMBER(tap_x); SF_LAYOUT_MEMBER(tap_y); SF_LAYOUT_MEMBER(vis_consts); SF_LAYOUT_MEMBER(vis); SF_LAYOUT_MEMBER(has_vis);
-    SF_LAYOUT_MEMBER(identity_camera); SF_LAYOUT_MEMBER(aspect); SF_LAYOUT_MEMBER(bg_scale_x); SF_LAYOUT_MEMBER(tile_pitch);
+    SF_LAYOUT_MEMBER(identity_camera); SF_LAYOUT_MEMBER(axis_camera); SF_LAYOUT_MEMBER(aspect); SF_LAYOUT_MEMBER(bg_scale_x); SF_LAYOUT_MEMBER(tile_pitch);
     SF_LAYOUT_MEMBER(tile_rows); SF_LAYOUT_MEMBER(top_down); SF_LAYOUT_MEMBER(inv_wr); SF_LAYOUT_MEMBER(inv_hr);
 #undef SF_LAYOUT_MEMBER
     h = layout_mix(h, sizeof(RenderArgs)); h = layout_mix(h, sizeof(Uniforms)); h = layout_mix(h, sizeof(Tex));

@@ -63,24 +63,28 @@ __global__ __launch_bounds__(128) void k_visualizer_axis(const RenderArgs a, con
 
     // vertex/default.glsl:1-17 and visualizer.frag:17-18 for ONE coordinate: the operations of make_varyings / visualizer_pre /
     // VisualizerShader::pre in the same order
-    auto centre_tap = [&](int index, float& ag, float& g, float& as) {
+    // `g` is the fragment's own gluv component (the strips of :72-73 and `out of bounds` use it), `uv` iCamera.gluv's: the same
+    // under the identity camera, get_camera along this axis for a zoomed / panned one (glsl.hpp camera_is_axis_aligned)
+    bool behind = false;
+    auto centre_tap = [&](int index, float& ag, float& g, float& as, float& uv) {
         const float centre = ((float)index + 0.5f)/(float)n;
         ag = centre*2.0f - 1.0f;
         g = ag*aspect;
         as = (ag + 1.0f)/2.0f;
-        const float bgc = (((g + 1.0f)/2.0f) - 0.5f)*c.zoom2 + 0.5f + offset;        // zoom(gluv2stuv(uv), z, 0.5) + offset
+        uv = a.identity_camera ? g : camera_along_axis<AXIS>(u, g, a.aspect, behind);
+        const float bgc = (((uv + 1.0f)/2.0f) - 0.5f)*c.zoom2 + 0.5f + offset;       // zoom(gluv2stuv(uv), z, 0.5) + offset
         const float st = ((((bgc*2.0f) - 1.0f)*scale) + 1.0f)/2.0f;                    // gluv2stuv(stuv2gluv(bg)*scale)
         return st*size - 0.5f;
     };
-    float ag, g, as;
-    const float centre = centre_tap(k, ag, g, as);
+    float ag, g, as, uv;
+    const float centre = centre_tap(k, ag, g, as, uv);
 
     // the window of the block this column/row belongs to: VisualizerShader::setup 1a (two corner samples bound all of them)
     const int per_block = AXIS == 0 ? t.block_columns : t.block_rows;
     const int block = k / per_block;
     const int first_index = block*per_block, last_index = min(first_index + per_block, n) - 1;
-    float dummy0, dummy1, dummy2;
-    const float c_first = centre_tap(first_index, dummy0, dummy1, dummy2), c_last = centre_tap(last_index, dummy0, dummy1, dummy2);
+    float dummy0, dummy1, dummy2, dummy3;
+    const float c_first = centre_tap(first_index, dummy0, dummy1, dummy2, dummy3), c_last = centre_tap(last_index, dummy0, dummy1, dummy2, dummy3);
     const float lo = fminf(c_first, c_last), hi = fmaxf(c_first, c_last);
     const float texels = fabsf(c.intensity*scale*size);               // blur radius in texels (glsl.hpp gtexture)
     const float reach = texels*1.101f + 0.001f;
@@ -129,12 +133,12 @@ __global__ __launch_bounds__(128) void k_visualizer_axis(const RenderArgs a, con
     e[0] = make_float4(r, frac_r, __int_as_float((int)cell_r*cell_bytes), __int_as_float(start*cell_bytes));
     if (AXIS == 0) {
         // rotate2d(-PI/2)*uv (visualizer.frag:39): x' = rot_c*x + rot_s*y, y' = (-rot_s)*x + rot_c*y — the products of x
-        e[1] = make_float4(c.rot_c*g, (-c.rot_s)*g, g*g, ag*ag);
+        e[1] = make_float4(c.rot_c*uv, (-c.rot_s)*uv, uv*uv, ag*ag);
         const Tex& wave = tex[TEX_WAVEFORM];
         const vec2 w = texture_xy(wave, vec2{as, 0.0f});                                       // :71
-        e[2] = make_float4(__builtin_amdgcn_logf(as*(1.0f - as)), 0.2f*w.x, 0.2f*w.y, __int_as_float((sf::abs(g) > u.iWantAspect) ? 1 : 0));
+        e[2] = make_float4(__builtin_amdgcn_logf(as*(1.0f - as)), 0.2f*w.x, 0.2f*w.y, __int_as_float((behind || sf::abs(g) > u.iWantAspect) ? 1 : 0));   // camera.glsl:83
     } else {
-        e[1] = make_float4(c.rot_s*g, c.rot_c*g, g*g, ag*ag);
+        e[1] = make_float4(c.rot_s*uv, c.rot_c*uv, uv*uv, ag*ag);
         e[2] = make_float4(__builtin_amdgcn_logf(as*(1.0f - as)), 1.0f - g, 1.0f + g, 0.0f);   // :72-73 compare these with the waveform
         if (t.ysteps) {
             // The y half of a diagonal tap — fraction and row of cells of y +- k*s (VisualizerShader::blur_tile's walk) — depends

@@ -180,6 +180,37 @@ def test_visualizer_lds_tile_kernel_with_a_moved_camera(gpu, camera, ssaa):
         assert_within_lsb(gpu.render_resolve(prog, w, h, ssaa, 2), O.resolve(screen, w, h, 2))
 
 
+@pytest.mark.parametrize("camera", [dict(iCameraZoom=0.8), dict(iCameraZoom=1.3, iCameraPosition=(0.11, -0.07, 0.0)),
+                                    dict(iCameraIsometric=0.35, iCameraZoom=0.9), dict(iCameraDolly=0.4, iCameraFocalLength=1.2),
+                                    dict(iCameraPosition=(0.0, 0.0, 1.5))])
+@pytest.mark.parametrize("ssaa", [1, 2, 4])
+def test_strip_kernel_with_a_zoomed_or_panned_camera(gpu, camera, ssaa):
+    """A perspective camera with the untouched basis (zoom, pan, isometric factor, dolly, focal length — no rotation) keeps
+    iCamera.gluv.x a function of the sample column and .y of the row (glsl.hpp camera_is_axis_aligned), so the strip kernel's tables
+    take get_camera per axis: whole frames against the oracle, the strip kernel asserted. The last camera looks at the plane from
+    behind (t < 0): every fragment is out of bounds."""
+    w, h = (640, 360) if ssaa < 4 else (320, 180)
+    u, arrays, params = visualizer_inputs(w, h, seed=29, volume=0.8, bg_size=(384, 216))
+    for key, value in camera.items():
+        cur = getattr(u, key)
+        if hasattr(cur, "__len__"):
+            for i, v in enumerate(value):
+                cur[i] = v
+        else:
+            setattr(u, key, value)
+    u.iSSAA = float(ssaa)
+    screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, threads=8)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    if ssaa == 1:
+        got, want = gpu.render(prog, w, h), screen
+    else:
+        got, want = gpu.render_resolve(prog, w, h, ssaa, 2), O.resolve(screen, w, h, 2)
+    assert _last_kernel(gpu).startswith("k_visualizer_strip<"), _last_kernel(gpu)
+    assert_within_lsb(got, want)
+
+
 @pytest.mark.parametrize("bg_size,ssaa", [((160, 90), 2), ((320, 180), 2), ((640, 360), 2), ((320, 180), 4)])
 def test_visualizer_dense_backgrounds_use_a_tile_sized_per_launch(gpu, bg_size, ssaa):
     """Backgrounds with more texels per shaded sample than the fixed tile holds: dynamic-LDS tile, narrower blocks as needed"""
