@@ -893,7 +893,7 @@ template <int KIND> static int launch_separable(const RenderArgs& a, int ssaa, i
     Context* ctx = g_launch_ctx;
     if (!ctx || ssaa != 2) return 0;
     if (getenv("SHADERFLOW_SEPARABLE") && atoi(getenv("SHADERFLOW_SEPARABLE")) == 0) return 0;        // A/B switch for measurements
-    if (KIND == SEP_DEFAULT && !a.identity_camera) return 0;             // default.glsl reads iCamera.gluv: separable under the identity camera only
+    if (KIND == SEP_DEFAULT && !(a.identity_camera || a.axis_camera)) return 0;   // default.glsl reads iCamera.gluv: separable per axis without a rotation only
     if (KIND == SEP_BARS) {
         // a one-column spectrogram picked with nearest filtering: the look-up is a function of the sample column alone
         const Tex& sp = a.tex[TEX_SPECTROGRAM];

@@ -59,8 +59,11 @@ __global__ __launch_bounds__(256) void k_separable_axis(const RenderArgs a, cons
         }
     } else if (KIND == SEP_DEFAULT) {
         // { gluv, parity of floor(uv*grid/2) (default.glsl:4-8, grid = 8), log2(astuv*(1 - astuv)) (:41-43), out of bounds (camera.glsl:83) }
-        const int parity = (int)::floorf(g*8.0f/2.0f) & 1;
-        e = make_float4(g, __int_as_float(parity), __builtin_amdgcn_logf(as*(1.0f - as)), __int_as_float((column && sf::abs(g) > u.iWantAspect) ? 1 : 0));
+        // iCamera.gluv along this axis: gluv itself under the identity camera, get_camera for one coordinate under a zoomed / panned one
+        bool behind = false;
+        const float uv = a.identity_camera ? g : (column ? camera_along_axis<0>(u, g, a.aspect, behind) : camera_along_axis<1>(u, g, a.aspect, behind));
+        const int parity = (int)::floorf(uv*8.0f/2.0f) & 1;
+        e = make_float4(uv, __int_as_float(parity), __builtin_amdgcn_logf(as*(1.0f - as)), __int_as_float((column && (behind || sf::abs(g) > u.iWantAspect)) ? 1 : 0));
     } else {
         if (column) {
             const vec2 w = texture_xy(tex[TEX_WAVEFORM], vec2{as, 0.0f});                                          // waveform.frag:6

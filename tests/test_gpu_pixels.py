@@ -251,14 +251,22 @@ def test_fused_render_resolve_within_one_lsb(gpu, name, ssaa, subsample):
     assert_within_lsb(got, want)
 
 
+@pytest.mark.parametrize("camera", [dict(), dict(iCameraZoom=1.4, iCameraPosition=(0.2, -0.1, 0.0)), dict(iCameraIsometric=0.3, iCameraDolly=0.5)])
 @pytest.mark.parametrize("w,h,tau", [(136, 40, 0.0), (75, 75, 0.31), (301, 169, 0.77), (640, 360, 0.5)])
-def test_default_fragment_separable_kernel_within_one_lsb(gpu, w, h, tau):
+def test_default_fragment_separable_kernel_within_one_lsb(gpu, w, h, tau, camera):
     """default.glsl at 2x SSAA under the identity camera runs k_separable_fused<default> (per-column / per-row tables, hardware
     reciprocals and logarithms for its colour-only polar terms): whole frames against the oracle, odd sizes included (a sample lands
     on gluv = (0, 0)), several iTau (the hue shift), both final.glsl kernels the fused path serves"""
     u, arrays, params = visualizer_inputs(w, h, seed=3)
     u.iSSAA = 2.0
     u.iTau = tau
+    for key, value in camera.items():                                  # zoomed / panned cameras stay separable per axis
+        cur = getattr(u, key)
+        if hasattr(cur, "__len__"):
+            for i, v in enumerate(value):
+                cur[i] = v
+        else:
+            setattr(u, key, value)
     prog, _ = gpu.program("default")
     gpu.set_uniforms(prog, u)
     gpu_bind_all(gpu, prog, arrays, params)
