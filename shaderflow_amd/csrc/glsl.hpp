@@ -357,7 +357,7 @@ SF_HD bool camera_is_identity(const Uniforms& u) {
 // product with an exact 0, so iCamera.gluv.x is a function of gluv.x alone and iCamera.gluv.y of gluv.y alone (up to the sign of a
 // zero), and `t` of CameraRay2D is the same for every fragment. camera_along_axis() evaluates get_camera for one coordinate.
 SF_HD bool camera_is_axis_aligned(const Uniforms& u) {
-    return u.iCameraProjection == 0
+    return u.iCameraProjection == 0                                // (the stereoscopic projection is separable too, but jumps at the centre column: a block's window is no longer bounded by its corner samples)
         && u.iCameraRight[0] == 1.0f && u.iCameraRight[1] == 0.0f && u.iCameraRight[2] == 0.0f
         && u.iCameraUpward[0] == 0.0f && u.iCameraUpward[1] == 1.0f && u.iCameraUpward[2] == 0.0f
         && u.iCameraForward[0] == 0.0f && u.iCameraForward[1] == 0.0f && u.iCameraForward[2] == 1.0f;
