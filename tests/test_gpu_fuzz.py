@@ -81,6 +81,10 @@ def test_strip_kernel_random_configurations(gpu, seed):
     u, arrays, params = visualizer_inputs(w, h, seed=seed, volume=float(rng.choice([0.0, 0.1, 0.5, 0.9, 1.4, 2.5])), bg_size=bg_size,
                                           time=float(rng.uniform(0, 40)), std=float(rng.uniform(0, 0.6)))
     params["background"] = ("linear", bool(rng.integers(0, 2)), bool(rng.integers(0, 2)))
+    if rng.random() < 0.4:                                           # a zoomed / panned camera (no rotation): still the tables' case
+        u.iCameraZoom = float(rng.uniform(0.6, 1.8)); u.iCameraIsometric = float(rng.uniform(0, 0.4))
+        u.iCameraPosition[0] = float(rng.uniform(-0.2, 0.2)); u.iCameraPosition[1] = float(rng.uniform(-0.2, 0.2))
+        u.iCameraDolly = float(rng.uniform(0, 0.5)); u.iCameraFocalLength = float(rng.uniform(0.8, 1.5))
     u.iSSAA = float(ssaa)
     screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, threads=8)
     prog, _ = gpu.program("visualizer")
