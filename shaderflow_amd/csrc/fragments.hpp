@@ -409,7 +409,9 @@ SF_HD vec4 frag_mandelbrot(const Frag& f) {
         const int quality = sf::to_int(1000.0f*f.u->iQuality);
         int iter = 0;
         for (; iter < quality; iter++) {
-            if (length(z) > 3.0f) break;
+            // length(z) > 3.0: sqrt is monotone and correctly rounded, and RN(sqrt(nextafter(9))) is already above 3, so the test is
+            // `z.x*z.x + z.y*z.y > 9` bit for bit (NaN: false either way) — without a square-root sequence per iteration
+            if (z.x*z.x + z.y*z.y > 9.0f) break;
             z = vec2{z.x*z.x - z.y*z.y, z.x*z.y + z.y*z.x} + c;                                // cmul(z, z) + c :2-7,21
         }
         c3 = palette_magma(sf::pow(1.0f - (float)iter/(float)quality, 20.0f));                 // :25
