@@ -13,8 +13,10 @@ final.glsl's footprint stays inside the output pixel's own supersample block.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 import re
+import struct
 from collections.abc import Iterable
 from pathlib import Path
 from typing import Any, Optional, Union
@@ -29,6 +31,8 @@ from shaderflow_amd.module import ShaderModule
 from shaderflow_amd.texture import DeviceTexture, ShaderTexture
 from shaderflow_amd.variable import FlatVariable, InVariable, OutVariable, ShaderVariable
 
+_PLAIN_SCALARS = (float, int, bool)
+_VECTOR_FAST = True
 _UNIFORM_TYPES = {"float": (N.T_FLOAT, np.float32, 1), "int": (N.T_INT, np.int32, 1), "bool": (N.T_BOOL, np.int32, 1),
                   "vec2": (N.T_VEC2, np.float32, 2), "vec3": (N.T_VEC3, np.float32, 3), "vec4": (N.T_VEC4, np.float32, 4),
                   "mat2": (N.T_MAT2, np.float32, 4), "mat3": (N.T_MAT3, np.float32, 9), "mat4": (N.T_MAT4, np.float32, 16)}
@@ -161,6 +165,8 @@ class ShaderProgram(ShaderModule):
     program: Optional[N.Handle] = None
     _pushed: dict = Factory(dict)
     """name → (bytes, known) of the value the device program holds: unchanged uniforms and samplers are not sent again"""
+    _pushed_plain: dict = Factory(dict)
+    """name → (type, python scalar, known): the same answer for python scalars before any conversion (`_push`)"""
     fallback: bool = False
     """True when the fragment was unknown and the `missing` kernel was bound (shader.py:336-340)"""
 
@@ -169,6 +175,7 @@ class ShaderProgram(ShaderModule):
             N.lib().sfx_program_destroy(self.program)
         self.program = None
         self._pushed.clear()
+        self._pushed_plain.clear()
         self._uniform_arrays = {}
 
     def compile(self, _vertex: str = None, _fragment: str = None):
@@ -255,10 +262,40 @@ class ShaderProgram(ShaderModule):
         self._push(name, value)
 
     def _push(self, name: str, value: Any, type: Optional[str] = None) -> bool:
+        # Most uniforms of most frames are python scalars that did not change: answered from the last (type, value) pair without a
+        # numpy round trip. 0.0 and -0.0 compare equal but are different bits, and NaN never equals itself: both take the long way.
+        if type is not None and value.__class__ in _PLAIN_SCALARS:
+            last = self._pushed_plain.get(name)
+            if (last is not None and last[0] is type and last[1].__class__ is value.__class__ and last[1] == value and
+                    (value != 0 or value.__class__ is not float or math.copysign(1.0, value) == math.copysign(1.0, last[1]))):
+                return last[2]
+            known = self._push_converted(name, value, type)
+            self._pushed_plain[name] = (type, value, known)
+            return known
+        if type is not None and _VECTOR_FAST:
+            # vectors: numpy arrays by their bytes, tuples and lists of python numbers by their float64 image
+            key = None
+            if value.__class__ is np.ndarray:
+                key = (value.dtype.str, value.tobytes())
+            elif value.__class__ in (tuple, list) and len(value) <= 16:
+                try:
+                    key = struct.pack(f"{len(value)}d", *value)
+                except (struct.error, TypeError):
+                    key = None
+            if key is not None:
+                last = self._pushed_plain.get(name)
+                if last is not None and last[0] is type and last[1] == key:
+                    return last[2]
+                known = self._push_converted(name, value, type)
+                self._pushed_plain[name] = (type, key, known)
+                return known
+        return self._push_converted(name, value, type)
+
+    def _push_converted(self, name: str, value: Any, type: Optional[str] = None) -> bool:
         if name in self._uniform_arrays:                              # `uniform T name[N]` of a translated fragment: element by element
             kind, length = self._uniform_arrays[name]
             elements = np.asarray(value, dtype=np.float64).reshape(length, -1)
-            return all([self._push(f"{name}[{index}]", elements[index], kind) for index in range(length)])
+            return all([self._push_converted(f"{name}[{index}]", elements[index], kind) for index in range(length)])
         if type is None:
             array = np.asarray(value)
             count = array.size

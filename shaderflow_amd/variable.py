@@ -22,9 +22,14 @@ class ShaderVariable:
 
     def __init__(self, type: str, name: str, value: Optional[Any] = None, qualifier: Optional[str] = None,
                  direction: Optional[str] = None, interpolation: Optional[str] = None):
-        given = dict(type=type, name=name, value=value, qualifier=qualifier, direction=direction, interpolation=interpolation)
-        for key in _FIELDS:
-            setattr(self, key, given[key] if given[key] is not None else self._defaults.get(key))
+        # (a scene's pipeline() builds a hundred of these per frame: plain assignments, the class defaults only where nothing was given)
+        defaults = self._defaults
+        self.type = type if type is not None else defaults.get("type")
+        self.name = name if name is not None else defaults.get("name")
+        self.value = value if value is not None else defaults.get("value")
+        self.qualifier = qualifier if qualifier is not None else defaults.get("qualifier")
+        self.direction = direction if direction is not None else defaults.get("direction")
+        self.interpolation = interpolation if interpolation is not None else defaults.get("interpolation")
 
     # Two variables are "the same" when they have the same name: a later pipeline entry replaces an earlier one
     def __eq__(self, other) -> bool:
