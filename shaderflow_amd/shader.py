@@ -316,6 +316,7 @@ class ShaderProgram(ShaderModule):
         known = C.c_int(0)
         N.check(N.lib().sfx_uniform_set(self.program, name.encode(), code, data.ctypes.data, C.byref(known)))
         self._pushed[name] = (raw, bool(known.value))
+        self._pushed_plain.pop(name, None)                            # whoever asked through `_push` records its own value again
         return bool(known.value)
 
     def get_uniform(self, name: str) -> Optional[Any]:

@@ -439,3 +439,21 @@ def test_flac_and_wav_files_drive_the_same_export(tmp_path):
     from_flac = make(Visualizer, audio=str(tmp_path/"clip.flac"), background=background).main(**kw)
     from_wav = make(Visualizer, audio=str(tmp_path/"clip.wav"), background=background).main(**kw)
     assert from_flac == from_wav and frames_of(from_flac, 96, 54).std() > 1
+
+
+def test_set_uniform_between_frames_is_not_masked_by_the_pipeline_cache():
+    """ShaderProgram answers an unchanged pipeline value from its last python value; a value set through set_uniform() in between
+    has to invalidate that answer, or the next (unchanged) pipeline push would leave set_uniform's value on the device"""
+    from examples.scenes import Basic
+    scene = Basic()
+    scene.initialize()
+    scene.relay(__import__("shaderflow_amd.message", fromlist=["ShaderMessage"]).ShaderMessage.Shader.Compile)
+    program = scene.shader
+    program.compile()
+    assert program._push("iTime", 1.5, "float") is not None
+    assert program._pushed_plain["iTime"][1] == 1.5
+    program.set_uniform("iTime", 9.0)                                 # another route to the same uniform
+    assert "iTime" not in program._pushed_plain
+    sent_before = program._pushed["iTime"]
+    program._push("iTime", 1.5, "float")                              # the pipeline's unchanged value must reach the device again
+    assert program._pushed["iTime"] != sent_before and program._pushed_plain["iTime"][1] == 1.5
