@@ -435,6 +435,8 @@ extern "C" int sfx_program_load(sfx_handle h, const void* code_object, size_t nb
 // A fragment that takes derivatives needs its 2x2 neighbours in the lanes of a DPP quad. The fused kernel has that layout for
 // ssaa == 2 only (the four supersamples of a pixel are the four lanes of a quad, x in bit 0, y in bit 1).
 static bool fusable(const Program* p, int ssaa) { return !(p->flags & 1u) || ssaa == 2; }
+// rows a lane walks in the code object's sfx_jit_render / sfx_jit_fused_1 (shader_rows_1x of its shader policy; older flags words say 0)
+static int jit_rows_1x(const Program* p) { const int rows = (int)((p->flags >> 8) & 255u); return rows > 0 ? rows : 1; }
 extern "C" int sfx_program_fusable(sfx_handle h, int ssaa) {
     Program* p = get<Program>(h, MAGIC_PROG);
     return (p && p->fragment != FRAG_FINAL && fusable(p, ssaa)) ? 1 : 0;
@@ -1045,13 +1047,14 @@ static int launch_render_p(const Program* p, const RenderArgs& a, int frames, hi
     g_launch_ctx = p->ctx;
     if (p->fragment != FRAG_JIT) return launch_render(p->fragment, a, frames, s);
     using P = PlainShader<FRAG_DEFAULT>;
-    return launch_jit(p->fn_render, a, dim3((a.wr + P::BLOCK_W - 1)/P::BLOCK_W, (a.hr + P::BLOCK_H - 1)/P::BLOCK_H, frames), dim3(P::BLOCK_W, P::BLOCK_H, 1), s);
+    const int block_rows = P::BLOCK_H*jit_rows_1x(p);
+    return launch_jit(p->fn_render, a, dim3((a.wr + P::BLOCK_W - 1)/P::BLOCK_W, (a.hr + block_rows - 1)/block_rows, frames), dim3(P::BLOCK_W, P::BLOCK_H, 1), s);
 }
 static int launch_fused_p(const Program* p, const RenderArgs& a, int ssaa, int frames, hipStream_t s) {
     g_launch_ctx = p->ctx;
     if (p->fragment != FRAG_JIT) return launch_fused(p->fragment, a, ssaa, frames, s);
     using P = PlainShader<FRAG_DEFAULT>;
-    if (ssaa == 1) return launch_jit(p->fn_fused[0], a, dim3(((a.w + 127)/128)*((a.h + 1)/2), 1, frames), dim3(256), s);
+    if (ssaa == 1) { const int rows = 2*jit_rows_1x(p); return launch_jit(p->fn_fused[0], a, dim3(((a.w + 127)/128)*((a.h + rows - 1)/rows), 1, frames), dim3(256), s); }
     if (ssaa != 2 && ssaa != 4) return fail(SFX_E_UNSUPPORTED, "fused ssaa %d", ssaa);
     constexpr int rows = P::FUSED_ROWS*P::THREAD_ROWS, threads = 4*P::BLOCK_PX*P::THREAD_ROWS;
     const int blocks_x = (a.w + P::BLOCK_PX - 1)/P::BLOCK_PX, row_blocks = (a.h + rows - 1)/rows;

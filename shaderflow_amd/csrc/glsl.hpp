@@ -264,18 +264,22 @@ SF_HD float pixel_centre(int i, int n, float inv) {
 }
 
 // `aspect` = iResolution.x/iResolution.y, the same IEEE division done once by the caller
-SF_HD void make_varyings(Frag& f, int i, int j, int wr, int hr, float aspect, float inv_wr = 0.0f, float inv_hr = 0.0f) {
+// (every varying is a function of agluv: a kernel that has to come back to a sample keeps that one vec2)
+SF_HD void varyings_from_agluv(Frag& f, vec2 agluv, float aspect) {
     const Uniforms& u = *f.u;
     vec2 res = {u.iResolution[0], u.iResolution[1]};
     f.aspect = aspect;
-    vec2 centre = {pixel_centre(i, wr, inv_wr), pixel_centre(j, hr, inv_hr)};
-    f.agluv = centre*2.0f - 1.0f;
+    f.agluv = agluv;
     f.gluv = f.agluv*vec2{f.aspect, 1.0f};                         // agluv2gluv, shaderflow.glsl:99
     f.astuv = gluv2stuv(f.agluv);
     f.stuv = gluv2stuv(f.gluv);
     f.stxy = (res*f.astuv) + 1.0f;
     f.glxy = f.stxy - res/2.0f;
     f.fragCoord = f.stxy;
+}
+SF_HD void make_varyings(Frag& f, int i, int j, int wr, int hr, float aspect, float inv_wr = 0.0f, float inv_hr = 0.0f) {
+    vec2 centre = {pixel_centre(i, wr, inv_wr), pixel_centre(j, hr, inv_hr)};
+    varyings_from_agluv(f, centre*2.0f - 1.0f, aspect);
 }
 
 // ---- prelude subset ------------------------------------------------------------------------------

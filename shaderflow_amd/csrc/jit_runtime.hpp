@@ -488,14 +488,68 @@ SF_HD mat4 inverse(const mat4& m) {
 }
 
 // ---- samplers (§8.7) --------------------------------------------------------------------------------------------------
-struct sampler2D { const Tex* t; };
+// One sampler of a translated fragment may be served from an LDS tile (SF_JIT_TILE_SLOT, chosen by the translator for tap-heavy
+// fragments — blurs, feedback kernels). The tile is a cache of decoded texels over a rectangle of UNWRAPPED texel indices,
+// entry (x, y) = texel(t, wrap(x), wrap(y)): a tap whose footprint lies inside reads LDS, any other tap takes the generic
+// fetch, and both blend the same floats with the same operations — results never depend on what was staged. The rectangle
+// comes from running the fragment once at the block's first and last sample in `record` mode (JitShader::setup below).
+#ifndef SF_JIT_TILE_SLOT
+#define SF_JIT_TILE_SLOT -1
+#endif
+constexpr int TILE_TEXELS = 3072;                    // 48 KiB of float4
+struct TileView {
+    const float4* texels;                            // nullptr: this sampler has no tile
+    int* record;                                     // not null: note the texels the taps touch {lo x, lo y, hi x, hi y} instead of reading the tile
+    int x0, y0, w;                                   // staged rectangle [x0, x0 + w) x [y0, y0 + h), row pitch w
+    unsigned nearest_w, nearest_h, linear_w, linear_h;   // w, h and max(w - 1, 0), max(h - 1, 0): the bounds of a tap's first texel
+};
+// (the view travels by value inside the sampler: a pointer from the fragment object to one of its own members would keep the
+// whole object out of registers)
+struct sampler2D { const Tex* t; TileView tile; };
 SF_HD vec4 up(sf::vec4 c) { return vec4(c.x, c.y, c.z, c.w); }
 SF_HD vec3 up(sf::vec3 c) { return vec3(c.x, c.y, c.z); }
 SF_HD vec2 up(sf::vec2 c) { return vec2(c.x, c.y); }
 SF_HD sf::vec2 lo(const vec2& c) { return {c.x, c.y}; }
 SF_HD sf::vec3 lo(const vec3& c) { return {c.x, c.y, c.z}; }
 // an unbound sampler reads as opaque black texels, like an incomplete GL texture
-SF_HD vec4 texture(sampler2D s, const vec2& uv) { return (s.t && s.t->data) ? up(sf::texture(*s.t, lo(uv))) : vec4(0.0f, 0.0f, 0.0f, 1.0f); }
+SF_HD int tile_bound(float texel) { return (int)sf::min(sf::max(texel, -16777216.0f), 16777216.0f); }
+SF_HD sf::vec4 tiled_texture(const Tex& t, const TileView& v, sf::vec2 uv) {      // sf::texture (glsl.hpp) with the texel fetch swapped
+    const float u = uv.x*(float)t.width, w = uv.y*(float)t.height;
+    const bool nearest = t.filter == FILTER_NEAREST;
+    const float ub = nearest ? u : u - 0.5f, vb = nearest ? w : w - 0.5f;
+    const float fu = ::floorf(ub), fv = ::floorf(vb);
+    if (v.record) {
+        const int i = tile_bound(fu), j = tile_bound(fv), far = nearest ? 0 : 1;
+        int* box = v.record;
+        if (i < box[0]) box[0] = i;
+        if (j < box[1]) box[1] = j;
+        if (i + far > box[2]) box[2] = i + far;
+        if (j + far > box[3]) box[3] = j + far;
+        return sf::texture(t, uv);
+    }
+    const unsigned rx = (unsigned)(int)fu - (unsigned)v.x0, ry = (unsigned)(int)fv - (unsigned)v.y0;
+    if (nearest) {
+        if (rx < v.nearest_w && ry < v.nearest_h) { const float4 c = v.texels[ry*(unsigned)v.w + rx]; return {c.x, c.y, c.z, c.w}; }
+        return sf::texture(t, uv);
+    }
+    if (rx < v.linear_w && ry < v.linear_h) {
+        const float4* p = v.texels + (ry*(unsigned)v.w + rx);
+        const float4 t00 = p[0], t10 = p[1], t01 = p[v.w], t11 = p[v.w + 1];
+        const float a = ub - fu, b = vb - fv;
+        const float na = 1.0f - a, nb = 1.0f - b;
+        const float w00 = na*nb, w10 = a*nb, w01 = na*b, w11 = a*b;
+        return {bilerp(w00, w10, w01, w11, t00.x, t10.x, t01.x, t11.x),
+                bilerp(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y),
+                bilerp(w00, w10, w01, w11, t00.z, t10.z, t01.z, t11.z),
+                bilerp(w00, w10, w01, w11, t00.w, t10.w, t01.w, t11.w)};
+    }
+    return sf::texture(t, uv);
+}
+SF_HD vec4 texture(sampler2D s, const vec2& uv) {
+    if (!(s.t && s.t->data)) return vec4(0.0f, 0.0f, 0.0f, 1.0f);
+    if (s.tile.texels) return up(tiled_texture(*s.t, s.tile, lo(uv)));
+    return up(sf::texture(*s.t, lo(uv)));
+}
 SF_HD vec4 texture(sampler2D s, const vec2& uv, float) { return texture(s, uv); }          // one level: the bias selects nothing
 SF_HD vec4 textureLod(sampler2D s, const vec2& uv, float) { return texture(s, uv); }
 SF_HD vec4 texelFetch(sampler2D s, ivec2 p, int) { return (s.t && s.t->data) ? up(sf::texel_fetch(*s.t, p.x, p.y)) : vec4(0.0f, 0.0f, 0.0f, 1.0f); }
@@ -660,6 +714,7 @@ struct FragmentBase {
     vec4 gl_FragCoord, fragColor;
     int instance;
     bool discarded_;
+    TileView tile_;                                  // set before load_user_() by a kernel that stages a tile; texels == nullptr: none
     float iTime, iTau, iDuration, iFrametime, iDeltatime, iCycle, iAspectRatio, iWidth, iHeight;
     vec2 iResolution, iMouse;
     float iWantAspect, iQuality, iSSAA, iFramerate;
@@ -679,7 +734,7 @@ struct FragmentBase {
         frag_ = &f;
         fragCoord = up(f.fragCoord); stxy = up(f.stxy); glxy = up(f.glxy); stuv = up(f.stuv); astuv = up(f.astuv); gluv = up(f.gluv); agluv = up(f.agluv);
         gl_FragCoord = vec4(f.fragCoord.x - 1.0f, f.fragCoord.y - 1.0f, 0.5f, 1.0f);     // stxy = iResolution*astuv + 1 (vertex/default.glsl:13)
-        fragColor = vec4(0.0f); instance = 0; discarded_ = false;
+        fragColor = vec4(0.0f); instance = 0; discarded_ = false; tile_ = TileView{};
         iTime = u.iTime; iTau = u.iTau; iDuration = u.iDuration;
         iFramerate = u.iFramerate; iFrametime = 1.0f/u.iFramerate; iDeltatime = iFrametime;    // shaderflow.glsl:13-14: the macro shadows the uniform
         iCycle = 2.0f*PI*u.iTau;                                                               // :15
@@ -701,7 +756,8 @@ struct FragmentBase {
         iSpectrogramOffset = u.iSpectrogramOffset; iSpectrogramMin = u.iSpectrogramMin; iSpectrogramMax = u.iSpectrogramMax;
     }
     // sampler slot k of the launch: the named slots are the per-frame copy (tape mode patches the audio textures), the rest is read in place
-    SF_HD sampler2D sampler_(int slot) const { return {(slot < TEX_HISTORY) ? &frag_->tex[slot] : &frag_->history[slot - TEX_HISTORY]}; }
+    SF_HD const Tex* texture_(int slot) const { return (slot < TEX_HISTORY) ? &frag_->tex[slot] : &frag_->history[slot - TEX_HISTORY]; }
+    SF_HD sampler2D sampler_(int slot) const { return {texture_(slot), (slot == SF_JIT_TILE_SLOT) ? tile_ : TileView{}}; }
     SF_HD float user_(int slot) const { return frag_->u->user[slot]; }
     SF_HD int user_int_(int slot) const { return (int)f2u(frag_->u->user[slot]); }
 
@@ -745,7 +801,7 @@ struct FragmentBase {
 
 // The shader policy of a translated fragment: FRAGMENT is the generated struct (derives from rt::FragmentBase, has
 // load_user_() and main_()).
-template <class FRAGMENT, bool DERIVATIVES = false> struct JitShader : PlainShader<FRAG_DEFAULT> {
+template <class FRAGMENT, bool DERIVATIVES = false, bool TILED = false> struct JitShader : PlainShader<FRAG_DEFAULT> {
     static constexpr bool QUADS = DERIVATIVES;
     SF_HD static vec4 run(const RenderArgs&, const Frag& f, const State&, const Shared&) {
         FRAGMENT s;
@@ -756,6 +812,76 @@ template <class FRAGMENT, bool DERIVATIVES = false> struct JitShader : PlainShad
         return {s.fragColor.x, s.fragColor.y, s.fragColor.z, s.fragColor.w};
     }
 };
+
+// The same policy with sampler SF_JIT_TILE_SLOT served from LDS (TileView above). setup(): the threads that own the block's
+// first and last sample run the fragment in record mode (the other lanes wait: one extra evaluation per block, against
+// FUSED_ROWS x S x S / 4 per lane in the pass proper); the union of the two boxes, cropped about its centre to TILE_TEXELS,
+// is decoded into LDS by the whole block. A fragment whose taps move monotonically with the pixel (any blur or feedback
+// kernel around the fragment's own position, under any affine map) finds every tap inside; what falls outside is fetched
+// the generic way.
+#if defined(__HIPCC__)
+template <class FRAGMENT> struct JitShader<FRAGMENT, false, true> : PlainShader<FRAG_DEFAULT> {
+    static constexpr int ROWS_1X = 4;                // the probe is one evaluation per block: as many per lane as the fused 2x kernel has
+    struct State { vec2 agluv; };
+    struct Shared {
+        __attribute__((aligned(16))) float4 texels[rt::TILE_TEXELS];
+        int box[2][4];
+    };
+    __device__ static void pre(const RenderArgs&, const Frag& f, bool, State& s) { s.agluv = f.agluv; }
+    __device__ static int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+    __device__ static void rectangle(const Shared& sh, int& x0, int& y0, int& w, int& h) {
+        const int lo_x = uniform(min(sh.box[0][0], sh.box[1][0])), lo_y = uniform(min(sh.box[0][1], sh.box[1][1]));
+        const int hi_x = uniform(max(sh.box[0][2], sh.box[1][2])), hi_y = uniform(max(sh.box[0][3], sh.box[1][3]));
+        x0 = lo_x; y0 = lo_y; w = hi_x - lo_x + 1; h = hi_y - lo_y + 1;
+        if (w <= 0 || h <= 0) { w = 0; h = 0; return; }             // the probes took no tap
+        constexpr int WIDEST = rt::TILE_TEXELS/4;
+        if (w > WIDEST) { x0 += (w - WIDEST)/2; w = WIDEST; }
+        if (w*h > rt::TILE_TEXELS) { const int fit = rt::TILE_TEXELS/w; y0 += (h - fit)/2; h = fit; }
+    }
+    template <int N> __device__ static void setup(const RenderArgs&, const Tex*, const Frag& f, State (&state)[N], const bool (&)[N], Shared& sh, int corner_tid) {
+        const int tid = threadIdx.y*blockDim.x + threadIdx.x, nthreads = blockDim.x*blockDim.y;
+        if (tid == 0 || tid == corner_tid) {
+            Frag g = f;
+            varyings_from_agluv(g, (tid == 0) ? state[0].agluv : state[N - 1].agluv, f.aspect);
+            FRAGMENT s;
+            s.load_(g);
+            int box[4] = {1 << 30, 1 << 30, -(1 << 30), -(1 << 30)};      // a local of its own: registers once `s` is taken apart
+            s.tile_.texels = sh.texels; s.tile_.record = box;
+            s.load_user_();
+            s.main_();
+            int* shared_box = sh.box[(tid == 0) ? 0 : 1];
+            for (int k = 0; k < 4; k++) shared_box[k] = box[k];
+            if (corner_tid == 0) for (int k = 0; k < 4; k++) sh.box[1][k] = box[k];
+        }
+        __syncthreads();
+        int x0, y0, w, h;
+        rectangle(sh, x0, y0, w, h);
+        const Tex& t = (SF_JIT_TILE_SLOT < TEX_HISTORY) ? f.tex[SF_JIT_TILE_SLOT] : f.history[SF_JIT_TILE_SLOT - TEX_HISTORY];
+        if (t.data) {
+            for (int k = tid; k < w*h; k += nthreads) {
+                const int y = k/w, x = k - y*w;
+                const vec4 c = texel(t, wrap_texel(x0 + x, t.width, t.repeat_x), wrap_texel(y0 + y, t.height, t.repeat_y));
+                sh.texels[k] = make_float4(c.x, c.y, c.z, c.w);
+            }
+        }
+        __syncthreads();
+    }
+    __device__ static vec4 run(const RenderArgs&, const Frag& f, const State&, const Shared& sh) {
+        FRAGMENT s;
+        s.load_(f);
+        int x0, y0, w, h;
+        rectangle(sh, x0, y0, w, h);
+        s.tile_.texels = sh.texels; s.tile_.record = nullptr;
+        s.tile_.x0 = x0; s.tile_.y0 = y0; s.tile_.w = w;
+        s.tile_.nearest_w = (unsigned)w; s.tile_.nearest_h = (unsigned)h;
+        s.tile_.linear_w = (unsigned)max(w - 1, 0); s.tile_.linear_h = (unsigned)max(h - 1, 0);
+        s.load_user_();
+        s.main_();
+        if (s.discarded_) return {0.0f, 0.0f, 0.0f, 0.0f};
+        return {s.fragColor.x, s.fragColor.y, s.fragColor.z, s.fragColor.w};
+    }
+};
+#endif
 
 }  // namespace sf
 
@@ -810,14 +936,19 @@ inline void sfx_jit_host_texture(sf::Tex* textures, int slot, const void* data, 
 #endif
 
 // Entry points of a code object (capi: sfx_program_load looks them up by these names)
+// sfx_jit_flags: bit 0 = SF_JIT_DERIVATIVES, bits 8-15 = rows a lane walks in sfx_jit_render / sfx_jit_fused_1 (the launch geometry).
 // SF_JIT_DERIVATIVES (0/1, defined by the translator before this macro): the fragment calls dFdx/dFdy/fwidth — the unfused kernel
 // uses the quad layout and the library keeps the program off the fused kernels except at ssaa 2, where the four supersamples of
 // a pixel already are the four lanes of a quad (all valid or all invalid together).
+// SF_JIT_TILED: the translator asked for an LDS tile (SF_JIT_TILE_SLOT) and the fragment takes no derivatives (a probe with
+// two live lanes has no neighbours to difference with).
+#define SF_JIT_TILED ((SF_JIT_TILE_SLOT >= 0) && !(SF_JIT_DERIVATIVES))
 #define SF_JIT_ENTRY_POINTS(FRAGMENT) \
     SF_JIT_HOST_POINTS(FRAGMENT) \
     extern "C" __device__ __attribute__((used)) const unsigned long long sfx_jit_layout = sf::render_args_layout(); \
-    extern "C" __device__ __attribute__((used)) const unsigned sfx_jit_flags = (SF_JIT_DERIVATIVES ? 1u : 0u); \
-    extern "C" __global__ __launch_bounds__(256) void sfx_jit_render(const sf::RenderArgs a) { sf::render_body<sf::JitShader<FRAGMENT, (SF_JIT_DERIVATIVES != 0)>>(a); } \
-    extern "C" __global__ __launch_bounds__(256) void sfx_jit_fused_1(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT>, 1>(a); } \
-    extern "C" __global__ __launch_bounds__(512) void sfx_jit_fused_2(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT, (SF_JIT_DERIVATIVES != 0)>, 2>(a); } \
-    extern "C" __global__ __launch_bounds__(512) void sfx_jit_fused_4(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT>, 4>(a); }
+    extern "C" __device__ __attribute__((used)) const unsigned sfx_jit_flags = (SF_JIT_DERIVATIVES ? 1u : 0u) | \
+        ((unsigned)sf::shader_rows_1x<sf::JitShader<FRAGMENT, false, SF_JIT_TILED>>::value << 8); \
+    extern "C" __global__ __launch_bounds__(256) void sfx_jit_render(const sf::RenderArgs a) { sf::render_body<sf::JitShader<FRAGMENT, (SF_JIT_DERIVATIVES != 0), SF_JIT_TILED>>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void sfx_jit_fused_1(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT, false, SF_JIT_TILED>, 1>(a); } \
+    extern "C" __global__ __launch_bounds__(512) void sfx_jit_fused_2(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT, (SF_JIT_DERIVATIVES != 0), SF_JIT_TILED>, 2>(a); } \
+    extern "C" __global__ __launch_bounds__(512) void sfx_jit_fused_4(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT, false, SF_JIT_TILED>, 4>(a); }

@@ -166,6 +166,11 @@ template <class S> struct shader_uses_quads<S, decltype((void)S::QUADS)> { stati
 template <class S, class = void> struct shader_fast_centres { static constexpr bool value = true; };
 template <class S> struct shader_fast_centres<S, decltype((void)S::FAST_CENTRES)> { static constexpr bool value = S::FAST_CENTRES; };
 
+// Rows a lane walks where the kernels give it one sample at a time (the 1x fused kernel; the unfused kernel's blocks stacked
+// vertically): 1 unless the shader's per-block setup wants more samples to pay for it (`ROWS_1X`, the tiled translated fragments)
+template <class S, class = void> struct shader_rows_1x { static constexpr int value = 1; };
+template <class S> struct shader_rows_1x<S, decltype((void)S::ROWS_1X)> { static constexpr int value = S::ROWS_1X; };
+
 template <class SHADER>
 __device__ __forceinline__ void render_body(const RenderArgs& a) {
     __shared__ typename SHADER::Shared shared;
@@ -177,25 +182,34 @@ __device__ __forceinline__ void render_body(const RenderArgs& a) {
         lx = (((lane >> 2) << 1) | (lane & 1)) + 32*(wave & 1);
         ly = ((lane >> 1) & 1) + 2*(wave >> 1);
     }
+    constexpr int R = shader_rows_1x<SHADER>::value;     // rows a thread walks: the block covers BLOCK_W x (BLOCK_H*R) pixels
+    static_assert(!(QUADS && R > 1), "the quad layout shades one pixel per lane");
     const int i = blockIdx.x*SHADER::BLOCK_W + lx;
-    const int j = blockIdx.y*SHADER::BLOCK_H + ly;
+    const int j = (blockIdx.y*SHADER::BLOCK_H + ly)*R;
     Uniforms u; Tex tex[TEX_HISTORY];
     frame_view(a, blockIdx.z, u, tex);
-    const bool inside = (i < a.wr) && (j < a.hr);
     Frag f; f.u = &u; f.tex = tex; f.history = a.tex + TEX_HISTORY;
-    make_varyings(f, i, j, a.wr, a.hr, a.aspect, shader_fast_centres<SHADER>::value ? a.inv_wr : 0.0f, shader_fast_centres<SHADER>::value ? a.inv_hr : 0.0f);
-    typename SHADER::State state[1];
-    const bool valid[1] = {inside};
-    SHADER::pre(a, f, inside, state[0]);
+    typename SHADER::State state[R];
+    bool valid[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        valid[r] = (i < a.wr) && (j + r < a.hr);
+        make_varyings(f, i, j + r, a.wr, a.hr, a.aspect, shader_fast_centres<SHADER>::value ? a.inv_wr : 0.0f, shader_fast_centres<SHADER>::value ? a.inv_hr : 0.0f);
+        SHADER::pre(a, f, valid[r], state[r]);
+    }
     // the thread that owns the block's last valid pixel (thread 0 owns the first): corner samples for monotone shaders
     const int i_last = min((int)(blockIdx.x + 1)*SHADER::BLOCK_W, a.wr) - 1 - (int)blockIdx.x*SHADER::BLOCK_W;
-    const int j_last = min((int)(blockIdx.y + 1)*SHADER::BLOCK_H, a.hr) - 1 - (int)blockIdx.y*SHADER::BLOCK_H;
-    SHADER::template setup<1>(a, tex, f, state, valid, shared, j_last*SHADER::BLOCK_W + i_last);
-    if constexpr (QUADS) {
-        const vec4 colour = SHADER::run(a, f, state[0], shared);      // helper lanes run too: their values feed the neighbours' differences
-        if (inside) store_target(a, blockIdx.z, i, j, colour);
-    } else {
-        if (inside) store_target(a, blockIdx.z, i, j, SHADER::run(a, f, state[0], shared));
+    const int j_last = (min((int)(blockIdx.y + 1)*SHADER::BLOCK_H*R, a.hr) - 1 - (int)blockIdx.y*SHADER::BLOCK_H*R)/R;
+    SHADER::template setup<R>(a, tex, f, state, valid, shared, j_last*SHADER::BLOCK_W + i_last);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if constexpr (R > 1) make_varyings(f, i, j + r, a.wr, a.hr, a.aspect, shader_fast_centres<SHADER>::value ? a.inv_wr : 0.0f, shader_fast_centres<SHADER>::value ? a.inv_hr : 0.0f);
+        if constexpr (QUADS) {
+            const vec4 colour = SHADER::run(a, f, state[r], shared);      // helper lanes run too: their values feed the neighbours' differences
+            if (valid[r]) store_target(a, blockIdx.z, i, j + r, colour);
+        } else {
+            if (valid[r]) store_target(a, blockIdx.z, i, j + r, SHADER::run(a, f, state[r], shared));
+        }
     }
 }
 template <class SHADER>
@@ -327,7 +341,7 @@ __device__ __forceinline__ void render_resolve_body(const RenderArgs& a) {
     // Output rows per block: S == 1 packs 2 rows of 128 pixels into its 256 threads; otherwise every quad walks
     // SHADER::FUSED_ROWS vertically adjacent pixels, which amortises the shader's per-block setup (LDS staging)
     constexpr int TROWS = (S == 1) ? 2 : SHADER::THREAD_ROWS;             // rows covered by different threads
-    constexpr int WALK = (S == 1) ? 1 : SHADER::FUSED_ROWS;               // pixels a lane group visits one after the other
+    constexpr int WALK = (S == 1) ? shader_rows_1x<SHADER>::value : SHADER::FUSED_ROWS;   // pixels a lane group visits one after the other
     constexpr int ROWS = TROWS*WALK;
     constexpr int PER_LANE = GROUP*WALK;
     constexpr int BPX = (S == 1) ? 128 : SHADER::BLOCK_PX;               // output pixels of a row per block (multiple of 16)
@@ -380,12 +394,15 @@ __device__ __forceinline__ void render_resolve_body(const RenderArgs& a) {
     SF_TICK(a, 2);                                   // run (blur + post)
 
     if constexpr (S == 1) {
-        const uint32_t block[1] = {mine[0]};
-        if (valid[0]) {
-            uint8_t* s = &staged[prow][(p % BPX)*3];
-            s[0] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 0);
-            s[1] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 8);
-            s[2] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 16);
+#pragma unroll
+        for (int r = 0; r < WALK; r++) {
+            const uint32_t block[1] = {mine[r]};
+            if (valid[r]) {
+                uint8_t* s = &staged[prow*WALK + r][(p % BPX)*3];
+                s[0] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 0);
+                s[1] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 8);
+                s[2] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 16);
+            }
         }
     } else {
 #pragma unroll

@@ -72,6 +72,7 @@ class Binding:
 class Translation:
     cpp: str
     bindings: list[Binding] = field(default_factory=list)
+    tiled_sampler: Optional[str] = None            # the sampler the kernels serve from an LDS tile (jit_runtime.hpp TileView), if any
 
     @property
     def key(self) -> str:
@@ -571,7 +572,10 @@ class _Translator:
                     next_float += count
         code = "".join(self.body)
         undefs = "".join(f"#undef {m}\n" for m in dict.fromkeys(self.macros))
+        derivatives = bool(self.identifiers & {'dFdx', 'dFdy', 'fwidth'})
+        tiled = None if derivatives else _sampler_worth_a_tile(code, [b for b in bindings if b.type == "sampler2D"])
         cpp = ("// generated by shaderflow_amd/glsl2hip.py from a GLSL fragment\n"
+               + (f"#define SF_JIT_TILE_SLOT {tiled.slot}      // {tiled.name}\n" if tiled else "") +
                "#include \"jit_runtime.hpp\"\n"
                "namespace sf { namespace rt {\n"
                "struct Fragment : FragmentBase {\n" + "\n".join(members) + "\n"
@@ -580,9 +584,36 @@ class _Translator:
                "// ---- end of translated fragment ----\n"
                "};\n"
                "}}\n" + undefs +
-               f"#define SF_JIT_DERIVATIVES {int(bool(self.identifiers & {'dFdx', 'dFdy', 'fwidth'}))}\n"
+               f"#define SF_JIT_DERIVATIVES {int(derivatives)}\n"
                "SF_JIT_ENTRY_POINTS(sf::rt::Fragment)\n")
-        return Translation(cpp, bindings)
+        return Translation(cpp, bindings, tiled.name if tiled else None)
+
+
+_TEXTURE_CALLS = r"(?:texture|textureLod|gtexture|gmtexture|stexture|astexture|agtexture|agmtexture)"
+
+
+def _sampler_worth_a_tile(code: str, samplers: list[Binding]) -> Optional[Binding]:
+    """The sampler a tap-heavy fragment reads most (a blur or feedback kernel: taps inside a loop, or eight and more written
+    out), or None. SHADERFLOW_JIT_TILE=0 turns the tile off, =<sampler name> forces it for that sampler.
+
+    The tile costs one extra evaluation of the fragment per block (jit_runtime.hpp JitShader::setup) and never changes a
+    result, so the choice is about speed only: a single tap does not pay for the probe."""
+    wish = os.environ.get("SHADERFLOW_JIT_TILE", "1")
+    if wish.lower() in ("0", "off", "false", "no"):
+        return None
+    forced = [b for b in samplers if b.name == wish or (b.name.endswith("0x0") and b.name[:-3] == wish)]
+    if forced:
+        return forced[0]
+    loop = re.search(r"\b(?:for|while)\s*\(", code)
+    best, best_score = None, 0
+    for binding in samplers:
+        names = {binding.name, binding.name[:-3] if binding.name.endswith("0x0") else binding.name}
+        pattern = re.compile(rf"\b{_TEXTURE_CALLS}\s*\(\s*(?:{'|'.join(map(re.escape, names))})\b")
+        taps = [m.start() for m in pattern.finditer(code)]
+        score = sum(16 if (loop and at > loop.start()) else 1 for at in taps)
+        if score > best_score:
+            best, best_score = binding, score
+    return best if best_score >= 8 else None
 
 
 _SCALAR_OF = {"float": float, "int": int, "uint": int, "bool": bool}

@@ -422,3 +422,116 @@ def test_device_and_host_builds_of_a_translation_agree_bit_for_bit(gpu, name):
     N.check(gpu.lib.sfx_program_destroy(prog))
     same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
     assert same.all(), f"{int((~same).sum())} of {same.size} floats differ; first at {np.argwhere(~same)[0].tolist()}: {got[~same][0]!r} vs {want[~same][0]!r}"
+
+
+# ---- the LDS tile of tap-heavy fragments (jit_runtime.hpp TileView / JitShader<…, true>) ---------------------------------------
+BLUR = """
+uniform float radius = 3.0;
+uniform vec2 drift = vec2(0.0);
+uniform float swirl = 0.0;
+void main() {
+    vec4 sum = vec4(0.0);
+    float total = 0.0;
+    vec2 texel = 1.0/vec2(textureSize(background, 0));
+    vec2 centre = rotate2d(swirl*length(agluv))*(astuv - 0.5) + 0.5 + drift;
+    for (int x = -4; x <= 4; x++) {
+        for (int y = -4; y <= 4; y++) {
+            float weight = exp(-float(x*x + y*y)/(radius*radius));
+            sum += weight*texture(background, centre + vec2(x, y)*texel*1.37);
+            total += weight;
+        }
+    }
+    fragColor = sum/total;
+}
+"""
+
+
+def _tile_texture(kind: str, rng) -> np.ndarray:
+    if kind == "rgba8":
+        return rng.integers(0, 256, (54, 96, 4), dtype=np.uint8)
+    if kind == "rgb8":
+        return rng.integers(0, 256, (37, 61, 3), dtype=np.uint8)
+    if kind == "wide":                                   # a block's footprint is larger than the tile: the crop and the generic fetch share the taps
+        return rng.integers(0, 256, (360, 640, 4), dtype=np.uint8)
+    return rng.random((40, 70, 2), dtype=np.float32)      # "rg32f"
+
+
+@pytest.mark.parametrize("kind,filter,repeat,drift,swirl", [
+    ("rgba8", "linear", True, (0.0, 0.0), 0.0),
+    ("rgba8", "linear", False, (-0.31, 0.93), 0.0),      # taps left of and above the texture: clamped copies in the tile
+    ("rgba8", "nearest", True, (0.6, -1.2), 0.0),        # wrapped several times over
+    ("rgb8", "linear", True, (0.013, 0.007), 0.0),
+    ("rg32f", "linear", False, (0.0, 0.0), 0.0),
+    ("wide", "linear", True, (0.0, 0.0), 0.0),
+    ("rgba8", "linear", True, (0.0, 0.0), 2.5),          # not monotone across a block: taps of the middle pixels leave the probed box
+    ("wide", "nearest", False, (0.2, 0.1), 1.0),
+])
+def test_tiled_sampler_gives_the_bits_of_the_host_build(gpu, kind, filter, repeat, drift, swirl):
+    """The tile is a cache: whatever was staged, a tap blends the same decoded texels with the same operations. The host build of the
+    same translation has no tile at all, so float-for-float equality checks the staged values, the wrap at stage time and the bounds."""
+    from tests.jit_host import HostFragment
+    prog, translation = load(gpu, BLUR, [("sampler2D", "background")])
+    assert translation.tiled_sampler == "background"
+    host = HostFragment(translation, CACHE)
+    data = _tile_texture(kind, np.random.default_rng(5))
+    w, h = 150, 43                                        # partial blocks on both axes
+    u = O.default_uniforms(w, h, iTime=0.5)
+    gpu.set_uniforms(prog, u); host.set_uniforms(u)
+    for key, value in (("radius", 2.5), ("drift", drift), ("swirl", swirl)):
+        assert gpu.set_values(prog, key, value); host.set(key, value)
+    gpu.bind(prog, "background", gpu.texture(data, filter, repeat, repeat))
+    host.bind("background", data, filter, repeat, repeat)
+    got = gpu.render(prog, w, h, comps=4, dtype=np.float32)
+    want = host.render_float(w, h)
+    N.check(gpu.lib.sfx_program_destroy(prog))
+    same = got.view(np.uint32) == want.view(np.uint32)
+    assert same.all(), f"{int((~same).sum())} of {same.size} floats differ; first at {np.argwhere(~same)[0].tolist()}"
+
+
+def test_tiled_and_untiled_translations_write_the_same_frames(gpu, monkeypatch):
+    """Every kernel of the code object (plain render, fused 1x / 2x / 4x) with the tile against the same fragment translated without it"""
+    data = _tile_texture("rgba8", np.random.default_rng(9))
+    frames = {}
+    for tile in ("1", "0"):
+        monkeypatch.setenv("SHADERFLOW_JIT_TILE", tile)
+        prog, translation = load(gpu, BLUR, [("sampler2D", "background")])
+        assert (translation.tiled_sampler is not None) == (tile == "1")
+        gpu.bind(prog, "background", gpu.texture(data, "linear", True, False))
+        for (ssaa, subsample) in ((1, 1), (2, 2), (2, 1), (4, 4), (4, 2)):
+            w, h = 301, 37
+            gpu.set_uniforms(prog, O.default_uniforms(w, h, iTime=0.4, iSSAA=float(ssaa)))
+            gpu.set_values(prog, "drift", (0.4, -0.2)); gpu.set_values(prog, "swirl", 0.3)
+            frames[tile, ssaa, subsample] = gpu.render_resolve(prog, w, h, ssaa, subsample)
+        frames[tile, "render"] = gpu.render(prog, 131, 67)
+        N.check(gpu.lib.sfx_program_destroy(prog))
+    for key in [k[1:] for k in frames if k[0] == "1"]:
+        assert np.array_equal(frames[("1",) + key], frames[("0",) + key]), key
+
+
+def test_a_fragment_that_never_taps_the_tiled_sampler_still_renders(gpu, monkeypatch):
+    """Forced tile on a sampler the probes do not read (the branch is off): an empty box, nothing staged, every later tap generic"""
+    monkeypatch.setenv("SHADERFLOW_JIT_TILE", "background")
+    text = """
+    uniform float gate = 0.0;
+    void main() {
+        fragColor = vec4(stuv, 0.25, 1.0);
+        if (gate > 0.5 && astuv.x > 0.3 && astuv.x < 0.6) fragColor = texture(background, astuv);
+    }
+    """
+    prog, translation = load(gpu, text, [("sampler2D", "background")])
+    assert translation.tiled_sampler == "background"
+    data = _tile_texture("rgba8", np.random.default_rng(2))
+    gpu.bind(prog, "background", gpu.texture(data, "nearest", False, False))
+    w, h = 192, 16
+    gpu.set_uniforms(prog, O.default_uniforms(w, h))
+    gpu.set_values(prog, "gate", 0.0)
+    off = gpu.render(prog, w, h)
+    gpu.set_values(prog, "gate", 1.0)
+    on = gpu.render(prog, w, h)
+    N.check(gpu.lib.sfx_program_destroy(prog))
+    columns = (np.arange(w) + 0.5)/w
+    inside = (columns > 0.3) & (columns < 0.6)
+    assert np.array_equal(on[:, ~inside], off[:, ~inside])
+    ix = np.floor(columns*96).astype(int)
+    iy = np.floor((np.arange(h) + 0.5)/h*54).astype(int)
+    assert np.array_equal(on[:, inside], data[iy][:, ix[inside]])

@@ -410,3 +410,48 @@ def test_mechanical_translation_of_the_layered_and_temporal_fragments(tmp_path):
     host.set_uniforms(u)
     assert host.bind("iVideo0x0", frame)
     assert np.array_equal(host.render(w, h), O.render("video", u, {0: O.make_texture(frame)}, w, h, threads=4))
+
+
+def test_the_translator_asks_for_a_tile_only_where_it_can_pay(monkeypatch):
+    """glsl2hip._sampler_worth_a_tile: taps in a loop (or many written out) on one sampler → SF_JIT_TILE_SLOT; a single tap, a fragment
+    that takes derivatives, or SHADERFLOW_JIT_TILE=0 → none; SHADERFLOW_JIT_TILE=<name> forces"""
+    monkeypatch.delenv("SHADERFLOW_JIT_TILE", raising=False)
+    blur = "void main() { vec4 s = vec4(0); for (int k = -3; k <= 3; k++) s += texture(background, astuv + vec2(k, 0)/256.0); fragColor = s/7.0; }"
+    single = "void main() { fragColor = texture(background, astuv); }"
+    edges = "void main() { vec4 s = vec4(0); for (int k = 0; k < 4; k++) s += texture(background, astuv + k*0.01); fragColor = s*fwidth(astuv.x); }"
+    two = ("uniform sampler2D other;\nvoid main() { vec4 s = texture(other, astuv); for (int k = 0; k < 4; k++) s += gtexture(background, gluv*0.5 + k*0.01) "
+           "+ texture(other, stuv); fragColor = s; }")
+    variables = [("sampler2D", "background")]
+    t = G.translate(blur, variables)
+    assert t.tiled_sampler == "background" and "#define SF_JIT_TILE_SLOT" in t.cpp
+    slot = next(b.slot for b in t.bindings if b.name == "background")
+    assert f"#define SF_JIT_TILE_SLOT {slot} " in t.cpp
+    assert G.translate(single, variables).tiled_sampler is None
+    assert G.translate(edges, variables).tiled_sampler is None
+    assert "SF_JIT_TILE_SLOT" not in G.translate(single, variables).cpp
+    assert G.translate(two, variables).tiled_sampler in ("background", "other")
+    monkeypatch.setenv("SHADERFLOW_JIT_TILE", "0")
+    assert G.translate(blur, variables).tiled_sampler is None
+    monkeypatch.setenv("SHADERFLOW_JIT_TILE", "background")
+    assert G.translate(single, variables).tiled_sampler == "background"
+    assert G.translate(edges, variables).tiled_sampler is None         # derivatives win over the wish
+
+
+def test_host_build_of_a_tiled_translation_is_the_untiled_fragment(tmp_path, monkeypatch):
+    """The tile exists on the device only; the host build of the same unit must compile and shade exactly what the untiled text shades"""
+    import numpy as np
+
+    from oracle import binding as O
+    from tests.jit_host import HostFragment
+    text = "void main() { vec4 s = vec4(0); for (int k = -3; k <= 3; k++) s += texture(background, astuv + vec2(k, k)/64.0); fragColor = s/7.0; }"
+    data = np.random.default_rng(3).integers(0, 256, (24, 32, 4), dtype=np.uint8)
+    images = []
+    for tile in ("1", "0"):
+        monkeypatch.setenv("SHADERFLOW_JIT_TILE", tile)
+        translation = G.translate(text, [("sampler2D", "background")])
+        assert (translation.tiled_sampler is not None) == (tile == "1")
+        host = HostFragment(translation, CACHE)
+        host.set_uniforms(O.default_uniforms(40, 20))
+        host.bind("background", data, "linear", True, False)
+        images.append(host.render_float(40, 20))
+    assert np.array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
