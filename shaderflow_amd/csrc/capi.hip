@@ -901,6 +901,7 @@ template <int KIND> static int launch_separable(const RenderArgs& a, int ssaa, i
         const Tex& sp = a.tex[TEX_SPECTROGRAM];
         if (sp.width != 1 || sp.filter != FILTER_NEAREST) return 0;
     }
+    if (KIND == SEP_WAVEFORM && a.hr > 0xffff) return 0;              // its column entries pack a first row and a row count into 16 bits each
     const size_t bytes = (size_t)frames*((size_t)a.wr + a.hr)*sizeof(float4);
     if (ctx->vis_tables_bytes < bytes) {
         hipStreamSynchronize(s);
@@ -913,7 +914,11 @@ template <int KIND> static int launch_separable(const RenderArgs& a, int ssaa, i
     t.rows = t.columns + (size_t)frames*a.wr;
     hipLaunchKernelGGL(k_separable_axis<KIND>, dim3((a.wr + a.hr + 255)/256, frames), dim3(256), 0, s, a, t);
     g_last_kernel = std::string("k_separable_fused<") + (KIND == SEP_BARS ? "bars" : (KIND == SEP_WAVEFORM ? "waveform" : "default")) + ">";
-    hipLaunchKernelGGL(k_separable_fused<KIND>, dim3((a.w + SEP_PIXELS - 1)/SEP_PIXELS, (a.h + SEP_ROWS - 1)/SEP_ROWS, frames), dim3(SEP_PIXELS), 0, s, a, t);
+    const int blocks_x = (a.w + SEP_PIXELS - 1)/SEP_PIXELS;
+    if ((long)blocks_x*((a.h + SEP_ROWS_LARGE - 1)/SEP_ROWS_LARGE)*frames >= 2048)
+        hipLaunchKernelGGL((k_separable_fused<KIND, SEP_ROWS_LARGE>), dim3(blocks_x, (a.h + SEP_ROWS_LARGE - 1)/SEP_ROWS_LARGE, frames), dim3(SEP_PIXELS), 0, s, a, t);
+    else
+        hipLaunchKernelGGL((k_separable_fused<KIND, SEP_ROWS_SMALL>), dim3(blocks_x, (a.h + SEP_ROWS_SMALL - 1)/SEP_ROWS_SMALL, frames), dim3(SEP_PIXELS), 0, s, a, t);
     return 1;
 }
 

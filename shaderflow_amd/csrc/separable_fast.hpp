@@ -25,12 +25,43 @@
 namespace sf {
 
 enum : int { SEP_BARS = 0, SEP_WAVEFORM = 1, SEP_DEFAULT = 2 };
-constexpr int SEP_ROWS = 4, SEP_PIXELS = 256;
+constexpr int SEP_PIXELS = 256;
+// Output rows a block walks with its column entries in registers: 32 where the launch has blocks to spare (the entries are
+// fetched once per 32 rows and the rows leave in one sweep), 8 for small launches (a single 1080p frame is 272 blocks of 32 rows)
+constexpr int SEP_ROWS_LARGE = 32, SEP_ROWS_SMALL = 8;
 
 struct SepTables {
     float4* columns;                     // [frame][wr]
     float4* rows;                        // [frame][hr]
 };
+
+// astuv.y of sample row j (vertex/default.glsl:1-17 for one coordinate, glsl.hpp make_varyings) and the number of rows below a height
+__device__ __forceinline__ float row_astuv(int j, int hr, float inv_hr) { return ((pixel_centre(j, hr, inv_hr)*2.0f - 1.0f) + 1.0f)/2.0f; }
+__device__ __forceinline__ int rows_below(float height, int hr, float inv_hr) {
+    int lo = 0, hi = hr;                           // rows [0, lo) are below, rows [hi, hr) are not (a NaN height: none is)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (row_astuv(mid, hr, inv_hr) < height) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// gluv.y of sample row j, and the rows with abs(gluv.y) < amplitude as first row | count << 16 (none for an amplitude <= 0 or NaN)
+__device__ __forceinline__ float row_gluv(int j, int hr, float inv_hr) { return pixel_centre(j, hr, inv_hr)*2.0f - 1.0f; }
+__device__ __forceinline__ int rows_inside(float amplitude, int hr, float inv_hr) {
+    int lo = 0, hi = hr;                           // first row with gluv.y > -amplitude
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (row_gluv(mid, hr, inv_hr) > -amplitude) hi = mid; else lo = mid + 1;
+    }
+    const int first = lo;
+    lo = 0; hi = hr;                               // first row with gluv.y >= amplitude
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (row_gluv(mid, hr, inv_hr) < amplitude) lo = mid + 1; else hi = mid;
+    }
+    return first | (((lo > first) ? lo - first : 0) << 16);
+}
 
 // thread k < wr builds column k, thread wr + k builds row k, of frame blockIdx.y
 template <int KIND>
@@ -53,7 +84,12 @@ __global__ __launch_bounds__(256) void k_separable_axis(const RenderArgs a, cons
             // texture(iSpectrogram, astuv.yx): any astuv.y picks the one column, astuv.x the bin (bars.frag:9)
             const vec2 s = texture_xy(tex[TEX_SPECTROGRAM], vec2{0.5f, as});
             const vec2 intensity = {sf::sqrt(s.x)/120.0f, sf::sqrt(s.y)/120.0f};                                   // :10
-            e = make_float4(intensity.x, intensity.y, (intensity.y + intensity.x)/2.0f, 0.4f*(intensity.x + intensity.y));   // :14-17
+            // :14-17 compare astuv.y with three heights. astuv.y does not decrease with the sample row, so `astuv.y < height` is
+            // `row < T(height)` with T = the number of rows below the height: three row counts per column instead of a float
+            // comparison per supersample and channel (rows_below searches the very row function the row entries come from).
+            const float mean = (intensity.y + intensity.x)/2.0f;
+            e = make_float4(__int_as_float(rows_below(intensity.x, a.hr, a.inv_hr)), __int_as_float(rows_below(intensity.y, a.hr, a.inv_hr)),
+                            __int_as_float(rows_below(mean, a.hr, a.inv_hr)), 0.4f*(intensity.x + intensity.y));
         } else {
             e = make_float4(as, 1.0f - as, 0.0f, 0.0f);
         }
@@ -67,7 +103,10 @@ __global__ __launch_bounds__(256) void k_separable_axis(const RenderArgs a, cons
     } else {
         if (column) {
             const vec2 w = texture_xy(tex[TEX_WAVEFORM], vec2{as, 0.0f});                                          // waveform.frag:6
-            e = make_float4(w.x, w.y, (w.x + w.y)/2.0f, 0.0f);                                                     // :13-15
+            // :13-15 compare abs(gluv.y) with three amplitudes. gluv.y does not decrease with the sample row, so `abs(gluv.y) < amplitude`
+            // (-amplitude < gluv.y < amplitude) holds on one run of rows: its first row and its length per column and channel
+            e = make_float4(__int_as_float(rows_inside(w.x, a.hr, a.inv_hr)), __int_as_float(rows_inside(w.y, a.hr, a.inv_hr)),
+                            __int_as_float(rows_inside((w.x + w.y)/2.0f, a.hr, a.inv_hr)), 0.0f);
         } else {
             e = make_float4(sf::abs(g), 0.0f, 0.0f, 0.0f);                                                         // abs(gluv.y), :13
         }
@@ -109,22 +148,20 @@ __device__ __forceinline__ uint32_t default_texel(const float4 c, const float4 r
     return pack_rgb8(col);
 }
 
-template <int KIND> __device__ __forceinline__ uint32_t separable_texel(const float4 c, const float4 r) {
-    vec3 col;
-    if (KIND == SEP_BARS) {                                           // bars.frag:11-18 on (intensity.x, .y, mean, 0.4*sum) and (astuv.y, 1 - astuv.y)
-        col.x = (r.x < c.x) ? 1.0f : 0.0f;
-        col.y = (r.x < c.y) ? 1.0f : 0.0f;
-        col.z = ((r.x < c.z) ? 1.0f : 0.0f) + c.w*r.y;
-    } else {                                                          // waveform.frag:10-15
-        col.x = (r.x < c.x) ? 1.0f : 0.2f;
-        col.y = (r.x < c.y) ? 1.0f : 0.2f;
-        col.z = (r.x < c.z) ? 1.0f : 0.2f;
-    }
-    return pack_rgb8(col);
+// which samples of the 2 x 2 block at sample row j0 are inside the runs of its two columns (bit y*2 + x, the block's texel order)
+__device__ __forceinline__ bool row_in_run(int run, int j) { return (unsigned)(j - (run & 0xffff)) < ((unsigned)run >> 16); }
+__device__ __forceinline__ int wave_pattern(int run0, int run1, int j0) {
+    return (row_in_run(run0, j0) ? 1 : 0) | (row_in_run(run1, j0) ? 2 : 0) | (row_in_run(run0, j0 + 1) ? 4 : 0) | (row_in_run(run1, j0 + 1) ? 8 : 0);
+}
+// how many of the sample rows j0, j0 + 1 are among the first `below` rows (one v_med3_i32)
+__device__ __forceinline__ int rows_of_pair(int below, int j0) { const int n = below - j0; return (n < 0) ? 0 : ((n > 2) ? 2 : n); }
+// bars.frag:17, the blue channel of one sample as the iScreen texel's byte (bits 16-23): (below the mean ? 1 : 0) + 0.4*sum*(1 - astuv.y)
+__device__ __forceinline__ uint32_t blue_texel(float below, float ramp, float one_minus_y) {
+    return __builtin_amdgcn_cvt_pk_u8_f32((below + ramp*one_minus_y)*255.0f, 2u, 0u);
 }
 
 // S == 2. grid (ceil(w/SEP_PIXELS), ceil(h/SEP_ROWS), frames), block SEP_PIXELS threads.
-template <int KIND>
+template <int KIND, int SEP_ROWS>
 __global__ __launch_bounds__(SEP_PIXELS) void k_separable_fused(const RenderArgs a, const SepTables t) {
     __shared__ __attribute__((aligned(16))) uint8_t staged[SEP_ROWS][SEP_PIXELS*3];
     const int frame = blockIdx.z;
@@ -135,6 +172,18 @@ __global__ __launch_bounds__(SEP_PIXELS) void k_separable_fused(const RenderArgs
     const float4* rows = t.rows + (long)frame*a.hr;
     const int i0 = (2*px < a.wr) ? 2*px : a.wr - 1, i1 = (2*px + 1 < a.wr) ? 2*px + 1 : a.wr - 1;
     const float4 c0 = columns[i0], c1 = columns[i1];
+    // waveform.frag: every channel of a sample is 1 or 0.2, so a pixel's byte is a function of WHICH of its four samples are inside
+    // the wave: sixteen blocks, resolved once per thread block by the chain every kernel uses
+    __shared__ uint8_t inside_lut[16];
+    if constexpr (KIND == SEP_WAVEFORM) {
+        if (tid < 16) {
+            uint32_t pattern[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) pattern[k] = unorm8(((tid >> k) & 1) ? 1.0f : 0.2f);
+            inside_lut[tid] = (uint8_t)resolve_channel_any<2>(pattern, a.subsample, 0);
+        }
+        __syncthreads();
+    }
     const float tau = a.dyn ? a.dyn[a.frame0 + frame].iTau : a.u.iTau;
     const float hue_shift = (2.0f*TAU*tau) - (PI/4.0f);               // default.glsl:22, the generic chain's operations
     (void)hue_shift;
@@ -144,25 +193,57 @@ __global__ __launch_bounds__(SEP_PIXELS) void k_separable_fused(const RenderArgs
         if (py >= a.h) break;
         const float4 r0 = rows[2*py], r1 = rows[2*py + 1];            // block-uniform: scalar loads
         uint32_t block[4];                                             // texel order y*2 + x (render_kernels.hpp)
-        if constexpr (KIND == SEP_DEFAULT) {
+        uint32_t rgb;                                                  // the output pixel, red in the low byte
+        if constexpr (KIND == SEP_BARS) {
+            // red and green are 0 or 1 per supersample: the resolve of such a block is exact in every step — the sum of the four
+            // texels/255 is their count, count/4 is exact, and the unorm8 write of it is RN(count*63.75) for either kernel size
+            // (the 1-tap kernel's weights are 0.25 each) — so the byte is a function of how many of the pixel's four samples lie
+            // below the column's height: min(max(T - first row, 0), 2) per column.
+            const int j0 = 2*py;
+            const int red = rows_of_pair(__float_as_int(c0.x), j0) + rows_of_pair(__float_as_int(c1.x), j0);
+            const int green = rows_of_pair(__float_as_int(c0.y), j0) + rows_of_pair(__float_as_int(c1.y), j0);
+            // blue adds the ramp 0.4*(sum)*(1 - astuv.y) (bars.frag:17): the generic chain on that channel alone
+            const int t0 = __float_as_int(c0.z), t1 = __float_as_int(c1.z);
+            block[0] = blue_texel((j0 < t0) ? 1.0f : 0.0f, c0.w, r0.y); block[1] = blue_texel((j0 < t1) ? 1.0f : 0.0f, c1.w, r0.y);
+            block[2] = blue_texel((j0 + 1 < t0) ? 1.0f : 0.0f, c0.w, r1.y); block[3] = blue_texel((j0 + 1 < t1) ? 1.0f : 0.0f, c1.w, r1.y);
+            rgb = __builtin_amdgcn_cvt_pk_u8_f32((float)red*63.75f, 0u, resolve_channel_any<2>(block, a.subsample, 16) << 16);
+            rgb = __builtin_amdgcn_cvt_pk_u8_f32((float)green*63.75f, 1u, rgb);
+        } else if constexpr (KIND == SEP_WAVEFORM) {
+            const int j0 = 2*py;
+            rgb = (uint32_t)inside_lut[wave_pattern(__float_as_int(c0.x), __float_as_int(c1.x), j0)]
+                | ((uint32_t)inside_lut[wave_pattern(__float_as_int(c0.y), __float_as_int(c1.y), j0)] << 8)
+                | ((uint32_t)inside_lut[wave_pattern(__float_as_int(c0.z), __float_as_int(c1.z), j0)] << 16);
+        } else {
             block[0] = default_texel(c0, r0, hue_shift); block[1] = default_texel(c1, r0, hue_shift);
             block[2] = default_texel(c0, r1, hue_shift); block[3] = default_texel(c1, r1, hue_shift);
-        } else {
-            block[0] = separable_texel<KIND>(c0, r0); block[1] = separable_texel<KIND>(c1, r0);
-            block[2] = separable_texel<KIND>(c0, r1); block[3] = separable_texel<KIND>(c1, r1);
+            rgb = resolve_channel_any<2>(block, a.subsample, 0) | (resolve_channel_any<2>(block, a.subsample, 8) << 8) | (resolve_channel_any<2>(block, a.subsample, 16) << 16);
         }
         uint8_t* s = &staged[r][tid*3];
-        s[0] = (uint8_t)resolve_channel_any<2>(block, a.subsample, 0);
-        s[1] = (uint8_t)resolve_channel_any<2>(block, a.subsample, 8);
-        s[2] = (uint8_t)resolve_channel_any<2>(block, a.subsample, 16);
+        s[0] = (uint8_t)rgb; s[1] = (uint8_t)(rgb >> 8); s[2] = (uint8_t)(rgb >> 16);
     }
-    (void)inside;
     __syncthreads();
     uint8_t* out = (uint8_t*)a.out + (long)frame*a.out_frame_stride;
+    // a full-width block of a frame whose rows are whole 16-byte groups: the block's rows leave as one sweep of 16-byte stores
+    // by all threads (the staged rows are contiguous in LDS, 48 groups each) instead of 48 threads per row, row after row
+    constexpr int GROUPS = SEP_PIXELS*3/16;
+    const int x0 = blockIdx.x*SEP_PIXELS;
+    if (x0 + SEP_PIXELS <= a.w && (a.w*3) % 16 == 0 && ((uintptr_t)out & 15) == 0) {
+        const int rows_here = min(SEP_ROWS, a.h - (int)blockIdx.y*SEP_ROWS);
 #pragma unroll
+        for (int i = 0; i < (SEP_ROWS*GROUPS + SEP_PIXELS - 1)/SEP_PIXELS; i++) {
+            const int k = tid + i*SEP_PIXELS, r = k/GROUPS, c = k - r*GROUPS;
+            if (r < rows_here) {
+                const int py = blockIdx.y*SEP_ROWS + r;
+                uint8_t* row = out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3 + (long)x0*3;
+                ((uint4*)row)[c] = ((const uint4*)&staged[0][0])[k];
+            }
+        }
+        return;
+    }
+#pragma unroll 1
     for (int r = 0; r < SEP_ROWS; r++) {
         const int py = blockIdx.y*SEP_ROWS + r;
-        if (py < a.h) store_rgb_row(out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3, blockIdx.x*SEP_PIXELS, a.w, staged[r], tid, SEP_PIXELS, SEP_PIXELS);
+        if (py < a.h) store_rgb_row(out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3, x0, a.w, staged[r], tid, SEP_PIXELS, SEP_PIXELS);
     }
 }
 

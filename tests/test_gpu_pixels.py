@@ -453,3 +453,30 @@ def test_float16_textures_and_render_targets_bit_exact(gpu):
     wide = O.render_to("video", u, {0: O.make_texture(data, "linear", True, True)}, w, h, 4, np.float16)
     got = gpu.render(prog, w, h, comps=4, dtype=np.float16)
     assert np.array_equal(got.view(np.uint16), wide.view(np.uint16))
+
+
+@pytest.mark.parametrize("name", ["bars", "waveform"])
+@pytest.mark.parametrize("w,h,subsample,gain", [(600, 362, 2, 3.0), (1279, 717, 1, 40.0), (257, 33, 2, 0.2)])
+def test_separable_audio_fragments_equal_the_generic_fused_kernel(gpu, name, w, h, subsample, gain, monkeypatch):
+    """k_separable_fused<bars|waveform> (per-column tables; bars: row counts instead of float comparisons, red and green resolved from
+    the count of samples below the bar; waveform: runs of rows and a table of the sixteen 2 x 2 patterns) against the generic fused
+    kernel shading every supersample (SHADERFLOW_SEPARABLE=0): the same bytes, on odd sizes, with bars from far below the frame to far
+    above it and non-finite spectrogram values (negative power: sqrt gives NaN) — and both within 1 LSB of render + resolve passes"""
+    u, arrays, params = visualizer_inputs(w, h, seed=77, volume=0.6)
+    u.iSSAA = 2.0
+    spectrogram = arrays["iSpectrogram"].astype(np.float32)*gain
+    flat = spectrogram.reshape(-1)
+    flat[3] = -1.0; flat[10] = np.inf; flat[17] = np.nan; flat[24] = 0.0; flat[31] = 120.0**2; flat[38] = np.float32(120.0**2)*np.float32(0.25)
+    arrays["iSpectrogram"] = spectrogram
+    prog, _ = gpu.program(name)
+    gpu.set_uniforms(prog, u)
+    for key in ("iSpectrogram", "iWaveform"):
+        gpu.bind(prog, key + "0x0", gpu.texture(arrays[key], *params[key]))
+    fused = gpu.render_resolve(prog, w, h, 2, subsample)
+    assert _last_kernel(gpu) == f"k_separable_fused<{name}>", _last_kernel(gpu)
+    monkeypatch.setenv("SHADERFLOW_SEPARABLE", "0")
+    generic = gpu.render_resolve(prog, w, h, 2, subsample)
+    assert _last_kernel(gpu).startswith("k_render_resolve<"), _last_kernel(gpu)
+    assert np.array_equal(fused, generic), lsb_report(fused, generic)
+    two_pass = gpu.resolve(gpu.render(prog, 2*w, 2*h), w, h, subsample)
+    assert_within_lsb(fused, two_pass)
