@@ -480,3 +480,23 @@ def test_separable_audio_fragments_equal_the_generic_fused_kernel(gpu, name, w, 
     assert np.array_equal(fused, generic), lsb_report(fused, generic)
     two_pass = gpu.resolve(gpu.render(prog, 2*w, 2*h), w, h, subsample)
     assert_within_lsb(fused, two_pass)
+
+
+@pytest.mark.parametrize("name", ["bars", "waveform"])
+def test_separable_audio_fragments_at_8k_where_blocks_walk_32_rows(gpu, name, monkeypatch):
+    """A launch with more than 2 048 blocks takes the 32-rows-per-block instance of k_separable_fused (the benchmark's batches of
+    60 4K frames do; no smaller test frame does): one 7680x4320 frame at 2x, whole frame against the generic fused kernel"""
+    w, h = 7680, 4320
+    u, arrays, params = visualizer_inputs(w, h, seed=78, volume=0.8)
+    u.iSSAA = 2.0
+    prog, _ = gpu.program(name)
+    gpu.set_uniforms(prog, u)
+    for key in ("iSpectrogram", "iWaveform"):
+        gpu.bind(prog, key + "0x0", gpu.texture(arrays[key], *params[key]))
+    fused = gpu.render_resolve(prog, w, h, 2, 2)
+    assert _last_kernel(gpu) == f"k_separable_fused<{name}>", _last_kernel(gpu)
+    monkeypatch.setenv("SHADERFLOW_SEPARABLE", "0")
+    generic = gpu.render_resolve(prog, w, h, 2, 2)
+    assert _last_kernel(gpu).startswith("k_render_resolve<"), _last_kernel(gpu)
+    assert np.array_equal(fused, generic)
+    assert len(np.unique(fused[::16, ::16].reshape(-1, 3), axis=0)) > 4     # not a blank frame
