@@ -836,7 +836,8 @@ template <class FRAGMENT> struct JitShader<FRAGMENT, false, true> : PlainShader<
         if (w <= 0 || h <= 0) { w = 0; h = 0; return; }             // the probes took no tap
         constexpr int WIDEST = rt::TILE_TEXELS/4;
         if (w > WIDEST) { x0 += (w - WIDEST)/2; w = WIDEST; }
-        if (w*h > rt::TILE_TEXELS) { const int fit = rt::TILE_TEXELS/w; y0 += (h - fit)/2; h = fit; }
+        const int fit = rt::TILE_TEXELS/w;                           // (a probe that tapped far away on both sides: h up to 2^25, w*h would overflow)
+        if (h > fit) { y0 += (h - fit)/2; h = fit; }
     }
     template <int N> __device__ static void setup(const RenderArgs&, const Tex*, const Frag& f, State (&state)[N], const bool (&)[N], Shared& sh, int corner_tid) {
         const int tid = threadIdx.y*blockDim.x + threadIdx.x, nthreads = blockDim.x*blockDim.y;

@@ -535,3 +535,33 @@ def test_a_fragment_that_never_taps_the_tiled_sampler_still_renders(gpu, monkeyp
     ix = np.floor(columns*96).astype(int)
     iy = np.floor((np.arange(h) + 0.5)/h*54).astype(int)
     assert np.array_equal(on[:, inside], data[iy][:, ix[inside]])
+
+
+def test_tiled_sampler_with_taps_far_away_on_both_sides(gpu, monkeypatch):
+    """A probe whose taps span the whole clamped coordinate range (+-2^24 texels each way): the box is cropped to the tile's capacity
+    about its centre without overflowing, and every tap — near ones, far ones outside the crop — equals the untiled translation's
+    (the host build is no reference here: float -> int conversion of such coordinates saturates on the device and does not on x86)"""
+    text = """
+    uniform float far = 1.0e9;
+    void main() {
+        vec4 sum = vec4(0.0);
+        for (int k = -3; k <= 3; k++) sum += texture(background, astuv*0.05 + vec2(k, -k)/96.0);
+        sum += texture(background, vec2(far, far)) + texture(background, vec2(-far, -far)) + texture(background, vec2(far, -far)*1.0e30);
+        fragColor = sum/10.0;
+    }
+    """
+    data = _tile_texture("rgba8", np.random.default_rng(11))
+    w, h = 130, 21
+    frames = {}
+    for tile in ("1", "0"):
+        monkeypatch.setenv("SHADERFLOW_JIT_TILE", tile)
+        prog, translation = load(gpu, text, [("sampler2D", "background")])
+        assert (translation.tiled_sampler == "background") == (tile == "1")
+        gpu.set_uniforms(prog, O.default_uniforms(w, h))
+        for repeat in (True, False):
+            gpu.bind(prog, "background", gpu.texture(data, "linear", repeat, repeat))
+            frames[tile, repeat] = gpu.render(prog, w, h, comps=4, dtype=np.float32)
+        N.check(gpu.lib.sfx_program_destroy(prog))
+    for repeat in (True, False):
+        assert np.array_equal(frames["1", repeat].view(np.uint32), frames["0", repeat].view(np.uint32)), repeat
+        assert frames["1", repeat].std() > 0.01
