@@ -829,9 +829,11 @@ template <class FRAGMENT> struct JitShader<FRAGMENT, false, true> : PlainShader<
     };
     __device__ static void pre(const RenderArgs&, const Frag& f, bool, State& s) { s.agluv = f.agluv; }
     __device__ static int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+    __device__ static int least(int a, int b) { return (b < a) ? b : a; }      // (sf::min / sf::max are the float ones)
+    __device__ static int most(int a, int b) { return (a < b) ? b : a; }
     __device__ static void rectangle(const Shared& sh, int& x0, int& y0, int& w, int& h) {
-        const int lo_x = uniform(min(sh.box[0][0], sh.box[1][0])), lo_y = uniform(min(sh.box[0][1], sh.box[1][1]));
-        const int hi_x = uniform(max(sh.box[0][2], sh.box[1][2])), hi_y = uniform(max(sh.box[0][3], sh.box[1][3]));
+        const int lo_x = uniform(least(sh.box[0][0], sh.box[1][0])), lo_y = uniform(least(sh.box[0][1], sh.box[1][1]));
+        const int hi_x = uniform(most(sh.box[0][2], sh.box[1][2])), hi_y = uniform(most(sh.box[0][3], sh.box[1][3]));
         x0 = lo_x; y0 = lo_y; w = hi_x - lo_x + 1; h = hi_y - lo_y + 1;
         if (w <= 0 || h <= 0) { w = 0; h = 0; return; }             // the probes took no tap
         constexpr int WIDEST = rt::TILE_TEXELS/4;
@@ -875,7 +877,7 @@ template <class FRAGMENT> struct JitShader<FRAGMENT, false, true> : PlainShader<
         s.tile_.texels = sh.texels; s.tile_.record = nullptr;
         s.tile_.x0 = x0; s.tile_.y0 = y0; s.tile_.w = w;
         s.tile_.nearest_w = (unsigned)w; s.tile_.nearest_h = (unsigned)h;
-        s.tile_.linear_w = (unsigned)max(w - 1, 0); s.tile_.linear_h = (unsigned)max(h - 1, 0);
+        s.tile_.linear_w = (unsigned)most(w - 1, 0); s.tile_.linear_h = (unsigned)most(h - 1, 0);
         s.load_user_();
         s.main_();
         if (s.discarded_) return {0.0f, 0.0f, 0.0f, 0.0f};

@@ -592,9 +592,38 @@ class _Translator:
 _TEXTURE_CALLS = r"(?:texture|textureLod|gtexture|gmtexture|stexture|astexture|agtexture|agmtexture)"
 
 
+def _closing_in_text(code: str, at: int, opening: str, closing: str) -> int:
+    """index just past the bracket that closes the one at `at`"""
+    depth = 0
+    for k in range(at, len(code)):
+        if code[k] == opening:
+            depth += 1
+        elif code[k] == closing:
+            depth -= 1
+            if depth == 0:
+                return k + 1
+    return len(code)
+
+
+def _loop_bodies(code: str) -> list[tuple[int, int]]:
+    """(first, last) text ranges of the header and body of every for / while loop"""
+    ranges = []
+    for match in re.finditer(r"\b(?:for|while)\s*\(", code):
+        header_end = _closing_in_text(code, match.end() - 1, "(", ")")
+        rest = code[header_end:]
+        body = header_end + len(rest) - len(rest.lstrip())
+        if body < len(code) and code[body] == "{":
+            end = _closing_in_text(code, body, "{", "}")
+        else:
+            semicolon = code.find(";", body)
+            end = len(code) if semicolon < 0 else semicolon + 1
+        ranges.append((match.start(), end))
+    return ranges
+
+
 def _sampler_worth_a_tile(code: str, samplers: list[Binding]) -> Optional[Binding]:
-    """The sampler a tap-heavy fragment reads most (a blur or feedback kernel: taps inside a loop, or eight and more written
-    out), or None. SHADERFLOW_JIT_TILE=0 turns the tile off, =<sampler name> forces it for that sampler.
+    """The sampler a tap-heavy fragment reads most (a blur or feedback kernel: taps inside the text of a loop, or eight and more
+    written out), or None. SHADERFLOW_JIT_TILE=0 turns the tile off, =<sampler name> forces it for that sampler.
 
     The tile costs one extra evaluation of the fragment per block (jit_runtime.hpp JitShader::setup) and never changes a
     result, so the choice is about speed only: a single tap does not pay for the probe."""
@@ -604,13 +633,13 @@ def _sampler_worth_a_tile(code: str, samplers: list[Binding]) -> Optional[Bindin
     forced = [b for b in samplers if b.name == wish or (b.name.endswith("0x0") and b.name[:-3] == wish)]
     if forced:
         return forced[0]
-    loop = re.search(r"\b(?:for|while)\s*\(", code)
+    loops = _loop_bodies(code)
     best, best_score = None, 0
     for binding in samplers:
         names = {binding.name, binding.name[:-3] if binding.name.endswith("0x0") else binding.name}
         pattern = re.compile(rf"\b{_TEXTURE_CALLS}\s*\(\s*(?:{'|'.join(map(re.escape, names))})\b")
         taps = [m.start() for m in pattern.finditer(code)]
-        score = sum(16 if (loop and at > loop.start()) else 1 for at in taps)
+        score = sum(16 if any(first <= at < last for (first, last) in loops) else 1 for at in taps)
         if score > best_score:
             best, best_score = binding, score
     return best if best_score >= 8 else None

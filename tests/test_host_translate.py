@@ -428,6 +428,10 @@ def test_the_translator_asks_for_a_tile_only_where_it_can_pay(monkeypatch):
     assert f"#define SF_JIT_TILE_SLOT {slot} " in t.cpp
     assert G.translate(single, variables).tiled_sampler is None
     assert G.translate(edges, variables).tiled_sampler is None
+    after = "void main() { float a = 0; for (int k = 0; k < 4; k++) { a += k; } fragColor = a*texture(background, stuv); }"
+    assert G.translate(after, variables).tiled_sampler is None           # a loop elsewhere in the text does not make one tap many
+    braceless = "void main() { vec4 s = vec4(0); int k = 0; while (k < 4) s += texture(background, astuv + 0.01*k++); fragColor = s; }"
+    assert G.translate(braceless, variables).tiled_sampler == "background"
     assert "SF_JIT_TILE_SLOT" not in G.translate(single, variables).cpp
     assert G.translate(two, variables).tiled_sampler in ("background", "other")
     monkeypatch.setenv("SHADERFLOW_JIT_TILE", "0")
