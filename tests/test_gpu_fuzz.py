@@ -166,3 +166,91 @@ def test_resolve_random_sizes(gpu, seed):
     want = O.resolve(screen, w, h, subsample, threads=4)
     got = gpu.resolve(screen, w, h, subsample)
     assert np.array_equal(got, want), ((w, h, factor, subsample), lsb_report(got, want))
+
+
+# ---- the LDS tile of translated fragments under random maps -----------------------------------------------------------------------
+TILE_FUZZ = """
+uniform vec4 map = vec4(1.0, 0.0, 0.0, 1.0);
+uniform vec2 drift = vec2(0.0);
+uniform vec2 spacing = vec2(0.01);
+uniform int taps = 2;
+uniform float bend = 0.0;
+void main() {
+    vec2 centre = mat2(map.x, map.y, map.z, map.w)*(astuv - 0.5) + 0.5 + drift + bend*sin(7.0*astuv.yx);
+    vec4 sum = vec4(0.0);
+    for (int x = -taps; x <= taps; x++)
+        for (int y = -taps; y <= taps; y++)
+            sum += texture(background, centre + vec2(x, y)*spacing)*(1.0 + 0.1*float(x - y));
+    fragColor = sum/float((2*taps + 1)*(2*taps + 1));
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def tile_programs(gpu):
+    """the same fragment translated with and without the tile (two code objects for the whole sweep)"""
+    import ctypes as C
+    import os
+    from pathlib import Path
+
+    from shaderflow_amd import _native as N
+    from shaderflow_amd import glsl2hip
+    programs = {}
+    before = os.environ.get("SHADERFLOW_JIT_TILE")
+    for tile in ("1", "0"):
+        os.environ["SHADERFLOW_JIT_TILE"] = tile
+        translation = glsl2hip.translate(TILE_FUZZ, [("sampler2D", "background")])
+        assert (translation.tiled_sampler is not None) == (tile == "1")
+        code = glsl2hip.compile(translation, cache=Path(__file__).parent.parent/"build"/"jit")
+        names = [b.name.encode() for b in translation.bindings]
+        table = (N.Binding*len(names))(*[N.Binding(n, int(b.sampler), b.slot, b.count, int(b.integer)) for n, b in zip(names, translation.bindings)])
+        handle = N.Handle()
+        N.check(gpu.lib.sfx_program_load(gpu.ctx.handle, code, len(code), table, len(names), C.byref(handle)))
+        programs[tile] = handle
+    if before is None:
+        os.environ.pop("SHADERFLOW_JIT_TILE", None)
+    else:
+        os.environ["SHADERFLOW_JIT_TILE"] = before
+    yield programs
+    for handle in programs.values():
+        gpu.lib.sfx_program_destroy(handle)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_tiled_translated_fragment_random_maps(gpu, tile_programs, seed):
+    """Scaled, sheared, mirrored, shifted and bent tap patterns over textures of every format, both filters and wraps, on every kernel of
+    the code object (plain, fused 1x / 2x / 4x): with the tile and without it the frames are the same bytes (floats for the plain kernel),
+    whether the probed box holds all the taps (affine maps), some (bends, footprints beyond the tile's capacity) or none"""
+    rng = np.random.default_rng(4000 + seed)
+    kind = ["rgba8", "rgb8", "r32f", "rgba16"][seed % 4]
+    tw, th = int(rng.integers(3, 300)), int(rng.integers(2, 200))
+    if kind == "rgba8":
+        data = rng.integers(0, 256, (th, tw, 4), dtype=np.uint8)
+    elif kind == "rgb8":
+        data = rng.integers(0, 256, (th, tw, 3), dtype=np.uint8)
+    elif kind == "r32f":
+        data = rng.random((th, tw, 1), dtype=np.float32)
+    else:
+        data = rng.integers(0, 65536, (th, tw, 4), dtype=np.uint16)
+    filter = "linear" if rng.random() < 0.7 else "nearest"
+    repeat = (bool(rng.integers(0, 2)), bool(rng.integers(0, 2)))
+    texture = gpu.texture(data, filter, *repeat)
+    scale = float(rng.choice([0.05, 0.3, 1.0, 1.0, 2.5, -1.0]))
+    shear = float(rng.choice([0.0, 0.0, 0.2, -0.6]))
+    values = {"map": (scale, shear, -shear*float(rng.random() < 0.5), scale*float(rng.choice([1.0, 0.5, -1.0]))),
+              "drift": (float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.5, 1.5))),
+              "spacing": (float(rng.uniform(0.2, 3.0))/tw, float(rng.uniform(0.2, 3.0))/th),
+              "bend": float(rng.choice([0.0, 0.0, 0.02, 0.3]))}
+    taps = int(rng.integers(0, 5))
+    w, h = int(rng.integers(5, 400)), int(rng.integers(3, 90))
+    ssaa, subsample = [(0, 0), (1, 1), (2, 2), (2, 1), (4, 4), (4, 2)][seed % 6]
+    frames = []
+    for tile in ("1", "0"):
+        prog = tile_programs[tile]
+        gpu.set_uniforms(prog, O.default_uniforms(w, h, iSSAA=float(max(ssaa, 1))))
+        for key, value in values.items():
+            assert gpu.set_values(prog, key, value)
+        assert gpu.set_values(prog, "taps", taps, integer=True)
+        gpu.bind(prog, "background", texture)
+        frames.append(gpu.render(prog, w, h, comps=4, dtype=np.float32).view(np.uint32) if ssaa == 0 else gpu.render_resolve(prog, w, h, ssaa, subsample))
+    assert np.array_equal(frames[0], frames[1]), (kind, filter, repeat, values, taps, (w, h), (ssaa, subsample))
