@@ -634,12 +634,29 @@ def _sampler_worth_a_tile(code: str, samplers: list[Binding]) -> Optional[Bindin
     if forced:
         return forced[0]
     loops = _loop_bodies(code)
+    in_loop = lambda at: any(first <= at < last for (first, last) in loops)
+    weight = lambda at: 16 if in_loop(at) else 1
+    tap_on = lambda names: re.compile(rf"\b{_TEXTURE_CALLS}\s*\(\s*(?:{'|'.join(map(re.escape, names))})\b")
+    # helper functions that tap a sampler PARAMETER (`vec4 blur(sampler2D tex, vec2 uv) { for (…) … texture(tex, …) }`): the taps
+    # count for whatever sampler a call passes in that position, once more heavily when the call itself sits in a loop
+    helpers = []                                               # (name, position of the sampler parameter, weight of its taps)
+    for definition in re.finditer(r"\bSF_HD\s+[\w:<>]+\s+(\w+)\s*\(([^()]*)\)\s*(?:const\s*)?\{", code):
+        body_end = _closing_in_text(code, definition.end() - 1, "{", "}")
+        for position, parameter in enumerate(_split_arguments(definition.group(2))):
+            declared = re.fullmatch(r"\s*(?:const\s+)?sampler2D\s*&?\s*(\w+)\s*", parameter)
+            if declared:
+                taps = sum(weight(m.start()) for m in tap_on([declared.group(1)]).finditer(code, definition.end(), body_end))
+                if taps:
+                    helpers.append((definition.group(1), position, taps))
     best, best_score = None, 0
     for binding in samplers:
         names = {binding.name, binding.name[:-3] if binding.name.endswith("0x0") else binding.name}
-        pattern = re.compile(rf"\b{_TEXTURE_CALLS}\s*\(\s*(?:{'|'.join(map(re.escape, names))})\b")
-        taps = [m.start() for m in pattern.finditer(code)]
-        score = sum(16 if any(first <= at < last for (first, last) in loops) else 1 for at in taps)
+        score = sum(weight(m.start()) for m in tap_on(names).finditer(code))
+        for (helper, position, taps) in helpers:
+            for call in re.finditer(rf"\b{re.escape(helper)}\s*\(", code):
+                arguments = _split_arguments(code[call.end():_closing_in_text(code, call.end() - 1, "(", ")") - 1])
+                if position < len(arguments) and arguments[position].strip() in names:
+                    score += taps*weight(call.start())
         if score > best_score:
             best, best_score = binding, score
     return best if best_score >= 8 else None

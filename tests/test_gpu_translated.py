@@ -565,3 +565,32 @@ def test_tiled_sampler_with_taps_far_away_on_both_sides(gpu, monkeypatch):
     for repeat in (True, False):
         assert np.array_equal(frames["1", repeat].view(np.uint32), frames["0", repeat].view(np.uint32)), repeat
         assert frames["1", repeat].std() > 0.01
+
+
+def test_tiled_sampler_passed_to_a_helper_function(gpu):
+    """`vec4 blur(sampler2D tex, …)` called with the tiled sampler: the view travels inside the sampler value, the probe's record too"""
+    from tests.jit_host import HostFragment
+    text = """
+    vec4 blur(sampler2D tex, vec2 uv, vec2 step) {
+        vec4 s = vec4(0.0);
+        for (int k = -5; k <= 5; k++) s += texture(tex, uv + float(k)*step);
+        return s/11.0;
+    }
+    void main() {
+        vec2 texel = 1.0/vec2(textureSize(background, 0));
+        fragColor = 0.5*blur(background, astuv, vec2(texel.x, 0.0)) + 0.5*blur(background, astuv, vec2(0.0, texel.y));
+    }
+    """
+    prog, translation = load(gpu, text, [("sampler2D", "background")])
+    assert translation.tiled_sampler == "background"
+    host = HostFragment(translation, CACHE)
+    data = _tile_texture("rgb8", np.random.default_rng(21))
+    w, h = 97, 41
+    u = O.default_uniforms(w, h)
+    gpu.set_uniforms(prog, u); host.set_uniforms(u)
+    gpu.bind(prog, "background", gpu.texture(data, "linear", False, True))
+    host.bind("background", data, "linear", False, True)
+    got = gpu.render(prog, w, h, comps=4, dtype=np.float32)
+    want = host.render_float(w, h)
+    N.check(gpu.lib.sfx_program_destroy(prog))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

@@ -432,6 +432,13 @@ def test_the_translator_asks_for_a_tile_only_where_it_can_pay(monkeypatch):
     assert G.translate(after, variables).tiled_sampler is None           # a loop elsewhere in the text does not make one tap many
     braceless = "void main() { vec4 s = vec4(0); int k = 0; while (k < 4) s += texture(background, astuv + 0.01*k++); fragColor = s; }"
     assert G.translate(braceless, variables).tiled_sampler == "background"
+    # helper functions tapping a sampler parameter: the taps count for the sampler a call passes, more when the call is in a loop
+    helper = "vec4 blur(sampler2D tex, vec2 uv) { vec4 s = vec4(0); for (int k = -3; k <= 3; k++) s += texture(tex, uv + vec2(k, 0)/64.0); return s/7.0; }\n"
+    once = "vec4 one(sampler2D tex, vec2 uv) { return texture(tex, uv); }\n"
+    assert G.translate(helper + "void main() { fragColor = blur(background, astuv); }", variables).tiled_sampler == "background"
+    assert G.translate(once + "void main() { fragColor = one(background, astuv) + one(background, stuv); }", variables).tiled_sampler is None
+    assert G.translate(once + "void main() { vec4 s = vec4(0); for (int k = 0; k < 9; k++) { s += one(background, stuv + 0.01*k); } fragColor = s; }",
+                       variables).tiled_sampler == "background"
     assert "SF_JIT_TILE_SLOT" not in G.translate(single, variables).cpp
     assert G.translate(two, variables).tiled_sampler in ("background", "other")
     monkeypatch.setenv("SHADERFLOW_JIT_TILE", "0")
