@@ -546,8 +546,8 @@ def test_tiled_sampler_with_taps_far_away_on_both_sides(gpu, monkeypatch):
     void main() {
         vec4 sum = vec4(0.0);
         for (int k = -3; k <= 3; k++) sum += texture(background, astuv*0.05 + vec2(k, -k)/96.0);
-        sum += texture(background, vec2(far, far)) + texture(background, vec2(-far, -far)) + texture(background, vec2(far, -far)*1.0e30);
-        fragColor = sum/10.0;
+        sum += texture(background, vec2(far, far)) + texture(background, vec2(-far, -far));
+        fragColor = vec4(sum.rgb/9.0, texture(background, vec2(far, -far)*1.0e30).a);      // infinite coordinates: a NaN, kept out of rgb
     }
     """
     data = _tile_texture("rgba8", np.random.default_rng(11))
@@ -558,13 +558,14 @@ def test_tiled_sampler_with_taps_far_away_on_both_sides(gpu, monkeypatch):
         prog, translation = load(gpu, text, [("sampler2D", "background")])
         assert (translation.tiled_sampler == "background") == (tile == "1")
         gpu.set_uniforms(prog, O.default_uniforms(w, h))
+        assert gpu.set_values(prog, "far", 1.0e9)                  # (sfx_program_load knows no initialisers: ShaderProgram applies them)
         for repeat in (True, False):
             gpu.bind(prog, "background", gpu.texture(data, "linear", repeat, repeat))
             frames[tile, repeat] = gpu.render(prog, w, h, comps=4, dtype=np.float32)
         N.check(gpu.lib.sfx_program_destroy(prog))
     for repeat in (True, False):
         assert np.array_equal(frames["1", repeat].view(np.uint32), frames["0", repeat].view(np.uint32)), repeat
-        assert frames["1", repeat].std() > 0.01
+        assert np.isfinite(frames["1", repeat][..., :3]).all() and frames["1", repeat][..., :3].std() > 0.01
 
 
 def test_tiled_sampler_passed_to_a_helper_function(gpu):
