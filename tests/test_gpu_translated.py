@@ -486,6 +486,7 @@ def test_tiled_sampler_gives_the_bits_of_the_host_build(gpu, kind, filter, repea
     N.check(gpu.lib.sfx_program_destroy(prog))
     same = got.view(np.uint32) == want.view(np.uint32)
     assert same.all(), f"{int((~same).sum())} of {same.size} floats differ; first at {np.argwhere(~same)[0].tolist()}"
+    assert np.isfinite(got).all() and got[..., 0].std() > 0.01         # a picture, not NaNs agreeing with NaNs
 
 
 def test_tiled_and_untiled_translations_write_the_same_frames(gpu, monkeypatch):
@@ -500,8 +501,9 @@ def test_tiled_and_untiled_translations_write_the_same_frames(gpu, monkeypatch):
         for (ssaa, subsample) in ((1, 1), (2, 2), (2, 1), (4, 4), (4, 2)):
             w, h = 301, 37
             gpu.set_uniforms(prog, O.default_uniforms(w, h, iTime=0.4, iSSAA=float(ssaa)))
-            gpu.set_values(prog, "drift", (0.4, -0.2)); gpu.set_values(prog, "swirl", 0.3)
+            assert gpu.set_values(prog, "radius", 2.0) and gpu.set_values(prog, "drift", (0.4, -0.2)) and gpu.set_values(prog, "swirl", 0.3)
             frames[tile, ssaa, subsample] = gpu.render_resolve(prog, w, h, ssaa, subsample)
+            assert frames[tile, ssaa, subsample].std() > 5          # a picture, not a blank frame
         frames[tile, "render"] = gpu.render(prog, 131, 67)
         N.check(gpu.lib.sfx_program_destroy(prog))
     for key in [k[1:] for k in frames if k[0] == "1"]:

@@ -41,6 +41,7 @@ for taps in (2, 4, 8):
             N.check(gpu.lib.sfx_program_load(gpu.ctx.handle, code, len(code), table, len(names), C.byref(prog)))
             gpu.bind(prog, "background", gpu.texture(background, "linear", True, True))
             gpu.set_uniforms(prog, O.default_uniforms(w, h, iSSAA=float(ssaa)))
+            assert gpu.set_values(prog, "radius", 6.0)             # (initialisers are applied by ShaderProgram, not by sfx_program_load)
             dst = gpu.empty(w, h, 3)
             for _ in range(2):
                 N.check(gpu.lib.sfx_render_resolve(prog, dst, ssaa, ssaa))
@@ -54,5 +55,6 @@ for taps in (2, 4, 8):
             frames[tile] = gpu.read(dst, w, h, 3)
             line += f"  tile {tile}: {dt*1e3:8.3f} ms"
             N.check(gpu.lib.sfx_program_destroy(prog))
+        assert frames["1"].mean() > 20 and frames["1"].std() > 0.2      # a picture (a wide blur of noise is nearly flat)
         print(line, " identical" if np.array_equal(frames["0"], frames["1"]) else " DIFFERENT", flush=True)
     gpu.close()
