@@ -216,6 +216,37 @@ class Plasma(ShaderScene):
         self.shader.fragment = self.FRAGMENT
 
 
+class Bloom(ShaderScene):
+    """A picture with a glow: a fragment of its own that gathers the bright parts around every pixel with a loop of taps — the kind
+    of fragment whose sampler the kernels serve from an LDS tile (DESIGN.md §9 "Translated fragments"; `SHADERFLOW_JIT_TILE=0`
+    renders the same frames without it)"""
+    background: Optional[np.ndarray] = None
+    FRAGMENT = """
+        uniform float iGlow = 0.6;
+        void main() {
+            vec2 texel = 1.0/vec2(textureSize(background, 0));
+            float reach = 2.0 + 1.5*sin(iTime);
+            vec3 glow = vec3(0);
+            float total = 0;
+            for (int x = -4; x <= 4; x++) {
+                for (int y = -4; y <= 4; y++) {
+                    float weight = exp(-float(x*x + y*y)/8.0);
+                    vec3 tap = texture(background, astuv + vec2(x, y)*texel*reach).rgb;
+                    glow += weight*max(tap - 0.5, 0.0);
+                    total += weight;
+                }
+            }
+            fragColor = vec4(texture(background, astuv).rgb + iGlow*2.0*glow/total, 1);
+        }
+    """
+
+    def build(self):
+        super().build()
+        image = self.background if self.background is not None else synth.background_image(640, 360)
+        self.back = ShaderTexture(scene=self, name="background").from_numpy(image)
+        self.shader.fragment = self.FRAGMENT
+
+
 def make(cls, audio=None, background=None, **fields):
     """Build a scene class with its inputs set before `build()` runs (class attributes, like demo.py's Life)"""
     attrs = {}

@@ -208,7 +208,7 @@ def test_encoder_handoff_top_down_rows_and_command(tmp_path, monkeypatch, batch)
     assert np.array_equal(frames_of(flipped, w, h), want[:, ::-1])
 
 
-@pytest.mark.parametrize("name,ssaa", [("Basic", 1), ("Basic", 2), ("ShaderToy", 2), ("Mandelbrot", 1), ("RayMarch", 2), ("Plasma", 2)])
+@pytest.mark.parametrize("name,ssaa", [("Basic", 1), ("Basic", 2), ("ShaderToy", 2), ("Mandelbrot", 1), ("RayMarch", 2), ("Plasma", 2), ("Bloom", 2), ("Bloom", 1)])
 def test_clock_tape_equals_frame_loop(name, ssaa):
     """Scenes without audio modules batch through a clock-only tape (iTime/iTau/iFrame per frame on the device):
     the same kernels with the same uniform values, so the frames are identical to the python frame loop's"""
@@ -224,6 +224,22 @@ def test_clock_tape_equals_frame_loop(name, ssaa):
     assert loop.shape == tape.shape == (70, 54, 96, 3)
     assert np.array_equal(loop, tape), lsb_report(tape, loop)
     assert not np.array_equal(tape[0], tape[-1]) or name in ("Mandelbrot", "RayMarch")       # time-dependent scenes move
+
+
+@pytest.mark.parametrize("ssaa", [1, 2, 4])
+def test_bloom_scene_with_and_without_the_lds_tile(ssaa, monkeypatch):
+    """examples.scenes.Bloom through scene.main (translate, compile, bind, tape): its glow loop makes the translator ask for the LDS
+    tile; with SHADERFLOW_JIT_TILE=0 the same text compiles without it — the exported frames are the same bytes"""
+    from examples.scenes import Bloom
+    from shaderflow_amd import glsl2hip
+    assert glsl2hip.translate(Bloom.FRAGMENT, [("sampler2D", "background")]).tiled_sampler == "background"
+    kw = dict(width=200, height=112, fps=30, time=12/30, ssaa=ssaa, output=bytes)
+    tiled = frames_of(Bloom().main(**kw), 200, 112)
+    monkeypatch.setenv("SHADERFLOW_JIT_TILE", "0")
+    assert glsl2hip.translate(Bloom.FRAGMENT, [("sampler2D", "background")]).tiled_sampler is None
+    plain = frames_of(Bloom().main(**kw), 200, 112)
+    assert tiled.shape == (12, 112, 200, 3) and np.array_equal(tiled, plain), lsb_report(tiled, plain)
+    assert tiled.std() > 10 and not np.array_equal(tiled[0], tiled[-1])
 
 
 @pytest.mark.parametrize("ssaa", [1, 2])
