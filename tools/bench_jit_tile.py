@@ -24,14 +24,22 @@ void main() {
     fragColor = sum/total;
 }
 """
+import argparse
+parser = argparse.ArgumentParser(description=__doc__)
+parser.add_argument("--only", help="one case for a profiler: TAPS:WIDTHxHEIGHT:SSAA:TILE, e.g. 4:3840x2160:2:1")
+options = parser.parse_args()
 gpu = Gpu()
 rng = np.random.default_rng(0)
 background = rng.integers(0, 256, (1080, 1920, 4), dtype=np.uint8)
-for taps in (2, 4, 8):
-    for (w, h, ssaa) in ((1920, 1080, 2), (1920, 1080, 1), (3840, 2160, 2)):
+tap_sweep, size_sweep, tile_sweep = (2, 4, 8), ((1920, 1080, 2), (1920, 1080, 1), (3840, 2160, 2)), ("0", "1")
+if options.only:
+    taps_, size_, ssaa_, tile_ = options.only.split(":")
+    tap_sweep, size_sweep, tile_sweep = (int(taps_),), ((*map(int, size_.split("x")), int(ssaa_)),), (tile_,)
+for taps in tap_sweep:
+    for (w, h, ssaa) in size_sweep:
         line = f"{(2*taps + 1)**2:4d} taps {w}x{h} ssaa {ssaa}:"
         frames = {}
-        for tile in ("0", "1"):
+        for tile in tile_sweep:
             os.environ["SHADERFLOW_JIT_TILE"] = tile
             t = glsl2hip.translate(BLUR.replace("TAPS", str(taps)), [("sampler2D", "background")])
             code = glsl2hip.compile(t)
@@ -55,6 +63,9 @@ for taps in (2, 4, 8):
             frames[tile] = gpu.read(dst, w, h, 3)
             line += f"  tile {tile}: {dt*1e3:8.3f} ms"
             N.check(gpu.lib.sfx_program_destroy(prog))
+        if options.only:
+            print(line, flush=True)
+            continue
         assert frames["1"].mean() > 20 and frames["1"].std() > 0.2      # a picture (a wide blur of noise is nearly flat)
         print(line, " identical" if np.array_equal(frames["0"], frames["1"]) else " DIFFERENT", flush=True)
     gpu.close()
