@@ -428,10 +428,25 @@ __device__ __forceinline__ void render_resolve_body(const RenderArgs& a) {
     }
     __syncthreads();
     uint8_t* frame = (uint8_t*)a.out + (long)blockIdx.z*a.out_frame_stride;
+    // a full-width block of a frame whose rows are whole 16-byte groups: all rows leave in one sweep of 16-byte stores (the block
+    // ends one store latency after its resolve; row after row, the other waves hold the block's registers and LDS meanwhile)
+    constexpr int GROUPS = BPX*3/16;
+    if (bx*BPX + BPX <= a.w && (a.w*3) % 16 == 0 && ((uintptr_t)frame & 15) == 0) {
+        const int rows_here = min(ROWS, a.h - by*ROWS);
+        for (int e = tid; e < ROWS*GROUPS; e += (int)blockDim.x) {
+            const int r = e/GROUPS, c = e - r*GROUPS;
+            if (r < rows_here) {
+                const int y = by*ROWS + r;
+                uint8_t* row = frame + (long)(a.top_down ? a.h - 1 - y : y)*a.w*3 + (long)bx*BPX*3;
+                ((uint4*)row)[c] = ((const uint4*)&staged[0][0])[e];
+            }
+        }
+    } else {
 #pragma unroll
-    for (int r = 0; r < ROWS; r++) {
-        const int y = by*ROWS + r;
-        if (y < a.h) store_rgb_row(frame + (long)(a.top_down ? a.h - 1 - y : y)*a.w*3, bx*BPX, a.w, staged[r], tid, blockDim.x, BPX);
+        for (int r = 0; r < ROWS; r++) {
+            const int y = by*ROWS + r;
+            if (y < a.h) store_rgb_row(frame + (long)(a.top_down ? a.h - 1 - y : y)*a.w*3, bx*BPX, a.w, staged[r], tid, blockDim.x, BPX);
+        }
     }
     SF_TICK(a, 3);                                   // resolve + store
 }

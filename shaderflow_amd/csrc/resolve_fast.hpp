@@ -104,6 +104,15 @@ __global__ __launch_bounds__(256) void k_resolve_fast(const ResolveArgs a, const
     s[0] = (uint8_t)unorm8(r); s[1] = (uint8_t)unorm8(g); s[2] = (uint8_t)unorm8(b);
     __syncthreads();
     uint8_t* out = a.out + (long)blockIdx.z*a.out_frame_stride;
+    // full-width blocks of frames whose rows are whole 16-byte groups: one sweep of 16-byte stores for all the block's rows
+    constexpr int GROUPS = BW*3/16;
+    if ((BW*3) % 16 == 0 && i_first + BW <= a.w && (a.w*3) % 16 == 0 && ((uintptr_t)out & 15) == 0 && ((i_first*3) & 15) == 0) {
+        for (int e = tid; e < BH*GROUPS; e += BW*BH) {
+            const int row = e/GROUPS, c = e - row*GROUPS, jr = j_first + row;
+            if (jr < a.h) ((uint4*)(out + (long)(a.top_down ? a.h - 1 - jr : jr)*a.w*3 + (long)i_first*3))[c] = ((const uint4*)&staged[0][0])[e];
+        }
+        return;
+    }
 #pragma unroll
     for (int row = 0; row < BH; row++) {
         const int jr = j_first + row;

@@ -620,6 +620,9 @@ struct VisualizerStrip {
                     ysteps[r] = t.ysteps + ((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*10;
                 }
                 float xp = xr + first, xm = xr - first;
+#ifndef VIS_STRIP_SWEEP_STORE
+#define VIS_STRIP_SWEEP_STORE 1        // 0: wave 0 stores the block's rows one after the other while seven waves hold the block's LDS and registers (-6 %)
+#endif
 #ifndef VIS_STRIP_DIAG_UNROLL
 #define VIS_STRIP_DIAG_UNROLL 1
 #endif
@@ -711,6 +714,24 @@ struct VisualizerStrip {
         }
         __syncthreads();
         uint8_t* out = (uint8_t*)a.out + (long)frame*a.out_frame_stride;
+#if VIS_STRIP_SWEEP_STORE
+        // a full-width block of a frame whose rows are whole 16-byte groups: all rows leave in ONE sweep of 16-byte stores by as many
+        // threads as there are groups (216 at 2x) — the block ends a store latency after its resolve instead of nine
+        constexpr int GROUPS = BLOCK_PX*3/16;
+        if (BLOCK_PX*3 % 16 == 0 && STAGED % 16 == 0 && bx*BLOCK_PX + BLOCK_PX <= a.w && (a.w*3) % 16 == 0 && ((uintptr_t)out & 15) == 0) {
+            const int rows_here = min(PIXEL_ROWS, a.h - by*PIXEL_ROWS);
+#pragma unroll
+            for (int e = tid; e < PIXEL_ROWS*GROUPS; e += THREADS) {
+                const int r = e/GROUPS, c = e - r*GROUPS;
+                if (r < rows_here) {
+                    const int py = by*PIXEL_ROWS + r;
+                    uint8_t* row = out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3 + (long)bx*BLOCK_PX*3;
+                    ((uint4*)row)[c] = ((const uint4*)staged)[e];
+                }
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int r = 0; r < PIXEL_ROWS; r++) {
             const int py = by*PIXEL_ROWS + r;
