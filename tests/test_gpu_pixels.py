@@ -500,3 +500,25 @@ def test_separable_audio_fragments_at_8k_where_blocks_walk_32_rows(gpu, name, mo
     assert _last_kernel(gpu).startswith("k_render_resolve<"), _last_kernel(gpu)
     assert np.array_equal(fused, generic)
     assert len(np.unique(fused[::16, ::16].reshape(-1, 3), axis=0)) > 4     # not a blank frame
+
+
+@pytest.mark.parametrize("name", ["default", "bars", "mandelbrot"])
+@pytest.mark.parametrize("ssaa,subsample", [(1, 1), (2, 2), (2, 1), (4, 4)])
+def test_generic_fused_kernel_on_frames_whose_rows_leave_in_one_sweep(gpu, name, ssaa, subsample, monkeypatch):
+    """k_render_resolve (the generic fused kernel: one thread or quad per output pixel) on a width of whole 128-pixel blocks and whole
+    16-byte groups — the path where a block's rows leave in one sweep of 16-byte stores (other widths store row by row and are
+    covered above) — against the oracle's two passes, with a height that leaves the last block partial"""
+    monkeypatch.setenv("SHADERFLOW_SEPARABLE", "0")                # default / bars: the generic kernel instead of the separable one
+    w, h = 256, 37
+    u, arrays, params = visualizer_inputs(w, h, seed=33, volume=0.7, bg_size=(100, 56))
+    u.iSSAA = float(ssaa)
+    screen = O.render(name, u, oracle_textures(arrays, params), w*ssaa, h*ssaa, threads=8)
+    want = O.resolve(screen, w, h, subsample)
+    prog, _ = gpu.program(name)
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    got = gpu.render_resolve(prog, w, h, ssaa, subsample)
+    assert _last_kernel(gpu).startswith("k_render_resolve<"), _last_kernel(gpu)
+    assert_within_lsb(got, want)
+    again = gpu.render_resolve(prog, w, h, ssaa, subsample)        # determinism of the sweep
+    assert np.array_equal(got, again)
