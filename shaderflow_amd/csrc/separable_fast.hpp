@@ -187,7 +187,10 @@ __global__ __launch_bounds__(SEP_PIXELS) void k_separable_fused(const RenderArgs
     const float tau = a.dyn ? a.dyn[a.frame0 + frame].iTau : a.u.iTau;
     const float hue_shift = (2.0f*TAU*tau) - (PI/4.0f);               // default.glsl:22, the generic chain's operations
     (void)hue_shift;
-#pragma unroll
+    // (default.glsl's four polar evaluations per row are ~2.7 KB of code: 32 unrolled rows would be 89 KB, more than the 64 KB
+    // instruction cache two CUs share — its rows run as a loop of pairs; the light kinds unroll fully)
+    constexpr int ROWS_UNROLLED = (KIND == SEP_DEFAULT) ? 2 : SEP_ROWS;
+#pragma unroll ROWS_UNROLLED
     for (int r = 0; r < SEP_ROWS; r++) {
         const int py = blockIdx.y*SEP_ROWS + r;
         if (py >= a.h) break;
