@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""
+Golden frames of THE REFERENCE ITSELF, run in the build container: /root/reference's own Python (ShaderScene.main and everything
+under it, imported in place, unmodified) renders through a real desktop OpenGL — Mesa llvmpipe, "4.5 (Core Profile)", the software
+rasteriser BASELINE.json's north star names as the reference's CPU path — with the GLSL exactly as shader.py:190-239 assembles it
+(`#version 330`, typed uniforms, no rewriting). `refhost.py` says what stands in for the third parties the image lacks (moderngl's
+API over raw GL calls, a window object, the ffmpeg/ffprobe executables) and `mesa_shim.c` how the context comes to be.
+
+Two kinds of fixtures go to mesa.npz (+ mesa_4k.npz from make_golden_mesa_4k.py); no GLSL or Python text of the reference is stored:
+
+  probes   one frame of a scene built for the purpose FROM THE REFERENCE'S CLASSES (ShaderScene, ShaderTexture, Uniform): a fragment
+           file of the reference, textures and uniform overrides that the parity tests reproduce on the oracle and on the HIP
+           kernels. Stored: the iScreen texture (RGBA8, the fragment pass) and the exported frame (RGB8, after final.glsl). Same tags
+           as the older SwiftShader set (gles.npz), which stays as a second witness.
+  scenes   the reference's example scenes (examples/basic/demo.py, examples/fractals) exported with `scene.main(output=…)` as a user
+           would: audio file → numpy STFT → DynamicNumbers → GLSL → final.glsl → encoder pipe. Stored: selected frames as the
+           encoder process received them.
+
+Run:  python tests/golden/make_golden_mesa.py        (≈ 2 min on 8 cores)
+"""
+from __future__ import annotations
+
+import re
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(ROOT))
+
+import refhost  # noqa: E402
+
+refhost.install()
+
+import demo  # noqa: E402  (examples/basic/demo.py of the reference)
+from attrs import define  # noqa: E402
+from PIL import Image  # noqa: E402
+from shaderflow.module import ShaderModule  # noqa: E402
+from shaderflow.scene import ShaderScene  # noqa: E402
+from shaderflow.texture import ShaderTexture  # noqa: E402
+from shaderflow.variable import Uniform  # noqa: E402
+
+from oracle import binding as O  # noqa: E402  (only for the Uniforms field list of the parity tests' inputs)
+from shaderflow_amd import synth  # noqa: E402
+from tests.helpers import i16_to_f32, visualizer_inputs  # noqa: E402
+
+REF = refhost.REFERENCE
+SHADERS = REF/"shaderflow/resources/shaders"
+EXAMPLES = REF/"examples/basic/shaders"
+FRACTALS = REF/"examples/fractals/shaders"
+WORK = refhost.WORK
+
+GLSL_TYPE = {"iResolution": "vec2", "iMouse": "vec2", "iCameraRight": "vec3", "iCameraUpward": "vec3", "iCameraForward": "vec3",
+             "iCameraPosition": "vec3", "iCameraZenith": "vec3", "iRealtime": "bool", "iMouseInside": "bool", "iMouse1": "bool",
+             "iMouse2": "bool"}
+INTEGERS = {"iFrame", "iLayer", "iSubsample", "iCameraMode", "iCameraProjection", "iSpectrogramLength", "iSpectrogramBins",
+            "iSpectrogramSmooth", "iSpectrogramScroll", "iWaveformLength"}
+
+
+@define
+class Overrides(ShaderModule):
+    """Last module of a probe scene: its uniforms are set after every other module's (shader.py:377-385 walks the modules in order)"""
+    values: dict = None
+
+    def pipeline(self):
+        for name, value in (self.values or {}).items():
+            if isinstance(value, tuple) and isinstance(value[0], str):
+                yield Uniform(value[0], name, value[1])
+            else:
+                kind = GLSL_TYPE.get(name, "int" if name in INTEGERS else "float")
+                yield Uniform(kind, name, tuple(value) if hasattr(value, "__len__") else value)
+
+
+def probe(fragment, width: int, height: int, *, textures: dict = None, params: dict = None, uniforms: dict = None, ssaa: float = 1.0,
+          subsample: int = 2, configure=None):
+    """One frame (t = 0) of a reference ShaderScene with `fragment` as its main shader → (iScreen RGBA8, exported frame RGB8).
+    textures: name → (h, w, c) array with row 0 = bottom; params: name → (filter, repeat_x, repeat_y)"""
+    textures, params = textures or {}, params or {}
+
+    class Probe(ShaderScene):
+        def build(self):
+            for name, data in textures.items():
+                mode, repeat_x, repeat_y = params[name]
+                mode = mode if isinstance(mode, str) else ("linear" if mode else "nearest")
+                texture = ShaderTexture(scene=self, name=name, filter=mode, repeat_x=bool(repeat_x), repeat_y=bool(repeat_y))
+                texture.from_numpy(np.flipud(np.asarray(data)))             # from_numpy flips back (texture.py:327-335)
+            self.shader.fragment = fragment
+            if configure:
+                configure(self)
+            Overrides(scene=self, name="overrides", values=dict(uniforms or {}))
+
+    scene = Probe()
+    frames = refhost.export(scene, width=width, height=height, ssaa=ssaa, subsample=subsample, fps=60.0, time=1/60, tag="probe")
+    box = scene.shader.texture.get_box().texture
+    screen = np.frombuffer(box.read(), np.uint8).reshape(box.size[1], box.size[0], 4).copy()
+    return screen, frames[0].copy()
+
+
+def oracle_inputs(u: "O.Uniforms", skip=("user", "iResolution", "iWantAspect", "iSubsample", "iLayer")) -> dict:
+    """Every field of the uniforms a parity test builds, as overrides — so the frame is rendered on exactly the test's inputs"""
+    values = {}
+    for name, _ in u._fields_:
+        if name in skip:
+            continue
+        value = getattr(u, name)
+        values[name] = tuple(value) if hasattr(value, "__len__") else value
+    return values
+
+
+def main() -> None:
+    started = time.time()
+    out: dict[str, np.ndarray] = {}
+    context = refhost.Context()
+    out["meta.renderer"] = np.array(f"{context.info['GL_VERSION']} | {context.info['GL_RENDERER']}")
+    print(out["meta.renderer"])
+    inline = re.findall(r'\("""(.*?)"""\)', (REF/"examples/basic/demo.py").read_text(), flags=re.S)     # multi_child, multi_main, dynamics, audio
+
+    def keep(tag: str, screen: np.ndarray, frame: np.ndarray = None) -> None:
+        out[f"{tag}.image"] = screen
+        if frame is not None:
+            out[f"{tag}.final"] = frame
+        print(f"{tag:28s} {screen.shape[1]}x{screen.shape[0]} mean {screen[..., :3].mean():6.1f}")
+
+    # --- untextured fragments, several cameras (the tests build the same uniforms with O.default_uniforms) ----------------------------
+    cameras = {"plain": {}, "moved": dict(iCameraZoom=1.3, iCameraIsometric=0.2, iCameraPosition=(0.1, -0.05, 0.0)),
+               "stereo": dict(iCameraProjection=1, iCameraSeparation=0.07, iCameraZoom=1.2), "equirect": dict(iCameraProjection=2, iCameraZoom=0.8)}
+    for camera, kw in cameras.items():
+        keep(f"default.{camera}", *probe(SHADERS/"fragment/default.glsl", 160, 90, uniforms=dict(iTime=0.75, iTau=0.3, **kw)))
+    keep("missing", *probe(SHADERS/"fragment/missing.glsl", 96, 54, uniforms=dict(iTime=3.0, iTau=0.3)))
+    keep("shadertoy", *probe(EXAMPLES/"shadertoy.frag", 96, 54, uniforms=dict(iTime=3.0, iTau=0.3)))
+    keep("raymarch", *probe(EXAMPLES/"raymarch.frag", 160, 90))
+    keep("raymarch.moved", *probe(EXAMPLES/"raymarch.frag", 160, 90, uniforms=dict(iCameraPosition=(0.4, 0.2, -1.5), iCameraZoom=0.8)))
+    keep("mandelbrot", *probe(FRACTALS/"mandelbrot.frag", 160, 90, uniforms=dict(iQuality=0.2)))
+    keep("tetration", *probe(FRACTALS/"tetration.frag", 160, 90))
+    keep("tetration.zoomed", *probe(FRACTALS/"tetration.frag", 160, 90, uniforms=dict(iCameraZoom=2.5, iCameraPosition=(-0.7, 0.1, 0.0))))
+    keep("multi_child", *probe(inline[0], 64, 36))
+
+    # --- audio-reactive fragments on the inputs of the parity tests ----------------------------------------------------------------------
+    for volume in (0.0, 0.5, 1.2):
+        u, arrays, params = visualizer_inputs(160, 90, seed=21, volume=volume, bg_size=(120, 68))
+        keep(f"visualizer.v{volume}", *probe(EXAMPLES/"visualizer.frag", 160, 90, textures=arrays, params=params, uniforms=oracle_inputs(u)))
+        out[f"visualizer.v{volume}.args"] = np.array([21, volume, 120, 68], np.float64)
+    u, arrays, params = visualizer_inputs(128, 72, seed=5)
+    arrays["iSpectrogram"] = arrays["iSpectrogram"]*3
+    for name in ("bars", "waveform"):
+        keep(name, *probe(EXAMPLES/f"{name}.frag", 128, 72, textures=arrays, params=params, uniforms=oracle_inputs(u)))
+    keep("dynamics", *probe(inline[2], 128, 72, textures={"background": arrays["background"]}, params=params,
+                            uniforms={**oracle_inputs(u), "iShaderDynamics": ("float", 0.35)}))
+    # the visualizer at 2x SSAA through final.glsl, and unresolved without SSAA (BASELINE configs 3 and 2 in small)
+    u, arrays, params = visualizer_inputs(192, 108, seed=33, volume=0.9, bg_size=(160, 90))
+    keep("visualizer.ssaa2", *probe(EXAMPLES/"visualizer.frag", 192, 108, ssaa=2, textures=arrays, params=params,
+                                    uniforms={**oracle_inputs(u), "iSSAA": 2.0}))
+    out["visualizer.ssaa2.args"] = np.array([33, 0.9, 160, 90], np.float64)
+
+    # --- the sampler alone: one texel grid, every filter / wrap combination, coordinates beyond [0, 1] ----------------------------------
+    rng = np.random.default_rng(9)
+    texels = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+    out["sampler.texels"] = texels
+    for linear in (False, True):
+        for repeat in (False, True):
+            keep(f"sampler.{'linear' if linear else 'nearest'}.{'repeat' if repeat else 'clamp'}",
+                 *probe("void main() { fragColor = texture(probe, astuv*2.5 - 0.75); }", 70, 50, textures={"probe": texels},
+                        params={"probe": (linear, repeat, repeat)}))
+
+    # --- final.glsl on a known iScreen: the main shader copies a noise texture texel for texel (nearest), final.glsl resolves it ----------
+    screen = rng.integers(0, 256, (72, 128, 4), dtype=np.uint8)
+    out["final.screen"] = screen
+    for (fw, fh, sub) in ((64, 36, 2), (64, 36, 1), (128, 72, 2), (32, 18, 4)):
+        copied, frame = probe("void main() { fragColor = texture(noise, astuv); }", fw, fh, ssaa=128/fw, subsample=sub,
+                              textures={"noise": screen}, params={"noise": ("nearest", False, False)})
+        assert np.array_equal(copied, screen), "iScreen is not the noise texture"
+        keep(f"final.{fw}x{fh}.k{sub}", np.dstack([frame, np.full(frame.shape[:2], 255, np.uint8)]))
+
+    # =================================================================================================================================
+    # scenes, exported by scene.main() as a user would
+    # =================================================================================================================================
+    def export(tag: str, scene, *, width, height, frames, ssaa=1.0, subsample=2, fps=60.0, pick=None, **more) -> np.ndarray:
+        got = refhost.export(scene, width=width, height=height, ssaa=ssaa, subsample=subsample, fps=fps, time=frames/fps, tag="scene", **more)
+        assert got.shape[0] == frames, (tag, got.shape)
+        pick = list(range(frames)) if pick is None else list(pick)
+        out[f"scene.{tag}.index"] = np.array(pick)
+        out[f"scene.{tag}.frames"] = got[pick].copy()
+        out[f"scene.{tag}.args"] = np.array([width, height, ssaa, subsample, fps, frames], np.float64)
+        print(f"scene.{tag:22s} {width}x{height} ssaa {ssaa} {frames} frames, kept {len(pick)}, mean {got[pick].mean():6.1f}")
+        return got
+
+    export("basic", demo.Basic(), width=256, height=256, frames=6, pick=(0, 5))                                  # BASELINE config 1
+    export("shadertoy", demo.ShaderToy(), width=96, height=54, frames=3, pick=(2,))
+    export("multishader", demo.MultiShader(), width=64, height=36, frames=2, pick=(1,))
+    export("raymarch", demo.RayMarch(), width=96, height=54, frames=3, pick=(2,), ssaa=2)
+
+    # synthetic assets in place of the downloads of demo.py:16-49 (same generators the product's example scenes use)
+    street = synth.background_image(480, 270)
+    Image.fromarray(street).save(WORK/"street.png")
+    demo.Assets.street = staticmethod(lambda: WORK/"street.png")
+    export("multipass", demo.Multipass(), width=128, height=72, frames=3)
+    export("motionblur", demo.MotionBlur(), width=96, height=54, frames=14, pick=(0, 1, 8, 9, 10, 13))
+    export("dynamics", demo.Dynamics(), width=128, height=72, frames=90, pick=(0, 1, 30, 59, 61, 89))
+
+    np.random.seed(20260102)                                                   # Life.setup draws its first generation from numpy's global state
+    life = demo.Life()
+    got = export("life", life, width=128, height=72, frames=20, pick=(0, 1, 5, 6, 7, 12, 13, 19))
+    np.random.seed(20260102)
+    out["scene.life.seed"] = np.array([20260102])
+    out["scene.life.first"] = np.random.randint(0, 2, (192, 108), dtype=bool)
+
+    # audio scenes: float32 RIFF/WAVE files in place of "/path/to/audio.ogg" (demo.py:162, 176, 195)
+    P = np.load(HERE/"pipeline.npz")
+    fps, samplerate, frames = float(P["meta"][0]), int(P["meta"][1]), int(P["meta"][2])
+    clip = refhost.write_wav_f32(WORK/"pipeline.wav", i16_to_f32(P["pcm_i16"]), samplerate)
+    Image.fromarray(synth.background_image(240, 135, seed=7)).save(WORK/"ethereal.png")
+    demo.Assets.ethereal = staticmethod(lambda: WORK/"ethereal.png")
+
+    def with_audio(cls, path):
+        # spectrogram_matrix is lru_cached on the module object (spectrogram.py:194): with a second scene in the same process the
+        # cache compares two modules with attrs' generated __eq__, which recurses through module.scene.modules — start each scene clean
+        from shaderflow.audio.spectrogram import BrokenSpectrogram
+        BrokenSpectrogram.spectrogram_matrix.cache_clear()
+        scene = cls()
+        scene.initialize()
+        scene.audio._file = path            # the literal placeholder path of demo.py does not exist; `setup()` opens this one (audio/module.py:433-434)
+        return scene
+
+    export("visualizer", with_audio(demo.Visualizer, clip), width=192, height=108, ssaa=2, frames=frames, fps=fps, pick=(0, 1, 10, 40, 99, frames - 1))
+    export("visualizer.ssaa1", with_audio(demo.Visualizer, clip), width=192, height=108, ssaa=1, frames=60, fps=fps, pick=(1, 30, 59))
+    export("musicbars", with_audio(demo.MusicBars, clip), width=160, height=90, ssaa=2, frames=60, fps=fps, pick=(1, 30, 59))
+    export("waveform", with_audio(demo.Waveform, clip), width=160, height=90, ssaa=2, frames=60, fps=fps, pick=(1, 30, 59))
+
+    np.savez_compressed(HERE/"mesa.npz", **out)
+    print("mesa.npz", (HERE/"mesa.npz").stat().st_size, "bytes,", len(out), "arrays,", f"{time.time() - started:.0f} s")
+
+
+if __name__ == "__main__":
+    main()

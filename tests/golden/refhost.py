@@ -1,0 +1,641 @@
+"""
+A host for the REFERENCE ITSELF in the build container: `/root/reference`'s own Python (ShaderScene.main, ShaderProgram,
+ShaderTexture, the audio modules, ExportingHelper — unmodified, imported in place) driving a real desktop OpenGL (Mesa llvmpipe 4.5
+core, `mesa.py`) with the reference's GLSL exactly as `shader.py:190-239` assembles it.
+
+TEST INFRASTRUCTURE, build container only: the golden generators (`make_golden_mesa*.py`) import this, nothing at test time does.
+
+What stands in for what (none of it is arithmetic the parity statement rests on — the shading happens in Mesa, the audio in the
+reference's numpy code):
+
+  moderngl, _moderngl      the subset the reference calls (texture.py:261-282, 321; shader.py:324-375; exporting.py:140-174;
+                           scene.py:441) over raw OpenGL calls, following moderngl 5.12's documented behaviour: `f1` = normalised
+                           uint8, `f4` = float32 formats, pixel-store alignment 1, `Framebuffer.use()` binds and sets the viewport,
+                           `Uniform.value` uses the setter of the uniform's declared type, `read`/`read_into` default to 3 components
+  moderngl_window          a window object with `.ctx`, `.size`, `.keys` and no-op event plumbing (headless backend)
+  turbopipe                pipe(buffer, fd) = write the buffer's bytes to the fd; sync/close = nothing
+  ffmpeg, ffprobe          executables put on PATH: `ffprobe` answers sample rate / channels of a RIFF/WAVE float32 file, `ffmpeg`
+                           either copies such a file's samples to stdout (the PCM decoder of ffmpeg.py:1294-1301; float32 in,
+                           float32 out: a byte copy) or stores the rawvideo frames it receives on stdin at the output path,
+                           applying `-vf vflip` (exporting.py:94-134)
+  ordered_set, quaternion  a dict-backed ordered set; quaternions as 4-vectors with the Hamilton product (camera.py:96-102) —
+                           exact for the unrotated camera every golden scene uses (1·v·1̄ = v)
+  dearlog, cyclopts, parsenaut, imgui_bundle (+ shaderflow.temp.imgui_window, the overlay renderer), watchdog, soundcard, thefuzz, pooch, pretty_midi, fluidsynth, glfw
+                           inert stubs (logging, CLI, UI, file watching, sound devices, downloads)
+  typing.Self              from typing_extensions (python 3.10)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+import types
+import typing
+from pathlib import Path
+from unittest.mock import MagicMock
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+REFERENCE = Path("/root/reference")
+WORK = ROOT/"build"/"mesa"
+
+sys.path.insert(0, str(HERE))
+import mesa  # noqa: E402
+from mesa import GL  # noqa: E402
+
+# ------------------------------------------------------------------------------------------------------------------------------- #
+# moderngl
+
+NEAREST, LINEAR = GL["NEAREST"], GL["LINEAR"]
+NEAREST_MIPMAP_NEAREST, LINEAR_MIPMAP_LINEAR = GL["NEAREST_MIPMAP_NEAREST"], GL["LINEAR_MIPMAP_LINEAR"]
+TRIANGLE_STRIP = GL["TRIANGLE_STRIP"]
+
+
+class Error(Exception):
+    """_moderngl.Error"""
+
+
+_FORMATS = {   # dtype → (internal formats by component count, base formats, GL type, numpy dtype)
+    "f1": (("R8", "RG8", "RGB8", "RGBA8"), ("RED", "RG", "RGB", "RGBA"), "UNSIGNED_BYTE", np.uint8),
+    "f2": (("R16F", "RG16F", "RGB16F", "RGBA16F"), ("RED", "RG", "RGB", "RGBA"), "HALF_FLOAT", np.float16),
+    "f4": (("R32F", "RG32F", "RGB32F", "RGBA32F"), ("RED", "RG", "RGB", "RGBA"), "FLOAT", np.float32),
+    "u2": (("R16UI", "RG16UI", "RGB16UI", "RGBA16UI"), ("RED_INTEGER", "RG_INTEGER", "RGB_INTEGER", "RGBA_INTEGER"), "UNSIGNED_SHORT", np.uint16),
+}
+
+
+def _bytes_of(data) -> bytes:
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data).tobytes()
+    return bytes(data)
+
+
+class Texture:
+    def __init__(self, ctx: "Context", size, components: int, data=None, *, dtype: str = "f1"):
+        gl = ctx.gl
+        self.ctx, self.size, self.components, self.dtype = ctx, tuple(int(v) for v in size), int(components), dtype
+        internal, base, kind, self._numpy = _FORMATS[dtype]
+        self._internal, self._base, self._kind = GL[internal[components - 1]], GL[base[components - 1]], GL[kind]
+        handle = C.c_uint()
+        gl.glGenTextures(1, C.byref(handle))
+        self.glo = handle.value
+        gl.glBindTexture(GL["TEXTURE_2D"], self.glo)
+        payload = _bytes_of(data) if data is not None else None
+        gl.glTexImage2D(GL["TEXTURE_2D"], 0, self._internal, self.size[0], self.size[1], 0, self._base, self._kind, payload)
+        # moderngl's defaults for a new texture: LINEAR / LINEAR (NEAREST for integer formats), repeat on both axes
+        self._filter = (NEAREST, NEAREST) if dtype == "u2" else (LINEAR, LINEAR)
+        self._repeat_x = self._repeat_y = True
+        self._anisotropy = 1.0
+        self._apply()
+        assert gl.glGetError() == 0, "texture creation"
+
+    def _apply(self) -> None:
+        gl = self.ctx.gl
+        gl.glBindTexture(GL["TEXTURE_2D"], self.glo)
+        gl.glTexParameteri(GL["TEXTURE_2D"], GL["TEXTURE_MIN_FILTER"], self._filter[0])
+        gl.glTexParameteri(GL["TEXTURE_2D"], GL["TEXTURE_MAG_FILTER"], self._filter[1])
+        gl.glTexParameteri(GL["TEXTURE_2D"], GL["TEXTURE_WRAP_S"], GL["REPEAT"] if self._repeat_x else GL["CLAMP_TO_EDGE"])
+        gl.glTexParameteri(GL["TEXTURE_2D"], GL["TEXTURE_WRAP_T"], GL["REPEAT"] if self._repeat_y else GL["CLAMP_TO_EDGE"])
+
+    filter = property(lambda self: self._filter)
+    repeat_x = property(lambda self: self._repeat_x)
+    repeat_y = property(lambda self: self._repeat_y)
+    anisotropy = property(lambda self: self._anisotropy)
+
+    @filter.setter
+    def filter(self, value):
+        self._filter = (int(value[0]), int(value[1]))
+        self._apply()
+
+    @repeat_x.setter
+    def repeat_x(self, value):
+        self._repeat_x = bool(value)
+        self._apply()
+
+    @repeat_y.setter
+    def repeat_y(self, value):
+        self._repeat_y = bool(value)
+        self._apply()
+
+    @anisotropy.setter
+    def anisotropy(self, value):
+        gl = self.ctx.gl
+        self._anisotropy = float(min(max(float(value), 1.0), self.ctx.max_anisotropy))      # moderngl clamps to the context's limit
+        if self.ctx.max_anisotropy > 1.0:
+            gl.glBindTexture(GL["TEXTURE_2D"], self.glo)
+            gl.glTexParameterf(GL["TEXTURE_2D"], GL["TEXTURE_MAX_ANISOTROPY"], self._anisotropy)
+
+    def build_mipmaps(self, base: int = 0, max_level: int = 1000) -> None:
+        gl = self.ctx.gl
+        gl.glBindTexture(GL["TEXTURE_2D"], self.glo)
+        gl.glTexParameteri(GL["TEXTURE_2D"], GL["TEXTURE_BASE_LEVEL"], base)
+        gl.glTexParameteri(GL["TEXTURE_2D"], GL["TEXTURE_MAX_LEVEL"], max_level)
+        gl.glGenerateMipmap(GL["TEXTURE_2D"])
+        self._filter = (LINEAR_MIPMAP_LINEAR, LINEAR)             # moderngl sets these in build_mipmaps
+        self._apply()
+
+    def write(self, data, viewport=None, level: int = 0, alignment: int = 1) -> None:
+        gl = self.ctx.gl
+        if viewport is None:
+            x, y, w, h = 0, 0, *self.size
+        elif len(viewport) == 2:
+            x, y, (w, h) = 0, 0, viewport
+        else:
+            x, y, w, h = viewport
+        payload = _bytes_of(data)
+        expected = int(w)*int(h)*self.components*np.dtype(self._numpy).itemsize
+        if len(payload) != expected:
+            raise Error(f"data size mismatch {len(payload)} != {expected}")
+        gl.glBindTexture(GL["TEXTURE_2D"], self.glo)
+        gl.glTexSubImage2D(GL["TEXTURE_2D"], level, int(x), int(y), int(w), int(h), self._base, self._kind, payload)
+        assert gl.glGetError() == 0, "texture write"
+
+    def read(self, level: int = 0, alignment: int = 1) -> bytes:
+        gl = self.ctx.gl
+        out = np.zeros(self.size[0]*self.size[1]*self.components, self._numpy)
+        gl.glBindTexture(GL["TEXTURE_2D"], self.glo)
+        gl.glGetTexImage(GL["TEXTURE_2D"], level, self._base, self._kind, C.c_void_p(out.ctypes.data))
+        return out.tobytes()
+
+    def use(self, location: int = 0) -> None:
+        gl = self.ctx.gl
+        gl.glActiveTexture(GL["TEXTURE0"] + int(location))
+        gl.glBindTexture(GL["TEXTURE_2D"], self.glo)
+
+    def release(self) -> None:
+        if self.glo:
+            handle = C.c_uint(self.glo)
+            self.ctx.gl.glDeleteTextures(1, C.byref(handle))
+            self.glo = 0
+
+
+class Buffer:
+    def __init__(self, ctx: "Context", data=None, *, reserve: int = 0, dynamic: bool = False):
+        gl = ctx.gl
+        self.ctx = ctx
+        payload = _bytes_of(data) if data is not None else None
+        self.size = len(payload) if payload is not None else int(reserve)
+        handle = C.c_uint()
+        gl.glGenBuffers(1, C.byref(handle))
+        self.glo = handle.value
+        gl.glBindBuffer(GL["ARRAY_BUFFER"], self.glo)
+        gl.glBufferData(GL["ARRAY_BUFFER"], self.size, payload, GL["DYNAMIC_DRAW"] if dynamic else GL["STATIC_DRAW"])
+        self.mglo = self                                          # what turbopipe is handed (exporting.py:147-171)
+
+    def read(self, size: int = -1, *, offset: int = 0) -> bytes:
+        gl = self.ctx.gl
+        size = self.size - offset if size < 0 else size
+        out = C.create_string_buffer(size)
+        gl.glBindBuffer(GL["ARRAY_BUFFER"], self.glo)
+        gl.glGetBufferSubData(GL["ARRAY_BUFFER"], offset, size, out)
+        return out.raw
+
+    def write(self, data, *, offset: int = 0) -> None:
+        gl = self.ctx.gl
+        payload = _bytes_of(data)
+        gl.glBindBuffer(GL["ARRAY_BUFFER"], self.glo)
+        gl.glBufferSubData(GL["ARRAY_BUFFER"], offset, len(payload), payload)
+
+    def release(self) -> None:
+        if self.glo:
+            handle = C.c_uint(self.glo)
+            self.ctx.gl.glDeleteBuffers(1, C.byref(handle))
+            self.glo = 0
+
+
+class Framebuffer:
+    def __init__(self, ctx: "Context", color_attachments=()):
+        gl = ctx.gl
+        self.ctx = ctx
+        self.color_attachments = tuple(color_attachments) if isinstance(color_attachments, (list, tuple)) else (color_attachments,)
+        self.size = self.color_attachments[0].size
+        self.width, self.height = self.size
+        self.viewport = (0, 0, *self.size)
+        handle = C.c_uint()
+        gl.glGenFramebuffers(1, C.byref(handle))
+        self.glo = handle.value
+        gl.glBindFramebuffer(GL["FRAMEBUFFER"], self.glo)
+        for index, texture in enumerate(self.color_attachments):
+            gl.glFramebufferTexture2D(GL["FRAMEBUFFER"], GL["COLOR_ATTACHMENT0"] + index, GL["TEXTURE_2D"], texture.glo, 0)
+        status = gl.glCheckFramebufferStatus(GL["FRAMEBUFFER"])
+        if status != GL["FRAMEBUFFER_COMPLETE"]:
+            raise Error(f"framebuffer incomplete: {status:#x}")
+
+    def use(self) -> None:
+        gl = self.ctx.gl
+        gl.glBindFramebuffer(GL["FRAMEBUFFER"], self.glo)
+        gl.glViewport(*[int(v) for v in self.viewport])
+        self.ctx.fbo = self
+
+    def clear(self, red=0.0, green=0.0, blue=0.0, alpha=0.0, depth=1.0, *, viewport=None, color=None) -> None:
+        gl = self.ctx.gl
+        gl.glBindFramebuffer(GL["FRAMEBUFFER"], self.glo)
+        gl.glClearColor(float(red), float(green), float(blue), float(alpha))
+        gl.glClear(GL["COLOR_BUFFER_BIT"])
+        if self.ctx.fbo is not None:
+            gl.glBindFramebuffer(GL["FRAMEBUFFER"], self.ctx.fbo.glo)
+
+    def _read(self, target, viewport, components: int, dtype: str) -> None:
+        gl = self.ctx.gl
+        x, y, w, h = (0, 0, *self.size) if viewport is None else ((0, 0, *viewport) if len(viewport) == 2 else viewport)
+        _, base, kind, _ = _FORMATS[dtype]
+        gl.glBindFramebuffer(GL["FRAMEBUFFER"], self.glo)
+        gl.glReadPixels(int(x), int(y), int(w), int(h), GL[base[components - 1]], GL[kind], target)
+        if self.ctx.fbo is not None:
+            gl.glBindFramebuffer(GL["FRAMEBUFFER"], self.ctx.fbo.glo)
+        assert gl.glGetError() == 0, "framebuffer read"
+
+    def read(self, viewport=None, components: int = 3, *, attachment: int = 0, alignment: int = 1, dtype: str = "f1", clamp: bool = False) -> bytes:
+        x, y, w, h = (0, 0, *self.size) if viewport is None else ((0, 0, *viewport) if len(viewport) == 2 else viewport)
+        out = C.create_string_buffer(int(w)*int(h)*components*np.dtype(_FORMATS[dtype][3]).itemsize)
+        self._read(out, viewport, components, dtype)
+        return out.raw
+
+    def read_into(self, buffer, viewport=None, components: int = 3, *, attachment: int = 0, alignment: int = 1, dtype: str = "f1", write_offset: int = 0) -> None:
+        gl = self.ctx.gl
+        if isinstance(buffer, Buffer):
+            gl.glBindBuffer(GL["PIXEL_PACK_BUFFER"], buffer.glo)
+            self._read(C.c_void_p(write_offset), viewport, components, dtype)
+            gl.glBindBuffer(GL["PIXEL_PACK_BUFFER"], 0)
+        else:
+            view = (C.c_char*len(buffer)).from_buffer(buffer)
+            self._read(C.byref(view, write_offset), viewport, components, dtype)
+
+    def release(self) -> None:
+        if self.glo:
+            handle = C.c_uint(self.glo)
+            self.ctx.gl.glDeleteFramebuffers(1, C.byref(handle))
+            self.glo = 0
+
+
+class Uniform:
+    def __init__(self, program: "Program", name: str, location: int, kind: int, size: int):
+        self.program, self.name, self.location, self.kind, self.array_length = program, name, location, kind, size
+        self._value = None
+
+    @property
+    def value(self):
+        return self._value
+
+    @value.setter
+    def value(self, value) -> None:
+        gl = self.program.ctx.gl
+        gl.glUseProgram(self.program.glo)
+        mesa.set_uniform(gl, self.location, self.kind, value)
+        self._value = value
+
+
+class Program:
+    def __init__(self, ctx: "Context", vertex_shader: str, fragment_shader: str):
+        self.ctx = ctx
+        self.glo = mesa.compile_program(ctx.gl, vertex_shader, fragment_shader, error=Error)
+        self._members = {name.split("[")[0]: Uniform(self, name, location, kind, size)
+                         for name, (location, kind, size) in mesa.active_uniforms(ctx.gl, self.glo).items()}
+
+    def get(self, key: str, default=None):
+        return self._members.get(key, default)
+
+    def __getitem__(self, key: str) -> Uniform:
+        return self._members[key]
+
+    def __contains__(self, key: str) -> bool:
+        return key in self._members
+
+    def __iter__(self):
+        return iter(self._members)
+
+    def release(self) -> None:
+        pass
+
+
+class VertexArray:
+    def __init__(self, ctx: "Context", program: Program, content, skip_errors: bool = False):
+        gl = ctx.gl
+        self.ctx, self.program = ctx, program
+        handle = C.c_uint()
+        gl.glGenVertexArrays(1, C.byref(handle))
+        self.glo = handle.value
+        gl.glBindVertexArray(self.glo)
+        self.vertices = 0
+        for buffer, layout, *names in content:
+            sizes = [int(token[:-1] or 1) for token in layout.split()]        # "2f 2f": floats only, what vao_definition emits
+            assert all(token.endswith("f") for token in layout.split()), layout
+            stride = 4*sum(sizes)
+            self.vertices = buffer.size//stride
+            gl.glBindBuffer(GL["ARRAY_BUFFER"], buffer.glo)
+            offset = 0
+            for count, name in zip(sizes, names):
+                location = gl.glGetAttribLocation(program.glo, name.encode())
+                if location < 0:
+                    if not skip_errors:
+                        raise Error(f"attribute {name} not found")
+                else:
+                    gl.glEnableVertexAttribArray(location)
+                    gl.glVertexAttribPointer(location, count, GL["FLOAT"], 0, stride, offset)
+                offset += 4*count
+
+    def render(self, mode: int = GL["TRIANGLE_STRIP"], vertices: int = -1, *, first: int = 0, instances: int = -1) -> None:
+        gl = self.ctx.gl
+        gl.glUseProgram(self.program.glo)
+        gl.glBindVertexArray(self.glo)
+        count = self.vertices if vertices < 0 else vertices
+        if instances is None or instances < 0:
+            instances = 1
+        gl.glDrawArraysInstanced(mode, first, count, instances)
+        assert gl.glGetError() == 0, "draw"
+
+    def release(self) -> None:
+        pass
+
+
+class Context:
+    ANISOTROPIC_EXTENSION = os.environ.get("REFHOST_ANISOTROPY") == "1"
+    """texture.py:280 asks for 16× anisotropy on every texture, mipmapped or not. That is an EXTENSION to OpenGL 3.3 core
+    (EXT_texture_filter_anisotropic; core only since 4.6) whose filter is implementation-defined. Hardware drivers keep the
+    bilinear filter for the isotropic footprints of this path (1:1 and 2:1 minification of a full-screen quad); llvmpipe 23.2
+    switches EVERY fetch of such a texture — also magnified, non-mipmapped ones — to its elliptical weighted-average kernel, which
+    moves 5 % of Basic's values by up to 17 LSB and 44 % of the Visualizer's (measured, DESIGN §5). The goldens are generated on the
+    context WITHOUT the extension (the request clamps to 1.0 as moderngl does when the limit is 1), i.e. with the filter OpenGL 3.3
+    core §3.8.11 specifies; REFHOST_ANISOTROPY=1 turns the extension on for the comparison."""
+
+    def __init__(self):
+        self.gl = gl = mesa.entry_points()
+        self.fbo: Framebuffer | None = None
+        dims = (C.c_int*2)()
+        gl.glGetIntegerv(GL["MAX_VIEWPORT_DIMS"], dims)
+        size = C.c_int()
+        gl.glGetIntegerv(GL["MAX_TEXTURE_SIZE"], C.byref(size))
+        anisotropy = C.c_float(1.0)
+        gl.glGetFloatv(GL["MAX_TEXTURE_MAX_ANISOTROPY"], C.byref(anisotropy))
+        gl.glGetError()
+        self.max_anisotropy = max(1.0, anisotropy.value) if self.ANISOTROPIC_EXTENSION else 1.0
+        self.info = {"GL_RENDERER": gl.glGetString(GL["RENDERER"]).decode(), "GL_VERSION": gl.glGetString(GL["VERSION"]).decode(),
+                     "GL_MAX_VIEWPORT_DIMS": (dims[0], dims[1]), "GL_MAX_TEXTURE_SIZE": size.value}
+        # moderngl's fresh-context state: blending, depth test and face culling off
+        for capability in ("BLEND", "DEPTH_TEST", "CULL_FACE"):
+            gl.glDisable(GL[capability])
+
+    def program(self, vertex_shader=None, fragment_shader=None, **ignored) -> Program:
+        return Program(self, vertex_shader, fragment_shader)
+
+    def texture(self, size, components, data=None, *, samples=0, alignment=1, dtype="f1", internal_format=None) -> Texture:
+        return Texture(self, size, components, data, dtype=dtype)
+
+    def framebuffer(self, color_attachments=(), depth_attachment=None) -> Framebuffer:
+        return Framebuffer(self, color_attachments)
+
+    def buffer(self, data=None, *, reserve=0, dynamic=False) -> Buffer:
+        return Buffer(self, data, reserve=reserve, dynamic=dynamic)
+
+    def vertex_array(self, program, content, *args, skip_errors=False, **ignored) -> VertexArray:
+        return VertexArray(self, program, content, skip_errors=skip_errors)
+
+    def release(self) -> None:
+        pass
+
+
+class _KeyNames(type):
+    def __getattr__(cls, name: str) -> int:
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return 1000 + sum(ord(c) << (7*k) for k, c in enumerate(name[:8]))      # any key has a code; none is ever pressed
+
+
+class _Keys(metaclass=_KeyNames):
+    ACTION_PRESS, ACTION_RELEASE = 1, 0
+
+
+class Window:
+    """moderngl_window.context.headless.Window, as far as scene.py:144-175, 433, 462 touches it"""
+    keys = _Keys
+
+    def __init__(self, size=(16, 16), **ignored):
+        self.ctx = Context()
+        self.size = tuple(size)
+        self.fbo = None
+
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+
+    def swap_buffers(self) -> None:
+        pass
+
+    def destroy(self) -> None:
+        pass
+
+
+# ------------------------------------------------------------------------------------------------------------------------------- #
+# small third parties with behaviour
+
+class OrderedSet:
+    def __init__(self, items=()):
+        self._items = dict.fromkeys(items)
+
+    def add(self, item) -> None:
+        self._items.setdefault(item)
+
+    def discard(self, item) -> None:
+        self._items.pop(item, None)
+
+    def __iter__(self):
+        return iter(self._items)
+
+    def __len__(self):
+        return len(self._items)
+
+    def __contains__(self, item):
+        return item in self._items
+
+    def __class_getitem__(cls, item):
+        return cls
+
+
+class quaternion(np.ndarray):
+    """numpy-quaternion's scalar as a float64 4-vector (w, x, y, z): elementwise + − and scalar ×, Hamilton product between two"""
+
+    def __new__(cls, w=1.0, x=0.0, y=0.0, z=0.0):
+        return np.asarray([w, x, y, z], np.float64).view(cls)
+
+    def __mul__(self, other):
+        if isinstance(other, quaternion):
+            a, b, c, d = (float(v) for v in self)
+            e, f, g, h = (float(v) for v in other)
+            return quaternion(a*e - b*f - c*g - d*h, a*f + b*e + c*h - d*g, a*g - b*h + c*e + d*f, a*h + b*g - c*f + d*e)
+        return np.ndarray.__mul__(self, other)
+
+    def conjugate(self):
+        return quaternion(self[0], -self[1], -self[2], -self[3])
+
+
+def _quaternion_module() -> types.ModuleType:
+    module = types.ModuleType("quaternion")
+    module.quaternion = quaternion
+    module.as_float_array = lambda q: np.asarray(q, np.float64).view(np.ndarray)
+    module.as_vector_part = lambda q: np.asarray(q, np.float64).view(np.ndarray)[1:]
+    return module
+
+
+class _Logger:
+    loud = os.environ.get("REFHOST_LOG") == "1"
+
+    def __getattr__(self, name):
+        def emit(*args, **kwargs):
+            if self.loud or name in ("error", "critical"):
+                print(f"[reference:{name}]", *args, file=sys.stderr)
+            return args[0] if args else None
+        return emit
+
+
+# ------------------------------------------------------------------------------------------------------------------------------- #
+# executables on PATH
+
+_FFPROBE = r'''#!/usr/bin/env python3
+import struct, sys
+path = sys.argv[sys.argv.index("-i") + 1]
+entry = sys.argv[sys.argv.index("-show_entries") + 1]
+data = open(path, "rb").read(4096)
+at = data.index(b"fmt ") + 8
+kind, channels, rate = struct.unpack_from("<HHI", data, at)
+print(rate if "sample_rate" in entry else channels)
+'''
+
+_FFMPEG = r'''#!/usr/bin/env python3
+"""stand-in: (a) `-i file.wav -f f32le … -` → the samples of a float32 RIFF/WAVE file on stdout; (b) `-f rawvideo -s WxH -pix_fmt
+rgb24 … -i - … [-vf vflip] out` → the frames from stdin stored at `out` (raw rgb24, rows flipped when vflip is in the chain)"""
+import struct, sys
+argv = sys.argv[1:]
+inputs = [argv[k + 1] for k, a in enumerate(argv) if a == "-i"]
+if "-" in inputs and "rawvideo" in argv:
+    width, height = (int(v) for v in argv[argv.index("-s") + 1].split("x"))
+    flip = any("vflip" in a for a in argv)
+    target = [a for a in argv if not a.startswith("-")][-1]
+    if argv[-1] == "-y":
+        target = argv[-2]
+    frame = width*height*3
+    with open(target, "wb") as out:
+        while True:
+            data = sys.stdin.buffer.read(frame)
+            if len(data) < frame:
+                break
+            if flip:
+                rows = [data[r*width*3:(r + 1)*width*3] for r in range(height)]
+                data = b"".join(reversed(rows))
+            out.write(data)
+else:
+    data = open(inputs[0], "rb").read()
+    at = data.index(b"fmt ") + 8
+    kind, channels, rate, _, _, bits = struct.unpack_from("<HHIIHH", data, at)
+    assert kind == 3 and bits == 32, "the stand-in decodes float32 RIFF/WAVE only"
+    at = data.index(b"data") + 4
+    size = struct.unpack_from("<I", data, at)[0]
+    sys.stdout.buffer.write(data[at + 4:at + 4 + size])
+'''
+
+
+def _install_executables() -> None:
+    bindir = WORK/"bin"
+    bindir.mkdir(parents=True, exist_ok=True)
+    for name, text in (("ffprobe", _FFPROBE), ("ffmpeg", _FFMPEG)):
+        (bindir/name).write_text(text)
+        (bindir/name).chmod(0o755)
+    os.environ["PATH"] = f"{bindir}:{os.environ['PATH']}"
+
+
+# ------------------------------------------------------------------------------------------------------------------------------- #
+
+_installed = False
+
+
+def install() -> None:
+    """Make `import shaderflow` resolve to /root/reference with the stand-ins above in place of what the image lacks"""
+    global _installed
+    if _installed:
+        return
+    _installed = True
+    import typing_extensions
+    if not hasattr(typing, "Self"):
+        typing.Self = typing_extensions.Self
+    os.environ.setdefault("WINDOW_BACKEND", "headless")
+    for variable in ("XDG_DATA_HOME", "XDG_CONFIG_HOME", "XDG_CACHE_HOME", "XDG_STATE_HOME"):
+        os.environ[variable] = str(WORK/"xdg")
+    _install_executables()
+
+    def module(name: str, **members) -> types.ModuleType:
+        created = types.ModuleType(name)
+        created.__dict__.update(members)
+        sys.modules[name] = created
+        return created
+
+    this = sys.modules[__name__]
+    module("moderngl", **{name: getattr(this, name) for name in (
+        "Context", "Texture", "Buffer", "Framebuffer", "Program", "VertexArray", "Uniform", "Error", "NEAREST", "LINEAR",
+        "NEAREST_MIPMAP_NEAREST", "LINEAR_MIPMAP_LINEAR", "TRIANGLE_STRIP")})
+    module("_moderngl", Error=Error)
+    window = module("moderngl_window")
+    context = module("moderngl_window.context")
+    window.context = context
+    context.headless = module("moderngl_window.context.headless", Window=Window, Keys=_Keys)
+    context.base = module("moderngl_window.context.base", BaseKeys=_Keys)
+    module("turbopipe", pipe=lambda buffer, fd: _write_all(fd, buffer.read()), sync=lambda *a: None, close=lambda *a: None,
+           done=lambda *a: None)
+    module("ordered_set", OrderedSet=OrderedSet)
+    sys.modules["quaternion"] = _quaternion_module()
+    module("dearlog", logger=_Logger())
+    events = module("watchdog.events", FileSystemEventHandler=type("FileSystemEventHandler", (), {}))
+    observers = module("watchdog.observers", Observer=MagicMock(name="Observer"))
+    module("watchdog", events=events, observers=observers)
+    for name in ("soundcard", "cyclopts", "thefuzz", "thefuzz.process", "imgui_bundle", "imgui_bundle.python_backends", "pretty_midi",
+                 "parsenaut", "parsenaut._cyclopts", "pooch", "fluidsynth", "glfw"):
+        sys.modules.setdefault(name, MagicMock(name=name))
+    # the imgui overlay (scene.py:161, 856-887: realtime UI, `render_ui` is off in an export) would build GL objects of its own
+    sys.modules["shaderflow.temp.imgui_window"] = module("shaderflow.temp.imgui_window", ModernglWindowRenderer=MagicMock(name="imgui"))
+    sys.path.insert(0, str(REFERENCE))
+    sys.path.insert(0, str(REFERENCE/"examples"/"basic"))
+    patch_reference_defects()
+
+
+def patch_reference_defects() -> None:
+    """One defect of the reference snapshot keeps its own audio-file path from running at all, and is worked around HERE (the
+    reference is never edited): `BrokenAudioReader.stream` (ffmpeg.py:1294-1301) passes `self.format.value` — a str — to
+    `FFmpeg.pcm()`, whose codec class then calls `.value` on it (ffmpeg.py:682-683: AttributeError). The work-around gives the codec
+    the enum back; the command line it then yields is the one the code evidently intends (`-c:a pcm_f32le -f f32le`)."""
+    import shaderflow.ffmpeg as ffmpeg
+
+    def command(self, _ffmpeg):
+        name = ffmpeg.FFmpegPCM(self.format).value
+        yield from ("-c:a", name)
+        yield from ("-f", name.removeprefix("pcm_"))
+    ffmpeg.FFmpegAudioCodecPCM.command = command
+
+
+def _write_all(fd: int, data: bytes) -> None:
+    view = memoryview(data)
+    while len(view):
+        view = view[os.write(fd, view):]
+
+
+def write_wav_f32(path: Path, pcm: np.ndarray, samplerate: int) -> Path:
+    """(samples, channels) float32 → RIFF/WAVE format 3 (IEEE float)"""
+    import struct
+    pcm = np.ascontiguousarray(pcm, "<f4")
+    channels = pcm.shape[1]
+    payload = pcm.tobytes()
+    header = b"RIFF" + struct.pack("<I", 36 + len(payload)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 3, channels, samplerate,
+             samplerate*channels*4, channels*4, 32) + b"data" + struct.pack("<I", len(payload))
+    path.write_bytes(header + payload)
+    return path
+
+
+def export(scene, *, width: int, height: int, ssaa: float = 1.0, subsample: int = 2, fps: float = 60.0, time: float, tag: str = "export",
+           **more) -> np.ndarray:
+    """`scene.main(output=<file>)` exactly as a user calls it; returns the frames the encoder process received, (n, h, w, 3) uint8 in
+    the order ffmpeg sees them BEFORE its vflip filter (bottom-up rows — what `fbo.read` hands over, exporting.py:170-174)"""
+    target = WORK/f"{tag}.rgb"
+    if target.exists():
+        target.unlink()
+    scene.main(width=width, height=height, ssaa=ssaa, subsample=subsample, fps=fps, time=time, output=str(target), **more)
+    raw = np.fromfile(target, np.uint8)
+    target.unlink()
+    frames = raw.reshape(-1, height, width, 3)
+    return frames[:, ::-1]                                       # the stand-in applied the vflip of the filter chain: undo it

@@ -1,0 +1,234 @@
+"""
+The oracle against THE REFERENCE ITSELF: tests/golden/mesa.npz holds frames that /root/reference's own Python (ShaderScene.main and
+everything under it, unmodified) rendered in the build container through a real desktop OpenGL — Mesa llvmpipe 4.5 core, the software
+rasteriser the north star names — with its GLSL as shader.py:190-239 assembles it (`#version 330`, typed uniforms). See
+tests/golden/make_golden_mesa.py, refhost.py and mesa_shim.c for how. This is what pins the pixel half of the oracle (and, through
+the scene exports, the audio half once more, end to end); gles.npz (SwiftShader, rewritten GLSL ES) stays as a second witness in
+tests/test_oracle_gles.py. CPU only.
+
+Bounds. `max ≤ 1 LSB` wherever the measured histogram says so — most images. Where a fragment reads an 8-bit texture through the
+bilinear filter twice (a textured fragment at ssaa 1 followed by final.glsl's tent, or multipass' second layer), llvmpipe's filter —
+8 fractional bits of weight for unorm8 textures, an implementation choice OpenGL allows (≥ 4 subtexel bits) — puts up to 1.3 % of
+the values 2 LSB away, never 3; SwiftShader's images of the same inputs sit with the oracle there (tools/parity_histogram.py).
+Chaotic fragments (tetration's boundary, default.glsl's 1/circle² ring) are held to a fraction, as in the older set.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from shaderflow_amd import synth
+from tests import replay as R
+from tests.helpers import i16_to_f32, oracle_textures, visualizer_inputs
+
+G = np.load(Path(__file__).parent/"golden"/"mesa.npz")
+CAMERAS = {"plain": {}, "moved": dict(iCameraZoom=1.3, iCameraIsometric=0.2, iCameraPosition=(0.1, -0.05, 0.0)),
+           "stereo": dict(iCameraProjection=1, iCameraSeparation=0.07, iCameraZoom=1.2), "equirect": dict(iCameraProjection=2, iCameraZoom=0.8)}
+
+
+def agree(tag: str, want: np.ndarray, fraction: float = 1.0, bound: int = 1, key: str = "image") -> None:
+    got = G[f"{tag}.{key}"]
+    want = want[..., :got.shape[2]]
+    assert got.shape == want.shape, (tag, got.shape, want.shape)
+    d = np.abs(got.astype(int) - want.astype(int))
+    within = (d <= 1).mean()
+    assert within >= fraction, f"{tag}.{key}: {100*within:.3f}% within 1 LSB (max {d.max()})"
+    if fraction == 1.0 or bound > 1:
+        assert d.max() <= bound, f"{tag}.{key}: max {d.max()} LSB"
+    assert np.abs(got.astype(float).mean() - want.astype(float).mean()) < 0.25, tag       # no systematic offset
+
+
+def test_the_fixture_was_rendered_by_a_desktop_opengl():
+    assert "llvmpipe" in str(G["meta.renderer"]) and "Core Profile" in str(G["meta.renderer"])
+
+
+@pytest.mark.parametrize("camera", list(CAMERAS))
+def test_default_fragment_every_projection(camera):
+    u = O.default_uniforms(160, 90, iTime=0.75, iTau=0.3, **CAMERAS[camera])
+    screen = O.render("default", u, {}, 160, 90, threads=4)
+    fraction = {"plain": 0.996, "stereo": 0.999}.get(camera, 1.0)          # the ring: 1/circle² next to circle = 0
+    agree(f"default.{camera}", screen, fraction)
+    agree(f"default.{camera}", O.resolve(screen, 160, 90, 2), fraction, key="final")
+
+
+def test_untextured_fragments():
+    u = O.default_uniforms(96, 54, iTime=3.0, iTau=0.3)
+    got = G["shadertoy.image"]
+    assert np.array_equal(got, O.render("shadertoy", u, {}, 96, 54))
+    assert np.array_equal(G["multi_child.image"], O.render("multi_child", O.default_uniforms(64, 36), {}, 64, 36))
+    assert np.array_equal(G["raymarch.image"], O.render("raymarch", O.default_uniforms(160, 90), {}, 160, 90, threads=4))
+    assert np.array_equal(G["raymarch.moved.image"],
+                          O.render("raymarch", O.default_uniforms(160, 90, iCameraPosition=(0.4, 0.2, -1.5), iCameraZoom=0.8), {}, 160, 90, threads=4))
+    agree("mandelbrot", O.render("mandelbrot", O.default_uniforms(160, 90, iQuality=0.2), {}, 160, 90, threads=4), 0.9999, bound=2)
+
+
+def test_missing_fragment_reads_an_uninitialised_output():
+    """fragment/missing.glsl:14-18 ACCUMULATES into `fragColor`, which nothing initialised: undefined in GLSL. Drivers that start
+    outputs at zero (SwiftShader, the vendors' desktop drivers) draw the magenta checkerboard, and that is the convention of the
+    oracle and of the kernels (gles.npz pins it); Mesa's compiler treats the read as undefined and llvmpipe's image is neither
+    checkerboard nor stable. What both agree on is the alpha the shader does assign. Kept as a witness of why this fragment is
+    pinned on the other implementation."""
+    image = G["missing.image"]
+    assert (image[..., 3] == 51).all()                                         # 0.2 → 51
+    want = O.render("missing", O.default_uniforms(96, 54, iTime=3.0, iTau=0.3), {}, 96, 54)
+    assert (want[..., 3] == 51).all() and not np.array_equal(image, want)
+
+
+@pytest.mark.parametrize("volume", [0.0, 0.5, 1.2])
+def test_visualizer_with_its_radial_blur(volume):
+    """The benchmark fragment on a pure-noise background (the worst case for a filter's weight precision). At volume 0 all 91 taps
+    coincide, so llvmpipe's 8-bit weights are not averaged out: 30 of 57 600 values are 2 LSB off, SwiftShader agrees with the oracle"""
+    u, arrays, params = visualizer_inputs(160, 90, seed=21, volume=volume, bg_size=(120, 68))
+    screen = O.render("visualizer", u, oracle_textures(arrays, params), 160, 90, threads=8)
+    if volume == 0.0:
+        agree(f"visualizer.v{volume}", screen, 0.999, bound=2)
+    else:
+        agree(f"visualizer.v{volume}", screen)
+
+
+def test_visualizer_supersampled_and_resolved():
+    """BASELINE config 3 in small: visualizer.frag at 2x SSAA, then final.glsl"""
+    u, arrays, params = visualizer_inputs(192, 108, seed=33, volume=0.9, bg_size=(160, 90))
+    u.iSSAA = 2.0
+    screen = O.render("visualizer", u, oracle_textures(arrays, params), 384, 216, threads=8)
+    agree("visualizer.ssaa2", screen)
+    agree("visualizer.ssaa2", O.resolve(screen, 192, 108, 2, threads=4), key="final")
+
+
+def test_audio_texture_fragments():
+    u, arrays, params = visualizer_inputs(128, 72, seed=5)
+    arrays["iSpectrogram"] = arrays["iSpectrogram"]*3
+    for name in ("bars", "waveform"):
+        assert np.array_equal(G[f"{name}.image"], O.render(name, u, oracle_textures(arrays, params), 128, 72, threads=4)), name
+    u.user[0] = 0.35
+    agree("dynamics", O.render("dynamics", u, oracle_textures(arrays, params), 128, 72))
+
+
+@pytest.mark.parametrize("filter", ["nearest", "linear"])
+@pytest.mark.parametrize("wrap", ["clamp", "repeat"])
+def test_sampler_addressing_and_filtering(filter, wrap):
+    """texture() on a 7x5 RGBA8 grid at coordinates from -0.75 to 1.75: texel addressing, wrap modes, bilinear weights"""
+    texture = O.make_texture(G["sampler.texels"], filter, wrap == "repeat", wrap == "repeat")
+    w, h = 70, 50
+    want = np.zeros((h, w, 4), np.uint8)
+    one, half, two = np.float32(1), np.float32(0.5), np.float32(2)
+    for j in range(h):
+        for i in range(w):
+            s = np.float32(((np.float32(i) + half)/np.float32(w)*two - one + one)/two)          # vertex/default.glsl:9-10
+            t = np.float32(((np.float32(j) + half)/np.float32(h)*two - one + one)/two)
+            c = O.sample(texture, s*np.float32(2.5) - np.float32(0.75), t*np.float32(2.5) - np.float32(0.75))
+            want[j, i] = np.rint(np.clip(c, 0, 1)*255)
+    if filter == "nearest":
+        assert np.array_equal(G[f"sampler.{filter}.{wrap}.image"], want)                        # no filtering arithmetic: identical
+    else:
+        agree(f"sampler.{filter}.{wrap}", want, 0.99, bound=2)                                   # random texels: the 8-bit weights show
+
+
+def test_final_glsl_every_kernel():
+    screen = G["final.screen"]
+    for (fw, fh, sub) in ((64, 36, 2), (64, 36, 1), (128, 72, 2), (32, 18, 4)):
+        want = O.resolve(screen, fw, fh, sub)
+        got = G[f"final.{fw}x{fh}.k{sub}.image"]
+        d = np.abs(got[..., :3].astype(int) - want.astype(int))
+        assert d.max() <= (1 if fw*sub == 128 or sub == 1 else 2), (fw, fh, sub, d.max())       # taps on texel centres: ≤ 1; between: the filter's bits
+        assert (d <= 1).mean() >= 0.99, (fw, fh, sub)
+
+
+@pytest.mark.parametrize("tag,kw", [("tetration", {}), ("tetration.zoomed", dict(iCameraZoom=2.5, iCameraPosition=(-0.7, 0.1, 0.0)))])
+def test_tetration_integer_division(tag, kw):
+    """`it / MAX_STEPS` is an integer division — here compiled as one, the GLSL is not rewritten. The iteration is chaotic along the
+    fractal's boundary, where the built-ins' last bits decide between escape and hue: ≥ 99.5 % of the values within 1 LSB"""
+    agree(tag, O.render("tetration", O.default_uniforms(160, 90, **kw), {}, 160, 90, threads=4), fraction=0.995)
+
+
+# ---- the reference's example scenes, exported by scene.main() ---------------------------------------------------------------------
+
+def scene(tag: str, want: np.ndarray, fraction: float = 1.0, bound: int = 1) -> None:
+    got = G[f"scene.{tag}.frames"]
+    assert got.shape == want.shape, (tag, got.shape, want.shape)
+    for n, k in enumerate(G[f"scene.{tag}.index"]):
+        d = np.abs(got[n].astype(int) - want[n].astype(int))
+        assert d.max() <= bound and (d <= 1).mean() >= fraction, f"scene.{tag} frame {k}: max {d.max()}, {100*(d <= 1).mean():.3f}% within 1"
+
+
+def test_basic_scene_baseline_config_1():
+    scene("basic", R.plain_scene("default", 256, 256, 1, 2, 60.0, 6, pick=(0, 5)))
+
+
+def test_clock_only_scenes():
+    scene("shadertoy", R.plain_scene("shadertoy", 96, 54, 1, 2, 60.0, 3, pick=(2,)))
+    scene("raymarch", R.plain_scene("raymarch", 96, 54, 2, 2, 60.0, 3, pick=(2,)))
+    scene("multishader", R.multishader_scene(64, 36, 60.0, 2, (1,)))
+
+
+def test_layered_and_temporal_scenes():
+    street = synth.background_image(480, 270)
+    scene("multipass", R.multipass_scene(street, 128, 72, 1, 60.0, 3), 0.985, bound=2)          # two chained bilinear fetches of 8-bit textures
+    frames = R.motionblur_scene(street, 96, 54, 60.0, 14)
+    scene("motionblur", frames[[0, 1, 8, 9, 10, 13]])
+    assert not G["scene.motionblur.frames"][:3].any() and G["scene.motionblur.frames"][3].any()     # black until temporal-1 frames have been rendered
+    scene("life", R.life_scene(G["scene.life.first"], 128, 72, 60.0, 20)[[0, 1, 5, 6, 7, 12, 13, 19]])
+
+
+def test_scene_with_python_logic_between_frames():
+    scene("dynamics", R.dynamics_scene(synth.background_image(480, 270), 128, 72, 60.0, 90, (0, 1, 30, 59, 61, 89)), 0.99, bound=2)
+
+
+def test_audio_scenes_end_to_end():
+    """Audio file → the reference's numpy STFT, filterbank, DynamicNumbers, waveform → its GLSL on llvmpipe → final.glsl → the encoder
+    pipe, against the oracle's audio tape + fragments on the same clip: the north star's parity statement, reference on one side"""
+    P = np.load(Path(__file__).parent/"golden"/"pipeline.npz")
+    fps, samplerate, frames = float(P["meta"][0]), int(P["meta"][1]), int(P["meta"][2])
+    pcm, background = i16_to_f32(P["pcm_i16"]), synth.background_image(240, 135, seed=7)
+    scene("visualizer", R.audio_scene("visualizer", pcm, samplerate, background, 192, 108, 2, 2, fps, frames, pick=(0, 1, 10, 40, 99, frames - 1)), 0.9995, bound=2)
+    scene("visualizer.ssaa1", R.audio_scene("visualizer", pcm, samplerate, background, 192, 108, 1, 2, fps, 60, pick=(1, 30, 59)), 0.99, bound=2)
+    scene("musicbars", R.audio_scene("bars", pcm, samplerate, None, 160, 90, 2, 2, fps, 60, pick=(1, 30, 59), high=18000.0))
+    want = R.audio_scene("waveform", pcm, samplerate, None, 160, 90, 2, 2, fps, 60, pick=(1, 30, 59), waveform_smooth=False)
+    assert np.array_equal(G["scene.waveform.frames"], want)
+
+
+# ---- the benchmark's configuration: 3840x2160 at 2x SSAA ---------------------------------------------------------------------------
+
+def c3_inputs(name: str):
+    """The inputs tests/golden/make_golden_mesa_4k.py rendered (restated here: the generator itself needs /root/reference)"""
+    K = np.load(Path(__file__).parent/"golden"/"mesa_4k.npz")
+    seed, volume, _ = K[f"{name}.args"]
+    w, h, ssaa = (int(v) for v in K["size"])
+    u, arrays, params = visualizer_inputs(w, h, seed=int(seed), volume=float(volume), bg_size=(1920, 1080))
+    if name == "bench":
+        arrays["background"] = np.ascontiguousarray(np.flipud(synth.background_image(1920, 1080)))
+    u.iSSAA = float(ssaa)
+    return K, u, arrays, params, w, h, ssaa
+
+
+def edge_aware_check(got_row: np.ndarray, want_row: np.ndarray, screen_rows: np.ndarray, where) -> np.ndarray:
+    """`max ≤ 1 LSB`, except where ONE of the four supersamples of a pixel sits on the other side of an edge in one of the two
+    renderings: that moves the resolved value by a quarter of the supersample spread around the pixel. Returns the |difference| histogram."""
+    d = np.abs(got_row.astype(int) - want_row.astype(int))
+    block = screen_rows[:, :, :3].astype(int).reshape(2, -1, 2, 3)                # (sample row, pixel, sample column, channel)
+    high, low = block.max(axis=(0, 2)), block.min(axis=(0, 2))
+    for side in (-1, 1):                                                          # the edge may run between this pixel and its neighbour
+        high, low = np.maximum(high, np.roll(high, side, axis=0)), np.minimum(low, np.roll(low, side, axis=0))
+    allowed = np.maximum(1, (high - low)//4 + 2)
+    assert (d <= allowed).all(), (where, np.argwhere(d > allowed)[:4].tolist(), int(d.max()))
+    return np.bincount(np.minimum(d.ravel(), 3), minlength=4)
+
+
+@pytest.mark.parametrize("name", ["noise", "bench"])
+def test_benchmark_size_frames_rendered_by_the_reference(name):
+    """Whole 3840x2160 2xSSAA frames exported by the reference on llvmpipe (every 13th / 27th row kept, all columns): ≥ 99.99 % of
+    the values within 1 LSB of the oracle, none further than one supersample crossing a bar's edge explains (≈ 1 pixel in 10⁵)"""
+    K, u, arrays, params, w, h, ssaa = c3_inputs(name)
+    textures = oracle_textures(arrays, params)
+    histogram = np.zeros(4, int)
+    for n, r in list(enumerate(K[f"{name}.rows"]))[::2]:                           # every other stored row keeps the CPU suite short
+        screen = O.render("visualizer", u, textures, w*ssaa, h*ssaa, rows=(r*ssaa, (r + 1)*ssaa), threads=8)
+        want = O.resolve(screen, w, h, 2, rows=(r, r + 1))[r]
+        histogram += edge_aware_check(K[f"{name}.final"][n], want, screen[r*ssaa:(r + 1)*ssaa], (name, int(r)))
+    assert histogram[:2].sum()/histogram.sum() >= 0.9999, histogram
+    # the fragment pass alone (every 16th supersample column of three bands): before final.glsl nothing sits on an averaged edge
+    for first, last in K["bands"]:
+        screen = O.render("visualizer", u, textures, w*ssaa, h*ssaa, rows=(first*ssaa, last*ssaa), threads=8)
+        d = np.abs(screen[first*ssaa:last*ssaa, ::16].astype(int) - K[f"{name}.band{first}.screen"].astype(int))
+        assert (d <= 1).mean() >= 0.9995, (name, int(first), np.bincount(d.ravel())[:6])
