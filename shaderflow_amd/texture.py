@@ -11,8 +11,11 @@ Rules that are observable and therefore kept:
     `scene.render_resolution` (= resolution × ssaa), times `track`, at least 1×1;
   * any change of shape/format re-allocates every box (`make`); a box remembers the bytes of its last FULL
     write and gets them back when the new allocation has the same byte size;
-  * sampler state (filter, wrap) is applied to every box (`apply`); mipmaps/anisotropy are accepted and ignored —
-    the in-scope fragments sample level 0 only;
+  * sampler state (filter, wrap) is applied to every box (`apply`). `mipmaps=True` (texture.py:131-137, 277-278:
+    `build_mipmaps` + LINEAR_MIPMAP_LINEAR) is REFUSED with NotImplementedError: the kernels sample level 0 only, and rendering
+    without the mip chain would silently change pixels. `anisotropy` is accepted: without mipmaps it does not change the bilinear
+    filter of a conforming OpenGL 3.3 implementation on the isotropic footprints of a full-screen quad (llvmpipe's optional
+    EXT_texture_filter_anisotropic kernel does: measured in DESIGN.md §5 and excluded from the goldens);
   * `from_numpy` flips rows so that row 0 is the BOTTOM row, like an OpenGL upload of an image;
   * the uniforms are `<name>Size`, `<name>Layers`, `<name>Temporal` and one sampler per box, `<name>{t}x{l}`.
 """
@@ -196,6 +199,10 @@ class ShaderTexture(ShaderModule):
 
     def apply(self):
         """Push filter and wrap state to every box"""
+        if self.mipmaps:
+            raise NotImplementedError(
+                f"ShaderTexture '{self.name}': mipmaps=True (LINEAR_MIPMAP_LINEAR sampling, reference texture.py:131-137, 277-278) is not "
+                "implemented by the HIP sampler, which reads level 0 only; rendering without the mip chain would change pixels silently")
         for (_, _, box) in self.boxes:
             if box.texture is not None:
                 box.texture.params(self.filter.value, self.repeat_x, self.repeat_y)

@@ -1,0 +1,159 @@
+"""
+Whole frames at BASELINE.json's sizes, through the paths bench.py times, against the oracle ("What's weak" #2):
+the strip kernel decides per block (window fits / `blur_direct`), per wave (speculation re-runs on ballots) and per thread (the
+216-thread sweep store) — all position dependent — so bands are not enough. The oracle renders a C3 frame in seconds on the GPU
+box's host cores (`threads=os.cpu_count()`); in a small container these tests take minutes.
+
+  C3  3840x2160 2xSSAA  one loud and one silent frame by `sfx_render_resolve`; frames 300 / 1500 / 2700 of the benchmark's 60 s
+                        sweep by `sfx_render_tape` (grid.z = 60, per-frame tables) against the oracle on the oracle's own audio
+                        tape; the tape's frames byte-equal to the frame loop's single launches
+  C2  1920x1080 no SSAA both passes (strip kernel into iScreen, then the resolve kernel), whole frames, tape path
+  C4  7680x4320 4xSSAA  76 rows around block seams, top and bottom included
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from shaderflow_amd import synth
+from tests import replay as R
+from tests.helpers import Gpu, gpu_bind_all, lsb_report, oracle_textures, visualizer_inputs
+
+pytestmark = pytest.mark.gpu
+THREADS = os.cpu_count() or 8
+
+
+@pytest.fixture()
+def gpu():
+    g = Gpu()
+    yield g
+    g.close()
+
+
+def whole_frame(u, arrays, params, w, h, ssaa):
+    screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, threads=THREADS)
+    return O.resolve(screen, w, h, 2, threads=THREADS)
+
+
+@pytest.mark.parametrize("volume,seed", [(1.1, 77), (0.0, 78)])
+def test_c3_whole_frame_single_launch(gpu, volume, seed):
+    """Loud (largest blur radius the bench reaches) and silent (radius 0: every line weight in one cell), bench's background"""
+    w, h, ssaa = 3840, 2160, 2
+    u, arrays, params = visualizer_inputs(w, h, seed=seed, volume=volume, bg_size=(1920, 1080))
+    arrays["background"] = np.ascontiguousarray(np.flipud(synth.background_image(1920, 1080)))
+    u.iSSAA = float(ssaa)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    got = gpu.render_resolve(prog, w, h, ssaa, 2)
+    assert gpu.lib.sfx_last_kernel().decode().startswith("k_visualizer_strip<"), gpu.lib.sfx_last_kernel()
+    want = whole_frame(u, arrays, params, w, h, ssaa)
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1, (lsb_report(got, want), np.argwhere(d > 1)[:5].tolist())
+
+
+def prepared_scene(w, h, ssaa, pcm, background, seconds):
+    """A Visualizer scene as `scene.main()` leaves it before the first frame (bench.py does the same)"""
+    from examples.scenes import Visualizer, make
+    from shaderflow_amd.message import ShaderMessage
+    scene = make(Visualizer, audio=(pcm, 44100), background=background)
+    scene.initialize()
+    scene.exporting = scene.freewheel = scene.headless = True
+    scene.realtime = False
+    scene.fps, scene.subsample, scene.time = 60.0, 2, 0.0
+    scene.relay(ShaderMessage.Shader.Compile)
+    scene.resize(width=w, height=h)
+    for module in scene.modules:
+        module.setup()
+    scene.set_duration(seconds)
+    scene.ssaa = ssaa
+    return scene
+
+
+def test_c3_tape_frames_of_the_benchmark_clip():
+    """What bench.py times: `sfx_tape_build` + `sfx_render_tape` over batches of 60 frames of the 60 s sweep. Frames 300, 1500 and
+    2700 (the three the CPU baseline samples) against the oracle fed by the oracle's own audio tape, whole frames"""
+    from shaderflow_amd import _native as N
+    from shaderflow_amd.tape import FrameTape
+    w, h, ssaa, seconds, batch = 3840, 2160, 2, 60.0, 60
+    picks = (300, 1500, 2700)
+    pcm, background = synth.sweep_clip(seconds, 44100), synth.background_image(1920, 1080, seed=0)
+    scene = prepared_scene(w, h, ssaa, pcm, background, seconds)
+    total = picks[-1] + batch
+    tape = FrameTape(scene, batch=batch).prepare(total)
+    tape.bind_static_uniforms()
+    N.check(N.lib().sfx_tape_reset(tape.handle))
+    frame_bytes = w*h*3
+    buffer = scene.context.alloc(frame_bytes*batch)
+    got = {}
+    try:
+        for first in range(0, total, batch):                       # the recurrences run through every batch; only three are rendered
+            tape.build(first, batch)
+            inside = [k for k in picks if first <= k < first + batch]
+            if inside:
+                tape.render(batch, buffer)                          # the whole batch in one launch, as in the bench
+                assert N.lib().sfx_last_kernel().decode().startswith("k_visualizer_strip<"), N.lib().sfx_last_kernel()
+                scene.context.synchronize()
+                for k in inside:
+                    got[k] = scene.context.read(buffer + (k - first)*frame_bytes, frame_bytes).reshape(h, w, 3).copy()
+    finally:
+        scene.context.synchronize()
+        scene.context.free(buffer)
+        tape.release()
+    # the oracle's frames carry iDuration = runtime of the export: the prepared scene's duration is `seconds`
+    want = R.audio_scene("visualizer", pcm, 44100, background, w, h, ssaa, 2, 60.0, int(seconds*60), pick=picks, threads=THREADS)
+    for n, k in enumerate(picks):
+        d = np.abs(got[k].astype(int) - want[n].astype(int))
+        # tape values within 1e-5 relative feed the fragments: a supersample on a bar's edge may change sides (a quarter of the
+        # pixel's contrast); everything else within 1 LSB
+        assert (d <= 1).mean() >= 0.99999, (k, lsb_report(got[k], want[n]))
+        assert d.max() <= 66, (k, lsb_report(got[k], want[n]))
+
+
+def test_c3_tape_equals_frame_loop_launches():
+    """Frame k of a tape launch (grid.z = frames, per-frame tables read by blockIdx.z) is byte-equal to the single launch the frame
+    loop makes for the same frame with host-side uniforms — at the benchmark's size"""
+    from examples.scenes import Visualizer, make
+    w, h, ssaa, frames = 3840, 2160, 2, 4
+    pcm, background = synth.sweep_clip(1.0, 44100), synth.background_image(1920, 1080, seed=0)
+    outputs = []
+    for batch in (True, False):
+        scene = make(Visualizer, audio=(pcm, 44100), background=background)
+        raw = scene.main(width=w, height=h, ssaa=ssaa, fps=60.0, time=frames/60.0, output=bytes, batch=batch)
+        outputs.append(np.frombuffer(raw, np.uint8).reshape(frames, h, w, 3))
+    assert np.array_equal(outputs[0], outputs[1]), lsb_report(outputs[0], outputs[1])
+
+
+def test_c2_two_pass_whole_frames_through_the_tape():
+    """BASELINE config 2: 1920x1080 without SSAA is two batched passes (the strip kernel's no-SSAA instance writes iScreen, alpha
+    included; the resolve kernel applies final.glsl's 3x3 tent). Whole frames against the oracle's tape + fragments"""
+    from examples.scenes import Visualizer, make
+    w, h, frames = 1920, 1080, 40
+    pcm, background = synth.sweep_clip(1.0, 44100), synth.background_image(1920, 1080, seed=0)
+    raw = make(Visualizer, audio=(pcm, 44100), background=background).main(width=w, height=h, ssaa=1, fps=60.0, time=frames/60.0, output=bytes, batch=True)
+    got = np.frombuffer(raw, np.uint8).reshape(frames, h, w, 3)
+    picks = (1, 20, 39)
+    want = R.audio_scene("visualizer", pcm, 44100, background, w, h, 1, 2, 60.0, frames, pick=picks, threads=THREADS)
+    for n, k in enumerate(picks):
+        d = np.abs(got[k].astype(int) - want[n].astype(int))
+        assert (d <= 1).mean() >= 0.99999 and d.max() <= 66, (k, lsb_report(got[k], want[n]))
+
+
+def test_c4_rows_around_block_seams(gpu):
+    """BASELINE config 4: 7680x4320 at 4xSSAA (530.8 M supersamples); the 4x instance's blocks are 10 output rows high"""
+    w, h, ssaa = 7680, 4320, 4
+    u, arrays, params = visualizer_inputs(w, h, seed=52, volume=0.8, bg_size=(1920, 1080))
+    arrays["background"] = np.ascontiguousarray(np.flipud(synth.background_image(1920, 1080)))
+    u.iSSAA = float(ssaa)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    got = gpu.render_resolve(prog, w, h, ssaa, 2)
+    assert gpu.lib.sfx_last_kernel().decode().startswith("k_visualizer_strip<"), gpu.lib.sfx_last_kernel()
+    textures = oracle_textures(arrays, params)
+    for first, last in ((0, 16), (1070, 1094), (2150, 2166), (4300, 4320)):
+        screen = O.render("visualizer", u, textures, w*ssaa, h*ssaa, rows=(first*ssaa, last*ssaa), threads=THREADS)
+        want = O.resolve(screen, w, h, 2, rows=(first, last), threads=THREADS)[first:last]
+        d = np.abs(got[first:last].astype(int) - want.astype(int))
+        assert d.max() <= 1, (first, lsb_report(got[first:last], want))

@@ -1,9 +1,9 @@
 """
 Scene-level parity on the GPU: the python API (ShaderScene/ShaderModule/…) drives the C-ABI and the frames are
 compared with the oracle run on the oracle's own audio tape — the whole path of SURVEY.md §3.2, end to end.
-End-to-end tolerance: tape values within 1e-5 relative feed the fragments, so a pixel sitting on a branch
-boundary (bar edge, nearest-texel step) may flip; the bound is 1 LSB on ≥ 99.9 % of the values and the rest is
-reported. Stage-wise tests (test_gpu_audio / test_gpu_pixels) hold each stage to its strict bound.
+End-to-end tolerance: 1 LSB on every value (tape values within 1e-5 relative feed the fragments, so a pixel sitting on a
+branch boundary could flip in principle; none does in these scenes). Stage-wise tests (test_gpu_audio / test_gpu_pixels)
+hold each stage to its strict bound; tests/test_gpu_fullsize.py has the whole frames at the benchmark's sizes.
 """
 import numpy as np
 import pytest
@@ -54,9 +54,11 @@ def oracle_visualizer_frames(pcm, samplerate, background, w, h, ssaa, subsample,
     return np.stack(out)
 
 
-def mostly_within_one_lsb(got, want, fraction=0.999):
+def mostly_within_one_lsb(got, want, fraction=1.0):
+    """Every value within 1 LSB — the north star's bound (round 2 accepted 0.1 % beyond it; the histogram of these scenes,
+    profiles/r02_parity_histogram.txt, has no such value)"""
     d = np.abs(got.astype(np.int32) - want.astype(np.int32))
-    assert (d <= 1).mean() >= fraction, lsb_report(got, want)
+    assert d.max() <= 1 and (d <= 1).mean() >= fraction, lsb_report(got, want)
 
 
 def test_basic_scene_256(tmp_path):
@@ -96,7 +98,7 @@ def test_visualizer_frame_loop_and_tape_match_oracle(ssaa, subsample):
     raw = tape.main(width=w, height=h, fps=fps, ssaa=ssaa, subsample=subsample, time=seconds, output=bytes, batch=None)
     got_tape = frames_of(raw, w, h)
     mostly_within_one_lsb(got_tape, want)
-    mostly_within_one_lsb(got_tape, got_loop, fraction=0.9995)
+    mostly_within_one_lsb(got_tape, got_loop)
 
 
 def test_tape_is_chosen_only_for_stock_scenes():
@@ -473,3 +475,17 @@ def test_set_uniform_between_frames_is_not_masked_by_the_pipeline_cache():
     sent_before = program._pushed["iTime"]
     program._push("iTime", 1.5, "float")                              # the pipeline's unchanged value must reach the device again
     assert program._pushed["iTime"] != sent_before and program._pushed_plain["iTime"][1] == 1.5
+
+
+def test_mipmaps_are_refused_not_ignored():
+    """the HIP sampler reads level 0 only, so a texture that asks for the mip chain (texture.py:131-137, 277-278)
+    raises instead of rendering other pixels than the reference silently; anisotropy without mipmaps is accepted"""
+    from examples.scenes import Basic
+    from shaderflow_amd.texture import ShaderTexture
+    scene = Basic()
+    scene.initialize()
+    with pytest.raises(NotImplementedError, match="mipmaps"):
+        ShaderTexture(scene=scene, name="mipmapped", mipmaps=True)
+    texture = ShaderTexture(scene=scene, name="plain", anisotropy=16)
+    with pytest.raises(NotImplementedError, match="mipmaps"):
+        texture.mipmaps = True

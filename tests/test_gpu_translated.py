@@ -234,7 +234,7 @@ def test_scrolling_spectrogram_frame_loop_tape_and_replay(gpu, smooth):
         host.bind("iSpectrogram", texture.copy(), "linear" if smooth else "nearest", True, False)
         want = O.resolve(host.render(w, h), w, h, 2)
         d = np.abs(loop[k].astype(int) - want.astype(int))
-        assert (d <= 1).mean() >= 0.999, (k, lsb_report(loop[k], want))
+        assert d.max() <= 1, (k, lsb_report(loop[k], want))
 
 
 def test_scene_with_its_own_fragment_through_the_frame_tape(gpu):
