@@ -25,7 +25,8 @@ Prints ONE JSON line (rank 0): value = frames/s of the whole job, plus
                  loudly). The HBM view the contract asks for sits beside it under `hbm`: algorithmic bytes over
                  the same launch time, and `traffic` = measured FETCH_SIZE + WRITE_SIZE per launch from the same profile.
   cpu_baseline — the oracle (kind "port": plain-C restatement of the reference path) on the host cores of this box, all cores
-                 and one thread, over bands of three frames of the same workload; rank 0 at N = 1 only, BEFORE the timed region.
+                 and one thread, over bands of three frames of the same workload; rank 0 at N = 1 only, AFTER the GPU legs.
+                 `llvmpipe_container`: the reference itself (numpy FFT + its GLSL on Mesa llvmpipe), measured in the build container.
   export_host  — the same frames through a real export to /dev/null including the read-out to host memory (N = 1: pinned ring
                  + writer thread; N > 1: every rank over its own PCIe link into the shared-memory ring, "host" mode).
 """
@@ -46,7 +47,13 @@ B_ALG_PER_FRAME = {  # iScreen write + resolve read + iFinal w
 }
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 256*4*32*2.4e9    # 256 CU x 4 SIMD32 x 2.4 GHz = 78.6e12 lane-instructions/s (157.3 TFLOP/s FMA)
-PROFILE = ROOT/"profiles"/"r02_bench_c3.json"      # written by tools/profile_bench.sh → tools/summarize_profile.py
+PROFILE = ROOT/"profiles"/"r03_bench_c3.json"      # written by tools/profile_bench.sh → tools/summarize_profile.py
+# The north star's CPU baseline measured with THE REFERENCE ITSELF (its own Python + numpy FFT + its GLSL on Mesa llvmpipe), in the
+# build container — it cannot travel to the GPU box (tools/measure_reference_cpu.py, profiles/r03_reference_llvmpipe.txt). Static.
+REFERENCE_LLVMPIPE = {"value": 0.477, "unit": "frames/s", "cores": 8, "kind": "reference",
+                      "sample": "8 frames of the reference's Visualizer scene, 3840x2160 2xSSAA, scene.main() on Mesa llvmpipe 23.2.1 (LLVM 15, 256-bit), "
+                                "8 logical cores of the build container, 16.8 s; C2 (1920x1080, no SSAA): 3.70 frames/s",
+                      "where": "build container, not this box (static block)"}
 
 
 def parse_args():
@@ -183,11 +190,6 @@ def main() -> None:
     background = synth.background_image(1920, 1080, seed=0)
     scene_class = {"visualizer": Visualizer, "bars": MusicBars, "waveform": Waveform, "basic": Basic}[args.scene]
 
-    # the CPU baseline first: the timed region (and the driver's GPU sampler) comes after it
-    baseline = None
-    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.scene == "visualizer":
-        baseline = cpu_baseline(args, pcm, background)
-
     # Everything of this rank runs on ONE stream, which is also torch's current stream: RCCL orders a send after the work already
     # queued on the current stream, and a later render waits for the transfer it must not overtake. (torch's default stream has
     # the handle 0, for which the context would create a stream of its own that nothing orders with — so a real one.)
@@ -295,10 +297,24 @@ def main() -> None:
     drain()
     barrier()
     elapsed = time.perf_counter() - t0
+    dist_backend = dist.get_backend() if distributed else None
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staged else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    ranks_seen, per_rank = world, None
+    if distributed:
+        # what an 8-GPU line needs to be read: did every rank take part, how fast did each render, how much did each link carry
+        ones = torch.ones(1, dtype=torch.float64, device="cpu" if staged else "cuda")
+        dist.all_reduce(ones)
+        ranks_seen = int(round(float(ones.item())))
+        events = [context.event_elapsed_ms(2*i, 2*i + 1) for i in range(min(args.steps, 32))]
+        mine = {"rank": rank, "render_ms_per_step": round(float(np.mean(events)), 3) if events else None,
+                "render_frames_per_s": round(fpb/(float(np.mean(events))/1e3), 1) if events else None,
+                "sent_GB_per_s": (round(args.steps*fpb*frame_bytes/elapsed/1e9, 2) if rank else 0.0)}
+        per_rank = [None]*world
+        dist.all_gather_object(per_rank, mine)
 
     kernel_ms = [context.event_elapsed_ms(2*i, 2*i + 1) for i in range(min(args.steps, 32))]
     launch_s = (float(np.mean(kernel_ms))/1e3/parts) if kernel_ms else float("nan")     # one launch = `piece` frames
@@ -322,6 +338,13 @@ def main() -> None:
         export = {"value": round(frames_export/took, 2), "unit": "frames/s", "frames": frames_export, "seconds": round(took, 3),
                   "mode": ("pinned ring + writer thread" if world == 1 else f"sharded export, SHADERFLOW_SHARD={os.environ.get('SHADERFLOW_SHARD', 'host')}"),
                   "note": "whole scene.main(): tape schedule, table set-up, render, read-out over PCIe, write to /dev/null"}
+
+    # the CPU baseline LAST: the GPU legs above are what the driver's utilisation sampler should see first
+    baseline = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.scene == "visualizer":
+        baseline = cpu_baseline(args, pcm, background)
+        if (w, h, s) == (3840, 2160, 2):
+            baseline["llvmpipe_container"] = REFERENCE_LLVMPIPE
 
     if rank == 0:
         c3 = (w, h, s) == (3840, 2160, 2) and args.scene == "visualizer"
@@ -353,6 +376,7 @@ def main() -> None:
                        "frames_per_step": fpb, "global_frames_per_step": fpb*world,
                        "parallelism": f"contiguous frame range per rank x{world}" + (f", every step sent to rank 0 over {dist.get_backend()} in {parts} pieces" if distributed else ""),
                        "ranks": world, "filterbank": "mfma" if tape.use_mfma else "csr"},
+            "rccl_ranks": ranks_seen,
             "realtime_factor": round(value/60.0, 2),
             "roofline": {"bound": "valu", "kernel": kernel,
                          "achieved": round(lane_ops/1e12, 2) if lane_ops else None, "peak": round(VALU_PEAK_LANE_OPS/1e12, 1), "unit": "T lane-instr/s",
@@ -372,6 +396,13 @@ def main() -> None:
             result["cpu_baseline"] = baseline
         if export is not None:
             result["export_host"] = export
+            result["value_host"] = export["value"]                 # frames/s DELIVERED to a host sink, beside `value` (frames resident in rank 0's HBM)
+        if per_rank is not None:
+            result["per_rank"] = per_rank
+            inbound = sum(r["sent_GB_per_s"] for r in per_rank)
+            result["gather"] = {"backend": dist_backend, "pieces_per_step": parts, "inbound_GB_per_s_rank0": round(inbound, 2),
+                                "note": "sent_GB_per_s = frames a rank sent to rank 0 / the timed region: every peer has its own xGMI link to rank 0; "
+                                        "a rank whose render_frames_per_s x 24.9 MB exceeds what its link sustains is link-bound (DESIGN.md §6)"}
     else:
         result = None
 

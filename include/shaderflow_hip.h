@@ -178,10 +178,12 @@ int sfx_shm_flush(sfx_handle shm);
 /* The first `frames` frames this rank pushed have left their device buffers (a batch buffer may be rendered into again). */
 int sfx_shm_wait(sfx_handle shm, int64_t frames);
 /* Rank 0: start the writer. Frames are written to `fd` run by run: counts[k] frames of rank ranks[k], each rank's frames in the
- * order that rank pushed them. */
+ * order that rank pushed them. fd < 0: no sink — the frames are consumed in the same order and discarded. */
 int sfx_shm_drain(sfx_handle shm, int fd, const int32_t* ranks, const int32_t* counts, int runs);
 int sfx_shm_drain_wait(sfx_handle shm);      /* the writer has written every run (or failed: SFX_E_IO) */
-int sfx_shm_destroy(sfx_handle shm);         /* unmaps; rank 0 also unlinks the segment */
+int sfx_shm_abort(sfx_handle shm);           /* any rank: every process of the group stops waiting (its calls fail with SFX_E_IO) */
+int sfx_shm_unlink(sfx_handle shm);          /* rank 0, after every rank has mapped the segment: its name goes, a crash cannot leak it */
+int sfx_shm_destroy(sfx_handle shm);         /* unmaps; rank 0 also unlinks the segment if sfx_shm_unlink did not */
 
 /* ------------------------------------------------------------------------------------------------ */
 /* Audio — replaces BrokenAudio's ring (audio/module.py:113-138), np.hanning/np.fft.rfft/csr.dot

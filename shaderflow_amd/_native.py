@@ -112,6 +112,8 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_shm_wait": (C.c_int, [Handle, C.c_int64]),
     "sfx_shm_drain": (C.c_int, [Handle, C.c_int, P(C.c_int32), P(C.c_int32), C.c_int]),
     "sfx_shm_drain_wait": (C.c_int, [Handle]),
+    "sfx_shm_abort": (C.c_int, [Handle]),
+    "sfx_shm_unlink": (C.c_int, [Handle]),
     "sfx_shm_destroy": (C.c_int, [Handle]),
     "sfx_flac_info": (C.c_int, [C.c_void_p, C.c_size_t, P(C.c_int64), P(C.c_int), P(C.c_int), P(C.c_int)]),
     "sfx_flac_decode": (C.c_int, [C.c_void_p, C.c_size_t, P(C.c_float), C.c_int64, P(C.c_int64)]),

@@ -212,17 +212,22 @@ class HostDelivery:
 
         from shaderflow_amd import _native as N
         self.N, self.C = N, C
-        self.rank, self.world, self.frame_bytes, self.pushed = rank, world, frame_bytes, 0
+        self.rank, self.world, self.frame_bytes, self.pushed, self.failed = rank, world, frame_bytes, 0, False
         name = [f"/shaderflow-{os.getpid()}-{id(self) & 0xffffff:x}", shm_slots_that_fit(frame_bytes, slots, world)]
         if world > 1:
             dist.broadcast_object_list(name, src=0)                 # one segment name and one ring size for the group
         slots = int(name[1])
         self.handle = N.Handle()
         N.check(N.lib().sfx_shm_create(context.handle, name[0].encode(), rank, world, frame_bytes, slots, C.byref(self.handle)))
+        if world > 1:
+            dist.barrier()                                          # every rank has mapped the segment …
         if rank == 0:
+            N.check(N.lib().sfx_shm_unlink(self.handle))            # … so its name can go: a crash leaves nothing in /dev/shm
+            # without a sink (fileno None: a benchmark or a freewheeling run under torchrun) the writer still consumes every frame,
+            # in the same order, and discards it — producers would otherwise fill their rings and wait for a consumer that never comes
             ranks = (C.c_int32*max(1, len(runs)))(*[r for r, _ in runs])
             counts = (C.c_int32*max(1, len(runs)))(*[c for _, c in runs])
-            N.check(N.lib().sfx_shm_drain(self.handle, -1 if fileno is None else fileno, ranks, counts, len(runs) if fileno is not None else 0))
+            N.check(N.lib().sfx_shm_drain(self.handle, -1 if fileno is None else fileno, ranks, counts, len(runs)))
 
     def push(self, pointer: int, count: int) -> None:
         for i in range(count):
@@ -233,14 +238,24 @@ class HostDelivery:
         """The first `frames` frames pushed by this rank have left their device buffers"""
         self.N.check(self.N.lib().sfx_shm_wait(self.handle, frames))
 
+    def abort(self) -> None:
+        """This rank cannot go on (an exception is propagating): every process of the group stops waiting for its frames"""
+        self.failed = True
+        self.N.lib().sfx_shm_abort(self.handle)
+
     def finish(self) -> None:
         import torch.distributed as dist
+        done = False
         try:
-            self.N.check(self.N.lib().sfx_shm_flush(self.handle))
-            if self.rank == 0:
-                self.N.check(self.N.lib().sfx_shm_drain_wait(self.handle))
+            if not self.failed:
+                self.N.check(self.N.lib().sfx_shm_flush(self.handle))
+                if self.rank == 0:
+                    self.N.check(self.N.lib().sfx_shm_drain_wait(self.handle))
+                done = True
         finally:
-            if self.world > 1:
+            if not done:
+                self.N.lib().sfx_shm_abort(self.handle)             # the peers' pushes and the writer fail at once instead of timing out
+            elif self.world > 1:
                 dist.barrier()                                      # nobody unmaps while the writer still reads
             self.N.lib().sfx_shm_destroy(self.handle)
 
@@ -260,18 +275,22 @@ def interleaved_host_export(world: int, rank: int, batches: list[tuple[int, int]
         delivery.push(buffer, count) / delivery.wait(frames)
     """
     marks: list[int] = []                                            # frames pushed after each of this rank's batches
-    for index, (first, count) in enumerate(batches):
-        if index % world != rank:
-            advance(first, count, None)
-            continue
-        mine = len(marks)
-        if mine >= len(buffers):
-            delivery.wait(marks[mine - len(buffers)])               # the batch that last lived in this buffer has been copied out
-        buffer = buffers[mine % len(buffers)]
-        advance(first, count, buffer)
-        render(count, buffer)
-        delivery.push(buffer, count)
-        marks.append(delivery.pushed)
+    try:
+        for index, (first, count) in enumerate(batches):
+            if index % world != rank:
+                advance(first, count, None)
+                continue
+            mine = len(marks)
+            if mine >= len(buffers):
+                delivery.wait(marks[mine - len(buffers)])           # the batch that last lived in this buffer has been copied out
+            buffer = buffers[mine % len(buffers)]
+            advance(first, count, buffer)
+            render(count, buffer)
+            delivery.push(buffer, count)
+            marks.append(delivery.pushed)
+    except BaseException:
+        delivery.abort()                                            # a producer that raises tells the others now, not after their time-out
+        raise
 
 
 # ---- device mode: contiguous ranges, resident in HBM, sent to rank 0 ---------------------------------------------------------

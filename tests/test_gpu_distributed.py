@@ -70,6 +70,55 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_export(tmp_path, name
     assert sharded == whole, f"{np.count_nonzero(np.frombuffer(sharded, np.uint8) != np.frombuffer(whole, np.uint8))} bytes differ"
 
 
+def _rank_without_sink(rank: int, world: int, port: int, fail_on: int):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", RANK=str(rank), WORLD_SIZE=str(world), SHADERFLOW_SHARD="host",
+                      SHADERFLOW_SHM_SLOTS="5", SHADERFLOW_SHM_TIMEOUT="20")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = _build("Visualizer")
+    if rank == fail_on:
+        from shaderflow_amd.tape import FrameTape
+        render, calls = FrameTape.render, []
+
+        def broken(self, count, device_out, first_slot=0):
+            calls.append(count)
+            if len(calls) == 2:
+                raise RuntimeError("injected producer failure")
+            return render(self, count, device_out, first_slot)
+        FrameTape.render = broken
+    try:
+        scene.main(freewheel=True, output=None, **KW["Visualizer"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(200)
+@pytest.mark.parametrize("fail_on", [-1, 1])
+def test_two_ranks_without_a_sink_and_with_a_failing_producer(fail_on):
+    """ADVICE round 2. (a) No sink (a freewheeling run under torchrun, fileno None): rank 0's writer consumes and DISCARDS the frames
+    of both ranks in frame order — before, it exited at once and every producer sat in sfx_shm_push until the time-out.
+    (b) A producer that raises mid-export tells the group through the segment's `failed` flag: both processes end within seconds
+    with an error instead of waiting 900 s for frames that never come; the segment's name is gone from /dev/shm either way."""
+    import time
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    before = set(os.listdir("/dev/shm"))
+    started = time.monotonic()
+    procs = [ctx.Process(target=_rank_without_sink, args=(r, 2, port, fail_on)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=150)
+    took = time.monotonic() - started
+    codes = [p.exitcode for p in procs]
+    if fail_on < 0:
+        assert codes == [0, 0], codes
+    else:
+        assert all(code not in (0, None) for code in codes), codes          # the failure reaches BOTH ranks …
+        assert took < 90, f"{took:.0f} s: a rank waited for its time-out"    # … at once
+    assert not {name for name in set(os.listdir("/dev/shm")) - before if name.startswith("shaderflow-")}
+
+
 @pytest.mark.timeout(400)
 def test_bench_with_two_ranks_prints_one_line_for_the_whole_job():
     """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one rank per GPU), here with two ranks on the one
@@ -91,6 +140,10 @@ def test_bench_with_two_ranks_prints_one_line_for_the_whole_job():
     assert record["n_gpus"] == 2 and record["steps"] == 2 and record["scaling"] == "weak"
     assert record["config"]["global_frames_per_step"] == 8 and record["value"] > 0 and record["config"]["ranks"] == 2
     assert "cpu_baseline" not in record                                       # rank 0 at N = 1 only
+    # a multi-rank line is diagnosable: every rank took part, each one's render rate and what it sent to rank 0
+    assert record["rccl_ranks"] == 2 and [r["rank"] for r in record["per_rank"]] == [0, 1]
+    assert all(r["render_frames_per_s"] > 0 for r in record["per_rank"]) and record["per_rank"][1]["sent_GB_per_s"] > 0
+    assert record["gather"]["backend"] == "gloo" and record["value_host"] == record["export_host"]["value"]
     # the second number: the same frames through a real sharded export, read-out to host memory included (host mode)
     assert record["export_host"]["frames"] == 16 and record["export_host"]["value"] > 0 and "SHADERFLOW_SHARD=host" in record["export_host"]["mode"]
     assert record["roofline"]["bound"] == "valu" and record["roofline"]["kernel"].startswith("k_") and record["roofline"]["hbm"]["achieved"] > 0
