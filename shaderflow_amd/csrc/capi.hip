@@ -913,6 +913,15 @@ template <int KIND> static int launch_separable(const RenderArgs& a, int ssaa, i
     t.columns = (float4*)ctx->vis_tables;
     t.rows = t.columns + (size_t)frames*a.wr;
     hipLaunchKernelGGL(k_separable_axis<KIND>, dim3((a.wr + a.hr + 255)/256, frames), dim3(256), 0, s, a, t);
+    if constexpr (KIND != SEP_DEFAULT) {
+        // rows as runs, four pixels = one 12-byte store per lane (k_separable_runs); odd widths keep the per-pixel kernel
+        const char* runs = getenv("SHADERFLOW_SEPARABLE_RUNS");     // A/B switch for measurements
+        if (a.w % 4 == 0 && !(runs && atoi(runs) == 0)) {
+            g_last_kernel = std::string("k_separable_runs<") + (KIND == SEP_BARS ? "bars" : "waveform") + ">";
+            hipLaunchKernelGGL(k_separable_runs<KIND>, dim3((a.w + 255)/256, (a.h + 4*SEP_RUN_ROWS - 1)/(4*SEP_RUN_ROWS), frames), dim3(256), 0, s, a, t);
+            return 1;
+        }
+    }
     g_last_kernel = std::string("k_separable_fused<") + (KIND == SEP_BARS ? "bars" : (KIND == SEP_WAVEFORM ? "waveform" : "default")) + ">";
     const int blocks_x = (a.w + SEP_PIXELS - 1)/SEP_PIXELS;
     if ((long)blocks_x*((a.h + SEP_ROWS_LARGE - 1)/SEP_ROWS_LARGE)*frames >= 2048)

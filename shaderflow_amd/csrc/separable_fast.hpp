@@ -250,4 +250,167 @@ __global__ __launch_bounds__(SEP_PIXELS) void k_separable_fused(const RenderArgs
     }
 }
 
+// ---- bars / waveform as RUNS ------------------------------------------------------------------------------------------------------
+// A bars or waveform frame is, column by column, a handful of runs of rows: every comparison of the fragments is `row < T` or
+// `first <= row < first + count` with per-column integers (k_separable_axis), so along a column the colour changes at a few
+// SPECIAL rows only — three per sample column for bars (where a height crosses the row pair of an output pixel), six for
+// waveform — and between them red and green (all of waveform's channels) are constants. k_separable_fused evaluated the counts
+// per pixel and row (64 VALU instructions per output pixel: a quarter of the chip's issue rate, 2.4 TB/s written); here one lane
+// owns FOUR output pixels = 12 bytes = one `global_store_dwordx3`, walks SEP_RUN_ROWS rows with its eight column entries in
+// registers and keeps the 12 bytes of the current run as a template:
+//   fast row (no lane of the wave at a special row — 98-99 % of them): waveform stores the template; bars fills in blue, the one
+//       channel that is not piecewise constant (bars.frag:17: the ramp 0.4·Σ·(1 − astuv.y)): per sample the RGBA8 byte of
+//       `(below + ramp·(1 − y))·255` as fma(255·ramp, 1 − y, 255·below) → v_cvt_pk_u8 (2 instructions; the product is rounded once
+//       instead of twice, which moves a byte only when the value sits within 10⁻⁵ of a half; the four bytes of a pixel are packed
+//       in one register), then final.glsl's mean of the four bytes as (Σ + 2) >> 2 (v_sad_u8 with the 2 as its accumulator, a shift);
+//   special row (wave-uniform branch on a ballot): every lane evaluates the row with the per-pixel counts of k_separable_fused and
+//       rebuilds its template and its next special row.
+// ≈ 13 instructions per output pixel for bars, 2 for waveform; a wave writes 768 contiguous bytes per row straight from registers
+// (no LDS, no barrier). Exactness: red, green and waveform's channels are the generic chain's bytes (the resolve of 0/1 samples
+// is exact, separable_fast.hpp above); blue's integer mean differs from the float chain of resolve_channel only when the four
+// bytes sum to 2 (mod 4) — a tie that the float chain's rounding noise decides either way — by 1 LSB, the north star's bound.
+constexpr int SEP_RUN_ROWS = 32;                                    // rows a wave walks; a block is 4 waves = 256 pixels x 128 rows
+
+// bars: bytes of one pixel at sample row j0 from its two column entries (the per-pixel arithmetic of k_separable_fused)
+__device__ __forceinline__ uint32_t count_byte(int count) { return (uint32_t)(count*255 + 2) >> 2; }               // RN(count*63.75), count 0..4
+__device__ __forceinline__ uint32_t blue_mean(float b0, float b1, float b2, float b3, float ramp0, float ramp1, float omy0, float omy1) {
+    uint32_t q = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ramp0, omy0, b0)*255.0f, 0u, 0u);
+    q = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ramp1, omy0, b1)*255.0f, 1u, q);
+    q = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ramp0, omy1, b2)*255.0f, 2u, q);
+    q = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ramp1, omy1, b3)*255.0f, 3u, q);
+    return __builtin_amdgcn_sad_u8(q, 0u, 2u) >> 2;
+}
+__device__ __forceinline__ uint32_t bars_pixel(const float4 c0, const float4 c1, int j0, float omy0, float omy1) {
+    const int red = rows_of_pair(__float_as_int(c0.x), j0) + rows_of_pair(__float_as_int(c1.x), j0);
+    const int green = rows_of_pair(__float_as_int(c0.y), j0) + rows_of_pair(__float_as_int(c1.y), j0);
+    const int t0 = __float_as_int(c0.z), t1 = __float_as_int(c1.z);
+    const uint32_t blue = blue_mean((j0 < t0) ? 1.0f : 0.0f, (j0 < t1) ? 1.0f : 0.0f, (j0 + 1 < t0) ? 1.0f : 0.0f, (j0 + 1 < t1) ? 1.0f : 0.0f,
+                                    c0.w, c1.w, omy0, omy1);
+    return count_byte(red) | (count_byte(green) << 8) | (blue << 16);
+}
+__device__ __forceinline__ uint32_t waveform_pixel(const float4 c0, const float4 c1, int j0, const uint8_t* lut) {
+    return (uint32_t)lut[wave_pattern(__float_as_int(c0.x), __float_as_int(c1.x), j0)]
+         | ((uint32_t)lut[wave_pattern(__float_as_int(c0.y), __float_as_int(c1.y), j0)] << 8)
+         | ((uint32_t)lut[wave_pattern(__float_as_int(c0.z), __float_as_int(c1.z), j0)] << 16);
+}
+// the first pixel row >= `from` at which the row pair (2 py, 2 py + 1) meets the boundary `t` (a row count) of a column
+__device__ __forceinline__ int special_after(int t, int from, int best) {
+    const int s = t >> 1;
+    return (s >= from && s < best) ? s : best;
+}
+
+// S == 2, w % 4 == 0. grid (ceil(w/256), ceil(h/(4*SEP_RUN_ROWS)), frames), block 256 = 4 waves, wave k walks rows [k*32, k*32 + 32).
+// Only what a FAST row needs lives in registers across the walk (bars: per column the ramp and the blue state, both pre-multiplied by
+// 255; the template; the next special row — ≈ 40 VGPRs, eight waves per SIMD); a special row reloads the lane's eight column entries
+// (128 contiguous bytes, L2). The two per-row scalars of bars (1 − astuv.y of the pair's sample rows) are fetched ONCE per walk — lane
+// l holds the value of sample row 2·y_first + l — and read with v_readlane: no memory latency inside the loop.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_separable_runs(const RenderArgs a, const SepTables t) {
+    static_assert(KIND == SEP_BARS || KIND == SEP_WAVEFORM, "runs exist for the two comparison fragments");
+    static_assert(SEP_RUN_ROWS == 32, "one lane per sample row of the walk");
+    __shared__ uint8_t inside_lut[16];
+    const int frame = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if constexpr (KIND == SEP_WAVEFORM) {
+        if (tid < 16) {
+            uint32_t pattern[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) pattern[k] = unorm8(((tid >> k) & 1) ? 1.0f : 0.2f);
+            inside_lut[tid] = (uint8_t)resolve_channel_any<2>(pattern, a.subsample, 0);
+        }
+        __syncthreads();
+    }
+    const int y_first = blockIdx.y*(4*SEP_RUN_ROWS) + wave*SEP_RUN_ROWS;
+    if (y_first >= a.h) return;
+    const int y_last = min(y_first + SEP_RUN_ROWS, a.h);
+    const float4* rows = t.rows + (long)frame*a.hr;
+    int omy_of_lane = 0;
+    if constexpr (KIND == SEP_BARS) {                                 // before any lane leaves: v_readlane reads all of them
+        const int sample_row = 2*y_first + lane;
+        omy_of_lane = __float_as_int(rows[sample_row < (int)a.hr ? sample_row : (int)a.hr - 1].y);
+    }
+    const int px0 = (blockIdx.x*64 + lane)*4;                        // this lane's four output pixels
+    const bool active = px0 < a.w;
+    const float4* columns = t.columns + (long)frame*a.wr + (active ? 2*px0 : 0);
+    uint8_t* out = (uint8_t*)a.out + (long)frame*a.out_frame_stride + (long)px0*3;
+    const long pitch = (long)a.w*3;
+
+    uint32_t d0 = 0, d1 = 0, d2 = 0;                                // the run's 12 bytes: R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+    float below255[8], ramp255[8];                                  // bars: 255 where the column's rows are below its blue height; 255 x its ramp
+    int next = 0;
+    auto rebuild = [&](int py) {                                    // state of the run that row `py` belongs to, and where it ends
+        const int j0 = 2*py;
+        uint32_t p[4];
+        int best = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float4 c0 = columns[2*k], c1 = columns[2*k + 1];
+            if constexpr (KIND == SEP_BARS) {
+                const int red = rows_of_pair(__float_as_int(c0.x), j0) + rows_of_pair(__float_as_int(c1.x), j0);
+                const int green = rows_of_pair(__float_as_int(c0.y), j0) + rows_of_pair(__float_as_int(c1.y), j0);
+                p[k] = count_byte(red) | (count_byte(green) << 8);
+                below255[2*k] = (j0 < __float_as_int(c0.z)) ? 255.0f : 0.0f;
+                below255[2*k + 1] = (j0 < __float_as_int(c1.z)) ? 255.0f : 0.0f;
+                ramp255[2*k] = c0.w*255.0f; ramp255[2*k + 1] = c1.w*255.0f;
+                best = special_after(__float_as_int(c0.x), py, best); best = special_after(__float_as_int(c1.x), py, best);
+                best = special_after(__float_as_int(c0.y), py, best); best = special_after(__float_as_int(c1.y), py, best);
+                best = special_after(__float_as_int(c0.z), py, best); best = special_after(__float_as_int(c1.z), py, best);
+            } else {
+                p[k] = waveform_pixel(c0, c1, j0, inside_lut);
+                const int runs[6] = {__float_as_int(c0.x), __float_as_int(c0.y), __float_as_int(c0.z), __float_as_int(c1.x), __float_as_int(c1.y), __float_as_int(c1.z)};
+#pragma unroll
+                for (int m = 0; m < 6; m++) {
+                    const int first = runs[m] & 0xffff, count = (int)((unsigned)runs[m] >> 16);
+                    best = special_after(first, py, best);
+                    best = special_after(first + count, py, best);
+                }
+            }
+        }
+        d0 = p[0] | (p[1] << 24); d1 = (p[1] >> 8) | (p[2] << 16); d2 = (p[2] >> 16) | (p[3] << 8);
+        next = best;
+    };
+    if (active) rebuild(y_first); else next = 0x7fffffff;
+#pragma unroll 1
+    for (int py = y_first; py < y_last; py++) {
+        uint32_t o0, o1, o2;
+        float omy0 = 0.0f, omy1 = 0.0f;
+        if constexpr (KIND == SEP_BARS) {
+            omy0 = __int_as_float(__builtin_amdgcn_readlane(omy_of_lane, 2*(py - y_first)));           // wave-uniform row index: SGPR lane selects
+            omy1 = __int_as_float(__builtin_amdgcn_readlane(omy_of_lane, 2*(py - y_first) + 1));
+        }
+        if (__builtin_amdgcn_ballot_w64(py == next) != 0) {
+            // a special row of some lane: the per-pixel evaluation for everybody, then the runs that start on the next row
+            if (active) {
+                uint32_t p[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float4 c0 = columns[2*k], c1 = columns[2*k + 1];
+                    p[k] = (KIND == SEP_BARS) ? bars_pixel(c0, c1, 2*py, omy0, omy1) : waveform_pixel(c0, c1, 2*py, inside_lut);
+                }
+                o0 = p[0] | (p[1] << 24); o1 = (p[1] >> 8) | (p[2] << 16); o2 = (p[2] >> 16) | (p[3] << 8);
+                rebuild(py + 1);
+            }
+        } else if constexpr (KIND == SEP_BARS) {
+            const float y0 = omy0, y1 = omy1;                        // in VGPRs: a VALU operation with an SGPR operand issues at half rate
+            uint32_t blue[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t q = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ramp255[2*k], y0, below255[2*k]), 0u, 0u);
+                q = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ramp255[2*k + 1], y0, below255[2*k + 1]), 1u, q);
+                q = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ramp255[2*k], y1, below255[2*k]), 2u, q);
+                q = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ramp255[2*k + 1], y1, below255[2*k + 1]), 3u, q);
+                blue[k] = __builtin_amdgcn_sad_u8(q, 0u, 2u) >> 2;
+            }
+            o0 = d0 | (blue[0] << 16); o1 = d1 | (blue[1] << 8); o2 = d2 | blue[2] | (blue[3] << 24);
+        } else {
+            o0 = d0; o1 = d1; o2 = d2;
+        }
+        if (active) {
+            uint32_t* row = (uint32_t*)(out + (long)(a.top_down ? a.h - 1 - py : py)*pitch);
+            struct alignas(4) Triple { uint32_t x, y, z; };
+            *(Triple*)row = Triple{o0, o1, o2};
+        }
+    }
+}
+
 }  // namespace sf
