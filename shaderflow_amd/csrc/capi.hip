@@ -1120,6 +1120,12 @@ static int launch_resolve(Context* ctx, const ResolveArgs& a, int frames, hipStr
         hipLaunchKernelGGL(k_resolve_axis<0>, dim3((a.w + 127)/128), dim3(128), 0, s, a, columns);
         hipLaunchKernelGGL(k_resolve_axis<1>, dim3((a.h + 127)/128), dim3(128), 0, s, a, rows);
         const ResolveTables t{columns, rows};
+        const char* tent = getenv("SHADERFLOW_RESOLVE_TENT");        // A/B switch for measurements
+        if (a.subsample == 2 && a.screen.width == a.w && a.screen.height == a.h && !(tent && atoi(tent) == 0)) {
+            // the two-pass configuration (no SSAA, final.glsl's 3 x 3 tent): four pixels per thread, each texel read once
+            hipLaunchKernelGGL(k_resolve_tent, dim3((a.w + TENT_BW - 1)/TENT_BW, (a.h + TENT_BH - 1)/TENT_BH, frames), dim3(TENT_BW, TENT_BH/TENT_ROWS_PER_THREAD), 0, s, a, t);
+            return SFX_OK;
+        }
         const dim3 grid((a.w + 63)/64, (a.h + 3)/4, frames), block(64, 4);
         // iScreen texels under a block of 64 x 4 pixels, two more per axis for the bilinear neighbours: the LDS window (a block
         // whose own window is larger — it cannot be — or a launch over the cap reads iScreen directly)
