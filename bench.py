@@ -232,12 +232,29 @@ def main() -> None:
         where = "cpu" if staged else "cuda"
         received = [[torch.zeros(fpb*frame_bytes, dtype=torch.uint8, device=where) for _ in range(2)] for _ in range(world)]
     in_flight: list = []
+    # SHADERFLOW_SHARD=device-sdma: the gather as peer copies on the SDMA engines instead of RCCL kernels (parallel.SdmaTransfer):
+    # rank 0 exports two step buffers per source rank as IPC handles, every other rank maps its pair
+    sdma = distributed and os.environ.get("SHADERFLOW_SHARD", "").strip().lower() == "device-sdma"
+    windows = None
+    if sdma:
+        handles = [None]
+        if rank == 0:
+            received = None
+            raw = [[context.alloc(fpb*frame_bytes) for _ in range(2)] for _ in range(world)]
+            handles = [[[context.peer_export(pointer) for pointer in pair] for pair in raw]]
+        dist.broadcast_object_list(handles, src=0)
+        if rank:
+            windows = [context.peer_open(handle) for handle in handles[0][rank]]
 
     def transfer(index: int, q: int, view) -> None:
         """piece q of step `index`: every other rank → rank 0, grouped point-to-point (the RCCL gather)"""
         if not distributed:
             return
         lo, hi = q*piece*frame_bytes, (q + 1)*piece*frame_bytes
+        if sdma:
+            if rank:
+                context.peer_copy(windows[index % 2] + lo, view.data_ptr(), hi - lo, lane=(index % 2)*parts + q)
+            return
         if rank == 0:
             ops = [dist.P2POp(dist.irecv, received[source][index % 2][lo:hi], source) for source in range(1, world)]
         else:
@@ -259,6 +276,8 @@ def main() -> None:
             context.event_record(2*timed_slot)
         for q in range(parts):
             drain(keep_transfers=2*parts - 1)                     # the transfer that last used this piece of this buffer (two steps ago) is done
+            if sdma and rank:
+                context.peer_fence((index % 2)*parts + q)         # device-side: the render waits for the copy that last read this piece
             view = target[q*piece*frame_bytes:(q + 1)*piece*frame_bytes]
             tape.render(piece, view.data_ptr(), first_slot=q*piece)
             transfer(index, q, view)
@@ -266,6 +285,8 @@ def main() -> None:
             context.event_record(2*timed_slot + 1)
 
     def barrier():
+        if sdma and rank:
+            context.peer_flush()                                  # this rank's frames have landed in rank 0's HBM
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -374,7 +395,7 @@ def main() -> None:
             "config": {"workload": f"{scene_class.__name__} scene {w}x{h} {s}xSSAA subsample 2, 60 fps, {seconds:.0f} s synthetic stereo sine sweep @44.1 kHz, "
                                    f"1920x1080 synthetic background; step = {fpb} frames (STFT + filterbank + dynamics tape, column/row tables, fused fragment+resolve)",
                        "frames_per_step": fpb, "global_frames_per_step": fpb*world,
-                       "parallelism": f"contiguous frame range per rank x{world}" + (f", every step sent to rank 0 over {dist.get_backend()} in {parts} pieces" if distributed else ""),
+                       "parallelism": f"contiguous frame range per rank x{world}" + (f", every step sent to rank 0 {'as SDMA peer copies (IPC windows)' if sdma else 'over ' + dist.get_backend()} in {parts} pieces" if distributed else ""),
                        "ranks": world, "filterbank": "mfma" if tape.use_mfma else "csr"},
             "rccl_ranks": ranks_seen,
             "realtime_factor": round(value/60.0, 2),
@@ -411,7 +432,7 @@ def main() -> None:
         if per_rank is not None:
             result["per_rank"] = per_rank
             inbound = sum(r["sent_GB_per_s"] for r in per_rank)
-            result["gather"] = {"backend": dist_backend, "pieces_per_step": parts, "inbound_GB_per_s_rank0": round(inbound, 2),
+            result["gather"] = {"backend": "sdma peer copies (hipIpc + hipMemcpyAsync)" if sdma else dist_backend, "pieces_per_step": parts, "inbound_GB_per_s_rank0": round(inbound, 2),
                                 "note": "sent_GB_per_s = frames a rank sent to rank 0 / the timed region: every peer has its own xGMI link to rank 0; "
                                         "a rank whose render_frames_per_s x 24.9 MB exceeds what its link sustains is link-bound (DESIGN.md §6)"}
     else:

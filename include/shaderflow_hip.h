@@ -298,6 +298,18 @@ int sfx_device_free(sfx_handle ctx, void* ptr);
 int sfx_device_copy(sfx_handle ctx, void* dst, const void* src, size_t nbytes);
 int sfx_device_read(sfx_handle ctx, const void* device_ptr, void* host, size_t nbytes);
 
+/* Peer windows — the gather of a sharded export without a collective and without compute units (no reference equivalent,
+ * SURVEY.md §8e "or hipMemcpyPeerAsync, each peer on its own xGMI link"; DESIGN.md §6 "device-sdma"). Rank 0 exports its resident
+ * frame buffer (a pointer from sfx_device_alloc) as 64 opaque bytes, passes them to the other processes by any means, each maps the
+ * buffer and copies its finished frames to where they belong on a copy stream (SDMA engines), concurrently with its next kernels. */
+int sfx_peer_export(sfx_handle ctx, void* device_ptr, void* handle64);
+int sfx_peer_open(sfx_handle ctx, const void* handle64, void** device_ptr);
+int sfx_peer_close(sfx_handle ctx, void* device_ptr);
+/* asynchronous; ordered after what the context's stream holds now. `lane` (0..15) names the source buffer for sfx_peer_fence */
+int sfx_peer_copy(sfx_handle ctx, void* remote_dst, const void* local_src, size_t nbytes, int lane);
+int sfx_peer_fence(sfx_handle ctx, int lane);    /* later work on the context's stream waits for the lane's last copy (device side) */
+int sfx_peer_flush(sfx_handle ctx);              /* host wait: every copy issued so far has landed */
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,12 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_ring_pipe": (C.c_int, [Handle, C.c_int, C.c_int]),
     "sfx_ring_pipe_sync": (C.c_int, [Handle, C.c_int]),
     "sfx_ring_destroy": (C.c_int, [Handle]),
+    "sfx_peer_export": (C.c_int, [Handle, C.c_void_p, C.c_void_p]),
+    "sfx_peer_open": (C.c_int, [Handle, C.c_void_p, P(C.c_void_p)]),
+    "sfx_peer_close": (C.c_int, [Handle, C.c_void_p]),
+    "sfx_peer_copy": (C.c_int, [Handle, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "sfx_peer_fence": (C.c_int, [Handle, C.c_int]),
+    "sfx_peer_flush": (C.c_int, [Handle]),
     "sfx_shm_create": (C.c_int, [Handle, C.c_char_p, C.c_int, C.c_int, C.c_size_t, C.c_int, P(Handle)]),
     "sfx_shm_push": (C.c_int, [Handle, C.c_void_p]),
     "sfx_shm_flush": (C.c_int, [Handle]),
@@ -218,6 +224,29 @@ class Context:
 
     def copy(self, dst: int, src: int, nbytes: int) -> None:
         check(lib().sfx_device_copy(self.handle, C.c_void_p(dst), C.c_void_p(src), nbytes))
+
+    # peer windows (sharded export, "device-sdma")
+    def peer_export(self, ptr: int) -> bytes:
+        handle = C.create_string_buffer(64)
+        check(lib().sfx_peer_export(self.handle, C.c_void_p(ptr), handle))
+        return handle.raw
+
+    def peer_open(self, handle: bytes) -> int:
+        ptr = C.c_void_p()
+        check(lib().sfx_peer_open(self.handle, C.create_string_buffer(handle, 64), C.byref(ptr)))
+        return ptr.value
+
+    def peer_close(self, ptr: int) -> None:
+        check(lib().sfx_peer_close(self.handle, C.c_void_p(ptr)))
+
+    def peer_copy(self, remote: int, local: int, nbytes: int, lane: int = 0) -> None:
+        check(lib().sfx_peer_copy(self.handle, C.c_void_p(remote), C.c_void_p(local), nbytes, lane))
+
+    def peer_fence(self, lane: int) -> None:
+        check(lib().sfx_peer_fence(self.handle, lane))
+
+    def peer_flush(self) -> None:
+        check(lib().sfx_peer_flush(self.handle))
 
     def read(self, ptr: int, nbytes: int) -> np.ndarray:
         out = np.empty(nbytes, np.uint8)

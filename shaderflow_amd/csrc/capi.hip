@@ -71,6 +71,10 @@ struct Context : Object {
     void* vis_tables = nullptr; size_t vis_tables_bytes = 0;
     float* vis_bars = nullptr; size_t vis_bars_count = 0;          // sqrt(texel/1000) of a bound spectrogram (single launches)
     void* resolve_tables = nullptr; size_t resolve_tables_bytes = 0;   // column/row tap tables of k_resolve_fast
+    // peer copies of the sharded export's "device-sdma" mode: two copy streams, an event per lane (sfx_peer_*)
+    hipStream_t peer_streams[2] = {nullptr, nullptr};
+    hipEvent_t peer_ready = nullptr, peer_done[16] = {};
+    uint64_t peer_copies = 0;
 };
 static thread_local Context* g_launch_ctx = nullptr;               // the context whose program is being launched (scratch owner)
 
@@ -169,6 +173,9 @@ extern "C" int sfx_ctx_destroy(sfx_handle h) {
     hipStreamSynchronize(c->stream);
     for (auto& e : c->events) hipEventDestroy(e);
     hipFree(c->vis_tables); hipFree(c->vis_bars); hipFree(c->resolve_tables);
+    for (hipStream_t stream : c->peer_streams) if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
+    if (c->peer_ready) hipEventDestroy(c->peer_ready);
+    for (auto& e : c->peer_done) if (e) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
     c->magic = 0;
     delete c;
@@ -210,6 +217,68 @@ extern "C" int sfx_device_copy(sfx_handle h, void* dst, const void* src, size_t 
     if (!dst || !src) return fail(SFX_E_INVALID, "null device pointer");
     USE_DEVICE(c);
     HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, c->stream));
+    return SFX_OK;
+}
+
+// ---- peer windows: frames from this rank's HBM straight into another process' buffer, on the copy engines ----------------------
+// The sharded export's gather without a collective and without compute units (DESIGN.md §6 "device-sdma"): rank 0 exports its
+// resident frame buffer as an IPC handle, every other rank maps it and copies its finished frames to where they belong with
+// hipMemcpyAsync on a copy stream — SDMA engines over the rank's own xGMI link, concurrent with the next batch's kernels.
+extern "C" int sfx_peer_export(sfx_handle h, void* device_ptr, void* handle64) {
+    CTX_OR_FAIL(c, h);
+    if (!device_ptr || !handle64) return fail(SFX_E_INVALID, "peer window: null pointer");
+    USE_DEVICE(c);
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the ABI carries IPC handles as 64 opaque bytes");
+    HIP_TRY(hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, device_ptr));
+    return SFX_OK;
+}
+extern "C" int sfx_peer_open(sfx_handle h, const void* handle64, void** device_ptr) {
+    CTX_OR_FAIL(c, h);
+    if (!device_ptr || !handle64) return fail(SFX_E_INVALID, "peer window: null pointer");
+    USE_DEVICE(c);
+    hipIpcMemHandle_t handle;
+    memcpy(&handle, handle64, sizeof handle);
+    HIP_TRY(hipIpcOpenMemHandle(device_ptr, handle, hipIpcMemLazyEnablePeerAccess));
+    return SFX_OK;
+}
+extern "C" int sfx_peer_close(sfx_handle h, void* device_ptr) {
+    CTX_OR_FAIL(c, h);
+    USE_DEVICE(c);
+    for (hipStream_t stream : c->peer_streams) if (stream) HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipIpcCloseMemHandle(device_ptr));
+    return SFX_OK;
+}
+// `nbytes` from `local_src` (complete on the context's stream when this call is made) to `remote_dst` (inside a window opened with
+// sfx_peer_open, or any device pointer): asynchronous, on a copy stream. `lane` (0..15) names the source buffer for sfx_peer_fence.
+extern "C" int sfx_peer_copy(sfx_handle h, void* remote_dst, const void* local_src, size_t nbytes, int lane) {
+    CTX_OR_FAIL(c, h);
+    if (!remote_dst || !local_src || lane < 0 || lane >= 16) return fail(SFX_E_INVALID, "peer copy: pointers / lane %d", lane);
+    USE_DEVICE(c);
+    if (!c->peer_ready) {
+        HIP_TRY(hipEventCreateWithFlags(&c->peer_ready, hipEventDisableTiming));
+        for (auto& stream : c->peer_streams) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    }
+    if (!c->peer_done[lane]) HIP_TRY(hipEventCreateWithFlags(&c->peer_done[lane], hipEventDisableTiming));
+    hipStream_t stream = c->peer_streams[c->peer_copies++ & 1];
+    HIP_TRY(hipEventRecord(c->peer_ready, c->stream));
+    HIP_TRY(hipStreamWaitEvent(stream, c->peer_ready, 0));
+    HIP_TRY(hipMemcpyAsync(remote_dst, local_src, nbytes, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipEventRecord(c->peer_done[lane], stream));
+    return SFX_OK;
+}
+// work queued on the context's stream from now on waits for the last copy of `lane` (its source may then be overwritten); no host wait
+extern "C" int sfx_peer_fence(sfx_handle h, int lane) {
+    CTX_OR_FAIL(c, h);
+    if (lane < 0 || lane >= 16) return fail(SFX_E_INVALID, "peer fence: lane %d", lane);
+    USE_DEVICE(c);
+    if (c->peer_done[lane]) HIP_TRY(hipStreamWaitEvent(c->stream, c->peer_done[lane], 0));
+    return SFX_OK;
+}
+// every copy issued so far has landed (host wait)
+extern "C" int sfx_peer_flush(sfx_handle h) {
+    CTX_OR_FAIL(c, h);
+    USE_DEVICE(c);
+    for (hipStream_t stream : c->peer_streams) if (stream) HIP_TRY(hipStreamSynchronize(stream));
     return SFX_OK;
 }
 

@@ -11,6 +11,10 @@ What is left to decide is how the finished RGB8 frames reach the ONE process tha
   (`RangeTransfer`: grouped point-to-point sends = the RCCL gather; on the fully connected xGMI fabric every peer has its own
   link to rank 0, ≈ 45 GB/s each against 24.9 MB x frames/s per rank: nothing to bucket). The frames then sit in rank 0's HBM;
   to reach a HOST sink they all cross rank 0's single PCIe link: ceiling ≈ 55 GB/s / 24.9 MB ≈ 2 200 frames/s at 4K whatever N is.
+* **device-sdma** — the same layout as "device", but the gather is not a collective: rank 0 exports its resident buffer as an IPC
+  handle, every other rank maps it and copies its finished chunks to where they belong with `hipMemcpyAsync` on a copy stream
+  (`SdmaTransfer`, sfx_peer_*): the SDMA engines move the bytes over the rank's own xGMI link at close to link rate and no compute
+  unit is taken from the render — what RCCL's point-to-point kernels cannot offer. A gloo side channel carries "chunk k has landed".
 * **host** — every rank reads its finished frames out over ITS OWN PCIe link into a shared-memory ring and rank 0's native
   writer thread interleaves them in frame order (`HostDelivery`, csrc/shm_ring.inc): no collective on the data path, ceiling
   N x min(render, PCIe) until the sink or host memory bandwidth binds. Here batches alternate between the ranks (batch b on
@@ -28,8 +32,8 @@ from typing import Optional
 def shard_mode() -> str:
     """How a sharded export delivers frames to the sink's process: "host" (per-rank PCIe + shared memory) or "device" (RCCL)"""
     mode = os.environ.get("SHADERFLOW_SHARD", "host").strip().lower()
-    if mode not in ("host", "device"):
-        raise ValueError(f"SHADERFLOW_SHARD={mode!r}: expected 'host' or 'device'")
+    if mode not in ("host", "device", "device-sdma"):
+        raise ValueError(f"SHADERFLOW_SHARD={mode!r}: expected 'host', 'device' or 'device-sdma'")
     return mode
 
 
@@ -317,7 +321,7 @@ class RangeTransfer:
         work = dist.irecv(stage if self.staged else view, src=source)
         self.works[(source, chunk)] = (work, stage, view)
 
-    def send(self, view) -> None:
+    def send(self, view, first_frame: Optional[int] = None) -> None:
         import torch.distributed as dist
         tensor = view.cpu() if self.staged else view
         self.sent.append((dist.isend(tensor, dst=0), tensor))
@@ -336,6 +340,68 @@ class RangeTransfer:
         for work, _ in self.sent:
             work.wait()
         self.sent.clear()
+
+
+class DeviceArray:
+    """A raw device allocation as something torch can view without copying (`torch.as_tensor(DeviceArray(ptr, n), device=…)`): IPC
+    handles exist for whole allocations only, and torch's caching allocator hands out pieces of larger ones"""
+
+    def __init__(self, pointer: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (pointer, False), "version": 2}
+
+
+class SdmaTransfer:
+    """RangeTransfer's interface over peer windows (SHADERFLOW_SHARD=device-sdma): a chunk travels as ONE asynchronous device-to-device
+    copy on a copy stream of the sending rank — SDMA engines, the rank's own xGMI link, no compute units, concurrent with the render of
+    the next chunk — straight into rank 0's resident buffer, which every rank has mapped through an IPC handle. Completion travels
+    on the host side: a sender waits for its PREVIOUS copy before it queues the next one (by then long done) and tells rank 0 with a
+    one-integer message over gloo."""
+
+    def __init__(self, world: int, rank: int, context, frame_bytes: int, resident_pointer: Optional[int]):
+        import torch.distributed as dist
+        self.world, self.rank, self.context, self.frame_bytes = world, rank, context, frame_bytes
+        self.control = None if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")     # RCCL carries device tensors only
+        handle = [context.peer_export(resident_pointer) if rank == 0 else None]
+        dist.broadcast_object_list(handle, src=0, group=self.control)
+        self.window = None if rank == 0 else context.peer_open(handle[0])
+        self.notices: list = []
+        self.pending: Optional[int] = None
+        self.chunks = 0
+
+    def expect(self, source: int, chunk: int, view) -> None:
+        pass                                                        # nothing to post: the sender writes into place
+
+    def _notify(self) -> None:
+        import torch
+        import torch.distributed as dist
+        if self.pending is not None:
+            self.context.peer_flush()                               # the previous chunk has landed in rank 0's HBM
+            message = torch.tensor([self.pending], dtype=torch.int64)
+            self.notices.append((dist.isend(message, dst=0, group=self.control), message))
+            self.pending = None
+
+    def send(self, view, first_frame: Optional[int] = None) -> None:
+        self._notify()
+        self.context.peer_copy(self.window + first_frame*self.frame_bytes, view.data_ptr(), view.numel(), lane=self.chunks % 16)
+        self.pending = self.chunks
+        self.chunks += 1
+
+    def arrived(self, source: int, chunk: int) -> None:
+        import torch
+        import torch.distributed as dist
+        message = torch.zeros(1, dtype=torch.int64)
+        dist.recv(message, src=source, group=self.control)
+        if int(message.item()) != chunk:
+            raise RuntimeError(f"peer window: rank {source} reported chunk {int(message.item())}, expected {chunk}")
+
+    def finish(self) -> None:
+        self._notify()
+        for work, _ in self.notices:
+            work.wait()
+        self.notices.clear()
+        if self.window is not None:
+            self.context.peer_close(self.window)
+            self.window = None
 
 
 def contiguous_device_export(world: int, rank: int, total: int, batch: int, frame_bytes: int, advance, render, emit, resident, transfer: "RangeTransfer") -> None:
@@ -362,7 +428,7 @@ def contiguous_device_export(world: int, rank: int, total: int, batch: int, fram
         if rank == 0:
             emit(view, c)
         else:
-            transfer.send(view)
+            transfer.send(view, f)
     if rank == 0:
         for source in range(1, world):
             for chunk, (f, c) in enumerate(shard_batches(*ranges[source], batch)):

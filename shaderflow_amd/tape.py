@@ -225,8 +225,8 @@ class FrameTape:
         """The whole export. With an initialised torch.distributed process group (one process per GPU) the frames are sharded over
         the ranks and delivered to rank 0, which owns the sink: per-rank read-out into shared memory ("host", the default) or
         contiguous HBM-resident ranges sent over RCCL ("device") — shaderflow_amd/parallel.py."""
-        from shaderflow_amd.parallel import (HostDelivery, RangeTransfer, contiguous_device_export, interleaved_host_export, interleaved_runs,
-                                             rank_world, shard_batches, shard_frames, shard_mode)
+        from shaderflow_amd.parallel import (DeviceArray, HostDelivery, RangeTransfer, SdmaTransfer, contiguous_device_export,
+                                             interleaved_host_export, interleaved_runs, rank_world, shard_batches, shard_frames, shard_mode)
         scene = self.scene
         total = export.total_frames
         rank, world = rank_world()
@@ -285,9 +285,20 @@ class FrameTape:
                 device = torch.device("cuda", context.device)
                 first, last = shard_frames(total, world, rank)
                 frames_here = total if rank == 0 else (last - first)
-                resident = torch.zeros(max(1, frames_here)*frame_bytes, dtype=torch.uint8, device=device)
-                torch.cuda.synchronize(device)                  # the fill runs on torch's stream, the renders on the context's
-                transfer = RangeTransfer(world, rank, device)
+                window = None
+                if shard_mode() == "device-sdma":
+                    # peer windows: rank 0's buffer is ONE raw allocation (IPC handles name whole allocations), mapped by every rank
+                    if rank == 0:
+                        window = context.alloc(max(1, frames_here)*frame_bytes)
+                        resident = torch.as_tensor(DeviceArray(window, max(1, frames_here)*frame_bytes), device=device)
+                    else:
+                        resident = torch.zeros(max(1, frames_here)*frame_bytes, dtype=torch.uint8, device=device)
+                    torch.cuda.synchronize(device)
+                    transfer = SdmaTransfer(world, rank, context, frame_bytes, window)
+                else:
+                    resident = torch.zeros(max(1, frames_here)*frame_bytes, dtype=torch.uint8, device=device)
+                    torch.cuda.synchronize(device)              # the fill runs on torch's stream, the renders on the context's
+                    transfer = RangeTransfer(world, rank, device)
 
                 def render(first_frame, count, view):
                     self.render(count, view.data_ptr())
@@ -298,6 +309,12 @@ class FrameTape:
 
                 contiguous_device_export(world, rank, total, self.batch, frame_bytes, self.build, render, emit, resident, transfer)
                 export.drain()                                  # `resident` outlives the queued reads
+                if shard_mode() == "device-sdma":
+                    import torch.distributed as dist
+                    dist.barrier()                              # every peer has closed its mapping of the window
+                    if window is not None:
+                        del resident
+                        context.free(window)
                 if rank != 0:
                     export.frame = total
             scene.time, scene.dt, scene.rdt = self.times[-1], self.dts[-1], self.dts[-1]      # clock of the last frame

@@ -44,12 +44,13 @@ def _rank(rank: int, world: int, port: int, name: str, path: str, top_down=None,
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("mode", ["host", "device"])
+@pytest.mark.parametrize("mode", ["host", "device", "device-sdma"])
 @pytest.mark.parametrize("name,top_down", [("Visualizer", None), ("MotionBlur", None), ("Visualizer", True), ("MotionBlur", True)])
 def test_two_ranks_on_one_gpu_reproduce_the_single_process_export(tmp_path, name, top_down, mode):
     """Both delivery modes of the sharded export (parallel.py): "host" = every rank reads its own batches out into the shared-memory
     ring and rank 0's writer thread interleaves them; "device" = contiguous HBM-resident ranges sent to rank 0 (tape scenes) /
-    gathered rounds (frame-loop scenes).
+    gathered rounds (frame-loop scenes); "device-sdma" = the same ranges copied into rank 0's buffer through an IPC window on the
+    copy engines (two processes mapping one allocation of the one test GPU; frame-loop scenes keep the gathered rounds).
     `top_down=True`: the row order an ffmpeg sink asks for must reach EVERY rank, not only the one that owns the sink
     (a rank that missed it would deliver its batches upside down)"""
     whole = _build(name).main(output=bytes, top_down=top_down, **KW[name])
@@ -82,8 +83,7 @@ def _rank_without_sink(rank: int, world: int, port: int, fail_on: int):
 
         def broken(self, count, device_out, first_slot=0):
             calls.append(count)
-            if len(calls) == 2:
-                raise RuntimeError("injected producer failure")
+            raise RuntimeError("injected producer failure")      # rank 1 owns the middle batch of three: its only render
             return render(self, count, device_out, first_slot)
         FrameTape.render = broken
     try:
@@ -117,6 +117,25 @@ def test_two_ranks_without_a_sink_and_with_a_failing_producer(fail_on):
         assert all(code not in (0, None) for code in codes), codes          # the failure reaches BOTH ranks …
         assert took < 90, f"{took:.0f} s: a rank waited for its time-out"    # … at once
     assert not {name for name in set(os.listdir("/dev/shm")) - before if name.startswith("shaderflow-")}
+
+
+@pytest.mark.timeout(400)
+def test_bench_with_two_ranks_over_peer_windows():
+    """bench.py --gpus 2 with SHADERFLOW_SHARD=device-sdma: the steps of rank 1 reach rank 0's buffers as peer copies"""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, SHADERFLOW_DIST_BACKEND="gloo", SHADERFLOW_SHARD="device-sdma")
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), str(root/"bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--frames-per-step", "4", "--width", "384", "--height", "216", "--no-export"]
+    out = subprocess.run(command, capture_output=True, text=True, timeout=360, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    record = json.loads([line for line in out.stdout.splitlines() if line.startswith("{")][-1])
+    assert record["n_gpus"] == 2 and record["rccl_ranks"] == 2 and "sdma" in record["gather"]["backend"]
+    assert record["per_rank"][1]["sent_GB_per_s"] > 0 and "SDMA" in record["config"]["parallelism"]
 
 
 @pytest.mark.timeout(400)
