@@ -208,6 +208,9 @@ int sfx_stft_plan(sfx_handle ctx, int fft_n, int window, int bins, int channels,
  * Amplitude = np.abs(x); both evaluated in float64 and cast to float32 like the reference (:169-171). */
 enum { SFX_MAGNITUDE_POWER = 0, SFX_MAGNITUDE_AMPLITUDE = 1 };
 int sfx_stft_plan_magnitude(sfx_handle plan, int magnitude);
+/* A window function of the caller's own (spectrogram.py:90-108 lets `window` be any callable N -> array): its float64 values
+ * replace the plan's table; n = 2**fft_n. */
+int sfx_stft_plan_window(sfx_handle plan, const double* window, int n);
 int sfx_stft_plan_destroy(sfx_handle plan);
 
 /* Per-frame entry points (the faithful frame loop: results come back to the host like numpy arrays).

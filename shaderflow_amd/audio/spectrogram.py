@@ -159,10 +159,17 @@ class BrokenSpectrogram:
             raise NotImplementedError("sample_rateio != 1 needs the third-party 'samplerate' resampler, which has no device path")
         if self.magnitude not in (FourierMagnitude.Power, FourierMagnitude.Amplitude):
             raise NotImplementedError("custom magnitudes have no device kernel (FourierMagnitude.Power, .Amplitude)")
+        custom = None
         if self.window not in _WINDOW_CODES:
-            raise NotImplementedError("custom windows have no device kernel (hanning, hann_poisson_window, none)")
+            # a window function of the user's own (the reference multiplies by whatever `self.window(N)` returns, in float64,
+            # spectrogram.py:155-171): evaluated here like there, its values replace the plan's table
+            if not callable(self.window):
+                raise TypeError(f"spectrogram window {self.window!r} is neither a SpectrogramWindow nor a callable")
+            custom = np.ascontiguousarray(self.window(self.fft_size), np.float64)
+            if custom.shape != (self.fft_size,):
+                raise ValueError(f"window function returned shape {custom.shape}, expected ({self.fft_size},)")
         amplitude = (self.magnitude is FourierMagnitude.Amplitude)
-        key = (hash(self), self.audio.channels, self.audio.samplerate, _WINDOW_CODES[self.window], amplitude)
+        key = (hash(self), self.audio.channels, self.audio.samplerate, _WINDOW_CODES.get(self.window, custom.tobytes() if custom is not None else None), amplitude)
         if self._plan is None or self._plan_key != key:
             self.release_plan()
             matrix = self.spectrogram_matrix()
@@ -170,10 +177,12 @@ class BrokenSpectrogram:
             indices = np.ascontiguousarray(matrix.indices, np.int32)
             data = np.ascontiguousarray(matrix.data, np.float32)
             handle = N.Handle()
-            N.check(N.lib().sfx_stft_plan(self._context().handle, self.fft_n, _WINDOW_CODES[self.window], self.spectrogram_bins,
+            N.check(N.lib().sfx_stft_plan(self._context().handle, self.fft_n, _WINDOW_CODES.get(self.window, _WINDOW_CODES[SpectrogramWindow.none]), self.spectrogram_bins,
                                           self.audio.channels, N.as_ptr(indptr, C.c_int32), N.as_ptr(indices, C.c_int32),
                                           N.as_ptr(data, C.c_float), C.byref(handle)))
             N.check(N.lib().sfx_stft_plan_magnitude(handle, int(amplitude)))
+            if custom is not None:
+                N.check(N.lib().sfx_stft_plan_window(handle, N.as_ptr(custom, C.c_double), int(custom.size)))
             self._plan, self._plan_key = handle, key
         return self._plan
 

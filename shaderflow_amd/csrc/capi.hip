@@ -1500,6 +1500,17 @@ static int plan_reserve(Plan* p, int frames) {
     return SFX_OK;
 }
 
+// A window of the caller's own (spectrogram.py:155-171 multiplies by whatever `self.window(N)` returns, in float64): replaces the
+// plan's table; `n` must be the plan's 2**fft_n.
+extern "C" int sfx_stft_plan_window(sfx_handle h, const double* window, int n) {
+    Plan* p = get<Plan>(h, MAGIC_PLAN);
+    if (!p || !window || n != (1 << p->fft_n)) return fail(SFX_E_INVALID, "stft plan window: %d values for a plan of %d", n, p ? (1 << p->fft_n) : 0);
+    USE_DEVICE(p->ctx);
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    HIP_TRY(hipMemcpy(p->d_window, window, sizeof(double)*n, hipMemcpyHostToDevice));
+    return SFX_OK;
+}
+
 extern "C" int sfx_stft_plan(sfx_handle h, int fft_n, int window, int bins, int channels,
                              const int32_t* indptr, const int32_t* indices, const float* data, sfx_handle* out) {
     CTX_OR_FAIL(c, h);

@@ -108,6 +108,30 @@ def test_stft_sizes_windows_and_start_of_stream(gpu, golden):
         close(got[k], O.fft_power(pcm, t))
 
 
+def test_window_function_of_the_callers_own():
+    """`window` may be any callable N -> array (spectrogram.py:90-108, 155-171 multiply by what it returns, in
+    float64). The host evaluates it like the reference does and the plan takes the table (sfx_stft_plan_window): the device's power
+    spectrum against numpy's on the reference's own formula, 1e-5 relative"""
+    from examples.scenes import MusicBars, make
+    rng = np.random.default_rng(4)
+    pcm = (0.4*rng.standard_normal((9000, 2))).astype(np.float32)
+    scene = make(MusicBars, audio=(pcm, 44100))
+    scene.initialize()
+    scene.audio.tell = 8000
+    spectrogram = scene.spectrogram
+    spectrogram.fft_n = 11
+    spectrogram.window = lambda size: np.kaiser(size, 6.0)
+    got = spectrogram.fft()
+    window = np.kaiser(2048, 6.0)
+    data = pcm.T[:, 8000 - 2048 - 1:8000 - 1]                                # get_last_n_samples excludes the newest sample
+    spectrum = np.fft.rfft(window*data)
+    want = (spectrum*spectrum.conj()).real.astype(np.float32)
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-5*float(want.max()))
+    with pytest.raises(ValueError, match="shape"):
+        spectrogram.window = lambda size: np.ones(size + 1)
+        spectrogram.fft()
+
+
 @pytest.mark.parametrize("tag,bins", [("piano115", 115), ("octave1000", 1000), ("mel64", 64)])
 def test_filterbank_csr_bit_exact_and_mfma_close(gpu, golden, tag, bins):
     f = golden("filterbank")
