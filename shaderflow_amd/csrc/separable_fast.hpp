@@ -114,9 +114,10 @@ __global__ __launch_bounds__(256) void k_separable_axis(const RenderArgs a, cons
     (column ? t.columns + (long)frame*a.wr : t.rows + (long)frame*a.hr)[index] = e;
 }
 
-// default.glsl:10-47 for one sample from its column and row entries; `hue_shift` = 2*TAU*iTau - PI/4 (:22), per frame
-__device__ __forceinline__ uint32_t default_texel(const float4 c, const float4 r, float hue_shift) {
-    const float ux = c.x, uy = r.x;
+// default.glsl:19-26, the two-dimensional part of one point: the hue wheel by polar angle (as 0.3 + hsv2rgb, :22) and the ring
+// `width` = 2e-4/circle² by radius; `hue_shift` = 2*TAU*iTau - PI/4 (:22), per frame
+struct DefaultPolar { float red, green, blue, circle, width, len; };
+__device__ __forceinline__ DefaultPolar default_polar(float ux, float uy, float hue_shift) {
     // :19 atan2(uv) in [0, 2 pi): sfmath.hpp's polynomial on min/max with hardware reciprocals (the hue is continuous in it)
     const float ax = sf::abs(ux), ay = sf::abs(uy);
     const float hi = __builtin_fmaxf(ax, ay), lo = __builtin_fminf(ax, ay);
@@ -135,17 +136,37 @@ __device__ __forceinline__ uint32_t default_texel(const float4 c, const float4 r
     float h = angle + hue_shift;
     h = h - TAU*::floorf(h*(1.0f/TAU));
     const float k = h*(3.0f/PI);
-    const float red = clamp01(sf::abs(k - 3.0f) - 1.0f), green = clamp01(2.0f - sf::abs(k - 2.0f)), blue = clamp01(2.0f - sf::abs(k - 4.0f));
+    DefaultPolar out;
+    out.red = 0.3f + clamp01(sf::abs(k - 3.0f) - 1.0f); out.green = 0.3f + clamp01(2.0f - sf::abs(k - 2.0f)); out.blue = 0.3f + clamp01(2.0f - sf::abs(k - 4.0f));
     // :25-26 the ring
-    const float circle = fmaf(1.333f, __builtin_amdgcn_sqrtf(ux*ux + uy*uy), -1.0f);
-    const float width = 2.0e-4f*sf::abs(__builtin_amdgcn_rcpf(circle*circle));
-    // :29-33 the disc or the checkerboard
-    const float base = (circle < 0.0f) ? 0.18f : (((__float_as_int(c.y) ^ __float_as_int(r.y)) & 1) ? 0.22f : 0.20f);
-    // :41-43 vignette: pow(50*ax(1-ax)*ay(1-ay), 0.1) clamped
+    out.len = __builtin_amdgcn_sqrtf(ux*ux + uy*uy);
+    out.circle = fmaf(1.333f, out.len, -1.0f);
+    out.width = 2.0e-4f*sf::abs(__builtin_amdgcn_rcpf(out.circle*out.circle));
+    return out;
+}
+// default.glsl:29-47 for one sample given the polar terms: the disc or the checkerboard (:29-33), the ring added (:36), the
+// vignette pow(50*ax(1-ax)*ay(1-ay), 0.1) clamped (:41-43), out of bounds (:14-16)
+__device__ __forceinline__ uint32_t default_colour(const DefaultPolar& polar, const float4 c, const float4 r) {
+    const float base = (polar.circle < 0.0f) ? 0.18f : (((__float_as_int(c.y) ^ __float_as_int(r.y)) & 1) ? 0.22f : 0.20f);
     const float vignette = clamp01(__builtin_amdgcn_exp2f(0.1f*((c.z + r.z) + 5.643856190f)));
-    vec3 col = {fmaf(width, 0.3f + red, base)*vignette, fmaf(width, 0.3f + green, base)*vignette, fmaf(width, 0.3f + blue, base)*vignette};
-    if (__float_as_int(c.w) != 0) col = vec3{0.15f, 0.15f, 0.15f};                               // :14-16
+    vec3 col = {fmaf(polar.width, polar.red, base)*vignette, fmaf(polar.width, polar.green, base)*vignette, fmaf(polar.width, polar.blue, base)*vignette};
+    if (__float_as_int(c.w) != 0) col = vec3{0.15f, 0.15f, 0.15f};
     return pack_rgb8(col);
+}
+// default.glsl:10-47 for one sample from its column and row entries
+__device__ __forceinline__ uint32_t default_texel(const float4 c, const float4 r, float hue_shift) {
+    return default_colour(default_polar(c.x, r.x, hue_shift), c, r);
+}
+// May the four samples of a pixel share ONE polar evaluation, at the pixel's centre? Away from the ring they may: `off` = the
+// distance from the centre to a sample (in gluv units: the tables' own spacing, so zoomed cameras and small frames are measured
+// as they are); moving a sample by `off` changes the ring term width*(0.3 + hue) by
+//   d(width) = 2*width/|circle| * 1.333*off      and      width * d(hue) <= width * (3/PI) * off/len,
+// and both are kept under 4e-5 (0.01 LSB of a channel: per-sample quantisation then flips with probability 2 %, and all four
+// samples of a pixel never flip together — what a second LSB of difference from the reference would take). Near the ring, next to
+// the origin, and for frames so small that a pixel spans a visible part of the glow the four samples are evaluated one by one.
+__device__ __forceinline__ bool default_shares_polar(const DefaultPolar& centre, float off) {
+    const float change = centre.width*off;
+    return (2.666f*change < 4.0e-5f*sf::abs(centre.circle)) && (0.955f*change < 4.0e-5f*centre.len);
 }
 
 // which samples of the 2 x 2 block at sample row j0 are inside the runs of its two columns (bit y*2 + x, the block's texel order)
@@ -189,7 +210,7 @@ __global__ __launch_bounds__(SEP_PIXELS) void k_separable_fused(const RenderArgs
     (void)hue_shift;
     // (default.glsl's four polar evaluations per row are ~2.7 KB of code: 32 unrolled rows would be 89 KB, more than the 64 KB
     // instruction cache two CUs share — its rows run as a loop of pairs; the light kinds unroll fully)
-    constexpr int ROWS_UNROLLED = (KIND == SEP_DEFAULT) ? 2 : SEP_ROWS;
+    constexpr int ROWS_UNROLLED = (KIND == SEP_DEFAULT) ? 1 : SEP_ROWS;
 #pragma unroll ROWS_UNROLLED
     for (int r = 0; r < SEP_ROWS; r++) {
         const int py = blockIdx.y*SEP_ROWS + r;
@@ -217,9 +238,23 @@ __global__ __launch_bounds__(SEP_PIXELS) void k_separable_fused(const RenderArgs
                 | ((uint32_t)inside_lut[wave_pattern(__float_as_int(c0.y), __float_as_int(c1.y), j0)] << 8)
                 | ((uint32_t)inside_lut[wave_pattern(__float_as_int(c0.z), __float_as_int(c1.z), j0)] << 16);
         } else {
-            block[0] = default_texel(c0, r0, hue_shift); block[1] = default_texel(c1, r0, hue_shift);
-            block[2] = default_texel(c0, r1, hue_shift); block[3] = default_texel(c1, r1, hue_shift);
-            rgb = resolve_channel_any<2>(block, a.subsample, 0) | (resolve_channel_any<2>(block, a.subsample, 8) << 8) | (resolve_channel_any<2>(block, a.subsample, 16) << 16);
+            // one polar evaluation per PIXEL where its four samples cannot tell the difference (default_shares_polar), else four
+            const DefaultPolar centre = default_polar(0.5f*(c0.x + c1.x), 0.5f*(r0.x + r1.x), hue_shift);
+            const float off = 0.5f*(sf::abs(c1.x - c0.x) + sf::abs(r1.x - r0.x));
+            if (default_shares_polar(centre, off)) {
+                block[0] = default_colour(centre, c0, r0); block[1] = default_colour(centre, c1, r0);
+                block[2] = default_colour(centre, c0, r1); block[3] = default_colour(centre, c1, r1);
+            } else {
+                block[0] = default_texel(c0, r0, hue_shift); block[1] = default_texel(c1, r0, hue_shift);
+                block[2] = default_texel(c0, r1, hue_shift); block[3] = default_texel(c1, r1, hue_shift);
+            }
+            // final.glsl's mean of the four RGBA8 texels as an INTEGER mean per channel, (sum + 2) >> 2, red and blue summed side by
+            // side in one register: what resolve_channel's float chain gives except on ties (sum = 2 mod 4), which its rounding noise
+            // decides either way — 1 LSB, like every approximation of this kernel (20 instructions instead of 60)
+            const uint32_t rb = (block[0] & 0x00ff00ffu) + (block[1] & 0x00ff00ffu) + (block[2] & 0x00ff00ffu) + (block[3] & 0x00ff00ffu);
+            const uint32_t gg = ((block[0] >> 8) & 0xffu) + ((block[1] >> 8) & 0xffu) + ((block[2] >> 8) & 0xffu) + ((block[3] >> 8) & 0xffu);
+            const uint32_t mean_rb = ((rb + 0x00020002u) >> 2) & 0x00ff00ffu;
+            rgb = mean_rb | (((gg + 2u) >> 2) << 8);
         }
         uint8_t* s = &staged[r][tid*3];
         s[0] = (uint8_t)rgb; s[1] = (uint8_t)(rgb >> 8); s[2] = (uint8_t)(rgb >> 16);
