@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_resolve_tent(const ResolveArgs a, const
     const int cx[3] = {ca.x - x0, ca.y - x0, cb.y - x0};
     __syncthreads();
     const int j_group = j_first + group*TENT_ROWS_PER_THREAD;
-    // texel rows under the four pixels: R[m] = first row of pixel m's tap 0, R[m + 1] = its second = first of tap 1, R[m + 2] = tap 1's second
+    // texel rows under the four pixels
     float4 texel[TENT_ROWS_PER_THREAD + 2][3];
     int4 qa[TENT_ROWS_PER_THREAD], qb[TENT_ROWS_PER_THREAD];
 #pragma unroll
@@ -168,7 +168,9 @@ __global__ __launch_bounds__(256) void k_resolve_tent(const ResolveArgs a, const
     }
 #pragma unroll
     for (int m = 0; m < TENT_ROWS_PER_THREAD + 2; m++) {
-        const int row = (m < TENT_ROWS_PER_THREAD) ? qa[m].x : (m == TENT_ROWS_PER_THREAD ? qb[TENT_ROWS_PER_THREAD - 1].x : qb[TENT_ROWS_PER_THREAD - 1].y);
+        // R[0] = the first row of pixel 0's tap 0, R[m + 1] = the second row of pixel m's tap 0 (= the first of its tap 1 = the first of
+        // pixel m + 1's tap 0 while that pixel exists; past the frame's last row the entries repeat and nothing reads the result)
+        const int row = (m == 0) ? qa[0].x : (m <= TENT_ROWS_PER_THREAD ? qa[m - 1].y : qb[TENT_ROWS_PER_THREAD - 1].y);
         const float4* line = window + (row - y0)*tw;
 #pragma unroll
         for (int x = 0; x < 3; x++) texel[m][x] = line[cx[x]];

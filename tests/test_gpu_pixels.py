@@ -117,6 +117,17 @@ def test_resolve_pass_bit_exact(gpu, ssaa, subsample):
     assert np.array_equal(got, want), lsb_report(got, want)
 
 
+@pytest.mark.parametrize("w,h", [(40, 24), (41, 23), (64, 17), (130, 50), (255, 9), (17, 5), (200, 16)])
+def test_two_pass_tent_kernel_at_every_edge(gpu, w, h):
+    """k_resolve_tent (iScreen the size of the output, kernel 2: four pixels per thread, blocks of 64 x 16): heights that are not
+    multiples of four or sixteen, widths that are not multiples of 64, frames smaller than a block — bit-exact against final.glsl"""
+    rng = np.random.default_rng(w*1000 + h)
+    screen = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    got = gpu.resolve(screen, w, h, 2)
+    want = O.resolve(screen, w, h, 2)
+    assert np.array_equal(got, want), lsb_report(got, want)
+
+
 def test_resolve_fractional_ssaa(gpu):
     """scene.ssaa = 1.5 → render resolution int(w*1.5) (scene.py:372-375): only the two-pass path applies"""
     rng = np.random.default_rng(3)
