@@ -8,18 +8,18 @@
  * Pinning status
  *   audio half (sfo_audio.c): PINNED against tests/golden/ fixtures, captured from the reference's own
  *       numpy code by tests/golden/make_golden.py (tests/test_oracle_audio.py).
- *   pixel half (sfo_pixel.c): PINNED TO 1 LSB against the reference's GLSL run by an independent OpenGL
- *       implementation. The reference evaluates GLSL inside an OpenGL 3.3 driver (moderngl), which cannot run
- *       here, and holds no golden images. tests/golden/make_golden_gles.py therefore assembles
- *       the reference's shader files the way shader.py:190-235 does, adapts them mechanically to GLSL ES 3.00
- *       and renders them with Google SwiftShader (OpenGL ES 3.0, CPU) — 33 images: every camera projection, the
- *       visualizer with its radial blur, bars, waveform, the inline demo fragments, raymarch, mandelbrot,
- *       tetration, life (simulation with its integer types, visuals), multipass/motionblur layers, final.glsl,
- *       and the bare sampler in every filter/wrap mode. The oracle matches them within 1 LSB per channel
- *       (tests/test_oracle_gles.py), which is as far as two conforming GL implementations agree (built-in
- *       precision and filter precision are implementation choices; sfo_math.h fixes ours). Two stated
- *       exceptions: the chaotic boundary of tetration (0.4 % of the values) and texelFetch outside the texture
- *       (undefined in GL: SwiftShader clamps, this oracle reads zero like robust-access desktop drivers).
+ *   pixel half (sfo_pixel.c): PINNED against frames of THE REFERENCE ITSELF, run in the build container: /root/reference's own
+ *       Python (ShaderScene.main and everything under it, unmodified) rendering through Mesa llvmpipe (OpenGL 4.5 core, the
+ *       software rasteriser BASELINE.json names) with its GLSL as shader.py:190-239 assembles it — tests/golden/mesa.npz and
+ *       mesa_4k.npz, written by tests/golden/make_golden_mesa*.py (refhost.py, mesa_shim.c say how): probes of every fragment on
+ *       the parity tests' inputs, twelve example scenes exported by scene.main(), two whole 3840x2160 2xSSAA frames.
+ *       tests/test_oracle_mesa.py: byte for byte on several, within 1 LSB elsewhere except where measured and bounded there
+ *       (llvmpipe's 8-fractional-bit filter weights: up to 1.3 % of the values 2 LSB off where an 8-bit texture is filtered twice
+ *       at 1:1; one supersample across a bar's edge in 1e5 pixels at 4K; tetration's chaotic boundary; default.glsl's ring).
+ *       Second witness (rounds 1-2): the same GLSL adapted mechanically to GLSL ES 3.00 on Google SwiftShader — gles.npz,
+ *       tests/test_oracle_gles.py — which also pins fragment/missing.glsl (it reads an uninitialised output: Mesa's image is
+ *       undefined, zero-initialising drivers draw the checkerboard) and texelFetch outside the texture (undefined in GL:
+ *       SwiftShader clamps, this oracle reads zero like robust-access desktop drivers).
  */
 #ifndef SFO_H
 #define SFO_H

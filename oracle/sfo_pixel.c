@@ -2,9 +2,10 @@
  * ORACLE (test infrastructure, never shipped, never on the product path).
  * Pixel half: CPU restatement of the reference's GLSL (vertex/default.glsl, include/shaderflow.glsl,
  * include/camera.glsl, fragment/{default,missing,final}.glsl, examples/basic/shaders/ fragments) and of
- * the OpenGL 3.3 rules the reference leans on. PINNED TO 1 LSB against the reference's GLSL executed by an
- * independent OpenGL implementation (tests/golden/gles.npz, tests/test_oracle_gles.py; see sfo.h); the
- * reference itself holds no golden images. Citations are file:line in /root/reference.
+ * the OpenGL 3.3 rules the reference leans on. PINNED against frames the reference itself rendered on Mesa llvmpipe in the
+ * build container (tests/golden/mesa.npz, mesa_4k.npz; tests/test_oracle_mesa.py) and, as a second witness, against its GLSL
+ * on SwiftShader (gles.npz, tests/test_oracle_gles.py) — see sfo.h; the reference itself holds no golden images.
+ * Citations are file:line in /root/reference.
  *
  * Conventions fixed here (and restated independently by the HIP kernels):
  *   - pixel (i, j) of a (wr, hr) target, origin bottom-left, is shaded at its centre; the varyings

@@ -267,6 +267,33 @@ class FFmpeg:
         return None
 
     @staticmethod
+    def _header(path: Path):
+        """(samples per channel, channels, samplerate) of a RIFF/WAVE or FLAC file from its HEADER — the probes below answer from it
+        without decoding (a FLAC file used to be decoded by each of them); None for other containers"""
+        import struct
+        from shaderflow_amd.audio.reader import flac_info
+        with open(path, "rb") as file:
+            head = file.read(12)
+            if head[:4] == b"fLaC":
+                samples, channels, samplerate, _ = flac_info(path)      # STREAMINFO only (sfx_flac_info)
+                return samples, channels, samplerate
+            if not (head[:4] == b"RIFF" and head[8:12] == b"WAVE"):
+                return None
+            channels = samplerate = block = None
+            while len(chunk := file.read(8)) == 8:
+                tag, size = chunk[:4], struct.unpack("<I", chunk[4:])[0]
+                if tag == b"fmt ":
+                    body = file.read(size + (size & 1))
+                    _, channels, samplerate, _, block, _ = struct.unpack("<HHIIHH", body[:16])
+                elif tag == b"data":
+                    if channels is None or not block:
+                        return None
+                    return size//block, channels, samplerate
+                else:
+                    file.seek(size + (size & 1), 1)
+        return None
+
+    @staticmethod
     def _probe(path: Path, stream: str, entry: str) -> str:
         if shutil.which("ffprobe") is None:
             raise RuntimeError(f"{path}: probing this container needs the ffprobe binary (RIFF/WAVE and FLAC files do not)")
@@ -277,22 +304,22 @@ class FFmpeg:
     def get_audio_samplerate(path: Path, *, stream: int = 0, echo: bool = True) -> Optional[int]:
         if not (path := Path(path)).exists():
             return None
-        wav = FFmpeg._wav(path)
-        return wav[1] if wav else int(FFmpeg._probe(path, f"a:{stream}", "stream=sample_rate"))
+        header = FFmpeg._header(path)
+        return header[2] if header else int(FFmpeg._probe(path, f"a:{stream}", "stream=sample_rate"))
 
     @staticmethod
     def get_audio_channels(path: Path, *, stream: int = 0, echo: bool = True) -> Optional[int]:
         if not (path := Path(path)).exists():
             return None
-        wav = FFmpeg._wav(path)
-        return wav[0].shape[1] if wav else int(FFmpeg._probe(path, f"a:{stream}", "stream=channels"))
+        header = FFmpeg._header(path)
+        return header[1] if header else int(FFmpeg._probe(path, f"a:{stream}", "stream=channels"))
 
     @staticmethod
     def get_audio_duration(path: Path, *, echo: bool = True) -> Optional[float]:
         if not (path := Path(path)).exists():
             return None
-        wav = FFmpeg._wav(path)
-        return wav[0].shape[0]/wav[1] if wav else float(FFmpeg._probe(path, "a:0", "format=duration"))
+        header = FFmpeg._header(path)
+        return header[0]/header[2] if header else float(FFmpeg._probe(path, "a:0", "format=duration"))
 
     @staticmethod
     def get_audio_numpy(path: Path, *, echo: bool = True):
