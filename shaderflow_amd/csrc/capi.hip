@@ -814,6 +814,7 @@ static int launch_visualizer_tables_and_kernel(Context* ctx, const RenderArgs& a
     VisTables t;
     t.blocks_x = (a.wr + COLS - 1)/COLS; t.blocks_y = (a.hr + BLOCK_ROWS - 1)/BLOCK_ROWS;
     t.block_columns = COLS; t.block_rows = BLOCK_ROWS; t.tile_pitch = PITCH; t.tile_rows = ROWS;
+    t.cell_bytes = (STRIP_S == 1) ? 8 : 48;                           // the no-SSAA strip instances keep float16 cells in three planes (visualizer_fast.hpp)
     const size_t entries = (size_t)frames*((size_t)a.wr + a.hr)*VIS_ENTRY_QUADS*sizeof(float4);
     const size_t blocks = (size_t)frames*((size_t)t.blocks_x + t.blocks_y)*sizeof(int4);
     const size_t ysteps = STRIP_S ? (size_t)frames*a.hr*10*sizeof(float4) : 0;

@@ -43,6 +43,7 @@ struct VisTables {
     int blocks_x, blocks_y;              // blocks per row / column of the sample grid
     int block_columns, block_rows;       // samples per block along x / y
     int tile_pitch, tile_rows;           // LDS tile the offsets are computed for (cells)
+    int cell_bytes;                      // distance between neighbouring cells of a tile row: 48 (float32 cells, three float4 together) or 8 (float16 cells in three planes)
 };
 
 // One axis of the sample grid: thread k builds the entry of column (AXIS == 0) or row (AXIS == 1) k of frame blockIdx.y.
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(128) void k_visualizer_axis(const RenderArgs a, con
     }
 
     float4* e = (AXIS == 0 ? t.columns : t.rows) + ((long)frame*n + k)*VIS_ENTRY_QUADS;
-    const int cell_bytes = AXIS == 0 ? 48 : t.tile_pitch*48;
+    const int cell_bytes = AXIS == 0 ? t.cell_bytes : t.tile_pitch*t.cell_bytes;
     e[0] = make_float4(r, frac_r, __int_as_float((int)cell_r*cell_bytes), __int_as_float(start*cell_bytes));
     if (AXIS == 0) {
         // rotate2d(-PI/2)*uv (visualizer.frag:39): x' = rot_c*x + rot_s*y, y' = (-rot_s)*x + rot_c*y — the products of x
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(128) void k_visualizer_axis(const RenderArgs a, con
             // on the sample ROW and the walk step only: 10 entries per row instead of eight instructions per tap quadruple of
             // every sample, and wave-uniform for a wave whose lanes share their rows
             const float dstep = (a.tap_x[11] - a.tap_x[10])*ax, dfirst = a.tap_x[10]*ax;
-            const float row_bytes = (float)(t.tile_pitch*48);
+            const float row_bytes = (float)(t.tile_pitch*t.cell_bytes);
             float4* ys = t.ysteps + ((long)frame*n + k)*10;
             for (int w = 0; w < 10; w++) {
                 const float d = fmaf((float)w, dstep, dfirst);
@@ -255,7 +256,10 @@ __device__ __forceinline__ uint32_t visualizer_fast_post(const RenderArgs& a, in
 }
 
 // Stages the window [x0, x0+tw) x [y0, y0+th) of the background as difference-basis cells (VisualizerShader::setup step 2)
-template <int TILE_PITCH, int THREADS>
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+// PLANE_CELLS == 0: float32 cells, a cell's three float4 side by side (48 bytes); otherwise float16 cells — every component is an
+// integer of magnitude <= 510, exact in float16 — as three planes of one half4 (8 bytes) per cell, PLANE_CELLS cells apart
+template <int TILE_PITCH, int THREADS, int PLANE_CELLS = 0>
 __device__ __forceinline__ void visualizer_fast_stage(const Tex& bg, float4* cells, int x0, int y0, int tw, int th, int tid) {
     const uint8_t* data = (const uint8_t*)bg.data;
     const int comps = bg.components;
@@ -274,10 +278,17 @@ __device__ __forceinline__ void visualizer_fast_stage(const Tex& bg, float4* cel
         const float r10 = (float)(w10 & 255u), g10 = (float)((w10 >> 8) & 255u), b10 = (float)((w10 >> 16) & 255u);
         const float r01 = (float)(w01 & 255u), g01 = (float)((w01 >> 8) & 255u), b01 = (float)((w01 >> 16) & 255u);
         const float r11 = (float)(w11 & 255u), g11 = (float)((w11 >> 8) & 255u), b11 = (float)((w11 >> 16) & 255u);
-        float4* cell = cells + (ty*TILE_PITCH + tx)*3;
-        cell[0] = make_float4(r00, g00, b00, r10 - r00);
-        cell[1] = make_float4(g10 - g00, b10 - b00, r01 - r00, g01 - g00);
-        cell[2] = make_float4(b01 - b00, (r00 - r10) - (r01 - r11), (g00 - g10) - (g01 - g11), (b00 - b10) - (b01 - b11));
+        if constexpr (PLANE_CELLS != 0) {
+            half4* cell = (half4*)cells + (ty*TILE_PITCH + tx);
+            cell[0] = half4{(_Float16)r00, (_Float16)g00, (_Float16)b00, (_Float16)(r10 - r00)};
+            cell[PLANE_CELLS] = half4{(_Float16)(g10 - g00), (_Float16)(b10 - b00), (_Float16)(r01 - r00), (_Float16)(g01 - g00)};
+            cell[2*PLANE_CELLS] = half4{(_Float16)(b01 - b00), (_Float16)((r00 - r10) - (r01 - r11)), (_Float16)((g00 - g10) - (g01 - g11)), (_Float16)((b00 - b10) - (b01 - b11))};
+        } else {
+            float4* cell = cells + (ty*TILE_PITCH + tx)*3;
+            cell[0] = make_float4(r00, g00, b00, r10 - r00);
+            cell[1] = make_float4(g10 - g00, b10 - b00, r01 - r00, g01 - g00);
+            cell[2] = make_float4(b01 - b00, (r00 - r10) - (r01 - r11), (g00 - g10) - (g01 - g11), (b00 - b10) - (b01 - b11));
+        }
     }
 }
 
@@ -463,7 +474,23 @@ struct VisualizerStrip {
     static constexpr int BLOCK_PX = COLS/S;                            // output pixels of a row per block: 128, 32
     static constexpr int RROWS = ROW_GROUPS*WALK;                      // sample rows of a block
     static constexpr int PIXEL_ROWS = RROWS/S;                         // output rows of a block
-    static constexpr int ROWBYTES = TILE_PITCH*48;
+    // Cell format. At 4K 2xSSAA the lanes of a wave are a quarter of a texel apart and mostly read the SAME cell (a broadcast): the
+    // kernel is bound by VALU issue and float32 cells with plain v_fmac are the cheapest. Without SSAA at 1080p they
+    // are 0.87 texel apart: 56 DIFFERENT cells per wave, every ds_read_b128 moves 1 KB = 8 LDS cycles, and the kernel is bound by LDS
+    // bandwidth (SQ_LDS_IDX_ACTIVE 0.90 of the CU cycles, VALU 0.55; profiles/r03_c2_counters.txt). There the cells are FLOAT16 —
+    // every component is a texel byte or a difference of texel bytes, an integer of magnitude <= 510: exact — in three planes of 8
+    // bytes per cell: half the LDS bytes, the multiply-adds that touch cell data become v_fma_mix_f32 (f16 operands converted on the
+    // fly, half issue rate — the slack is there), and the results are the float32 kernel's bit for bit.
+    static constexpr bool HALF = (S == 1);
+    using Quad = typename std::conditional<HALF, half4, float4>::type;
+    static constexpr int CELL = HALF ? 8 : 48;                         // bytes between neighbouring cells
+    static constexpr int PLANE = HALF ? TILE_ROWS*TILE_PITCH*8 : 16;   // bytes between the three quads of one cell
+    static_assert(2*PLANE < 65536, "the planes are reached through ds_read's 16-bit immediate offset");
+    static constexpr int ROWBYTES = TILE_PITCH*CELL;
+    __device__ __forceinline__ static void load_cell(const char* p, Quad& q0, Quad& q1, Quad& q2) {
+        q0 = *(const Quad*)p; q1 = *(const Quad*)(p + PLANE); q2 = *(const Quad*)(p + 2*PLANE);
+    }
+    template <class T> __device__ __forceinline__ static float F(T x) { return (float)x; }     // a cell component as a multiply-add operand
     static_assert(COLUMN_GROUPS*ROW_GROUPS == 8 && RROWS % S == 0 && COLS % S == 0, "block geometry");
     using Fast = VisualizerFast<TILE_PITCH, TILE_ROWS, 128>;
 #ifndef VIS_STRIP_COLUMN_BRANCHFREE
@@ -473,7 +500,7 @@ struct VisualizerStrip {
 #define VIS_STRIP_YSTEPS_LDS 0                                         // 1: the block's ysteps through LDS (broadcast reads + v_readfirstlane) instead of scalar loads
 #endif
     struct Shared {
-        float4 cells[TILE_ROWS*TILE_PITCH*3];                          // later: uint32 texels[RROWS][COLS], then the RGB8 rows at STAGED
+        float4 cells[TILE_ROWS*TILE_PITCH*3/(S == 1 ? 2 : 1) + 1];     // (float16 cells without SSAA) later: uint32 texels[RROWS][COLS], then the RGB8 rows at STAGED
         float4 row_entries[RROWS][VIS_ENTRY_QUADS];
         float4 ysteps[VIS_STRIP_YSTEPS_LDS ? RROWS : 1][10];
         float4 zeros;                                                  // weights of a slot that does not exist
@@ -511,7 +538,7 @@ struct VisualizerStrip {
         const VisualizerConsts c = a.vis_consts ? a.vis_consts[a.frame0 + frame] : a.vis;
         const float4* ce = t.columns + ((long)frame*a.wr + i)*VIS_ENTRY_QUADS;
 
-        if (fits) visualizer_fast_stage<TILE_PITCH, THREADS>(bg, sh.cells, wx.x, wy.x, wx.y, wy.y, tid);
+        if (fits) visualizer_fast_stage<TILE_PITCH, THREADS, HALF ? TILE_ROWS*TILE_PITCH : 0>(bg, sh.cells, wx.x, wy.x, wx.y, wy.y, tid);
         if (tid < RROWS*VIS_ENTRY_QUADS) {
             const int row = tid / VIS_ENTRY_QUADS, quad = tid - row*VIS_ENTRY_QUADS;
             const int jr = by*RROWS + row;
@@ -553,12 +580,12 @@ struct VisualizerStrip {
                         P[0] = P[1] = P[2] = Q[0] = Q[1] = Q[2] = 0.0f;
 #pragma unroll
                         for (int k = 0; k < VIS_LINE_CELLS; k++) {
-                            const float4* q = (const float4*)(line + k*48);
-                            const float4 q0 = q[0], q1 = q[1], q2 = q[2];
-                            P[0] = fmaf(n[k], q0.x, P[0]); P[1] = fmaf(n[k], q0.y, P[1]); P[2] = fmaf(n[k], q0.z, P[2]);
-                            P[0] = fmaf(s[k], q0.w, P[0]); P[1] = fmaf(s[k], q1.x, P[1]); P[2] = fmaf(s[k], q1.y, P[2]);
-                            Q[0] = fmaf(n[k], q1.z, Q[0]); Q[1] = fmaf(n[k], q1.w, Q[1]); Q[2] = fmaf(n[k], q2.x, Q[2]);
-                            Q[0] = fmaf(s[k], q2.y, Q[0]); Q[1] = fmaf(s[k], q2.z, Q[1]); Q[2] = fmaf(s[k], q2.w, Q[2]);
+                            Quad q0, q1, q2;
+                            load_cell(line + k*CELL, q0, q1, q2);
+                            P[0] = fmaf(n[k], F(q0.x), P[0]); P[1] = fmaf(n[k], F(q0.y), P[1]); P[2] = fmaf(n[k], F(q0.z), P[2]);
+                            P[0] = fmaf(s[k], F(q0.w), P[0]); P[1] = fmaf(s[k], F(q1.x), P[1]); P[2] = fmaf(s[k], F(q1.y), P[2]);
+                            Q[0] = fmaf(n[k], F(q1.z), Q[0]); Q[1] = fmaf(n[k], F(q1.w), Q[1]); Q[2] = fmaf(n[k], F(q2.x), Q[2]);
+                            Q[0] = fmaf(s[k], F(q2.y), Q[0]); Q[1] = fmaf(s[k], F(q2.z), Q[1]); Q[2] = fmaf(s[k], F(q2.w), Q[2]);
                         }
                     }
                     acc[r][0] = fmaf(r0.y, Q[0], P[0]); acc[r][1] = fmaf(r0.y, Q[1], P[1]); acc[r][2] = fmaf(r0.y, Q[2], P[2]);
@@ -576,10 +603,10 @@ struct VisualizerStrip {
                 const int first = start[0];
                 const char* column_cells = tile + __float_as_int(c0.z);
                 for (int k = first; k < last; k++) {
-                    const float4* q = (const float4*)(column_cells + k*ROWBYTES);
-                    const float4 q0 = q[0], q1 = q[1], q2 = q[2];
-                    const float U0 = fmaf(fx, q0.w, q0.x), U1 = fmaf(fx, q1.x, q0.y), U2 = fmaf(fx, q1.y, q0.z);
-                    const float V0 = fmaf(fx, q2.y, q1.z), V1 = fmaf(fx, q2.z, q1.w), V2 = fmaf(fx, q2.w, q2.x);
+                    Quad q0, q1, q2;
+                    load_cell(column_cells + k*ROWBYTES, q0, q1, q2);
+                    const float U0 = fmaf(fx, F(q0.w), F(q0.x)), U1 = fmaf(fx, F(q1.x), F(q0.y)), U2 = fmaf(fx, F(q1.y), F(q0.z));
+                    const float V0 = fmaf(fx, F(q2.y), F(q1.z)), V1 = fmaf(fx, F(q2.z), F(q1.w)), V2 = fmaf(fx, F(q2.w), F(q2.x));
                     if (VIS_STRIP_COLUMN_BRANCHFREE) {
                         float2 weights[WALK];
 #pragma unroll
@@ -629,7 +656,7 @@ struct VisualizerStrip {
 #pragma unroll VIS_STRIP_DIAG_UNROLL
                 for (int w = 0; w < 10; w++) {
                     const float axp = __builtin_amdgcn_fractf(xp), axm = __builtin_amdgcn_fractf(xm);
-                    const int cxp = (int)((xp - axp)*48.0f), cxm = (int)((xm - axm)*48.0f);
+                    const int cxp = (int)((xp - axp)*(float)CELL), cxm = (int)((xm - axm)*(float)CELL);
                     float4 y[WALK];
 #pragma unroll
                     for (int r = 0; r < WALK; r++) y[r] = VIS_STRIP_YSTEPS_LDS ? sh.ysteps[row0 + r][w] : ysteps[r][w];   // { frac(y+), frac(y-), row bytes(y+), row bytes(y-) }
@@ -642,16 +669,18 @@ struct VisualizerStrip {
                         const int cell_row = VIS_STRIP_YSTEPS_LDS ? __builtin_amdgcn_readfirstlane(__float_as_int(side ? y[r].w : y[r].z)) : __float_as_int(side ? y[r].w : y[r].z);
                         if (cell_row != previous[side]) {
                             previous[side] = cell_row;
-                            const float4* p = (const float4*)(tile + (cxp + cell_row));
-                            const float4* m = (const float4*)(tile + (cxm + cell_row));
-                            const float4 p0 = p[0], p1 = p[1], p2 = p[2], m0 = m[0], m1 = m[1], m2 = m[2];
+                            Quad p0, p1, p2, m0, m1, m2;
+                            load_cell(tile + (cxp + cell_row), p0, p1, p2);
+                            load_cell(tile + (cxm + cell_row), m0, m1, m2);
                             float* u = U[side]; float* v = V[side];
-                            u[0] = p0.x + m0.x;          u[1] = p0.y + m0.y;          u[2] = p0.z + m0.z;
-                            u[0] = fmaf(axp, p0.w, u[0]);  u[1] = fmaf(axp, p1.x, u[1]);  u[2] = fmaf(axp, p1.y, u[2]);
-                            u[0] = fmaf(axm, m0.w, u[0]);  u[1] = fmaf(axm, m1.x, u[1]);  u[2] = fmaf(axm, m1.y, u[2]);
-                            v[0] = p1.z + m1.z;          v[1] = p1.w + m1.w;          v[2] = p2.x + m2.x;
-                            v[0] = fmaf(axp, p2.y, v[0]);  v[1] = fmaf(axp, p2.z, v[1]);  v[2] = fmaf(axp, p2.w, v[2]);
-                            v[0] = fmaf(axm, m2.y, v[0]);  v[1] = fmaf(axm, m2.z, v[1]);  v[2] = fmaf(axm, m2.w, v[2]);
+                            // (float16 cells: the sums of two components are exact in float16 — packed adds, two per instruction)
+                            const Quad s0 = p0 + m0, s1 = p1 + m1, s2 = p2 + m2;
+                            u[0] = F(s0.x);          u[1] = F(s0.y);          u[2] = F(s0.z);
+                            u[0] = fmaf(axp, F(p0.w), u[0]);  u[1] = fmaf(axp, F(p1.x), u[1]);  u[2] = fmaf(axp, F(p1.y), u[2]);
+                            u[0] = fmaf(axm, F(m0.w), u[0]);  u[1] = fmaf(axm, F(m1.x), u[1]);  u[2] = fmaf(axm, F(m1.y), u[2]);
+                            v[0] = F(s1.z);          v[1] = F(s1.w);          v[2] = F(s2.x);
+                            v[0] = fmaf(axp, F(p2.y), v[0]);  v[1] = fmaf(axp, F(p2.z), v[1]);  v[2] = fmaf(axp, F(p2.w), v[2]);
+                            v[0] = fmaf(axm, F(m2.y), v[0]);  v[1] = fmaf(axm, F(m2.z), v[1]);  v[2] = fmaf(axm, F(m2.w), v[2]);
                         }
                         const float ay = VIS_STRIP_YSTEPS_LDS ? (side ? y[r].y : y[r].x) : in_vgpr(side ? y[r].y : y[r].x);
                         acc[r][0] = acc[r][0] + U[side][0];           acc[r][1] = acc[r][1] + U[side][1];           acc[r][2] = acc[r][2] + U[side][2];
