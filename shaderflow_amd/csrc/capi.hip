@@ -807,14 +807,14 @@ template <class SHADER> static int launch_fused_s(const RenderArgs& a, int ssaa,
 // One geometry of the fast path: the tables for it, then the kernel. STRIP_S == 0: k_visualizer_fast (a quad of lanes per pixel,
 // 2x SSAA); otherwise k_visualizer_strip<PITCH, ROWS, STRIP_S, WALK, WAVES, CG> (lanes walk strips of their column; 2x or 4x SSAA
 // fused with the resolve, or STRIP_S == 1: the samples to an RGBA8 iScreen).
-template <int PITCH, int ROWS, int STRIP_S, int WALK, int WAVES, int CG = (STRIP_S ? 8/STRIP_S : 4)>
+template <int PITCH, int ROWS, int STRIP_S, int WALK, int WAVES, int CG = (STRIP_S ? 8/STRIP_S : 4), bool HALF = (STRIP_S == 1)>
 static int launch_visualizer_tables_and_kernel(Context* ctx, const RenderArgs& a, int frames, hipStream_t s) {
     constexpr int COLS = STRIP_S ? 64*CG : 256;                       // sample columns per block
     constexpr int BLOCK_ROWS = STRIP_S ? (8/CG)*WALK : 2;             // sample rows per block
     VisTables t;
     t.blocks_x = (a.wr + COLS - 1)/COLS; t.blocks_y = (a.hr + BLOCK_ROWS - 1)/BLOCK_ROWS;
     t.block_columns = COLS; t.block_rows = BLOCK_ROWS; t.tile_pitch = PITCH; t.tile_rows = ROWS;
-    t.cell_bytes = (STRIP_S == 1) ? 8 : 48;                           // the no-SSAA strip instances keep float16 cells in three planes (visualizer_fast.hpp)
+    t.cell_bytes = HALF ? 8 : 48;                                     // float16 cells in three planes where the lanes of a wave read different cells (visualizer_fast.hpp)
     const size_t entries = (size_t)frames*((size_t)a.wr + a.hr)*VIS_ENTRY_QUADS*sizeof(float4);
     const size_t blocks = (size_t)frames*((size_t)t.blocks_x + t.blocks_y)*sizeof(int4);
     const size_t ysteps = STRIP_S ? (size_t)frames*a.hr*10*sizeof(float4) : 0;
@@ -833,7 +833,7 @@ static int launch_visualizer_tables_and_kernel(Context* ctx, const RenderArgs& a
     hipLaunchKernelGGL(k_visualizer_axis<1>, dim3((a.hr + 127)/128, frames), dim3(128), 0, s, a, t);
     if constexpr (STRIP_S != 0) {
         g_last_kernel = "k_visualizer_strip<" + std::to_string(PITCH) + ", " + std::to_string(ROWS) + ", " + std::to_string(STRIP_S) + ", " + std::to_string(WALK) + ", " + std::to_string(WAVES) + ", " + std::to_string(CG) + ">";
-        hipLaunchKernelGGL((k_visualizer_strip<PITCH, ROWS, STRIP_S, WALK, WAVES, CG>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(512), 0, s, a, t);
+        hipLaunchKernelGGL((k_visualizer_strip<PITCH, ROWS, STRIP_S, WALK, WAVES, CG, HALF>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(512), 0, s, a, t);
     } else {
         g_last_kernel = "k_visualizer_fast<" + std::to_string(PITCH) + ", " + std::to_string(ROWS) + ", 128, " + std::to_string(WAVES) + ">";
         hipLaunchKernelGGL((k_visualizer_fast<PITCH, ROWS, 128, WAVES>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(512), 0, s, a, t);
@@ -918,7 +918,28 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
         if (VIS_STRIP_WALK1 == 2 && fits(64, 16, 66, 22)) return launch_visualizer_tables_and_kernel<66, 22, 1, 2, 4, 1>(ctx, a, frames, s);
         if (fits(64, 8, 66, 15)) return launch_visualizer_tables_and_kernel<66, 15, 1, 1, 6, 1>(ctx, a, frames, s);
     } else if (ssaa == 2) {
-        if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*WALK2, VIS_STRIP_PITCH2, VIS_STRIP_ROWS2)) return launch_visualizer_tables_and_kernel<VIS_STRIP_PITCH2, VIS_STRIP_ROWS2, 2, WALK2, VIS_STRIP_WAVES2>(ctx, a, frames, s);
+#ifndef VIS_STRIP_HALF2
+#define VIS_STRIP_HALF2 false
+#endif
+// float16 cells (visualizer_fast.hpp): where the lanes of a wave read DIFFERENT cells the kernel is bound by LDS bandwidth and
+// half the bytes win — 1080p 2x 7 200 -> 7 970, 1440p 2x 4 480 -> 4 920, 720p 2x 9 430 -> 13 270 frames/s (profiles/r03_variants.txt);
+// at 4K 2x the lanes share their cells and plain float32 multiply-adds are cheaper
+#ifndef VIS_DENSE_HALF
+#define VIS_DENSE_HALF true
+#endif
+#ifndef VIS_SPARSE_HALF
+#define VIS_SPARSE_HALF true
+#endif
+#ifndef VIS_STRIP_HALF4
+#define VIS_STRIP_HALF4 false
+#endif
+#ifndef VIS_MID4_HALF
+#define VIS_MID4_HALF false
+#endif
+#ifndef VIS_SPARSE4_HALF
+#define VIS_SPARSE4_HALF false
+#endif
+        if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*WALK2, VIS_STRIP_PITCH2, VIS_STRIP_ROWS2)) return launch_visualizer_tables_and_kernel<VIS_STRIP_PITCH2, VIS_STRIP_ROWS2, 2, WALK2, VIS_STRIP_WAVES2, 4, VIS_STRIP_HALF2>(ctx, a, frames, s);
         // denser outputs (1080p or 1440p at 2x SSAA over a 1080-row background: up to 0.43 texel per sample): strips of six rows
         // over a 120 x 13 tile, two blocks per CU
 #ifndef VIS_DENSE_WALK
@@ -927,7 +948,7 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
 #ifndef VIS_DENSE_ROWS
 #define VIS_DENSE_ROWS 13
 #endif
-        if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*VIS_DENSE_WALK, 120, VIS_DENSE_ROWS)) return launch_visualizer_tables_and_kernel<120, VIS_DENSE_ROWS, 2, VIS_DENSE_WALK, 4>(ctx, a, frames, s);
+        if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*VIS_DENSE_WALK, 120, VIS_DENSE_ROWS)) return launch_visualizer_tables_and_kernel<120, VIS_DENSE_ROWS, 2, VIS_DENSE_WALK, 4, 4, VIS_DENSE_HALF>(ctx, a, frames, s);
         // sparser still (720p at 2x SSAA: 0.65 texel per sample): 128 columns x 12 rows per block, strips of three, 92 x 16 tile
 #ifndef VIS_SPARSE_WALK
 #define VIS_SPARSE_WALK 3
@@ -935,10 +956,10 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
 #ifndef VIS_SPARSE_ROWS
 #define VIS_SPARSE_ROWS 16
 #endif
-        if (VIS_FAST_WALK > 0 && !plain && fits(128, 4*VIS_SPARSE_WALK, 92, VIS_SPARSE_ROWS)) return launch_visualizer_tables_and_kernel<92, VIS_SPARSE_ROWS, 2, VIS_SPARSE_WALK, 4, 2>(ctx, a, frames, s);
+        if (VIS_FAST_WALK > 0 && !plain && fits(128, 4*VIS_SPARSE_WALK, 92, VIS_SPARSE_ROWS)) return launch_visualizer_tables_and_kernel<92, VIS_SPARSE_ROWS, 2, VIS_SPARSE_WALK, 4, 2, VIS_SPARSE_HALF>(ctx, a, frames, s);
         if (fits(256, 2, 72, 10)) return launch_visualizer_tables_and_kernel<72, 10, 0, 0, 8>(ctx, a, frames, s);
     } else if (VIS_FAST_WALK > 0) {
-        if (fits(128, 4*WALK4, 40, VIS_STRIP_ROWS4)) return launch_visualizer_tables_and_kernel<40, VIS_STRIP_ROWS4, 4, WALK4, VIS_STRIP_WAVES4>(ctx, a, frames, s);
+        if (fits(128, 4*WALK4, 40, VIS_STRIP_ROWS4)) return launch_visualizer_tables_and_kernel<40, VIS_STRIP_ROWS4, 4, WALK4, VIS_STRIP_WAVES4, 2, VIS_STRIP_HALF4>(ctx, a, frames, s);
         // 1080p at 4x SSAA: the same tile width with strips of six rows
 #ifndef VIS_MID4_WALK
 #define VIS_MID4_WALK 6
@@ -952,9 +973,9 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
 #ifndef VIS_SPARSE4_ROWS
 #define VIS_SPARSE4_ROWS 16
 #endif
-        if (WALK4 != VIS_MID4_WALK && fits(128, 4*VIS_MID4_WALK, 40, VIS_MID4_ROWS)) return launch_visualizer_tables_and_kernel<40, VIS_MID4_ROWS, 4, VIS_MID4_WALK, 8>(ctx, a, frames, s);
+        if (WALK4 != VIS_MID4_WALK && fits(128, 4*VIS_MID4_WALK, 40, VIS_MID4_ROWS)) return launch_visualizer_tables_and_kernel<40, VIS_MID4_ROWS, 4, VIS_MID4_WALK, 8, 2, VIS_MID4_HALF>(ctx, a, frames, s);
         // 720p at 4x SSAA (0.32 texel per sample)
-        if (fits(128, 4*VIS_SPARSE4_WALK, 56, VIS_SPARSE4_ROWS)) return launch_visualizer_tables_and_kernel<56, VIS_SPARSE4_ROWS, 4, VIS_SPARSE4_WALK, 8>(ctx, a, frames, s);
+        if (fits(128, 4*VIS_SPARSE4_WALK, 56, VIS_SPARSE4_ROWS)) return launch_visualizer_tables_and_kernel<56, VIS_SPARSE4_ROWS, 4, VIS_SPARSE4_WALK, 8, 2, VIS_SPARSE4_HALF>(ctx, a, frames, s);
     }
     return 0;
 }

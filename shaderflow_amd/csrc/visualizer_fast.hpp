@@ -464,7 +464,7 @@ struct VisualizerFast {
 // the four lanes of a quad: wave w holds the WALK consecutive sample rows of row group w % ROW_GROUPS for the 64 sample columns of
 // column group w / ROW_GROUPS; the RGBA8 texels meet in LDS (over the cells, which are dead by then) and one thread per output pixel resolves all
 // three channels — cheaper than the DPP exchange it replaces.
-template <int TILE_PITCH, int TILE_ROWS, int S, int WALK, int COLUMN_GROUPS = 8/S>
+template <int TILE_PITCH, int TILE_ROWS, int S, int WALK, int COLUMN_GROUPS = 8/S, bool HALF_CELLS = (S == 1)>
 struct VisualizerStrip {
     // S x S supersamples per pixel (2 or 4), or S == 1: no resolve, the RGBA8 samples go to iScreen (the two-pass configuration).
     // A block is 512 threads = 8 waves = COLUMN_GROUPS groups of 64 sample columns x ROW_GROUPS groups of WALK consecutive rows.
@@ -481,7 +481,7 @@ struct VisualizerStrip {
     // every component is a texel byte or a difference of texel bytes, an integer of magnitude <= 510: exact — in three planes of 8
     // bytes per cell: half the LDS bytes, the multiply-adds that touch cell data become v_fma_mix_f32 (f16 operands converted on the
     // fly, half issue rate — the slack is there), and the results are the float32 kernel's bit for bit.
-    static constexpr bool HALF = (S == 1);
+    static constexpr bool HALF = HALF_CELLS;
     using Quad = typename std::conditional<HALF, half4, float4>::type;
     static constexpr int CELL = HALF ? 8 : 48;                         // bytes between neighbouring cells
     static constexpr int PLANE = HALF ? TILE_ROWS*TILE_PITCH*8 : 16;   // bytes between the three quads of one cell
@@ -499,14 +499,17 @@ struct VisualizerStrip {
 #ifndef VIS_STRIP_YSTEPS_LDS
 #define VIS_STRIP_YSTEPS_LDS 0                                         // 1: the block's ysteps through LDS (broadcast reads + v_readfirstlane) instead of scalar loads
 #endif
+    // the cell tile; once every wave is done with it, the texel exchange and the staged RGB8 rows live in the same memory
+    static constexpr int CELLS_BYTES = TILE_ROWS*TILE_PITCH*(HALF_CELLS ? 24 : 48);
+    static constexpr int EXCHANGE_BYTES = (S == 1) ? 0 : (int)sizeof(uint32_t)*ROW_GROUPS*WALK*64*COLUMN_GROUPS + (ROW_GROUPS*WALK/S)*(64*COLUMN_GROUPS/S)*3;
     struct Shared {
-        float4 cells[TILE_ROWS*TILE_PITCH*3/(S == 1 ? 2 : 1) + 1];     // (float16 cells without SSAA) later: uint32 texels[RROWS][COLS], then the RGB8 rows at STAGED
+        float4 cells[(CELLS_BYTES > EXCHANGE_BYTES ? CELLS_BYTES : EXCHANGE_BYTES)/16 + 1];     // (float16 cells without SSAA) later: uint32 texels[RROWS][COLS], then the RGB8 rows at STAGED
         float4 row_entries[RROWS][VIS_ENTRY_QUADS];
         float4 ysteps[VIS_STRIP_YSTEPS_LDS ? RROWS : 1][10];
         float4 zeros;                                                  // weights of a slot that does not exist
     };
     static constexpr int STAGED = (int)sizeof(uint32_t)*RROWS*COLS;    // byte offset of the staged RGB8 rows inside the (dead) cell tile, after the texels
-    static_assert(S == 1 || STAGED + PIXEL_ROWS*BLOCK_PX*3 <= (int)sizeof(float4)*TILE_ROWS*TILE_PITCH*3, "the texel exchange and the staged rows live in the cell tile");
+    static_assert(S == 1 || STAGED + PIXEL_ROWS*BLOCK_PX*3 == EXCHANGE_BYTES, "the texel exchange and the staged rows live in the cell tile");
 
     // a wave-uniform float that has to sit in a vector register: VALU operations with a scalar operand issue at half rate on gfx950
     // (tools/ubench_valu.hip), one v_mov per value used three times is cheaper
@@ -769,9 +772,9 @@ struct VisualizerStrip {
     }
 };
 
-template <int TILE_PITCH, int TILE_ROWS, int S, int WALK, int MIN_WAVES, int COLUMN_GROUPS = 8/S>
+template <int TILE_PITCH, int TILE_ROWS, int S, int WALK, int MIN_WAVES, int COLUMN_GROUPS = 8/S, bool HALF_CELLS = (S == 1)>
 __global__ __launch_bounds__(512, MIN_WAVES) void k_visualizer_strip(const RenderArgs a, const VisTables t) {
-    VisualizerStrip<TILE_PITCH, TILE_ROWS, S, WALK, COLUMN_GROUPS>::run(a, t);
+    VisualizerStrip<TILE_PITCH, TILE_ROWS, S, WALK, COLUMN_GROUPS, HALF_CELLS>::run(a, t);
 }
 
 template <int TILE_PITCH, int TILE_ROWS, int BLOCK_PX, int MIN_WAVES>
