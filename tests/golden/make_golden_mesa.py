@@ -193,6 +193,37 @@ def main() -> None:
     export("multishader", demo.MultiShader(), width=64, height=36, frames=2, pick=(1,))
     export("raymarch", demo.RayMarch(), width=96, height=54, frames=3, pick=(2,), ssaa=2)
 
+    # a scene that drives the camera from update(): move, zoom, rotate2d (the camera's second-order systems, quaternion rotation,
+    # right/up/forward basis: camera.py:196-235 → camera.glsl) and a projection switch; tests/test_gpu_scene.py has the same class
+    from shaderflow.camera import CameraProjection
+
+    snapshots = []
+
+    @define
+    class Snapshot(ShaderModule):
+        def update(self):
+            snapshots.append({v.name: np.array(v.value, dtype=np.float64).ravel() for v in self.scene.shader.full_pipeline()
+                              if v.type != "sampler2D" and v.value is not None})
+
+    class Moving(demo.Basic):
+        frame_count = 0
+
+        def build(self):
+            Snapshot(scene=self, name="snapshot")
+
+        def update(self):
+            self.camera.move(np.array([0.02, -0.01, 0.0]))
+            self.camera.apply_zoom(0.05)
+            self.camera.rotate2d(3.0)
+            if self.frame_count == 3:
+                self.camera.projection = CameraProjection.Stereoscopic
+            self.frame_count += 1
+    export("moving_camera", Moving(), width=96, height=54, frames=6, fps=30.0)
+    names = sorted(snapshots[0])
+    out["scene.moving_camera.uniform_names"] = np.array(names)
+    out["scene.moving_camera.uniform_sizes"] = np.array([len(snapshots[0][n]) for n in names])
+    out["scene.moving_camera.uniforms"] = np.stack([np.concatenate([snap[n] for n in names]) for snap in snapshots[-6:]])     # the pipeline's values, frame by frame
+
     # synthetic assets in place of the downloads of demo.py:16-49 (same generators the product's example scenes use)
     street = synth.background_image(480, 270)
     Image.fromarray(street).save(WORK/"street.png")

@@ -122,6 +122,49 @@ def test_layered_temporal_and_scripted_scenes():
     same_frames("life", export(S.Life(), "life"))
 
 
+def test_scene_that_drives_the_camera():
+    """The same scene class on both sides (move / zoom / rotate2d / projection switch from update()): the product's camera systems
+    emit the reference's uniform values frame by frame (float64 DynamicNumbers on the host, as in the reference), and its frames
+    are the reference's within the default fragment's bound"""
+    from examples.scenes import Basic
+    from shaderflow_amd.camera import CameraProjection
+    from shaderflow_amd.module import ShaderModule
+    snapshots = []
+
+    class Snapshot(ShaderModule):
+        def update(self):
+            snapshots.append({v.name: np.array(v.value, dtype=np.float64).ravel() for v in self.scene.shader.full_pipeline()
+                              if v.type != "sampler2D" and v.value is not None})
+
+    class Moving(Basic):
+        frame_count = 0
+
+        def build(self):
+            Snapshot(scene=self)
+
+        def update(self):
+            self.camera.move(np.array([0.02, -0.01, 0.0]))
+            self.camera.apply_zoom(0.05)
+            self.camera.rotate2d(3.0)
+            if self.frame_count == 3:
+                self.camera.projection = CameraProjection.Stereoscopic
+            self.frame_count += 1
+
+    got = export(Moving(), "moving_camera")
+    want = G["scene.moving_camera.frames"]
+    for k in range(6):
+        d = np.abs(got[k].astype(int) - want[k].astype(int))
+        assert (d <= 1).mean() >= 0.99, (k, d.max())                        # default.glsl's ring (1/circle^2 next to zero)
+    names, sizes, values = G["scene.moving_camera.uniform_names"], G["scene.moving_camera.uniform_sizes"], G["scene.moving_camera.uniforms"]
+    for k in range(6):
+        at = 0
+        for name, size in zip(names, sizes):
+            if str(name).startswith("iCamera"):
+                mine = snapshots[k][str(name)]
+                assert np.allclose(mine, values[k][at:at + size], rtol=1e-12, atol=1e-14), (k, str(name), mine, values[k][at:at + size])
+            at += size
+
+
 @pytest.mark.parametrize("batch", [None, False])
 def test_audio_scenes_from_pcm_to_frames(batch):
     """The north star's parity statement with the reference on the other side: the product exports the scene from PCM (STFT,

@@ -171,6 +171,38 @@ def test_layered_and_temporal_scenes():
     scene("life", R.life_scene(G["scene.life.first"], 128, 72, 60.0, 20)[[0, 1, 5, 6, 7, 12, 13, 19]])
 
 
+def reference_uniforms(tag: str, frame: int, w: int, h: int) -> "O.Uniforms":
+    """The values the REFERENCE's pipeline emitted for that frame (captured by a module of the exported scene), as oracle uniforms"""
+    names, sizes, values = G[f"scene.{tag}.uniform_names"], G[f"scene.{tag}.uniform_sizes"], G[f"scene.{tag}.uniforms"][frame]
+    u, at = O.default_uniforms(w, h), 0
+    for name, size in zip(names, sizes):
+        value = values[at:at + size]
+        at += size
+        if hasattr(u, str(name)):
+            current = getattr(u, str(name))
+            if hasattr(current, "__len__"):
+                for i in range(len(current)):
+                    current[i] = float(value[i])
+            else:
+                setattr(u, str(name), type(current)(value[0]))
+    return u
+
+
+def test_scene_that_drives_the_camera():
+    """move / zoom / rotate2d / projection switch from update(): the reference's camera systems (float64 DynamicNumbers, quaternion
+    rotation → right/up/forward) produce the uniforms, its camera.glsl the pixels; the oracle on those uniforms gives the frames"""
+    got = G["scene.moving_camera.frames"]
+    for k in range(6):
+        u = reference_uniforms("moving_camera", k, 96, 54)
+        want = O.resolve(O.render("default", u, {}, 96, 54, threads=4), 96, 54, 2)
+        d = np.abs(got[k].astype(int) - want.astype(int))
+        assert (d <= 1).mean() >= 0.99, (k, d.max(), (d <= 1).mean())           # default.glsl's ring: a 96 x 54 frame has little else
+    assert not np.array_equal(got[0], got[5])
+    names = list(G["scene.moving_camera.uniform_names"])
+    at = int(np.sum(G["scene.moving_camera.uniform_sizes"][:names.index("iCameraProjection")]))
+    assert G["scene.moving_camera.uniforms"][2][at] == 0 and G["scene.moving_camera.uniforms"][5][at] == 1
+
+
 def test_scene_with_python_logic_between_frames():
     scene("dynamics", R.dynamics_scene(synth.background_image(480, 270), 128, 72, 60.0, 90, (0, 1, 30, 59, 61, 89)), 0.99, bound=2)
 
