@@ -240,6 +240,22 @@ class FrameTape:
         def emit_frames(pointer: int, count: int, fence: Optional[int] = None) -> None:
             export.pipe_device_frames(pointer, frame_bytes, count, turbo=turbo, fence=fence)
 
+        mode = shard_mode() if world > 1 else "single"
+        if mode.startswith("device"):
+            # device modes keep every frame of the export resident in rank 0's HBM (a 60 s 4K clip: 89.6 GB of 288). A clip that does
+            # not fit falls back to host mode — for ALL ranks: rank 0 decides, everybody follows
+            import torch
+            import torch.distributed as dist
+            verdict = [True]
+            if rank == 0:
+                free, _ = torch.cuda.mem_get_info(context.device)
+                verdict[0] = total*frame_bytes + (4 << 30) < free
+            dist.broadcast_object_list(verdict, src=0)
+            if not verdict[0]:
+                if rank == 0:
+                    print(f"shaderflow_amd: {total} frames of {frame_bytes >> 20} MiB do not fit rank 0's free device memory: "
+                          f"SHADERFLOW_SHARD={mode} falls back to host mode", flush=True)
+                mode = "host"
         try:
             if world == 1:
                 buffers = [context.alloc(frame_bytes*self.batch) for _ in range(2)]
@@ -264,7 +280,7 @@ class FrameTape:
                     context.synchronize()
                     for pointer in buffers:
                         context.free(pointer)
-            elif shard_mode() == "host":
+            elif mode == "host":
                 # every rank reads its own batches out over its own PCIe link into shared memory; rank 0's writer thread hands
                 # them to the sink in frame order (parallel.HostDelivery): no collective on the data path
                 slots = int(os.environ.get("SHADERFLOW_SHM_SLOTS", 0)) or max(4, min(2*self.batch, (4 << 30)//frame_bytes))
@@ -286,7 +302,7 @@ class FrameTape:
                 first, last = shard_frames(total, world, rank)
                 frames_here = total if rank == 0 else (last - first)
                 window = None
-                if shard_mode() == "device-sdma":
+                if mode == "device-sdma":
                     # peer windows: rank 0's buffer is ONE raw allocation (IPC handles name whole allocations), mapped by every rank
                     if rank == 0:
                         window = context.alloc(max(1, frames_here)*frame_bytes)
@@ -309,7 +325,7 @@ class FrameTape:
 
                 contiguous_device_export(world, rank, total, self.batch, frame_bytes, self.build, render, emit, resident, transfer)
                 export.drain()                                  # `resident` outlives the queued reads
-                if shard_mode() == "device-sdma":
+                if mode == "device-sdma":
                     import torch.distributed as dist
                     dist.barrier()                              # every peer has closed its mapping of the window
                     if window is not None:
