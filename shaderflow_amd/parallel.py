@@ -222,9 +222,19 @@ class HostDelivery:
             dist.broadcast_object_list(name, src=0)                 # one segment name and one ring size for the group
         slots = int(name[1])
         self.handle = N.Handle()
-        N.check(N.lib().sfx_shm_create(context.handle, name[0].encode(), rank, world, frame_bytes, slots, C.byref(self.handle)))
+        failure = None
+        try:
+            N.check(N.lib().sfx_shm_create(context.handle, name[0].encode(), rank, world, frame_bytes, slots, C.byref(self.handle)))
+        except Exception as error:                                  # tell the group instead of leaving it in a barrier
+            failure = f"rank {rank}: {error}"
         if world > 1:
-            dist.barrier()                                          # every rank has mapped the segment …
+            reports = [None]*world
+            dist.all_gather_object(reports, failure)                # every rank has mapped the segment … or everybody learns who has not
+            failure = next((report for report in reports if report), None)
+        if failure:
+            if self.handle.value:
+                N.lib().sfx_shm_destroy(self.handle)
+            raise RuntimeError(f"cross-process frame ring: {failure}")
         if rank == 0:
             N.check(N.lib().sfx_shm_unlink(self.handle))            # … so its name can go: a crash leaves nothing in /dev/shm
             # without a sink (fileno None: a benchmark or a freewheeling run under torchrun) the writer still consumes every frame,
