@@ -676,12 +676,18 @@ struct VisualizerStrip {
                             load_cell(tile + (cxp + cell_row), p0, p1, p2);
                             load_cell(tile + (cxm + cell_row), m0, m1, m2);
                             float* u = U[side]; float* v = V[side];
-                            // (float16 cells: the sums of two components are exact in float16 — packed adds, two per instruction)
-                            const Quad s0 = p0 + m0, s1 = p1 + m1, s2 = p2 + m2;
-                            u[0] = F(s0.x);          u[1] = F(s0.y);          u[2] = F(s0.z);
+                            if constexpr (HALF) {
+                                // the sums of two components are exact in float16: packed adds, two per instruction
+                                const Quad s0 = p0 + m0, s1 = p1 + m1, s2 = p2 + m2;
+                                u[0] = F(s0.x); u[1] = F(s0.y); u[2] = F(s0.z);
+                                v[0] = F(s1.z); v[1] = F(s1.w); v[2] = F(s2.x);
+                            } else {
+                                // (six scalar adds: a vector add would become v_pk_add_f32 — twice the issue cost for twelve sums, six unused)
+                                u[0] = p0.x + m0.x; u[1] = p0.y + m0.y; u[2] = p0.z + m0.z;
+                                v[0] = p1.z + m1.z; v[1] = p1.w + m1.w; v[2] = p2.x + m2.x;
+                            }
                             u[0] = fmaf(axp, F(p0.w), u[0]);  u[1] = fmaf(axp, F(p1.x), u[1]);  u[2] = fmaf(axp, F(p1.y), u[2]);
                             u[0] = fmaf(axm, F(m0.w), u[0]);  u[1] = fmaf(axm, F(m1.x), u[1]);  u[2] = fmaf(axm, F(m1.y), u[2]);
-                            v[0] = F(s1.z);          v[1] = F(s1.w);          v[2] = F(s2.x);
                             v[0] = fmaf(axp, F(p2.y), v[0]);  v[1] = fmaf(axp, F(p2.z), v[1]);  v[2] = fmaf(axp, F(p2.w), v[2]);
                             v[0] = fmaf(axm, F(m2.y), v[0]);  v[1] = fmaf(axm, F(m2.z), v[1]);  v[2] = fmaf(axm, F(m2.w), v[2]);
                         }
