@@ -21,6 +21,10 @@ pytestmark = pytest.mark.gpu
 HERE = Path(__file__).parent
 G = np.load(HERE/"golden"/"jit.npz")
 CASES = json.loads(str(G["cases"]))
+# the same fragments as `scene.shader.fragment` of a scene of the reference itself, rendered on desktop OpenGL (Mesa llvmpipe:
+# tests/golden/make_golden_jit_mesa.py; even sizes only — scene.main() fits resolutions to even numbers)
+M = np.load(HERE/"golden"/"jit_mesa.npz")
+MESA_CASES = json.loads(str(M["cases"]))
 CACHE = HERE.parent/"build"/"jit"
 
 
@@ -65,6 +69,17 @@ def test_translated_fragment_against_an_opengl_implementation(gpu, name):
     print(name, lsb_report(got, want))
     # differences of neighbouring pixels scaled by the resolution amplify the last bit of the built-ins: more 1 LSB values there
     assert d.max() <= 1 and (d == 0).mean() >= (0.95 if name.startswith("edges") else 0.98), lsb_report(got, want)
+
+
+@pytest.mark.parametrize("name", list(MESA_CASES))
+def test_translated_fragment_against_the_reference_on_desktop_opengl(gpu, name):
+    """The translated code object against what the REFERENCE renders with the same text as its fragment (its own source assembly,
+    `#version 330`, Mesa llvmpipe): within 1 LSB on every value"""
+    got = render_case(gpu, name)
+    want = M[f"{name}.image"]
+    d = np.abs(got.astype(int) - want.astype(int))
+    print(name, lsb_report(got, want))
+    assert d.max() <= 1 and (d == 0).mean() >= 0.90, lsb_report(got, want)
 
 
 GRADIENT = """
