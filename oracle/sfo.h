@@ -12,7 +12,7 @@
  *       Python (ShaderScene.main and everything under it, unmodified) rendering through Mesa llvmpipe (OpenGL 4.5 core, the
  *       software rasteriser BASELINE.json names) with its GLSL as shader.py:190-239 assembles it — tests/golden/mesa.npz and
  *       mesa_4k.npz, written by tests/golden/make_golden_mesa*.py (refhost.py, mesa_shim.c say how): probes of every fragment on
- *       the parity tests' inputs, thirteen example scenes exported by scene.main(), two whole 3840x2160 2xSSAA frames.
+ *       the parity tests' inputs, fifteen example scenes exported by scene.main(), two whole 3840x2160 2xSSAA frames.
  *       tests/test_oracle_mesa.py: byte for byte on several, within 1 LSB elsewhere except where measured and bounded there
  *       (llvmpipe's 8-fractional-bit filter weights: up to 1.3 % of the values 2 LSB off where an 8-bit texture is filtered twice
  *       at 1:1; one supersample across a bar's edge in 1e5 pixels at 4K; tetration's chaotic boundary; default.glsl's ring).

@@ -46,7 +46,7 @@ from shaderflow.variable import Uniform  # noqa: E402
 
 from oracle import binding as O  # noqa: E402  (only for the Uniforms field list of the parity tests' inputs)
 from shaderflow_amd import synth  # noqa: E402
-from tests.helpers import i16_to_f32, visualizer_inputs  # noqa: E402
+from tests.helpers import SCROLL_FRAGMENT, i16_to_f32, visualizer_inputs  # noqa: E402
 
 REF = refhost.REFERENCE
 SHADERS = REF/"shaderflow/resources/shaders"
@@ -260,6 +260,22 @@ def main() -> None:
     export("visualizer.ssaa1", with_audio(demo.Visualizer, clip), width=192, height=108, ssaa=1, frames=60, fps=fps, pick=(1, 30, 59))
     export("musicbars", with_audio(demo.MusicBars, clip), width=160, height=90, ssaa=2, frames=60, fps=fps, pick=(1, 30, 59))
     export("waveform", with_audio(demo.Waveform, clip), width=160, height=90, ssaa=2, frames=60, fps=fps, pick=(1, 30, 59))
+
+    # a scrolling spectrogram (length > 0: a texture `length*fps` columns wide, one column rewritten per frame) shown by a fragment of
+    # this repository's own — on the product's side it goes through the run-time translator
+    from shaderflow.audio import ShaderAudio
+    from shaderflow.audio.spectrogram import ShaderSpectrogram
+    from shaderflow.piano import PianoNote
+    sweep = refhost.write_wav_f32(WORK/"sweep2.wav", synth.sweep_clip(2.0, 44100), 44100)
+    for smooth in (False, True):
+        class Scroller(ShaderScene):
+            def build(self):
+                self.audio = ShaderAudio(scene=self, name="iAudio", file="/path/to/audio.ogg")
+                self.spectrogram = ShaderSpectrogram(scene=self, audio=self.audio, length=0.5, smooth=smooth)
+                self.spectrogram.from_notes(start=PianoNote.from_frequency(20), end=PianoNote.from_frequency(14000), piano=True)
+                self.shader.fragment = SCROLL_FRAGMENT
+        export(f"scroller.{'smooth' if smooth else 'nearest'}", with_audio(Scroller, sweep), width=96, height=54, ssaa=2, frames=100, fps=60.0,
+               pick=(0, 1, 28, 29, 30, 59, 60, 61, 99))
 
     np.savez_compressed(HERE/"mesa.npz", **out)
     print("mesa.npz", (HERE/"mesa.npz").stat().st_size, "bytes,", len(out), "arrays,", f"{time.time() - started:.0f} s")

@@ -133,3 +133,15 @@ def gpu_bind_all(gpu: Gpu, prog, arrays, params):
 def lsb_report(got: np.ndarray, want: np.ndarray) -> str:
     d = np.abs(got.astype(np.int32) - want.astype(np.int32))
     return f"max {d.max()} LSB, {int((d > 0).sum())}/{d.size} differ, {int((d > 1).sum())} above 1 LSB"
+
+
+# A fragment of this repository's own for scrolling spectrograms (ShaderSpectrogram(length > 0), spectrogram.py:272-311): the texture is
+# `length*fps` columns wide, one column is rewritten per frame, iSpectrogramOffset tells where. Rendered by the reference on Mesa
+# (tests/golden/make_golden_mesa.py) and by the product through the run-time translator (tests/test_gpu_translated.py, test_gpu_mesa.py).
+SCROLL_FRAGMENT = """
+void main() {
+    vec2 uv = vec2(astuv.x + iSpectrogramOffset, astuv.y);
+    vec2 s = sqrt(texture(iSpectrogram, uv).xy)/40.0;
+    fragColor = vec4(s, float(iSpectrogramLength)/64.0, 1);
+}
+"""

@@ -180,6 +180,32 @@ def test_audio_scenes_from_pcm_to_frames(batch):
     same_frames("waveform", export(S.make(S.Waveform, audio=audio), "waveform", batch=batch))
 
 
+@pytest.mark.parametrize("smooth", [False, True])
+@pytest.mark.parametrize("batch", [None, False])
+def test_scrolling_spectrogram_through_the_translator(smooth, batch):
+    """ShaderSpectrogram(length = 0.5 s): a 30-column texture, one column rewritten per frame, shown by a fragment of this repository's
+    own. The reference compiled the text with its GL driver and scrolled its numpy spectrogram; here the text goes through glsl2hip and
+    the frame tape keeps one texture state per frame of a batch (k_spectrogram_scroll). Same frames, tape and frame loop."""
+    from shaderflow_amd import ShaderScene
+    from shaderflow_amd.audio import ShaderAudio
+    from shaderflow_amd.audio.spectrogram import ShaderSpectrogram
+    from shaderflow_amd.piano import PianoNote
+    from tests.helpers import SCROLL_FRAGMENT
+    pcm = synth.sweep_clip(2.0, 44100)
+
+    class Scroller(ShaderScene):
+        def build(self):
+            super().build()
+            self.audio = ShaderAudio(scene=self, name="iAudio")
+            self.audio.load(samples=pcm, samplerate=44100)
+            self.spectrogram = ShaderSpectrogram(scene=self, audio=self.audio, length=0.5, smooth=smooth)
+            self.spectrogram.from_notes(start=PianoNote.from_frequency(20), end=PianoNote.from_frequency(14000), piano=True)
+            self.shader.fragment = SCROLL_FRAGMENT
+
+    tag = f"scroller.{'smooth' if smooth else 'nearest'}"
+    same_frames(tag, export(Scroller(), tag, batch=batch))
+
+
 # ---- the benchmark's configuration --------------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("name", ["noise", "bench"])

@@ -177,13 +177,7 @@ def test_a_code_object_with_another_argument_layout_is_refused(gpu, monkeypatch)
     assert b"argument layout" in gpu.lib.sfx_last_error()
 
 
-SCROLL = """
-void main() {
-    vec2 uv = vec2(astuv.x + iSpectrogramOffset, astuv.y);
-    vec2 s = sqrt(texture(iSpectrogram, uv).xy)/40.0;
-    fragColor = vec4(s, float(iSpectrogramLength)/64.0, 1);
-}
-"""
+from tests.helpers import SCROLL_FRAGMENT as SCROLL  # noqa: E402
 
 
 @pytest.mark.parametrize("smooth", [False, True])

@@ -207,6 +207,44 @@ def test_scene_with_python_logic_between_frames():
     scene("dynamics", R.dynamics_scene(synth.background_image(480, 270), 128, 72, 60.0, 90, (0, 1, 30, 59, 61, 89)), 0.99, bound=2)
 
 
+@pytest.mark.parametrize("smooth", [False, True])
+def test_scrolling_spectrogram_scene(smooth):
+    """ShaderSpectrogram(length = 0.5 s) on the reference: a 30-column texture scrolled by its numpy code and shown by a fragment of
+    this repository's own, compiled by Mesa. Here: the oracle's audio tape replays spectrogram.py:298-311 and the HOST build of the
+    run-time translation of the same text (tests/jit_host.py) shades the frames — within 1 LSB"""
+    from shaderflow_amd import glsl2hip
+    from tests.helpers import SCROLL_FRAGMENT
+    from tests.jit_host import HostFragment
+    tag = f"scroller.{'smooth' if smooth else 'nearest'}"
+    w, h, ssaa, _, fps, frames = G[f"scene.{tag}.args"]
+    w, h, ssaa, frames = int(w), int(h), int(ssaa), int(frames)
+    pcm, samplerate, width = synth.sweep_clip(2.0, 44100), 44100, int(0.5*fps)
+    planar = np.ascontiguousarray(pcm.T)
+    times, dts, rdts = O.clock(fps, frames)
+    _, tell = O.reader(rdts, samplerate, 2, planar.shape[1])
+    fmin, fmax, bins = O.from_notes(O.lib().sfo_note_of_frequency(20.0, 440.0), O.lib().sfo_note_of_frequency(14000.0, 440.0), True)
+    indptr, indices, data = O.filterbank(0, 0, fmin, fmax, bins, 12, samplerate)
+    spec = O.DynF32(2*bins, 4, 1, 0)
+    texture = np.zeros((bins, width, 2), np.float32)
+    host = HostFragment(glsl2hip.translate(SCROLL_FRAGMENT, [("sampler2D", "iSpectrogram")]), Path(__file__).parent.parent/"build"/"jit")
+    keep = {int(k): n for n, k in enumerate(G[f"scene.{tag}.index"])}
+    offset = 0
+    for k in range(frames):
+        offset = (offset + 1) % width
+        target = O.csr_dot(indptr, indices, data, O.fft_power(planar, int(tell[k])))
+        texture[:, offset, :] = spec.step(target.ravel(), abs(dts[k])).reshape(bins, 2)
+        if k not in keep:
+            continue
+        u = O.default_uniforms(w, h, iTime=times[k], iTau=(times[k]/(frames/fps)) % 1.0, iDuration=frames/fps, iDeltatime=dts[k], iFramerate=fps,
+                               iFrame=round(times[k]*fps), iSSAA=float(ssaa), iSubsample=2, iSpectrogramLength=width, iSpectrogramBins=bins,
+                               iSpectrogramSmooth=int(smooth), iSpectrogramOffset=offset/width)
+        host.set_uniforms(u)
+        host.bind("iSpectrogram", texture.copy(), "linear" if smooth else "nearest", True, False)
+        want = O.resolve(host.render(w*ssaa, h*ssaa), w, h, 2)
+        d = np.abs(G[f"scene.{tag}.frames"][keep[k]].astype(int) - want.astype(int))
+        assert d.max() <= 1, (tag, k, d.max(), (d > 1).sum())
+
+
 def test_audio_scenes_end_to_end():
     """Audio file → the reference's numpy STFT, filterbank, DynamicNumbers, waveform → its GLSL on llvmpipe → final.glsl → the encoder
     pipe, against the oracle's audio tape + fragments on the same clip: the north star's parity statement, reference on one side"""
