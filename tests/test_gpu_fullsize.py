@@ -53,6 +53,24 @@ def test_c3_whole_frame_single_launch(gpu, volume, seed):
     assert d.max() <= 1, (lsb_report(got, want), np.argwhere(d > 1)[:5].tolist())
 
 
+@pytest.mark.parametrize("w,h,kernel", [(1920, 1080, "k_visualizer_strip<120, 13, 2, 6, "), (1280, 720, "k_visualizer_strip<92, 16, 2, 3, ")])
+def test_dense_2x_instances_whole_frame(gpu, w, h, kernel):
+    """The 2xSSAA instances for outputs denser than 4K over the same background (0.43 / 0.65 texel per sample): their lanes read
+    different cells, so they keep the cells in FLOAT16 (exact: integers <= 510) — whole frames against the oracle, loud and silent"""
+    for volume, seed in ((1.0, 81), (0.0, 82)):
+        u, arrays, params = visualizer_inputs(w, h, seed=seed, volume=volume, bg_size=(1920, 1080))
+        arrays["background"] = np.ascontiguousarray(np.flipud(synth.background_image(1920, 1080)))
+        u.iSSAA = 2.0
+        prog, _ = gpu.program("visualizer")
+        gpu.set_uniforms(prog, u)
+        gpu_bind_all(gpu, prog, arrays, params)
+        got = gpu.render_resolve(prog, w, h, 2, 2)
+        assert gpu.lib.sfx_last_kernel().decode().startswith(kernel) and gpu.lib.sfx_last_kernel().decode().endswith("true>"), gpu.lib.sfx_last_kernel()
+        want = whole_frame(u, arrays, params, w, h, 2)
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert d.max() <= 1, (volume, lsb_report(got, want), np.argwhere(d > 1)[:5].tolist())
+
+
 def prepared_scene(w, h, ssaa, pcm, background, seconds):
     """A Visualizer scene as `scene.main()` leaves it before the first frame (bench.py does the same)"""
     from examples.scenes import Visualizer, make
