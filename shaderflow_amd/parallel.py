@@ -312,7 +312,10 @@ def interleaved_host_export(world: int, rank: int, batches: list[tuple[int, int]
 class RangeTransfer:
     """Point-to-point transfer of frame chunks to rank 0 (RCCL send/recv; staged through host memory under gloo, which has no
     device transport — tests with several processes on one GPU). Rank 0 posts every receive up front, into the places of its
-    resident buffer where the frames belong; a rank's chunks arrive in the order it sends them."""
+    resident buffer where the frames belong; a rank's chunks arrive in the order it sends them. (Up front on purpose: an RCCL send
+    is a kernel that waits for its receive, so a receive posted late would stall the SENDER's stream and with it its renders. The
+    price: a chunk that arrives later than the process group's time-out — NCCL's watchdog, 10 minutes by default — aborts the job;
+    exports that long should raise `timeout=` in init_process_group or use SHADERFLOW_SHARD=device-sdma / host, which post nothing.)"""
 
     def __init__(self, world: int, rank: int, device):
         import torch
