@@ -29,6 +29,7 @@ constexpr int SEP_PIXELS = 256;
 // Output rows a block walks with its column entries in registers: 32 where the launch has blocks to spare (the entries are
 // fetched once per 32 rows and the rows leave in one sweep), 8 for small launches (a single 1080p frame is 272 blocks of 32 rows)
 constexpr int SEP_ROWS_LARGE = 32, SEP_ROWS_SMALL = 8;
+constexpr int SEP_ROWS_DEFAULT = 16;
 
 struct SepTables {
     float4* columns;                     // [frame][wr]
@@ -94,12 +95,14 @@ __global__ __launch_bounds__(256) void k_separable_axis(const RenderArgs a, cons
             e = make_float4(as, 1.0f - as, 0.0f, 0.0f);
         }
     } else if (KIND == SEP_DEFAULT) {
-        // { gluv, parity of floor(uv*grid/2) (default.glsl:4-8, grid = 8), log2(astuv*(1 - astuv)) (:41-43), out of bounds (camera.glsl:83) }
+        // { gluv, parity of floor(uv*grid/2) (default.glsl:4-8, grid = 8), this axis' factor of the vignette (:41-43), out of bounds (camera.glsl:83) }
+        // pow(50*ax(1-ax)*ay(1-ay), 0.1) = (sqrt(50)*ax(1-ax))^0.1 * (sqrt(50)*ay(1-ay))^0.1: one exp2 per table entry instead of one per supersample
         // iCamera.gluv along this axis: gluv itself under the identity camera, get_camera for one coordinate under a zoomed / panned one
         bool behind = false;
         const float uv = a.identity_camera ? g : (column ? camera_along_axis<0>(u, g, a.aspect, behind) : camera_along_axis<1>(u, g, a.aspect, behind));
         const int parity = (int)::floorf(uv*8.0f/2.0f) & 1;
-        e = make_float4(uv, __int_as_float(parity), __builtin_amdgcn_logf(as*(1.0f - as)), __int_as_float((column && (behind || sf::abs(g) > u.iWantAspect)) ? 1 : 0));
+        const float vignette = __builtin_amdgcn_exp2f(0.1f*(__builtin_amdgcn_logf(as*(1.0f - as)) + 2.821928095f));
+        e = make_float4(uv, __int_as_float(parity), vignette, __int_as_float((column && (behind || sf::abs(g) > u.iWantAspect)) ? 1 : 0));
     } else {
         if (column) {
             const vec2 w = texture_xy(tex[TEX_WAVEFORM], vec2{as, 0.0f});                                          // waveform.frag:6
@@ -114,10 +117,12 @@ __global__ __launch_bounds__(256) void k_separable_axis(const RenderArgs a, cons
     (column ? t.columns + (long)frame*a.wr : t.rows + (long)frame*a.hr)[index] = e;
 }
 
-// default.glsl:19-26, the two-dimensional part of one point: the hue wheel by polar angle (as 0.3 + hsv2rgb, :22) and the ring
-// `width` = 2e-4/circle² by radius; `hue_shift` = 2*TAU*iTau - PI/4 (:22), per frame
-struct DefaultPolar { float red, green, blue, circle, width, len; };
-__device__ __forceinline__ DefaultPolar default_polar(float ux, float uy, float hue_shift) {
+// default.glsl:19-26, the two-dimensional part of one point in two halves: the hue wheel by polar angle (as 0.3 + hsv2rgb, :22) and
+// the ring `width` = 2e-4/circle² by radius; `hue_shift` = 2*TAU*iTau - PI/4 (:22), per frame
+struct DefaultHue { float red, green, blue; };
+struct DefaultRing { float circle, width, len; };
+// the hue wheel's coordinate k = 3/PI * mod(atan2(uv) + shift, TAU) in [0, 6)
+__device__ __forceinline__ float default_wheel(float ux, float uy, float hue_shift) {
     // :19 atan2(uv) in [0, 2 pi): sfmath.hpp's polynomial on min/max with hardware reciprocals (the hue is continuous in it)
     const float ax = sf::abs(ux), ay = sf::abs(uy);
     const float hi = __builtin_fmaxf(ax, ay), lo = __builtin_fminf(ax, ay);
@@ -132,42 +137,52 @@ __device__ __forceinline__ DefaultPolar default_polar(float ux, float uy, float 
     if (ay > ax) angle = HALF_PI - angle;
     if (ux < 0.0f) angle = PI - angle;
     if (uy < 0.0f) angle = TAU - angle;
-    // :22 hsv2rgb(angle + shift, 1, 1) + 0.3: the hue wheel in its continuous form
     float h = angle + hue_shift;
     h = h - TAU*::floorf(h*(1.0f/TAU));
-    const float k = h*(3.0f/PI);
-    DefaultPolar out;
-    out.red = 0.3f + clamp01(sf::abs(k - 3.0f) - 1.0f); out.green = 0.3f + clamp01(2.0f - sf::abs(k - 2.0f)); out.blue = 0.3f + clamp01(2.0f - sf::abs(k - 4.0f));
-    // :25-26 the ring
+    return h*(3.0f/PI);
+}
+// :22 hsv2rgb(angle + shift, 1, 1) + 0.3: the hue wheel in its continuous form, piecewise linear in k
+__device__ __forceinline__ DefaultHue default_wheel_colours(float k) {
+    return DefaultHue{0.3f + clamp01(sf::abs(k - 3.0f) - 1.0f), 0.3f + clamp01(2.0f - sf::abs(k - 2.0f)), 0.3f + clamp01(2.0f - sf::abs(k - 4.0f))};
+}
+__device__ __forceinline__ DefaultHue default_hue(float ux, float uy, float hue_shift) { return default_wheel_colours(default_wheel(ux, uy, hue_shift)); }
+// the wheel at a sample next to a point whose coordinate is known: d(angle) = (x dy - y dx)/len², exact to second order in the
+// step over the radius (the callers keep that under 1/8: relative error < 1 % of a step that is itself a fraction of a hue)
+__device__ __forceinline__ DefaultHue default_hue_beside(float k, float step) {
+    const float moved = k + step;
+    return default_wheel_colours(moved - 6.0f*::floorf(moved*(1.0f/6.0f)));
+}
+__device__ __forceinline__ DefaultRing default_ring(float ux, float uy) {                                           // :25-26
+    DefaultRing out;
     out.len = __builtin_amdgcn_sqrtf(ux*ux + uy*uy);
     out.circle = fmaf(1.333f, out.len, -1.0f);
     out.width = 2.0e-4f*sf::abs(__builtin_amdgcn_rcpf(out.circle*out.circle));
     return out;
 }
-// default.glsl:29-47 for one sample given the polar terms: the disc or the checkerboard (:29-33), the ring added (:36), the
-// vignette pow(50*ax(1-ax)*ay(1-ay), 0.1) clamped (:41-43), out of bounds (:14-16)
-__device__ __forceinline__ uint32_t default_colour(const DefaultPolar& polar, const float4 c, const float4 r) {
-    const float base = (polar.circle < 0.0f) ? 0.18f : (((__float_as_int(c.y) ^ __float_as_int(r.y)) & 1) ? 0.22f : 0.20f);
-    const float vignette = clamp01(__builtin_amdgcn_exp2f(0.1f*((c.z + r.z) + 5.643856190f)));
-    vec3 col = {fmaf(polar.width, polar.red, base)*vignette, fmaf(polar.width, polar.green, base)*vignette, fmaf(polar.width, polar.blue, base)*vignette};
-    if (__float_as_int(c.w) != 0) col = vec3{0.15f, 0.15f, 0.15f};
-    return pack_rgb8(col);
+// default.glsl:29-47 for sample K of a pixel given the polar terms: `base255` = 255 * (the disc's 0.18 or the checkerboard's 0.20 /
+// 0.22, :29-33), the ring added (:36, `width255` = 255*width), times the vignette clamped (:41-43, column factor * row factor): the
+// unorm8 scale rides on the constants. The sample's bytes go to byte K of one register per channel (v_cvt_pk_u8_f32 writes any
+// byte of its destination).
+struct DefaultBytes { uint32_t red, green, blue; };
+constexpr float DEFAULT_DISC = 0.18f*255.0f, DEFAULT_EVEN = 0.20f*255.0f, DEFAULT_ODD = 0.22f*255.0f;
+template <int K>
+__device__ __forceinline__ void default_colour(DefaultBytes& out, const DefaultHue& hue, float width255, float base255, float vignette) {
+    const float ring = width255*vignette, base = base255*vignette;
+    out.red = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.red, base), K, out.red);
+    out.green = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.green, base), K, out.green);
+    out.blue = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.blue, base), K, out.blue);
 }
-// default.glsl:10-47 for one sample from its column and row entries
-__device__ __forceinline__ uint32_t default_texel(const float4 c, const float4 r, float hue_shift) {
-    return default_colour(default_polar(c.x, r.x, hue_shift), c, r);
-}
-// May the four samples of a pixel share ONE polar evaluation, at the pixel's centre? Away from the ring they may: `off` = the
-// distance from the centre to a sample (in gluv units: the tables' own spacing, so zoomed cameras and small frames are measured
-// as they are); moving a sample by `off` changes the ring term width*(0.3 + hue) by
+// May the four samples of a pixel share ONE evaluation at the pixel's centre? `off` = the distance from the centre to a sample (in
+// gluv units: the tables' own spacing, so zoomed cameras and small frames are measured as they are); moving a sample by `off`
+// changes the ring term width*(0.3 + hue) by
 //   d(width) = 2*width/|circle| * 1.333*off      and      width * d(hue) <= width * (3/PI) * off/len,
-// and both are kept under 4e-5 (0.01 LSB of a channel: per-sample quantisation then flips with probability 2 %, and all four
-// samples of a pixel never flip together — what a second LSB of difference from the reference would take). Near the ring, next to
-// the origin, and for frames so small that a pixel spans a visible part of the glow the four samples are evaluated one by one.
-__device__ __forceinline__ bool default_shares_polar(const DefaultPolar& centre, float off) {
-    const float change = centre.width*off;
-    return (2.666f*change < 4.0e-5f*sf::abs(centre.circle)) && (0.955f*change < 4.0e-5f*centre.len);
-}
+// each kept under 4e-5 (0.01 LSB of a channel: per-sample quantisation then flips with probability 2 %, and all four samples of a
+// pixel never flip together — what a second LSB of difference from the reference would take). Three tiers: away from the ring
+// both are shared (one polar evaluation per pixel); in the band around the ring the steep 1/circle² is evaluated per sample
+// (a square root and a reciprocal each) under the centre's hue; on the ring itself, next to the origin, and for frames so small
+// that a pixel spans a visible part of the glow the four samples are evaluated one by one.
+__device__ __forceinline__ bool default_shares_ring(const DefaultRing& centre, float off) { return 2.666f*centre.width*off < 4.0e-5f*sf::abs(centre.circle); }
+__device__ __forceinline__ bool default_shares_hue(float width, float len, float off) { return 0.955f*width*off < 4.0e-5f*len; }
 
 // which samples of the 2 x 2 block at sample row j0 are inside the runs of its two columns (bit y*2 + x, the block's texel order)
 __device__ __forceinline__ bool row_in_run(int run, int j) { return (unsigned)(j - (run & 0xffff)) < ((unsigned)run >> 16); }
@@ -183,7 +198,7 @@ __device__ __forceinline__ uint32_t blue_texel(float below, float ramp, float on
 
 // S == 2. grid (ceil(w/SEP_PIXELS), ceil(h/SEP_ROWS), frames), block SEP_PIXELS threads.
 template <int KIND, int SEP_ROWS>
-__global__ __launch_bounds__(SEP_PIXELS) void k_separable_fused(const RenderArgs a, const SepTables t) {
+__global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(8))) void k_separable_fused(const RenderArgs a, const SepTables t) {
     __shared__ __attribute__((aligned(16))) uint8_t staged[SEP_ROWS][SEP_PIXELS*3];
     const int frame = blockIdx.z;
     const int tid = threadIdx.x;
@@ -208,6 +223,11 @@ __global__ __launch_bounds__(SEP_PIXELS) void k_separable_fused(const RenderArgs
     const float tau = a.dyn ? a.dyn[a.frame0 + frame].iTau : a.u.iTau;
     const float hue_shift = (2.0f*TAU*tau) - (PI/4.0f);               // default.glsl:22, the generic chain's operations
     (void)hue_shift;
+    const bool odd_column0 = (__float_as_int(c0.y) & 1) != 0, odd_column1 = (__float_as_int(c1.y) & 1) != 0;   // default.glsl only
+    const bool outside = (__float_as_int(c0.w) | __float_as_int(c1.w)) != 0;
+    const float cx = 0.5f*(c0.x + c1.x);
+    int shared_until = 0; DefaultRing pair_ring = {}; DefaultHue pair_hue = {};
+    (void)odd_column0; (void)odd_column1; (void)outside; (void)cx; (void)shared_until; (void)pair_ring; (void)pair_hue;
     // (default.glsl's four polar evaluations per row are ~2.7 KB of code: 32 unrolled rows would be 89 KB, more than the 64 KB
     // instruction cache two CUs share — its rows run as a loop of pairs; the light kinds unroll fully)
     constexpr int ROWS_UNROLLED = (KIND == SEP_DEFAULT) ? 1 : SEP_ROWS;
@@ -238,23 +258,93 @@ __global__ __launch_bounds__(SEP_PIXELS) void k_separable_fused(const RenderArgs
                 | ((uint32_t)inside_lut[wave_pattern(__float_as_int(c0.y), __float_as_int(c1.y), j0)] << 8)
                 | ((uint32_t)inside_lut[wave_pattern(__float_as_int(c0.z), __float_as_int(c1.z), j0)] << 16);
         } else {
-            // one polar evaluation per PIXEL where its four samples cannot tell the difference (default_shares_polar), else four
-            const DefaultPolar centre = default_polar(0.5f*(c0.x + c1.x), 0.5f*(r0.x + r1.x), hue_shift);
-            const float off = 0.5f*(sf::abs(c1.x - c0.x) + sf::abs(r1.x - r0.x));
-            if (default_shares_polar(centre, off)) {
-                block[0] = default_colour(centre, c0, r0); block[1] = default_colour(centre, c1, r0);
-                block[2] = default_colour(centre, c0, r1); block[3] = default_colour(centre, c1, r1);
-            } else {
-                block[0] = default_texel(c0, r0, hue_shift); block[1] = default_texel(c1, r0, hue_shift);
-                block[2] = default_texel(c0, r1, hue_shift); block[3] = default_texel(c1, r1, hue_shift);
+            // rows in groups: where the ring is far enough for the samples of FOUR rows of pixels (sixteen samples), or of two, to
+            // share one evaluation at the point in their middle, the group's first row makes it and the others reuse it
+            // (`shared_until` = the first block row it no longer serves)
+            if ((r & 1) == 0 && r >= shared_until) {
+                const float dx = 0.5f*sf::abs(c1.x - c0.x), dy = sf::abs(r1.x - r0.x);
+                bool found = false;
+                if ((r & 3) == 0 && py + 3 < a.h) {
+                    const float cy = 0.5f*(rows[2*py + 3].x + rows[2*py + 4].x);
+                    const float reach = dx + 3.5f*dy;
+                    pair_ring = default_ring(cx, cy);
+                    found = default_shares_ring(pair_ring, reach) && default_shares_hue(pair_ring.width, pair_ring.len, reach);
+                    if (found) { pair_hue = default_hue(cx, cy, hue_shift); shared_until = r + 4; }
+                }
+                if (!found && py + 1 < a.h) {
+                    const float cy = 0.5f*(r1.x + rows[2*py + 2].x);
+                    const float reach = dx + 1.5f*dy;
+                    pair_ring = default_ring(cx, cy);
+                    found = default_shares_ring(pair_ring, reach) && default_shares_hue(pair_ring.width, pair_ring.len, reach);
+                    if (found) { pair_hue = default_hue(cx, cy, hue_shift); shared_until = r + 2; }
+                }
             }
-            // final.glsl's mean of the four RGBA8 texels as an INTEGER mean per channel, (sum + 2) >> 2, red and blue summed side by
-            // side in one register: what resolve_channel's float chain gives except on ties (sum = 2 mod 4), which its rounding noise
-            // decides either way — 1 LSB, like every approximation of this kernel (20 instructions instead of 60)
-            const uint32_t rb = (block[0] & 0x00ff00ffu) + (block[1] & 0x00ff00ffu) + (block[2] & 0x00ff00ffu) + (block[3] & 0x00ff00ffu);
-            const uint32_t gg = ((block[0] >> 8) & 0xffu) + ((block[1] >> 8) & 0xffu) + ((block[2] >> 8) & 0xffu) + ((block[3] >> 8) & 0xffu);
-            const uint32_t mean_rb = ((rb + 0x00020002u) >> 2) & 0x00ff00ffu;
-            rgb = mean_rb | (((gg + 2u) >> 2) << 8);
+            const bool pair_shares = r < shared_until;
+            // the sample's checkerboard colour by the parities of its column and row; the row's side is block-uniform (scalar selects)
+            const float even0 = (__float_as_int(r0.y) & 1) ? DEFAULT_ODD : DEFAULT_EVEN, odd0 = (__float_as_int(r0.y) & 1) ? DEFAULT_EVEN : DEFAULT_ODD;
+            const float even1 = (__float_as_int(r1.y) & 1) ? DEFAULT_ODD : DEFAULT_EVEN, odd1 = (__float_as_int(r1.y) & 1) ? DEFAULT_EVEN : DEFAULT_ODD;
+            const float board[4] = {odd_column0 ? odd0 : even0, odd_column1 ? odd0 : even0, odd_column0 ? odd1 : even1, odd_column1 ? odd1 : even1};
+            const float vignette[4] = {clamp01(c0.z*r0.z), clamp01(c1.z*r0.z), clamp01(c0.z*r1.z), clamp01(c1.z*r1.z)};
+            const float cy = 0.5f*(r0.x + r1.x);
+            const float off = 0.5f*(sf::abs(c1.x - c0.x) + sf::abs(r1.x - r0.x));
+            DefaultRing centre = pair_ring;
+            DefaultHue hue = pair_hue;
+            bool shared = pair_shares;
+            if (!pair_shares) {
+                centre = default_ring(cx, cy);
+                shared = default_shares_ring(centre, off) && default_shares_hue(centre.width, centre.len, off);
+                if (shared) hue = default_hue(cx, cy, hue_shift);
+            }
+            DefaultBytes bytes = {0u, 0u, 0u};
+            if (shared) {                                             // one ring and one hue for the four samples
+                const float width255 = centre.width*255.0f;
+                const bool disc = centre.circle < 0.0f;
+                default_colour<0>(bytes, hue, width255, disc ? DEFAULT_DISC : board[0], vignette[0]);
+                default_colour<1>(bytes, hue, width255, disc ? DEFAULT_DISC : board[1], vignette[1]);
+                default_colour<2>(bytes, hue, width255, disc ? DEFAULT_DISC : board[2], vignette[2]);
+                default_colour<3>(bytes, hue, width255, disc ? DEFAULT_DISC : board[3], vignette[3]);
+            } else {                                                  // the ring per sample; the hue at the centre if it may be, else per sample
+                const float ux[4] = {c0.x, c1.x, c0.x, c1.x}, uy[4] = {r0.x, r0.x, r1.x, r1.x};
+                DefaultRing ring[4];
+                float widest = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { ring[k] = default_ring(ux[k], uy[k]); widest = __builtin_fmaxf(widest, ring[k].width); }
+                float width255[4], base255[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { width255[k] = ring[k].width*255.0f; base255[k] = (ring[k].circle < 0.0f) ? DEFAULT_DISC : board[k]; }
+                if (centre.len > 8.0f*off) {
+                    const float wheel = default_wheel(cx, cy, hue_shift);
+                    if (default_shares_hue(widest, centre.len, off)) {
+                        hue = default_wheel_colours(wheel);
+                        default_colour<0>(bytes, hue, width255[0], base255[0], vignette[0]); default_colour<1>(bytes, hue, width255[1], base255[1], vignette[1]);
+                        default_colour<2>(bytes, hue, width255[2], base255[2], vignette[2]); default_colour<3>(bytes, hue, width255[3], base255[3], vignette[3]);
+                    } else {
+                        // on the ring the glow is wide enough to show the hue turning inside a pixel: the centre's wheel coordinate
+                        // moved by each sample's own angle (one atan2 per pixel instead of four)
+                        const float turn = (3.0f/PI)*__builtin_amdgcn_rcpf(centre.len*centre.len);
+                        const float along = cx*(0.5f*(r1.x - r0.x))*turn, across = cy*(0.5f*(c1.x - c0.x))*turn;   // x dy, y dx
+                        default_colour<0>(bytes, default_hue_beside(wheel, across - along), width255[0], base255[0], vignette[0]);
+                        default_colour<1>(bytes, default_hue_beside(wheel, -across - along), width255[1], base255[1], vignette[1]);
+                        default_colour<2>(bytes, default_hue_beside(wheel, across + along), width255[2], base255[2], vignette[2]);
+                        default_colour<3>(bytes, default_hue_beside(wheel, along - across), width255[3], base255[3], vignette[3]);
+                    }
+                } else {                                              // next to the origin: every sample by itself
+                    default_colour<0>(bytes, default_hue(ux[0], uy[0], hue_shift), width255[0], base255[0], vignette[0]);
+                    default_colour<1>(bytes, default_hue(ux[1], uy[1], hue_shift), width255[1], base255[1], vignette[1]);
+                    default_colour<2>(bytes, default_hue(ux[2], uy[2], hue_shift), width255[2], base255[2], vignette[2]);
+                    default_colour<3>(bytes, default_hue(ux[3], uy[3], hue_shift), width255[3], base255[3], vignette[3]);
+                }
+            }
+            if (outside) {                                            // camera.glsl:83 / default.glsl:14-16, per column: 0.15 grey = byte 38
+                const uint32_t keep = ((__float_as_int(c0.w) != 0) ? 0u : 0x00ff00ffu) | ((__float_as_int(c1.w) != 0) ? 0u : 0xff00ff00u);
+                const uint32_t grey = 0x26262626u & ~keep;
+                bytes.red = (bytes.red & keep) | grey; bytes.green = (bytes.green & keep) | grey; bytes.blue = (bytes.blue & keep) | grey;
+            }
+            // final.glsl's mean of the four RGBA8 texels as an INTEGER mean per channel, (sum + 2) >> 2 with the sum of a register's
+            // four bytes from v_sad_u8: what resolve_channel's float chain gives except on ties (sum = 2 mod 4), which its rounding
+            // noise decides either way — 1 LSB, like every approximation of this kernel (8 instructions instead of 60)
+            rgb = (__builtin_amdgcn_sad_u8(bytes.red, 0u, 2u) >> 2) | ((__builtin_amdgcn_sad_u8(bytes.green, 0u, 2u) >> 2) << 8)
+                | ((__builtin_amdgcn_sad_u8(bytes.blue, 0u, 2u) >> 2) << 16);
         }
         uint8_t* s = &staged[r][tid*3];
         s[0] = (uint8_t)rgb; s[1] = (uint8_t)(rgb >> 8); s[2] = (uint8_t)(rgb >> 16);

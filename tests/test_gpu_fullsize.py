@@ -9,6 +9,7 @@ box's host cores (`threads=os.cpu_count()`); in a small container these tests ta
                         tape; the tape's frames byte-equal to the frame loop's single launches
   C2  1920x1080 no SSAA both passes (strip kernel into iScreen, then the resolve kernel), whole frames, tape path
   C4  7680x4320 4xSSAA  76 rows around block seams, top and bottom included
+  Basic (default.glsl) 3840x2160 2xSSAA  whole frames, identity and zoomed camera (the sharing tiers of k_separable_fused<default>)
 """
 import os
 
@@ -69,6 +70,26 @@ def test_dense_2x_instances_whole_frame(gpu, w, h, kernel):
         want = whole_frame(u, arrays, params, w, h, 2)
         d = np.abs(got.astype(int) - want.astype(int))
         assert d.max() <= 1, (volume, lsb_report(got, want), np.argwhere(d > 1)[:5].tolist())
+
+
+@pytest.mark.parametrize("zoom,tau", [(1.0, 0.37), (0.55, 0.81)])
+def test_basic_whole_frame_4k(gpu, zoom, tau):
+    """default.glsl (the Basic scene) at 3840x2160 2xSSAA: k_separable_fused<default> shares the polar terms between the four
+    samples of a pixel in three tiers by the distance to the ring (separable_fast.hpp default_shares_ring / default_shares_hue) —
+    where the tiers fall depends on the size of a pixel, so the whole frame at the size bench.py --scene basic times, and a
+    zoomed camera that puts the ring elsewhere"""
+    w, h = 3840, 2160
+    u, arrays, params = visualizer_inputs(w, h, seed=5)
+    u.iSSAA, u.iTau, u.iCameraZoom = 2.0, tau, zoom
+    prog, _ = gpu.program("default")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    got = gpu.render_resolve(prog, w, h, 2, 2)
+    assert gpu.lib.sfx_last_kernel().decode() == "k_separable_fused<default>", gpu.lib.sfx_last_kernel()
+    screen = O.render("default", u, oracle_textures(arrays, params), w*2, h*2, threads=THREADS)
+    want = O.resolve(screen, w, h, 2, threads=THREADS)
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1, (lsb_report(got, want), np.argwhere(d > 1)[:5].tolist())
 
 
 def prepared_scene(w, h, ssaa, pcm, background, seconds):
