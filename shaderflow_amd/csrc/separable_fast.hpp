@@ -29,6 +29,9 @@ constexpr int SEP_PIXELS = 256;
 // Output rows a block walks with its column entries in registers: 32 where the launch has blocks to spare (the entries are
 // fetched once per 32 rows and the rows leave in one sweep), 8 for small launches (a single 1080p frame is 272 blocks of 32 rows)
 constexpr int SEP_ROWS_LARGE = 32, SEP_ROWS_SMALL = 8;
+// default.glsl is arithmetic, not stores: 16 rows (12 KB of staged rows) let eight blocks = 8 waves per SIMD live on a CU, and the
+// kernel asks the compiler for that many (amdgpu_waves_per_eu: 52 registers instead of the 109 it takes when nobody asks) —
+// 4 -> 8 waves per SIMD is 1.39 -> 1.17 ms per 60 frames of 4K; 8-row blocks are slower again (1.09 against 1.07 ms)
 constexpr int SEP_ROWS_DEFAULT = 16;
 
 struct SepTables {
@@ -172,16 +175,30 @@ __device__ __forceinline__ void default_colour(DefaultBytes& out, const DefaultH
     out.green = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.green, base), K, out.green);
     out.blue = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.blue, base), K, out.blue);
 }
-// May the four samples of a pixel share ONE evaluation at the pixel's centre? `off` = the distance from the centre to a sample (in
-// gluv units: the tables' own spacing, so zoomed cameras and small frames are measured as they are); moving a sample by `off`
-// changes the ring term width*(0.3 + hue) by
-//   d(width) = 2*width/|circle| * 1.333*off      and      width * d(hue) <= width * (3/PI) * off/len,
+// May several samples share ONE evaluation of the polar terms, made at the point in their middle? `reach` = the distance from that
+// point to the farthest sample (in gluv units: the tables' own spacing, so zoomed cameras and small frames are measured as they
+// are). Moving by d changes the ring term width*(0.3 + hue) through
+//   the width:  width(len + d) = width*(1 - 2e + 3e² - ...), e = 1.333*d/circle — the linear term is applied per sample
+//               (DefaultSlope), the quadratic one, 3*(1.333*reach/circle)²*width, is what sharing leaves out;
+//   the hue:    width * d(hue) <= width * (3/PI) * reach/len,
 // each kept under 4e-5 (0.01 LSB of a channel: per-sample quantisation then flips with probability 2 %, and all four samples of a
-// pixel never flip together — what a second LSB of difference from the reference would take). Three tiers: away from the ring
-// both are shared (one polar evaluation per pixel); in the band around the ring the steep 1/circle² is evaluated per sample
-// (a square root and a reciprocal each) under the centre's hue; on the ring itself, next to the origin, and for frames so small
-// that a pixel spans a visible part of the glow the four samples are evaluated one by one.
-__device__ __forceinline__ bool default_shares_ring(const DefaultRing& centre, float off) { return 2.666f*centre.width*off < 4.0e-5f*sf::abs(centre.circle); }
+// pixel never flip together — what a second LSB of difference from the reference would take). The tiers of k_separable_fused:
+//   * FOUR rows of pixels (sixteen samples per column pair) share one evaluation where both hold — |circle| > 0.1 at 4K, 87 % of the
+//     frame; the group's first row makes it, the others reuse it;
+//   * else the steep 1/circle² is evaluated per sample (a square root and a reciprocal each) under the hue at the pixel's centre;
+//   * on the ring itself the glow is wide enough to show the hue turning inside a pixel: the centre's wheel coordinate is moved
+//     by each sample's own angle (default_hue_beside: one atan2 per pixel instead of four);
+//   * next to the origin (len < 8 reach) every sample is evaluated by itself.
+__device__ __forceinline__ bool default_shares_slope(const DefaultRing& centre, float reach) {
+    const float e = 1.333f*reach, c2 = centre.circle*centre.circle;
+    return (3.5f*e*e*centre.width < 4.0e-5f*c2) && (centre.len > 8.0f*reach);
+}
+// d(255*width)/d(position) at the centre, along x and y: -2*1.333*width/circle * (x, y)/len
+struct DefaultSlope { float x, y; };
+__device__ __forceinline__ DefaultSlope default_slope(const DefaultRing& centre, float cx, float cy) {
+    const float g = -2.666f*255.0f*centre.width*__builtin_amdgcn_rcpf(centre.circle*centre.len);
+    return DefaultSlope{g*cx, g*cy};
+}
 __device__ __forceinline__ bool default_shares_hue(float width, float len, float off) { return 0.955f*width*off < 4.0e-5f*len; }
 
 // which samples of the 2 x 2 block at sample row j0 are inside the runs of its two columns (bit y*2 + x, the block's texel order)
@@ -226,10 +243,10 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(8)))
     const bool odd_column0 = (__float_as_int(c0.y) & 1) != 0, odd_column1 = (__float_as_int(c1.y) & 1) != 0;   // default.glsl only
     const bool outside = (__float_as_int(c0.w) | __float_as_int(c1.w)) != 0;
     const float cx = 0.5f*(c0.x + c1.x);
-    int shared_until = 0; DefaultRing pair_ring = {}; DefaultHue pair_hue = {};
-    (void)odd_column0; (void)odd_column1; (void)outside; (void)cx; (void)shared_until; (void)pair_ring; (void)pair_hue;
-    // (default.glsl's four polar evaluations per row are ~2.7 KB of code: 32 unrolled rows would be 89 KB, more than the 64 KB
-    // instruction cache two CUs share — its rows run as a loop of pairs; the light kinds unroll fully)
+    int shared_until = 0; bool attempted = false; (void)attempted; DefaultRing group_ring = {}; DefaultHue group_hue = {}; DefaultSlope group_slope = {}; float group_y = 0.0f;
+    (void)odd_column0; (void)odd_column1; (void)outside; (void)cx; (void)shared_until; (void)group_ring; (void)group_hue; (void)group_slope; (void)group_y;
+    // (default.glsl's row is ~3 KB of code with its tiers: unrolled rows would overflow the 64 KB instruction cache two CUs share —
+    // its rows run as a loop; the light kinds unroll fully)
     constexpr int ROWS_UNROLLED = (KIND == SEP_DEFAULT) ? 1 : SEP_ROWS;
 #pragma unroll ROWS_UNROLLED
     for (int r = 0; r < SEP_ROWS; r++) {
@@ -258,28 +275,21 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(8)))
                 | ((uint32_t)inside_lut[wave_pattern(__float_as_int(c0.y), __float_as_int(c1.y), j0)] << 8)
                 | ((uint32_t)inside_lut[wave_pattern(__float_as_int(c0.z), __float_as_int(c1.z), j0)] << 16);
         } else {
-            // rows in groups: where the ring is far enough for the samples of FOUR rows of pixels (sixteen samples), or of two, to
-            // share one evaluation at the point in their middle, the group's first row makes it and the others reuse it
-            // (`shared_until` = the first block row it no longer serves)
-            if ((r & 1) == 0 && r >= shared_until) {
-                const float dx = 0.5f*sf::abs(c1.x - c0.x), dy = sf::abs(r1.x - r0.x);
-                bool found = false;
-                if ((r & 3) == 0 && py + 3 < a.h) {
+            // rows in groups of four: the group's first row evaluates the polar terms at the point in the middle of its sixteen samples
+            // and, where default_shares_slope / default_shares_hue allow, the four rows use them (`shared_until` = the first block row
+            // they no longer serve)
+            if ((r & 3) == 0) {
+                attempted = py + 3 < a.h;
+                if (attempted) {
                     const float cy = 0.5f*(rows[2*py + 3].x + rows[2*py + 4].x);
-                    const float reach = dx + 3.5f*dy;
-                    pair_ring = default_ring(cx, cy);
-                    found = default_shares_ring(pair_ring, reach) && default_shares_hue(pair_ring.width, pair_ring.len, reach);
-                    if (found) { pair_hue = default_hue(cx, cy, hue_shift); shared_until = r + 4; }
-                }
-                if (!found && py + 1 < a.h) {
-                    const float cy = 0.5f*(r1.x + rows[2*py + 2].x);
-                    const float reach = dx + 1.5f*dy;
-                    pair_ring = default_ring(cx, cy);
-                    found = default_shares_ring(pair_ring, reach) && default_shares_hue(pair_ring.width, pair_ring.len, reach);
-                    if (found) { pair_hue = default_hue(cx, cy, hue_shift); shared_until = r + 2; }
+                    const float reach = 0.5f*sf::abs(c1.x - c0.x) + 3.5f*sf::abs(r1.x - r0.x);
+                    group_ring = default_ring(cx, cy);
+                    if (default_shares_slope(group_ring, reach) && default_shares_hue(1.5f*group_ring.width, group_ring.len, reach)) {
+                        group_hue = default_hue(cx, cy, hue_shift); group_slope = default_slope(group_ring, cx, cy); group_y = cy; shared_until = r + 4;
+                    }
                 }
             }
-            const bool pair_shares = r < shared_until;
+            const bool group_shares = r < shared_until;
             // the sample's checkerboard colour by the parities of its column and row; the row's side is block-uniform (scalar selects)
             const float even0 = (__float_as_int(r0.y) & 1) ? DEFAULT_ODD : DEFAULT_EVEN, odd0 = (__float_as_int(r0.y) & 1) ? DEFAULT_EVEN : DEFAULT_ODD;
             const float even1 = (__float_as_int(r1.y) & 1) ? DEFAULT_ODD : DEFAULT_EVEN, odd1 = (__float_as_int(r1.y) & 1) ? DEFAULT_EVEN : DEFAULT_ODD;
@@ -287,22 +297,26 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(8)))
             const float vignette[4] = {clamp01(c0.z*r0.z), clamp01(c1.z*r0.z), clamp01(c0.z*r1.z), clamp01(c1.z*r1.z)};
             const float cy = 0.5f*(r0.x + r1.x);
             const float off = 0.5f*(sf::abs(c1.x - c0.x) + sf::abs(r1.x - r0.x));
-            DefaultRing centre = pair_ring;
-            DefaultHue hue = pair_hue;
-            bool shared = pair_shares;
-            if (!pair_shares) {
+            DefaultRing centre = group_ring;
+            DefaultHue hue = group_hue;
+            DefaultSlope slope = group_slope;
+            float slope_y = group_y;
+            bool shared = group_shares;
+            if (!group_shares) {
                 centre = default_ring(cx, cy);
-                shared = default_shares_ring(centre, off) && default_shares_hue(centre.width, centre.len, off);
-                if (shared) hue = default_hue(cx, cy, hue_shift);
+                // (the last rows of a frame whose height is not a multiple of four have no group: the same test for the pixel alone)
+                shared = !attempted && default_shares_slope(centre, off) && default_shares_hue(1.5f*centre.width, centre.len, off);
+                if (shared) { hue = default_hue(cx, cy, hue_shift); slope = default_slope(centre, cx, cy); slope_y = cy; }
             }
             DefaultBytes bytes = {0u, 0u, 0u};
-            if (shared) {                                             // one ring and one hue for the four samples
-                const float width255 = centre.width*255.0f;
+            if (shared) {                                             // one ring and one hue for the samples, the ring's width to first order
+                const float lower = fmaf(slope.y, r0.x - slope_y, centre.width*255.0f), upper = fmaf(slope.y, r1.x - slope_y, centre.width*255.0f);
+                const float side = slope.x*(0.5f*(c1.x - c0.x));
                 const bool disc = centre.circle < 0.0f;
-                default_colour<0>(bytes, hue, width255, disc ? DEFAULT_DISC : board[0], vignette[0]);
-                default_colour<1>(bytes, hue, width255, disc ? DEFAULT_DISC : board[1], vignette[1]);
-                default_colour<2>(bytes, hue, width255, disc ? DEFAULT_DISC : board[2], vignette[2]);
-                default_colour<3>(bytes, hue, width255, disc ? DEFAULT_DISC : board[3], vignette[3]);
+                default_colour<0>(bytes, hue, lower - side, disc ? DEFAULT_DISC : board[0], vignette[0]);
+                default_colour<1>(bytes, hue, lower + side, disc ? DEFAULT_DISC : board[1], vignette[1]);
+                default_colour<2>(bytes, hue, upper - side, disc ? DEFAULT_DISC : board[2], vignette[2]);
+                default_colour<3>(bytes, hue, upper + side, disc ? DEFAULT_DISC : board[3], vignette[3]);
             } else {                                                  // the ring per sample; the hue at the centre if it may be, else per sample
                 const float ux[4] = {c0.x, c1.x, c0.x, c1.x}, uy[4] = {r0.x, r0.x, r1.x, r1.x};
                 DefaultRing ring[4];

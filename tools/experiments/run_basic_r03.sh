@@ -1,3 +1,4 @@
+# The tests that cover default.glsl's fused kernel + the Basic bench line (round 3's work on k_separable_fused<default>)
 set -x
 mkdir -p gpurun_out/basic
 timeout 1200 python -m pytest tests/test_gpu_fullsize.py::test_basic_whole_frame_4k tests/test_gpu_pixels.py tests/test_gpu_gles.py tests/test_gpu_mesa.py tests/test_gpu_scene.py -x -q -m gpu > gpurun_out/basic/tests.log 2>&1; echo "tests rc=$?"

@@ -14,7 +14,7 @@ for f in glob.glob("gpurun_out/pmcq/**/*counter_collection.csv", recursive=True)
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"].split("(")[0][-90:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
-    if "render" not in k and "visualizer" not in k and "separable_fused" not in k: continue
+    if not any(s in k for s in ("render", "visualizer", "separable", "resolve")): continue
     waves = sum(cs.get("SQ_WAVES", [1]))/max(1, len(cs.get("SQ_WAVES", [1])))
     print(k)
     for n, v in sorted(cs.items()):
