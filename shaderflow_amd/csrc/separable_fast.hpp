@@ -443,11 +443,12 @@ __device__ __forceinline__ int special_after(int t, int from, int best) {
 // 255; the template; the next special row — ≈ 40 VGPRs, eight waves per SIMD); a special row reloads the lane's eight column entries
 // (128 contiguous bytes, L2). The two per-row scalars of bars (1 − astuv.y of the pair's sample rows) are fetched ONCE per walk — lane
 // l holds the value of sample row 2·y_first + l — and read with v_readlane: no memory latency inside the loop.
-// (the kernel is stores: the more waves a SIMD holds, the more stores are in flight — asked for, the compiler fits waveform's walk in
-// 64 registers = 8 waves per SIMD instead of 70 = 7, +8 %; bars' in 80 = 6 instead of 91 = 5 with four spilled dwords, +7 %; at 8
-// waves bars spills thirteen and loses half of that again)
+// (the kernel is stores: the more waves a SIMD holds, the more stores are in flight. Asked for, the compiler fits waveform's walk in
+// 64 registers = 8 waves per SIMD instead of 70 = 7 — 283-293 us per 60 frames of 4K on three boxes against 294, inside their
+// spread. bars' needs 91 = 5 waves; pressed into 80 or 64 it spills, and the spills are HBM writes of their own — 47 MB per
+// launch at 6 waves, 308 -> 324 us — so it stays at 5)
 template <int KIND>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == SEP_BARS ? 6 : 8))) void k_separable_runs(const RenderArgs a, const SepTables t) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == SEP_BARS ? 5 : 8))) void k_separable_runs(const RenderArgs a, const SepTables t) {
     static_assert(KIND == SEP_BARS || KIND == SEP_WAVEFORM, "runs exist for the two comparison fragments");
     static_assert(SEP_RUN_ROWS == 32, "one lane per sample row of the walk");
     __shared__ uint8_t inside_lut[16];
