@@ -1783,28 +1783,78 @@ extern "C" int sfx_dynamics_scan_f64(sfx_handle h, int nframes, int nsystems, co
 // ---------------------------------------------------------------------------------------------------------
 // Tape
 
+// The arrays a batch of frames lives in exist TWICE (two banks): sfx_tape_build fills the bank the last render did not read, on
+// the tape's own stream, while the context's stream still renders from the other one — the audio kernels of batch i + 1 (a chain
+// of small latency-bound launches, 0.13-0.2 ms) run beside the render of batch i instead of in front of batch i + 1's, and the host
+// never waits for a render to hand over its schedule (the borrowed host arrays are copied to pinned memory of the bank).
+// Events order the two streams: `built` (recorded after a bank's last audio kernel; renders and reads wait for it), `rendered`
+// (recorded after every render from a bank; the build that refills the bank waits for it). The recurrences' state (d_state,
+// d_scalars, the scrolling ring) exists once: only the tape's stream touches it, in frame order.
+struct TapeBank {
+    long* d_tell = nullptr; float *d_power = nullptr, *d_targets = nullptr, *d_columns = nullptr, *d_rows = nullptr, *d_loudness = nullptr;
+    FrameDyn* d_dyn = nullptr; DynCoeffF32* d_coeff = nullptr; DynCoeffF64 *d_vol = nullptr, *d_std = nullptr; FrameClock* d_clock = nullptr;
+    VisualizerConsts* d_vis = nullptr; float *d_bars = nullptr, *d_scroll = nullptr;
+    char* staging = nullptr;         // pinned: the host's schedule arrays of the batch, laid out like d_schedule
+    char* d_schedule = nullptr;      // d_tell | d_clock | d_coeff | d_vol | d_std in one allocation: one copy per build
+    hipEvent_t built = nullptr, rendered = nullptr;
+};
 struct Tape : Object {
     Plan* plan; Audio* audio; Context* ctx;
     sfx_tape_desc desc;
     int max_frames, n;               // n = bins*channels
-    long* d_tell; float* d_power; float* d_targets; float* d_columns; float* d_rows; float* d_loudness;
-    float* d_state; ScalarState* d_scalars; FrameDyn* d_dyn;
-    DynCoeffF32* d_coeff; DynCoeffF64 *d_vol, *d_std; FrameClock* d_clock;
-    VisualizerConsts* d_vis;
+    // the bank the last sfx_tape_build filled (what renders and reads see)
+    long* d_tell = nullptr; float *d_power = nullptr, *d_targets = nullptr, *d_columns = nullptr, *d_rows = nullptr, *d_loudness = nullptr;
+    FrameDyn* d_dyn = nullptr;
+    DynCoeffF32* d_coeff = nullptr; DynCoeffF64 *d_vol = nullptr, *d_std = nullptr; FrameClock* d_clock = nullptr;
+    VisualizerConsts* d_vis = nullptr;
     float* d_bars = nullptr;         // sqrt(column/1000) of every frame of the batch (visualizer.frag:45)
+    float* d_scroll = nullptr;       // scrolling spectrogram: the texture's state per frame of the batch
+    TapeBank bank[2]; int current = 0; bool built_once = false;
+    hipStream_t audio_stream = nullptr;
+    float* d_state = nullptr; ScalarState* d_scalars = nullptr;
     void* d_screen = nullptr; size_t screen_bytes = 0;   // iScreen scratch of the two-pass path (frames of a batch)
-    // scrolling spectrogram (length_samples > 1, spectrogram.py:298-311): ring of the last columns, per-frame texture states
+    // scrolling spectrogram (length_samples > 1, spectrogram.py:298-311): ring of the last columns
     int width = 1, ring_frames = 0; long frames_done = 0;
-    float* d_ring = nullptr; float* d_scroll = nullptr;
+    float* d_ring = nullptr;
 };
+static void tape_select(Tape* t, int b) {
+    const TapeBank& k = t->bank[b];
+    t->d_tell = k.d_tell; t->d_power = k.d_power; t->d_targets = k.d_targets; t->d_columns = k.d_columns; t->d_rows = k.d_rows;
+    t->d_loudness = k.d_loudness; t->d_dyn = k.d_dyn; t->d_coeff = k.d_coeff; t->d_vol = k.d_vol; t->d_std = k.d_std; t->d_clock = k.d_clock;
+    t->d_vis = k.d_vis; t->d_bars = k.d_bars; t->d_scroll = k.d_scroll;
+    t->current = b;
+}
+// offsets of the five schedule arrays in a bank's block (each 16-byte aligned), [5] = the block's size
+struct ScheduleLayout { size_t at[6]; };
+static ScheduleLayout schedule_layout(int frames) {
+    const size_t sizes[5] = {sizeof(long), sizeof(FrameClock), sizeof(DynCoeffF32), sizeof(DynCoeffF64), sizeof(DynCoeffF64)};
+    ScheduleLayout l; size_t at = 0;
+    for (int i = 0; i < 5; i++) { l.at[i] = at; at += (sizes[i]*(size_t)frames + 15) & ~(size_t)15; }
+    l.at[5] = at;
+    return l;
+}
+static size_t tape_staging_bytes(int frames) { return std::max(schedule_layout(frames).at[5], sizeof(FrameDyn)*(size_t)frames); }
+// streams, events and pinned staging of both banks; false = out of memory
+static bool tape_open_streams(Tape* t) {
+    // the audio kernels are small and the render kernel fills the chip: at the highest priority their workgroups take the next free
+    // slots instead of queueing behind the render's
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+    if (hipStreamCreateWithPriority(&t->audio_stream, hipStreamNonBlocking, greatest) != hipSuccess) return false;
+    for (TapeBank& k : t->bank) {
+        if (hipEventCreateWithFlags(&k.built, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&k.rendered, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipHostMalloc((void**)&k.staging, tape_staging_bytes(t->max_frames), hipHostMallocDefault) != hipSuccess) return false;
+    }
+    return true;
+}
 
 extern "C" int sfx_tape_reset(sfx_handle h) {
     Tape* t = get<Tape>(h, MAGIC_TAPE);
     if (!t) return fail(SFX_E_INVALID, "invalid tape handle");
     if (!t->plan) return SFX_OK;                                    // clock tape: no recurrences to reset
     USE_DEVICE(t->ctx);
-    HIP_TRY(hipMemsetAsync(t->d_state, 0, sizeof(float)*3*t->n, t->ctx->stream));
-    HIP_TRY(hipMemsetAsync(t->d_scalars, 0, sizeof(ScalarState)*2, t->ctx->stream));
+    HIP_TRY(hipMemsetAsync(t->d_state, 0, sizeof(float)*3*t->n, t->audio_stream));   // in order with the builds before and after it
+    HIP_TRY(hipMemsetAsync(t->d_scalars, 0, sizeof(ScalarState)*2, t->audio_stream));
     t->frames_done = 0;                                             // the scrolling texture starts empty again
     return SFX_OK;
 }
@@ -1818,9 +1868,11 @@ extern "C" int sfx_clock_tape_create(sfx_handle hc, int max_frames, sfx_handle* 
     Tape* t = new Tape();
     memset(static_cast<void*>(&t->desc), 0, sizeof t->desc);
     t->magic = MAGIC_TAPE; t->plan = nullptr; t->audio = nullptr; t->ctx = c; t->max_frames = max_frames; t->n = 0;
-    t->d_tell = nullptr; t->d_power = t->d_targets = t->d_columns = t->d_rows = t->d_loudness = t->d_state = nullptr;
-    t->d_scalars = nullptr; t->d_coeff = nullptr; t->d_vol = t->d_std = nullptr; t->d_clock = nullptr;
-    if (hipMalloc(&t->d_dyn, sizeof(FrameDyn)*max_frames) != hipSuccess || hipMalloc(&t->d_vis, sizeof(VisualizerConsts)*max_frames) != hipSuccess) {
+    bool ok = tape_open_streams(t);
+    for (TapeBank& k : t->bank)
+        ok = ok && hipMalloc(&k.d_dyn, sizeof(FrameDyn)*max_frames) == hipSuccess && hipMalloc(&k.d_vis, sizeof(VisualizerConsts)*max_frames) == hipSuccess;
+    tape_select(t, 0);
+    if (!ok) {
         sfx_tape_destroy(handle_of(t));
         return fail(SFX_E_HIP, "clock tape of %d frames: out of device memory", max_frames);
     }
@@ -1840,32 +1892,35 @@ extern "C" int sfx_tape_create(sfx_handle hp, sfx_handle ha, const sfx_tape_desc
     t->n = p->bins*p->channels;
     const size_t F = max_frames;
     const int pts = desc->points > 0 ? desc->points : 1;
-    t->d_tell = nullptr; t->d_power = t->d_targets = t->d_columns = t->d_rows = t->d_loudness = t->d_state = nullptr;
-    t->d_scalars = nullptr; t->d_dyn = nullptr; t->d_coeff = nullptr; t->d_vol = t->d_std = nullptr; t->d_clock = nullptr; t->d_vis = nullptr;
-    const bool allocated =
-        hipMalloc(&t->d_tell, sizeof(long)*F) == hipSuccess &&
-        hipMalloc(&t->d_power, sizeof(float)*F*p->channels*p->fft_bins) == hipSuccess &&
-        hipMalloc(&t->d_targets, sizeof(float)*F*t->n) == hipSuccess &&
-        hipMalloc(&t->d_columns, sizeof(float)*F*t->n) == hipSuccess &&
-        hipMalloc(&t->d_rows, sizeof(float)*F*pts*a->channels) == hipSuccess &&
-        hipMalloc(&t->d_loudness, sizeof(float)*F*2) == hipSuccess &&
-        hipMalloc(&t->d_state, sizeof(float)*3*t->n) == hipSuccess &&
-        hipMalloc(&t->d_scalars, sizeof(ScalarState)*2) == hipSuccess &&
-        hipMalloc(&t->d_dyn, sizeof(FrameDyn)*F) == hipSuccess &&
-        hipMalloc(&t->d_coeff, sizeof(DynCoeffF32)*F) == hipSuccess &&
-        hipMalloc(&t->d_vol, sizeof(DynCoeffF64)*F) == hipSuccess &&
-        hipMalloc(&t->d_std, sizeof(DynCoeffF64)*F) == hipSuccess &&
-        hipMalloc(&t->d_clock, sizeof(FrameClock)*F) == hipSuccess &&
-        hipMalloc(&t->d_vis, sizeof(VisualizerConsts)*F) == hipSuccess &&
-        hipMalloc(&t->d_bars, sizeof(float)*F*t->n) == hipSuccess;
     t->width = desc->length_samples > 1 ? desc->length_samples : 1;
-    bool scroll_ok = true;
+    bool allocated = tape_open_streams(t) &&
+        hipMalloc(&t->d_state, sizeof(float)*3*t->n) == hipSuccess &&
+        hipMalloc(&t->d_scalars, sizeof(ScalarState)*2) == hipSuccess;
+    for (TapeBank& k : t->bank)
+        allocated = allocated &&
+            hipMalloc((void**)&k.d_schedule, schedule_layout(max_frames).at[5]) == hipSuccess &&
+            hipMalloc(&k.d_power, sizeof(float)*F*p->channels*p->fft_bins) == hipSuccess &&
+            hipMalloc(&k.d_targets, sizeof(float)*F*t->n) == hipSuccess &&
+            hipMalloc(&k.d_columns, sizeof(float)*F*t->n) == hipSuccess &&
+            hipMalloc(&k.d_rows, sizeof(float)*F*pts*a->channels) == hipSuccess &&
+            hipMalloc(&k.d_loudness, sizeof(float)*F*2) == hipSuccess &&
+            hipMalloc(&k.d_dyn, sizeof(FrameDyn)*F) == hipSuccess &&
+            hipMalloc(&k.d_vis, sizeof(VisualizerConsts)*F) == hipSuccess &&
+            hipMalloc(&k.d_bars, sizeof(float)*F*t->n) == hipSuccess &&
+            (t->width <= 1 || hipMalloc(&k.d_scroll, sizeof(float)*F*t->n*t->width) == hipSuccess);
     if (allocated && t->width > 1) {
         t->ring_frames = t->width + max_frames;
-        scroll_ok = hipMalloc(&t->d_ring, sizeof(float)*(size_t)t->ring_frames*t->n) == hipSuccess &&
-                    hipMalloc(&t->d_scroll, sizeof(float)*F*t->n*t->width) == hipSuccess;
+        allocated = hipMalloc(&t->d_ring, sizeof(float)*(size_t)t->ring_frames*t->n) == hipSuccess;
     }
-    if (!allocated || !scroll_ok) {
+    if (allocated) {
+        const ScheduleLayout l = schedule_layout(max_frames);
+        for (TapeBank& k : t->bank) {
+            k.d_tell = (long*)(k.d_schedule + l.at[0]); k.d_clock = (FrameClock*)(k.d_schedule + l.at[1]); k.d_coeff = (DynCoeffF32*)(k.d_schedule + l.at[2]);
+            k.d_vol = (DynCoeffF64*)(k.d_schedule + l.at[3]); k.d_std = (DynCoeffF64*)(k.d_schedule + l.at[4]);
+        }
+    }
+    tape_select(t, 0);
+    if (!allocated) {
         sfx_tape_destroy(handle_of(t));                             // frees what was allocated (hipFree(nullptr) is a no-op)
         return fail(SFX_E_HIP, "tape of %d frames: out of device memory", max_frames);
     }
@@ -1878,46 +1933,59 @@ extern "C" int sfx_tape_build(sfx_handle h, int nframes, const int64_t* tell, co
     Tape* t = get<Tape>(h, MAGIC_TAPE);
     if (!t) return fail(SFX_E_INVALID, "invalid tape handle");
     if (nframes < 1 || nframes > t->max_frames || !clock) return fail(SFX_E_INVALID, "tape build of %d frames (capacity %d) or null clock", nframes, t->max_frames);
+    USE_DEVICE(t->ctx);
+    // the bank the last render did not read; its previous copy out of the pinned staging is long done (two builds ago) — the wait
+    // is there for callers that build without rendering
+    const int b = t->built_once ? (t->current ^ 1) : 0;
+    TapeBank& k = t->bank[b];
+    HIP_TRY(hipEventSynchronize(k.built));
+    hipStream_t s = t->audio_stream;
+    HIP_TRY(hipStreamWaitEvent(s, k.rendered, 0));                  // the renders that read this bank
     if (!t->plan) {                                                 // clock tape: the per-frame uniforms are the clock itself
-        USE_DEVICE(t->ctx);
-        std::vector<FrameDyn> dyn(nframes);
-        for (int k = 0; k < nframes; k++) {
-            memset(&dyn[k], 0, sizeof(FrameDyn));
-            dyn[k].iTime = clock[k].iTime; dyn[k].iTau = clock[k].iTau; dyn[k].iSpectrogramOffset = clock[k].iSpectrogramOffset; dyn[k].iFrame = clock[k].iFrame;
+        FrameDyn* dyn = (FrameDyn*)k.staging;
+        for (int f = 0; f < nframes; f++) {
+            memset(&dyn[f], 0, sizeof(FrameDyn));
+            dyn[f].iTime = clock[f].iTime; dyn[f].iTau = clock[f].iTau; dyn[f].iSpectrogramOffset = clock[f].iSpectrogramOffset; dyn[f].iFrame = clock[f].iFrame;
         }
-        HIP_TRY(hipMemcpyAsync(t->d_dyn, dyn.data(), sizeof(FrameDyn)*nframes, hipMemcpyHostToDevice, t->ctx->stream));
-        HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+        HIP_TRY(hipMemcpyAsync(k.d_dyn, dyn, sizeof(FrameDyn)*nframes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(k.built, s));
+        tape_select(t, b); t->built_once = true;
         return SFX_OK;
     }
     if (!tell || !spectrogram || !volume || !std_) return fail(SFX_E_INVALID, "tape build with null audio schedule arrays");
     static_assert(sizeof(sfx_dyn_coeff_f32) == sizeof(DynCoeffF32) && sizeof(sfx_dyn_coeff_f64) == sizeof(DynCoeffF64) && sizeof(sfx_frame_clock) == sizeof(FrameClock), "ABI structs");
-    USE_DEVICE(t->ctx);
-    hipStream_t s = t->ctx->stream;
+    static_assert(sizeof(long) == sizeof(int64_t), "tell");
     Plan* p = t->plan; const Audio* a = t->audio;
-    HIP_TRY(hipMemcpyAsync(t->d_tell, tell, sizeof(long)*nframes, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(t->d_clock, clock, sizeof(FrameClock)*nframes, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(t->d_coeff, spectrogram, sizeof(DynCoeffF32)*nframes, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(t->d_vol, volume, sizeof(DynCoeffF64)*nframes, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(t->d_std, std_, sizeof(DynCoeffF64)*nframes, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));                               // host arrays are borrowed for the call only
-    launch_stft(p, a, t->d_tell, nframes, t->d_power, s);
-    launch_filterbank(p, nframes, t->desc.use_mfma, t->d_power, t->d_targets, s);
+    // host arrays are borrowed for the call only: into the bank's pinned staging, from there to the device in ONE copy behind the
+    // host's back
+    const ScheduleLayout l = schedule_layout(t->max_frames);
+    memcpy(k.staging + l.at[0], tell, sizeof(long)*nframes);
+    memcpy(k.staging + l.at[1], clock, sizeof(FrameClock)*nframes);
+    memcpy(k.staging + l.at[2], spectrogram, sizeof(DynCoeffF32)*nframes);
+    memcpy(k.staging + l.at[3], volume, sizeof(DynCoeffF64)*nframes);
+    memcpy(k.staging + l.at[4], std_, sizeof(DynCoeffF64)*nframes);
+    HIP_TRY(hipMemcpyAsync(k.d_schedule, k.staging, l.at[4] + sizeof(DynCoeffF64)*nframes, hipMemcpyHostToDevice, s));
+    launch_stft(p, a, k.d_tell, nframes, k.d_power, s);
+    launch_filterbank(p, nframes, t->desc.use_mfma, k.d_power, k.d_targets, s);
     if (t->desc.points > 0)
         hipLaunchKernelGGL(k_waveform_rows, dim3((t->desc.points*a->channels + 3)/4, nframes), dim3(256), 0, s,
-                           a->pcm, a->samples, a->channels, t->d_tell, t->desc.chunk_size, t->desc.points, t->desc.reducer, t->d_rows);
-    hipLaunchKernelGGL(k_volume_std, dim3(nframes), dim3(256), 0, s, a->pcm, a->samples, a->channels, t->d_tell, t->desc.volume_window, t->d_loudness);
-    launch_dynamics_scan(s, nframes, t->n, t->d_targets, t->d_coeff, (float)t->desc.precision,
-                         t->d_state, t->d_columns, t->d_loudness, t->d_vol, t->d_std, t->desc.precision,
-                         t->desc.volume_integrate, t->desc.std_integrate, t->d_scalars, t->d_clock, t->d_dyn);
+                           a->pcm, a->samples, a->channels, k.d_tell, t->desc.chunk_size, t->desc.points, t->desc.reducer, k.d_rows);
+    hipLaunchKernelGGL(k_volume_std, dim3(nframes), dim3(256), 0, s, a->pcm, a->samples, a->channels, k.d_tell, t->desc.volume_window, k.d_loudness);
+    launch_dynamics_scan(s, nframes, t->n, k.d_targets, k.d_coeff, (float)t->desc.precision,
+                         t->d_state, k.d_columns, k.d_loudness, k.d_vol, k.d_std, t->desc.precision,
+                         t->desc.volume_integrate, t->desc.std_integrate, t->d_scalars, k.d_clock, k.d_dyn);
     if (t->width > 1) {
         const long count = (long)nframes*t->n;
-        hipLaunchKernelGGL(k_spectrogram_ring_store, dim3((unsigned)((count + 255)/256)), dim3(256), 0, s, t->d_columns, nframes, t->n, t->frames_done, t->ring_frames, t->d_ring);
+        hipLaunchKernelGGL(k_spectrogram_ring_store, dim3((unsigned)((count + 255)/256)), dim3(256), 0, s, k.d_columns, nframes, t->n, t->frames_done, t->ring_frames, t->d_ring);
         const long texels = count*t->width;
         hipLaunchKernelGGL(k_spectrogram_scroll, dim3((unsigned)((texels + 255)/256)), dim3(256), 0, s, t->d_ring, t->ring_frames, t->frames_done, nframes,
-                           p->bins, p->channels, t->width, t->d_scroll);
+                           p->bins, p->channels, t->width, k.d_scroll);
     }
     t->frames_done += nframes;
-    return launch_status();
+    const int rc = launch_status();
+    HIP_TRY(hipEventRecord(k.built, s));
+    tape_select(t, b); t->built_once = true;
+    return rc;
 }
 
 extern "C" int sfx_tape_read(sfx_handle h, int what, int frame0, int nframes, void* out, size_t nbytes) {
@@ -1940,6 +2008,7 @@ extern "C" int sfx_tape_read(sfx_handle h, int what, int frame0, int nframes, vo
         default: return fail(SFX_E_INVALID, "tape section %d", what);
     }
     if (nbytes != per*nframes) return fail(SFX_E_INVALID, "tape read of %zu bytes, section needs %zu", nbytes, per*nframes);
+    HIP_TRY(hipStreamWaitEvent(t->ctx->stream, t->bank[t->current].built, 0));
     HIP_TRY(hipMemcpyAsync(out, src + per*frame0, nbytes, hipMemcpyDeviceToHost, t->ctx->stream));
     HIP_TRY(hipStreamSynchronize(t->ctx->stream));
     return SFX_OK;
@@ -1949,9 +2018,17 @@ extern "C" int sfx_tape_destroy(sfx_handle h) {
     Tape* t = get<Tape>(h, MAGIC_TAPE);
     if (!t) return fail(SFX_E_INVALID, "invalid tape handle");
     hipSetDevice(t->ctx->device);
+    if (t->audio_stream) hipStreamSynchronize(t->audio_stream);
     hipStreamSynchronize(t->ctx->stream);
-    hipFree(t->d_tell); hipFree(t->d_power); hipFree(t->d_targets); hipFree(t->d_columns); hipFree(t->d_rows); hipFree(t->d_loudness);
-    hipFree(t->d_state); hipFree(t->d_scalars); hipFree(t->d_dyn); hipFree(t->d_coeff); hipFree(t->d_vol); hipFree(t->d_std); hipFree(t->d_clock); hipFree(t->d_vis); hipFree(t->d_bars); hipFree(t->d_screen); hipFree(t->d_ring); hipFree(t->d_scroll);
+    for (TapeBank& k : t->bank) {
+        hipFree(k.d_schedule); hipFree(k.d_power); hipFree(k.d_targets); hipFree(k.d_columns); hipFree(k.d_rows); hipFree(k.d_loudness);
+        hipFree(k.d_dyn); hipFree(k.d_vis); hipFree(k.d_bars); hipFree(k.d_scroll);
+        if (k.staging) hipHostFree(k.staging);
+        if (k.built) hipEventDestroy(k.built);
+        if (k.rendered) hipEventDestroy(k.rendered);
+    }
+    hipFree(t->d_state); hipFree(t->d_scalars); hipFree(t->d_screen); hipFree(t->d_ring);
+    if (t->audio_stream) hipStreamDestroy(t->audio_stream);
     t->magic = 0;
     delete t;
     return SFX_OK;
@@ -1976,6 +2053,10 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
     set_pixel_centres(a);
     a.out = device_out; a.out_frame_stride = (long)width*height*3;
     a.dyn = t->d_dyn; a.frame0 = frame0;
+    // the bank was filled on the tape's stream: this stream waits for its last audio kernel, and leaves a mark behind its own last
+    // kernel that the build refilling the bank will wait for (Tape, above)
+    HIP_TRY(hipStreamWaitEvent(p->ctx->stream, t->bank[t->current].built, 0));
+    struct RenderedMark { hipEvent_t event; hipStream_t stream; ~RenderedMark() { hipEventRecord(event, stream); } } mark{t->bank[t->current].rendered, p->ctx->stream};
     if (t->plan) {
     // iSpectrogram: width 1 (length=0 scenes), height bins, RG32F (spectrogram.py:298-311); the bound texture's
     // sampler state is kept, only its storage is redirected to the tape column of the frame
