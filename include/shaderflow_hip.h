@@ -273,7 +273,11 @@ int sfx_tape_create(sfx_handle plan, sfx_handle audio, const sfx_tape_desc* desc
  * built with sfx_tape_build(tape, n, NULL, clock, NULL, NULL, NULL), rendered with sfx_render_tape (scene.py:456-479 per frame). */
 int sfx_clock_tape_create(sfx_handle ctx, int max_frames, sfx_handle* tape);
 int sfx_tape_reset(sfx_handle tape);         /* ShaderDynamics.setup → reset (dynamics.py:273-274)  */
-/* Computes frames [0, nframes) of the tape from the running dynamics state (continues across calls). */
+/* Computes frames [0, nframes) of the tape from the running dynamics state (continues across calls). The host arrays are borrowed
+ * for the call only (copied to pinned memory of the tape). The work is queued on a stream of the tape's own, into the one of its
+ * two banks that the last sfx_render_tape did not read, and the call returns without waiting for the device: the next batch's audio
+ * kernels run beside the previous batch's render. sfx_render_tape / sfx_tape_read order themselves after the build they read
+ * (events); a build orders itself after the renders of the bank it refills. Batches must be built in frame order. */
 int sfx_tape_build(sfx_handle tape, int nframes, const int64_t* tell, const sfx_frame_clock* clock,
                    const sfx_dyn_coeff_f32* spectrogram, const sfx_dyn_coeff_f64* volume,
                    const sfx_dyn_coeff_f64* std);
