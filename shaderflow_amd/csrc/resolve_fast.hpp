@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_resolve_fast(const ResolveArgs a, const
     if ((BW*3) % 16 == 0 && i_first + BW <= a.w && (a.w*3) % 16 == 0 && ((uintptr_t)out & 15) == 0 && ((i_first*3) & 15) == 0) {
         for (int e = tid; e < BH*GROUPS; e += BW*BH) {
             const int row = e/GROUPS, c = e - row*GROUPS, jr = j_first + row;
-            if (jr < a.h) ((uint4*)(out + (long)(a.top_down ? a.h - 1 - jr : jr)*a.w*3 + (long)i_first*3))[c] = ((const uint4*)&staged[0][0])[e];
+            if (jr < a.h) stream_store16((uint4*)(out + (long)(a.top_down ? a.h - 1 - jr : jr)*a.w*3 + (long)i_first*3) + c, (const uint4*)&staged[0][0] + e);
         }
         return;
     }
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_resolve_tent(const ResolveArgs a, const
 #pragma unroll
         for (int e = tid; e < TENT_BH*GROUPS; e += 256) {
             const int row = e/GROUPS, c = e - row*GROUPS, jr = j_first + row;
-            if (jr < a.h) ((uint4*)(out + (long)(a.top_down ? a.h - 1 - jr : jr)*a.w*3 + (long)i_first*3))[c] = ((const uint4*)&staged[0][0])[e];
+            if (jr < a.h) stream_store16((uint4*)(out + (long)(a.top_down ? a.h - 1 - jr : jr)*a.w*3 + (long)i_first*3) + c, (const uint4*)&staged[0][0] + e);
         }
         return;
     }

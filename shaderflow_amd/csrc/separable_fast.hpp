@@ -377,7 +377,7 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(8)))
             if (r < rows_here) {
                 const int py = blockIdx.y*SEP_ROWS + r;
                 uint8_t* row = out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3 + (long)x0*3;
-                ((uint4*)row)[c] = ((const uint4*)&staged[0][0])[k];
+                stream_store16((uint4*)row + c, (const uint4*)&staged[0][0] + k);
             }
         }
         return;
@@ -550,8 +550,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == SEP
         }
         if (active) {
             uint32_t* row = (uint32_t*)(out + (long)(a.top_down ? a.h - 1 - py : py)*pitch);
-            struct alignas(4) Triple { uint32_t x, y, z; };
-            *(Triple*)row = Triple{o0, o1, o2};
+            // non-temporal (`global_store_dwordx3 ... nt`): nobody on the device reads a frame back, so its lines need not stay in
+            // the L2 — bars 308 -> 261 us per 60 frames of 4K (5.7 TB/s written = 0.71 of the HBM roof), waveform 293 -> 289 (its
+            // time is the special rows around the wave, not the stores)
+            typedef uint32_t Triple __attribute__((ext_vector_type(3), aligned(4)));
+            __builtin_nontemporal_store(Triple{o0, o1, o2}, (Triple*)row);
         }
     }
 }

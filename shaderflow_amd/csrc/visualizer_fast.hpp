@@ -764,7 +764,7 @@ struct VisualizerStrip {
                 if (r < rows_here) {
                     const int py = by*PIXEL_ROWS + r;
                     uint8_t* row = out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3 + (long)bx*BLOCK_PX*3;
-                    ((uint4*)row)[c] = ((const uint4*)staged)[e];
+                    stream_store16((uint4*)row + c, (const uint4*)staged + e);
                 }
             }
             return;
