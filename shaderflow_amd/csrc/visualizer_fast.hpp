@@ -10,7 +10,7 @@
 // against W*H = 33.2 M supersamples at 4K 2xSSAA. The tables hold, per column (row):
 //   q0 = { r, frac(r), byte offset of cell floor(r) inside the block's LDS tile, byte offset of the line's first cell }
 //   q1 = { rot_c*u | -rot_s*u (col) or rot_s*u | rot_c*u (row), u*u, agluv*agluv }     (u = gluv.x or gluv.y)
-//   q2 = { log2(astuv*(1-astuv)), waveform.x*0.2 | 1-gluv.y, waveform.y*0.2 | 1+gluv.y, out of bounds }
+//   q2 = { (sqrt(20)*astuv*(1-astuv))^vig_exp: this axis' factor of the frame's vignette, waveform.x*0.2 | 1-gluv.y, waveform.y*0.2 | 1+gluv.y, out of bounds }
 //   q3..q6 = the AXIS LINE: the blur's taps along this axis (visualizer.frag:26-31, directions 0 and 180 degrees plus the
 //            centre tap for a row of texels, 90 and 270 degrees for a column) summed per texel cell in closed form — for each
 //            of the VIS_LINE_CELLS consecutive cells the line can touch: n = sum of tap weights, s = sum of weight*fraction.
@@ -130,6 +130,9 @@ __global__ __launch_bounds__(128) void k_visualizer_axis(const RenderArgs a, con
     }
 
     float4* e = (AXIS == 0 ? t.columns : t.rows) + ((long)frame*n + k)*VIS_ENTRY_QUADS;
+    // this axis' factor of the vignette: pow(vig.x*vig.y*20, e) = (sqrt(20)*ax(1-ax))^e * (sqrt(20)*ay(1-ay))^e with the frame's
+    // exponent (visualizer.frag:65-66) — one exp2 per table entry instead of one per supersample
+    const float vignette = __builtin_amdgcn_exp2f(c.vig_exp*(__builtin_amdgcn_logf(as*(1.0f - as)) + 2.1609640475f));
     const int cell_bytes = AXIS == 0 ? t.cell_bytes : t.tile_pitch*t.cell_bytes;
     e[0] = make_float4(r, frac_r, __int_as_float((int)cell_r*cell_bytes), __int_as_float(start*cell_bytes));
     if (AXIS == 0) {
@@ -137,10 +140,10 @@ __global__ __launch_bounds__(128) void k_visualizer_axis(const RenderArgs a, con
         e[1] = make_float4(c.rot_c*uv, (-c.rot_s)*uv, uv*uv, ag*ag);
         const Tex& wave = tex[TEX_WAVEFORM];
         const vec2 w = texture_xy(wave, vec2{as, 0.0f});                                       // :71
-        e[2] = make_float4(__builtin_amdgcn_logf(as*(1.0f - as)), 0.2f*w.x, 0.2f*w.y, __int_as_float((behind || sf::abs(g) > u.iWantAspect) ? 1 : 0));   // camera.glsl:83
+        e[2] = make_float4(vignette, 0.2f*w.x, 0.2f*w.y, __int_as_float((behind || sf::abs(g) > u.iWantAspect) ? 1 : 0));   // camera.glsl:83
     } else {
         e[1] = make_float4(c.rot_s*uv, c.rot_c*uv, uv*uv, ag*ag);
-        e[2] = make_float4(__builtin_amdgcn_logf(as*(1.0f - as)), 1.0f - g, 1.0f + g, 0.0f);   // :72-73 compare these with the waveform
+        e[2] = make_float4(vignette, 1.0f - g, 1.0f + g, 0.0f);   // :72-73 compare these with the waveform
         if (t.ysteps) {
             // The y half of a diagonal tap — fraction and row of cells of y +- k*s (VisualizerShader::blur_tile's walk) — depends
             // on the sample ROW and the walk step only: 10 entries per row instead of eight instructions per tap quadruple of
@@ -183,13 +186,14 @@ template <bool WITH_ALPHA = false>                               // the fused ke
 __device__ __forceinline__ uint32_t visualizer_fast_post(const RenderArgs& a, int frame, const VisualizerConsts& c, float r, float g, float b,
                                                          const float4 c1, const float4 c2, const float4 r1, const float4 r2) {
     const float norm = 1.0f/(255.0f*10.0f*8.0f);                      // (sum/255)/(quality*directions), visualizer.frag:32
-    vec3 col = {r*norm, g*norm, b*norm};
     const vec3 space = vec3{1.0f, 11.0f, 26.0f}/255.0f;                                                // :9
+    vec3 col;
     {
         const float la = __builtin_amdgcn_sqrtf(c1.w + r1.w);                                   // length(agluv), colour only
         const float cl = clamp01(la - 0.3f);
         const float c2l = cl*cl;
-        col = col*(1.0f + c.flash*(c2l*c2l*c2l));                                               // :36
+        const float flash = norm*(1.0f + c.flash*(c2l*c2l*c2l));                                // :32 and :36 in one factor
+        col = vec3{r*flash, g*flash, b*flash};
     }
     const vec2 music_uv = vec2{c1.x + r1.x, c1.y + r1.y}*c.shrink;                              // :39-40
     const float radius = 0.17f;
@@ -240,8 +244,8 @@ __device__ __forceinline__ uint32_t visualizer_fast_post(const RenderArgs& a, in
         const float lp = __builtin_amdgcn_sqrtf(c1.z + r1.z)*0.05f;                             // length(uv)/20, colour only
         col = mix(col, space, smoothstep01(lp));                                                // :62
     }
-    // pow(vig.x*vig.y*20, e) = exp2(e*(log2(ax(1-ax)) + log2(ay(1-ay)) + log2(20))), :65-66
-    col = col*__builtin_amdgcn_exp2f(c.vig_exp*((c2.x + r2.x) + 4.321928095f));
+    // the vignette (:65-66) = column factor * row factor (k_visualizer_axis); the unorm8 scale rides on it
+    col = col*((c2.x*r2.x)*255.0f);
     // the waveform strips along the top and bottom edges and the bars outside the wanted aspect: most waves have no such lane
     const bool strip_top = r2.y < c2.y, strip_bottom = r2.z < c2.z, outside = __float_as_int(c2.w) != 0;
     uint32_t alpha = 0xff000000u;                                                               // fragColor.a = 1 (:68)
@@ -249,10 +253,13 @@ __device__ __forceinline__ uint32_t visualizer_fast_post(const RenderArgs& a, in
         float opacity = 1.0f;
         if (strip_top) { col = col*0.8f; opacity = opacity*0.8f; }                              // :72 scales the whole vec4
         if (strip_bottom) { col = col*0.8f; opacity = opacity*0.8f; }                           // :73
-        if (outside) { col = space; opacity = 0.0f; }                                           // :11-14
+        if (outside) { col = space*255.0f; opacity = 0.0f; }                                    // :11-14
         if (WITH_ALPHA) alpha = unorm8(opacity) << 24;
     }
-    return WITH_ALPHA ? (pack_rgb8(col) | alpha) : pack_rgb8(col);
+    uint32_t texel = __builtin_amdgcn_cvt_pk_u8_f32(col.x, 0u, 0u);                            // pack_rgb8 of col/255
+    texel = __builtin_amdgcn_cvt_pk_u8_f32(col.y, 1u, texel);
+    texel = __builtin_amdgcn_cvt_pk_u8_f32(col.z, 2u, texel);
+    return WITH_ALPHA ? (texel | alpha) : texel;
 }
 
 // Stages the window [x0, x0+tw) x [y0, y0+th) of the background as difference-basis cells (VisualizerShader::setup step 2)
