@@ -201,6 +201,9 @@ __device__ __forceinline__ uint32_t visualizer_fast_post(const RenderArgs& a, in
     const float* bars = a.tape_bars + (long)(a.frame0 + frame)*a.spectrogram_stride;
     const float height = (float)sp.height;
     const float square = music_uv.x*music_uv.x + music_uv.y*music_uv.y;
+    // length(iCamera.gluv): :62 wants it /20 for the colour, and music_uv is that vector rotated and shrunk (:39-40), so its length —
+    // for the lanes that are certain of their side of both radii by 5e-4 — is this one times |shrink| (one square root for two)
+    const float reach = __builtin_amdgcn_sqrtf(c1.z + r1.z);
 
     float circle, len, bar, rr;
     auto heights = [&](float circle_, float len_) {                                             // :45-46, :52, given the angle
@@ -225,7 +228,7 @@ __device__ __forceinline__ uint32_t visualizer_fast_post(const RenderArgs& a, in
         if (ay > ax) angle = HALF_PI - angle;
         if (music_uv.x < 0.0f) angle = 0x1.921fb6p+1f - angle;                                  // |atan(y, x)|: the sign of y does not matter
         const float approximate = angle*0x1.45f306p-2f;                                         // /PI
-        heights(approximate, __builtin_amdgcn_sqrtf(square));
+        heights(approximate, reach*sf::abs(c.shrink));
         const float scaled = approximate*height;
         const float fraction = scaled - ::floorf(scaled);
         const float margin = fmaf(height, 1.0e-6f, 2.0e-6f);
@@ -241,7 +244,7 @@ __device__ __forceinline__ uint32_t visualizer_fast_post(const RenderArgs& a, in
         else col = col*ColourMath<true>::pow((len - rr)*0.5f, 0.05f);                           // :58
     }
     {
-        const float lp = __builtin_amdgcn_sqrtf(c1.z + r1.z)*0.05f;                             // length(uv)/20, colour only
+        const float lp = reach*0.05f;                                                            // length(uv)/20, colour only
         col = mix(col, space, smoothstep01(lp));                                                // :62
     }
     // the vignette (:65-66) = column factor * row factor (k_visualizer_axis); the unorm8 scale rides on it
