@@ -410,7 +410,7 @@ def main() -> None:
                                  "algorithmic_bytes_per_launch": b_alg*piece,
                                  "measured": round(traffic/launch_s/1e9, 1) if traffic else None,
                                  "note": "algorithmic bytes = the reference's two-pass data-flow (SURVEY.md §8d); the fused kernel writes the RGB8 frame only"},
-                         "note": "FP32 VALU issue binds the kernel (the 91-tap blur folded to ~560 instructions per supersample, DESIGN.md §4; LDS ~55 % busy); "
+                         "note": "FP32 VALU issue binds the kernel (the 91-tap blur folded to ~550 instructions per supersample, DESIGN.md §4; LDS ~55 % busy); "
                                  "HBM carries the finished RGB8 frames and L2-resident tables only, so the HBM figure is a fraction of what the two-pass data-flow would move"},
         }
         if args.scene != "visualizer":
