@@ -266,6 +266,26 @@ def test_waveform_scene_tape_equals_frame_loop(ssaa):
     assert not np.array_equal(tape[5], tape[40])
 
 
+@pytest.mark.parametrize("batch", [1, 2, 3, 7])
+def test_tape_banks_with_small_batches(batch, monkeypatch):
+    """The tape's two banks and streams (capi.hip Tape): with batches of a few frames the builds run far ahead of the renders and
+    the banks alternate dozens of times — the frames must be the ones a single batch gives, for an audio scene with both passes
+    (no SSAA: fragment into iScreen, then final.glsl) and for the fused path; tools/stress_tape_banks.py is the long version"""
+    from examples.scenes import MusicBars, Visualizer, make
+    from shaderflow_amd import synth
+    from shaderflow_amd.tape import FrameTape
+    frames = 45
+    pcm, background = synth.sweep_clip(frames/60.0, 44100), synth.background_image(320, 180, seed=0)
+    for cls, ssaa in ((MusicBars, 2), (Visualizer, 1), (Visualizer, 2)):
+        kwargs = dict(audio=(pcm, 44100), **({"background": background} if cls is Visualizer else {}))
+        kw = dict(width=192, height=108, fps=60.0, time=frames/60.0, ssaa=ssaa, output=bytes, batch=True)
+        whole = frames_of(make(cls, **kwargs).main(**kw), 192, 108)
+        monkeypatch.setattr(FrameTape, "BATCH", batch)
+        small = frames_of(make(cls, **kwargs).main(**kw), 192, 108)
+        monkeypatch.undo()
+        assert np.array_equal(small, whole), (cls.__name__, ssaa, lsb_report(small, whole))
+
+
 def test_piano_module_writes_its_textures(tmp_path):
     """ShaderPiano inside a scene: textures of the reference's shapes, written every frame, uniforms in the pipeline; a MIDI
     file round trip feeds it (the texture CONTENTS are pinned on CPU, tests/test_host_piano.py)"""
