@@ -829,8 +829,7 @@ static int launch_visualizer_tables_and_kernel(Context* ctx, const RenderArgs& a
     t.block_x = (int4*)(t.rows + (size_t)frames*a.hr*VIS_ENTRY_QUADS);
     t.block_y = t.block_x + (size_t)frames*t.blocks_x;
     t.ysteps = STRIP_S ? (float4*)(t.block_y + (size_t)frames*t.blocks_y) : nullptr;
-    hipLaunchKernelGGL(k_visualizer_axis<0>, dim3((a.wr + 127)/128, frames), dim3(128), 0, s, a, t);
-    hipLaunchKernelGGL(k_visualizer_axis<1>, dim3((a.hr + 127)/128, frames), dim3(128), 0, s, a, t);
+    hipLaunchKernelGGL(k_visualizer_axes, dim3((a.wr + 127)/128 + (a.hr + 127)/128, frames), dim3(128), 0, s, a, t);
     if constexpr (STRIP_S != 0) {
         g_last_kernel = "k_visualizer_strip<" + std::to_string(PITCH) + ", " + std::to_string(ROWS) + ", " + std::to_string(STRIP_S) + ", " + std::to_string(WALK) + ", " + std::to_string(WAVES) + ", " + std::to_string(CG) + (HALF ? ", true>" : ", false>");
         hipLaunchKernelGGL((k_visualizer_strip<PITCH, ROWS, STRIP_S, WALK, WAVES, CG, HALF>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(512), 0, s, a, t);

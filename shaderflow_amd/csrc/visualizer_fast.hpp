@@ -48,11 +48,9 @@ struct VisTables {
 
 // One axis of the sample grid: thread k builds the entry of column (AXIS == 0) or row (AXIS == 1) k of frame blockIdx.y.
 template <int AXIS>
-__global__ __launch_bounds__(128) void k_visualizer_axis(const RenderArgs a, const VisTables t) {
-    const int k = blockIdx.x*128 + threadIdx.x;
+__device__ __forceinline__ void visualizer_axis_entry(const RenderArgs& a, const VisTables& t, int k, int frame) {
     const int n = AXIS == 0 ? a.wr : a.hr;
     if (k >= n) return;
-    const int frame = blockIdx.y;
     Uniforms u; Tex tex[TEX_HISTORY];
     frame_view(a, frame, u, tex);
     const VisualizerConsts c = a.vis_consts ? a.vis_consts[a.frame0 + frame] : (a.has_vis ? a.vis : visualizer_consts(u.iTime, u.iAudioVolume, u.iAudioSTD));
@@ -163,6 +161,13 @@ __global__ __launch_bounds__(128) void k_visualizer_axis(const RenderArgs a, con
     e[4] = make_float4(wn[2], ws[2], wn[3], ws[3]);
     e[5] = make_float4(wn[4], ws[4], wn[5], ws[5]);
     e[6] = make_float4(wn[6], ws[6], wn[7], ws[7]);
+}
+// both axes in ONE launch (the two tables are latency-bound chains of a few thousand threads each: side by side they take the time
+// of one — 53 instead of 105 us per 60 frames of 4K): blocks [0, ceil(wr/128)) build columns, the rest rows; frame = blockIdx.y
+__global__ __launch_bounds__(128) void k_visualizer_axes(const RenderArgs a, const VisTables t) {
+    const int column_blocks = (a.wr + 127)/128;
+    if ((int)blockIdx.x < column_blocks) visualizer_axis_entry<0>(a, t, blockIdx.x*128 + threadIdx.x, blockIdx.y);
+    else visualizer_axis_entry<1>(a, t, ((int)blockIdx.x - column_blocks)*128 + threadIdx.x, blockIdx.y);
 }
 
 // visualizer.frag:32-73 (fragments.hpp visualizer_post<true>) on the blur's sums and the separable terms of the tables: c1/c2 the
