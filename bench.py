@@ -235,6 +235,7 @@ def main() -> None:
     # SHADERFLOW_SHARD=device-sdma: the gather as peer copies on the SDMA engines instead of RCCL kernels (parallel.SdmaTransfer):
     # rank 0 exports two step buffers per source rank as IPC handles, every other rank maps its pair
     sdma = distributed and os.environ.get("SHADERFLOW_SHARD", "").strip().lower() == "device-sdma"
+    loopback = distributed and world == 1 and dist.get_backend() == "nccl" and not sdma
     windows = None
     if sdma:
         handles = [None]
@@ -255,14 +256,19 @@ def main() -> None:
             if rank:
                 context.peer_copy(windows[index % 2] + lo, view.data_ptr(), hi - lo, lane=(index % 2)*parts + q)
             return
-        if rank == 0:
+        if loopback:
+            # ONE rank over RCCL (SHADERFLOW_FORCE_DIST=1): the piece is sent to this rank itself — the same grouped point-to-point
+            # call, RCCL's own kernel on the render stream, the same ordering against the next render — so that everything the
+            # first multi-GPU run depends on has executed on a single GPU before (tests/test_gpu_rccl.py)
+            ops = [dist.P2POp(dist.irecv, received[0][index % 2][lo:hi], 0), dist.P2POp(dist.isend, view, 0)]
+        elif rank == 0:
             ops = [dist.P2POp(dist.irecv, received[source][index % 2][lo:hi], source) for source in range(1, world)]
         else:
             ops = [dist.P2POp(dist.isend, view.cpu() if staged else view, 0)]
         if ops:
             in_flight.extend(dist.batch_isend_irecv(ops))
 
-    works_per_transfer = (world - 1) if rank == 0 else 1
+    works_per_transfer = 2 if loopback else ((world - 1) if rank == 0 else 1)
 
     def drain(keep_transfers: int = 0) -> None:
         while len(in_flight) > keep_transfers*works_per_transfer:
@@ -319,6 +325,10 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     dist_backend = dist.get_backend() if distributed else None
+    loopback_intact = None
+    if loopback:                                                   # what RCCL delivered is what was rendered (last step, both on this device)
+        last = args.warmup + args.steps - 1
+        loopback_intact = bool(torch.equal(received[0][last % 2], buffers[last % 2]))
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staged else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -333,7 +343,7 @@ def main() -> None:
         events = [context.event_elapsed_ms(2*i, 2*i + 1) for i in range(min(args.steps, 32))]
         mine = {"rank": rank, "render_ms_per_step": round(float(np.mean(events)), 3) if events else None,
                 "render_frames_per_s": round(fpb/(float(np.mean(events))/1e3), 1) if events else None,
-                "sent_GB_per_s": (round(args.steps*fpb*frame_bytes/elapsed/1e9, 2) if rank else 0.0)}
+                "sent_GB_per_s": (round(args.steps*fpb*frame_bytes/elapsed/1e9, 2) if (rank or loopback) else 0.0)}
         per_rank = [None]*world
         dist.all_gather_object(per_rank, mine)
 
@@ -432,7 +442,7 @@ def main() -> None:
         if per_rank is not None:
             result["per_rank"] = per_rank
             inbound = sum(r["sent_GB_per_s"] for r in per_rank)
-            result["gather"] = {"backend": "sdma peer copies (hipIpc + hipMemcpyAsync)" if sdma else dist_backend, "pieces_per_step": parts, "inbound_GB_per_s_rank0": round(inbound, 2),
+            result["gather"] = {"backend": "sdma peer copies (hipIpc + hipMemcpyAsync)" if sdma else dist_backend, "pieces_per_step": parts, "inbound_GB_per_s_rank0": round(inbound, 2), "loopback": loopback, "loopback_intact": loopback_intact,
                                 "note": "sent_GB_per_s = frames a rank sent to rank 0 / the timed region: every peer has its own xGMI link to rank 0; "
                                         "a rank whose render_frames_per_s x 24.9 MB exceeds what its link sustains is link-bound (DESIGN.md §6)"}
     else:

@@ -1499,6 +1499,11 @@ extern "C" int sfx_audio_destroy(sfx_handle h) {
     return SFX_OK;
 }
 
+// k-split partial sums of the MFMA filterbank: one per USER of a plan — the plan's own for the per-frame entry points on the context's
+// stream, one per tape for its builds on the tape's audio stream — so that a build never shares scratch with a launch on another
+// stream (the plan-level buffer was written by both)
+struct FilterbankScratch { float* d_partial = nullptr; size_t floats = 0; };
+
 struct Plan : Object {
     Context* ctx;
     int fft_n, window, bins, channels, fft_bins, nnz;
@@ -1508,7 +1513,7 @@ struct Plan : Object {
     float* d_dense = nullptr; int2* d_band = nullptr; int k_pad = 0, row_tiles = 0;
     // scratch that grows on demand
     long* d_tell = nullptr; float* d_power = nullptr; float* d_out = nullptr; int cap_frames = 0;
-    float* d_partial = nullptr; size_t partial_floats = 0;        // k-split partial sums of the MFMA filterbank
+    FilterbankScratch scratch;                                    // … of the per-frame entry points (the context's stream)
 };
 
 static int plan_reserve(Plan* p, int frames) {
@@ -1607,7 +1612,7 @@ extern "C" int sfx_stft_plan_destroy(sfx_handle h) {
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
     hipFree(p->d_window); hipFree(p->d_twiddle); hipFree(p->d_indptr); hipFree(p->d_indices); hipFree(p->d_data);
-    hipFree(p->d_dense); hipFree(p->d_band); hipFree(p->d_tell); hipFree(p->d_power); hipFree(p->d_out); hipFree(p->d_partial);
+    hipFree(p->d_dense); hipFree(p->d_band); hipFree(p->d_tell); hipFree(p->d_power); hipFree(p->d_out); hipFree(p->scratch.d_partial);
     p->magic = 0;
     delete p;
     return SFX_OK;
@@ -1632,20 +1637,20 @@ static void launch_stft(const Plan* p, const Audio* a, const long* d_tell, int f
     hipLaunchKernelGGL(k_stft_power, dim3(frames, p->channels), dim3(256), (N/2)*sizeof(double2), s,
                        a->pcm, a->samples, d_tell, p->fft_n, p->d_window, p->d_twiddle, d_power, p->amplitude);
 }
-static void launch_filterbank(Plan* p, int frames, int use_mfma, const float* d_power, float* d_out, hipStream_t s) {
+static void launch_filterbank(Plan* p, FilterbankScratch& scratch, int frames, int use_mfma, const float* d_power, float* d_out, hipStream_t s) {
     const int ncols = frames*p->channels;
     const size_t partial = (size_t)FILTERBANK_SPLITS*p->row_tiles*32*ncols;
-    if (use_mfma && p->partial_floats < partial) {
-        hipStreamSynchronize(s);
-        hipFree(p->d_partial); p->d_partial = nullptr; p->partial_floats = 0;
-        if (hipMalloc(&p->d_partial, partial*sizeof(float)) == hipSuccess) p->partial_floats = partial;
+    if (use_mfma && scratch.floats < partial) {
+        hipStreamSynchronize(s);                                      // the scratch's only user is this stream
+        hipFree(scratch.d_partial); scratch.d_partial = nullptr; scratch.floats = 0;
+        if (hipMalloc(&scratch.d_partial, partial*sizeof(float)) == hipSuccess) scratch.floats = partial;
         else { (void)hipGetLastError(); use_mfma = 0; }               // out of memory for the scratch: the CSR kernel needs none
     }
     if (use_mfma) {
         hipLaunchKernelGGL(k_filterbank_mfma, dim3((ncols + 31)/32, p->row_tiles, FILTERBANK_SPLITS), dim3(64), 0, s,
-                           p->d_dense, p->k_pad, p->d_band, p->fft_bins, ncols, d_power, p->d_partial);
+                           p->d_dense, p->k_pad, p->d_band, p->fft_bins, ncols, d_power, scratch.d_partial);
         const long total = (long)ncols*p->bins;
-        hipLaunchKernelGGL(k_filterbank_reduce, dim3((unsigned)((total + 255)/256)), dim3(256), 0, s, p->d_partial, p->row_tiles*32, p->bins, p->channels, ncols, d_out);
+        hipLaunchKernelGGL(k_filterbank_reduce, dim3((unsigned)((total + 255)/256)), dim3(256), 0, s, scratch.d_partial, p->row_tiles*32, p->bins, p->channels, ncols, d_out);
     } else {
         const long total = (long)ncols*p->bins;
         hipLaunchKernelGGL(k_filterbank_csr, dim3((unsigned)((total + 255)/256)), dim3(256), 0, s,
@@ -1679,7 +1684,7 @@ extern "C" int sfx_spectrogram_targets(sfx_handle hp, sfx_handle ha, const int64
     hipStream_t s = p->ctx->stream;
     HIP_TRY(hipMemcpyAsync(p->d_tell, tell, sizeof(long)*nframes, hipMemcpyHostToDevice, s));
     launch_stft(p, a, p->d_tell, nframes, p->d_power, s);
-    launch_filterbank(p, nframes, use_mfma, p->d_power, p->d_out, s);
+    launch_filterbank(p, p->scratch, nframes, use_mfma, p->d_power, p->d_out, s);
     if ((rc = launch_status())) return rc;
     HIP_TRY(hipMemcpyAsync(out, p->d_out, sizeof(float)*(size_t)nframes*p->channels*p->bins, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1810,6 +1815,7 @@ struct Tape : Object {
     float* d_scroll = nullptr;       // scrolling spectrogram: the texture's state per frame of the batch
     TapeBank bank[2]; int current = 0; bool built_once = false;
     hipStream_t audio_stream = nullptr;
+    FilterbankScratch scratch;       // of this tape's builds (audio_stream)
     float* d_state = nullptr; ScalarState* d_scalars = nullptr;
     void* d_screen = nullptr; size_t screen_bytes = 0;   // iScreen scratch of the two-pass path (frames of a batch)
     // scrolling spectrogram (length_samples > 1, spectrogram.py:298-311): ring of the last columns
@@ -1965,7 +1971,7 @@ extern "C" int sfx_tape_build(sfx_handle h, int nframes, const int64_t* tell, co
     memcpy(k.staging + l.at[4], std_, sizeof(DynCoeffF64)*nframes);
     HIP_TRY(hipMemcpyAsync(k.d_schedule, k.staging, l.at[4] + sizeof(DynCoeffF64)*nframes, hipMemcpyHostToDevice, s));
     launch_stft(p, a, k.d_tell, nframes, k.d_power, s);
-    launch_filterbank(p, nframes, t->desc.use_mfma, k.d_power, k.d_targets, s);
+    launch_filterbank(p, t->scratch, nframes, t->desc.use_mfma, k.d_power, k.d_targets, s);
     if (t->desc.points > 0)
         hipLaunchKernelGGL(k_waveform_rows, dim3((t->desc.points*a->channels + 3)/4, nframes), dim3(256), 0, s,
                            a->pcm, a->samples, a->channels, k.d_tell, t->desc.chunk_size, t->desc.points, t->desc.reducer, k.d_rows);
@@ -2026,7 +2032,7 @@ extern "C" int sfx_tape_destroy(sfx_handle h) {
         if (k.built) hipEventDestroy(k.built);
         if (k.rendered) hipEventDestroy(k.rendered);
     }
-    hipFree(t->d_state); hipFree(t->d_scalars); hipFree(t->d_screen); hipFree(t->d_ring);
+    hipFree(t->d_state); hipFree(t->d_scalars); hipFree(t->d_screen); hipFree(t->d_ring); hipFree(t->scratch.d_partial);
     if (t->audio_stream) hipStreamDestroy(t->audio_stream);
     t->magic = 0;
     delete t;

@@ -46,6 +46,17 @@ def rank_world() -> tuple[int, int]:
     return 0, 1
 
 
+def is_sharded() -> bool:
+    """An export takes the multi-rank code paths: a process group with more than one rank — or, with SHADERFLOW_FORCE_DIST=1, a group
+    of ONE rank (the RCCL backend, its streams and the shard modes exercised end to end on a single GPU: tests/test_gpu_rccl.py)"""
+    rank, world = rank_world()
+    if world > 1:
+        return True
+    import sys
+    dist = sys.modules.get("torch.distributed")
+    return bool(os.environ.get("SHADERFLOW_FORCE_DIST") == "1" and dist is not None and dist.is_available() and dist.is_initialized())
+
+
 def shard_frames(total: int, world: int, rank: int) -> tuple[int, int]:
     """Contiguous frame range [first, last) of `rank`: sizes differ by at most one, earlier ranks get the extra"""
     base, extra = divmod(total, world)
@@ -258,20 +269,31 @@ class HostDelivery:
         self.N.lib().sfx_shm_abort(self.handle)
 
     def finish(self) -> None:
+        """Every rank enters: flush (rank 0: until the writer has handed over the last frame), then ONE collective that carries each
+        rank's outcome — so that a late failure on one rank (the sink's EPIPE on rank 0 after a peer has flushed everything) raises
+        on every rank at once instead of leaving the healthy ones alone in a barrier — and only then the unmap."""
         import torch.distributed as dist
-        done = False
-        try:
-            if not self.failed:
+        error: Optional[BaseException] = None
+        if not self.failed:
+            try:
                 self.N.check(self.N.lib().sfx_shm_flush(self.handle))
                 if self.rank == 0:
                     self.N.check(self.N.lib().sfx_shm_drain_wait(self.handle))
-                done = True
-        finally:
-            if not done:
-                self.N.lib().sfx_shm_abort(self.handle)             # the peers' pushes and the writer fail at once instead of timing out
-            elif self.world > 1:
-                dist.barrier()                                      # nobody unmaps while the writer still reads
-            self.N.lib().sfx_shm_destroy(self.handle)
+            except Exception as caught:
+                error = caught
+        mine = None if not (self.failed or error) else f"rank {self.rank}: {error or 'its producer raised'}"
+        if mine:
+            self.N.lib().sfx_shm_abort(self.handle)                 # the peers' pushes and the writer fail at once instead of timing out
+        outcomes = [mine]
+        if self.world > 1:
+            outcomes = [None]*self.world
+            dist.all_gather_object(outcomes, mine)                  # also the barrier: nobody unmaps while the writer still reads
+        self.N.lib().sfx_shm_destroy(self.handle)
+        if error is not None:
+            raise error
+        failed = [outcome for outcome in outcomes if outcome]
+        if failed and not self.failed:                              # (a rank whose own exception is propagating re-raises that one)
+            raise RuntimeError("sharded export failed: " + "; ".join(failed))
 
 
 def interleaved_runs(world: int, batches: list[tuple[int, int]]) -> list[tuple[int, int]]:

@@ -33,7 +33,7 @@ from shaderflow_amd.exporting import ExportingHelper
 from shaderflow_amd.ffmpeg import FFmpeg
 from shaderflow_amd.message import ShaderMessage
 from shaderflow_amd.module import ShaderModule, logger
-from shaderflow_amd.parallel import rank_world
+from shaderflow_amd.parallel import is_sharded, rank_world
 from shaderflow_amd.resolution import Resolution
 from shaderflow_amd.scheduler import Scheduler
 from shaderflow_amd.shader import ShaderProgram
@@ -354,7 +354,7 @@ class ShaderScene(ShaderModule):
 
         self.vsync = self.scheduler.new(task=self.next, frequency=self.fps, freewheel=self.freewheel,
                                         frameskip=frameskip, precise=True)
-        if self.exporting and (rank_world()[1] > 1 or shard is not None):
+        if self.exporting and (is_sharded() or shard is not None):
             return self._sharded_frame_loop(export, turbo, *(shard or rank_world()))
         while (task := self.scheduler.next()):
             if (task is not self.vsync):
@@ -387,7 +387,7 @@ class ShaderScene(ShaderModule):
             warmup = 2*(depth - 1)
         modes = frame_modes(batches, world, rank, warmup)
         context = self.context
-        distributed = rank_world()[1] > 1
+        distributed = is_sharded()
         if distributed and shard_mode() == "host":
             # every rank reads the frames of its own batches out over its own PCIe link into shared memory; rank 0's writer thread
             # hands them to the sink in frame order (parallel.HostDelivery)

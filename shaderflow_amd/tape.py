@@ -226,7 +226,7 @@ class FrameTape:
         the ranks and delivered to rank 0, which owns the sink: per-rank read-out into shared memory ("host", the default) or
         contiguous HBM-resident ranges sent over RCCL ("device") — shaderflow_amd/parallel.py."""
         from shaderflow_amd.parallel import (DeviceArray, HostDelivery, RangeTransfer, SdmaTransfer, contiguous_device_export,
-                                             interleaved_host_export, interleaved_runs, rank_world, shard_batches, shard_frames, shard_mode)
+                                             interleaved_host_export, interleaved_runs, is_sharded, rank_world, shard_batches, shard_frames, shard_mode)
         scene = self.scene
         total = export.total_frames
         rank, world = rank_world()
@@ -240,7 +240,7 @@ class FrameTape:
         def emit_frames(pointer: int, count: int, fence: Optional[int] = None) -> None:
             export.pipe_device_frames(pointer, frame_bytes, count, turbo=turbo, fence=fence)
 
-        mode = shard_mode() if world > 1 else "single"
+        mode = shard_mode() if is_sharded() else "single"
         if mode.startswith("device"):
             # device modes keep every frame of the export resident in rank 0's HBM (a 60 s 4K clip: 89.6 GB of 288). A clip that does
             # not fit falls back to host mode — for ALL ranks: rank 0 decides, everybody follows
@@ -257,7 +257,7 @@ class FrameTape:
                           f"SHADERFLOW_SHARD={mode} falls back to host mode", flush=True)
                 mode = "host"
         try:
-            if world == 1:
+            if mode == "single":
                 buffers = [context.alloc(frame_bytes*self.batch) for _ in range(2)]
                 try:
                     # software pipeline: batch b+1 is rendering while the frames of batch b travel to the host

@@ -86,19 +86,36 @@ def _rank_without_sink(rank: int, world: int, port: int, fail_on: int):
             raise RuntimeError("injected producer failure")      # rank 1 owns the middle batch of three: its only render
             return render(self, count, device_out, first_slot)
         FrameTape.render = broken
+    output = None
+    if fail_on == SINK_DIES and rank == 0:
+        from shaderflow_amd.exporting import ExportingHelper
+
+        def popen(self, open_sink=True):                             # the sink: a pipe nobody reads (an encoder that exited) → EPIPE in the writer
+            self.scene.context.output_top_down(bool(self.top_down))
+            reader, writer = os.pipe()
+            os.close(reader)
+            self.fileno = writer
+        ExportingHelper.popen = popen
+    if fail_on == SINK_DIES:
+        output = f"/tmp/shaderflow-test-{os.getpid()}.rgb"
     try:
-        scene.main(freewheel=True, output=None, **KW["Visualizer"])
+        scene.main(freewheel=(output is None), output=output, **KW["Visualizer"])
     finally:
         dist.destroy_process_group()
 
 
+SINK_DIES = 100
+
+
 @pytest.mark.timeout(200)
-@pytest.mark.parametrize("fail_on", [-1, 1])
+@pytest.mark.parametrize("fail_on", [-1, 1, SINK_DIES])
 def test_two_ranks_without_a_sink_and_with_a_failing_producer(fail_on):
     """ADVICE round 2. (a) No sink (a freewheeling run under torchrun, fileno None): rank 0's writer consumes and DISCARDS the frames
     of both ranks in frame order — before, it exited at once and every producer sat in sfx_shm_push until the time-out.
     (b) A producer that raises mid-export tells the group through the segment's `failed` flag: both processes end within seconds
-    with an error instead of waiting 900 s for frames that never come; the segment's name is gone from /dev/shm either way."""
+    with an error instead of waiting 900 s for frames that never come; the segment's name is gone from /dev/shm either way.
+    (c) ADVICE round 3: the SINK fails on rank 0 (EPIPE in the writer thread): the outcome travels in HostDelivery.finish's collective,
+    so the peer that had already flushed all its frames raises too instead of sitting alone in a barrier."""
     import time
     ctx = mp.get_context("spawn")
     port = _free_port()
