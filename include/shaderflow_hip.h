@@ -77,6 +77,12 @@ int sfx_ctx_synchronize(sfx_handle ctx);
 /* Encoder hand-off (exporting.py:94-103 adds ffmpeg's `vflip` filter because GL rows are bottom-up): with enabled != 0
  * sfx_resolve / sfx_render_resolve / sfx_render_tape write their RGB8 frames top-down, so no filter is needed. */
 int sfx_ctx_output_top_down(sfx_handle ctx, int enabled);
+/* The context's two copy streams (read-out ring = turbopipe's role, exporting.py:147-171; shared-memory ring; peer windows) are chosen
+ * once, on first use or by this call, so that neither shares a hardware queue with the render stream: HIP folds its streams onto a
+ * few in-order queues, and a copy stream on the render stream's queue serialises read-out and render (C3: 2 080 → 1 215 frames/s).
+ * Candidates are created until two are found whose copies complete while a kernel holds the render stream. Reports how many
+ * streams were looked at and how many of them ran in series with the render stream (either may be NULL). */
+int sfx_ctx_copy_streams(sfx_handle ctx, int* candidates, int* colliding);
 int sfx_ctx_destroy(sfx_handle ctx);
 
 /* Timing on the context's stream with HIP events (bench.py roofline leg). slot in [0, 64). */

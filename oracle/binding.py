@@ -99,6 +99,7 @@ def lib() -> C.CDLL:
         L.sfo_render_to.argtypes = [C.c_int, P(Uniforms), P(Texture), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.sfo_resolve.argtypes = [P(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_uint8)]
         L.sfo_sample.argtypes = [P(Texture), C.c_float, C.c_float, P(C.c_float)]
+        L.sfo_set_llvmpipe_filter.argtypes = [C.c_int]
         L.sfo_test_math.argtypes = [C.c_int, C.c_float, C.c_float]
         L.sfo_test_math.restype = C.c_float
         _lib = L
@@ -282,6 +283,20 @@ def resolve(screen: np.ndarray, w: int, h: int, subsample: int,
     y0, y1 = rows or (0, h)
     lib().sfo_resolve(_p(screen, C.c_uint8), wr, hr, w, h, subsample, y0, y1, threads, _p(out, C.c_uint8))
     return out
+
+
+class llvmpipe_filter:
+    """`with O.llvmpipe_filter():` — unorm8 textures are filtered as Mesa llvmpipe filters them (24.8 fixed-point coordinates, 8-bit
+    weights, every lerp rounded to 8 bits: sfo_pixel.c). A checker's switch for the tests that demonstrate where the > 1 LSB values
+    against the llvmpipe goldens come from; off by default and for every parity test of the HIP kernels."""
+
+    def __enter__(self):
+        lib().sfo_set_llvmpipe_filter(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().sfo_set_llvmpipe_filter(0)
+        return False
 
 
 def sample(tex: Texture, s: float, t: float) -> np.ndarray:

@@ -180,6 +180,11 @@ void sfo_render_to(int fragment, const sfo_uniforms* u, const sfo_texture* textu
 void sfo_resolve(const uint8_t* screen, int wr, int hr, int w, int h, int subsample,
                  int y0, int y1, int threads, uint8_t* out);
 
+/* Checker's switch, off by default: filter unorm8 textures as Mesa llvmpipe does (24.8 fixed-point coordinates, 8-bit weights, every
+ * lerp rounded back to 8 bits — sfo_pixel.c). It exists to DEMONSTRATE the cause of the > 1 LSB values against the llvmpipe goldens
+ * (tests/test_oracle_mesa.py); parity tests of the HIP kernels run with it off. Process-wide; set it outside sfo_render calls. */
+void sfo_set_llvmpipe_filter(int on);
+
 /* GL `texture()` on one coordinate, exposed for sampler unit tests */
 void sfo_sample(const sfo_texture* t, float s, float tt, float rgba[4]);
 

@@ -87,6 +87,39 @@ static inline v4 fetch_texel(const sfo_texture* t, int i, int j) {
     return c;
 }
 
+/* The filter of the implementation the golden frames were rendered on, as a CHECKER'S SWITCH (never the default, never in the kernels):
+ * Mesa llvmpipe 23.2 samples 8-bit unorm textures through its fixed-point path — texel coordinates in 24.8 fixed point,
+ * fx = rint(s*N*256) - 128, weight = fx & 255 (8 fractional bits, the coordinate ROUNDED, not truncated), i0 = fx >> 8; the wrap mode
+ * applied to i0 and i0+1; one lerp along x on the 8-bit values, a + ((w*(b - a) + 128) >> 8), ROUNDED BACK TO 8 BITS, then the same
+ * lerp along y — so a filtered unorm8 texel is always k/255. OpenGL allows it (>= 4 subtexel bits, section 3.8.11). Measured, not
+ * read: tests/golden/make_golden_filter.py renders probe textures through the reference on llvmpipe into a float32 target; this
+ * model reproduces all 2.8 M filtered values of that fixture bit for bit (tests/test_oracle_mesa.py). With the switch on, the
+ * oracle's frames meet the llvmpipe goldens at <= 1 LSB where the spec-precision filter leaves up to 1.3 % of the values 2 off. */
+static int g_llvmpipe_filter = 0;
+void sfo_set_llvmpipe_filter(int on) { g_llvmpipe_filter = on; }
+
+static inline int fixed_wrap(int i, int n, int repeat) {
+    if (repeat) { i %= n; return i < 0 ? i + n : i; }
+    return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+}
+static inline int fixed_lerp(int w, int a, int b) { return (a + ((w*(b - a) + 128) >> 8)) & 255; }
+
+static v4 sample_llvmpipe_u8(const sfo_texture* t, v2 uv) {
+    const int fx = (int)lrintf(uv.x*(float)t->width*256.0f) - 128, fy = (int)lrintf(uv.y*(float)t->height*256.0f) - 128;
+    const int wx = fx & 255, wy = fy & 255;
+    const int i0 = fixed_wrap(fx >> 8, t->width, t->repeat_x), i1 = fixed_wrap((fx >> 8) + 1, t->width, t->repeat_x);
+    const int j0 = fixed_wrap(fy >> 8, t->height, t->repeat_y), j1 = fixed_wrap((fy >> 8) + 1, t->height, t->repeat_y);
+    const uint8_t* data = (const uint8_t*)t->data;
+    v4 c = V4(0.0f, 0.0f, 0.0f, 1.0f);
+    float* out = &c.x;
+    for (int k = 0; k < t->components && k < 4; k++) {
+        const int t00 = data[((int64_t)j0*t->width + i0)*t->components + k], t10 = data[((int64_t)j0*t->width + i1)*t->components + k];
+        const int t01 = data[((int64_t)j1*t->width + i0)*t->components + k], t11 = data[((int64_t)j1*t->width + i1)*t->components + k];
+        out[k] = (float)fixed_lerp(wy, fixed_lerp(wx, t00, t10), fixed_lerp(wx, t01, t11))/255.0f;
+    }
+    return c;
+}
+
 static v4 sample(const sfo_texture* t, v2 uv) {
     float u = uv.x*(float)t->width;
     float v = uv.y*(float)t->height;
@@ -95,6 +128,7 @@ static v4 sample(const sfo_texture* t, v2 uv) {
         int j = wrap_index((int)floorf(v), t->height, t->repeat_y);
         return fetch_texel(t, i, j);
     }
+    if (g_llvmpipe_filter && t->dtype == SFO_U8) return sample_llvmpipe_u8(t, uv);
     float ub = u - 0.5f, vb = v - 0.5f;
     float fu = floorf(ub), fv = floorf(vb);
     float a = ub - fu, b = vb - fv;

@@ -75,6 +75,7 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_ctx_info": (C.c_int, [Handle, P(CtxInfo)]),
     "sfx_ctx_synchronize": (C.c_int, [Handle]),
     "sfx_ctx_output_top_down": (C.c_int, [Handle, C.c_int]),
+    "sfx_ctx_copy_streams": (C.c_int, [Handle, P(C.c_int), P(C.c_int)]),
     "sfx_ctx_destroy": (C.c_int, [Handle]),
     "sfx_event_record": (C.c_int, [Handle, C.c_int]),
     "sfx_event_elapsed_ms": (C.c_int, [Handle, C.c_int, C.c_int, P(C.c_float)]),
@@ -203,6 +204,12 @@ class Context:
 
     def synchronize(self) -> None:
         check(lib().sfx_ctx_synchronize(self.handle))
+
+    def copy_streams(self) -> tuple[int, int]:
+        """(streams looked at, of which in series with the render stream) when the context's two copy streams were chosen"""
+        candidates, colliding = C.c_int(), C.c_int()
+        check(lib().sfx_ctx_copy_streams(self.handle, C.byref(candidates), C.byref(colliding)))
+        return candidates.value, colliding.value
 
     def output_top_down(self, enabled: bool) -> None:
         check(lib().sfx_ctx_output_top_down(self.handle, 1 if enabled else 0))

@@ -11,6 +11,8 @@
 #include "separable_fast.hpp"
 #include "uniform_table.hpp"
 
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 #include <atomic>
 #include <cerrno>
 #include <chrono>
@@ -71,7 +73,12 @@ struct Context : Object {
     void* vis_tables = nullptr; size_t vis_tables_bytes = 0;
     float* vis_bars = nullptr; size_t vis_bars_count = 0;          // sqrt(texel/1000) of a bound spectrogram (single launches)
     void* resolve_tables = nullptr; size_t resolve_tables_bytes = 0;   // column/row tap tables of k_resolve_fast
-    // peer copies of the sharded export's "device-sdma" mode: two copy streams, an event per lane (sfx_peer_*)
+    // the context's two copy streams (read-out ring, shared-memory ring, peer windows): chosen once so that neither shares a hardware
+    // queue with `stream` (context_copy_streams)
+    hipStream_t copy_streams[2] = {nullptr, nullptr};
+    int copy_candidates = 0, copy_colliding = 0;                   // how many streams the choice looked at / found serialised behind `stream`
+    struct EngineCopy* engines = nullptr;                           // read-out on named SDMA engines (readout_copy); null until first use
+    // peer copies of the sharded export's "device-sdma" mode: the copy streams, an event per lane (sfx_peer_*)
     hipStream_t peer_streams[2] = {nullptr, nullptr};
     hipEvent_t peer_ready = nullptr, peer_done[16] = {};
     uint64_t peer_copies = 0;
@@ -120,6 +127,179 @@ static void build_tap_table(float* tx, float* ty) {
     tx[n] = 0.0f; ty[n] = 0.0f;                                   // [80]: the centre tap
 }
 
+// Copy streams (read-out ring, shared-memory ring, peer windows). HIP multiplexes its streams onto a handful of IN-ORDER hardware
+// queues (GPU_MAX_HW_QUEUES, 4 by default; a new stream joins the queue with the fewest streams). A copy stream that lands on the
+// render stream's queue puts its wait-for-the-copy barrier packets in front of the next render kernel: read-out and render stop
+// overlapping — measured at C3: 2 080 → 1 215 frames/s (= render + copy in series), which is what happened whenever other streams
+// had been created before (torch's pool of 32, an earlier export's; with GPU_MAX_HW_QUEUES=2 always) and explains the 1 770-1 860 of
+// bench.py's export leg against 2 080 for the same export in a fresh process (profiles/r04_export_streams.txt). Stream priorities are
+// no way out (queues of another priority: 830 frames/s). So the choice is MEASURED, once per context: candidates are created until two
+// are found whose copies complete WHILE a kernel occupies the render stream.
+__global__ void k_hold_stream(const int* release, long long ticks) {
+    const long long start = wall_clock64();                         // 100 MHz: `ticks` bounds the hold whatever the host does
+    while (__hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 && wall_clock64() - start < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+static int context_copy_streams(Context* c) {
+    if (c->copy_streams[0]) return SFX_OK;
+    const char* off = getenv("SHADERFLOW_COPY_STREAM_PROBE");
+    int* release = nullptr; void* pinned = nullptr; void* device = nullptr; hipEvent_t landed = nullptr;
+    bool probe = !(off && !strcmp(off, "0"));
+    if (probe && (hipHostMalloc((void**)&release, 4096, hipHostMallocMapped) != hipSuccess || hipHostMalloc(&pinned, 4096, hipHostMallocDefault) != hipSuccess ||
+                  hipMalloc(&device, 4096) != hipSuccess || hipEventCreateWithFlags(&landed, hipEventDisableTiming) != hipSuccess)) { (void)hipGetLastError(); probe = false; }
+    std::vector<hipStream_t> rejected;
+    int found = 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int candidate = 0; found < 2 && candidate < 12; candidate++) {
+        hipStream_t stream = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        c->copy_candidates++;
+        bool independent = true;
+        if (probe) {
+            *release = 0;
+            hipLaunchKernelGGL(k_hold_stream, dim3(1), dim3(1), 0, c->stream, release, 2000000LL);      // ≤ 20 ms, normally ≈ 0.1 ms
+            hipMemcpyAsync(pinned, device, 4096, hipMemcpyDeviceToHost, stream);
+            hipEventRecord(landed, stream);
+            const auto started = std::chrono::steady_clock::now();
+            independent = false;
+            while (std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count() < 3e-3)
+                if (hipEventQuery(landed) == hipSuccess) { independent = true; break; }
+            (void)hipGetLastError();                                // hipErrorNotReady of the queries
+            __atomic_store_n(release, 1, __ATOMIC_RELEASE);
+            hipStreamSynchronize(c->stream);
+            hipStreamSynchronize(stream);
+        }
+        if (independent) c->copy_streams[found++] = stream;
+        else { c->copy_colliding++; rejected.push_back(stream); }
+    }
+    // nothing independent to be had (one hardware queue): the rejected ones still work, in series with the render
+    while (found < 2 && !rejected.empty()) { c->copy_streams[found++] = rejected.back(); rejected.pop_back(); }
+    for (hipStream_t stream : rejected) hipStreamDestroy(stream);
+    if (release) hipHostFree(release);
+    if (pinned) hipHostFree(pinned);
+    if (device) hipFree(device);
+    if (landed) hipEventDestroy(landed);
+    if (found < 2) return fail(SFX_E_HIP, "no copy streams");
+    return SFX_OK;
+}
+
+// One frame from device memory to pinned (or HIP-registered) host memory, in order on copy stream `lane` of the context.
+//
+// Not hipMemcpyAsync: the runtime picks an SDMA engine per stream — the lowest one free at that moment, then sticky — and the sixteen
+// engines of an MI355X are far from equal for device-to-host traffic (tools/ubench_sdma_engines.hip, profiles/r04_export_streams.txt):
+// engines 0-3 move 42-54 GB/s, 4-7 ≈ 12, 8-11 ≈ 9, 12-15 ≈ 7. A copy stream that draws a far engine reads 4K frames out at a quarter
+// of the bus for the rest of its life — the 830 frames/s exports of the third context of a process, against 2 080 for the first.
+// So the copy names its engine: a host function on the copy stream (in order with the event waits before and the event record after
+// it, exactly where the hipMemcpyAsync stood) hands the frame to HSA's copy-on-engine call on one of the two engines HSA itself
+// recommends for this direction (hsa_amd_memory_get_preferred_copy_engine; SHADERFLOW_SDMA_ENGINES=a,b overrides) and waits for it.
+// Route "hip" (SHADERFLOW_READOUT=hip, or whenever HSA does not answer) is the plain hipMemcpyAsync; "kernel" a 256-workgroup copy
+// kernel storing into the mapped host buffer (measured: does not overlap a render that fills the chip — 1 235 frames/s).
+struct EngineCopy {
+    bool usable = false;
+    hsa_agent_t gpu{}, cpu{};
+    uint32_t engine[2] = {0, 0};
+    hsa_signal_t done[2] = {};
+    std::atomic<int> failed{0};
+};
+struct ReadoutJob { EngineCopy* e; void* host; const void* device; size_t nbytes; int lane; };
+
+static hsa_status_t collect_agents(hsa_agent_t agent, void* data) {
+    auto* lists = (std::pair<std::vector<hsa_agent_t>, std::vector<hsa_agent_t>>*)data;
+    hsa_device_type_t type;
+    if (hsa_agent_get_info(agent, HSA_AGENT_INFO_DEVICE, &type) == HSA_STATUS_SUCCESS) (type == HSA_DEVICE_TYPE_GPU ? lists->first : lists->second).push_back(agent);
+    return HSA_STATUS_SUCCESS;
+}
+
+// the agents of a frame's two ends, from the pointers themselves; engines from HSA's recommendation
+static EngineCopy* engine_copy(Context* c, const void* host, const void* device) {
+    if (c->engines) return c->engines->usable ? c->engines : nullptr;
+    EngineCopy* e = c->engines = new EngineCopy();
+    const char* route = getenv("SHADERFLOW_READOUT");
+    if (route && strcmp(route, "engine")) return nullptr;
+    if (hsa_init() != HSA_STATUS_SUCCESS) return nullptr;             // reference-counted: HIP holds the runtime open already
+    hsa_amd_pointer_info_t info{}; info.size = sizeof(info);
+    if (hsa_amd_pointer_info(device, &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || info.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return nullptr;
+    e->gpu = info.agentOwner;
+    std::pair<std::vector<hsa_agent_t>, std::vector<hsa_agent_t>> agents;
+    if (hsa_iterate_agents(collect_agents, &agents) != HSA_STATUS_SUCCESS || agents.second.empty()) return nullptr;
+    bool is_gpu = false;
+    for (hsa_agent_t a : agents.first) is_gpu |= (a.handle == e->gpu.handle);
+    if (!is_gpu) return nullptr;
+    e->cpu = agents.second[0];
+    hsa_amd_pointer_info_t host_info{}; host_info.size = sizeof(host_info);
+    if (hsa_amd_pointer_info(host, &host_info, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS)
+        for (hsa_agent_t a : agents.second) if (a.handle == host_info.agentOwner.handle) e->cpu = a;      // the socket the ring lives on
+    uint32_t free_mask = 0, preferred = 0;
+    if (hsa_amd_memory_copy_engine_status(e->cpu, e->gpu, &free_mask) != HSA_STATUS_SUCCESS && free_mask == 0) return nullptr;
+    if (hsa_amd_memory_get_preferred_copy_engine(e->cpu, e->gpu, &preferred) != HSA_STATUS_SUCCESS) preferred = 0;
+    uint32_t pick = __builtin_popcount(preferred) >= 2 ? preferred : 0x3u;
+    int a = -1, b = -1;
+    if (const char* named = getenv("SHADERFLOW_SDMA_ENGINES")) { if (sscanf(named, "%d,%d", &a, &b) == 2 && a >= 0 && a < 16 && b >= 0 && b < 16) pick = (1u << a) | (1u << b); }
+    e->engine[0] = pick & (~pick + 1u);                              // lowest set bit
+    e->engine[1] = (pick & (pick - 1u)) ? ((pick & (pick - 1u)) & (~(pick & (pick - 1u)) + 1u)) : e->engine[0];
+    if (a >= 0 && b >= 0) { e->engine[0] = 1u << a; e->engine[1] = 1u << b; }
+    for (auto& signal : e->done) if (hsa_signal_create(0, 0, nullptr, &signal) != HSA_STATUS_SUCCESS) return nullptr;
+    e->usable = true;
+    return e;
+}
+
+static void readout_on_engine(void* data) {
+    ReadoutJob* job = (ReadoutJob*)data;
+    EngineCopy* e = job->e;
+    hsa_signal_t done = e->done[job->lane];                         // one copy at a time per lane: host functions of a stream run in order
+    hsa_signal_store_relaxed(done, 1);
+    hsa_status_t status = hsa_amd_memory_async_copy_on_engine(job->host, e->cpu, job->device, e->gpu, job->nbytes, 0, nullptr, done,
+                                                              (hsa_amd_sdma_engine_id_t)e->engine[job->lane], false);
+    if (status != HSA_STATUS_SUCCESS) {                              // the engine's queue could not be had: let HSA choose (no HIP calls in here)
+        hsa_signal_store_relaxed(done, 1);
+        status = hsa_amd_memory_async_copy(job->host, e->cpu, job->device, e->gpu, job->nbytes, 0, nullptr, done);
+    }
+    if (status == HSA_STATUS_SUCCESS) hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
+    else e->failed.store((int)status);
+    delete job;
+}
+
+typedef unsigned int readout_u4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_readout(const readout_u4* __restrict__ src, readout_u4* __restrict__ dst, size_t n16,
+                                                 const unsigned char* __restrict__ src_tail, unsigned char* __restrict__ dst_tail, int tail) {
+    for (size_t i = blockIdx.x*(size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x*blockDim.x)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
+static hipError_t readout_copy(Context* c, void* host, const void* device, size_t nbytes, int lane) {
+    hipStream_t stream = c->copy_streams[lane & 1];
+    if (EngineCopy* e = engine_copy(c, host, device)) {
+        if (!e->failed.load()) return hipLaunchHostFunc(stream, readout_on_engine, new ReadoutJob{e, host, device, nbytes, lane & 1});
+    }
+    const char* route = getenv("SHADERFLOW_READOUT");
+    void* mapped = nullptr;
+    if (route && !strcmp(route, "kernel") && !(((uintptr_t)host | (uintptr_t)device) & 15) && hipHostGetDevicePointer(&mapped, host, 0) == hipSuccess) {
+        const size_t n16 = nbytes/16;
+        hipLaunchKernelGGL(k_readout, dim3(256), dim3(256), 0, stream, (const readout_u4*)device, (readout_u4*)mapped, n16, (const unsigned char*)device + n16*16,
+                           (unsigned char*)mapped + n16*16, (int)(nbytes - n16*16));
+        return hipGetLastError();
+    }
+    (void)hipGetLastError();
+    return hipMemcpyAsync(host, device, nbytes, hipMemcpyDeviceToHost, stream);
+}
+// a copy that HSA refused on every route leaves a frame unread: said once, loudly, by whoever waits for frames next
+static int readout_status(Context* c) {
+    if (c->engines && c->engines->failed.load()) return fail(SFX_E_HIP, "frame read-out: HSA refused the copy (status 0x%x)", c->engines->failed.load());
+    return SFX_OK;
+}
+
+// how the copy streams of this context were chosen: streams looked at, and how many of them ran in series with the render stream
+extern "C" int sfx_ctx_copy_streams(sfx_handle h, int* candidates, int* colliding) {
+    CTX_OR_FAIL(c, h);
+    USE_DEVICE(c);
+    int rc = context_copy_streams(c);
+    if (rc) return rc;
+    if (candidates) *candidates = c->copy_candidates;
+    if (colliding) *colliding = c->copy_colliding;
+    return SFX_OK;
+}
+
 extern "C" int sfx_ctx_create(int device_id, void* stream, sfx_handle* out) {
     if (!out) return fail(SFX_E_INVALID, "null output");
     int count = 0;
@@ -135,6 +315,9 @@ extern "C" int sfx_ctx_create(int device_id, void* stream, sfx_handle* out) {
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     for (auto& e : c->events) HIP_TRY(hipEventCreate(&e));
     build_tap_table(c->tap_x, c->tap_y);
+    // the copy streams NOW, before any other stream of this context exists (a tape's audio stream, …): chosen after a tape had run on
+    // the context, the same export read out at 36.4 ms per 60 frames instead of 27.9 (tools/experiments/export_like_bench.py)
+    if (int rc = context_copy_streams(c)) { delete c; return rc; }
     *out = handle_of(c);
     return SFX_OK;
 }
@@ -173,7 +356,8 @@ extern "C" int sfx_ctx_destroy(sfx_handle h) {
     hipStreamSynchronize(c->stream);
     for (auto& e : c->events) hipEventDestroy(e);
     hipFree(c->vis_tables); hipFree(c->vis_bars); hipFree(c->resolve_tables);
-    for (hipStream_t stream : c->peer_streams) if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
+    for (hipStream_t stream : c->copy_streams) if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
+    if (c->engines) { if (c->engines->usable) for (auto& signal : c->engines->done) hsa_signal_destroy(signal); delete c->engines; }
     if (c->peer_ready) hipEventDestroy(c->peer_ready);
     for (auto& e : c->peer_done) if (e) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -256,7 +440,8 @@ extern "C" int sfx_peer_copy(sfx_handle h, void* remote_dst, const void* local_s
     USE_DEVICE(c);
     if (!c->peer_ready) {
         HIP_TRY(hipEventCreateWithFlags(&c->peer_ready, hipEventDisableTiming));
-        for (auto& stream : c->peer_streams) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        { int rc = context_copy_streams(c); if (rc) return rc; }
+        c->peer_streams[0] = c->copy_streams[0]; c->peer_streams[1] = c->copy_streams[1];
     }
     if (!c->peer_done[lane]) HIP_TRY(hipEventCreateWithFlags(&c->peer_done[lane], hipEventDisableTiming));
     hipStream_t stream = c->peer_streams[c->peer_copies++ & 1];
@@ -1284,6 +1469,7 @@ struct Ring : Object {
     size_t frame_bytes;
     int slots;
     std::vector<void*> host;
+    std::vector<void*> staging;                                     // device copies of texture reads (sfx_ring_read_async), allocated on first use
     std::vector<hipEvent_t> copied;
     hipStream_t copy_streams[2] = {nullptr, nullptr};              // frames alternate between two copy streams: 55 instead of 51.5 GB/s (tools/ubench_d2h.hip)
     int copy_stream_count = 2;
@@ -1335,7 +1521,8 @@ extern "C" int sfx_ring_create(sfx_handle h, size_t frame_bytes, int slots, sfx_
     r->magic = MAGIC_RING; r->ctx = c; r->frame_bytes = frame_bytes; r->slots = slots;
     r->host.resize(slots); r->copied.resize(slots); r->pending.assign(slots, 0);
     if (const char* n = getenv("SHADERFLOW_COPY_STREAMS")) r->copy_stream_count = atoi(n) == 1 ? 1 : 2;   // A/B switch for measurements
-    for (int k = 0; k < r->copy_stream_count; k++) HIP_TRY(hipStreamCreateWithFlags(&r->copy_streams[k], hipStreamNonBlocking));
+    { int rc = context_copy_streams(c); if (rc) { delete r; return rc; } }
+    for (int k = 0; k < r->copy_stream_count; k++) r->copy_streams[k] = c->copy_streams[k];    // borrowed: the context's
     HIP_TRY(hipEventCreateWithFlags(&r->produced, hipEventDisableTiming));
     for (auto& f : r->fences) HIP_TRY(hipEventCreateWithFlags(&f, hipEventDisableTiming));
     for (int k = 0; k < slots; k++) {
@@ -1350,6 +1537,7 @@ extern "C" int sfx_ring_create(sfx_handle h, size_t frame_bytes, int slots, sfx_
 static int ring_wait_slot(Ring* r, int slot) {
     std::unique_lock<std::mutex> lock(r->mutex);
     r->idle.wait(lock, [&] { return r->pending[slot] == 0; });
+    if (int rc = readout_status(r->ctx)) return rc;
     return r->io_error ? fail(SFX_E_IO, "pipe write failed: %s", strerror(r->io_error)) : SFX_OK;
 }
 
@@ -1361,7 +1549,7 @@ extern "C" int sfx_ring_read_device_async(sfx_handle h, const void* dptr, int sl
     if (rc) return rc;
     HIP_TRY(hipEventRecord(r->produced, r->ctx->stream));           // the frame is complete on the render stream…
     HIP_TRY(hipStreamWaitEvent(r->copy_stream_of(slot), r->produced, 0));    // …before the copy engine reads it
-    HIP_TRY(hipMemcpyAsync(r->host[slot], dptr, r->frame_bytes, hipMemcpyDeviceToHost, r->copy_stream_of(slot)));
+    HIP_TRY(readout_copy(r->ctx, r->host[slot], dptr, r->frame_bytes, r->copy_stream_count > 1 ? (slot & 1) : 0));
     HIP_TRY(hipEventRecord(r->copied[slot], r->copy_stream_of(slot)));
     return SFX_OK;
 }
@@ -1381,7 +1569,7 @@ extern "C" int sfx_ring_read_fenced_async(sfx_handle h, const void* dptr, int sl
     int rc = ring_wait_slot(r, slot);
     if (rc) return rc;
     HIP_TRY(hipStreamWaitEvent(r->copy_stream_of(slot), r->fences[which], 0));
-    HIP_TRY(hipMemcpyAsync(r->host[slot], dptr, r->frame_bytes, hipMemcpyDeviceToHost, r->copy_stream_of(slot)));
+    HIP_TRY(readout_copy(r->ctx, r->host[slot], dptr, r->frame_bytes, r->copy_stream_count > 1 ? (slot & 1) : 0));
     HIP_TRY(hipEventRecord(r->copied[slot], r->copy_stream_of(slot)));
     return SFX_OK;
 }
@@ -1394,12 +1582,22 @@ extern "C" int sfx_ring_stream_wait(sfx_handle h, int slot) {
     return SFX_OK;
 }
 
+// fbo.read_into(buffer) is a GL command: it has read the texture before the next draw call touches it. Here the read-out runs beside
+// the render stream, so the frame is first copied — on the render stream, in order with the draws — into a device buffer of the slot,
+// and the asynchronous read-out takes it from there (the frame loop renders the next frame into the same texture right away).
 extern "C" int sfx_ring_read_async(sfx_handle h, sfx_handle tex, int slot) {
     Ring* r = get<Ring>(h, MAGIC_RING);
     Texture* t = get<Texture>(tex, MAGIC_TEX);
-    if (!r || !t) return fail(SFX_E_INVALID, "invalid ring or texture handle");
+    if (!r || !t || slot < 0 || slot >= r->slots) return fail(SFX_E_INVALID, "invalid ring or texture handle, or slot");
     if (t->nbytes != r->frame_bytes) return fail(SFX_E_INVALID, "texture holds %zu bytes, ring slots %zu", t->nbytes, r->frame_bytes);
-    return sfx_ring_read_device_async(h, t->data, slot);
+    USE_DEVICE(r->ctx);
+    int rc = ring_wait_slot(r, slot);                               // the slot's last frame has left its staging buffer too
+    if (rc) return rc;
+    if (r->staging.empty()) r->staging.assign(r->slots, nullptr);
+    if (!r->staging[slot]) HIP_TRY(hipMalloc(&r->staging[slot], r->frame_bytes));
+    HIP_TRY(hipStreamWaitEvent(r->ctx->stream, r->copied[slot], 0));    // (already complete when its write has finished; orders a read that was never piped)
+    HIP_TRY(hipMemcpyAsync(r->staging[slot], t->data, r->frame_bytes, hipMemcpyDeviceToDevice, r->ctx->stream));
+    return sfx_ring_read_device_async(h, r->staging[slot], slot);
 }
 
 extern "C" int sfx_ring_sync(sfx_handle h, int slot, void** host_ptr) {
@@ -1454,9 +1652,10 @@ extern "C" int sfx_ring_destroy(sfx_handle h) {
     hipSetDevice(r->ctx->device);
     for (int k = 0; k < r->copy_stream_count; k++) hipStreamSynchronize(r->copy_streams[k]);
     for (int k = 0; k < r->slots; k++) { hipHostFree(r->host[k]); hipEventDestroy(r->copied[k]); }
+    for (void* p : r->staging) if (p) hipFree(p);
     hipEventDestroy(r->produced);
     for (auto& f : r->fences) hipEventDestroy(f);
-    for (int k = 0; k < r->copy_stream_count; k++) hipStreamDestroy(r->copy_streams[k]);
+
     r->magic = 0;
     delete r;
     return SFX_OK;
