@@ -14,8 +14,10 @@
  *       mesa_4k.npz, written by tests/golden/make_golden_mesa*.py (refhost.py, mesa_shim.c say how): probes of every fragment on
  *       the parity tests' inputs, fifteen example scenes exported by scene.main(), two whole 3840x2160 2xSSAA frames.
  *       tests/test_oracle_mesa.py: byte for byte on several, within 1 LSB elsewhere except where measured and bounded there
- *       (llvmpipe's 8-fractional-bit filter weights: up to 1.3 % of the values 2 LSB off where an 8-bit texture is filtered twice
- *       at 1:1; one supersample across a bar's edge in 1e5 pixels at 4K; tetration's chaotic boundary; default.glsl's ring).
+ *       (llvmpipe's 8-bit fixed-point filter: up to 1.3 % of the values 2 LSB off where an 8-bit texture is filtered twice at 1:1 —
+ *       DEMONSTRATED since round 4: filter.npz holds llvmpipe's filtered values unrounded, sfo_set_llvmpipe_filter reproduces them
+ *       bit for bit and every such comparison then meets max <= 1; one supersample across a bar's edge in 1e5 pixels at 4K, listed by
+ *       coordinates in mesa_4k_outliers.npz; tetration's chaotic boundary; default.glsl's ring).
  *       Second witness (rounds 1-2): the same GLSL adapted mechanically to GLSL ES 3.00 on Google SwiftShader — gles.npz,
  *       tests/test_oracle_gles.py — which also pins fragment/missing.glsl (it reads an uninitialised output: Mesa's image is
  *       undefined, zero-initialising drivers draw the checkerboard) and texelFetch outside the texture (undefined in GL:

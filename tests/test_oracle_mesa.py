@@ -258,6 +258,123 @@ def test_audio_scenes_end_to_end():
     assert np.array_equal(G["scene.waveform.frames"], want)
 
 
+# ---- what llvmpipe's filter is, and what it explains -----------------------------------------------------------
+
+F = np.load(Path(__file__).parent/"golden"/"filter.npz")
+
+
+@pytest.mark.parametrize("tag", ["row", "grid.repeat", "grid.clamp"])
+def test_llvmpipe_filters_unorm8_textures_in_8_bit_fixed_point(tag):
+    """filter.npz: `texture(probe, astuv*S + O)` rendered by the reference on llvmpipe into a FLOAT32 target. Every filtered value is
+    k/255 — the filter's result is rounded back to 8 bits — and the oracle's llvmpipe switch (24.8 fixed-point coordinates, 8-bit
+    weights, a + ((w·(b − a) + 128) >> 8) along x then y) reproduces all of them, bit for bit; the float-weight filter of OpenGL's
+    specification does not (by at most 1 LSB: the source of every 2 LSB once a second filter or a quantisation follows)."""
+    assert float(F["filter.max_distance_from_k_over_255"]) < 1e-6           # the fixture's float32 values sit ON the 8-bit grid
+    texels = F[f"filter.{tag.split('.')[0]}.texels"]
+    width, height, sx, sy, ox, oy, repeat = F[f"filter.{tag}.args"]
+    width, height, repeat = int(width), int(height), bool(repeat)
+    texture = O.make_texture(texels, "linear", repeat, repeat)
+    want = F[f"filter.{tag}.k"]
+    one, half = np.float32(1), np.float32(0.5)
+    rows = range(height) if height <= 2 else range(0, height, 7)              # every 7th row of the grids keeps this under a second
+    model, spec = np.zeros((len(rows), width, 4), np.uint8), np.zeros((len(rows), width, 4), np.uint8)
+    for n, j in enumerate(rows):
+        t = (np.float32(j) + half)/np.float32(height)*np.float32(sy) + np.float32(oy)
+        for i in range(width):
+            s = (np.float32(i) + half)/np.float32(width)*np.float32(sx) + np.float32(ox)
+            with O.llvmpipe_filter():
+                model[n, i] = np.rint(O.sample(texture, s, t)*255)
+            spec[n, i] = np.rint(np.clip(O.sample(texture, s, t), 0, 1)*255)
+    kept = want[list(rows)]
+    assert np.array_equal(model, kept), np.argwhere(model != kept)[:4]
+    d = np.abs(spec.astype(int) - kept.astype(int))
+    assert d.max() == 1 and 0.02 < (d == 1).mean() < 0.5                       # the specification's filter: close, not equal
+
+
+LLVMPIPE_CASES = {
+    # tag: (oracle image under the switch, exact?)  — the bounds of the tests above WITHOUT the switch: max 2, up to 1.3 % at 2
+    "sampler.linear.clamp": True, "sampler.linear.repeat": True, "final.64x36.k1": True, "dynamics": True,
+    "visualizer.v0.0": False, "visualizer.v0.5": False, "visualizer.v1.2": False,
+    "final.64x36.k2": False, "final.128x72.k2": False, "final.32x18.k4": False,
+}
+
+
+def _probe_under_the_switch(tag: str) -> tuple[np.ndarray, np.ndarray]:
+    if tag.startswith("sampler"):
+        wrap = tag.split(".")[2]
+        texture = O.make_texture(G["sampler.texels"], "linear", wrap == "repeat", wrap == "repeat")
+        w, h = 70, 50
+        want = np.zeros((h, w, 4), np.uint8)
+        one, half, two = np.float32(1), np.float32(0.5), np.float32(2)
+        for j in range(h):
+            for i in range(w):
+                s = np.float32(((np.float32(i) + half)/np.float32(w)*two - one + one)/two)
+                t = np.float32(((np.float32(j) + half)/np.float32(h)*two - one + one)/two)
+                want[j, i] = np.rint(np.clip(O.sample(texture, s*np.float32(2.5) - np.float32(0.75), t*np.float32(2.5) - np.float32(0.75)), 0, 1)*255)
+        return G[f"{tag}.image"], want
+    if tag.startswith("final"):
+        size, k = tag.split(".")[1], int(tag.split(".")[2][1:])
+        fw, fh = (int(v) for v in size.split("x"))
+        return G[f"{tag}.image"][..., :3], O.resolve(G["final.screen"], fw, fh, k)
+    if tag == "dynamics":
+        u, arrays, params = visualizer_inputs(128, 72, seed=5)
+        u.user[0] = 0.35
+        return G["dynamics.image"], O.render("dynamics", u, oracle_textures(arrays, params), 128, 72)
+    volume = float(tag[len("visualizer.v"):])
+    u, arrays, params = visualizer_inputs(160, 90, seed=21, volume=volume, bg_size=(120, 68))
+    return G[f"{tag}.image"], O.render("visualizer", u, oracle_textures(arrays, params), 160, 90, threads=8)
+
+
+@pytest.mark.parametrize("tag", list(LLVMPIPE_CASES))
+def test_probes_beyond_one_lsb_are_the_filters_weights(tag):
+    """Every probe the tests above hold to `max ≤ 2`: with the oracle filtering unorm8 textures as llvmpipe does, the same comparison
+    gives max ≤ 1 — byte-identical for the sampler, the 1:1 resolve and the textured inline fragment. The cause of the 2-LSB values
+    is demonstrated, not asserted; the kernels keep the specification's float weights (the switch is the checker's)."""
+    with O.llvmpipe_filter():
+        got, want = _probe_under_the_switch(tag)
+    want = want[..., :got.shape[2]]
+    d = np.abs(got.astype(int) - want.astype(int))
+    if LLVMPIPE_CASES[tag]:
+        assert d.max() == 0, (tag, np.bincount(d.ravel())[:4])
+    else:
+        assert d.max() <= 1 and (d == 0).mean() >= 0.94, (tag, np.bincount(d.ravel())[:4])
+
+
+def test_scenes_beyond_one_lsb_are_the_filters_weights():
+    """The exported scenes held to `max ≤ 2` above (two chained bilinear fetches of 8-bit textures: BASELINE config 2's own path,
+    multipass, the dynamics demo): max ≤ 1 under the llvmpipe filter model, and 96-98 % of the values identical (60-75 % without)"""
+    street = synth.background_image(480, 270)
+    P = np.load(Path(__file__).parent/"golden"/"pipeline.npz")
+    fps, samplerate, frames = float(P["meta"][0]), int(P["meta"][1]), int(P["meta"][2])
+    pcm, background = i16_to_f32(P["pcm_i16"]), synth.background_image(240, 135, seed=7)
+    with O.llvmpipe_filter():
+        cases = {"multipass": R.multipass_scene(street, 128, 72, 1, 60.0, 3),
+                 "dynamics": R.dynamics_scene(street, 128, 72, 60.0, 90, (0, 1, 30, 59, 61, 89)),
+                 "visualizer.ssaa1": R.audio_scene("visualizer", pcm, samplerate, background, 192, 108, 1, 2, fps, 60, pick=(1, 30, 59)),
+                 "visualizer": R.audio_scene("visualizer", pcm, samplerate, background, 192, 108, 2, 2, fps, frames, pick=(0, 1, 10, 40, 99, frames - 1))}
+    for tag, want in cases.items():
+        d = np.abs(G[f"scene.{tag}.frames"].astype(int) - want.astype(int))
+        assert d.max() <= 1 and (d == 0).mean() >= 0.95, (tag, np.bincount(d.ravel())[:4])
+
+
+def test_anisotropic_extension_is_a_recorded_deviation():
+    """texture.py:280 asks for 16x anisotropy on every texture. Where the context exposes EXT_texture_filter_anisotropic, llvmpipe
+    answers with another filter for EVERY fetch of such a texture (also magnified, non-mipmapped ones); mesa.npz was rendered with the
+    extension masked = the filter OpenGL 3.3 core specifies and hardware keeps for these isotropic footprints. filter.npz holds two
+    probes with the extension ON and the measured distance — the decision as data: the oracle (and the kernels) follow the isotropic
+    image and are far from the anisotropic one."""
+    assert float(F["aniso.max"]) == 16.0
+    differ, beyond, worst = F["aniso.visualizer.v0.5.image.deviation"]
+    assert differ > 0.5 and beyond > 0.45 and worst > 200                     # 54 % of the Visualizer's values move, 49 % by more than 1 LSB
+    assert F["aniso.default.plain.image.deviation"][0] == 0                   # an untextured fragment is untouched …
+    assert F["aniso.default.plain.final.deviation"][1] > 0.05                 # … until final.glsl samples iScreen (anisotropy 16 there too)
+    u, arrays, params = visualizer_inputs(160, 90, seed=21, volume=0.5, bg_size=(120, 68))
+    screen = O.render("visualizer", u, oracle_textures(arrays, params), 160, 90, threads=8)
+    near = np.abs(G["visualizer.v0.5.image"].astype(int) - screen.astype(int))
+    far = np.abs(F["aniso.visualizer.v0.5.image"].astype(int) - screen.astype(int))
+    assert near.max() <= 1 and (far > 1).mean() > 0.45
+
+
 # ---- the benchmark's configuration: 3840x2160 at 2x SSAA ---------------------------------------------------------------------------
 
 def c3_inputs(name: str):
@@ -283,6 +400,66 @@ def edge_aware_check(got_row: np.ndarray, want_row: np.ndarray, screen_rows: np.
     allowed = np.maximum(1, (high - low)//4 + 2)
     assert (d <= allowed).all(), (where, np.argwhere(d > allowed)[:4].tolist(), int(d.max()))
     return np.bincount(np.minimum(d.ravel(), 3), minlength=4)
+
+
+def one_supersample_explains(screen: np.ndarray, r: int, x: int, reference_rgb: np.ndarray) -> bool:
+    """Does ONE of the four supersamples of output pixel (r, x) taking the colour of a supersample in its 6x6 neighbourhood — i.e. landing
+    on the other side of an edge — turn the box mean into the reference's value (within the 1 LSB everything else meets)?
+    `screen`: the oracle's supersampled rows (at least rows 2r-2 … 2r+3 present)"""
+    block = screen[2*r:2*r + 2, 2*x:2*x + 2, :3].astype(float).reshape(4, 3)
+    hood = screen[max(0, 2*r - 2):2*r + 4, max(0, 2*x - 2):2*x + 4, :3].astype(float).reshape(-1, 3)
+    for i in range(4):
+        trial = np.repeat(block[None], len(hood), axis=0)
+        trial[:, i] = hood
+        if (np.abs(np.rint(trial.mean(axis=1)) - reference_rgb.astype(float)) <= 1).all(axis=1).any():
+            return True
+    return False
+
+
+@pytest.mark.parametrize("name", ["noise", "bench"])
+def test_every_value_beyond_one_lsb_at_the_benchmark_size_is_accounted_for(name):
+    """VERDICT round 3, item 2. tests/golden/mesa_4k_outliers.npz lists, by coordinates, every value of the reference's two 4K frames
+    that the oracle misses by more than 1 LSB (30 + 76 of 2.77 M with the float-weight filter the kernels use). Here the SET is
+    recomputed on every other stored row and must be exactly the stored one; each such pixel must be explained by ONE supersample
+    sitting on the other side of an edge (a bar's outline, the waveform strip) — except the few that are llvmpipe's 8-bit filter
+    weights, which vanish when the oracle filters as llvmpipe does (rows with outliers are rendered a second time under that switch)."""
+    K, u, arrays, params, w, h, ssaa = c3_inputs(name)
+    L = np.load(Path(__file__).parent/"golden"/"mesa_4k_outliers.npz")
+    textures = oracle_textures(arrays, params)
+    rows = [(n, int(r)) for n, r in enumerate(K[f"{name}.rows"])][::2]
+    subset = {r for _, r in rows}
+
+    def stored(mode: str) -> set:
+        return {(int(r), int(x), int(c)) for r, x, c, _, _ in L[f"{name}.{mode}"] if int(r) in subset}
+
+    def found(r: int, n: int, llvmpipe: bool):
+        def go():
+            screen = O.render("visualizer", u, textures, w*ssaa, h*ssaa, rows=(max(0, r*ssaa - 2), min(h*ssaa, (r + 1)*ssaa + 2)), threads=8)
+            return screen, O.resolve(screen, w, h, 2, rows=(r, r + 1))[r]
+        if llvmpipe:
+            with O.llvmpipe_filter():
+                screen, want = go()
+        else:
+            screen, want = go()
+        got = K[f"{name}.final"][n]
+        d = np.abs(got.astype(int) - want.astype(int))
+        return screen, got, {(r, int(x), int(c)) for x, c in np.argwhere(d > 1)}
+
+    spec, fixed, unexplained = set(), set(), []
+    for n, r in rows:
+        screen, got, here = found(r, n, False)
+        spec |= here
+        if here or any(q[0] == r for q in stored("llvmpipe")):
+            screen, _, there = found(r, n, True)
+            fixed |= there
+            for x in {x for _, x, _ in there}:
+                if not one_supersample_explains(screen, r, x, got[x]):
+                    unexplained.append((r, x))
+    assert spec == stored("spec"), (sorted(spec ^ stored("spec"))[:8])
+    assert fixed == stored("llvmpipe"), (sorted(fixed ^ stored("llvmpipe"))[:8])
+    assert not unexplained, unexplained                              # what the filter model does not remove is one supersample across an edge
+    assert len(spec - fixed) <= 3                                    # … and what it does remove is 2 LSB, the filter's weights
+    assert all(d == 2 for r, x, c, d, _ in L[f"{name}.spec"] if (int(r), int(x), int(c)) in spec - fixed)
 
 
 @pytest.mark.parametrize("name", ["noise", "bench"])
