@@ -47,7 +47,7 @@ B_ALG_PER_FRAME = {  # iScreen write + resolve read + iFinal w
 }
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 256*4*32*2.4e9    # 256 CU x 4 SIMD32 x 2.4 GHz = 78.6e12 lane-instructions/s (157.3 TFLOP/s FMA)
-PROFILE = ROOT/"profiles"/"r03_bench_c3.json"      # written by tools/profile_bench.sh → tools/summarize_profile.py
+PROFILE = ROOT/"profiles"/"r04_bench_c3.json"      # written by tools/profile_bench.sh → tools/summarize_profile.py
 # The north star's CPU baseline measured with THE REFERENCE ITSELF (its own Python + numpy FFT + its GLSL on Mesa llvmpipe), in the
 # build container — it cannot travel to the GPU box (tools/measure_reference_cpu.py, profiles/r03_reference_llvmpipe.txt). Static.
 REFERENCE_LLVMPIPE = {"value": 0.477, "unit": "frames/s", "cores": 8, "kind": "reference",
@@ -148,6 +148,36 @@ def profile_counters(kernel: str) -> dict | None:
             return dict(entry, frames_per_launch=(line.get("roofline") or {}).get("frames_per_launch"))
     print(f"bench.py: {PROFILE.name} has no counters for '{kernel}' (it holds {list(record.get('kernels', {}))[:4]}…)", file=sys.stderr)
     return None
+
+
+# SIMD cycles a wave64 VALU instruction of each class occupies, as measured on this chip (tools/ubench_valu.hip,
+# profiles/r02_ubench_valu.txt: add/mul/fma f32 2.3-2.6 cycles at the nominal clock = 2 at the clock the loop sustained; conversions,
+# integer multiply-adds, shifts, min/max/perm, anything with an SGPR operand 4.1-4.4; v_rcp/v_sqrt/v_exp/v_log 8.2-8.7)
+CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2, "SQ_INSTS_VALU_MUL_F32": 2, "SQ_INSTS_VALU_FMA_F32": 2, "SQ_INSTS_VALU_INT32": 4, "SQ_INSTS_VALU_CVT": 4,
+                "SQ_INSTS_VALU_TRANS_F32": 8, "SQ_INSTS_VALU_ADD_F16": 4, "SQ_INSTS_VALU_FMA_F16": 4}
+
+
+def issue_model(cs: dict, launch_ns: float | None) -> dict | None:
+    """VALU issue cycles the profiled launch NEEDED (rocprofv3's per-class instruction counters x the measured cycles per class; the
+    instructions no class counter covers — moves, selects, compares, min/max, bit operations — priced at 2 cycles for `frac_low` and at
+    4 for `frac`) over the SIMD cycles it HAD (GRBM_GUI_ACTIVE counts every XCD: / 8 = cycles of the launch at the clock the chip
+    actually ran, x 256 CUs x 4 SIMDs). The honest roofline of this kernel: how busy its issue ports are."""
+    if not cs.get("SQ_INSTS_VALU") or not cs.get("GRBM_GUI_ACTIVE") or "SQ_INSTS_VALU_FMA_F32" not in cs:
+        return None
+    classes = {name: cs.get(name, 0.0) for name in CLASS_CYCLES}
+    counted = sum(classes.values())
+    other = max(0.0, cs["SQ_INSTS_VALU"] - counted)
+    priced = sum(classes[name]*cycles for name, cycles in CLASS_CYCLES.items())
+    cycles = cs["GRBM_GUI_ACTIVE"]/8.0
+    had = cycles*256*4
+    return {"frac": round((priced + 4*other)/had, 4), "frac_low": round((priced + 2*other)/had, 4),
+            "simd_cycles_available": had, "effective_clock_GHz": round(cycles/launch_ns, 3) if launch_ns else None,
+            "instructions": {"add_f32": classes["SQ_INSTS_VALU_ADD_F32"], "mul_f32": classes["SQ_INSTS_VALU_MUL_F32"], "fma_f32": classes["SQ_INSTS_VALU_FMA_F32"],
+                             "int32": classes["SQ_INSTS_VALU_INT32"], "cvt": classes["SQ_INSTS_VALU_CVT"], "trans_f32": classes["SQ_INSTS_VALU_TRANS_F32"],
+                             "other": other, "all": cs["SQ_INSTS_VALU"]},
+            "wave_cycles": {"active_inst_any": cs.get("SQ_ACTIVE_INST_ANY"), "wait_inst_any": cs.get("SQ_WAIT_INST_ANY"), "wait_any": cs.get("SQ_WAIT_ANY"),
+                            "all": cs.get("SQ_WAVE_CYCLES")},
+            "lane_utilisation": round(cs["SQ_THREAD_CYCLES_VALU"]/(cs["SQ_INSTS_VALU"]*64.0), 4) if cs.get("SQ_THREAD_CYCLES_VALU") else None}
 
 
 def main() -> None:
@@ -383,7 +413,7 @@ def main() -> None:
         hbm_achieved = b_alg*piece/launch_s/1e9
         samples_per_s = (w*s)*(h*s)*piece/launch_s
         counters = profile_counters(kernel) if c3 else None
-        per_sample = traffic = lds_busy = None
+        per_sample = traffic = lds_busy = issue = None
         if counters:
             cs = counters["counters"]
             if cs.get("SQ_INSTS_VALU"):                            # wave-instructions x 64 lanes over the supersamples of the profiled launch
@@ -394,6 +424,7 @@ def main() -> None:
                 traffic = (cs["FETCH_SIZE"] + cs["WRITE_SIZE"])*1024.0*piece/profiled_frames
             if cs.get("GRBM_GUI_ACTIVE") and cs.get("SQ_LDS_IDX_ACTIVE"):
                 lds_busy = cs["SQ_LDS_IDX_ACTIVE"]/(cs["GRBM_GUI_ACTIVE"]/8.0*256.0)     # LDS-array cycles / (cycles x CUs); GRBM counts per XCD
+            issue = issue_model(cs, (counters.get("duration") or {}).get("average_ns"))
         lane_ops = samples_per_s*per_sample if per_sample else None
         result = {
             "metric": "frames/sec at 4K 2xSSAA music-visualizer" if c3 else f"frames/sec {args.scene} {w}x{h} {s}xSSAA",
@@ -414,6 +445,7 @@ def main() -> None:
                          "frac": round(lane_ops/VALU_PEAK_LANE_OPS, 4) if lane_ops else None,
                          "valu_instructions_per_supersample": round(per_sample, 1) if per_sample else None,
                          "lds_busy": round(lds_busy, 3) if lds_busy else None,
+                         "issue_cycles_frac": issue["frac"] if issue else None, "issue_model": issue,
                          "traffic": traffic, "counters_from": str(PROFILE.relative_to(ROOT)) if counters else None,
                          "launch_ms": round(launch_s*1e3, 3), "frames_per_launch": piece, "launches_per_step": parts,
                          "hbm": {"achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved/HBM_PEAK_GBS, 4),

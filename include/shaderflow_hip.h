@@ -39,7 +39,8 @@ enum {
 };
 
 enum { SFX_U8 = 0, SFX_F32 = 1, SFX_U16 = 2, SFX_F16 = 3 };          /* numpy2mgltype, texture.py:28-38 */
-enum { SFX_NEAREST = 0, SFX_LINEAR = 1 };                              /* TextureFilter, texture.py:42-44 */
+enum { SFX_NEAREST = 0, SFX_LINEAR = 1,                               /* TextureFilter, texture.py:42-44 */
+       SFX_LINEAR_MIPMAP_LINEAR = 2, SFX_NEAREST_MIPMAP_NEAREST = 3 };      /* … with mipmaps=True: moderngl_filter, texture.py:131-137 */
 enum { SFX_WINDOW_HANNING = 0, SFX_WINDOW_HANN_POISSON = 1, SFX_WINDOW_NONE = 2 };   /* spectrogram.py:90-108 */
 enum { SFX_REDUCER_AVERAGE = 0, SFX_REDUCER_RMS = 1, SFX_REDUCER_STD = 2 };          /* waveform.py:14-22 */
 
@@ -98,6 +99,12 @@ int sfx_texture_params(sfx_handle tex, int filter, int repeat_x, int repeat_y);
 /* viewport (x, y, w, h) in texels, row 0 = bottom; w == h == 0 means the whole texture */
 int sfx_texture_write(sfx_handle tex, const void* data, size_t nbytes, int x, int y, int w, int h);
 int sfx_texture_read(sfx_handle tex, void* data, size_t nbytes);
+/* texture.build_mipmaps() (texture.py:277-278): levels 1… of the chain from the current level 0 (each level the LINEAR-filtered,
+ * edge-clamped half-size image of the one above: the 2x2 box mean where an extent halves exactly). A later sfx_texture_write changes
+ * level 0 only, as glTexSubImage2D does. Sampled by the filters SFX_LINEAR_MIPMAP_LINEAR / SFX_NEAREST_MIPMAP_NEAREST
+ * (sfx_texture_params), level of detail from the implicit derivatives of the coordinate (OpenGL 3.3 section 3.8.11). */
+int sfx_texture_build_mipmaps(sfx_handle tex);
+int sfx_texture_read_level(sfx_handle tex, int level, void* data, size_t nbytes);
 int sfx_texture_device_ptr(sfx_handle tex, void** ptr, size_t* nbytes);
 int sfx_texture_destroy(sfx_handle tex);
 

@@ -28,6 +28,7 @@ class Texture(C.Structure):
     _fields_ = [
         ("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("components", C.c_int32),
         ("dtype", C.c_int32), ("filter", C.c_int32), ("repeat_x", C.c_int32), ("repeat_y", C.c_int32),
+        ("levels", C.c_int32), ("mips", C.c_void_p),
     ]
 
 
@@ -100,6 +101,12 @@ def lib() -> C.CDLL:
         L.sfo_resolve.argtypes = [P(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_uint8)]
         L.sfo_sample.argtypes = [P(Texture), C.c_float, C.c_float, P(C.c_float)]
         L.sfo_set_llvmpipe_filter.argtypes = [C.c_int]
+        L.sfo_sample_quad.argtypes = [P(Texture)] + [C.c_float]*6 + [P(C.c_float)]
+        L.sfo_mip_levels.argtypes = [C.c_int, C.c_int]
+        L.sfo_mip_levels.restype = C.c_int
+        L.sfo_mip_offset.argtypes = [P(Texture), C.c_int]
+        L.sfo_mip_offset.restype = C.c_int64
+        L.sfo_build_mipmaps.argtypes = [P(Texture), C.c_void_p]
         L.sfo_test_math.argtypes = [C.c_int, C.c_float, C.c_float]
         L.sfo_test_math.restype = C.c_float
         _lib = L
@@ -221,9 +228,36 @@ def make_texture(data: np.ndarray, filter: str = "linear", repeat_x: bool = True
     if data.ndim == 2:
         data = data[:, :, None]
     t = Texture(data.ctypes.data, data.shape[1], data.shape[0], data.shape[2], DTYPES[data.dtype],
-                1 if filter == "linear" else 0, int(repeat_x), int(repeat_y))
+                1 if filter == "linear" else 0, int(repeat_x), int(repeat_y), 0, None)
     t._keep = data
     return t
+
+
+def build_mipmaps(t: Texture, source: np.ndarray | None = None) -> Texture:
+    """texture.build_mipmaps() + the mipmap minification filter (texture.py:131-137, 277-278): the chain is built from `source`
+    (default: the texture's own level 0 — pass the content level 0 had when the reference last called apply(), e.g. zeros for a
+    texture that was only ever filled by from_numpy) and attached; t.filter becomes LINEAR_MIPMAP / NEAREST_MIPMAP"""
+    levels = lib().sfo_mip_levels(t.width, t.height)
+    whole = Texture.from_buffer_copy(t)
+    whole.levels = levels
+    chain = np.zeros(max(16, lib().sfo_mip_offset(C.byref(whole), levels)), np.uint8)
+    base = whole
+    if source is not None:
+        source = np.ascontiguousarray(source)
+        base = Texture.from_buffer_copy(t)
+        base.data = source.ctypes.data
+    lib().sfo_build_mipmaps(C.byref(base), chain.ctypes.data)
+    t.levels, t.mips, t.filter = levels, chain.ctypes.data, (2 if (t.filter & 1) else 3)
+    t._chain = chain
+    return t
+
+
+def mip_level(t: Texture, level: int) -> np.ndarray:
+    """level >= 1 of a built chain as (h, w, components)"""
+    w, h = max(1, t.width >> level), max(1, t.height >> level)
+    dtype = {v: k for k, v in DTYPES.items()}[t.dtype]
+    offset = lib().sfo_mip_offset(C.byref(t), level)
+    return np.frombuffer(t._chain, dtype, count=w*h*t.components, offset=offset).reshape(h, w, t.components).copy()
 
 
 def default_uniforms(width: int, height: int, **kw) -> Uniforms:
@@ -282,6 +316,14 @@ def resolve(screen: np.ndarray, w: int, h: int, subsample: int,
     out = np.zeros((h, w, 3), np.uint8)
     y0, y1 = rows or (0, h)
     lib().sfo_resolve(_p(screen, C.c_uint8), wr, hr, w, h, subsample, y0, y1, threads, _p(out, C.c_uint8))
+    return out
+
+
+def sample_quad(tex: Texture, here, right, above) -> np.ndarray:
+    """texture() at `here` with the implicit derivatives a 2x2 quad provides: `right` / `above` are the coordinates of the pixel's
+    horizontal and vertical quad neighbours (sfo_sample_quad)"""
+    out = np.zeros(4, np.float32)
+    lib().sfo_sample_quad(C.byref(tex), here[0], here[1], right[0], right[1], above[0], above[1], _p(out, C.c_float))
     return out
 
 

@@ -113,12 +113,25 @@ void sfo_volume_std(const float* pcm, int64_t total, int channels, int64_t tell,
 /* Pixel half */
 
 enum { SFO_U8 = 0, SFO_F32 = 1, SFO_U16 = 2, SFO_F16 = 3 };
-enum { SFO_NEAREST = 0, SFO_LINEAR = 1 };
+/* SFO_*_MIPMAP: the minification filter of a texture with mipmaps=True (moderngl_filter, texture.py:131-137); magnification stays
+ * LINEAR / NEAREST (OpenGL refuses a mipmap filter there: texture.py:279 hands it the same enum, INVALID_ENUM, no effect) */
+enum { SFO_NEAREST = 0, SFO_LINEAR = 1, SFO_LINEAR_MIPMAP = 2, SFO_NEAREST_MIPMAP = 3 };
 
 typedef struct {
     const void* data;      /* row 0 = bottom row (GL order), tightly packed */
     int32_t width, height, components, dtype, filter, repeat_x, repeat_y;
+    int32_t levels;        /* 0/1: no chain. Else `mips` holds levels 1 … levels-1 (sfo_mip_offset) */
+    const void* mips;
 } sfo_texture;
+
+/* texture.build_mipmaps() (texture.py:277-278) as the OpenGL implementation behind the goldens does it — Mesa renders level k+1 as a
+ * LINEAR-filtered, edge-clamped blit of level k at the new level's pixel centres (the 2x2 box mean where an extent halves exactly;
+ * measured: tests/golden/mip.npz holds llvmpipe's levels). Float weights, unorm results rounded to nearest; under
+ * sfo_set_llvmpipe_filter the unorm8 levels come from its fixed-point filter instead (bit-identical to llvmpipe's).
+ * sfo_mip_offset(level >= 1): byte offset of that level inside `mips`; level == levels: the size of the whole chain. */
+int sfo_mip_levels(int width, int height);
+int64_t sfo_mip_offset(const sfo_texture* t, int level);
+void sfo_build_mipmaps(const sfo_texture* t, void* mips);
 
 /* Every uniform the in-scope fragments can read (scene.py:687-703, camera.py:196-201 + its nine
  * ShaderDynamics camera.py:147-185, audio/module.py:413-421, spectrogram.py:313-320, waveform.py:89-90) */
@@ -189,6 +202,10 @@ void sfo_set_llvmpipe_filter(int on);
 
 /* GL `texture()` on one coordinate, exposed for sampler unit tests */
 void sfo_sample(const sfo_texture* t, float s, float tt, float rgba[4]);
+
+/* … with the implicit derivatives of a 2x2 quad: the coordinates of the pixel's horizontal and vertical quad neighbours (mipmapped
+ * textures: level of detail per OpenGL 3.3 section 3.8.11; other filters ignore them) */
+void sfo_sample_quad(const sfo_texture* t, float s, float tt, float s_right, float t_right, float s_above, float t_above, float rgba[4]);
 
 /* sfmath entry points for the accuracy / cross-implementation tests */
 float sfo_test_math(int fn, float a, float b);

@@ -120,7 +120,125 @@ static v4 sample_llvmpipe_u8(const sfo_texture* t, v2 uv) {
     return c;
 }
 
+/* ---- mipmapped sampling: OpenGL 3.3 core section 3.8.11 (texture.py:131-137, 277-278) ----------------------------------------------
+ * The level of detail needs the derivatives of the coordinate across the pixel's 2x2 quad. The fragments here are plain functions of
+ * one pixel, so render_rows shades a pixel of a frame with a mipmapped texture THREE times: its horizontal and its vertical quad
+ * neighbour first, RECORDING the texel-space coordinate of every mipmapped texture() call in order, then the pixel itself, where call
+ * number k finds its neighbours' coordinates of call number k (uniform control flow across a quad is GLSL's own condition for
+ * implicit derivatives). rho = the longer footprint axis in level-0 texels, lambda = log2(rho), clamped to the chain; lambda <= 0:
+ * the magnification filter on level 0; LINEAR_MIPMAP_LINEAR: levels floor(lambda), +1 blended by frac(lambda);
+ * NEAREST_MIPMAP_NEAREST: nearest texel of level ceil(lambda + 0.5) - 1.
+ * Under the llvmpipe switch: lambda = log2(rho^2)/2 with log2 taken as exponent + (mantissa - 1), the blend weight trunc(frac*256) and
+ * a + ((w*(b - a) + 128) >> 8) on the two levels' 8-bit results (unorm8; measured like the filter itself, tests/golden/mip.npz). */
+static inline uint8_t to_unorm8(float c);
+enum { LOD_OFF = 0, LOD_RECORD_X = 1, LOD_RECORD_Y = 2, LOD_REPLAY = 3, LOD_CALLS = 256 };
+static __thread struct { int mode, count; float ux[LOD_CALLS], vx[LOD_CALLS], uy[LOD_CALLS], vy[LOD_CALLS]; } g_lod;
+
+int sfo_mip_levels(int width, int height) {
+    int levels = 1;
+    while (width > 1 || height > 1) { width = width > 1 ? width >> 1 : 1; height = height > 1 ? height >> 1 : 1; levels++; }
+    return levels;
+}
+static inline int64_t texel_size(const sfo_texture* t) { return (int64_t)t->components*(t->dtype == SFO_U8 ? 1 : (t->dtype == SFO_F32 ? 4 : 2)); }
+int64_t sfo_mip_offset(const sfo_texture* t, int level) {
+    int64_t offset = 0;
+    int w = t->width, h = t->height;
+    for (int l = 1; l < level; l++) { w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1; offset += (w*(int64_t)h*texel_size(t) + 15) & ~(int64_t)15; }
+    return offset;
+}
+static sfo_texture mip_level(const sfo_texture* t, int k) {
+    sfo_texture v = *t;
+    v.levels = 0; v.mips = NULL;
+    if (k <= 0 || t->levels <= 1 || !t->mips) return v;
+    if (k > t->levels - 1) k = t->levels - 1;
+    for (int l = 0; l < k; l++) { v.width = v.width > 1 ? v.width >> 1 : 1; v.height = v.height > 1 ? v.height >> 1 : 1; }
+    v.data = (const char*)t->mips + sfo_mip_offset(t, k);
+    return v;
+}
+static v4 sample(const sfo_texture* t, v2 uv);
+void sfo_build_mipmaps(const sfo_texture* t, void* mips) {
+    sfo_texture whole = *t;
+    whole.levels = sfo_mip_levels(t->width, t->height); whole.mips = mips;
+    for (int l = 1; l < whole.levels; l++) {
+        sfo_texture above = mip_level(&whole, l - 1), here = mip_level(&whole, l);
+        above.filter = SFO_LINEAR; above.repeat_x = 0; above.repeat_y = 0;
+        for (int j = 0; j < here.height; j++) {
+            for (int i = 0; i < here.width; i++) {
+                v4 c;
+                if (g_llvmpipe_filter && t->dtype == SFO_U8) {        /* the blit's own coordinates: normalised, as a varying */
+                    c = sample(&above, V2(((float)i + 0.5f)/(float)here.width, ((float)j + 0.5f)/(float)here.height));
+                } else {                                              /* exact texel coordinates: an exact halving weighs 1/2, 1/2 */
+                    const double ub = ((double)i + 0.5)*(double)above.width/(double)here.width - 0.5, vb = ((double)j + 0.5)*(double)above.height/(double)here.height - 0.5;
+                    const double fu = floor(ub), fv = floor(vb);
+                    const float ax = (float)(ub - fu), ay = (float)(vb - fv);
+                    const int i0 = wrap_index((int)fu, above.width, 0), i1 = wrap_index((int)fu + 1, above.width, 0);
+                    const int j0 = wrap_index((int)fv, above.height, 0), j1 = wrap_index((int)fv + 1, above.height, 0);
+                    const v4 t00 = fetch_texel(&above, i0, j0), t10 = fetch_texel(&above, i1, j0), t01 = fetch_texel(&above, i0, j1), t11 = fetch_texel(&above, i1, j1);
+                    const float nx = 1.0f - ax, ny = 1.0f - ay, w00 = nx*ny, w10 = ax*ny, w01 = nx*ay, w11 = ax*ay;
+                    c.x = fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00*t00.x)));
+                    c.y = fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00*t00.y)));
+                    c.z = fmaf(w11, t11.z, fmaf(w01, t01.z, fmaf(w10, t10.z, w00*t00.z)));
+                    c.w = fmaf(w11, t11.w, fmaf(w01, t01.w, fmaf(w10, t10.w, w00*t00.w)));
+                }
+                const float channel[4] = {c.x, c.y, c.z, c.w};
+                const int64_t at = ((int64_t)j*here.width + i)*t->components;
+                for (int k = 0; k < t->components; k++) {
+                    if (t->dtype == SFO_U8) ((uint8_t*)here.data)[at + k] = to_unorm8(channel[k]);
+                    else if (t->dtype == SFO_F32) ((float*)here.data)[at + k] = channel[k];
+                    else if (t->dtype == SFO_F16) ((uint16_t*)here.data)[at + k] = float_to_half(channel[k]);
+                    else { float q = channel[k] > 0.0f ? channel[k] : 0.0f; q = q < 1.0f ? q : 1.0f; ((uint16_t*)here.data)[at + k] = (uint16_t)rintf(q*65535.0f); }
+                }
+            }
+        }
+    }
+}
+
+static v4 sample_level(const sfo_texture* t, v2 uv, int level, int filter) {
+    sfo_texture v = mip_level(t, level);
+    v.filter = filter;
+    return sample(&v, uv);
+}
+static v4 sample_mipmapped(const sfo_texture* t, v2 uv) {
+    const int linear = (t->filter == SFO_LINEAR_MIPMAP), magnify = linear ? SFO_LINEAR : SFO_NEAREST;
+    const float u = uv.x*(float)t->width, v = uv.y*(float)t->height;
+    const int k = g_lod.count++;
+    if (g_lod.mode == LOD_RECORD_X) { if (k < LOD_CALLS) { g_lod.ux[k] = u; g_lod.vx[k] = v; } return sample_level(t, uv, 0, magnify); }
+    if (g_lod.mode == LOD_RECORD_Y) { if (k < LOD_CALLS) { g_lod.uy[k] = u; g_lod.vy[k] = v; } return sample_level(t, uv, 0, magnify); }
+    if (g_lod.mode != LOD_REPLAY || k >= LOD_CALLS || t->levels <= 1) return sample_level(t, uv, 0, magnify);
+    const float dudx = u - g_lod.ux[k], dvdx = v - g_lod.vx[k], dudy = u - g_lod.uy[k], dvdy = v - g_lod.vy[k];
+    const float along_x = dudx*dudx + dvdx*dvdx, along_y = dudy*dudy + dvdy*dvdy;
+    const float rho2 = along_x > along_y ? along_x : along_y;
+    float lambda;
+    if (g_llvmpipe_filter) {
+        int exponent = 0;
+        const float mantissa = frexpf(rho2, &exponent)*2.0f;         /* rho2 = mantissa * 2^(exponent-1), mantissa in [1, 2) */
+        lambda = rho2 > 0.0f ? 0.5f*((float)(exponent - 1) + (mantissa - 1.0f)) : -INFINITY;
+    } else {
+        lambda = 0.5f*sfo_log2(rho2);
+    }
+    const float top = (float)(t->levels - 1);
+    if (lambda > top) lambda = top;
+    if (!(lambda > 0.0f)) return sample_level(t, uv, 0, magnify);
+    if (!linear) return sample_level(t, uv, (int)ceilf(lambda + 0.5f) - 1, SFO_NEAREST);
+    const float below = floorf(lambda), f = lambda - below;
+    const int d1 = (int)below, d2 = d1 + 1 < t->levels ? d1 + 1 : t->levels - 1;
+    const v4 a = sample_level(t, uv, d1, SFO_LINEAR);
+    if (d2 == d1 || f == 0.0f) return a;
+    const v4 b = sample_level(t, uv, d2, SFO_LINEAR);
+    v4 r;
+    if (g_llvmpipe_filter && t->dtype == SFO_U8) {
+        const int w = (int)(f*256.0f);
+        const float* pa = &a.x; const float* pb = &b.x; float* pr = &r.x;
+        for (int c = 0; c < 4; c++) pr[c] = (float)fixed_lerp(w, (int)lrintf(pa[c]*255.0f), (int)lrintf(pb[c]*255.0f))/255.0f;
+        if (t->components < 4) r.w = 1.0f;
+        return r;
+    }
+    r.x = fmaf(f, b.x - a.x, a.x); r.y = fmaf(f, b.y - a.y, a.y); r.z = fmaf(f, b.z - a.z, a.z); r.w = fmaf(f, b.w - a.w, a.w);
+    return r;
+}
+
 static v4 sample(const sfo_texture* t, v2 uv) {
+    if (t->filter >= SFO_LINEAR_MIPMAP) return sample_mipmapped(t, uv);
     float u = uv.x*(float)t->width;
     float v = uv.y*(float)t->height;
     if (t->filter == SFO_NEAREST) {
@@ -144,6 +262,15 @@ static v4 sample(const sfo_texture* t, v2 uv) {
     r.z = fmaf(w11, t11.z, fmaf(w01, t01.z, fmaf(w10, t10.z, w00*t00.z)));
     r.w = fmaf(w11, t11.w, fmaf(w01, t01.w, fmaf(w10, t10.w, w00*t00.w)));
     return r;
+}
+
+void sfo_sample_quad(const sfo_texture* t, float s, float tt, float s_right, float t_right, float s_above, float t_above, float rgba[4]) {
+    g_lod.mode = LOD_REPLAY; g_lod.count = 0;
+    g_lod.ux[0] = s_right*(float)t->width; g_lod.vx[0] = t_right*(float)t->height;
+    g_lod.uy[0] = s_above*(float)t->width; g_lod.vy[0] = t_above*(float)t->height;
+    v4 c = sample(t, V2(s, tt));
+    g_lod.mode = LOD_OFF;
+    rgba[0] = c.x; rgba[1] = c.y; rgba[2] = c.z; rgba[3] = c.w;
 }
 
 void sfo_sample(const sfo_texture* t, float s, float tt, float rgba[4]) {
@@ -743,10 +870,22 @@ typedef struct {
 
 static void render_rows(const job_t* jb) {
     frag_in f; f.u = jb->u; f.tex = jb->tex;
+    int mipmapped = 0;
+    for (int k = 0; k < SFO_TEX_SLOTS; k++) mipmapped |= (jb->tex[k].data && jb->tex[k].filter >= SFO_LINEAR_MIPMAP && jb->tex[k].levels > 1);
     for (int j = jb->y0; j < jb->y1; j++) {
         for (int i = 0; i < jb->wr; i++) {
+            if (mipmapped) {                                            /* the quad's other column and other row first (see sample_mipmapped) */
+                g_lod.mode = LOD_RECORD_X; g_lod.count = 0;
+                make_varyings(&f, i ^ 1, j, jb->wr, jb->hr);
+                (void)shade(jb->fragment, &f);
+                g_lod.mode = LOD_RECORD_Y; g_lod.count = 0;
+                make_varyings(&f, i, j ^ 1, jb->wr, jb->hr);
+                (void)shade(jb->fragment, &f);
+                g_lod.mode = LOD_REPLAY; g_lod.count = 0;
+            }
             make_varyings(&f, i, j, jb->wr, jb->hr);
             v4 c = shade(jb->fragment, &f);
+            g_lod.mode = LOD_OFF;
             const float channel[4] = {c.x, c.y, c.z, c.w};
             const int n = jb->out_components;
             for (int k = 0; k < n; k++) {

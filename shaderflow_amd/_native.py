@@ -83,6 +83,8 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_texture_params": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int]),
     "sfx_texture_write": (C.c_int, [Handle, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sfx_texture_read": (C.c_int, [Handle, C.c_void_p, C.c_size_t]),
+    "sfx_texture_build_mipmaps": (C.c_int, [Handle]),
+    "sfx_texture_read_level": (C.c_int, [Handle, C.c_int, C.c_void_p, C.c_size_t]),
     "sfx_texture_device_ptr": (C.c_int, [Handle, P(C.c_void_p), P(C.c_size_t)]),
     "sfx_texture_destroy": (C.c_int, [Handle]),
     "sfx_program_lookup": (C.c_int, [Handle, C.c_char_p, P(Handle), P(C.c_int)]),

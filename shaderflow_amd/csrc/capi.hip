@@ -90,6 +90,7 @@ struct Texture : Object {
     int width, height, components, dtype, filter = SFX_LINEAR, repeat_x = 1, repeat_y = 1;
     void* data = nullptr;
     size_t nbytes = 0;
+    void* mips = nullptr; int levels = 1;      // levels 1… of the chain, built by sfx_texture_build_mipmaps (glsl.hpp mip_level says where each one starts)
 };
 
 static size_t dtype_size(int dtype) { return dtype == SFX_U8 ? 1 : (dtype == SFX_F32 ? 4 : 2); }
@@ -97,7 +98,7 @@ static size_t dtype_size(int dtype) { return dtype == SFX_U8 ? 1 : (dtype == SFX
 static Tex tex_view(const Texture* t) {
     Tex v{};
     if (t) { v.data = t->data; v.width = t->width; v.height = t->height; v.components = t->components;
-             v.dtype = t->dtype; v.filter = t->filter; v.repeat_x = t->repeat_x; v.repeat_y = t->repeat_y; }
+             v.dtype = t->dtype; v.filter = t->filter; v.repeat_x = t->repeat_x; v.repeat_y = t->repeat_y; v.mips = t->mips; v.levels = t->levels; }
     return v;
 }
 
@@ -500,7 +501,75 @@ extern "C" int sfx_texture_create(sfx_handle h, int width, int height, int compo
 extern "C" int sfx_texture_params(sfx_handle h, int filter, int repeat_x, int repeat_y) {
     Texture* t = get<Texture>(h, MAGIC_TEX);
     if (!t) return fail(SFX_E_INVALID, "invalid texture handle");
-    t->filter = filter ? SFX_LINEAR : SFX_NEAREST; t->repeat_x = !!repeat_x; t->repeat_y = !!repeat_y;
+    if (filter < SFX_NEAREST || filter > SFX_NEAREST_MIPMAP_NEAREST) return fail(SFX_E_INVALID, "texture filter %d", filter);
+    t->filter = filter; t->repeat_x = !!repeat_x; t->repeat_y = !!repeat_y;
+    return SFX_OK;
+}
+
+static int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SFX_OK : fail(SFX_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+}
+
+// One level of the chain from the one above it — what glGenerateMipmap does on the implementation the goldens come from (Mesa renders
+// every level as a LINEAR-filtered, edge-clamped blit of the previous one: tests/golden/mip.npz holds its levels): texel (i, j) of the
+// w x h level samples the W x H level at ((i + ½)·W/w, (j + ½)·H/h) — the 2 x 2 box mean where an extent halves exactly, two-texel
+// taps that skip texels where an odd extent is floored. unorm formats round the float result to nearest.
+__global__ void k_mip_level(Tex src, void* dst, int w, int h) {
+    const int i = blockIdx.x*64 + threadIdx.x, j = blockIdx.y*4 + threadIdx.y;
+    if (i >= w || j >= h) return;
+    // the tap's texel coordinates, exact (an exact halving gives weights of exactly ½: the box mean); edge-clamped
+    const double ub = ((double)i + 0.5)*(double)src.width/(double)w - 0.5, vb = ((double)j + 0.5)*(double)src.height/(double)h - 0.5;
+    const double fu = ::floor(ub), fv = ::floor(vb);
+    const float ax = (float)(ub - fu), ay = (float)(vb - fv);
+    const int i0 = wrap_texel((int)fu, src.width, 0), i1 = wrap_texel((int)fu + 1, src.width, 0);
+    const int j0 = wrap_texel((int)fv, src.height, 0), j1 = wrap_texel((int)fv + 1, src.height, 0);
+    const vec4 t00 = texel(src, i0, j0), t10 = texel(src, i1, j0), t01 = texel(src, i0, j1), t11 = texel(src, i1, j1);
+    const float nx = 1.0f - ax, ny = 1.0f - ay, w00 = nx*ny, w10 = ax*ny, w01 = nx*ay, w11 = ax*ay;
+    const float v[4] = {bilerp(w00, w10, w01, w11, t00.x, t10.x, t01.x, t11.x), bilerp(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y),
+                        bilerp(w00, w10, w01, w11, t00.z, t10.z, t01.z, t11.z), bilerp(w00, w10, w01, w11, t00.w, t10.w, t01.w, t11.w)};
+    const size_t at = ((size_t)j*w + i)*src.components;
+    for (int k = 0; k < src.components; k++) {
+        if (src.dtype == DT_U8) ((uint8_t*)dst)[at + k] = (uint8_t)unorm8(v[k]);
+        else if (src.dtype == DT_F32) ((float*)dst)[at + k] = v[k];
+        else if (src.dtype == DT_F16) ((_Float16*)dst)[at + k] = (_Float16)v[k];
+        else { float q = v[k] > 0.0f ? v[k] : 0.0f; q = q < 1.0f ? q : 1.0f; ((uint16_t*)dst)[at + k] = (uint16_t)::rintf(q*65535.0f); }
+    }
+}
+
+// box.texture.build_mipmaps() of texture.py:277-278: (re)builds levels 1… from the CURRENT level 0. As in OpenGL, and as the
+// reference uses it, a later sfx_texture_write changes level 0 only — the chain is as old as the last call of this function.
+extern "C" int sfx_texture_build_mipmaps(sfx_handle h) {
+    Texture* t = get<Texture>(h, MAGIC_TEX);
+    if (!t) return fail(SFX_E_INVALID, "invalid texture handle");
+    USE_DEVICE(t->ctx);
+    int levels = 1;
+    for (int w = t->width, hh = t->height; w > 1 || hh > 1; levels++) { w = w > 1 ? w >> 1 : 1; hh = hh > 1 ? hh >> 1 : 1; }
+    if (levels == 1) return SFX_OK;                                   // a 1 x 1 texture is its own chain
+    if (!t->mips) {
+        Tex whole = tex_view(t); whole.levels = levels;
+        size_t bytes = 0;
+        for (int w = t->width, hh = t->height, l = 1; l < levels; l++) { w = w > 1 ? w >> 1 : 1; hh = hh > 1 ? hh >> 1 : 1; bytes += (((size_t)w*hh*texel_bytes(whole)) + 15) & ~(size_t)15; }
+        HIP_TRY(hipMalloc(&t->mips, bytes + 16));
+    }
+    t->levels = levels;
+    const Tex whole = tex_view(t);
+    for (int l = 1; l < levels; l++) {
+        const Tex above = mip_level(whole, l - 1), here = mip_level(whole, l);
+        hipLaunchKernelGGL(k_mip_level, dim3((here.width + 63)/64, (here.height + 3)/4), dim3(64, 4), 0, t->ctx->stream, above, (void*)here.data, here.width, here.height);
+    }
+    return launch_status();
+}
+
+// level `level` of the chain (0: the texture) into `data`: max(1, width >> level) x max(1, height >> level) texels, rows bottom-up
+extern "C" int sfx_texture_read_level(sfx_handle h, int level, void* data, size_t nbytes) {
+    Texture* t = get<Texture>(h, MAGIC_TEX);
+    if (!t || !data || level < 0 || level >= t->levels) return fail(SFX_E_INVALID, "invalid texture handle, data or level %d of %d", level, t ? t->levels : 0);
+    const Tex v = mip_level(tex_view(t), level);
+    if (nbytes != (size_t)v.width*v.height*texel_bytes(v)) return fail(SFX_E_INVALID, "level %d holds %zu bytes, asked for %zu", level, (size_t)v.width*v.height*texel_bytes(v), nbytes);
+    USE_DEVICE(t->ctx);
+    HIP_TRY(hipMemcpyAsync(data, v.data, nbytes, hipMemcpyDeviceToHost, t->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(t->ctx->stream));
     return SFX_OK;
 }
 
@@ -542,7 +611,7 @@ extern "C" int sfx_texture_destroy(sfx_handle h) {
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
     forget_texture(t);                                              // no program keeps a pointer to it
-    hipFree(t->data);
+    hipFree(t->data); hipFree(t->mips);
     t->magic = 0;
     delete t;
     return SFX_OK;
@@ -688,7 +757,12 @@ extern "C" int sfx_program_load(sfx_handle h, const void* code_object, size_t nb
 
 // A fragment that takes derivatives needs its 2x2 neighbours in the lanes of a DPP quad. The fused kernel has that layout for
 // ssaa == 2 only (the four supersamples of a pixel are the four lanes of a quad, x in bit 0, y in bit 1).
-static bool fusable(const Program* p, int ssaa) { return !(p->flags & 1u) || ssaa == 2; }
+// A mipmapped sampler takes them implicitly (glsl.hpp texture_mipmapped): same rule.
+static bool samples_mipmaps(const Program* p) {
+    for (int k = 0; k < TEX_SLOTS; k++) if (p->samplers[k] && p->samplers[k]->filter >= SFX_LINEAR_MIPMAP_LINEAR) return true;
+    return false;
+}
+static bool fusable(const Program* p, int ssaa) { return !((p->flags & 1u) || samples_mipmaps(p)) || ssaa == 2; }
 // rows a lane walks in the code object's sfx_jit_render / sfx_jit_fused_1 (shader_rows_1x of its shader policy; older flags words say 0)
 static int jit_rows_1x(const Program* p) { const int rows = (int)((p->flags >> 8) & 255u); return rows > 0 ? rows : 1; }
 extern "C" int sfx_program_fusable(sfx_handle h, int ssaa) {
@@ -794,6 +868,7 @@ static void fill_args(const Program* p, RenderArgs& a) {
     a.axis_camera = camera_is_axis_aligned(p->u) ? 1 : 0;
     a.bg_scale_x = a.tex[TEX_BACKGROUND].data ? (float)a.tex[TEX_BACKGROUND].height/(float)a.tex[TEX_BACKGROUND].width : 1.0f;
     a.top_down = p->ctx->top_down;
+    a.quads = samples_mipmaps(p) ? 1 : 0;                           // the unfused kernel lays its lanes out as 2 x 2 quads: implicit derivatives
 }
 
 // RN(1/n) if glsl.hpp pixel_centre(i, n, RN(1/n)) equals the IEEE quotient (i + 0.5)/n for every pixel index of an n-pixel axis,
@@ -1350,11 +1425,6 @@ static int launch_fused_p(const Program* p, const RenderArgs& a, int ssaa, int f
     constexpr int rows = P::FUSED_ROWS*P::THREAD_ROWS, threads = 4*P::BLOCK_PX*P::THREAD_ROWS;
     const int blocks_x = (a.w + P::BLOCK_PX - 1)/P::BLOCK_PX, row_blocks = (a.h + rows - 1)/rows;
     return launch_jit(p->fn_fused[ssaa == 2 ? 1 : 2], a, dim3(blocks_x*row_blocks, 1, frames), dim3(threads), s);
-}
-
-static int launch_status() {
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? SFX_OK : fail(SFX_E_HIP, "kernel launch: %s", hipGetErrorString(e));
 }
 
 extern "C" int sfx_render(sfx_handle h, sfx_handle target, int layer) {

@@ -47,12 +47,32 @@ SF_HD void set_rgb(vec4& c, vec3 v) { c.x = v.x; c.y = v.y; c.z = v.z; }
 // ---- textures ----------------------------------------------------------------------------------
 
 enum : int { DT_U8 = 0, DT_F32 = 1, DT_U16 = 2, DT_F16 = 3 };
-enum : int { FILTER_NEAREST = 0, FILTER_LINEAR = 1 };
+// FILTER_LINEAR_MIPMAP / FILTER_NEAREST_MIPMAP: texture.py:131-137 — moderngl.LINEAR_MIPMAP_LINEAR / NEAREST_MIPMAP_NEAREST as the
+// minification filter once `mipmaps=True` has built the chain (texture.py:277-278); the magnification filter stays LINEAR / NEAREST
+enum : int { FILTER_NEAREST = 0, FILTER_LINEAR = 1, FILTER_LINEAR_MIPMAP = 2, FILTER_NEAREST_MIPMAP = 3 };
 
 struct Tex {                       // one TextureBox of texture.py:56-70, rows bottom-up, tightly packed
     const void* data;
     int width, height, components, dtype, filter, repeat_x, repeat_y;
+    const void* mips;              // levels 1 … levels-1, tightly packed one after the other (level k: max(1, width >> k) x max(1, height >> k))
+    int levels;                    // 0 or 1: no chain (the mipmap filters then read level 0 only)
 };
+
+SF_HD size_t texel_bytes(const Tex& t) { return (size_t)t.components*(t.dtype == DT_U8 ? 1 : (t.dtype == DT_F32 ? 4 : 2)); }
+// level k of a chain as a texture of its own (k = 0: the texture itself)
+SF_HD Tex mip_level(const Tex& t, int k) {
+    Tex v = t;
+    if (k <= 0 || t.levels <= 1 || !t.mips) return v;
+    if (k > t.levels - 1) k = t.levels - 1;
+    size_t offset = 0;
+    int w = t.width, h = t.height;
+    for (int l = 1; l <= k; l++) {
+        w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1;
+        if (l < k) offset += (((size_t)w*h*texel_bytes(t)) + 15) & ~(size_t)15;     // every level starts 16-byte aligned (+ the RGB8 over-read)
+    }
+    v.data = (const char*)t.mips + offset; v.width = w; v.height = h;
+    return v;
+}
 
 SF_HD int wrap_texel(int i, int size, int repeat) {
     if ((unsigned)i < (unsigned)size) return i;    // inside the texture: no integer division
@@ -120,7 +140,9 @@ SF_HD float bilerp(float w00, float w10, float w01, float w11, float t00, float 
     return fmaf(w11, t11, fmaf(w01, t01, fmaf(w10, t10, w00*t00)));
 }
 
-SF_HD vec4 texture(const Tex& t, vec2 uv) {       // GLSL texture(sampler2D, vec2), level 0
+SF_HD vec4 texture_mipmapped(const Tex& t, vec2 uv);
+SF_HD vec4 texture(const Tex& t, vec2 uv) {       // GLSL texture(sampler2D, vec2)
+    if (t.filter >= FILTER_LINEAR_MIPMAP) return texture_mipmapped(t, uv);
     float u = uv.x*(float)t.width;
     float v = uv.y*(float)t.height;
     if (t.filter == FILTER_NEAREST) {
@@ -142,6 +164,57 @@ SF_HD vec4 texture(const Tex& t, vec2 uv) {       // GLSL texture(sampler2D, vec
             bilerp(w00, w10, w01, w11, t00.w, t10.w, t01.w, t11.w)};
 }
 
+// ---- mipmapped sampling (OpenGL 3.3 core section 3.8.11; texture.py:131-137, 277-278) ----------------------------------------------
+// Level of detail from the implicit derivatives of the coordinate: the kernels that may meet such a texture lay their lanes out as
+// 2 x 2 quads (render_kernels.hpp: lane bit 0 = x, bit 1 = y inside the quad), and the derivative is the difference across the
+// quad's row / column — the "fine" form, as dFdx/dFdy of translated fragments. rho is the longer of the two footprint axes in texels
+// of level 0 (equation 3.21's ideal scale factor), lambda = log2(rho), no bias (the reference sets none), clamped to the chain.
+// lambda <= 0 magnifies: the plain LINEAR / NEAREST filter on level 0. LINEAR_MIPMAP_LINEAR blends the bilinear samples of levels
+// floor(lambda) and floor(lambda)+1 by frac(lambda); NEAREST_MIPMAP_NEAREST takes the nearest texel of level ceil(lambda + 0.5) - 1.
+// What an implementation may approximate here it does (llvmpipe: log2 by mantissa, 8-bit blend — the oracle's llvmpipe switch has its
+// arithmetic, tests/golden/mip.npz its frames); these are the specification's own formulas in binary32.
+SF_HD float quad_dx(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0xF5, 0xf, 0xf, true)) - __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0xA0, 0xf, 0xf, true));
+#else
+    (void)v; return 0.0f;                                            // host builds (tests of translated fragments) read level 0
+#endif
+}
+SF_HD float quad_dy(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0xEE, 0xf, 0xf, true)) - __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0x44, 0xf, 0xf, true));
+#else
+    (void)v; return 0.0f;
+#endif
+}
+SF_HD vec4 texture_level(const Tex& t, vec2 uv, int level, int filter) {
+    Tex v = mip_level(t, level);
+    v.filter = filter;
+    return texture(v, uv);
+}
+SF_HD float mip_lambda(const Tex& t, float dudx, float dvdx, float dudy, float dvdy) {
+    const float along_x = dudx*dudx + dvdx*dvdx, along_y = dudy*dudy + dvdy*dvdy;
+    const float rho2 = along_x > along_y ? along_x : along_y;
+    const float lambda = 0.5f*sf::log2(rho2);                        // log2(rho); rho2 = 0 (a constant coordinate) gives -inf: magnification
+    const float top = (float)((t.levels > 1 ? t.levels : 1) - 1);
+    return lambda > top ? top : lambda;
+}
+SF_HD vec4 texture_mipmapped(const Tex& t, vec2 uv) {
+    const float u = uv.x*(float)t.width, v = uv.y*(float)t.height;
+    const float lambda = mip_lambda(t, quad_dx(u), quad_dx(v), quad_dy(u), quad_dy(v));
+    const bool linear = (t.filter == FILTER_LINEAR_MIPMAP);
+    if (!(lambda > 0.0f) || t.levels <= 1) return texture_level(t, uv, 0, linear ? FILTER_LINEAR : FILTER_NEAREST);
+    if (!linear) return texture_level(t, uv, (int)::ceilf(lambda + 0.5f) - 1, FILTER_NEAREST);
+    const float below = ::floorf(lambda), f = lambda - below;
+    const int d1 = (int)below, d2 = d1 + 1 < t.levels ? d1 + 1 : t.levels - 1;
+    const vec4 a = texture_level(t, uv, d1, FILTER_LINEAR);
+    if (d2 == d1 || f == 0.0f) return a;
+    const vec4 b = texture_level(t, uv, d2, FILTER_LINEAR);
+    return {fmaf(f, b.x - a.x, a.x), fmaf(f, b.y - a.y, a.y), fmaf(f, b.z - a.z, a.z), fmaf(f, b.w - a.w, a.w)};
+}
+
 // texture(t, uv).xy for fragments that read two components only: the same operations as texture() on .x and .y
 // (so the same bits), without blending the two components the caller drops
 SF_HD vec2 texel_xy(const Tex& t, int i, int j) {
@@ -149,6 +222,7 @@ SF_HD vec2 texel_xy(const Tex& t, int i, int j) {
     return {c.x, c.y};
 }
 SF_HD vec2 texture_xy(const Tex& t, vec2 uv) {
+    if (t.filter >= FILTER_LINEAR_MIPMAP) { const vec4 c = texture_mipmapped(t, uv); return {c.x, c.y}; }
     float u = uv.x*(float)t.width;
     float v = uv.y*(float)t.height;
     if (t.filter == FILTER_NEAREST) {

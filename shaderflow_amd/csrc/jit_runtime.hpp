@@ -514,6 +514,7 @@ SF_HD sf::vec3 lo(const vec3& c) { return {c.x, c.y, c.z}; }
 // an unbound sampler reads as opaque black texels, like an incomplete GL texture
 SF_HD int tile_bound(float texel) { return (int)sf::min(sf::max(texel, -16777216.0f), 16777216.0f); }
 SF_HD sf::vec4 tiled_texture(const Tex& t, const TileView& v, sf::vec2 uv) {      // sf::texture (glsl.hpp) with the texel fetch swapped
+    if (t.filter >= FILTER_LINEAR_MIPMAP) return sf::texture(t, uv);       // mipmapped: the tile holds level 0 only
     const float u = uv.x*(float)t.width, w = uv.y*(float)t.height;
     const bool nearest = t.filter == FILTER_NEAREST;
     const float ub = nearest ? u : u - 0.5f, vb = nearest ? w : w - 0.5f;

@@ -46,6 +46,7 @@ struct RenderArgs {
     int tile_pitch, tile_rows;       // geometry of the LDS tile when it is a launch parameter (VisualizerShader<0, …>)
     int top_down;                    // K9: write the RGB8 frame rows top-down (the encoder's `vflip`, exporting.py:103, done here)
     float inv_wr, inv_hr;            // RN(1/wr), RN(1/hr) when the host verified glsl.hpp pixel_centre() for them, else 0
+    int quads;                       // a bound sampler is mipmapped: k_render covers 32 x 2 pixels per wave as 2 x 2 quads (64 x 4 blocks), helper lanes shaded
 #ifdef SF_SECTION_TIMERS
     unsigned long long* timers;      // profiling builds (tools/variants.sh): per-section shader-clock sums, see SF_TICK
 #endif
@@ -64,7 +65,7 @@ constexpr unsigned long long render_args_layout() {
     SF_LAYOUT_MEMBER(tape_bars); SF_LAYOUT_MEMBER(tape_waveform); SF_LAYOUT_MEMBER(waveform_stride); SF_LAYOUT_MEMBER(frame0);
     SF_LAYOUT_MEMBER(tap_x); SF_LAYOUT_MEMBER(tap_y); SF_LAYOUT_MEMBER(vis_consts); SF_LAYOUT_MEMBER(vis); SF_LAYOUT_MEMBER(has_vis);
     SF_LAYOUT_MEMBER(identity_camera); SF_LAYOUT_MEMBER(axis_camera); SF_LAYOUT_MEMBER(aspect); SF_LAYOUT_MEMBER(bg_scale_x); SF_LAYOUT_MEMBER(tile_pitch);
-    SF_LAYOUT_MEMBER(tile_rows); SF_LAYOUT_MEMBER(top_down); SF_LAYOUT_MEMBER(inv_wr); SF_LAYOUT_MEMBER(inv_hr);
+    SF_LAYOUT_MEMBER(tile_rows); SF_LAYOUT_MEMBER(top_down); SF_LAYOUT_MEMBER(inv_wr); SF_LAYOUT_MEMBER(inv_hr); SF_LAYOUT_MEMBER(quads);
 #undef SF_LAYOUT_MEMBER
     h = layout_mix(h, sizeof(RenderArgs)); h = layout_mix(h, sizeof(Uniforms)); h = layout_mix(h, sizeof(Tex));
     h = layout_mix(h, sizeof(FrameDyn)); h = layout_mix(h, sizeof(VisualizerConsts));
@@ -175,15 +176,18 @@ template <class SHADER>
 __device__ __forceinline__ void render_body(const RenderArgs& a) {
     __shared__ typename SHADER::Shared shared;
     constexpr bool QUADS = shader_uses_quads<SHADER>::value;
+    constexpr int R = shader_rows_1x<SHADER>::value;     // rows a thread walks: the block covers BLOCK_W x (BLOCK_H*R) pixels
+    static_assert(!(QUADS && R > 1), "the quad layout shades one pixel per lane");
+    // shaders written for 64 x 4 blocks that shade one pixel per lane take the quad layout at run time too (a.quads: a mipmapped sampler)
+    constexpr bool QUADS_POSSIBLE = (SHADER::BLOCK_W == 64 && SHADER::BLOCK_H == 4 && R == 1);
+    const bool quads = QUADS || (QUADS_POSSIBLE && a.quads);
     int lx = threadIdx.x, ly = threadIdx.y;
-    if constexpr (QUADS) {
-        static_assert(SHADER::BLOCK_W == 64 && SHADER::BLOCK_H == 4, "the quad layout is written for 64 x 4 blocks");
+    if (quads) {
+        static_assert(!QUADS || (SHADER::BLOCK_W == 64 && SHADER::BLOCK_H == 4), "the quad layout is written for 64 x 4 blocks");
         const int tid = ly*64 + lx, wave = tid >> 6, lane = tid & 63;
         lx = (((lane >> 2) << 1) | (lane & 1)) + 32*(wave & 1);
         ly = ((lane >> 1) & 1) + 2*(wave >> 1);
     }
-    constexpr int R = shader_rows_1x<SHADER>::value;     // rows a thread walks: the block covers BLOCK_W x (BLOCK_H*R) pixels
-    static_assert(!(QUADS && R > 1), "the quad layout shades one pixel per lane");
     const int i = blockIdx.x*SHADER::BLOCK_W + lx;
     const int j = (blockIdx.y*SHADER::BLOCK_H + ly)*R;
     Uniforms u; Tex tex[TEX_HISTORY];
@@ -204,7 +208,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a) {
 #pragma unroll
     for (int r = 0; r < R; r++) {
         if constexpr (R > 1) make_varyings(f, i, j + r, a.wr, a.hr, a.aspect, shader_fast_centres<SHADER>::value ? a.inv_wr : 0.0f, shader_fast_centres<SHADER>::value ? a.inv_hr : 0.0f);
-        if constexpr (QUADS) {
+        if (quads) {
             const vec4 colour = SHADER::run(a, f, state[r], shared);      // helper lanes run too: their values feed the neighbours' differences
             if (valid[r]) store_target(a, blockIdx.z, i, j + r, colour);
         } else {

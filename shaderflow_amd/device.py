@@ -29,8 +29,22 @@ class DeviceTexture:
     def nbytes(self) -> int:
         return self.size[0]*self.size[1]*self.components*self.dtype.itemsize
 
-    def params(self, filter: str, repeat_x: bool, repeat_y: bool) -> None:
-        N.check(N.lib().sfx_texture_params(self.handle, N.LINEAR if filter == "linear" else N.NEAREST, int(repeat_x), int(repeat_y)))
+    def params(self, filter: str, repeat_x: bool, repeat_y: bool, mipmaps: bool = False) -> None:
+        """`mipmaps`: the minification filter becomes LINEAR_MIPMAP_LINEAR / NEAREST_MIPMAP_NEAREST (moderngl_filter, texture.py:131-137)"""
+        linear = (filter == "linear")
+        code = (2 if linear else 3) if mipmaps else (N.LINEAR if linear else N.NEAREST)      # SFX_LINEAR_MIPMAP_LINEAR / SFX_NEAREST_MIPMAP_NEAREST
+        N.check(N.lib().sfx_texture_params(self.handle, code, int(repeat_x), int(repeat_y)))
+
+    def build_mipmaps(self) -> None:
+        """moderngl.Texture.build_mipmaps(): levels 1… from the current level 0 (later writes touch level 0 only, as in OpenGL)"""
+        N.check(N.lib().sfx_texture_build_mipmaps(self.handle))
+
+    def read_level(self, level: int) -> np.ndarray:
+        """(height >> level, width >> level, components) of a built chain, row 0 = bottom"""
+        w, h = max(1, self.size[0] >> level), max(1, self.size[1] >> level)
+        out = np.empty((h, w, self.components), self.dtype)
+        N.check(N.lib().sfx_texture_read_level(self.handle, level, out.ctypes.data, out.nbytes))
+        return out
 
     def write(self, data, viewport: Optional[tuple[int, int, int, int]] = None) -> None:
         buffer = np.frombuffer(data, np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else np.ascontiguousarray(data).view(np.uint8).ravel()

@@ -11,11 +11,15 @@ Rules that are observable and therefore kept:
     `scene.render_resolution` (= resolution × ssaa), times `track`, at least 1×1;
   * any change of shape/format re-allocates every box (`make`); a box remembers the bytes of its last FULL
     write and gets them back when the new allocation has the same byte size;
-  * sampler state (filter, wrap) is applied to every box (`apply`). `mipmaps=True` (texture.py:131-137, 277-278:
-    `build_mipmaps` + LINEAR_MIPMAP_LINEAR) is REFUSED with NotImplementedError: the kernels sample level 0 only, and rendering
-    without the mip chain would silently change pixels. `anisotropy` is accepted: without mipmaps it does not change the bilinear
-    filter of a conforming OpenGL 3.3 implementation on the isotropic footprints of a full-screen quad (llvmpipe's optional
-    EXT_texture_filter_anisotropic kernel does: measured in DESIGN.md §5 and excluded from the goldens);
+  * sampler state (filter, wrap) is applied to every box (`apply`). With `mipmaps=True` (texture.py:131-137, 277-278) `apply`
+    ALSO rebuilds the mip chain of every box from its current level 0 and the minification filter becomes LINEAR_MIPMAP_LINEAR
+    (NEAREST_MIPMAP_NEAREST for "nearest"); the level of detail comes from the implicit derivatives of the coordinate (OpenGL 3.3
+    §3.8.11, glsl.hpp texture_mipmapped). As in the reference, `write` touches level 0 only: the chain is as old as the last
+    `apply` — `from_numpy` runs `make()` → `apply()` BEFORE its `write`, so a texture that is only ever filled by `from_numpy` /
+    `from_image` samples an EMPTY (zero) chain when minified, until something applies again (`repeat()`, a filter change).
+    That is what the reference does on OpenGL (tests/golden/mip.npz holds both cases), so it is what happens here.
+    `anisotropy` is accepted and ignored: it is an extension to OpenGL 3.3 core whose filter is implementation-defined
+    (tests/golden/filter.npz pins what llvmpipe's does to the goldens' inputs, and that the goldens are rendered without it);
   * `from_numpy` flips rows so that row 0 is the BOTTOM row, like an OpenGL upload of an image;
   * the uniforms are `<name>Size`, `<name>Layers`, `<name>Temporal` and one sampler per box, `<name>{t}x{l}`.
 """
@@ -199,13 +203,11 @@ class ShaderTexture(ShaderModule):
 
     def apply(self):
         """Push filter and wrap state to every box"""
-        if self.mipmaps:
-            raise NotImplementedError(
-                f"ShaderTexture '{self.name}': mipmaps=True (LINEAR_MIPMAP_LINEAR sampling, reference texture.py:131-137, 277-278) is not "
-                "implemented by the HIP sampler, which reads level 0 only; rendering without the mip chain would change pixels silently")
         for (_, _, box) in self.boxes:
             if box.texture is not None:
-                box.texture.params(self.filter.value, self.repeat_x, self.repeat_y)
+                if self.mipmaps:
+                    box.texture.build_mipmaps()                     # texture.py:277-278: from whatever level 0 holds NOW
+                box.texture.params(self.filter.value, self.repeat_x, self.repeat_y, mipmaps=self.mipmaps)
         return self
 
     def repeat(self, value: bool):

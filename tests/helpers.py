@@ -121,6 +121,18 @@ def visualizer_inputs(w, h, seed=0, bg_size=(96, 54), volume=0.8, std=0.2, time=
     return u, arrays, params
 
 
+def mip_probe_texture(width: int, height: int, dtype) -> np.ndarray:
+    """The texture of the mipmap probes (tests/golden/make_golden_mip.py renders it on the reference): smooth gradients plus seeded
+    noise, so that neighbouring levels differ visibly; (height, width, 4), row 0 = bottom"""
+    rng = np.random.default_rng(17)
+    y, x = np.mgrid[0:height, 0:width]
+    base = np.stack([x/(width - 1), y/(height - 1), 0.5 + 0.5*np.sin(x*0.7)*np.cos(y*0.5), np.ones_like(x, float)], axis=-1)
+    image = np.clip(0.7*base + 0.3*rng.random((height, width, 4)), 0.0, 1.0)
+    if np.dtype(dtype) == np.uint8:
+        return np.rint(image*255).astype(np.uint8)
+    return image.astype(np.float32)
+
+
 def oracle_textures(arrays, params):
     return {k: O.make_texture(v, *params[k]) for k, v in arrays.items()}
 
