@@ -497,15 +497,22 @@ def test_set_uniform_between_frames_is_not_masked_by_the_pipeline_cache():
     assert program._pushed["iTime"] != sent_before and program._pushed_plain["iTime"][1] == 1.5
 
 
-def test_mipmaps_are_refused_not_ignored():
-    """the HIP sampler reads level 0 only, so a texture that asks for the mip chain (texture.py:131-137, 277-278)
-    raises instead of rendering other pixels than the reference silently; anisotropy without mipmaps is accepted"""
+def test_mipmaps_follow_the_references_build_order():
+    """SURVEY §8 P1 (texture.py:116-137, 274-283; whole-image parity: tests/test_gpu_mip.py). Observable rules of the reference kept:
+    `mipmaps=True` makes apply() rebuild the chain from the CURRENT level 0; write() touches level 0 only; from_numpy() runs
+    make() → apply() before its write, so the chain of a texture that is only ever filled that way is the chain of zeros."""
     from examples.scenes import Basic
     from shaderflow_amd.texture import ShaderTexture
     scene = Basic()
     scene.initialize()
-    with pytest.raises(NotImplementedError, match="mipmaps"):
-        ShaderTexture(scene=scene, name="mipmapped", mipmaps=True)
-    texture = ShaderTexture(scene=scene, name="plain", anisotropy=16)
-    with pytest.raises(NotImplementedError, match="mipmaps"):
-        texture.mipmaps = True
+    data = np.full((8, 8, 4), 200, np.uint8)
+    texture = ShaderTexture(scene=scene, name="mipmapped", mipmaps=True, anisotropy=16).from_numpy(data)
+    box = texture.get_box().texture
+    assert np.array_equal(box.read_level(0), data) and not box.read_level(1).any()      # level 0 written after the chain was built
+    texture.repeat(False)                                                               # apply(): the chain of the data
+    assert (box.read_level(1) == 200).all() and (box.read_level(3) == 200).all() and box.read_level(3).shape == (1, 1, 4)
+    texture.write(np.zeros((8, 8, 4), np.uint8))
+    assert not box.read_level(0).any() and (box.read_level(1) == 200).all()             # … and stale again after the next write
+    plain = ShaderTexture(scene=scene, name="plain").from_numpy(data)
+    plain.mipmaps = True                                                                # the setter applies (texture.py:116): the chain of the data
+    assert (plain.get_box().texture.read_level(2) == 200).all()
