@@ -34,7 +34,9 @@ def read_wav(path: Path) -> tuple[np.ndarray, int]:
             if fmt[0] == 0xFFFE and len(body) >= 26:                 # WAVE_FORMAT_EXTENSIBLE: sub-format GUID
                 fmt = (struct.unpack("<H", body[24:26])[0], *fmt[1:])
         elif tag == b"data":
-            data = body
+            if size in (0, 0xFFFFFFFF):                              # a streamed / piped WAV: the writer never came back to patch the size
+                body, size = raw[pos + 8:], len(raw) - pos - 8
+            data = body                                              # (a truncated file: the slice ends with the file)
         pos += 8 + size + (size & 1)
     if fmt is None or data is None:
         raise ValueError(f"{path}: missing fmt or data chunk")
@@ -65,7 +67,8 @@ def flac_info(path: Path) -> tuple[int, int, int, int]:
     import ctypes as C
 
     from shaderflow_amd import _native as N
-    raw = Path(path).read_bytes()
+    with open(path, "rb") as file:
+        raw = file.read(1 << 16)                                     # STREAMINFO is the first metadata block: no need for the audio
     samples, channels, samplerate, bits = C.c_int64(), C.c_int(), C.c_int(), C.c_int()
     N.check(N.lib().sfx_flac_info(raw, len(raw), C.byref(samples), C.byref(channels), C.byref(samplerate), C.byref(bits)))
     return samples.value, channels.value, samplerate.value, bits.value

@@ -17,6 +17,7 @@ already (the read-out kernels flip rows while writing), so no `vflip` filter is 
 """
 from __future__ import annotations
 
+import os
 import shutil
 import subprocess
 from enum import Enum
@@ -288,6 +289,9 @@ class FFmpeg:
                 elif tag == b"data":
                     if channels is None or not block:
                         return None
+                    # what a decoder will find, not what the header promises: a streamed WAV says 0 or 0xFFFFFFFF, a truncated one too much
+                    rest = os.fstat(file.fileno()).st_size - file.tell()
+                    size = rest if size in (0, 0xFFFFFFFF) else min(size, rest)
                     return size//block, channels, samplerate
                 else:
                     file.seek(size + (size & 1), 1)

@@ -376,6 +376,10 @@ class RangeTransfer:
             work.wait()
         self.sent.clear()
 
+    def abort(self) -> None:
+        """This rank cannot go on: receives posted for its chunks end with the process group (torchrun tears the job down)"""
+        self.sent.clear()
+
 
 class DeviceArray:
     """A raw device allocation as something torch can view without copying (`torch.as_tensor(DeviceArray(ptr, n), device=…)`): IPC
@@ -421,11 +425,15 @@ class SdmaTransfer:
         self.pending = self.chunks
         self.chunks += 1
 
+    ABORTED = -1                                                    # a sender that raised says so instead of the next chunk number
+
     def arrived(self, source: int, chunk: int) -> None:
         import torch
         import torch.distributed as dist
         message = torch.zeros(1, dtype=torch.int64)
         dist.recv(message, src=source, group=self.control)
+        if int(message.item()) == self.ABORTED:
+            raise RuntimeError(f"peer window: rank {source} failed before its chunk {chunk}")
         if int(message.item()) != chunk:
             raise RuntimeError(f"peer window: rank {source} reported chunk {int(message.item())}, expected {chunk}")
 
@@ -434,7 +442,22 @@ class SdmaTransfer:
         for work, _ in self.notices:
             work.wait()
         self.notices.clear()
+        self.close()
+
+    def abort(self) -> None:
+        """This rank raised: rank 0, which waits for its next notice in arrived(), learns it now instead of never"""
+        import torch
+        import torch.distributed as dist
+        self.pending = None
+        if self.rank != 0:
+            try:
+                dist.send(torch.tensor([self.ABORTED], dtype=torch.int64), dst=0, group=self.control)
+            except Exception:
+                pass
+
+    def close(self) -> None:
         if self.window is not None:
+            self.context.peer_flush()
             self.context.peer_close(self.window)
             self.window = None
 

@@ -323,14 +323,28 @@ class FrameTape:
                 def emit(view, count):
                     emit_frames(view.data_ptr(), count)
 
-                contiguous_device_export(world, rank, total, self.batch, frame_bytes, self.build, render, emit, resident, transfer)
-                export.drain()                                  # `resident` outlives the queued reads
-                if mode == "device-sdma":
-                    import torch.distributed as dist
-                    dist.barrier()                              # every peer has closed its mapping of the window
-                    if window is not None:
-                        del resident
-                        context.free(window)
+                # a rank that raises mid-export must not leave the others waiting for its chunks, nor rank 0's whole-export allocation
+                # and the peers' mappings behind: the outcome is exchanged, then every rank tears down
+                failure: Optional[BaseException] = None
+                try:
+                    contiguous_device_export(world, rank, total, self.batch, frame_bytes, self.build, render, emit, resident, transfer)
+                    export.drain()                              # `resident` outlives the queued reads
+                except BaseException as error:
+                    failure = error
+                    transfer.abort()
+                finally:
+                    if mode == "device-sdma":
+                        import torch.distributed as dist
+                        try:
+                            transfer.close()                        # the peers' mappings of the window
+                            dist.barrier(group=transfer.control)    # every peer has closed its mapping
+                        finally:
+                            if window is not None:
+                                del resident
+                                context.synchronize()
+                                context.free(window)
+                if failure is not None:
+                    raise failure
                 if rank != 0:
                     export.frame = total
             scene.time, scene.dt, scene.rdt = self.times[-1], self.dts[-1], self.dts[-1]      # clock of the last frame

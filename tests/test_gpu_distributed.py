@@ -71,9 +71,9 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_export(tmp_path, name
     assert sharded == whole, f"{np.count_nonzero(np.frombuffer(sharded, np.uint8) != np.frombuffer(whole, np.uint8))} bytes differ"
 
 
-def _rank_without_sink(rank: int, world: int, port: int, fail_on: int):
+def _rank_without_sink(rank: int, world: int, port: int, fail_on: int, mode: str = "host"):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", RANK=str(rank), WORLD_SIZE=str(world), SHADERFLOW_SHARD="host",
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", RANK=str(rank), WORLD_SIZE=str(world), SHADERFLOW_SHARD=mode,
                       SHADERFLOW_SHM_SLOTS="5", SHADERFLOW_SHM_TIMEOUT="20")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     scene = _build("Visualizer")
@@ -96,7 +96,7 @@ def _rank_without_sink(rank: int, world: int, port: int, fail_on: int):
             os.close(reader)
             self.fileno = writer
         ExportingHelper.popen = popen
-    if fail_on == SINK_DIES:
+    if fail_on == SINK_DIES or mode != "host":
         output = f"/tmp/shaderflow-test-{os.getpid()}.rgb"
     try:
         scene.main(freewheel=(output is None), output=output, **KW["Visualizer"])
@@ -134,6 +134,25 @@ def test_two_ranks_without_a_sink_and_with_a_failing_producer(fail_on):
         assert all(code not in (0, None) for code in codes), codes          # the failure reaches BOTH ranks …
         assert took < 90, f"{took:.0f} s: a rank waited for its time-out"    # … at once
     assert not {name for name in set(os.listdir("/dev/shm")) - before if name.startswith("shaderflow-")}
+
+
+@pytest.mark.timeout(200)
+def test_peer_window_export_with_a_failing_sender():
+    """device-sdma mode, rank 1 raises in its first render. Rank 0 — waiting for rank 1's first notice — is told
+    (SdmaTransfer.abort), both ranks close the window, rank 0 frees its whole-export allocation, and both processes end with an error
+    within seconds instead of hanging in a gloo recv / the barrier."""
+    import time
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    started = time.monotonic()
+    procs = [ctx.Process(target=_rank_without_sink, args=(r, 2, port, 1, "device-sdma")) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=150)
+    codes = [p.exitcode for p in procs]
+    assert all(code not in (0, None) for code in codes), codes
+    assert time.monotonic() - started < 90
 
 
 @pytest.mark.timeout(400)

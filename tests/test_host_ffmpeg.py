@@ -80,6 +80,29 @@ def test_audio_probes_answer_wav_files_natively(tmp_path):
     assert FFmpeg.get_audio_samplerate(tmp_path/"missing.wav") is None and FFmpeg.get_video_resolution(tmp_path/"missing.mp4") is None
 
 
+@pytest.mark.parametrize("claimed", [0, 0xFFFFFFFF, "double", "truncated"])
+def test_probes_agree_with_the_decoder_on_streamed_and_truncated_wavs(tmp_path, claimed):
+    """the duration a probe reports (it sizes the export: total frames) must be the duration the decoder delivers.
+    A streamed / piped WAV leaves 0 or 0xFFFFFFFF in the data chunk's size; a truncated or over-promising one says more than is there."""
+    import struct
+    from shaderflow_amd.audio.reader import read_wav, write_wav_f32
+    samples = np.random.default_rng(1).uniform(-1, 1, (1000, 2)).astype(np.float32)
+    raw = bytearray(write_wav_f32(tmp_path/"clip.wav", samples, 8000).read_bytes())
+    at = raw.index(b"data") + 4
+    expected = samples
+    if claimed == "double":
+        raw[at:at + 4] = struct.pack("<I", 2*samples.nbytes)
+    elif claimed == "truncated":
+        raw, expected = raw[:-8*300], samples[:700]
+    else:
+        raw[at:at + 4] = struct.pack("<I", claimed)
+    path = tmp_path/"odd.wav"
+    path.write_bytes(bytes(raw))
+    decoded, samplerate = read_wav(path)
+    assert samplerate == 8000 and np.array_equal(decoded, expected)
+    assert FFmpeg.get_audio_duration(path) == pytest.approx(len(expected)/8000)
+
+
 FAKE_DECODER = """#!/usr/bin/env python3
 import sys
 src = sys.argv[sys.argv.index('-i') + 1]
