@@ -77,7 +77,7 @@ struct Context : Object {
     // queue with `stream` (context_copy_streams)
     hipStream_t copy_streams[2] = {nullptr, nullptr};
     int copy_candidates = 0, copy_colliding = 0;                   // how many streams the choice looked at / found serialised behind `stream`
-    struct EngineCopy* engines = nullptr;                           // read-out on named SDMA engines (readout_copy); null until first use
+    struct EngineCopy* engines = nullptr;                           // agents and SDMA engines of the read-out (EngineLanes); null until first use
     // peer copies of the sharded export's "device-sdma" mode: the copy streams, an event per lane (sfx_peer_*)
     hipStream_t peer_streams[2] = {nullptr, nullptr};
     hipEvent_t peer_ready = nullptr, peer_done[16] = {};
@@ -184,25 +184,25 @@ static int context_copy_streams(Context* c) {
     return SFX_OK;
 }
 
-// One frame from device memory to pinned (or HIP-registered) host memory, in order on copy stream `lane` of the context.
+// Frames leave device memory through `EngineLanes`: two device-to-host copies in flight, each on an SDMA engine NAMED by this library.
 //
-// Not hipMemcpyAsync: the runtime picks an SDMA engine per stream — the lowest one free at that moment, then sticky — and the sixteen
-// engines of an MI355X are far from equal for device-to-host traffic (tools/ubench_sdma_engines.hip, profiles/r04_export_streams.txt):
-// engines 0-3 move 42-54 GB/s, 4-7 ≈ 12, 8-11 ≈ 9, 12-15 ≈ 7. A copy stream that draws a far engine reads 4K frames out at a quarter
-// of the bus for the rest of its life — the 830 frames/s exports of the third context of a process, against 2 080 for the first.
-// So the copy names its engine: a host function on the copy stream (in order with the event waits before and the event record after
-// it, exactly where the hipMemcpyAsync stood) hands the frame to HSA's copy-on-engine call on one of the two engines HSA itself
-// recommends for this direction (hsa_amd_memory_get_preferred_copy_engine; SHADERFLOW_SDMA_ENGINES=a,b overrides) and waits for it.
-// Route "hip" (SHADERFLOW_READOUT=hip, or whenever HSA does not answer) is the plain hipMemcpyAsync; "kernel" a 256-workgroup copy
-// kernel storing into the mapped host buffer (measured: does not overlap a render that fills the chip — 1 235 frames/s).
+// Not hipMemcpyAsync on a copy stream (rounds 1-3): the runtime picks an engine per stream — the lowest one free at that moment, then
+// sticky — and the sixteen engines of an MI355X are far from equal for device-to-host traffic (tools/ubench_sdma_engines.hip,
+// profiles/r04_export_streams.txt): engines 0-3 move 42-54 GB/s, 4-7 ≈ 12, 8-11 ≈ 9, 12-15 ≈ 7. A stream that draws a far engine reads
+// 4K frames out at a quarter of the bus for the rest of its life: the 830 frames/s exports of the third context of a process. And a
+// copy stream that shares a hardware queue with the render stream serialises read-out and render (1 215 frames/s). So the read-out
+// owns no stream at all: a thread of the ring waits for the frame on the host (hipEventSynchronize of an event recorded on the render
+// stream), hands it to HSA's copy-on-engine call on one of the two engines HSA itself recommends for this direction
+// (hsa_amd_memory_get_preferred_copy_engine; SHADERFLOW_SDMA_ENGINES=a,b overrides) and waits for HSA's completion signal. Nothing
+// of it passes through a HIP queue, so nothing of it depends on how the runtime folds streams onto queues. (A host FUNCTION on a copy
+// stream doing the same was measured first: ≈ 1 ms of latency per callback — fine behind a deep queue, 800 frames/s in the frame loop.)
+// When HSA does not answer (or SHADERFLOW_READOUT=hip) a lane is hipMemcpyAsync + hipStreamSynchronize on one of the context's
+// probed copy streams.
 struct EngineCopy {
     bool usable = false;
     hsa_agent_t gpu{}, cpu{};
     uint32_t engine[2] = {0, 0};
-    hsa_signal_t done[2] = {};
-    std::atomic<int> failed{0};
 };
-struct ReadoutJob { EngineCopy* e; void* host; const void* device; size_t nbytes; int lane; };
 
 static hsa_status_t collect_agents(hsa_agent_t agent, void* data) {
     auto* lists = (std::pair<std::vector<hsa_agent_t>, std::vector<hsa_agent_t>>*)data;
@@ -211,8 +211,10 @@ static hsa_status_t collect_agents(hsa_agent_t agent, void* data) {
     return HSA_STATUS_SUCCESS;
 }
 
-// the agents of a frame's two ends, from the pointers themselves; engines from HSA's recommendation
+// the agents of a frame's two ends, from the pointers themselves; engines from HSA's recommendation. Once per context.
 static EngineCopy* engine_copy(Context* c, const void* host, const void* device) {
+    static std::mutex lock;
+    std::lock_guard<std::mutex> guard(lock);
     if (c->engines) return c->engines->usable ? c->engines : nullptr;
     EngineCopy* e = c->engines = new EngineCopy();
     const char* route = getenv("SHADERFLOW_READOUT");
@@ -234,61 +236,74 @@ static EngineCopy* engine_copy(Context* c, const void* host, const void* device)
     if (hsa_amd_memory_copy_engine_status(e->cpu, e->gpu, &free_mask) != HSA_STATUS_SUCCESS && free_mask == 0) return nullptr;
     if (hsa_amd_memory_get_preferred_copy_engine(e->cpu, e->gpu, &preferred) != HSA_STATUS_SUCCESS) preferred = 0;
     uint32_t pick = __builtin_popcount(preferred) >= 2 ? preferred : 0x3u;
-    int a = -1, b = -1;
-    if (const char* named = getenv("SHADERFLOW_SDMA_ENGINES")) { if (sscanf(named, "%d,%d", &a, &b) == 2 && a >= 0 && a < 16 && b >= 0 && b < 16) pick = (1u << a) | (1u << b); }
     e->engine[0] = pick & (~pick + 1u);                              // lowest set bit
-    e->engine[1] = (pick & (pick - 1u)) ? ((pick & (pick - 1u)) & (~(pick & (pick - 1u)) + 1u)) : e->engine[0];
-    if (a >= 0 && b >= 0) { e->engine[0] = 1u << a; e->engine[1] = 1u << b; }
-    for (auto& signal : e->done) if (hsa_signal_create(0, 0, nullptr, &signal) != HSA_STATUS_SUCCESS) return nullptr;
+    const uint32_t rest = pick & (pick - 1u);
+    e->engine[1] = rest ? (rest & (~rest + 1u)) : e->engine[0];
+    int a = -1, b = -1;
+    if (const char* named = getenv("SHADERFLOW_SDMA_ENGINES")) if (sscanf(named, "%d,%d", &a, &b) == 2 && a >= 0 && a < 16 && b >= 0 && b < 16) { e->engine[0] = 1u << a; e->engine[1] = 1u << b; }
     e->usable = true;
     return e;
 }
 
-static void readout_on_engine(void* data) {
-    ReadoutJob* job = (ReadoutJob*)data;
-    EngineCopy* e = job->e;
-    hsa_signal_t done = e->done[job->lane];                         // one copy at a time per lane: host functions of a stream run in order
-    hsa_signal_store_relaxed(done, 1);
-    hsa_status_t status = hsa_amd_memory_async_copy_on_engine(job->host, e->cpu, job->device, e->gpu, job->nbytes, 0, nullptr, done,
-                                                              (hsa_amd_sdma_engine_id_t)e->engine[job->lane], false);
-    if (status != HSA_STATUS_SUCCESS) {                              // the engine's queue could not be had: let HSA choose (no HIP calls in here)
-        hsa_signal_store_relaxed(done, 1);
-        status = hsa_amd_memory_async_copy(job->host, e->cpu, job->device, e->gpu, job->nbytes, 0, nullptr, done);
-    }
-    if (status == HSA_STATUS_SUCCESS) hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
-    else e->failed.store((int)status);
-    delete job;
-}
-
-typedef unsigned int readout_u4 __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(256) k_readout(const readout_u4* __restrict__ src, readout_u4* __restrict__ dst, size_t n16,
-                                                 const unsigned char* __restrict__ src_tail, unsigned char* __restrict__ dst_tail, int tail) {
-    for (size_t i = blockIdx.x*(size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x*blockDim.x)
-        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+// device-to-device copy of a frame as a KERNEL on the caller's stream (hipMemcpyAsync hands it to a copy engine: measured 5.6 GB/s for
+// a 6.2 MB frame inside the frame loop — 1.1 ms per frame; this is 2-3 us)
+typedef unsigned int frame_u4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_frame_copy(const frame_u4* __restrict__ src, frame_u4* __restrict__ dst, size_t n16, const unsigned char* __restrict__ src_tail,
+                                                    unsigned char* __restrict__ dst_tail, int tail) {
+    for (size_t i = blockIdx.x*(size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x*blockDim.x) dst[i] = src[i];
     if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
+static hipError_t frame_copy(void* dst, const void* src, size_t nbytes, hipStream_t stream) {
+    if (((uintptr_t)dst | (uintptr_t)src) & 15) return hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, stream);
+    const size_t n16 = nbytes/16;
+    const unsigned blocks = (unsigned)std::min<size_t>(2048, (n16 + 255)/256 + 1);
+    hipLaunchKernelGGL(k_frame_copy, dim3(blocks), dim3(256), 0, stream, (const frame_u4*)src, (frame_u4*)dst, n16, (const unsigned char*)src + n16*16,
+                       (unsigned char*)dst + n16*16, (int)(nbytes - n16*16));
+    return hipGetLastError();
+}
 
-static hipError_t readout_copy(Context* c, void* host, const void* device, size_t nbytes, int lane) {
-    hipStream_t stream = c->copy_streams[lane & 1];
-    if (EngineCopy* e = engine_copy(c, host, device)) {
-        if (!e->failed.load()) return hipLaunchHostFunc(stream, readout_on_engine, new ReadoutJob{e, host, device, nbytes, lane & 1});
+struct EngineLanes {
+    Context* c = nullptr;
+    EngineCopy* e = nullptr;                                        // null: the lanes are the context's copy streams
+    bool resolved = false;
+    hsa_signal_t done[2] = {};
+    bool busy[2] = {false, false};
+
+    // `host` / `device`: the first frame's two ends (they name the agents). Called from the thread that issues.
+    void resolve(Context* context, const void* host, const void* device) {
+        if (resolved) return;
+        resolved = true; c = context;
+        e = engine_copy(context, host, device);
+        if (e) for (auto& signal : done) if (hsa_signal_create(0, 0, nullptr, &signal) != HSA_STATUS_SUCCESS) { e = nullptr; break; }
     }
-    const char* route = getenv("SHADERFLOW_READOUT");
-    void* mapped = nullptr;
-    if (route && !strcmp(route, "kernel") && !(((uintptr_t)host | (uintptr_t)device) & 15) && hipHostGetDevicePointer(&mapped, host, 0) == hipSuccess) {
-        const size_t n16 = nbytes/16;
-        hipLaunchKernelGGL(k_readout, dim3(256), dim3(256), 0, stream, (const readout_u4*)device, (readout_u4*)mapped, n16, (const unsigned char*)device + n16*16,
-                           (unsigned char*)mapped + n16*16, (int)(nbytes - n16*16));
-        return hipGetLastError();
+    // false: the copy could not be queued on any route
+    bool issue(int lane, void* host, const void* device, size_t nbytes) {
+        if (e) {
+            hsa_signal_store_relaxed(done[lane], 1);
+            hsa_status_t status = hsa_amd_memory_async_copy_on_engine(host, e->cpu, device, e->gpu, nbytes, 0, nullptr, done[lane], (hsa_amd_sdma_engine_id_t)e->engine[lane], false);
+            if (status != HSA_STATUS_SUCCESS) {                      // the engine's queue could not be had: let HSA choose
+                hsa_signal_store_relaxed(done[lane], 1);
+                status = hsa_amd_memory_async_copy(host, e->cpu, device, e->gpu, nbytes, 0, nullptr, done[lane]);
+            }
+            if (status == HSA_STATUS_SUCCESS) { busy[lane] = true; return true; }
+            e = nullptr;                                             // HSA refuses: HIP's copy from here on
+        }
+        if (hipMemcpyAsync(host, device, nbytes, hipMemcpyDeviceToHost, c->copy_streams[lane]) != hipSuccess) { (void)hipGetLastError(); return false; }
+        busy[lane] = true;
+        return true;
     }
-    (void)hipGetLastError();
-    return hipMemcpyAsync(host, device, nbytes, hipMemcpyDeviceToHost, stream);
-}
-// a copy that HSA refused on every route leaves a frame unread: said once, loudly, by whoever waits for frames next
-static int readout_status(Context* c) {
-    if (c->engines && c->engines->failed.load()) return fail(SFX_E_HIP, "frame read-out: HSA refused the copy (status 0x%x)", c->engines->failed.load());
-    return SFX_OK;
-}
+    void finish(int lane) {
+        if (!busy[lane]) return;
+        if (e) hsa_signal_wait_scacquire(done[lane], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
+        else hipStreamSynchronize(c->copy_streams[lane]);
+        busy[lane] = false;
+    }
+    void release() {
+        finish(0); finish(1);
+        if (resolved && done[0].handle) for (auto& signal : done) if (signal.handle) hsa_signal_destroy(signal);
+        done[0] = done[1] = hsa_signal_t{};
+    }
+};
 
 // how the copy streams of this context were chosen: streams looked at, and how many of them ran in series with the render stream
 extern "C" int sfx_ctx_copy_streams(sfx_handle h, int* candidates, int* colliding) {
@@ -358,7 +373,7 @@ extern "C" int sfx_ctx_destroy(sfx_handle h) {
     for (auto& e : c->events) hipEventDestroy(e);
     hipFree(c->vis_tables); hipFree(c->vis_bars); hipFree(c->resolve_tables);
     for (hipStream_t stream : c->copy_streams) if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
-    if (c->engines) { if (c->engines->usable) for (auto& signal : c->engines->done) hsa_signal_destroy(signal); delete c->engines; }
+    delete c->engines;
     if (c->peer_ready) hipEventDestroy(c->peer_ready);
     for (auto& e : c->peer_done) if (e) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -401,7 +416,7 @@ extern "C" int sfx_device_copy(sfx_handle h, void* dst, const void* src, size_t 
     CTX_OR_FAIL(c, h);
     if (!dst || !src) return fail(SFX_E_INVALID, "null device pointer");
     USE_DEVICE(c);
-    HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(frame_copy(dst, src, nbytes, c->stream));              // a kernel on the context's stream, not a copy engine
     return SFX_OK;
 }
 
@@ -1540,21 +1555,67 @@ struct Ring : Object {
     int slots;
     std::vector<void*> host;
     std::vector<void*> staging;                                     // device copies of texture reads (sfx_ring_read_async), allocated on first use
-    std::vector<hipEvent_t> copied;
-    hipStream_t copy_streams[2] = {nullptr, nullptr};              // frames alternate between two copy streams: 55 instead of 51.5 GB/s (tools/ubench_d2h.hip)
-    int copy_stream_count = 2;
-    hipStream_t copy_stream_of(int slot) const { return copy_streams[copy_stream_count > 1 ? (slot & 1) : 0]; }
-    hipEvent_t produced;
+    std::vector<hipEvent_t> ready;                                  // per slot: recorded on the render stream when the slot's frame is complete
     hipEvent_t fences[2];
+    // copier: waits for a frame on the host, copies it on an engine lane (two in flight), marks the slot copied
+    struct CopyJob { int slot; const void* source; hipEvent_t ready; };
+    std::thread copier;
+    std::deque<CopyJob> copy_queue;
+    std::vector<int> copying;                       // 1 while the slot's copy is queued or in flight
+    EngineLanes lanes;
+    int lane_count = 2;
+    int copy_error = 0;
     // writer
     std::thread writer;
     std::mutex mutex;
-    std::condition_variable wake, idle;
+    std::condition_variable wake, idle, copy_wake;
     std::deque<std::pair<int, int>> queue;          // (slot, fd)
     std::vector<int> pending;                       // writes queued or running per slot
     bool stop = false;
     int io_error = 0;
 };
+
+static void ring_copier(Ring* r) {
+    hipSetDevice(r->ctx->device);
+    int in_lane[2] = {-1, -1}, next = 0;
+    auto finish = [&](int lane) {
+        if (in_lane[lane] < 0) return;
+        r->lanes.finish(lane);
+        { std::lock_guard<std::mutex> lock(r->mutex); r->copying[in_lane[lane]] = 0; }
+        in_lane[lane] = -1;
+        r->idle.notify_all();
+    };
+    for (;;) {
+        Ring::CopyJob job;
+        {
+            std::unique_lock<std::mutex> lock(r->mutex);
+            if (r->copy_queue.empty()) {                             // nothing to issue: let what is in flight land (in issue order), then sleep
+                lock.unlock();
+                finish(next); finish(next ^ 1);
+                lock.lock();
+                r->copy_wake.wait(lock, [&] { return r->stop || !r->copy_queue.empty(); });
+                if (r->copy_queue.empty()) return;
+            }
+            job = r->copy_queue.front(); r->copy_queue.pop_front();
+        }
+        static const bool trace = getenv("SHADERFLOW_RING_TRACE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        hipEventSynchronize(job.ready);                              // the frame is complete on the render stream
+        const auto t1 = std::chrono::steady_clock::now();
+        finish(next);                                                // the lane's previous copy
+        const auto t2 = std::chrono::steady_clock::now();
+        if (trace) fprintf(stderr, "ring copier: slot %d event wait %.0f us, lane finish %.0f us\n", job.slot, std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count());
+        r->lanes.resolve(r->ctx, r->host[job.slot], job.source);
+        if (!r->lanes.issue(next, r->host[job.slot], job.source, r->frame_bytes)) {
+            std::lock_guard<std::mutex> lock(r->mutex);
+            r->copy_error = 1; r->copying[job.slot] = 0;
+            r->idle.notify_all();
+            continue;
+        }
+        in_lane[next] = job.slot;
+        if (r->lane_count > 1) next ^= 1;
+    }
+}
 
 static void ring_writer(Ring* r) {
     for (;;) {
@@ -1564,8 +1625,8 @@ static void ring_writer(Ring* r) {
             r->wake.wait(lock, [&] { return r->stop || !r->queue.empty(); });
             if (r->queue.empty()) return;
             job = r->queue.front(); r->queue.pop_front();
+            r->idle.wait(lock, [&] { return r->copying[job.first] == 0; });      // the frame has landed in the slot's host buffer
         }
-        hipEventSynchronize(r->copied[job.first]);
         const char* p = (const char*)r->host[job.first];
         size_t left = r->frame_bytes;
         int err = 0;
@@ -1589,26 +1650,39 @@ extern "C" int sfx_ring_create(sfx_handle h, size_t frame_bytes, int slots, sfx_
     USE_DEVICE(c);
     Ring* r = new Ring();
     r->magic = MAGIC_RING; r->ctx = c; r->frame_bytes = frame_bytes; r->slots = slots;
-    r->host.resize(slots); r->copied.resize(slots); r->pending.assign(slots, 0);
-    if (const char* n = getenv("SHADERFLOW_COPY_STREAMS")) r->copy_stream_count = atoi(n) == 1 ? 1 : 2;   // A/B switch for measurements
-    { int rc = context_copy_streams(c); if (rc) { delete r; return rc; } }
-    for (int k = 0; k < r->copy_stream_count; k++) r->copy_streams[k] = c->copy_streams[k];    // borrowed: the context's
-    HIP_TRY(hipEventCreateWithFlags(&r->produced, hipEventDisableTiming));
+    r->host.resize(slots); r->ready.resize(slots); r->pending.assign(slots, 0); r->copying.assign(slots, 0);
+    if (const char* n = getenv("SHADERFLOW_COPY_STREAMS")) r->lane_count = atoi(n) == 1 ? 1 : 2;   // A/B switch for measurements
     for (auto& f : r->fences) HIP_TRY(hipEventCreateWithFlags(&f, hipEventDisableTiming));
     for (int k = 0; k < slots; k++) {
         HIP_TRY(hipHostMalloc(&r->host[k], frame_bytes, hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&r->copied[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&r->ready[k], hipEventDisableTiming));
     }
+    r->copier = std::thread(ring_copier, r);
     r->writer = std::thread(ring_writer, r);
     *out = handle_of(r);
     return SFX_OK;
 }
 
+// the slot's last frame has been written out (turbopipe.sync(buffer) before reuse) AND any copy into it has landed
 static int ring_wait_slot(Ring* r, int slot) {
     std::unique_lock<std::mutex> lock(r->mutex);
-    r->idle.wait(lock, [&] { return r->pending[slot] == 0; });
-    if (int rc = readout_status(r->ctx)) return rc;
+    r->idle.wait(lock, [&] { return r->pending[slot] == 0 && r->copying[slot] == 0; });
+    if (r->copy_error) return fail(SFX_E_HIP, "frame read-out: neither HSA nor HIP accepted the copy");
     return r->io_error ? fail(SFX_E_IO, "pipe write failed: %s", strerror(r->io_error)) : SFX_OK;
+}
+static int ring_wait_copy(Ring* r, int slot) {
+    std::unique_lock<std::mutex> lock(r->mutex);
+    r->idle.wait(lock, [&] { return r->copying[slot] == 0; });
+    return r->copy_error ? fail(SFX_E_HIP, "frame read-out: neither HSA nor HIP accepted the copy") : SFX_OK;
+}
+static int ring_queue_copy(Ring* r, const void* dptr, int slot, hipEvent_t ready) {
+    {
+        std::lock_guard<std::mutex> lock(r->mutex);
+        r->copying[slot] = 1;
+        r->copy_queue.push_back({slot, dptr, ready});
+    }
+    r->copy_wake.notify_one();
+    return SFX_OK;
 }
 
 extern "C" int sfx_ring_read_device_async(sfx_handle h, const void* dptr, int slot) {
@@ -1617,11 +1691,8 @@ extern "C" int sfx_ring_read_device_async(sfx_handle h, const void* dptr, int sl
     USE_DEVICE(r->ctx);
     int rc = ring_wait_slot(r, slot);                               // turbopipe.sync(buffer) before reuse
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(r->produced, r->ctx->stream));           // the frame is complete on the render stream…
-    HIP_TRY(hipStreamWaitEvent(r->copy_stream_of(slot), r->produced, 0));    // …before the copy engine reads it
-    HIP_TRY(readout_copy(r->ctx, r->host[slot], dptr, r->frame_bytes, r->copy_stream_count > 1 ? (slot & 1) : 0));
-    HIP_TRY(hipEventRecord(r->copied[slot], r->copy_stream_of(slot)));
-    return SFX_OK;
+    HIP_TRY(hipEventRecord(r->ready[slot], r->ctx->stream));        // the frame is complete on the render stream when this event is
+    return ring_queue_copy(r, dptr, slot, r->ready[slot]);
 }
 
 extern "C" int sfx_ring_fence(sfx_handle h, int which) {
@@ -1638,18 +1709,16 @@ extern "C" int sfx_ring_read_fenced_async(sfx_handle h, const void* dptr, int sl
     USE_DEVICE(r->ctx);
     int rc = ring_wait_slot(r, slot);
     if (rc) return rc;
-    HIP_TRY(hipStreamWaitEvent(r->copy_stream_of(slot), r->fences[which], 0));
-    HIP_TRY(readout_copy(r->ctx, r->host[slot], dptr, r->frame_bytes, r->copy_stream_count > 1 ? (slot & 1) : 0));
-    HIP_TRY(hipEventRecord(r->copied[slot], r->copy_stream_of(slot)));
-    return SFX_OK;
+    return ring_queue_copy(r, dptr, slot, r->fences[which]);
 }
 
+// The frame read into `slot` has left its device buffer: the caller may render into that buffer again when this returns. (Rounds 1-3
+// made the render STREAM wait for a copy event; the read-out no longer runs on a HIP stream, so the host waits — by the time a
+// pipelined export asks, the copy it names finished a whole batch ago.)
 extern "C" int sfx_ring_stream_wait(sfx_handle h, int slot) {
     Ring* r = get<Ring>(h, MAGIC_RING);
     if (!r || slot < 0 || slot >= r->slots) return fail(SFX_E_INVALID, "invalid ring handle or slot");
-    USE_DEVICE(r->ctx);
-    HIP_TRY(hipStreamWaitEvent(r->ctx->stream, r->copied[slot], 0));
-    return SFX_OK;
+    return ring_wait_copy(r, slot);
 }
 
 // fbo.read_into(buffer) is a GL command: it has read the texture before the next draw call touches it. Here the read-out runs beside
@@ -1665,16 +1734,16 @@ extern "C" int sfx_ring_read_async(sfx_handle h, sfx_handle tex, int slot) {
     if (rc) return rc;
     if (r->staging.empty()) r->staging.assign(r->slots, nullptr);
     if (!r->staging[slot]) HIP_TRY(hipMalloc(&r->staging[slot], r->frame_bytes));
-    HIP_TRY(hipStreamWaitEvent(r->ctx->stream, r->copied[slot], 0));    // (already complete when its write has finished; orders a read that was never piped)
-    HIP_TRY(hipMemcpyAsync(r->staging[slot], t->data, r->frame_bytes, hipMemcpyDeviceToDevice, r->ctx->stream));
-    return sfx_ring_read_device_async(h, r->staging[slot], slot);
+    HIP_TRY(frame_copy(r->staging[slot], t->data, r->frame_bytes, r->ctx->stream));
+    HIP_TRY(hipEventRecord(r->ready[slot], r->ctx->stream));
+    return ring_queue_copy(r, r->staging[slot], slot, r->ready[slot]);
 }
 
 extern "C" int sfx_ring_sync(sfx_handle h, int slot, void** host_ptr) {
     Ring* r = get<Ring>(h, MAGIC_RING);
     if (!r || slot < 0 || slot >= r->slots) return fail(SFX_E_INVALID, "invalid ring handle or slot");
-    USE_DEVICE(r->ctx);
-    HIP_TRY(hipEventSynchronize(r->copied[slot]));
+    int rc = ring_wait_copy(r, slot);
+    if (rc) return rc;
     if (host_ptr) *host_ptr = r->host[slot];
     return SFX_OK;
 }
@@ -1686,12 +1755,14 @@ extern "C" int sfx_ring_pipe(sfx_handle h, int slot, int fd) {
         std::lock_guard<std::mutex> lock(r->mutex);
         if (r->io_error) return fail(SFX_E_IO, "pipe write failed: %s", strerror(r->io_error));
         r->pending[slot]++;
-        r->queue.emplace_back(slot, fd);
+        r->queue.push_back({slot, fd});
     }
     r->wake.notify_one();
     return SFX_OK;
 }
 
+// `count` frames of a batch, `stride` bytes apart, through consecutive slots from `first_slot`: read (after fence `which`, or after
+// everything queued on the render stream so far when which < 0) and piped to `fd` — one native call instead of 2·count
 extern "C" int sfx_ring_pipe_frames(sfx_handle h, const void* dptr, size_t stride, int count, int first_slot, int which, int fd) {
     Ring* r = get<Ring>(h, MAGIC_RING);
     if (!r || !dptr || count < 0 || first_slot < 0 || which > 1 || fd < 0) return fail(SFX_E_INVALID, "invalid ring handle, pointer, count, slot, fence or fd");
@@ -1717,15 +1788,14 @@ extern "C" int sfx_ring_destroy(sfx_handle h) {
     Ring* r = get<Ring>(h, MAGIC_RING);
     if (!r) return fail(SFX_E_INVALID, "invalid ring handle");
     { std::lock_guard<std::mutex> lock(r->mutex); r->stop = true; }
-    r->wake.notify_all();
+    r->wake.notify_all(); r->copy_wake.notify_all();
+    if (r->copier.joinable()) r->copier.join();
     if (r->writer.joinable()) r->writer.join();
     hipSetDevice(r->ctx->device);
-    for (int k = 0; k < r->copy_stream_count; k++) hipStreamSynchronize(r->copy_streams[k]);
-    for (int k = 0; k < r->slots; k++) { hipHostFree(r->host[k]); hipEventDestroy(r->copied[k]); }
+    r->lanes.release();
+    for (int k = 0; k < r->slots; k++) { hipHostFree(r->host[k]); hipEventDestroy(r->ready[k]); }
     for (void* p : r->staging) if (p) hipFree(p);
-    hipEventDestroy(r->produced);
     for (auto& f : r->fences) hipEventDestroy(f);
-
     r->magic = 0;
     delete r;
     return SFX_OK;

@@ -208,11 +208,9 @@ __device__ __forceinline__ void render_body(const RenderArgs& a) {
 #pragma unroll
     for (int r = 0; r < R; r++) {
         if constexpr (R > 1) make_varyings(f, i, j + r, a.wr, a.hr, a.aspect, shader_fast_centres<SHADER>::value ? a.inv_wr : 0.0f, shader_fast_centres<SHADER>::value ? a.inv_hr : 0.0f);
-        if (quads) {
-            const vec4 colour = SHADER::run(a, f, state[r], shared);      // helper lanes run too: their values feed the neighbours' differences
+        if (quads || valid[r]) {                                          // quad layout: helper lanes run too — their values feed the neighbours' differences
+            const vec4 colour = SHADER::run(a, f, state[r], shared);
             if (valid[r]) store_target(a, blockIdx.z, i, j + r, colour);
-        } else {
-            if (valid[r]) store_target(a, blockIdx.z, i, j + r, SHADER::run(a, f, state[r], shared));
         }
     }
 }
