@@ -106,11 +106,14 @@ def cpu_baseline(args, pcm, background) -> dict:
         return time.perf_counter() - t
 
     u, tex, audio_s = frame_inputs(600)
-    probe_rows = max(2, threads//4)
-    probe = band(u, tex, h//2, probe_rows, threads)                # calibrate: seconds per output row on all cores
+    # every thread gets whole rows, and at least two of them: round 3 measured bands of threads/4 … threads rows, i.e. most of the 256
+    # threads of the GPU box idle or starting up — 0.064 frames/s "on 256 threads" was a statement about the sample, not the cores
+    probe_rows = min(h, 2*threads)
+    probe = band(u, tex, (h - probe_rows)//2, probe_rows, threads)  # calibrate: seconds per output row on all cores
     per_row = probe/probe_rows
     budget_all, budget_one = 0.7*args.cpu_seconds, 0.3*args.cpu_seconds
-    rows_all = int(min(h, max(threads, budget_all/3.0/per_row)))
+    rows_all = int(min(h, max(2*threads, budget_all/3.0/per_row)))
+    rows_all -= rows_all % threads if rows_all >= threads else 0
     frames = (300, 1500, 2700)                                     # three frames spread over the clip (different audio, zoom, blur radius)
     seconds_all, audio_all = 0.0, 0.0
     for k in frames:

@@ -143,6 +143,11 @@ class ShaderCamera(ShaderModule):
     def fov(self, value: float):
         self.zoom.target = math.tan(math.radians(value)/2.0) + float(self.isometric.value)
 
+    def pipeline_token(self):
+        # mode, projection and the quaternion the three basis vectors are rotated by (three numpy rotations per frame otherwise)
+        rotation = self.rotation.value
+        return (self.mode, self.projection, rotation.tobytes() if rotation.__class__ is np.ndarray else None) if rotation.__class__ is np.ndarray else None
+
     def pipeline(self) -> Iterable[ShaderVariable]:
         yield Uniform("int", f"{self.name}Mode", value=self.mode.value)
         yield Uniform("int", f"{self.name}Projection", value=self.projection.value)

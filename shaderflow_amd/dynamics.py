@@ -187,6 +187,18 @@ class ShaderDynamics(ShaderModule, DynamicNumber):
             return "float"
         return {1: "float", 2: "vec2", 3: "vec3", 4: "vec4"}.get(shape[0])
 
+    def pipeline_token(self):
+        # the bytes of what pipeline() exports: a frozen system (dynamics.py:222-225) is skipped, a moving one walked
+        value = self.value
+        if value.__class__ is not np.ndarray:
+            return None
+        token = value.tobytes()
+        if self.integrate:
+            token += np.asarray(self.integral).tobytes()
+        if self.differentiate:
+            token += np.asarray(self.derivative).tobytes()
+        return (self.primary, token)
+
     def pipeline(self) -> Iterable[ShaderVariable]:
         if (not self.type):
             return None

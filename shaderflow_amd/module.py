@@ -63,6 +63,12 @@ class ShaderModule:
     def pipeline(self) -> Iterable[ShaderVariable]:
         return []
 
+    def pipeline_token(self) -> Any:
+        """What `pipeline()` would yield, summarised: a value that compares equal as long as every variable this module yields is
+        unchanged — a ShaderProgram then skips the module for that frame (shader.py use_scene_pipeline). None (the default, and the
+        right answer for any module that cannot tell cheaply): walk `pipeline()` every frame, as the reference does."""
+        return None
+
     def full_pipeline(self) -> Iterable[ShaderVariable]:
         for module in self.scene.modules:
             yield from (module.pipeline() or [])

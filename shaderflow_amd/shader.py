@@ -167,6 +167,10 @@ class ShaderProgram(ShaderModule):
     """name → (bytes, known) of the value the device program holds: unchanged uniforms and samplers are not sent again"""
     _pushed_plain: dict = Factory(dict)
     """name → (type, python scalar, known): the same answer for python scalars before any conversion (`_push`)"""
+    _module_tokens: dict = Factory(dict)
+    """id(module) → the pipeline_token() this program last consumed that module's pipeline under (use_scene_pipeline)"""
+    _module_names: dict = Factory(dict)
+    _shared_names: frozenset = frozenset()
     fallback: bool = False
     """True when the fragment was unknown and the `missing` kernel was bound (shader.py:336-340)"""
 
@@ -176,6 +180,9 @@ class ShaderProgram(ShaderModule):
         self.program = None
         self._pushed.clear()
         self._pushed_plain.clear()
+        self._module_tokens.clear()
+        self._module_names.clear()
+        self._shared_names = frozenset()
         self._uniform_arrays = {}
 
     def compile(self, _vertex: str = None, _fragment: str = None):
@@ -259,6 +266,9 @@ class ShaderProgram(ShaderModule):
             raise RuntimeError("Shader hasn't been compiled yet")
         if (value is None):
             return
+        for key, yielded in self._module_names.items():              # a module that yields this name says its own value again next frame
+            if name in yielded:
+                self._module_tokens.pop(key, None)
         self._push(name, value)
 
     def _push(self, name: str, value: Any, type: Optional[str] = None) -> bool:
@@ -339,6 +349,34 @@ class ShaderProgram(ShaderModule):
                 continue
             self._push(variable.name, variable.value, variable.type)
 
+    def use_scene_pipeline(self) -> None:
+        """`use_pipeline(full_pipeline())` (shader.py:377-385) without walking modules whose variables cannot have changed: a module
+        that answers `pipeline_token()` with the value this program saw when it last consumed the module's pipeline is skipped —
+        unless a module walked earlier in this frame yields a name the skipped one yields too (the later module's value must win,
+        as it does when everything is walked in order). Modules without a token are walked every frame."""
+        tokens, names = self._module_tokens, self._module_names
+        touched: set = set()                                          # shared names pushed by modules walked so far this frame
+        shared = self._shared_names
+        for module in self.scene.modules:
+            key = id(module)
+            token = module.pipeline_token()
+            if token is not None and key in tokens and tokens[key] == token and not (shared and not touched.isdisjoint(names[key])):
+                continue
+            variables = list(module.pipeline() or ())
+            self.use_pipeline(variables)
+            tokens[key] = token
+            yielded = frozenset(variable.name for variable in variables)
+            if names.get(key) != yielded:
+                names[key] = yielded
+                seen: set = set()
+                again: set = set()
+                for other in names.values():
+                    again |= (seen & other)
+                    seen |= other
+                self._shared_names = shared = frozenset(again)
+            if shared:
+                touched |= (yielded & shared)
+
     def render_to_fbo(self, fbo: DeviceTexture, clear: bool = True, layer: int = 0) -> None:
         if self.SKIP_GPU:
             return
@@ -359,7 +397,7 @@ class ShaderProgram(ShaderModule):
             return None
 
         if not skip:
-            self.use_pipeline(self.full_pipeline())
+            self.use_scene_pipeline()
 
         # Main pass + resolve in one kernel when final.glsl only needs the pixel's own supersamples
         if (self is self.scene.shader) and self.scene._can_fuse(self):

@@ -271,6 +271,10 @@ class ShaderTexture(ShaderModule):
         if self.track and isinstance(message, ShaderMessage.Shader.RecreateTextures):
             self.make()
 
+    def pipeline_token(self):
+        # Size / Layers / Temporal and one sampler per box: which DEVICE texture sits in which box, in matrix order (roll() rotates it)
+        return (self.name, self.resolution, tuple(0 if box.texture is None else box.texture.serial for (_, _, box) in self.boxes))
+
     def pipeline(self) -> Iterable[ShaderVariable]:
         if not self.name:
             return

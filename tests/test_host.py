@@ -242,3 +242,42 @@ def test_written_out_freewheel_clock_equals_the_scheduler_task():
         want = freewheel_clock_by_task(fps, frames, speed)
         got = freewheel_clock(fps, frames, speed)
         assert all(list(g) == list(w) for g, w in zip(got, want)), (fps, frames, speed)
+
+
+def test_module_skipping_keeps_the_order_in_which_modules_override_each_other():
+    """shader.py use_scene_pipeline: a module whose pipeline_token() is unchanged is not walked again — unless a module walked earlier
+    in the frame yields one of its names (then the later module has to say its value again: last writer wins, as in a full walk)"""
+    from shaderflow_amd.shader import ShaderProgram
+
+    class Module:
+        def __init__(self, name, values, token):
+            self.name, self.values, self.token, self.walks = name, values, token, 0
+
+        def pipeline_token(self):
+            return self.token
+
+        def pipeline(self):
+            self.walks += 1
+            from shaderflow_amd.variable import Uniform
+            return [Uniform("float", key, value) for key, value in self.values.items()]
+
+    class Scene:
+        modules: list = []
+
+    first, second, third = Module("a", {"shared": 1.0, "own": 5.0}, None), Module("b", {"shared": 2.0}, "t0"), Module("c", {"other": 3.0}, "t0")
+    scene = Scene()
+    scene.modules = [first, second, third]
+    program = ShaderProgram.__new__(ShaderProgram)
+    program.__dict__.update(scene=scene, _module_tokens={}, _module_names={}, _shared_names=frozenset(), sent=[])
+    program.use_pipeline = lambda variables: program.sent.extend((v.name, v.value) for v in variables)
+    program.use_scene_pipeline()
+    assert [m.walks for m in scene.modules] == [1, 1, 1] and program._shared_names == {"shared"}
+    program.sent.clear()
+    program.use_scene_pipeline()                                      # `first` has no token: walked; it touches "shared", so `second` follows; `third` rests
+    assert [m.walks for m in scene.modules] == [2, 2, 1] and program.sent == [("shared", 1.0), ("own", 5.0), ("shared", 2.0)]
+    first.token = "fixed"
+    program.use_scene_pipeline(); program.sent.clear(); program.use_scene_pipeline()
+    assert [m.walks for m in scene.modules] == [3, 3, 1] and program.sent == []          # everything known and unchanged: nothing walked
+    third.token = "t1"
+    program.use_scene_pipeline()
+    assert [m.walks for m in scene.modules] == [3, 3, 2] and program.sent == [("other", 3.0)]
