@@ -143,6 +143,10 @@ int sfx_program_fusable(sfx_handle program, int ssaa);
  * *known (may be NULL) tells which */
 int sfx_uniform_set(sfx_handle program, const char* name, int type, const void* value, int* known);
 int sfx_sampler_bind(sfx_handle program, const char* name, sfx_handle tex, int* known);
+/* … `count` of them in one call (the samplers of a temporal x layers matrix after texture.roll(), texture.py:295-298, 351-381) */
+int sfx_sampler_bind_many(sfx_handle program, const char* const* names, const sfx_handle* textures, int count);
+/* iTime, iTau, iDeltatime, iFrame (scene.py:687-703): what a frame changes when only the clock moves, in one call */
+int sfx_uniform_set_clock(sfx_handle program, float time, float tau, float deltatime, int frame);
 int sfx_program_destroy(sfx_handle program);
 
 /* One draw of the fullscreen quad into `target` (any format; RGBA8 for iScreen): shader.py:401-403 */

@@ -93,6 +93,8 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_program_fusable": (C.c_int, [Handle, C.c_int]),
     "sfx_uniform_set": (C.c_int, [Handle, C.c_char_p, C.c_int, C.c_void_p, P(C.c_int)]),
     "sfx_sampler_bind": (C.c_int, [Handle, C.c_char_p, Handle, P(C.c_int)]),
+    "sfx_sampler_bind_many": (C.c_int, [Handle, P(C.c_char_p), P(Handle), C.c_int]),
+    "sfx_uniform_set_clock": (C.c_int, [Handle, C.c_float, C.c_float, C.c_float, C.c_int]),
     "sfx_program_destroy": (C.c_int, [Handle]),
     "sfx_render": (C.c_int, [Handle, Handle, C.c_int]),
     "sfx_resolve": (C.c_int, [Handle, Handle, Handle, C.c_int]),

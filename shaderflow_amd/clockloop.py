@@ -1,0 +1,131 @@
+"""
+ClockLoop: the frame loop of scenes in which nothing but the clock moves (no reference equivalent).
+
+`ShaderScene.next` (scene.py:456-479) updates every module and lets every program walk every module's `pipeline()` — ≈ 150 µs of
+python per frame whatever the scene does. Scenes made only of stock modules whose `DynamicNumber`s are at rest — Multipass, MotionBlur,
+Life, any layered / temporal feedback scene without python logic between frames — change, from one frame to the next, exactly:
+the four clock uniforms (iTime, iTau, iDeltatime, iFrame: scene.py:687-703), `iLayer` per draw, and WHICH device texture sits
+behind every sampler of a temporal texture after its `roll()` (texture.py:295-298, 351-381). This loop does that and nothing else
+per frame: one `sfx_uniform_set_clock`, one `sfx_sampler_bind_many` per rolled texture matrix, the draws, the resolve, the read-out.
+Same launches in the same order with the same uniform values as the frame loop, so the same frames byte for byte
+(tests/test_gpu_multipass.py); anything it is not sure about takes the frame loop.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import TYPE_CHECKING
+
+import numpy as np
+
+from shaderflow_amd import _native as N
+from shaderflow_amd.camera import ShaderCamera
+from shaderflow_amd.dynamics import ShaderDynamics
+from shaderflow_amd.module import ShaderModule
+from shaderflow_amd.scheduler import freewheel_clock
+from shaderflow_amd.shader import ShaderProgram
+from shaderflow_amd.texture import ShaderTexture
+
+if TYPE_CHECKING:
+    from shaderflow_amd.exporting import ExportingHelper
+    from shaderflow_amd.scene import ShaderScene
+
+
+class ClockLoop:
+    @staticmethod
+    def applicable(scene: "ShaderScene") -> bool:
+        from shaderflow_amd.scene import ShaderScene
+        if type(scene).update is not ShaderModule.update:
+            return False
+        if type(scene).pipeline is not ShaderScene.pipeline and not ClockLoop.pipeline_is_static(scene):
+            return False
+        for module in scene.modules:
+            if module is scene or isinstance(module, ShaderScene):
+                continue
+            if type(module) not in (ShaderCamera, ShaderDynamics, ShaderProgram, ShaderTexture):
+                return False
+            if isinstance(module, ShaderDynamics):
+                # at rest, and staying there: the early-out of dynamics.py:222-225 — and no integral that keeps running
+                value, target = np.asarray(module.value), np.asarray(module.target)
+                if module.integrate or value.shape != target.shape or value.dtype.kind not in "fiu":
+                    return False
+                if value.size and float(np.abs(target - value).max()) >= module.precision:
+                    return False
+        return True
+
+    CLOCK = ("iTime", "iTau", "iDeltatime", "iFrame")
+
+    @staticmethod
+    def pipeline_is_static(scene: "ShaderScene") -> bool:
+        """A scene that overrides pipeline() to ADD uniforms (demo.py's Life: `iLifePeriod`): fine as long as what it adds does not move
+        with the clock — asked the way the frame loop asks, by calling pipeline(), at two different times"""
+        def snapshot():
+            out = []
+            for variable in scene.pipeline():
+                if variable.name in ClockLoop.CLOCK:
+                    continue
+                value = variable.value
+                if isinstance(value, np.ndarray):
+                    value = (value.dtype.str, value.shape, value.tobytes())
+                elif isinstance(value, (list, tuple)):
+                    value = tuple(float(v) if isinstance(v, (int, float, np.number)) else repr(v) for v in value)
+                elif not isinstance(value, (int, float, str, bool, type(None))):
+                    value = id(value)                                  # a texture: the same object or not
+                out.append((variable.type, variable.name, value))
+            return out
+        saved = (scene.time, scene.dt, scene.rdt)
+        try:
+            first = snapshot()
+            scene.time, scene.dt, scene.rdt = saved[0] + 1.2345, 0.0173, 0.0173
+            second = snapshot()
+        except Exception:
+            return False
+        finally:
+            scene.time, scene.dt, scene.rdt = saved
+        return first == second
+
+    def __init__(self, scene: "ShaderScene"):
+        self.scene = scene
+        self.programs = [m for m in reversed(scene.modules) if isinstance(m, ShaderProgram)]      # the order scene.next renders them in
+        # texture matrices whose samplers move every frame: (names as a C array, the texture) — the names never change
+        self.rolling = []
+        for module in scene.modules:
+            if isinstance(module, ShaderTexture) and module.name and module.temporal > 1:
+                names = [module._sampler_name(t, l).encode() for (t, l, _) in module.boxes]
+                self.rolling.append((module, (C.c_char_p*len(names))(*names), len(names)))
+
+    def bind_rolled(self, program: ShaderProgram) -> None:
+        for texture, names, count in self.rolling:
+            handles = (N.Handle*count)(*[box.texture.handle if box.texture is not None else N.Handle() for (_, _, box) in texture.boxes])
+            N.check(N.lib().sfx_sampler_bind_many(program.program, names, handles, count))
+
+    def run(self, export: "ExportingHelper", turbo: bool):
+        scene = self.scene
+        total = export.total_frames
+        times, dts, rdts = freewheel_clock(scene.fps, total, scene.speed)
+        lib = N.lib()
+        # frame 0's state through the ordinary pipeline walk: every uniform and sampler of every program is on the device
+        scene.time, scene.dt, scene.rdt = times[0], dts[0], rdts[0]
+        for program in self.programs:
+            if program.program is None:
+                program.compile()
+            if not program.texture.final:
+                program.use_scene_pipeline()
+        runtime, fps = scene.runtime, scene.fps
+        try:
+            for k in range(total):
+                time = times[k]
+                scene.time, scene.dt, scene.rdt = time, dts[k], rdts[k]
+                scene._fused_this_frame = False
+                for program in self.programs:
+                    if not program.texture.final:
+                        N.check(lib.sfx_uniform_set_clock(program.program, time, (time/runtime) % 1.0, dts[k], round(time*fps)))
+                        self.bind_rolled(program)
+                    program.render(pipeline=False)
+                export.pipe(turbo=turbo)
+                export.update()
+        finally:
+            # what this loop sent behind the programs' backs: their caches of sent values say something older
+            for program in self.programs:
+                program._pushed.clear(); program._pushed_plain.clear(); program._module_tokens.clear()
+        scene.time, scene.dt, scene.rdt = times[-1], dts[-1], rdts[-1]          # the clock of the last frame
+        return export.finish()

@@ -73,10 +73,14 @@ struct Context : Object {
     void* vis_tables = nullptr; size_t vis_tables_bytes = 0;
     float* vis_bars = nullptr; size_t vis_bars_count = 0;          // sqrt(texel/1000) of a bound spectrogram (single launches)
     void* resolve_tables = nullptr; size_t resolve_tables_bytes = 0;   // column/row tap tables of k_resolve_fast
+    long resolve_tables_key[8] = {};                               // the geometry (and stream) they were built for
     // the context's two copy streams (read-out ring, shared-memory ring, peer windows): chosen once so that neither shares a hardware
     // queue with `stream` (context_copy_streams)
     hipStream_t copy_streams[2] = {nullptr, nullptr};
     int copy_candidates = 0, copy_colliding = 0;                   // how many streams the choice looked at / found serialised behind `stream`
+    // read-out rings of this context: (ring, "every frame handed to it so far has left device memory"). Their copies run outside HIP's
+    // queues, so hipFree's implicit wait knows nothing of them: sfx_device_free asks them first.
+    std::vector<std::pair<void*, void (*)(void*)>> readouts;
     struct EngineCopy* engines = nullptr;                           // agents and SDMA engines of the read-out (EngineLanes); null until first use
     // peer copies of the sharded export's "device-sdma" mode: the copy streams, an event per lane (sfx_peer_*)
     hipStream_t peer_streams[2] = {nullptr, nullptr};
@@ -409,6 +413,7 @@ extern "C" int sfx_device_free(sfx_handle h, void* ptr) {
     CTX_OR_FAIL(c, h);
     USE_DEVICE(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto& readout : c->readouts) readout.second(readout.first);  // a frame buffer may still be being read out (engine copies: no HIP stream)
     HIP_TRY(hipFree(ptr));
     return SFX_OK;
 }
@@ -850,6 +855,22 @@ extern "C" int sfx_sampler_bind(sfx_handle h, const char* name, sfx_handle tex, 
     else slot = sampler_slot(p->fragment, name);
     if (known) *known = (slot >= 0);
     if (slot >= 0) p->samplers[slot] = t;
+    return SFX_OK;
+}
+
+// `count` sampler uniforms in one call (a temporal x layers texture matrix after a roll: texture.py:351-381 yields one sampler per
+// box and frame); names as for sfx_sampler_bind, unknown ones ignored. The frame loop's per-frame cost is calls, not work.
+extern "C" int sfx_sampler_bind_many(sfx_handle h, const char* const* names, const sfx_handle* textures, int count) {
+    if (count < 0 || (count > 0 && (!names || !textures))) return fail(SFX_E_INVALID, "sampler table of %d entries", count);
+    for (int k = 0; k < count; k++) { int rc = sfx_sampler_bind(h, names[k], textures[k], nullptr); if (rc) return rc; }
+    return SFX_OK;
+}
+
+// The uniforms of scene.py:687-703 that a frame changes when nothing but the clock moves — iTime, iTau, iDeltatime, iFrame — in one call
+extern "C" int sfx_uniform_set_clock(sfx_handle h, float time, float tau, float deltatime, int frame) {
+    Program* p = get<Program>(h, MAGIC_PROG);
+    if (!p) return fail(SFX_E_INVALID, "invalid program handle");
+    p->u.iTime = time; p->u.iTau = tau; p->u.iDeltatime = deltatime; p->u.iFrame = frame;
     return SFX_OK;
 }
 
@@ -1474,13 +1495,19 @@ static int launch_resolve(Context* ctx, const ResolveArgs& a, int frames, hipStr
         const size_t bytes = ((size_t)a.w + a.h)*a.subsample*sizeof(int4);
         if (ctx->resolve_tables_bytes < bytes) {
             hipStreamSynchronize(s);
-            hipFree(ctx->resolve_tables); ctx->resolve_tables = nullptr; ctx->resolve_tables_bytes = 0;
+            hipFree(ctx->resolve_tables); ctx->resolve_tables = nullptr; ctx->resolve_tables_bytes = 0; memset(ctx->resolve_tables_key, 0, sizeof ctx->resolve_tables_key);
             if (hipMalloc(&ctx->resolve_tables, bytes) != hipSuccess) return fail(SFX_E_HIP, "resolve tables: out of device memory");
             ctx->resolve_tables_bytes = bytes;
         }
         int4* columns = (int4*)ctx->resolve_tables; int4* rows = columns + (size_t)a.w*a.subsample;
-        hipLaunchKernelGGL(k_resolve_axis<0>, dim3((a.w + 127)/128), dim3(128), 0, s, a, columns);
-        hipLaunchKernelGGL(k_resolve_axis<1>, dim3((a.h + 127)/128), dim3(128), 0, s, a, rows);
+        // the tables are a function of the geometry alone: a frame loop resolves the same geometry every frame (two launches of
+        // ≈ 5 us each per frame saved; a stream other than the one that built them rebuilds)
+        const long key[8] = {a.w, a.h, a.screen.width, a.screen.height, a.screen.repeat_x, a.screen.repeat_y, a.subsample, (long)(uintptr_t)s};
+        if (memcmp(key, ctx->resolve_tables_key, sizeof key) != 0) {
+            hipLaunchKernelGGL(k_resolve_axis<0>, dim3((a.w + 127)/128), dim3(128), 0, s, a, columns);
+            hipLaunchKernelGGL(k_resolve_axis<1>, dim3((a.h + 127)/128), dim3(128), 0, s, a, rows);
+            memcpy(ctx->resolve_tables_key, key, sizeof key);
+        }
         const ResolveTables t{columns, rows};
         const char* tent = getenv("SHADERFLOW_RESOLVE_TENT");        // A/B switch for measurements
         if (a.subsample == 2 && a.screen.width == a.w && a.screen.height == a.h && !(tent && atoi(tent) == 0)) {
@@ -1659,6 +1686,11 @@ extern "C" int sfx_ring_create(sfx_handle h, size_t frame_bytes, int slots, sfx_
     }
     r->copier = std::thread(ring_copier, r);
     r->writer = std::thread(ring_writer, r);
+    c->readouts.push_back({r, [](void* ring) {
+        Ring* q = (Ring*)ring;
+        std::unique_lock<std::mutex> lock(q->mutex);
+        q->idle.wait(lock, [&] { for (int busy : q->copying) if (busy) return false; return true; });
+    }});
     *out = handle_of(r);
     return SFX_OK;
 }
@@ -1793,6 +1825,7 @@ extern "C" int sfx_ring_destroy(sfx_handle h) {
     if (r->writer.joinable()) r->writer.join();
     hipSetDevice(r->ctx->device);
     r->lanes.release();
+    { auto& list = r->ctx->readouts; list.erase(std::remove_if(list.begin(), list.end(), [&](const std::pair<void*, void (*)(void*)>& e) { return e.first == r; }), list.end()); }
     for (int k = 0; k < r->slots; k++) { hipHostFree(r->host[k]); hipEventDestroy(r->ready[k]); }
     for (void* p : r->staging) if (p) hipFree(p);
     for (auto& f : r->fences) hipEventDestroy(f);

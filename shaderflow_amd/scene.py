@@ -19,6 +19,7 @@ Two execution modes produce the same frames:
 from __future__ import annotations
 
 import math
+import os
 from collections.abc import Iterable
 from pathlib import Path
 from typing import Any, Optional, Union
@@ -56,6 +57,8 @@ class ShaderScene(ShaderModule):
     _final: ShaderProgram = None
 
     fuse: bool = True
+    clock_loop: bool = os.environ.get("SHADERFLOW_CLOCK_LOOP", "1") != "0"
+    """Scenes in which only the clock moves between frames take clockloop.ClockLoop (same frames, a fifth of the python per frame)"""
     """Shade + resolve in one kernel when final.glsl's taps stay inside the pixel's own supersamples"""
 
     _fused_this_frame: bool = False
@@ -356,6 +359,10 @@ class ShaderScene(ShaderModule):
                                         frameskip=frameskip, precise=True)
         if self.exporting and (is_sharded() or shard is not None):
             return self._sharded_frame_loop(export, turbo, *(shard or rank_world()))
+        # nothing but the clock moves between frames (layered / temporal scenes without python logic): the lean loop, same frames
+        from shaderflow_amd.clockloop import ClockLoop
+        if self.freewheel and batch is None and self.clock_loop and ClockLoop.applicable(self):
+            return ClockLoop(self).run(export, turbo)
         while (task := self.scheduler.next()):
             if (task is not self.vsync):
                 continue

@@ -382,7 +382,8 @@ class ShaderProgram(ShaderModule):
             return
         N.check(N.lib().sfx_render(self.program, fbo.handle, layer))
 
-    def render(self) -> None:
+    def render(self, pipeline: bool = True) -> None:
+        """`pipeline=False`: the caller has set the uniforms and samplers this frame changes (clockloop.py)"""
         if self.program is None:
             self.compile()
         # host-only frames of a sharded export (parallel.frame_modes mode 0): the temporal matrix still rolls
@@ -396,7 +397,7 @@ class ShaderProgram(ShaderModule):
             N.check(N.lib().sfx_resolve(self.scene.context.handle, source.handle, self.texture.fbo.handle, self.scene.subsample))
             return None
 
-        if not skip:
+        if not skip and pipeline:
             self.use_scene_pipeline()
 
         # Main pass + resolve in one kernel when final.glsl only needs the pixel's own supersamples

@@ -274,3 +274,37 @@ def test_sharded_frame_loop_reproduces_the_single_process_frames(name):
     assert np.array_equal(parts[0], whole[:30]), lsb_report(parts[0], whole[:30])
     assert np.array_equal(parts[1], whole[30:]), lsb_report(parts[1], whole[30:])
     assert whole[30:].std() > 0
+
+
+@pytest.mark.parametrize("name", ["Multipass", "MotionBlur", "Life"])
+def test_clock_loop_gives_the_frame_loops_bytes(name, monkeypatch):
+    """clockloop.ClockLoop — scenes in which only the clock moves between frames (layers, temporal history, a second program, a scene
+    pipeline() that adds a constant uniform) — against scene.next's loop: the same launches with the same uniforms, so the same bytes;
+    and it is really the loop that ran"""
+    import examples.scenes as scenes
+    from shaderflow_amd.clockloop import ClockLoop
+    kw = dict(width=96, height=54, fps=30.0, ssaa=1, time=14/30, output=bytes)
+    if name == "Multipass":
+        kw["ssaa"] = 2
+
+    def build(clock_loop: bool):
+        np.random.seed(11)                                            # Life seeds its first generation from numpy's global state
+        scene = scenes.make(getattr(scenes, name), background=synth.background_image(120, 68, seed=4)) if name != "Life" else scenes.Life()
+        scene.clock_loop = clock_loop
+        return scene
+    runs = []
+    original = ClockLoop.run
+    monkeypatch.setattr(ClockLoop, "run", lambda self, export, turbo: (runs.append(name), original(self, export, turbo))[1])
+    lean = build(True).main(**kw)
+    assert runs == [name]
+    loop = build(False).main(**kw)
+    assert runs == [name] and len(lean) == len(loop) == 14*96*54*3
+    assert lean == loop, f"{np.count_nonzero(np.frombuffer(lean, np.uint8) != np.frombuffer(loop, np.uint8))} bytes differ"
+    # a scene with python logic between frames never qualifies, nor one whose DynamicNumbers are still moving
+    scripted = scenes.make(scenes.Dynamics, background=synth.background_image(120, 68, seed=4))
+    scripted.initialize()
+    assert not ClockLoop.applicable(scripted)
+    moving = build(True)
+    moving.initialize()
+    moving.camera.zoom.target = 2.0
+    assert not ClockLoop.applicable(moving)
