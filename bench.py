@@ -7,12 +7,12 @@ bench.py — frames/s of the music-visualizer export path on MI355X.
 
 Workload (BASELINE.json metric config, `configs[2]`): Visualizer scene, 3840x2160, 2x SSAA, subsample 2, 60 fps,
 synthetic 44.1 kHz stereo sine sweep, synthetic 1920x1080 background; inputs resident in HBM before timing.
-One STEP = one batch of 60 frames (1 s of video) through the whole hot path: STFT of the 60 frames → filterbank →
-DynamicNumber scan → waveform/loudness → per-frame column/row tables → 60 fused fragment+SSAA-resolve frames written as
-RGB8 into a device frame buffer.
+One STEP = one batch of 300 frames (5 s of video; --frames-per-step) through the whole hot path: STFT of the batch's frames →
+filterbank → DynamicNumber scan → waveform/loudness → per-frame column/row tables → the batch's fused fragment+SSAA-resolve
+frames written as RGB8 into a device frame buffer (two alternating buffers of 7.5 GB each).
 
 N > 1 (one rank per GPU, weak scaling): rank r renders ITS OWN contiguous range of the clip — frames
-[r*(W+K)*60, (r+1)*(W+K)*60) — after replaying the DynamicNumber recurrences of everything before it (untimed set-up, as
+[r*(W+K)*F, (r+1)*(W+K)*F) — after replaying the DynamicNumber recurrences of everything before it (untimed set-up, as
 in the sharded export's device mode, shaderflow_amd/parallel.py), and every finished step is sent to rank 0 over
 RCCL/xGMI (grouped point-to-point = the gather of the north star), the transfer of step i overlapping the render of
 step i+1. `value` = frames of all ranks / max-over-ranks time: frames resident in rank 0's HBM.
@@ -64,7 +64,9 @@ def parse_args():
     p.add_argument("--width", type=int, default=3840)
     p.add_argument("--height", type=int, default=2160)
     p.add_argument("--ssaa", type=int, default=2)
-    p.add_argument("--frames-per-step", type=int, default=60)
+    p.add_argument("--frames-per-step", type=int, default=300,
+                   help="frames of one step = one batch through the hot path = ONE launch of the dominant kernel (grid.z); 300 = 5 s of video, "
+                        "so that the driver's 20 timed steps are 2 s of GPU time (round 3's 60-frame steps: 0.41 s, too short for its utilisation sampler)")
     p.add_argument("--seconds", type=float, default=60.0, help="length of the synthetic clip (grown when the ranks need more frames)")
     p.add_argument("--scene", choices=("visualizer", "bars", "waveform", "basic"), default="visualizer",
                    help="visualizer = the metric's scene; bars = MusicBars, waveform = Waveform, basic = Basic (default.glsl): light fragments")
@@ -74,13 +76,34 @@ def parse_args():
     return p.parse_args()
 
 
+def host_cores() -> tuple[int, str]:
+    """Cores this process may really use: the CPUs it may be scheduled on, capped by the cgroup's CPU quota. The pool's GPU boxes show
+    256 logical CPUs and grant 16 CPUs' worth of time (cpu.max = 1600000 100000): round 3's "0.064 frames/s on 256 threads" was 16
+    cores throttled by 256 runnable threads (tools/experiments/oracle_scaling.py: 17.7x one thread at 16 threads, 12x at 256)."""
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        limit, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if limit != "max":
+            quota = max(1, int(float(limit)/float(period) + 0.5))
+    except (OSError, ValueError):
+        try:
+            limit, period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if limit > 0:
+                quota = max(1, int(limit/period + 0.5))
+        except (OSError, ValueError):
+            pass
+    cores = min(visible, quota) if quota else visible
+    return cores, f"{visible} logical CPUs visible, cgroup quota {quota if quota else 'none'}"
+
+
 def cpu_baseline(args, pcm, background) -> dict:
     """Oracle on the host cores: bands of THREE frames of the same workload on all cores, one band on a single thread."""
     import numpy as np
 
     from oracle import binding as O
     w, h, s = args.width, args.height, args.ssaa
-    threads = os.cpu_count() or 1
+    threads, quota = host_cores()
     planar = np.ascontiguousarray(pcm.T)
     fmin, fmax, bins = O.from_notes(O.lib().sfo_note_of_frequency(20.0, 440.0), O.lib().sfo_note_of_frequency(14000.0, 440.0), True)
     indptr, indices, data = O.filterbank(0, 0, fmin, fmax, bins, 12, 44100)
@@ -125,7 +148,7 @@ def cpu_baseline(args, pcm, background) -> dict:
     rows_one = int(max(1, min(rows_all, budget_one/max(probe_one, 1e-6))))
     seconds_one = band(u, tex, (h - rows_one)//2, rows_one, 1)
     frame_s_one = seconds_one*(h/rows_one) + audio_all/len(frames)
-    return {"value": 1.0/frame_s_all, "unit": "frames/s", "cores": threads, "kind": "port",
+    return {"value": 1.0/frame_s_all, "unit": "frames/s", "cores": threads, "kind": "port", "host": quota,
             "single_thread": {"value": 1.0/frame_s_one, "unit": "frames/s", "cores": 1,
                               "sample": f"{rows_one} of {h} output rows of one frame ({seconds_one:.1f} s), scaled to a whole frame"},
             "sample": f"{rows_all} of {h} output rows of each of {len(frames)} frames {frames} of the {w}x{h} {s}xSSAA visualizer clip "

@@ -20,7 +20,7 @@ from tests.helpers import Gpu, gpu_bind_all, i16_to_f32, oracle_textures, visual
 from tests.test_oracle_mesa import c3_inputs                      # noqa: E402
 
 G = np.load(ROOT/"tests"/"golden"/"mesa.npz")
-THREADS = os.cpu_count() or 8
+THREADS = min(os.cpu_count() or 8, 16)
 
 
 def histogram(tag: str, got: np.ndarray, want: np.ndarray) -> None:
