@@ -201,6 +201,9 @@ __device__ __forceinline__ DefaultSlope default_slope(const DefaultRing& centre,
 }
 __device__ __forceinline__ bool default_shares_hue(float width, float len, float off) { return 0.955f*width*off < 4.0e-5f*len; }
 
+#ifndef SEP_DEFAULT_FLOAT_MEAN
+#define SEP_DEFAULT_FLOAT_MEAN 1        // 0: every pixel of the shared tier resolved from its four quantised samples (round 3), for A/B
+#endif
 // which samples of the 2 x 2 block at sample row j0 are inside the runs of its two columns (bit y*2 + x, the block's texel order)
 __device__ __forceinline__ bool row_in_run(int run, int j) { return (unsigned)(j - (run & 0xffff)) < ((unsigned)run >> 16); }
 __device__ __forceinline__ int wave_pattern(int run0, int run1, int j0) {
@@ -309,14 +312,36 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(8)))
                 if (shared) { hue = default_hue(cx, cy, hue_shift); slope = default_slope(centre, cx, cy); slope_y = cy; }
             }
             DefaultBytes bytes = {0u, 0u, 0u};
+            bool meaned = false;
             if (shared) {                                             // one ring and one hue for the samples, the ring's width to first order
                 const float lower = fmaf(slope.y, r0.x - slope_y, centre.width*255.0f), upper = fmaf(slope.y, r1.x - slope_y, centre.width*255.0f);
                 const float side = slope.x*(0.5f*(c1.x - c0.x));
                 const bool disc = centre.circle < 0.0f;
+#if SEP_DEFAULT_FLOAT_MEAN
+                // Round 4: where the four samples also share their base colour (the disc, or one square of the checkerboard) the
+                // pixel is resolved in FLOAT: mean_k vig_k*(base + w_k*hue) = base*V/4 + hue*R/4 with V = sum vig_k and
+                // R = sum vig_k*w_k, w = {lower, upper} -/+ side — 16 operations instead of 4 x 8 + the byte sums. The reference
+                // quantises every sample first: the mean of four roundings is within 1/2 of the mean, so the two bytes are
+                // roundings of numbers within 1/2 of each other: they differ by at most ONE, the tolerance of every fused
+                // kernel (no sample saturates in the shared tier: |circle| > 0.1 keeps the ring term under 0.03).
+                const bool one_base = disc || ((odd_column0 == odd_column1) && (((__float_as_int(r0.y) ^ __float_as_int(r1.y)) & 1) == 0));
+                if (one_base && !outside) {
+                    const float below = vignette[0] + vignette[1], above = vignette[2] + vignette[3];
+                    const float across = (vignette[1] - vignette[0]) + (vignette[3] - vignette[2]);
+                    const float ring = fmaf(side, across, fmaf(upper, above, lower*below))*0.25f;
+                    const float ground = (disc ? DEFAULT_DISC : board[0])*(0.25f*(below + above));
+                    rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.red, ground), 0u, 0u);
+                    rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.green, ground), 1u, rgb);
+                    rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.blue, ground), 2u, rgb);
+                    meaned = true;
+                }
+#endif
+                if (!meaned) {
                 default_colour<0>(bytes, hue, lower - side, disc ? DEFAULT_DISC : board[0], vignette[0]);
                 default_colour<1>(bytes, hue, lower + side, disc ? DEFAULT_DISC : board[1], vignette[1]);
                 default_colour<2>(bytes, hue, upper - side, disc ? DEFAULT_DISC : board[2], vignette[2]);
                 default_colour<3>(bytes, hue, upper + side, disc ? DEFAULT_DISC : board[3], vignette[3]);
+                }
             } else {                                                  // the ring per sample; the hue at the centre if it may be, else per sample
                 const float ux[4] = {c0.x, c1.x, c0.x, c1.x}, uy[4] = {r0.x, r0.x, r1.x, r1.x};
                 DefaultRing ring[4];
@@ -357,8 +382,9 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(8)))
             // final.glsl's mean of the four RGBA8 texels as an INTEGER mean per channel, (sum + 2) >> 2 with the sum of a register's
             // four bytes from v_sad_u8: what resolve_channel's float chain gives except on ties (sum = 2 mod 4), which its rounding
             // noise decides either way — 1 LSB, like every approximation of this kernel (8 instructions instead of 60)
-            rgb = (__builtin_amdgcn_sad_u8(bytes.red, 0u, 2u) >> 2) | ((__builtin_amdgcn_sad_u8(bytes.green, 0u, 2u) >> 2) << 8)
-                | ((__builtin_amdgcn_sad_u8(bytes.blue, 0u, 2u) >> 2) << 16);
+            if (!meaned)
+                rgb = (__builtin_amdgcn_sad_u8(bytes.red, 0u, 2u) >> 2) | ((__builtin_amdgcn_sad_u8(bytes.green, 0u, 2u) >> 2) << 8)
+                    | ((__builtin_amdgcn_sad_u8(bytes.blue, 0u, 2u) >> 2) << 16);
         }
         uint8_t* s = &staged[r][tid*3];
         s[0] = (uint8_t)rgb; s[1] = (uint8_t)(rgb >> 8); s[2] = (uint8_t)(rgb >> 16);
