@@ -279,6 +279,7 @@ struct EngineLanes {
         resolved = true; c = context;
         e = engine_copy(context, host, device);
         if (e) for (auto& signal : done) if (hsa_signal_create(0, 0, nullptr, &signal) != HSA_STATUS_SUCCESS) { e = nullptr; break; }
+        if (!e) (void)context_copy_streams(context);                  // the lanes are HIP copy streams then
     }
     // false: the copy could not be queued on any route
     bool issue(int lane, void* host, const void* device, size_t nbytes) {
@@ -291,6 +292,7 @@ struct EngineLanes {
             }
             if (status == HSA_STATUS_SUCCESS) { busy[lane] = true; return true; }
             e = nullptr;                                             // HSA refuses: HIP's copy from here on
+            if (context_copy_streams(c) != SFX_OK) return false;
         }
         if (hipMemcpyAsync(host, device, nbytes, hipMemcpyDeviceToHost, c->copy_streams[lane]) != hipSuccess) { (void)hipGetLastError(); return false; }
         busy[lane] = true;
@@ -335,9 +337,9 @@ extern "C" int sfx_ctx_create(int device_id, void* stream, sfx_handle* out) {
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     for (auto& e : c->events) HIP_TRY(hipEventCreate(&e));
     build_tap_table(c->tap_x, c->tap_y);
-    // the copy streams NOW, before any other stream of this context exists (a tape's audio stream, …): chosen after a tape had run on
-    // the context, the same export read out at 36.4 ms per 60 frames instead of 27.9 (tools/experiments/export_like_bench.py)
-    if (int rc = context_copy_streams(c)) { delete c; return rc; }
+    // (the copy streams are chosen on first use: peer windows, or a read-out that HSA refuses. Chosen HERE, before the tape's audio
+    // stream exists, they cost the light kernels the overlap of audio and render — MusicBars 188 000 → 129 000 frames/s; the
+    // read-out rings, which needed them early, no longer run on streams at all)
     *out = handle_of(c);
     return SFX_OK;
 }
