@@ -422,7 +422,18 @@ def main() -> None:
         scene2.main(width=w, height=h, ssaa=s, fps=60.0, time=frames_export/60.0, output="/dev/null")
         barrier()
         took = time.perf_counter() - t1
-        export = {"value": round(frames_export/took, 2), "unit": "frames/s", "frames": frames_export, "seconds": round(took, 3),
+        planar = None
+        if world == 1 and not distributed:
+            # the same export with the frames converted to planar yuv420p on the device (scene.main(pixel_format="yuv420p"), opt-in:
+            # SURVEY §8 f1's optional half): 12.4 MB per frame over PCIe instead of 24.9
+            scene3 = build_scene(prepared=False)
+            barrier()
+            t2 = time.perf_counter()
+            scene3.main(width=w, height=h, ssaa=s, fps=60.0, time=frames_export/60.0, output="/dev/null", pixel_format="yuv420p")
+            barrier()
+            planar = {"value": round(frames_export/(time.perf_counter() - t2), 2), "unit": "frames/s", "frames": frames_export,
+                      "note": "BT.601 limited range, chroma from the rounded 2x2 mean; not the reference's byte stream (it hands ffmpeg rgb24)"}
+        export = {"value": round(frames_export/took, 2), "unit": "frames/s", "frames": frames_export, "seconds": round(took, 3), "yuv420p": planar,
                   "mode": ("pinned ring + writer thread" if world == 1 else f"sharded export, SHADERFLOW_SHARD={os.environ.get('SHADERFLOW_SHARD', 'host')}"),
                   "note": "whole scene.main(): tape schedule, table set-up, render, read-out over PCIe, write to /dev/null"}
 

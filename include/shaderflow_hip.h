@@ -180,6 +180,12 @@ int sfx_ring_pipe(sfx_handle ring, int slot, int fd);                           
 int sfx_ring_pipe_sync(sfx_handle ring, int slot);                                  /* turbopipe.sync; slot < 0: all */
 int sfx_ring_destroy(sfx_handle ring);
 
+/* Encoder hand-off, optional half (exporting.py:94-134): `frames` RGB8 frames (consecutive, width*height*3 bytes each) on
+ * the device → planar yuv420p (I420: Y, U, V; width*height*3/2 bytes each) on the device, on the context's stream. BT.601 limited
+ * range (matrix 0) or BT.709 limited (1) in 8-bit integer arithmetic, chroma from the rounded 2x2 mean of R, G, B — defined in
+ * capi.hip, restated in the oracle. Half the bytes over PCIe and the pipe: ffmpeg takes `-pix_fmt yuv420p` rawvideo as it is. */
+int sfx_rgb_to_yuv420(sfx_handle ctx, const void* rgb, void* yuv, int width, int height, int frames, int matrix);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* Cross-process frame queue of a sharded export (one process per GPU; no reference equivalent). The sink takes
  * one byte stream, so one process owns it (rank 0) — but every rank reads its finished frames out over its OWN PCIe link into a

@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
         L.sfo_resolve.argtypes = [P(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_uint8)]
         L.sfo_sample.argtypes = [P(Texture), C.c_float, C.c_float, P(C.c_float)]
         L.sfo_set_llvmpipe_filter.argtypes = [C.c_int]
+        L.sfo_rgb_to_yuv420.argtypes = [P(C.c_uint8), C.c_int, C.c_int, C.c_int, P(C.c_uint8)]
         L.sfo_sample_quad.argtypes = [P(Texture)] + [C.c_float]*6 + [P(C.c_float)]
         L.sfo_mip_levels.argtypes = [C.c_int, C.c_int]
         L.sfo_mip_levels.restype = C.c_int
@@ -316,6 +317,15 @@ def resolve(screen: np.ndarray, w: int, h: int, subsample: int,
     out = np.zeros((h, w, 3), np.uint8)
     y0, y1 = rows or (0, h)
     lib().sfo_resolve(_p(screen, C.c_uint8), wr, hr, w, h, subsample, y0, y1, threads, _p(out, C.c_uint8))
+    return out
+
+
+def rgb_to_yuv420(frame: np.ndarray, matrix: int = 0) -> np.ndarray:
+    """(h, w, 3) uint8 → the w*h*3/2 bytes of planar yuv420p, rows in the frame's own order"""
+    frame = np.ascontiguousarray(frame, np.uint8)
+    h, w = frame.shape[:2]
+    out = np.zeros(w*h*3//2, np.uint8)
+    lib().sfo_rgb_to_yuv420(_p(frame, C.c_uint8), w, h, matrix, _p(out, C.c_uint8))
     return out
 
 

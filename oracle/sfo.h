@@ -200,6 +200,10 @@ void sfo_resolve(const uint8_t* screen, int wr, int hr, int w, int h, int subsam
  * (tests/test_oracle_mesa.py); parity tests of the HIP kernels run with it off. Process-wide; set it outside sfo_render calls. */
 void sfo_set_llvmpipe_filter(int on);
 
+/* RGB8 (w x h, even) → planar yuv420p (w*h*3/2 bytes): the product's own definition of the optional device-side conversion
+ * (sfx_rgb_to_yuv420), restated; matrix 0 = BT.601 limited, 1 = BT.709 limited */
+void sfo_rgb_to_yuv420(const uint8_t* rgb, int w, int h, int matrix, uint8_t* yuv);
+
 /* GL `texture()` on one coordinate, exposed for sampler unit tests */
 void sfo_sample(const sfo_texture* t, float s, float tt, float rgba[4]);
 

@@ -264,6 +264,32 @@ static v4 sample(const sfo_texture* t, v2 uv) {
     return r;
 }
 
+/* The optional half of the encoder hand-off: RGB8 → planar yuv420p, the arithmetic the product DEFINES for it
+ * (shaderflow_amd/csrc/capi.hip k_rgb_to_yuv420; there is no reference implementation to restate — the reference leaves the conversion
+ * to ffmpeg's swscale, and no ffmpeg binary exists here). matrix 0: BT.601 limited range, 1: BT.709 limited range; 8-bit integer
+ * coefficients, arithmetic shifts, chroma from the rounded mean of the 2x2 block's R, G, B. */
+void sfo_rgb_to_yuv420(const uint8_t* rgb, int w, int h, int matrix, uint8_t* yuv) {
+    static const int M[2][9] = {{66, 129, 25, -38, -74, 112, 112, -94, -18}, {47, 157, 16, -26, -86, 112, 112, -102, -10}};
+    const int* m = M[matrix == 1];
+    uint8_t* u_plane = yuv + (int64_t)w*h;
+    uint8_t* v_plane = u_plane + (int64_t)(w/2)*(h/2);
+    for (int by = 0; by < h/2; by++) {
+        for (int bx = 0; bx < w/2; bx++) {
+            int sr = 0, sg = 0, sb = 0;
+            for (int y = 0; y < 2; y++) {
+                for (int x = 0; x < 2; x++) {
+                    const uint8_t* p = rgb + ((int64_t)(2*by + y)*w + 2*bx + x)*3;
+                    sr += p[0]; sg += p[1]; sb += p[2];
+                    yuv[(int64_t)(2*by + y)*w + 2*bx + x] = (uint8_t)(((m[0]*p[0] + m[1]*p[1] + m[2]*p[2] + 128) >> 8) + 16);
+                }
+            }
+            const int r = (sr + 2) >> 2, g = (sg + 2) >> 2, b = (sb + 2) >> 2;
+            u_plane[(int64_t)by*(w/2) + bx] = (uint8_t)(((m[3]*r + m[4]*g + m[5]*b + 128) >> 8) + 128);
+            v_plane[(int64_t)by*(w/2) + bx] = (uint8_t)(((m[6]*r + m[7]*g + m[8]*b + 128) >> 8) + 128);
+        }
+    }
+}
+
 void sfo_sample_quad(const sfo_texture* t, float s, float tt, float s_right, float t_right, float s_above, float t_above, float rgba[4]) {
     g_lod.mode = LOD_REPLAY; g_lod.count = 0;
     g_lod.ux[0] = s_right*(float)t->width; g_lod.vx[0] = t_right*(float)t->height;

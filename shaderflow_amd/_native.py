@@ -111,6 +111,7 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_ring_pipe": (C.c_int, [Handle, C.c_int, C.c_int]),
     "sfx_ring_pipe_sync": (C.c_int, [Handle, C.c_int]),
     "sfx_ring_destroy": (C.c_int, [Handle]),
+    "sfx_rgb_to_yuv420": (C.c_int, [Handle, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sfx_peer_export": (C.c_int, [Handle, C.c_void_p, C.c_void_p]),
     "sfx_peer_open": (C.c_int, [Handle, C.c_void_p, P(C.c_void_p)]),
     "sfx_peer_close": (C.c_int, [Handle, C.c_void_p]),
@@ -233,6 +234,10 @@ class Context:
 
     def free(self, ptr: int) -> None:
         check(lib().sfx_device_free(self.handle, C.c_void_p(ptr)))
+
+    def rgb_to_yuv420(self, rgb: int, yuv: int, width: int, height: int, frames: int = 1, matrix: int = 0) -> None:
+        """`frames` consecutive RGB8 frames on the device → planar yuv420p on the device (sfx_rgb_to_yuv420), on the context's stream"""
+        check(lib().sfx_rgb_to_yuv420(self.handle, C.c_void_p(rgb), C.c_void_p(yuv), width, height, frames, matrix))
 
     def copy(self, dst: int, src: int, nbytes: int) -> None:
         check(lib().sfx_device_copy(self.handle, C.c_void_p(dst), C.c_void_p(src), nbytes))

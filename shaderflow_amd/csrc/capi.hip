@@ -1836,6 +1836,54 @@ extern "C" int sfx_ring_destroy(sfx_handle h) {
     return SFX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Encoder hand-off, optional half (exporting.py:94-134 hands rgb24 to ffmpeg, whose swscale converts to the codec's
+// yuv420p on the CPU): planar 4:2:0 on the device halves what crosses PCIe and the pipe. The arithmetic is DEFINED here (no ffmpeg
+// binary exists in this environment to pin swscale's against): BT.601 limited range in the classic 8-bit integer form,
+//   Y = ((66 R + 129 G + 25 B + 128) >> 8) + 16 per pixel; chroma from the rounded mean of the 2 x 2 block's R, G, B
+//   ((sum + 2) >> 2): U = ((-38 R - 74 G + 112 B + 128) >> 8) + 128, V = ((112 R - 94 G - 18 B + 128) >> 8) + 128
+// (arithmetic shifts; `matrix` 1: BT.709 limited, 47/157/16, -26/-86/112, 112/-102/-10). Rows keep the RGB frame's order.
+// Layout I420: Y (h rows of w), U (h/2 rows of w/2), V. The parity oracle restates it in C (sfo_rgb_to_yuv420).
+struct YuvMatrix { int yr, yg, yb, ur, ug, ub, vr, vg, vb; };
+__device__ __forceinline__ YuvMatrix yuv_matrix(int matrix) {
+    return matrix == 1 ? YuvMatrix{47, 157, 16, -26, -86, 112, 112, -102, -10} : YuvMatrix{66, 129, 25, -38, -74, 112, 112, -94, -18};
+}
+__global__ __launch_bounds__(256) void k_rgb_to_yuv420(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ yuv, int w, int h, long rgb_stride, long yuv_stride, int matrix) {
+    const int bx = blockIdx.x*blockDim.x + threadIdx.x, by = blockIdx.y;          // one 2 x 2 block of pixels per thread
+    if (bx >= w/2 || by >= h/2) return;
+    const YuvMatrix m = yuv_matrix(matrix);
+    const uint8_t* frame = rgb + (long)blockIdx.z*rgb_stride;
+    uint8_t* out = yuv + (long)blockIdx.z*yuv_stride;
+    int sum_r = 0, sum_g = 0, sum_b = 0;
+#pragma unroll
+    for (int y = 0; y < 2; y++) {
+        const uint8_t* p = frame + ((long)(2*by + y)*w + 2*bx)*3;
+        uint8_t luma[2];
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+            const int r = p[3*x], g = p[3*x + 1], b = p[3*x + 2];
+            sum_r += r; sum_g += g; sum_b += b;
+            luma[x] = (uint8_t)(((m.yr*r + m.yg*g + m.yb*b + 128) >> 8) + 16);
+        }
+        *(uchar2*)(out + (long)(2*by + y)*w + 2*bx) = make_uchar2(luma[0], luma[1]);
+    }
+    const int r = (sum_r + 2) >> 2, g = (sum_g + 2) >> 2, b = (sum_b + 2) >> 2;
+    uint8_t* u_plane = out + (long)w*h;
+    uint8_t* v_plane = u_plane + (long)(w/2)*(h/2);
+    u_plane[(long)by*(w/2) + bx] = (uint8_t)(((m.ur*r + m.ug*g + m.ub*b + 128) >> 8) + 128);
+    v_plane[(long)by*(w/2) + bx] = (uint8_t)(((m.vr*r + m.vg*g + m.vb*b + 128) >> 8) + 128);
+}
+
+extern "C" int sfx_rgb_to_yuv420(sfx_handle h, const void* rgb, void* yuv, int width, int height, int frames, int matrix) {
+    CTX_OR_FAIL(c, h);
+    if (!rgb || !yuv || width < 2 || height < 2 || (width & 1) || (height & 1) || frames < 1 || matrix < 0 || matrix > 1)
+        return fail(SFX_E_INVALID, "rgb → yuv420p of %d frame(s) of %dx%d (even extents only), matrix %d", frames, width, height, matrix);
+    USE_DEVICE(c);
+    hipLaunchKernelGGL(k_rgb_to_yuv420, dim3((width/2 + 255)/256, height/2, frames), dim3(256), 0, c->stream, (const uint8_t*)rgb, (uint8_t*)yuv, width, height,
+                       (long)width*height*3, (long)width*height*3/2, matrix);
+    return launch_status();
+}
+
 #include "shm_ring.inc"
 #include "flac.inc"
 

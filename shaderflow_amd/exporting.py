@@ -54,6 +54,12 @@ class ExportingHelper:
     file: Any = None
     fileno: Optional[int] = None
     top_down: Optional[bool] = None       # None: top-down exactly when an ffmpeg process is the sink
+    pixel_format: str = "rgb24"
+    """What the sink receives: "rgb24" — the reference's byte stream (exporting.py:97) — or "yuv420p": planar 4:2:0 made on the device
+    (sfx_rgb_to_yuv420: BT.601 limited range, or `yuv_matrix = "bt709"`), half the bytes over PCIe and the pipe; ffmpeg takes it as
+    `-pix_fmt yuv420p` rawvideo and the codec's own conversion falls away. Opt-in: `scene.main(pixel_format="yuv420p")`."""
+    yuv_matrix: str = "bt601"
+    _yuv_slots: list = Factory(list)      # device staging of the frame loop's converted frames, one per ring slot
 
     # ring
     ring: Optional[N.Handle] = None
@@ -62,6 +68,19 @@ class ExportingHelper:
     @property
     def total_frames(self) -> int:
         return max(1, round(self.scene.runtime*self.scene.fps))
+
+    @property
+    def planar(self) -> bool:
+        return self.pixel_format == "yuv420p"
+
+    @property
+    def frame_bytes(self) -> int:
+        """Bytes of one frame as the sink receives it"""
+        pixels = self.scene.width*self.scene.height
+        return pixels*3//2 if self.planar else pixels*3
+
+    def to_yuv(self, rgb: int, yuv: int, frames: int = 1) -> None:
+        self.scene.context.rgb_to_yuv420(rgb, yuv, self.scene.width, self.scene.height, frames, 1 if self.yuv_matrix == "bt709" else 0)
 
     @property
     def finished(self) -> bool:
@@ -86,7 +105,11 @@ class ExportingHelper:
 
     def ffmpeg_sizes(self, width: int, height: int) -> None:
         self.ffmpeg.time = self.scene.runtime
-        self.ffmpeg.pipe_input(pixel_format="rgb24", width=self.scene.width, height=self.scene.height, framerate=self.scene.fps)
+        if self.pixel_format not in ("rgb24", "yuv420p"):
+            raise ValueError(f"pixel_format {self.pixel_format!r}: 'rgb24' (the reference's stream) or 'yuv420p' (converted on the device)")
+        if self.planar and (self.scene.width % 2 or self.scene.height % 2):
+            raise ValueError(f"yuv420p needs even extents, the scene is {self.scene.width}x{self.scene.height}")
+        self.ffmpeg.pipe_input(pixel_format=self.pixel_format, width=self.scene.width, height=self.scene.height, framerate=self.scene.fps)
         self.ffmpeg.scale(width=width, height=height)
         self.ffmpeg.vflip()
 
@@ -138,13 +161,18 @@ class ExportingHelper:
     def make_buffers(self, n: int = 2) -> None:
         self.release_buffers()
         handle = N.Handle()
-        N.check(N.lib().sfx_ring_create(self.scene.context.handle, self.scene._final.texture.size_t, max(1, n), C.byref(handle)))
+        N.check(N.lib().sfx_ring_create(self.scene.context.handle, self.frame_bytes, max(1, n), C.byref(handle)))
         self.ring, self.slots = handle, max(1, n)
+        if self.planar:
+            self._yuv_slots = [self.scene.context.alloc(self.frame_bytes) for _ in range(self.slots)]
 
     def release_buffers(self) -> None:
         if self.ring is not None and self.ring.value:
             N.check(N.lib().sfx_ring_pipe_sync(self.ring, -1))
             N.lib().sfx_ring_destroy(self.ring)
+        for pointer in self._yuv_slots:
+            self.scene.context.free(pointer)
+        self._yuv_slots = []
         self.ring, self.slots = None, 0
 
     def _check_encoder(self) -> None:
@@ -166,7 +194,13 @@ class ExportingHelper:
             return
         self._check_encoder()
         slot = self.frame % self.slots
-        N.check(N.lib().sfx_ring_read_async(self.ring, self.scene._final.texture.texture.handle, slot))
+        if self.planar:
+            # the slot's last frame has left its staging buffer; then convert (on the render stream, in order with the draws) and read out
+            N.check(N.lib().sfx_ring_pipe_sync(self.ring, slot))
+            self.to_yuv(self.scene._final.texture.texture.device_ptr(), self._yuv_slots[slot])
+            N.check(N.lib().sfx_ring_read_device_async(self.ring, C.c_void_p(self._yuv_slots[slot]), slot))
+        else:
+            N.check(N.lib().sfx_ring_read_async(self.ring, self.scene._final.texture.texture.handle, slot))
         N.check(N.lib().sfx_ring_pipe(self.ring, slot, self.fileno))
         if not turbo:
             N.check(N.lib().sfx_ring_pipe_sync(self.ring, slot))
@@ -192,6 +226,10 @@ class ExportingHelper:
             return
         self._check_encoder()
         slot = self.frame % self.slots
+        if self.planar and not getattr(self, "_device_frames_are_planar", False):
+            N.check(N.lib().sfx_ring_pipe_sync(self.ring, slot))     # (an RGB frame in a device buffer: the sharded frame loop's path)
+            self.to_yuv(device_ptr, self._yuv_slots[slot])
+            device_ptr, fence = self._yuv_slots[slot], None
         if fence is None:
             N.check(N.lib().sfx_ring_read_device_async(self.ring, C.c_void_p(device_ptr), slot))
         else:

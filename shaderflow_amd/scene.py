@@ -298,13 +298,15 @@ class ShaderScene(ShaderModule):
         batch: Optional[bool] = None,
         top_down: Optional[bool] = None,
         shard: Optional[tuple[int, int]] = None,
+        pixel_format: Optional[str] = None,
     ) -> Optional[Union[Path, bytes]]:
         """Render the scene to `output` (scene.py:493-639). `output` may be a path (raw rgb24 frames, or a video
         when an `ffmpeg` binary exists), "pipe"/"-"/bytes (returns the raw frames), or None with freewheel=True
         (renders without writing). `batch`: None = frame tape when the scene allows it, False = frame loop.
         `top_down`: write frame rows top-down on the device (None = exactly when an ffmpeg process is the sink).
         `shard`: (rank, world) to run ONE rank's share of a sharded frame-loop export without a process group (tests,
-        external launchers); with torch.distributed initialised the group's rank and size are used."""
+        external launchers); with torch.distributed initialised the group's rank and size are used.
+        `pixel_format`: "rgb24" (default: the reference's stream) or "yuv420p" — converted on the device (ExportingHelper.pixel_format)."""
         self.initialize()
         self.exporting = (bool(output))
         self.freewheel = (self.exporting or freewheel)
@@ -335,7 +337,9 @@ class ShaderScene(ShaderModule):
         else:
             self.ssaa = ssaa
 
-        export = ExportingHelper(self, top_down=top_down)
+        export = ExportingHelper(self, top_down=top_down, pixel_format=(pixel_format or os.environ.get("SHADERFLOW_PIXEL_FORMAT") or "rgb24"))
+        if export.planar and (is_sharded() or shard is not None):
+            raise NotImplementedError("pixel_format='yuv420p' is a single-process option (the sharded modes move rgb24 frames)")
         if (self.exporting):
             # Every rank of a sharded export resolves the sink the same way — its kind decides the row order the kernels write
             # (exporting.py:94-118) — but only rank 0 opens it and owns the read-out ring (tape.py, _sharded_frame_loop)

@@ -237,8 +237,8 @@ class FrameTape:
         context = scene.context
         batches = shard_batches(0, total, self.batch)
 
-        def emit_frames(pointer: int, count: int, fence: Optional[int] = None) -> None:
-            export.pipe_device_frames(pointer, frame_bytes, count, turbo=turbo, fence=fence)
+        def emit_frames(pointer: int, count: int, fence: Optional[int] = None, stride: int = frame_bytes) -> None:
+            export.pipe_device_frames(pointer, stride, count, turbo=turbo, fence=fence)
 
         mode = shard_mode() if is_sharded() else "single"
         if mode.startswith("device"):
@@ -259,18 +259,26 @@ class FrameTape:
         try:
             if mode == "single":
                 buffers = [context.alloc(frame_bytes*self.batch) for _ in range(2)]
+                # pixel_format "yuv420p": every batch is converted on the device right behind its render (12 bytes of 8 read and 1.5
+                # written per pixel: microseconds) and the PLANAR frames are what crosses PCIe — half the bytes
+                planar = [context.alloc(export.frame_bytes*self.batch) for _ in range(2)] if export.planar else None
+                export._device_frames_are_planar = export.planar
+
+                def render_batch(which: int, count: int) -> None:
+                    self.render(count, buffers[which])
+                    if planar is not None:
+                        export.to_yuv(buffers[which], planar[which], count)
+                    export.fence(which)
                 try:
                     # software pipeline: batch b+1 is rendering while the frames of batch b travel to the host
                     self.build(*batches[0])
-                    self.render(batches[0][1], buffers[0])
-                    export.fence(0)
+                    render_batch(0, batches[0][1])
                     for index, (first, count) in enumerate(batches):
                         if index + 1 < len(batches):
                             export.render_waits_for_last_read()          # buffers[(index+1) % 2] held batch index-1
                             self.build(*batches[index + 1])
-                            self.render(batches[index + 1][1], buffers[(index + 1) % 2])
-                            export.fence((index + 1) % 2)
-                        emit_frames(buffers[index % 2], count, fence=index % 2)
+                            render_batch((index + 1) % 2, batches[index + 1][1])
+                        emit_frames((planar or buffers)[index % 2], count, fence=index % 2, stride=export.frame_bytes)
                     # leave the last frame in iFinal, where the frame loop would have left it (scene.screenshot(), scene.py:439-443)
                     context.synchronize()
                     last = context.read(buffers[(len(batches) - 1) % 2] + (batches[-1][1] - 1)*frame_bytes, frame_bytes)
@@ -278,7 +286,8 @@ class FrameTape:
                     scene._final.texture.texture.write(np.ascontiguousarray(last[::-1] if export.top_down else last))
                 finally:
                     context.synchronize()
-                    for pointer in buffers:
+                    export._device_frames_are_planar = False
+                    for pointer in buffers + (planar or []):
                         context.free(pointer)
             elif mode == "host":
                 # every rank reads its own batches out over its own PCIe link into shared memory; rank 0's writer thread hands
