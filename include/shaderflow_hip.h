@@ -84,6 +84,10 @@ int sfx_ctx_output_top_down(sfx_handle ctx, int enabled);
  * Candidates are created until two are found whose copies complete while a kernel holds the render stream. Reports how many
  * streams were looked at and how many of them ran in series with the render stream (either may be NULL). */
 int sfx_ctx_copy_streams(sfx_handle ctx, int* candidates, int* colliding);
+/* Tuning aid for the LDS-tiled visualizer kernels: the number of blocks, since the previous call, whose tap window did not fit the
+ * tile chosen for the launch and which therefore ran the generic taps (same pixels, about 20 times slower). The first call starts
+ * the count and reports 0. No counterpart in the reference. */
+int sfx_ctx_tile_misses(sfx_handle ctx, unsigned long long* blocks);
 int sfx_ctx_destroy(sfx_handle ctx);
 
 /* Timing on the context's stream with HIP events (bench.py roofline leg). slot in [0, 64). */

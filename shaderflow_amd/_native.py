@@ -76,6 +76,7 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_ctx_synchronize": (C.c_int, [Handle]),
     "sfx_ctx_output_top_down": (C.c_int, [Handle, C.c_int]),
     "sfx_ctx_copy_streams": (C.c_int, [Handle, P(C.c_int), P(C.c_int)]),
+    "sfx_ctx_tile_misses": (C.c_int, [Handle, P(C.c_ulonglong)]),
     "sfx_ctx_destroy": (C.c_int, [Handle]),
     "sfx_event_record": (C.c_int, [Handle, C.c_int]),
     "sfx_event_elapsed_ms": (C.c_int, [Handle, C.c_int, C.c_int, P(C.c_float)]),
@@ -215,6 +216,12 @@ class Context:
         candidates, colliding = C.c_int(), C.c_int()
         check(lib().sfx_ctx_copy_streams(self.handle, C.byref(candidates), C.byref(colliding)))
         return candidates.value, colliding.value
+
+    def tile_misses(self) -> int:
+        """Blocks of the LDS-tiled visualizer kernels that ran the generic taps since the previous call (the first call starts the count)"""
+        blocks = C.c_ulonglong()
+        check(lib().sfx_ctx_tile_misses(self.handle, C.byref(blocks)))
+        return blocks.value
 
     def output_top_down(self, enabled: bool) -> None:
         check(lib().sfx_ctx_output_top_down(self.handle, 1 if enabled else 0))

@@ -77,6 +77,7 @@ struct Context : Object {
     // the context's two copy streams (read-out ring, shared-memory ring, peer windows): chosen once so that neither shares a hardware
     // queue with `stream` (context_copy_streams)
     hipStream_t copy_streams[2] = {nullptr, nullptr};
+    unsigned* tile_misses = nullptr;                               // device counter of sfx_ctx_tile_misses, allocated by its first call
     int copy_candidates = 0, copy_colliding = 0;                   // how many streams the choice looked at / found serialised behind `stream`
     // read-out rings of this context: (ring, "every frame handed to it so far has left device memory"). Their copies run outside HIP's
     // queues, so hipFree's implicit wait knows nothing of them: sfx_device_free asks them first.
@@ -322,6 +323,23 @@ extern "C" int sfx_ctx_copy_streams(sfx_handle h, int* candidates, int* collidin
     return SFX_OK;
 }
 
+// Blocks of the LDS-tiled visualizer kernels whose tap window did not fit their tile (they ran the generic taps instead) since the
+// previous call; counting starts with the first call. A tuning aid: results are the same either way.
+extern "C" int sfx_ctx_tile_misses(sfx_handle h, unsigned long long* blocks) {
+    CTX_OR_FAIL(c, h);
+    USE_DEVICE(c);
+    unsigned count = 0;
+    if (!c->tile_misses) {
+        HIP_TRY(hipMalloc((void**)&c->tile_misses, sizeof(unsigned)));
+    } else {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(&count, c->tile_misses, sizeof count, hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(hipMemset(c->tile_misses, 0, sizeof(unsigned)));
+    if (blocks) *blocks = count;
+    return SFX_OK;
+}
+
 extern "C" int sfx_ctx_create(int device_id, void* stream, sfx_handle* out) {
     if (!out) return fail(SFX_E_INVALID, "null output");
     int count = 0;
@@ -377,7 +395,7 @@ extern "C" int sfx_ctx_destroy(sfx_handle h) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (auto& e : c->events) hipEventDestroy(e);
-    hipFree(c->vis_tables); hipFree(c->vis_bars); hipFree(c->resolve_tables);
+    hipFree(c->vis_tables); hipFree(c->vis_bars); hipFree(c->resolve_tables); hipFree(c->tile_misses);
     for (hipStream_t stream : c->copy_streams) if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
     delete c->engines;
     if (c->peer_ready) hipEventDestroy(c->peer_ready);
@@ -906,6 +924,7 @@ static void fill_args(const Program* p, RenderArgs& a) {
     a.axis_camera = camera_is_axis_aligned(p->u) ? 1 : 0;
     a.bg_scale_x = a.tex[TEX_BACKGROUND].data ? (float)a.tex[TEX_BACKGROUND].height/(float)a.tex[TEX_BACKGROUND].width : 1.0f;
     a.top_down = p->ctx->top_down;
+    a.tile_misses = p->ctx->tile_misses;
     a.quads = samples_mipmaps(p) ? 1 : 0;                           // the unfused kernel lays its lanes out as 2 x 2 quads: implicit derivatives
 }
 
@@ -983,27 +1002,69 @@ template <class SHADER> static void launch_render_t(const RenderArgs& a, int fra
 // visualizer.frag's taps — the numbers VisualizerShader::setup derives per block, bounded over the frames of a launch.
 // Texels per sample are zoom^2 * background.height / shaded_height on both axes (visualizer.frag:17, gtexture); on the
 // tape path the per-frame zoom and blur radius live on the device, so their largest values are used (z <= 0.93,
-// intensity <= 0.003). A moved camera scales the footprint by an unknown factor: a generous guess, and the kernel
-// still checks every block (a window that does not fit falls back to the generic taps).
+// intensity <= 0.003). A zoomed / panned camera scales each axis by its slope; any other camera (rolled, tilted) mixes the axes:
+// camera_slopes() bounds the four partial derivatives of iCamera.gluv over the screen. The kernel still checks every block
+// (a window that does not fit falls back to the generic taps), so the bound decides speed, never results.
+
+// Bounds of |d iCamera.gluv / d gluv| over the screen for a camera that is neither the identity nor axis aligned, from get_camera on
+// a 17 x 17 lattice of fragments. A camera rolled about its untouched forward axis (right.z == up.z == 0, forward == z) keeps `t` of
+// CameraRay2D constant: the map is affine and the lattice differences ARE the slopes; a tilted camera is projective, where the
+// slope inside a lattice cell can exceed the difference across it — half as much again covers it for the tilts a plane in front of
+// the camera allows before the horizon enters the screen (and the horizon itself fails the finiteness check).
+static bool camera_slopes(const RenderArgs& a, float (&slope)[2][2]) {
+    const Uniforms& u = a.u;
+    const bool affine = u.iCameraProjection == 0 && u.iCameraRight[2] == 0.0f && u.iCameraUpward[2] == 0.0f
+        && u.iCameraForward[0] == 0.0f && u.iCameraForward[1] == 0.0f && u.iCameraForward[2] == 1.0f;
+    if (u.iCameraProjection != 0) return false;          // stereoscopic jumps at the centre column, equirectangular wraps
+    constexpr int G = 16;
+    vec2 hit[G + 1][G + 1];
+    for (int j = 0; j <= G; j++) for (int i = 0; i <= G; i++) {
+        Frag f{};
+        f.u = &u; f.aspect = a.aspect;
+        f.gluv = vec2{a.aspect*(2.0f*(float)i/(float)G - 1.0f), 2.0f*(float)j/(float)G - 1.0f};
+        f.agluv = f.gluv/vec2{a.aspect, 1.0f};
+        const Camera c = get_camera(f);
+        if (!(fabsf(c.gluv.x) < 1e6f) || !(fabsf(c.gluv.y) < 1e6f)) return false;
+        hit[j][i] = c.gluv;
+    }
+    const float step_x = 2.0f*a.aspect/(float)G, step_y = 2.0f/(float)G, margin = affine ? 1.002f : 1.5f;
+    slope[0][0] = slope[0][1] = slope[1][0] = slope[1][1] = 0.0f;
+    for (int j = 0; j <= G; j++) for (int i = 0; i <= G; i++) {
+        if (i < G) {
+            slope[0][0] = fmaxf(slope[0][0], fabsf(hit[j][i + 1].x - hit[j][i].x)/step_x);
+            slope[1][0] = fmaxf(slope[1][0], fabsf(hit[j][i + 1].y - hit[j][i].y)/step_x);
+        }
+        if (j < G) {
+            slope[0][1] = fmaxf(slope[0][1], fabsf(hit[j + 1][i].x - hit[j][i].x)/step_y);
+            slope[1][1] = fmaxf(slope[1][1], fabsf(hit[j + 1][i].y - hit[j][i].y)/step_y);
+        }
+    }
+    for (auto& row : slope) for (float& v : row) v *= margin;
+    return true;
+}
+
 static void visualizer_window_bound(const RenderArgs& a, int sx, int sy, int& tw, int& th) {
     const Tex& bg = a.tex[TEX_BACKGROUND];
     const float zoom2 = a.has_vis ? a.vis.zoom2 : 0.93f*0.93f;
     const float intensity = a.has_vis ? fabsf(a.vis.intensity) : 0.003f;
-    float density = zoom2*(float)bg.height/(float)a.hr;
-    float density_x = density, density_y = density;
+    const float density = zoom2*(float)bg.height/(float)a.hr;
+    // texels along x / y per sample step along x / y
+    float xx = density, xy = 0.0f, yx = 0.0f, yy = density;
     if (a.axis_camera && !a.identity_camera) {
         // a zoomed / panned camera: iCamera.gluv is an affine function of gluv per axis (glsl.hpp camera_along_axis): its slopes
         bool behind = false;
         const float sx_ = (camera_along_axis<0>(a.u, 1.0f, a.aspect, behind) - camera_along_axis<0>(a.u, -1.0f, a.aspect, behind))/2.0f;
         const float sy_ = (camera_along_axis<1>(a.u, 1.0f, a.aspect, behind) - camera_along_axis<1>(a.u, -1.0f, a.aspect, behind))/2.0f;
-        density_x *= fabsf(sx_)*1.001f; density_y *= fabsf(sy_)*1.001f;
-        if (!(density_x == density_x) || !(density_y == density_y)) { density_x = density_y = 1e9f; }
+        xx *= fabsf(sx_)*1.001f; yy *= fabsf(sy_)*1.001f;
+        if (!(xx == xx) || !(yy == yy)) { xx = yy = 1e9f; }
     } else if (!a.identity_camera) {
-        density_x = density_y = density*2.0f*fmaxf(1.0f, fabsf(a.u.iCameraZoom));
+        float slope[2][2];
+        if (camera_slopes(a, slope)) { xx = density*slope[0][0]; xy = density*slope[0][1]; yx = density*slope[1][0]; yy = density*slope[1][1]; }
+        else xx = yy = 1e9f;
     }
     const float rx = intensity*a.bg_scale_x*(float)bg.width*1.101f + 0.001f, ry = intensity*(float)bg.height*1.101f + 0.001f;
-    tw = (int)floorf(fminf((float)(sx - 1)*density_x + 2.0f*rx, 1e6f)) + 2;
-    th = (int)floorf(fminf((float)(sy - 1)*density_y + 2.0f*ry, 1e6f)) + 2;
+    tw = (int)floorf(fminf((float)(sx - 1)*xx + (float)(sy - 1)*xy + 2.0f*rx, 1e6f)) + 2;
+    th = (int)floorf(fminf((float)(sx - 1)*yx + (float)(sy - 1)*yy + 2.0f*ry, 1e6f)) + 2;
 }
 static const size_t VIS_LDS_LIMIT = 150*1024;                         // leave room for the static shared state of the kernels
 
@@ -1389,6 +1450,31 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
                     int tw4 = 0, th4 = 0;
                     visualizer_window_bound(a, 32*4, 4*4, tw4, th4);
                     if (tw4 <= 56 && th4 <= 14) return launch_fused_s<VisualizerShader<56, 14, VIS_MIN_WAVES_S4, 1, 4, 32>>(a, ssaa, frames, s);
+                }
+                if (ssaa == 2 && !a.identity_camera && !a.axis_camera) {
+                    // a rolled or tilted camera: a block's window grows with the block's extent along BOTH axes, so squarer blocks
+                    // stage fewer cells per pixel (C3 rolled by 45 degrees: 64 x 2 pixels see 31 x 31 cells, 32 x 4 see 23 x 23)
+                    struct Shape { int px, rows; } const shapes[] = {{128, 1}, {64, 2}, {32, 4}};
+                    int best = -1, best_tw = 0, best_th = 0;
+                    float best_cost = 0.0f;
+                    static const int only = [] { const char* e = getenv("SHADERFLOW_VIS_SHAPE"); return e ? atoi(e) : -1; }();   // A/B switch for measurements
+                    for (int k = 0; k < 3; k++) {
+                        int w = 0, h = 0;
+                        if (only >= 0 && k != only) continue;
+                        visualizer_window_bound(a, shapes[k].px*2, shapes[k].rows*2, w, h);
+                        if ((size_t)w*h*48 > 72*1024) continue;                       // two 512-thread blocks per CU at least
+                        const float cost = (float)w*(float)h/(float)(shapes[k].px*shapes[k].rows);
+                        if (best < 0 || cost < best_cost) { best = k; best_cost = cost; best_tw = w; best_th = h; }
+                    }
+                    if (best >= 0) {
+                        RenderArgs d = a;
+                        d.tile_pitch = best_tw; d.tile_rows = best_th;
+                        const size_t lds = (size_t)best_tw*best_th*48;
+                        if (best == 0) return launch_fused_s<VisualizerShader<0, 0, 4, VIS_FUSED_ROWS, VIS_THREAD_ROWS, 128>>(d, ssaa, frames, s, lds);
+                        // eight waves per SIMD, not the four of the other tiles sized per launch: 555 -> 696 frames/s at C3 rolled by 17 degrees
+                        if (best == 1) return launch_fused_s<VisualizerShader<0, 0, 8, 1, 2, 64>>(d, ssaa, frames, s, lds);
+                        return launch_fused_s<VisualizerShader<0, 0, 8, 1, 4, 32>>(d, ssaa, frames, s, lds);
+                    }
                 }
                 if (ssaa != 1) {
                     // denser backgrounds (1080p output at 2x SSAA over a 1080-row background: 0.43 texel per sample; backgrounds

@@ -47,6 +47,7 @@ struct RenderArgs {
     int top_down;                    // K9: write the RGB8 frame rows top-down (the encoder's `vflip`, exporting.py:103, done here)
     float inv_wr, inv_hr;            // RN(1/wr), RN(1/hr) when the host verified glsl.hpp pixel_centre() for them, else 0
     int quads;                       // a bound sampler is mipmapped: k_render covers 32 x 2 pixels per wave as 2 x 2 quads (64 x 4 blocks), helper lanes shaded
+    unsigned* tile_misses;           // when set (sfx_ctx_tile_misses): counts the blocks of the LDS-tiled kernels that fell back to the generic taps
 #ifdef SF_SECTION_TIMERS
     unsigned long long* timers;      // profiling builds (tools/variants.sh): per-section shader-clock sums, see SF_TICK
 #endif
@@ -65,7 +66,7 @@ constexpr unsigned long long render_args_layout() {
     SF_LAYOUT_MEMBER(tape_bars); SF_LAYOUT_MEMBER(tape_waveform); SF_LAYOUT_MEMBER(waveform_stride); SF_LAYOUT_MEMBER(frame0);
     SF_LAYOUT_MEMBER(tap_x); SF_LAYOUT_MEMBER(tap_y); SF_LAYOUT_MEMBER(vis_consts); SF_LAYOUT_MEMBER(vis); SF_LAYOUT_MEMBER(has_vis);
     SF_LAYOUT_MEMBER(identity_camera); SF_LAYOUT_MEMBER(axis_camera); SF_LAYOUT_MEMBER(aspect); SF_LAYOUT_MEMBER(bg_scale_x); SF_LAYOUT_MEMBER(tile_pitch);
-    SF_LAYOUT_MEMBER(tile_rows); SF_LAYOUT_MEMBER(top_down); SF_LAYOUT_MEMBER(inv_wr); SF_LAYOUT_MEMBER(inv_hr); SF_LAYOUT_MEMBER(quads);
+    SF_LAYOUT_MEMBER(tile_rows); SF_LAYOUT_MEMBER(top_down); SF_LAYOUT_MEMBER(inv_wr); SF_LAYOUT_MEMBER(inv_hr); SF_LAYOUT_MEMBER(quads); SF_LAYOUT_MEMBER(tile_misses);
 #undef SF_LAYOUT_MEMBER
     h = layout_mix(h, sizeof(RenderArgs)); h = layout_mix(h, sizeof(Uniforms)); h = layout_mix(h, sizeof(Tex));
     h = layout_mix(h, sizeof(FrameDyn)); h = layout_mix(h, sizeof(VisualizerConsts));

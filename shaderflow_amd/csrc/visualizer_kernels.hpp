@@ -181,6 +181,7 @@ struct VisualizerShader {
         ok = sh.ok; x0 = sh.x0; y0 = sh.y0; tw = sh.tw; th = sh.th;
         }
         SF_TICK(a, 4);                               // window (incl. its barriers)
+        if (ok == 0 && tid == 0 && a.tile_misses) atomicAdd(a.tile_misses, 1u);
         if (ok != 1) { __syncthreads(); return; }    // sh.ok is read by run(): publish it like the staged path does
         // 2. stage the cells
         const uint8_t* data = (const uint8_t*)bg.data;

@@ -5,6 +5,8 @@ quantisation. The generic kernels evaluate the same binary32 operation sequences
 additionally REQUIRED to be bit-exact here; the fused and LDS-tiled kernels re-associate and are
 held to the 1 LSB bound.
 """
+import math
+
 import numpy as np
 import pytest
 
@@ -220,6 +222,49 @@ def test_strip_kernel_with_a_zoomed_or_panned_camera(gpu, camera, ssaa):
         got, want = gpu.render_resolve(prog, w, h, ssaa, 2), O.resolve(screen, w, h, 2)
     assert _last_kernel(gpu).startswith("k_visualizer_strip<"), _last_kernel(gpu)
     assert_within_lsb(got, want)
+
+
+def _turn_camera(u, roll=0.0, tilt=0.0, **others):
+    """The camera basis rolled about its forward axis, then tilted about its right axis (degrees) — what camera.py's rotate / rotate2d
+    leave in iCameraRight / iCameraUpward / iCameraForward"""
+    c, s = math.cos(math.radians(roll)), math.sin(math.radians(roll))
+    ct, st = math.cos(math.radians(tilt)), math.sin(math.radians(tilt))
+    right, up, forward = (c, s, 0.0), (-s*ct, c*ct, st), (s*st, -c*st, ct)
+    for name, vector in (("iCameraRight", right), ("iCameraUpward", up), ("iCameraForward", forward)):
+        for i, v in enumerate(vector):
+            getattr(u, name)[i] = v
+    for key, value in others.items():
+        cur = getattr(u, key)
+        if hasattr(cur, "__len__"):
+            for i, v in enumerate(value):
+                cur[i] = v
+        else:
+            setattr(u, key, value)
+
+
+@pytest.mark.parametrize("camera,all_tiled", [(dict(roll=17.0), True), (dict(roll=45.0), True), (dict(roll=90.0), True),
+                                              (dict(roll=-30.0, iCameraZoom=1.25, iCameraPosition=(0.1, -0.06, 0.0)), True),
+                                              (dict(roll=200.0, iCameraIsometric=0.3), True), (dict(roll=10.0, tilt=12.0), False)])
+def test_visualizer_lds_tile_kernel_with_a_rolled_camera(gpu, camera, all_tiled):
+    """A camera rolled about its forward axis mixes the screen axes: a block's tap window is bounded from the camera's four slopes
+    (capi camera_slopes), the tile is sized per launch and the block shape is the one that stages the fewest cells per pixel. With
+    the affine (rolled, zoomed, panned) cameras no block may fall back to the generic taps; a tilted camera is projective and its
+    bound is a heuristic, so only the pixels are asserted."""
+    w, h, ssaa = 640, 360, 2
+    u, arrays, params = visualizer_inputs(w, h, seed=31, volume=0.8, bg_size=(384, 216))
+    _turn_camera(u, **camera)
+    u.iSSAA = float(ssaa)
+    screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, threads=8)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    gpu.ctx.tile_misses()
+    got = gpu.render_resolve(prog, w, h, ssaa, 2)
+    misses = gpu.ctx.tile_misses()
+    assert _last_kernel(gpu).startswith("k_render_resolve<VisualizerShader<0, 0, "), _last_kernel(gpu)
+    if all_tiled:
+        assert misses == 0, f"{misses} blocks ran the generic taps"
+    assert_within_lsb(got, O.resolve(screen, w, h, 2))
 
 
 @pytest.mark.parametrize("bg_size,ssaa", [((160, 90), 2), ((320, 180), 2), ((640, 360), 2), ((320, 180), 4)])
