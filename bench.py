@@ -70,6 +70,8 @@ def parse_args():
     p.add_argument("--seconds", type=float, default=60.0, help="length of the synthetic clip (grown when the ranks need more frames)")
     p.add_argument("--scene", choices=("visualizer", "bars", "waveform", "basic"), default="visualizer",
                    help="visualizer = the metric's scene; bars = MusicBars, waveform = Waveform, basic = Basic (default.glsl): light fragments")
+    p.add_argument("--camera-zoom", type=float, default=1.0,
+                   help="tier analysis of the light fragments (tools/experiments/basic_tiers.sh): the camera's zoom; the metric's runs leave it at 1")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-export", action="store_true", help="skip the host-inclusive export measurement")
     p.add_argument("--cpu-seconds", type=float, default=18.0, help="budget of the CPU baseline (all cores + one thread)")
@@ -267,6 +269,8 @@ def main() -> None:
             module.setup()
         scene.set_duration(seconds)
         scene.ssaa = s
+        if args.camera_zoom != 1.0:
+            scene.camera.zoom.set(args.camera_zoom)
         return scene
 
     scene = build_scene()

@@ -1373,7 +1373,9 @@ template <int KIND> static int launch_separable(const RenderArgs& a, int ssaa, i
     }
     g_last_kernel = std::string("k_separable_fused<") + (KIND == SEP_BARS ? "bars" : (KIND == SEP_WAVEFORM ? "waveform" : "default")) + ">";
     const int blocks_x = (a.w + SEP_PIXELS - 1)/SEP_PIXELS;
-    if (KIND == SEP_DEFAULT && (long)blocks_x*((a.h + SEP_ROWS_DEFAULT - 1)/SEP_ROWS_DEFAULT)*frames >= 2048)
+    if (KIND == SEP_DEFAULT && (long)blocks_x*((a.h + SEP_ROWS_DEFAULT*SEP_CHUNKS_DEFAULT - 1)/(SEP_ROWS_DEFAULT*SEP_CHUNKS_DEFAULT))*frames >= 8192)
+        hipLaunchKernelGGL((k_separable_fused<KIND, SEP_ROWS_DEFAULT, SEP_CHUNKS_DEFAULT>), dim3(blocks_x, (a.h + SEP_ROWS_DEFAULT*SEP_CHUNKS_DEFAULT - 1)/(SEP_ROWS_DEFAULT*SEP_CHUNKS_DEFAULT), frames), dim3(SEP_PIXELS), 0, s, a, t);
+    else if (KIND == SEP_DEFAULT && (long)blocks_x*((a.h + SEP_ROWS_DEFAULT - 1)/SEP_ROWS_DEFAULT)*frames >= 2048)
         hipLaunchKernelGGL((k_separable_fused<KIND, SEP_ROWS_DEFAULT>), dim3(blocks_x, (a.h + SEP_ROWS_DEFAULT - 1)/SEP_ROWS_DEFAULT, frames), dim3(SEP_PIXELS), 0, s, a, t);
     else if ((long)blocks_x*((a.h + SEP_ROWS_LARGE - 1)/SEP_ROWS_LARGE)*frames >= 2048)
         hipLaunchKernelGGL((k_separable_fused<KIND, SEP_ROWS_LARGE>), dim3(blocks_x, (a.h + SEP_ROWS_LARGE - 1)/SEP_ROWS_LARGE, frames), dim3(SEP_PIXELS), 0, s, a, t);

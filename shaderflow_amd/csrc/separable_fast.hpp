@@ -29,10 +29,16 @@ constexpr int SEP_PIXELS = 256;
 // Output rows a block walks with its column entries in registers: 32 where the launch has blocks to spare (the entries are
 // fetched once per 32 rows and the rows leave in one sweep), 8 for small launches (a single 1080p frame is 272 blocks of 32 rows)
 constexpr int SEP_ROWS_LARGE = 32, SEP_ROWS_SMALL = 8;
-// default.glsl is arithmetic, not stores: 16 rows (12 KB of staged rows) let eight blocks = 8 waves per SIMD live on a CU, and the
+// default.glsl is arithmetic, not stores: 16 rows (16 KB of staged rows) let eight blocks = 8 waves per SIMD live on a CU, and the
 // kernel asks the compiler for that many (amdgpu_waves_per_eu: 52 registers instead of the 109 it takes when nobody asks) —
 // 4 -> 8 waves per SIMD is 1.39 -> 1.17 ms per 60 frames of 4K; 8-row blocks are slower again (1.09 against 1.07 ms)
-constexpr int SEP_ROWS_DEFAULT = 16;
+#ifndef SEP_ROWS_DEFAULT_N
+#define SEP_ROWS_DEFAULT_N 16
+#endif
+constexpr int SEP_ROWS_DEFAULT = SEP_ROWS_DEFAULT_N;
+#ifndef SEP_CHUNKS_DEFAULT
+#define SEP_CHUNKS_DEFAULT 1              // walks per block where the launch has blocks to spare (see k_separable_fused)
+#endif
 
 struct SepTables {
     float4* columns;                     // [frame][wr]
@@ -105,7 +111,18 @@ __global__ __launch_bounds__(256) void k_separable_axis(const RenderArgs a, cons
         const float uv = a.identity_camera ? g : (column ? camera_along_axis<0>(u, g, a.aspect, behind) : camera_along_axis<1>(u, g, a.aspect, behind));
         const int parity = (int)::floorf(uv*8.0f/2.0f) & 1;
         const float vignette = __builtin_amdgcn_exp2f(0.1f*(__builtin_amdgcn_logf(as*(1.0f - as)) + 2.821928095f));
-        e = make_float4(uv, __int_as_float(parity), vignette, __int_as_float((column && (behind || sf::abs(g) > u.iWantAspect)) ? 1 : 0));
+        if (column) {
+            e = make_float4(uv, __int_as_float(parity), vignette, __int_as_float((behind || sf::abs(g) > u.iWantAspect) ? 1 : 0));
+        } else {
+            // .w of a row: the mean of the vignette factors of the two sample rows of its output pixel at 2x SSAA (the smooth tier of
+            // k_separable_fused resolves a pixel from means: mean_ij c_i r_j = mean_i c_i * mean_j r_j)
+            const int other = ((index ^ 1) < n) ? (index ^ 1) : index;
+            const float ag_other = pixel_centre(other, n, a.inv_hr)*2.0f - 1.0f;
+            const float as_other = (ag_other + 1.0f)/2.0f;
+            const float vignette_other = __builtin_amdgcn_exp2f(0.1f*(__builtin_amdgcn_logf(as_other*(1.0f - as_other)) + 2.821928095f));
+            const float mean = 0.5f*(vignette + vignette_other);
+            e = make_float4(uv, __int_as_float(parity), vignette, mean);
+        }
     } else {
         if (column) {
             const vec2 w = texture_xy(tex[TEX_WAVEFORM], vec2{as, 0.0f});                                          // waveform.frag:6
@@ -216,13 +233,26 @@ __device__ __forceinline__ uint32_t blue_texel(float below, float ramp, float on
     return __builtin_amdgcn_cvt_pk_u8_f32((below + ramp*one_minus_y)*255.0f, 2u, 0u);
 }
 
-// S == 2. grid (ceil(w/SEP_PIXELS), ceil(h/SEP_ROWS), frames), block SEP_PIXELS threads.
-template <int KIND, int SEP_ROWS>
-__global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(8))) void k_separable_fused(const RenderArgs a, const SepTables t) {
-    __shared__ __attribute__((aligned(16))) uint8_t staged[SEP_ROWS][SEP_PIXELS*3];
+#ifndef SEP_WAVES
+#define SEP_WAVES 8                     // waves per SIMD asked of the compiler (tools/variants.sh: 4 halves the occupancy, to tell latency from issue)
+#endif
+// S == 2. grid (ceil(w/SEP_PIXELS), ceil(h/(SEP_ROWS*CHUNKS)), frames), block SEP_PIXELS threads. A block makes CHUNKS walks of SEP_ROWS
+// rows one below the other with its column entries in registers: the stores of a walk drain while the next one is computed. (A wave
+// does not retire before its stores are acknowledged — microseconds under load — and a block that makes one walk spends that time
+// holding its registers and LDS: default.glsl's smooth frames ran at 3.7 TB/s with their waves 87 % idle, and neither fewer
+// instructions nor fewer LDS operations moved them.)
+template <int KIND, int SEP_ROWS, int CHUNKS = 1>
+__global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(SEP_WAVES))) void k_separable_fused(const RenderArgs a, const SepTables t) {
+    // a pixel is staged as ONE dword (red in the low byte): 64 lanes write 64 consecutive banks in one pass. (As three byte stores per
+    // pixel — lanes sharing dwords — the LDS' write port bounded the smooth frames of default.glsl: 6.4 us where issue asks for 4.)
+    __shared__ __attribute__((aligned(16))) uint32_t staged[SEP_ROWS][SEP_PIXELS];
     const int frame = blockIdx.z;
     const int tid = threadIdx.x;
     const int px = blockIdx.x*SEP_PIXELS + tid;
+#ifdef SEP_LDS_PAD                                                     // tools/variants.sh: LDS nobody uses, to cap the blocks per CU (latency or issue?)
+    __shared__ uint32_t occupancy_pad[SEP_LDS_PAD/4];
+    if (a.w < 0) occupancy_pad[tid] = (uint32_t)tid;
+#endif
     const bool inside = px < a.w;
     const float4* columns = t.columns + (long)frame*a.wr;
     const float4* rows = t.rows + (long)frame*a.hr;
@@ -246,172 +276,306 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(8)))
     const bool odd_column0 = (__float_as_int(c0.y) & 1) != 0, odd_column1 = (__float_as_int(c1.y) & 1) != 0;   // default.glsl only
     const bool outside = (__float_as_int(c0.w) | __float_as_int(c1.w)) != 0;
     const float cx = 0.5f*(c0.x + c1.x);
+    // smooth tier of default.glsl: the pixel column's means (see the row loop)
+    float smooth_cz = 0.0f, smooth_g0 = 0.0f, smooth_g1 = 0.0f, smooth_b0 = 0.0f, smooth_b1 = 0.0f, smooth_ground0 = 0.0f, smooth_ground1 = 0.0f, smooth_base0 = 0.0f, smooth_base1 = 0.0f, smooth_half_slope = 0.0f, smooth_offset = 0.0f;
+    int smooth_until = 0;                                              // wave-uniform: rows [r, smooth_until) of the walk are smooth for every lane of the wave
+    const bool wave_one_square = __builtin_amdgcn_ballot_w64(odd_column0 == odd_column1) == __builtin_amdgcn_ballot_w64(true);
+    if constexpr (KIND == SEP_DEFAULT) {
+        // the checkerboard under a sample: (column parity ^ row parity) ? 0.22 : 0.20 (default.glsl:4-8)
+        const float even_rows0 = odd_column0 ? DEFAULT_ODD : DEFAULT_EVEN, even_rows1 = odd_column1 ? DEFAULT_ODD : DEFAULT_EVEN;
+        const float odd_rows0 = odd_column0 ? DEFAULT_EVEN : DEFAULT_ODD, odd_rows1 = odd_column1 ? DEFAULT_EVEN : DEFAULT_ODD;
+        smooth_cz = 0.5f*(c0.z + c1.z);
+        smooth_g0 = 0.5f*fmaf(c0.z, even_rows0, c1.z*even_rows1); smooth_g1 = 0.5f*fmaf(c0.z, odd_rows0, c1.z*odd_rows1);
+        smooth_b0 = 0.5f*(even_rows0 + even_rows1); smooth_b1 = 0.5f*(odd_rows0 + odd_rows1);
+    }
+    (void)smooth_cz; (void)smooth_g0; (void)smooth_g1; (void)smooth_b0; (void)smooth_b1; (void)smooth_ground0; (void)smooth_ground1; (void)smooth_base0; (void)smooth_base1; (void)smooth_half_slope; (void)smooth_offset; (void)smooth_until; (void)wave_one_square;
     int shared_until = 0; bool attempted = false; (void)attempted; DefaultRing group_ring = {}; DefaultHue group_hue = {}; DefaultSlope group_slope = {}; float group_y = 0.0f;
     (void)odd_column0; (void)odd_column1; (void)outside; (void)cx; (void)shared_until; (void)group_ring; (void)group_hue; (void)group_slope; (void)group_y;
-    // (default.glsl's row is ~3 KB of code with its tiers: unrolled rows would overflow the 64 KB instruction cache two CUs share —
-    // its rows run as a loop; the light kinds unroll fully)
-    constexpr int ROWS_UNROLLED = (KIND == SEP_DEFAULT) ? 1 : SEP_ROWS;
-#pragma unroll ROWS_UNROLLED
-    for (int r = 0; r < SEP_ROWS; r++) {
-        const int py = blockIdx.y*SEP_ROWS + r;
-        if (py >= a.h) break;
-        const float4 r0 = rows[2*py], r1 = rows[2*py + 1];            // block-uniform: scalar loads
-        uint32_t block[4];                                             // texel order y*2 + x (render_kernels.hpp)
-        uint32_t rgb;                                                  // the output pixel, red in the low byte
-        if constexpr (KIND == SEP_BARS) {
-            // red and green are 0 or 1 per supersample: the resolve of such a block is exact in every step — the sum of the four
-            // texels/255 is their count, count/4 is exact, and the unorm8 write of it is RN(count*63.75) for either kernel size
-            // (the 1-tap kernel's weights are 0.25 each) — so the byte is a function of how many of the pixel's four samples lie
-            // below the column's height: min(max(T - first row, 0), 2) per column.
-            const int j0 = 2*py;
-            const int red = rows_of_pair(__float_as_int(c0.x), j0) + rows_of_pair(__float_as_int(c1.x), j0);
-            const int green = rows_of_pair(__float_as_int(c0.y), j0) + rows_of_pair(__float_as_int(c1.y), j0);
-            // blue adds the ramp 0.4*(sum)*(1 - astuv.y) (bars.frag:17): the generic chain on that channel alone
-            const int t0 = __float_as_int(c0.z), t1 = __float_as_int(c1.z);
-            block[0] = blue_texel((j0 < t0) ? 1.0f : 0.0f, c0.w, r0.y); block[1] = blue_texel((j0 < t1) ? 1.0f : 0.0f, c1.w, r0.y);
-            block[2] = blue_texel((j0 + 1 < t0) ? 1.0f : 0.0f, c0.w, r1.y); block[3] = blue_texel((j0 + 1 < t1) ? 1.0f : 0.0f, c1.w, r1.y);
-            rgb = __builtin_amdgcn_cvt_pk_u8_f32((float)red*63.75f, 0u, resolve_channel_any<2>(block, a.subsample, 16) << 16);
-            rgb = __builtin_amdgcn_cvt_pk_u8_f32((float)green*63.75f, 1u, rgb);
-        } else if constexpr (KIND == SEP_WAVEFORM) {
-            const int j0 = 2*py;
-            rgb = (uint32_t)inside_lut[wave_pattern(__float_as_int(c0.x), __float_as_int(c1.x), j0)]
-                | ((uint32_t)inside_lut[wave_pattern(__float_as_int(c0.y), __float_as_int(c1.y), j0)] << 8)
-                | ((uint32_t)inside_lut[wave_pattern(__float_as_int(c0.z), __float_as_int(c1.z), j0)] << 16);
-        } else {
-            // rows in groups of four: the group's first row evaluates the polar terms at the point in the middle of its sixteen samples
-            // and, where default_shares_slope / default_shares_hue allow, the four rows use them (`shared_until` = the first block row
-            // they no longer serve)
-            if ((r & 3) == 0) {
-                attempted = py + 3 < a.h;
-                if (attempted) {
-                    const float cy = 0.5f*(rows[2*py + 3].x + rows[2*py + 4].x);
-                    const float reach = 0.5f*sf::abs(c1.x - c0.x) + 3.5f*sf::abs(r1.x - r0.x);
-                    group_ring = default_ring(cx, cy);
-                    if (default_shares_slope(group_ring, reach) && default_shares_hue(1.5f*group_ring.width, group_ring.len, reach)) {
-                        group_hue = default_hue(cx, cy, hue_shift); group_slope = default_slope(group_ring, cx, cy); group_y = cy; shared_until = r + 4;
-                    }
-                }
-            }
-            const bool group_shares = r < shared_until;
-            // the sample's checkerboard colour by the parities of its column and row; the row's side is block-uniform (scalar selects)
-            const float even0 = (__float_as_int(r0.y) & 1) ? DEFAULT_ODD : DEFAULT_EVEN, odd0 = (__float_as_int(r0.y) & 1) ? DEFAULT_EVEN : DEFAULT_ODD;
-            const float even1 = (__float_as_int(r1.y) & 1) ? DEFAULT_ODD : DEFAULT_EVEN, odd1 = (__float_as_int(r1.y) & 1) ? DEFAULT_EVEN : DEFAULT_ODD;
-            const float board[4] = {odd_column0 ? odd0 : even0, odd_column1 ? odd0 : even0, odd_column0 ? odd1 : even1, odd_column1 ? odd1 : even1};
-            const float vignette[4] = {clamp01(c0.z*r0.z), clamp01(c1.z*r0.z), clamp01(c0.z*r1.z), clamp01(c1.z*r1.z)};
-            const float cy = 0.5f*(r0.x + r1.x);
-            const float off = 0.5f*(sf::abs(c1.x - c0.x) + sf::abs(r1.x - r0.x));
-            DefaultRing centre = group_ring;
-            DefaultHue hue = group_hue;
-            DefaultSlope slope = group_slope;
-            float slope_y = group_y;
-            bool shared = group_shares;
-            if (!group_shares) {
-                centre = default_ring(cx, cy);
-                // (the last rows of a frame whose height is not a multiple of four have no group: the same test for the pixel alone)
-                shared = !attempted && default_shares_slope(centre, off) && default_shares_hue(1.5f*centre.width, centre.len, off);
-                if (shared) { hue = default_hue(cx, cy, hue_shift); slope = default_slope(centre, cx, cy); slope_y = cy; }
-            }
-            DefaultBytes bytes = {0u, 0u, 0u};
-            bool meaned = false;
-            if (shared) {                                             // one ring and one hue for the samples, the ring's width to first order
-                const float lower = fmaf(slope.y, r0.x - slope_y, centre.width*255.0f), upper = fmaf(slope.y, r1.x - slope_y, centre.width*255.0f);
-                const float side = slope.x*(0.5f*(c1.x - c0.x));
-                const bool disc = centre.circle < 0.0f;
-#if SEP_DEFAULT_FLOAT_MEAN
-                // Round 4: where the four samples also share their base colour (the disc, or one square of the checkerboard) the
-                // pixel is resolved in FLOAT: mean_k vig_k*(base + w_k*hue) = base*V/4 + hue*R/4 with V = sum vig_k and
-                // R = sum vig_k*w_k, w = {lower, upper} -/+ side — 16 operations instead of 4 x 8 + the byte sums. The reference
-                // quantises every sample first: the mean of four roundings is within 1/2 of the mean, so the two bytes are
-                // roundings of numbers within 1/2 of each other: they differ by at most ONE, the tolerance of every fused
-                // kernel (no sample saturates in the shared tier: |circle| > 0.1 keeps the ring term under 0.03).
-                const bool one_base = disc || ((odd_column0 == odd_column1) && (((__float_as_int(r0.y) ^ __float_as_int(r1.y)) & 1) == 0));
-                if (one_base && !outside) {
-                    const float below = vignette[0] + vignette[1], above = vignette[2] + vignette[3];
-                    const float across = (vignette[1] - vignette[0]) + (vignette[3] - vignette[2]);
-                    const float ring = fmaf(side, across, fmaf(upper, above, lower*below))*0.25f;
-                    const float ground = (disc ? DEFAULT_DISC : board[0])*(0.25f*(below + above));
-                    rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.red, ground), 0u, 0u);
-                    rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.green, ground), 1u, rgb);
-                    rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.blue, ground), 2u, rgb);
-                    meaned = true;
-                }
-#endif
-                if (!meaned) {
-                default_colour<0>(bytes, hue, lower - side, disc ? DEFAULT_DISC : board[0], vignette[0]);
-                default_colour<1>(bytes, hue, lower + side, disc ? DEFAULT_DISC : board[1], vignette[1]);
-                default_colour<2>(bytes, hue, upper - side, disc ? DEFAULT_DISC : board[2], vignette[2]);
-                default_colour<3>(bytes, hue, upper + side, disc ? DEFAULT_DISC : board[3], vignette[3]);
-                }
-            } else {                                                  // the ring per sample; the hue at the centre if it may be, else per sample
-                const float ux[4] = {c0.x, c1.x, c0.x, c1.x}, uy[4] = {r0.x, r0.x, r1.x, r1.x};
-                DefaultRing ring[4];
-                float widest = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 4; k++) { ring[k] = default_ring(ux[k], uy[k]); widest = __builtin_fmaxf(widest, ring[k].width); }
-                float width255[4], base255[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) { width255[k] = ring[k].width*255.0f; base255[k] = (ring[k].circle < 0.0f) ? DEFAULT_DISC : board[k]; }
-                if (centre.len > 8.0f*off) {
-                    const float wheel = default_wheel(cx, cy, hue_shift);
-                    if (default_shares_hue(widest, centre.len, off)) {
-                        hue = default_wheel_colours(wheel);
-                        default_colour<0>(bytes, hue, width255[0], base255[0], vignette[0]); default_colour<1>(bytes, hue, width255[1], base255[1], vignette[1]);
-                        default_colour<2>(bytes, hue, width255[2], base255[2], vignette[2]); default_colour<3>(bytes, hue, width255[3], base255[3], vignette[3]);
-                    } else {
-                        // on the ring the glow is wide enough to show the hue turning inside a pixel: the centre's wheel coordinate
-                        // moved by each sample's own angle (one atan2 per pixel instead of four)
-                        const float turn = (3.0f/PI)*__builtin_amdgcn_rcpf(centre.len*centre.len);
-                        const float along = cx*(0.5f*(r1.x - r0.x))*turn, across = cy*(0.5f*(c1.x - c0.x))*turn;   // x dy, y dx
-                        default_colour<0>(bytes, default_hue_beside(wheel, across - along), width255[0], base255[0], vignette[0]);
-                        default_colour<1>(bytes, default_hue_beside(wheel, -across - along), width255[1], base255[1], vignette[1]);
-                        default_colour<2>(bytes, default_hue_beside(wheel, across + along), width255[2], base255[2], vignette[2]);
-                        default_colour<3>(bytes, default_hue_beside(wheel, along - across), width255[3], base255[3], vignette[3]);
-                    }
-                } else {                                              // next to the origin: every sample by itself
-                    default_colour<0>(bytes, default_hue(ux[0], uy[0], hue_shift), width255[0], base255[0], vignette[0]);
-                    default_colour<1>(bytes, default_hue(ux[1], uy[1], hue_shift), width255[1], base255[1], vignette[1]);
-                    default_colour<2>(bytes, default_hue(ux[2], uy[2], hue_shift), width255[2], base255[2], vignette[2]);
-                    default_colour<3>(bytes, default_hue(ux[3], uy[3], hue_shift), width255[3], base255[3], vignette[3]);
-                }
-            }
-            if (outside) {                                            // camera.glsl:83 / default.glsl:14-16, per column: 0.15 grey = byte 38
-                const uint32_t keep = ((__float_as_int(c0.w) != 0) ? 0u : 0x00ff00ffu) | ((__float_as_int(c1.w) != 0) ? 0u : 0xff00ff00u);
-                const uint32_t grey = 0x26262626u & ~keep;
-                bytes.red = (bytes.red & keep) | grey; bytes.green = (bytes.green & keep) | grey; bytes.blue = (bytes.blue & keep) | grey;
-            }
-            // final.glsl's mean of the four RGBA8 texels as an INTEGER mean per channel, (sum + 2) >> 2 with the sum of a register's
-            // four bytes from v_sad_u8: what resolve_channel's float chain gives except on ties (sum = 2 mod 4), which its rounding
-            // noise decides either way — 1 LSB, like every approximation of this kernel (8 instructions instead of 60)
-            if (!meaned)
-                rgb = (__builtin_amdgcn_sad_u8(bytes.red, 0u, 2u) >> 2) | ((__builtin_amdgcn_sad_u8(bytes.green, 0u, 2u) >> 2) << 8)
-                    | ((__builtin_amdgcn_sad_u8(bytes.blue, 0u, 2u) >> 2) << 16);
-        }
-        uint8_t* s = &staged[r][tid*3];
-        s[0] = (uint8_t)rgb; s[1] = (uint8_t)(rgb >> 8); s[2] = (uint8_t)(rgb >> 16);
-    }
-    __syncthreads();
-    uint8_t* out = (uint8_t*)a.out + (long)frame*a.out_frame_stride;
-    // a full-width block of a frame whose rows are whole 16-byte groups: the block's rows leave as one sweep of 16-byte stores
-    // by all threads (the staged rows are contiguous in LDS, 48 groups each) instead of 48 threads per row, row after row
-    constexpr int GROUPS = SEP_PIXELS*3/16;
-    const int x0 = blockIdx.x*SEP_PIXELS;
-    if (x0 + SEP_PIXELS <= a.w && (a.w*3) % 16 == 0 && ((uintptr_t)out & 15) == 0) {
-        const int rows_here = min(SEP_ROWS, a.h - (int)blockIdx.y*SEP_ROWS);
-#pragma unroll
-        for (int i = 0; i < (SEP_ROWS*GROUPS + SEP_PIXELS - 1)/SEP_PIXELS; i++) {
-            const int k = tid + i*SEP_PIXELS, r = k/GROUPS, c = k - r*GROUPS;
-            if (r < rows_here) {
-                const int py = blockIdx.y*SEP_ROWS + r;
-                uint8_t* row = out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3 + (long)x0*3;
-                stream_store16((uint4*)row + c, (const uint4*)&staged[0][0] + k);
-            }
-        }
-        return;
-    }
 #pragma unroll 1
-    for (int r = 0; r < SEP_ROWS; r++) {
-        const int py = blockIdx.y*SEP_ROWS + r;
-        if (py < a.h) store_rgb_row(out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3, x0, a.w, staged[r], tid, SEP_PIXELS, SEP_PIXELS);
+    for (int chunk = 0; chunk < CHUNKS; chunk++) {
+        const int block_row = blockIdx.y*CHUNKS + chunk;               // which walk of the frame
+        if (block_row*SEP_ROWS >= a.h) break;
+        if (chunk) {
+            __syncthreads();                                           // the previous walk's rows have left the LDS
+            smooth_until = 0; shared_until = 0; attempted = false;
+        }
+        if constexpr (KIND == SEP_DEFAULT) {
+            // default.glsl: the walk in groups of four rows. (A row of the tiers below is ~3 KB of code: it exists once, in a loop.)
+            static_assert(SEP_ROWS % 4 == 0, "the walk is made of groups of four rows");
+            auto stage = [&](int r, uint32_t rgb) {
+                staged[r][tid] = rgb;
+            };
+            // one row of a smooth group from its two row entries (see the group's prologue): eleven vector operations and nothing
+            // scalar — a wave issues one instruction of ANY kind per turn, so the selects and branches on the rows' parity that used to
+            // sit here cost as much as the arithmetic (347 scalar against 470 vector instructions per wave)
+            // (`smooth_offset` = the ring's width at gluv.y = 0 by the group's slope: w(y) = smooth_offset + slope.y*y; `ground_of_rows`,
+            // `base_of_rows` = the group's choice among smooth_ground0/1, smooth_base0/1 by the parity its eight sample rows share)
+            auto smooth_row = [&](const float4 r0, const float4 r1, const bool one_square, const float ground_of_rows, const float base_of_rows) -> uint32_t {
+#ifdef SEP_STUB_SMOOTH                                                 // tools/variants.sh: what do the smooth rows' operations cost?
+                return __float_as_uint(r0.x + smooth_cz) & 0xffffffu;
+#endif
+                const float vignette = clamp01(smooth_cz*r0.w);
+                const float ring = fmaf(smooth_half_slope, r0.x, fmaf(smooth_half_slope, r1.x, smooth_offset))*vignette;
+                const float ground = one_square ? base_of_rows*vignette                       // min(r*c*B, B) = B*min(r*c, 1)
+                                                : __builtin_fminf(r0.w*ground_of_rows, base_of_rows);
+                uint32_t rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, group_hue.red, ground), 0u, 0u);
+                rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, group_hue.green, ground), 1u, rgb);
+                return __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, group_hue.blue, ground), 2u, rgb);
+            };
+            // one row by the tiers that look at every pixel by itself
+            auto general_row = [&](int r, const float4 r0, const float4 r1) -> uint32_t {
+                uint32_t rgb = 0u;
+                const bool group_shares = r < shared_until;
+                // the sample's checkerboard colour by the parities of its column and row; the row's side is block-uniform (scalar selects)
+                const float even0 = (__float_as_int(r0.y) & 1) ? DEFAULT_ODD : DEFAULT_EVEN, odd0 = (__float_as_int(r0.y) & 1) ? DEFAULT_EVEN : DEFAULT_ODD;
+                const float even1 = (__float_as_int(r1.y) & 1) ? DEFAULT_ODD : DEFAULT_EVEN, odd1 = (__float_as_int(r1.y) & 1) ? DEFAULT_EVEN : DEFAULT_ODD;
+                const float board[4] = {odd_column0 ? odd0 : even0, odd_column1 ? odd0 : even0, odd_column0 ? odd1 : even1, odd_column1 ? odd1 : even1};
+                const float vignette[4] = {clamp01(c0.z*r0.z), clamp01(c1.z*r0.z), clamp01(c0.z*r1.z), clamp01(c1.z*r1.z)};
+                const float cy = 0.5f*(r0.x + r1.x);
+                const float off = 0.5f*(sf::abs(c1.x - c0.x) + sf::abs(r1.x - r0.x));
+                DefaultRing centre = group_ring;
+                DefaultHue hue = group_hue;
+                DefaultSlope slope = group_slope;
+                float slope_y = group_y;
+                bool shared = group_shares;
+                if (!group_shares) {
+                    centre = default_ring(cx, cy);
+                    // the same test for the pixel alone: its reach is a seventh of the group's, so half of the band that four rows cannot
+                    // share (0.05 < |circle| < 0.1 at 4K) is served by one evaluation per pixel instead of four
+                    shared = default_shares_slope(centre, off) && default_shares_hue(1.5f*centre.width, centre.len, off);
+                    if (shared) { hue = default_hue(cx, cy, hue_shift); slope = default_slope(centre, cx, cy); slope_y = cy; }
+                }
+                DefaultBytes bytes = {0u, 0u, 0u};
+                bool meaned = false;
+                if (shared) {                                             // one ring and one hue for the samples, the ring's width to first order
+                    const float lower = fmaf(slope.y, r0.x - slope_y, centre.width*255.0f), upper = fmaf(slope.y, r1.x - slope_y, centre.width*255.0f);
+                    const float side = slope.x*(0.5f*(c1.x - c0.x));
+                    const bool disc = centre.circle < 0.0f;
+    #if SEP_DEFAULT_FLOAT_MEAN
+                    // Round 4: where the four samples also share their base colour (the disc, or one square of the checkerboard) the
+                    // pixel is resolved in FLOAT: mean_k vig_k*(base + w_k*hue) = base*V/4 + hue*R/4 with V = sum vig_k and
+                    // R = sum vig_k*w_k, w = {lower, upper} -/+ side — 16 operations instead of 4 x 8 + the byte sums. The reference
+                    // quantises every sample first: the mean of four roundings is within 1/2 of the mean, so the two bytes are
+                    // roundings of numbers within 1/2 of each other: they differ by at most ONE, the tolerance of every fused
+                    // kernel (no sample saturates in the shared tier: |circle| > 0.1 keeps the ring term under 0.03).
+                    const bool one_base = disc || ((odd_column0 == odd_column1) && (((__float_as_int(r0.y) ^ __float_as_int(r1.y)) & 1) == 0));
+                    if (one_base && !outside) {
+                        const float below = vignette[0] + vignette[1], above = vignette[2] + vignette[3];
+                        const float across = (vignette[1] - vignette[0]) + (vignette[3] - vignette[2]);
+                        const float ring = fmaf(side, across, fmaf(upper, above, lower*below))*0.25f;
+                        const float ground = (disc ? DEFAULT_DISC : board[0])*(0.25f*(below + above));
+                        rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.red, ground), 0u, 0u);
+                        rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.green, ground), 1u, rgb);
+                        rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.blue, ground), 2u, rgb);
+                        meaned = true;
+                    }
+#endif
+                    if (!meaned) {
+                    default_colour<0>(bytes, hue, lower - side, disc ? DEFAULT_DISC : board[0], vignette[0]);
+                    default_colour<1>(bytes, hue, lower + side, disc ? DEFAULT_DISC : board[1], vignette[1]);
+                    default_colour<2>(bytes, hue, upper - side, disc ? DEFAULT_DISC : board[2], vignette[2]);
+                    default_colour<3>(bytes, hue, upper + side, disc ? DEFAULT_DISC : board[3], vignette[3]);
+                    }
+                } else {                                                  // the ring per sample; the hue at the centre if it may be, else per sample
+                    const float ux[4] = {c0.x, c1.x, c0.x, c1.x}, uy[4] = {r0.x, r0.x, r1.x, r1.x};
+                    DefaultRing ring[4];
+                    float widest = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { ring[k] = default_ring(ux[k], uy[k]); widest = __builtin_fmaxf(widest, ring[k].width); }
+                    float width255[4], base255[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { width255[k] = ring[k].width*255.0f; base255[k] = (ring[k].circle < 0.0f) ? DEFAULT_DISC : board[k]; }
+                    if (centre.len > 8.0f*off) {
+                        const float wheel = default_wheel(cx, cy, hue_shift);
+                        if (default_shares_hue(widest, centre.len, off)) {
+                            hue = default_wheel_colours(wheel);
+                            default_colour<0>(bytes, hue, width255[0], base255[0], vignette[0]); default_colour<1>(bytes, hue, width255[1], base255[1], vignette[1]);
+                            default_colour<2>(bytes, hue, width255[2], base255[2], vignette[2]); default_colour<3>(bytes, hue, width255[3], base255[3], vignette[3]);
+                        } else {
+                            // on the ring the glow is wide enough to show the hue turning inside a pixel: the centre's wheel coordinate
+                            // moved by each sample's own angle (one atan2 per pixel instead of four)
+                            const float turn = (3.0f/PI)*__builtin_amdgcn_rcpf(centre.len*centre.len);
+                            const float along = cx*(0.5f*(r1.x - r0.x))*turn, across = cy*(0.5f*(c1.x - c0.x))*turn;   // x dy, y dx
+                            default_colour<0>(bytes, default_hue_beside(wheel, across - along), width255[0], base255[0], vignette[0]);
+                            default_colour<1>(bytes, default_hue_beside(wheel, -across - along), width255[1], base255[1], vignette[1]);
+                            default_colour<2>(bytes, default_hue_beside(wheel, across + along), width255[2], base255[2], vignette[2]);
+                            default_colour<3>(bytes, default_hue_beside(wheel, along - across), width255[3], base255[3], vignette[3]);
+                        }
+                    } else {                                              // next to the origin: every sample by itself
+                        default_colour<0>(bytes, default_hue(ux[0], uy[0], hue_shift), width255[0], base255[0], vignette[0]);
+                        default_colour<1>(bytes, default_hue(ux[1], uy[1], hue_shift), width255[1], base255[1], vignette[1]);
+                        default_colour<2>(bytes, default_hue(ux[2], uy[2], hue_shift), width255[2], base255[2], vignette[2]);
+                        default_colour<3>(bytes, default_hue(ux[3], uy[3], hue_shift), width255[3], base255[3], vignette[3]);
+                    }
+                }
+                if (outside) {                                            // camera.glsl:83 / default.glsl:14-16, per column: 0.15 grey = byte 38
+                    const uint32_t keep = ((__float_as_int(c0.w) != 0) ? 0u : 0x00ff00ffu) | ((__float_as_int(c1.w) != 0) ? 0u : 0xff00ff00u);
+                    const uint32_t grey = 0x26262626u & ~keep;
+                    bytes.red = (bytes.red & keep) | grey; bytes.green = (bytes.green & keep) | grey; bytes.blue = (bytes.blue & keep) | grey;
+                }
+                // final.glsl's mean of the four RGBA8 texels as an INTEGER mean per channel, (sum + 2) >> 2 with the sum of a register's
+                // four bytes from v_sad_u8: what resolve_channel's float chain gives except on ties (sum = 2 mod 4), which its rounding
+                // noise decides either way — 1 LSB, like every approximation of this kernel (8 instructions instead of 60)
+                if (!meaned)
+                    rgb = (__builtin_amdgcn_sad_u8(bytes.red, 0u, 2u) >> 2) | ((__builtin_amdgcn_sad_u8(bytes.green, 0u, 2u) >> 2) << 8)
+                        | ((__builtin_amdgcn_sad_u8(bytes.blue, 0u, 2u) >> 2) << 16);
+                return rgb;
+            };
+#pragma unroll 1
+            for (int r = 0; r < SEP_ROWS; r += 4) {
+                const int py = block_row*SEP_ROWS + r;
+                if (py >= a.h) break;
+                const float4 r0 = rows[2*py], r1 = rows[2*py + 1];        // block-uniform: scalar loads
+                // rows in groups of four: the group's first row evaluates the polar terms at the point in the middle of its sixteen samples
+                // and, where default_shares_slope / default_shares_hue allow, the four rows use them (`shared_until` = the first block row
+                // they no longer serve)
+                if (r >= smooth_until) {
+                    // THE SMOOTH TIER (round 4). Where every lane of the wave may share one evaluation of the polar terms, the pixel is
+                    // resolved from MEANS in float: mean_k vig_k*(base_k + w_k*hue) over its four samples k = (column i, row j) with
+                    // vig_k = min(c_i*r_j, 1) is, up to terms far below the quantisation step,
+                    //     min(mean_j r_j * mean_i c_i*base_i, mean_i base_i)  +  min(mean_i c_i * mean_j r_j, 1) * w(pixel centre) * hue
+                    // — the products factorise exactly, the clamp differs only where some of the four products exceed 1 and others do not
+                    // (the middle of the frame, where they differ by 1e-4), the covariance of vig and w inside a pixel is second order
+                    // (< 0.005 LSB at the frame's edge). Column means live in registers for the walk, row means in the row table (.w):
+                    // ≈ 20 operations per pixel. Against the reference, which quantises each sample: the mean of four roundings is within
+                    // 1/2 of the mean, so the bytes are roundings of numbers within 1/2 (+ 0.03) of each other — at most ONE apart, the
+                    // bound of every fused kernel (no sample saturates here: |circle| > 0.1 keeps the ring term under 0.03).
+                    // One evaluation serves the WHOLE walk of a full block when the test holds over its sixteen rows (|circle| > 0.3 at 4K:
+                    // two thirds of the frame), else four rows at a time; rows whose two sample rows sit in different squares of the
+                    // checkerboard, and waves with a lane that fails, take the tiers below.
+                    bool whole_walk = false;
+                    if (r == 0 && (int)block_row*SEP_ROWS + SEP_ROWS <= a.h && SEP_ROWS > 4) {
+                        const float cy = 0.5f*(rows[2*py + SEP_ROWS - 1].x + rows[2*py + SEP_ROWS].x);
+                        const float reach = 0.5f*sf::abs(c1.x - c0.x) + ((float)SEP_ROWS - 0.5f)*sf::abs(r1.x - r0.x);
+                        group_ring = default_ring(cx, cy);
+                        const bool fine = !outside && default_shares_slope(group_ring, reach) && default_shares_hue(1.5f*group_ring.width, group_ring.len, reach);
+                        if (__builtin_amdgcn_ballot_w64(fine) == __builtin_amdgcn_ballot_w64(true)) {
+                            group_hue = default_hue(cx, cy, hue_shift); group_slope = default_slope(group_ring, cx, cy); group_y = cy;
+                            shared_until = SEP_ROWS; smooth_until = SEP_ROWS; whole_walk = true;
+                        }
+                    }
+                    if (!whole_walk) {
+                        attempted = py + 3 < a.h;
+                        bool fine = false;
+                        if (attempted) {
+                            const float cy = 0.5f*(rows[2*py + 3].x + rows[2*py + 4].x);
+                            const float reach = 0.5f*sf::abs(c1.x - c0.x) + 3.5f*sf::abs(r1.x - r0.x);
+                            group_ring = default_ring(cx, cy);
+                            if (default_shares_slope(group_ring, reach) && default_shares_hue(1.5f*group_ring.width, group_ring.len, reach)) {
+                                group_hue = default_hue(cx, cy, hue_shift); group_slope = default_slope(group_ring, cx, cy); group_y = cy; shared_until = r + 4;
+                                fine = !outside;
+                            }
+                        }
+                        if (__builtin_amdgcn_ballot_w64(fine) == __builtin_amdgcn_ballot_w64(true)) smooth_until = r + 4;
+                    }
+                    if (r < smooth_until) {
+                        const bool disc = group_ring.circle < 0.0f;
+                        smooth_ground0 = disc ? DEFAULT_DISC*smooth_cz : smooth_g0; smooth_ground1 = disc ? DEFAULT_DISC*smooth_cz : smooth_g1;
+                        smooth_base0 = disc ? DEFAULT_DISC : smooth_b0; smooth_base1 = disc ? DEFAULT_DISC : smooth_b1;
+                        smooth_half_slope = 0.5f*group_slope.y;
+                        smooth_offset = fmaf(-group_slope.y, group_y, group_ring.width*255.0f);
+                    }
+                }
+                if (r < smooth_until && py + 3 < a.h) {
+                    // the group's eight row entries in one fetch (a fetch per row is a round trip to the L2 in front of fifteen operations)
+                    float4 e[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) e[k] = rows[2*py + k];
+                    // (the eight sample rows in one square of the checkerboard's rows — 66 groups in 67 at 4K; the others go below)
+                    int mixed = 0;
+#pragma unroll
+                    for (int k = 1; k < 8; k++) mixed |= __float_as_int(e[k].y) ^ __float_as_int(e[0].y);
+                    if ((mixed & 1) == 0) {
+                        const bool odd_rows = (__float_as_int(e[0].y) & 1) != 0;
+                        const float ground_of_rows = odd_rows ? smooth_ground1 : smooth_ground0, base_of_rows = odd_rows ? smooth_base1 : smooth_base0;
+                        if (wave_one_square) {                          // wave-uniform: both sample columns of every lane in one square of the checkerboard's columns
+#pragma unroll
+                            for (int k = 0; k < 4; k++) stage(r + k, smooth_row(e[2*k], e[2*k + 1], true, ground_of_rows, base_of_rows));
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) stage(r + k, smooth_row(e[2*k], e[2*k + 1], false, ground_of_rows, base_of_rows));
+                        }
+                        continue;
+                    }
+                }
+#pragma unroll 1
+                for (int k = 0; k < 4; k++) {
+                    if (py + k >= a.h) break;
+                    const float4 q0 = rows[2*(py + k)], q1 = rows[2*(py + k) + 1];
+                    stage(r + k, general_row(r + k, q0, q1));
+                }
+            }
+        } else {
+#pragma unroll
+        for (int r = 0; r < SEP_ROWS; r++) {
+            const int py = block_row*SEP_ROWS + r;
+            if (py >= a.h) break;
+            const float4 r0 = rows[2*py], r1 = rows[2*py + 1];            // block-uniform: scalar loads
+            uint32_t block[4];                                             // texel order y*2 + x (render_kernels.hpp)
+            uint32_t rgb;                                                  // the output pixel, red in the low byte
+            if constexpr (KIND == SEP_BARS) {
+                // red and green are 0 or 1 per supersample: the resolve of such a block is exact in every step — the sum of the four
+                // texels/255 is their count, count/4 is exact, and the unorm8 write of it is RN(count*63.75) for either kernel size
+                // (the 1-tap kernel's weights are 0.25 each) — so the byte is a function of how many of the pixel's four samples lie
+                // below the column's height: min(max(T - first row, 0), 2) per column.
+                const int j0 = 2*py;
+                const int red = rows_of_pair(__float_as_int(c0.x), j0) + rows_of_pair(__float_as_int(c1.x), j0);
+                const int green = rows_of_pair(__float_as_int(c0.y), j0) + rows_of_pair(__float_as_int(c1.y), j0);
+                // blue adds the ramp 0.4*(sum)*(1 - astuv.y) (bars.frag:17): the generic chain on that channel alone
+                const int t0 = __float_as_int(c0.z), t1 = __float_as_int(c1.z);
+                block[0] = blue_texel((j0 < t0) ? 1.0f : 0.0f, c0.w, r0.y); block[1] = blue_texel((j0 < t1) ? 1.0f : 0.0f, c1.w, r0.y);
+                block[2] = blue_texel((j0 + 1 < t0) ? 1.0f : 0.0f, c0.w, r1.y); block[3] = blue_texel((j0 + 1 < t1) ? 1.0f : 0.0f, c1.w, r1.y);
+                rgb = __builtin_amdgcn_cvt_pk_u8_f32((float)red*63.75f, 0u, resolve_channel_any<2>(block, a.subsample, 16) << 16);
+                rgb = __builtin_amdgcn_cvt_pk_u8_f32((float)green*63.75f, 1u, rgb);
+            } else if constexpr (KIND == SEP_WAVEFORM) {
+                const int j0 = 2*py;
+                rgb = (uint32_t)inside_lut[wave_pattern(__float_as_int(c0.x), __float_as_int(c1.x), j0)]
+                    | ((uint32_t)inside_lut[wave_pattern(__float_as_int(c0.y), __float_as_int(c1.y), j0)] << 8)
+                    | ((uint32_t)inside_lut[wave_pattern(__float_as_int(c0.z), __float_as_int(c1.z), j0)] << 16);
+            }
+            staged[r][tid] = rgb;
+        }
+        }
+        __syncthreads();
+        uint8_t* out = (uint8_t*)a.out + (long)frame*a.out_frame_stride;
+        // a full-width block of a frame whose rows are whole dwords: a lane packs four staged pixels into their twelve bytes (three
+        // v_perm_b32) and stores them as one non-temporal `global_store_dwordx3`; a wave writes 768 contiguous bytes of one row per pass.
+        // Wave `v` takes rows v, v + 4, ...: the row and its address are SCALAR (as a function of the thread index the compiler spent
+        // twenty vector operations per pass on 64-bit products — a sixth of a smooth wave's instructions).
+        const int x0 = blockIdx.x*SEP_PIXELS;
+        if (x0 + SEP_PIXELS <= a.w && (a.w & 3) == 0 && ((uintptr_t)out & 3) == 0 && (a.out_frame_stride & 3) == 0) {
+            const int rows_here = min(SEP_ROWS, a.h - (int)block_row*SEP_ROWS);
+            typedef uint32_t Triple __attribute__((ext_vector_type(3), aligned(4)));
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+            uint8_t* const block_out = out + (long)x0*3;                  // block-uniform
+            const uint32_t lane_bytes = (uint32_t)lane*12u;
+#pragma unroll
+            for (int i = 0; i < SEP_ROWS/4; i++) {
+                const int r = wave + 4*i;
+                if (r < rows_here) {
+                    const int py = block_row*SEP_ROWS + r;
+                    const uint4 p = *(const uint4*)&staged[r][4*lane];
+                    uint8_t* row = block_out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3;
+#ifdef SEP_STUB_STORES                                                 // tools/variants.sh: what do the stores cost? (one lane in 64 stores)
+                    if (lane == (p.x & 63u) + 64u) continue;
+                    if (lane != 0) continue;
+#endif
+                    __builtin_nontemporal_store(Triple{__builtin_amdgcn_perm(p.y, p.x, 0x04020100u), __builtin_amdgcn_perm(p.z, p.y, 0x05040201u),
+                                                       __builtin_amdgcn_perm(p.w, p.z, 0x06050402u)}, (Triple*)(row + lane_bytes));
+                }
+            }
+            continue;
+        }
+        const int pixels_here = min(SEP_PIXELS, a.w - x0);
+#pragma unroll 1
+        for (int r = 0; r < SEP_ROWS; r++) {
+            const int py = block_row*SEP_ROWS + r;
+            if (py < a.h && tid < pixels_here) {
+                uint8_t* pixel = out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3 + (long)(x0 + tid)*3;
+                const uint32_t rgb = staged[r][tid];
+                pixel[0] = (uint8_t)rgb; pixel[1] = (uint8_t)(rgb >> 8); pixel[2] = (uint8_t)(rgb >> 16);
+            }
+        }
     }
 }
 
