@@ -277,18 +277,20 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(SEP_
     const bool outside = (__float_as_int(c0.w) | __float_as_int(c1.w)) != 0;
     const float cx = 0.5f*(c0.x + c1.x);
     // smooth tier of default.glsl: the pixel column's means (see the row loop)
-    float smooth_cz = 0.0f, smooth_g0 = 0.0f, smooth_g1 = 0.0f, smooth_b0 = 0.0f, smooth_b1 = 0.0f, smooth_ground0 = 0.0f, smooth_ground1 = 0.0f, smooth_base0 = 0.0f, smooth_base1 = 0.0f, smooth_half_slope = 0.0f, smooth_offset = 0.0f;
+    // (few registers across the walk — the kernel lives at 64: the odd rows' means are (0.20 + 0.22)*255 times the column mean minus the
+    // even rows', what a group needs beyond that it derives when it begins)
+    float smooth_cz = 0.0f, smooth_g0 = 0.0f, smooth_b0 = 0.0f;
     int smooth_until = 0;                                              // wave-uniform: rows [r, smooth_until) of the walk are smooth for every lane of the wave
     const bool wave_one_square = __builtin_amdgcn_ballot_w64(odd_column0 == odd_column1) == __builtin_amdgcn_ballot_w64(true);
     if constexpr (KIND == SEP_DEFAULT) {
         // the checkerboard under a sample: (column parity ^ row parity) ? 0.22 : 0.20 (default.glsl:4-8)
         const float even_rows0 = odd_column0 ? DEFAULT_ODD : DEFAULT_EVEN, even_rows1 = odd_column1 ? DEFAULT_ODD : DEFAULT_EVEN;
-        const float odd_rows0 = odd_column0 ? DEFAULT_EVEN : DEFAULT_ODD, odd_rows1 = odd_column1 ? DEFAULT_EVEN : DEFAULT_ODD;
         smooth_cz = 0.5f*(c0.z + c1.z);
-        smooth_g0 = 0.5f*fmaf(c0.z, even_rows0, c1.z*even_rows1); smooth_g1 = 0.5f*fmaf(c0.z, odd_rows0, c1.z*odd_rows1);
-        smooth_b0 = 0.5f*(even_rows0 + even_rows1); smooth_b1 = 0.5f*(odd_rows0 + odd_rows1);
+        smooth_g0 = 0.5f*fmaf(c0.z, even_rows0, c1.z*even_rows1);
+        smooth_b0 = 0.5f*(even_rows0 + even_rows1);
     }
-    (void)smooth_cz; (void)smooth_g0; (void)smooth_g1; (void)smooth_b0; (void)smooth_b1; (void)smooth_ground0; (void)smooth_ground1; (void)smooth_base0; (void)smooth_base1; (void)smooth_half_slope; (void)smooth_offset; (void)smooth_until; (void)wave_one_square;
+    (void)smooth_cz; (void)smooth_g0; (void)smooth_b0; (void)smooth_until; (void)wave_one_square;
+    float group_wheel = 0.0f; int wheel_until = 0; (void)group_wheel; (void)wheel_until;
     int shared_until = 0; bool attempted = false; (void)attempted; DefaultRing group_ring = {}; DefaultHue group_hue = {}; DefaultSlope group_slope = {}; float group_y = 0.0f;
     (void)odd_column0; (void)odd_column1; (void)outside; (void)cx; (void)shared_until; (void)group_ring; (void)group_hue; (void)group_slope; (void)group_y;
 #pragma unroll 1
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(SEP_
         if (block_row*SEP_ROWS >= a.h) break;
         if (chunk) {
             __syncthreads();                                           // the previous walk's rows have left the LDS
-            smooth_until = 0; shared_until = 0; attempted = false;
+            smooth_until = 0; shared_until = 0; attempted = false; wheel_until = 0;
         }
         if constexpr (KIND == SEP_DEFAULT) {
             // default.glsl: the walk in groups of four rows. (A row of the tiers below is ~3 KB of code: it exists once, in a loop.)
@@ -308,14 +310,14 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(SEP_
             // one row of a smooth group from its two row entries (see the group's prologue): eleven vector operations and nothing
             // scalar — a wave issues one instruction of ANY kind per turn, so the selects and branches on the rows' parity that used to
             // sit here cost as much as the arithmetic (347 scalar against 470 vector instructions per wave)
-            // (`smooth_offset` = the ring's width at gluv.y = 0 by the group's slope: w(y) = smooth_offset + slope.y*y; `ground_of_rows`,
-            // `base_of_rows` = the group's choice among smooth_ground0/1, smooth_base0/1 by the parity its eight sample rows share)
-            auto smooth_row = [&](const float4 r0, const float4 r1, const bool one_square, const float ground_of_rows, const float base_of_rows) -> uint32_t {
+            // (`offset` = the ring's width at gluv.y = 0 by the group's slope: w(y) = offset + slope.y*y; `ground_of_rows`, `base_of_rows` =
+            // the means of the group's rows: the disc's, or the checkerboard's by the parity its eight sample rows share)
+            auto smooth_row = [&](const float4 r0, const float4 r1, const bool one_square, const float ground_of_rows, const float base_of_rows, const float half_slope, const float offset) -> uint32_t {
 #ifdef SEP_STUB_SMOOTH                                                 // tools/variants.sh: what do the smooth rows' operations cost?
                 return __float_as_uint(r0.x + smooth_cz) & 0xffffffu;
 #endif
                 const float vignette = clamp01(smooth_cz*r0.w);
-                const float ring = fmaf(smooth_half_slope, r0.x, fmaf(smooth_half_slope, r1.x, smooth_offset))*vignette;
+                const float ring = fmaf(half_slope, r0.x, fmaf(half_slope, r1.x, offset))*vignette;
                 const float ground = one_square ? base_of_rows*vignette                       // min(r*c*B, B) = B*min(r*c, 1)
                                                 : __builtin_fminf(r0.w*ground_of_rows, base_of_rows);
                 uint32_t rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, group_hue.red, ground), 0u, 0u);
@@ -325,12 +327,21 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(SEP_
             // one row by the tiers that look at every pixel by itself
             auto general_row = [&](int r, const float4 r0, const float4 r1) -> uint32_t {
                 uint32_t rgb = 0u;
+                // the hue wheel's coordinate at the pixel's centre: from the group's, or by itself
+                auto wheel_at = [&](float cy) -> float {
+                    if (r < wheel_until) {
+                        const float moved = fmaf((3.0f/PI)*cx*__builtin_amdgcn_rcpf(group_ring.len*group_ring.len), cy - group_y, group_wheel);
+                        return moved - 6.0f*::floorf(moved*(1.0f/6.0f));
+                    }
+                    return default_wheel(cx, cy, hue_shift);
+                };
                 const bool group_shares = r < shared_until;
                 // the sample's checkerboard colour by the parities of its column and row; the row's side is block-uniform (scalar selects)
                 const float even0 = (__float_as_int(r0.y) & 1) ? DEFAULT_ODD : DEFAULT_EVEN, odd0 = (__float_as_int(r0.y) & 1) ? DEFAULT_EVEN : DEFAULT_ODD;
                 const float even1 = (__float_as_int(r1.y) & 1) ? DEFAULT_ODD : DEFAULT_EVEN, odd1 = (__float_as_int(r1.y) & 1) ? DEFAULT_EVEN : DEFAULT_ODD;
-                const float board[4] = {odd_column0 ? odd0 : even0, odd_column1 ? odd0 : even0, odd_column0 ? odd1 : even1, odd_column1 ? odd1 : even1};
-                const float vignette[4] = {clamp01(c0.z*r0.z), clamp01(c1.z*r0.z), clamp01(c0.z*r1.z), clamp01(c1.z*r1.z)};
+                // (functions, not arrays: evaluated where a tier uses them — the tier that resolves from means does not)
+                auto board_of = [&](int k) -> float { return (k & 1 ? odd_column1 : odd_column0) ? (k & 2 ? odd1 : odd0) : (k & 2 ? even1 : even0); };
+                auto vignette_of = [&](int k) -> float { return clamp01((k & 1 ? c1.z : c0.z)*(k & 2 ? r1.z : r0.z)); };
                 const float cy = 0.5f*(r0.x + r1.x);
                 const float off = 0.5f*(sf::abs(c1.x - c0.x) + sf::abs(r1.x - r0.x));
                 DefaultRing centre = group_ring;
@@ -343,7 +354,7 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(SEP_
                     // the same test for the pixel alone: its reach is a seventh of the group's, so half of the band that four rows cannot
                     // share (0.05 < |circle| < 0.1 at 4K) is served by one evaluation per pixel instead of four
                     shared = default_shares_slope(centre, off) && default_shares_hue(1.5f*centre.width, centre.len, off);
-                    if (shared) { hue = default_hue(cx, cy, hue_shift); slope = default_slope(centre, cx, cy); slope_y = cy; }
+                    if (shared) { hue = default_wheel_colours(wheel_at(cy)); slope = default_slope(centre, cx, cy); slope_y = cy; }
                 }
                 DefaultBytes bytes = {0u, 0u, 0u};
                 bool meaned = false;
@@ -351,19 +362,16 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(SEP_
                     const float lower = fmaf(slope.y, r0.x - slope_y, centre.width*255.0f), upper = fmaf(slope.y, r1.x - slope_y, centre.width*255.0f);
                     const float side = slope.x*(0.5f*(c1.x - c0.x));
                     const bool disc = centre.circle < 0.0f;
-    #if SEP_DEFAULT_FLOAT_MEAN
-                    // Round 4: where the four samples also share their base colour (the disc, or one square of the checkerboard) the
-                    // pixel is resolved in FLOAT: mean_k vig_k*(base + w_k*hue) = base*V/4 + hue*R/4 with V = sum vig_k and
-                    // R = sum vig_k*w_k, w = {lower, upper} -/+ side — 16 operations instead of 4 x 8 + the byte sums. The reference
-                    // quantises every sample first: the mean of four roundings is within 1/2 of the mean, so the two bytes are
-                    // roundings of numbers within 1/2 of each other: they differ by at most ONE, the tolerance of every fused
-                    // kernel (no sample saturates in the shared tier: |circle| > 0.1 keeps the ring term under 0.03).
-                    const bool one_base = disc || ((odd_column0 == odd_column1) && (((__float_as_int(r0.y) ^ __float_as_int(r1.y)) & 1) == 0));
-                    if (one_base && !outside) {
-                        const float below = vignette[0] + vignette[1], above = vignette[2] + vignette[3];
-                        const float across = (vignette[1] - vignette[0]) + (vignette[3] - vignette[2]);
-                        const float ring = fmaf(side, across, fmaf(upper, above, lower*below))*0.25f;
-                        const float ground = (disc ? DEFAULT_DISC : board[0])*(0.25f*(below + above));
+#if SEP_DEFAULT_FLOAT_MEAN
+                    // the pixel from MEANS, as a smooth row does (see the group's prologue), with the ring's width at the pixel's centre:
+                    // mean_k vig_k*(base_k + w_k*hue) = min(r*G, B) + min(c*r, 1)*w(centre)*hue up to second-order terms — twelve
+                    // operations, no per-sample board or vignette. Within one of the reference like every float mean (no sample
+                    // saturates in a shared tier: |circle| > 0.05 keeps the ring term under 0.1).
+                    if (!outside && (((__float_as_int(r0.y) ^ __float_as_int(r1.y)) & 1) == 0)) {
+                        const bool odd_rows = (__float_as_int(r0.y) & 1) != 0;
+                        const float vignette = clamp01(smooth_cz*r0.w);
+                        const float ring = fmaf(slope.y, cy - slope_y, centre.width*255.0f)*vignette;
+                        const float ground = __builtin_fminf(r0.w*(disc ? DEFAULT_DISC*smooth_cz : (odd_rows ? (DEFAULT_EVEN + DEFAULT_ODD)*smooth_cz - smooth_g0 : smooth_g0)), disc ? DEFAULT_DISC : (odd_rows ? (DEFAULT_EVEN + DEFAULT_ODD) - smooth_b0 : smooth_b0));
                         rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.red, ground), 0u, 0u);
                         rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.green, ground), 1u, rgb);
                         rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ring, hue.blue, ground), 2u, rgb);
@@ -371,10 +379,10 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(SEP_
                     }
 #endif
                     if (!meaned) {
-                    default_colour<0>(bytes, hue, lower - side, disc ? DEFAULT_DISC : board[0], vignette[0]);
-                    default_colour<1>(bytes, hue, lower + side, disc ? DEFAULT_DISC : board[1], vignette[1]);
-                    default_colour<2>(bytes, hue, upper - side, disc ? DEFAULT_DISC : board[2], vignette[2]);
-                    default_colour<3>(bytes, hue, upper + side, disc ? DEFAULT_DISC : board[3], vignette[3]);
+                    default_colour<0>(bytes, hue, lower - side, disc ? DEFAULT_DISC : board_of(0), vignette_of(0));
+                    default_colour<1>(bytes, hue, lower + side, disc ? DEFAULT_DISC : board_of(1), vignette_of(1));
+                    default_colour<2>(bytes, hue, upper - side, disc ? DEFAULT_DISC : board_of(2), vignette_of(2));
+                    default_colour<3>(bytes, hue, upper + side, disc ? DEFAULT_DISC : board_of(3), vignette_of(3));
                     }
                 } else {                                                  // the ring per sample; the hue at the centre if it may be, else per sample
                     const float ux[4] = {c0.x, c1.x, c0.x, c1.x}, uy[4] = {r0.x, r0.x, r1.x, r1.x};
@@ -384,28 +392,28 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(SEP_
                     for (int k = 0; k < 4; k++) { ring[k] = default_ring(ux[k], uy[k]); widest = __builtin_fmaxf(widest, ring[k].width); }
                     float width255[4], base255[4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) { width255[k] = ring[k].width*255.0f; base255[k] = (ring[k].circle < 0.0f) ? DEFAULT_DISC : board[k]; }
+                    for (int k = 0; k < 4; k++) { width255[k] = ring[k].width*255.0f; base255[k] = (ring[k].circle < 0.0f) ? DEFAULT_DISC : board_of(k); }
                     if (centre.len > 8.0f*off) {
-                        const float wheel = default_wheel(cx, cy, hue_shift);
+                        const float wheel = wheel_at(cy);
                         if (default_shares_hue(widest, centre.len, off)) {
                             hue = default_wheel_colours(wheel);
-                            default_colour<0>(bytes, hue, width255[0], base255[0], vignette[0]); default_colour<1>(bytes, hue, width255[1], base255[1], vignette[1]);
-                            default_colour<2>(bytes, hue, width255[2], base255[2], vignette[2]); default_colour<3>(bytes, hue, width255[3], base255[3], vignette[3]);
+                            default_colour<0>(bytes, hue, width255[0], base255[0], vignette_of(0)); default_colour<1>(bytes, hue, width255[1], base255[1], vignette_of(1));
+                            default_colour<2>(bytes, hue, width255[2], base255[2], vignette_of(2)); default_colour<3>(bytes, hue, width255[3], base255[3], vignette_of(3));
                         } else {
                             // on the ring the glow is wide enough to show the hue turning inside a pixel: the centre's wheel coordinate
                             // moved by each sample's own angle (one atan2 per pixel instead of four)
                             const float turn = (3.0f/PI)*__builtin_amdgcn_rcpf(centre.len*centre.len);
                             const float along = cx*(0.5f*(r1.x - r0.x))*turn, across = cy*(0.5f*(c1.x - c0.x))*turn;   // x dy, y dx
-                            default_colour<0>(bytes, default_hue_beside(wheel, across - along), width255[0], base255[0], vignette[0]);
-                            default_colour<1>(bytes, default_hue_beside(wheel, -across - along), width255[1], base255[1], vignette[1]);
-                            default_colour<2>(bytes, default_hue_beside(wheel, across + along), width255[2], base255[2], vignette[2]);
-                            default_colour<3>(bytes, default_hue_beside(wheel, along - across), width255[3], base255[3], vignette[3]);
+                            default_colour<0>(bytes, default_hue_beside(wheel, across - along), width255[0], base255[0], vignette_of(0));
+                            default_colour<1>(bytes, default_hue_beside(wheel, -across - along), width255[1], base255[1], vignette_of(1));
+                            default_colour<2>(bytes, default_hue_beside(wheel, across + along), width255[2], base255[2], vignette_of(2));
+                            default_colour<3>(bytes, default_hue_beside(wheel, along - across), width255[3], base255[3], vignette_of(3));
                         }
                     } else {                                              // next to the origin: every sample by itself
-                        default_colour<0>(bytes, default_hue(ux[0], uy[0], hue_shift), width255[0], base255[0], vignette[0]);
-                        default_colour<1>(bytes, default_hue(ux[1], uy[1], hue_shift), width255[1], base255[1], vignette[1]);
-                        default_colour<2>(bytes, default_hue(ux[2], uy[2], hue_shift), width255[2], base255[2], vignette[2]);
-                        default_colour<3>(bytes, default_hue(ux[3], uy[3], hue_shift), width255[3], base255[3], vignette[3]);
+                        default_colour<0>(bytes, default_hue(ux[0], uy[0], hue_shift), width255[0], base255[0], vignette_of(0));
+                        default_colour<1>(bytes, default_hue(ux[1], uy[1], hue_shift), width255[1], base255[1], vignette_of(1));
+                        default_colour<2>(bytes, default_hue(ux[2], uy[2], hue_shift), width255[2], base255[2], vignette_of(2));
+                        default_colour<3>(bytes, default_hue(ux[3], uy[3], hue_shift), width255[3], base255[3], vignette_of(3));
                     }
                 }
                 if (outside) {                                            // camera.glsl:83 / default.glsl:14-16, per column: 0.15 grey = byte 38
@@ -467,13 +475,16 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(SEP_
                             }
                         }
                         if (__builtin_amdgcn_ballot_w64(fine) == __builtin_amdgcn_ballot_w64(true)) smooth_until = r + 4;
-                    }
-                    if (r < smooth_until) {
-                        const bool disc = group_ring.circle < 0.0f;
-                        smooth_ground0 = disc ? DEFAULT_DISC*smooth_cz : smooth_g0; smooth_ground1 = disc ? DEFAULT_DISC*smooth_cz : smooth_g1;
-                        smooth_base0 = disc ? DEFAULT_DISC : smooth_b0; smooth_base1 = disc ? DEFAULT_DISC : smooth_b1;
-                        smooth_half_slope = 0.5f*group_slope.y;
-                        smooth_offset = fmaf(-group_slope.y, group_y, group_ring.width*255.0f);
+                        else if (attempted) {
+                            // the group's rows go through the tiers below, pixel by pixel: ONE arctangent for the four rows of a lane,
+                            // at the group's middle; a row moves the wheel by its own angle x*dy/len² (default_hue_beside: second order
+                            // in dy/len, < 1e-5 of the wheel where the ring lives), unless the lane sits next to the origin
+                            const float cy = 0.5f*(rows[2*py + 3].x + rows[2*py + 4].x);
+                            const float reach = 0.5f*sf::abs(c1.x - c0.x) + 3.5f*sf::abs(r1.x - r0.x);
+                            group_wheel = default_wheel(cx, cy, hue_shift);
+                            group_y = cy;
+                            wheel_until = (group_ring.len > 16.0f*reach) ? r + 4 : 0;
+                        }
                     }
                 }
                 if (r < smooth_until && py + 3 < a.h) {
@@ -487,13 +498,16 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(SEP_
                     for (int k = 1; k < 8; k++) mixed |= __float_as_int(e[k].y) ^ __float_as_int(e[0].y);
                     if ((mixed & 1) == 0) {
                         const bool odd_rows = (__float_as_int(e[0].y) & 1) != 0;
-                        const float ground_of_rows = odd_rows ? smooth_ground1 : smooth_ground0, base_of_rows = odd_rows ? smooth_base1 : smooth_base0;
+                        const bool disc = group_ring.circle < 0.0f;
+                        const float ground_of_rows = disc ? DEFAULT_DISC*smooth_cz : (odd_rows ? (DEFAULT_EVEN + DEFAULT_ODD)*smooth_cz - smooth_g0 : smooth_g0);
+                        const float base_of_rows = disc ? DEFAULT_DISC : (odd_rows ? (DEFAULT_EVEN + DEFAULT_ODD) - smooth_b0 : smooth_b0);
+                        const float half_slope = 0.5f*group_slope.y, offset = fmaf(-group_slope.y, group_y, group_ring.width*255.0f);
                         if (wave_one_square) {                          // wave-uniform: both sample columns of every lane in one square of the checkerboard's columns
 #pragma unroll
-                            for (int k = 0; k < 4; k++) stage(r + k, smooth_row(e[2*k], e[2*k + 1], true, ground_of_rows, base_of_rows));
+                            for (int k = 0; k < 4; k++) stage(r + k, smooth_row(e[2*k], e[2*k + 1], true, ground_of_rows, base_of_rows, half_slope, offset));
                         } else {
 #pragma unroll
-                            for (int k = 0; k < 4; k++) stage(r + k, smooth_row(e[2*k], e[2*k + 1], false, ground_of_rows, base_of_rows));
+                            for (int k = 0; k < 4; k++) stage(r + k, smooth_row(e[2*k], e[2*k + 1], false, ground_of_rows, base_of_rows, half_slope, offset));
                         }
                         continue;
                     }
