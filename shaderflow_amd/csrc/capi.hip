@@ -271,8 +271,12 @@ struct EngineLanes {
     Context* c = nullptr;
     EngineCopy* e = nullptr;                                        // null: the lanes are the context's copy streams
     bool resolved = false;
-    hsa_signal_t done[2] = {};
-    bool busy[2] = {false, false};
+    // up to four copies in flight: lanes 0 and 2 on one engine, 1 and 3 on the other. An engine takes its second copy from its own
+    // queue the moment the first ends; with one copy per engine both ended together and the link idled until the host had issued the
+    // next pair (1080p frames: 137 us per frame where the link needs 112)
+    static constexpr int LANES = 4;
+    hsa_signal_t done[LANES] = {};
+    bool busy[LANES] = {};
 
     // `host` / `device`: the first frame's two ends (they name the agents). Called from the thread that issues.
     void resolve(Context* context, const void* host, const void* device) {
@@ -286,7 +290,7 @@ struct EngineLanes {
     bool issue(int lane, void* host, const void* device, size_t nbytes) {
         if (e) {
             hsa_signal_store_relaxed(done[lane], 1);
-            hsa_status_t status = hsa_amd_memory_async_copy_on_engine(host, e->cpu, device, e->gpu, nbytes, 0, nullptr, done[lane], (hsa_amd_sdma_engine_id_t)e->engine[lane], false);
+            hsa_status_t status = hsa_amd_memory_async_copy_on_engine(host, e->cpu, device, e->gpu, nbytes, 0, nullptr, done[lane], (hsa_amd_sdma_engine_id_t)e->engine[lane & 1], false);
             if (status != HSA_STATUS_SUCCESS) {                      // the engine's queue could not be had: let HSA choose
                 hsa_signal_store_relaxed(done[lane], 1);
                 status = hsa_amd_memory_async_copy(host, e->cpu, device, e->gpu, nbytes, 0, nullptr, done[lane]);
@@ -295,20 +299,20 @@ struct EngineLanes {
             e = nullptr;                                             // HSA refuses: HIP's copy from here on
             if (context_copy_streams(c) != SFX_OK) return false;
         }
-        if (hipMemcpyAsync(host, device, nbytes, hipMemcpyDeviceToHost, c->copy_streams[lane]) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipMemcpyAsync(host, device, nbytes, hipMemcpyDeviceToHost, c->copy_streams[lane & 1]) != hipSuccess) { (void)hipGetLastError(); return false; }
         busy[lane] = true;
         return true;
     }
     void finish(int lane) {
         if (!busy[lane]) return;
         if (e) hsa_signal_wait_scacquire(done[lane], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
-        else hipStreamSynchronize(c->copy_streams[lane]);
+        else hipStreamSynchronize(c->copy_streams[lane & 1]);       // (a stream's later copy too: in order, so nothing is released early)
         busy[lane] = false;
     }
     void release() {
-        finish(0); finish(1);
+        for (int lane = 0; lane < LANES; lane++) finish(lane);
         if (resolved && done[0].handle) for (auto& signal : done) if (signal.handle) hsa_signal_destroy(signal);
-        done[0] = done[1] = hsa_signal_t{};
+        for (auto& signal : done) signal = hsa_signal_t{};
     }
 };
 
@@ -1694,7 +1698,7 @@ struct Ring : Object {
 
 static void ring_copier(Ring* r) {
     hipSetDevice(r->ctx->device);
-    int in_lane[2] = {-1, -1}, next = 0;
+    int in_lane[EngineLanes::LANES] = {-1, -1, -1, -1}, next = 0;
     auto finish = [&](int lane) {
         if (in_lane[lane] < 0) return;
         r->lanes.finish(lane);
@@ -1708,7 +1712,7 @@ static void ring_copier(Ring* r) {
             std::unique_lock<std::mutex> lock(r->mutex);
             if (r->copy_queue.empty()) {                             // nothing to issue: let what is in flight land (in issue order), then sleep
                 lock.unlock();
-                finish(next); finish(next ^ 1);
+                for (int k = 0; k < r->lane_count; k++) finish((next + k) % r->lane_count);
                 lock.lock();
                 r->copy_wake.wait(lock, [&] { return r->stop || !r->copy_queue.empty(); });
                 if (r->copy_queue.empty()) return;
@@ -1730,7 +1734,7 @@ static void ring_copier(Ring* r) {
             continue;
         }
         in_lane[next] = job.slot;
-        if (r->lane_count > 1) next ^= 1;
+        next = (next + 1) % r->lane_count;
     }
 }
 
@@ -1768,7 +1772,8 @@ extern "C" int sfx_ring_create(sfx_handle h, size_t frame_bytes, int slots, sfx_
     Ring* r = new Ring();
     r->magic = MAGIC_RING; r->ctx = c; r->frame_bytes = frame_bytes; r->slots = slots;
     r->host.resize(slots); r->ready.resize(slots); r->pending.assign(slots, 0); r->copying.assign(slots, 0);
-    if (const char* n = getenv("SHADERFLOW_COPY_STREAMS")) r->lane_count = atoi(n) == 1 ? 1 : 2;   // A/B switch for measurements
+    r->lane_count = std::min(EngineLanes::LANES, std::max(1, slots - 1));                             // (a slot is being filled or written while the others land)
+    if (const char* n = getenv("SHADERFLOW_COPY_STREAMS")) r->lane_count = std::min(r->lane_count, std::max(1, atoi(n)));   // A/B switch for measurements
     for (auto& f : r->fences) HIP_TRY(hipEventCreateWithFlags(&f, hipEventDisableTiming));
     for (int k = 0; k < slots; k++) {
         HIP_TRY(hipHostMalloc(&r->host[k], frame_bytes, hipHostMallocDefault));
