@@ -1,6 +1,6 @@
 # Light fragments and the two-pass configuration: kernel-trace + WRITE_SIZE / FETCH_SIZE passes, achieved HBM GB/s per kernel.
 # Runs on the GPU box; writes gpurun_out/r04/light_kernels.txt (copied to profiles/r04_light_kernels.txt by hand).
-cd /root/repo
+cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r04
 OUT=gpurun_out/r04/light_kernels.txt

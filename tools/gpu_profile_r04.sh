@@ -1,7 +1,7 @@
 # round-4 evidence run on the GPU box: profile of the bench command (kernel trace + PMC passes incl. the VALU class counters), light
 # kernels (WRITE/FETCH per kernel), bench lines of the other configurations, frame-loop scenes, export stress, parity histogram.
 # Everything lands in gpurun_out/r04/ (copied to profiles/ by hand).
-cd /root/repo
+cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r04
 bash tools/profile_bench.sh r04 > gpurun_out/r04/profile_summary_stdout.txt 2>&1
@@ -18,6 +18,9 @@ for cfg in "--width 256 --height 256 --ssaa 1 --frames-per-step 60" "--width 192
 done
 { python tools/profile_frame_loop.py; python tools/profile_clock_loop.py; } 2>&1 | grep "frames/s" > gpurun_out/r04/frame_loop.txt
 { python tools/profile_export.py own; python tools/profile_export.py torch; GPU_MAX_HW_QUEUES=2 python tools/profile_export.py own; python tools/experiments/export_like_bench.py --first-leg; } 2>&1 | grep -E "frames/s" > gpurun_out/r04/export_stress.txt
+{ python tools/experiments/rotated_camera.py; } 2>&1 | grep "camera rotated" > gpurun_out/r04/rolled_camera.txt
+{ python tools/experiments/life_pixel_formats.py; } 2>&1 | grep "frames/s" > gpurun_out/r04/frame_loop_pixel_formats.txt
+{ ZOOM_LIST="1 0.2 2.2 0.74" tools/experiments/basic_variants.sh; } 2>&1 | grep zoom > gpurun_out/r04/basic_tiers.txt
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r04/bench_c3.line.json 2> gpurun_out/r04/bench_c3.err
 tail -2 gpurun_out/r04/bench_c3.err; cat gpurun_out/r04/bench_c3.line.json
 python3 - <<'PY'
