@@ -20,9 +20,11 @@ step i+1. `value` = frames of all ranks / max-over-ranks time: frames resident i
 Prints ONE JSON line (rank 0): value = frames/s of the whole job, plus
   roofline     — the dominant kernel (named by the library: sfx_last_kernel). It is bound by VALU issue and LDS bandwidth, not
                  by HBM, so `bound` is "valu": achieved = instruction lanes per second from the launch time measured HERE (HIP
-                 events on the launch stream inside the timed region) x the instructions per supersample rocprofv3 counted for
-                 THIS build (profiles/*.json, checked against the library's source fingerprint — stale counters are dropped,
-                 loudly). The HBM view the contract asks for sits beside it under `hbm`: algorithmic bytes over
+                 events on the launch stream inside the timed region) x the instructions per supersample rocprofv3 counts IN THIS
+                 RUN (two short children of this script under `rocprofv3 --pmc`: the VALU class counters and GRBM_GUI_ACTIVE;
+                 `--no-live-counters` skips them). What a short run cannot afford — HBM traffic, LDS and wave-state counters —
+                 comes from the tracked profile of THIS build (profiles/*.json, checked against the library's source
+                 fingerprint — stale counters are dropped, loudly); `roofline.counters_from` says which is which. The HBM view the contract asks for sits beside it under `hbm`: algorithmic bytes over
                  the same launch time, and `traffic` = measured FETCH_SIZE + WRITE_SIZE per launch from the same profile.
   cpu_baseline — the oracle (kind "port": plain-C restatement of the reference path) on the host cores of this box, all cores
                  and one thread, over bands of three frames of the same workload; rank 0 at N = 1 only, AFTER the GPU legs.
@@ -74,6 +76,9 @@ def parse_args():
                    help="tier analysis of the light fragments (tools/experiments/basic_tiers.sh): the camera's zoom; the metric's runs leave it at 1")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-export", action="store_true", help="skip the host-inclusive export measurement")
+    p.add_argument("--no-live-counters", action="store_true",
+                   help="do not collect the dominant kernel's instruction counters in this run (two short rocprofv3 children of this script); "
+                        "the roofline then rests on the tracked profile alone")
     p.add_argument("--cpu-seconds", type=float, default=18.0, help="budget of the CPU baseline (all cores + one thread)")
     return p.parse_args()
 
@@ -176,6 +181,58 @@ def profile_counters(kernel: str) -> dict | None:
             return dict(entry, frames_per_launch=(line.get("roofline") or {}).get("frames_per_launch"))
     print(f"bench.py: {PROFILE.name} has no counters for '{kernel}' (it holds {list(record.get('kernels', {}))[:4]}…)", file=sys.stderr)
     return None
+
+
+LIVE_PASSES = (("SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
+                "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT", "SQ_THREAD_CYCLES_VALU"),
+               ("GRBM_GUI_ACTIVE", "GRBM_COUNT"))
+
+
+def live_counters(args, kernel: str) -> dict | None:
+    """The instruction counters of `kernel` measured IN THIS RUN: one short child of this script per pass under `rocprofv3 --kernel-trace
+    --pmc` (counters in runs of their own, the program itself after `--`), this run's frames per launch. The same structure as
+    profile_counters(); None — with the reason on stderr — when the profiler is not there or a pass fails (the tracked profile stands)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        print("bench.py: no rocprofv3 on PATH: the roofline's counters come from the tracked profile", file=sys.stderr)
+        return None
+    frames = args.frames_per_step
+    counters: dict = {}
+    durations: list = []
+    with tempfile.TemporaryDirectory(prefix="shaderflow_bench_pmc_", dir="/tmp") as scratch:
+        for index, names in enumerate(LIVE_PASSES):
+            out = Path(scratch)/f"pass{index}"
+            command = ["rocprofv3", "--kernel-trace", "--pmc", *names, "-f", "csv", "-d", str(out), "-o", "pmc", "--",
+                       sys.executable, str(Path(__file__).resolve()), "--steps", "1", "--warmup", "1", "--frames-per-step", str(frames),
+                       "--width", str(args.width), "--height", str(args.height), "--ssaa", str(args.ssaa),
+                       "--no-cpu-baseline", "--no-export", "--no-live-counters"]
+            try:
+                done = subprocess.run(command, capture_output=True, text=True, timeout=240, env=dict(os.environ, TMPDIR="/tmp"), cwd=str(ROOT))
+            except (OSError, subprocess.TimeoutExpired) as error:
+                print(f"bench.py: counter pass {index} did not run ({error}): the tracked profile stands", file=sys.stderr)
+                return None
+            found: dict = {}
+            for table in out.glob("**/*counter_collection.csv"):
+                with open(table) as handle:
+                    for row in csv.DictReader(handle):
+                        name = row["Kernel_Name"].replace("sf::", "").replace("void ", "").split("(")[0]
+                        if name.replace(" ", "") == kernel.replace(" ", ""):
+                            found.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            if done.returncode != 0 or not found:
+                print(f"bench.py: counter pass {index} gave nothing for '{kernel}' (rc {done.returncode}): the tracked profile stands\n{done.stderr[-400:]}", file=sys.stderr)
+                return None
+            counters.update({name: sum(values)/len(values) for name, values in found.items()})
+            if index == len(LIVE_PASSES) - 1:                       # the pass GRBM_GUI_ACTIVE came from: its own durations give the clock
+                for table in out.glob("**/*kernel_trace.csv"):
+                    with open(table) as handle:
+                        for row in csv.DictReader(handle):
+                            name = row["Kernel_Name"].replace("sf::", "").replace("void ", "").split("(")[0]
+                            if name.replace(" ", "") == kernel.replace(" ", ""):
+                                durations.append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    return {"counters": counters, "duration": {"average_ns": sum(durations)/len(durations)} if durations else None, "frames_per_launch": frames}
 
 
 # SIMD cycles a wave64 VALU instruction of each class occupies, as measured on this chip (tools/ubench_valu.hip,
@@ -454,6 +511,19 @@ def main() -> None:
         hbm_achieved = b_alg*piece/launch_s/1e9
         samples_per_s = (w*s)*(h*s)*piece/launch_s
         counters = profile_counters(kernel) if c3 else None
+        counters_from = str(PROFILE.relative_to(ROOT)) if counters else None
+        profiled = any(key.startswith(("ROCPROF", "ROCP_")) for key in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")   # this run IS a profiler's child
+        if c3 and world == 1 and not distributed and not profiled and not args.no_live_counters:
+            # the driver's run measures its own instruction counters; what a short run cannot afford —
+            # the HBM traffic passes, the LDS and wave-state counters — stays with the tracked profile when its sources match
+            live = live_counters(args, kernel)
+            if live:
+                tracked = counters if (counters and counters.get("frames_per_launch") == live["frames_per_launch"]) else None   # per-launch counters of another launch size do not mix
+                merged = dict(tracked["counters"]) if tracked else {}
+                merged.update(live["counters"])
+                counters = {"counters": merged, "duration": live["duration"] or (tracked or {}).get("duration"), "frames_per_launch": live["frames_per_launch"]}
+                counters_from = ("live: " + ", ".join(name for names in LIVE_PASSES for name in names) + " (rocprofv3 children of this run)"
+                                 + (f"; the rest: {counters_from}" if tracked else ""))
         per_sample = traffic = lds_busy = issue = None
         if counters:
             cs = counters["counters"]
@@ -487,7 +557,7 @@ def main() -> None:
                          "valu_instructions_per_supersample": round(per_sample, 1) if per_sample else None,
                          "lds_busy": round(lds_busy, 3) if lds_busy else None,
                          "issue_cycles_frac": issue["frac"] if issue else None, "issue_model": issue,
-                         "traffic": traffic, "counters_from": str(PROFILE.relative_to(ROOT)) if counters else None,
+                         "traffic": traffic, "counters_from": counters_from,
                          "launch_ms": round(launch_s*1e3, 3), "frames_per_launch": piece, "launches_per_step": parts,
                          "hbm": {"achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved/HBM_PEAK_GBS, 4),
                                  "algorithmic_bytes_per_launch": b_alg*piece,

@@ -394,6 +394,29 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert record["cpu_baseline"]["single_thread"]["cores"] == 1 and record["export_host"]["value"] > 0
 
 
+def test_bench_measures_the_instruction_counters_of_its_own_run():
+    """The benchmark's configuration (C3) as the driver runs it, short: the dominant kernel's VALU counters come from two rocprofv3
+    children of the run itself, and they say what the tracked profile says — 549 instructions per
+    supersample for a kernel that has not changed since round 3. Skipped where the profiler is not installed."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    from pathlib import Path
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("no rocprofv3 on this box")
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root/"bench.py"), "--steps", "2", "--warmup", "1", "--frames-per-step", "30", "--no-cpu-baseline", "--no-export"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    record = json.loads([line for line in out.stdout.splitlines() if line.startswith("{")][-1])
+    roofline = record["roofline"]
+    assert roofline["counters_from"].startswith("live: SQ_INSTS_VALU"), (roofline["counters_from"], out.stderr[-1500:])
+    assert 540.0 < roofline["valu_instructions_per_supersample"] < 560.0, roofline
+    assert 0.5 < roofline["issue_cycles_frac"] < 1.0 and 0.4 < roofline["frac"] < 0.8, roofline
+    assert 1.8 < roofline["issue_model"]["effective_clock_GHz"] < 2.5, roofline["issue_model"]
+
+
 @pytest.mark.parametrize("samplerate,fps,seconds", [(48000, 30.0, 0.4), (22050, 50.0, 0.3), (32000, 24.0, 0.5)])
 def test_visualizer_other_sample_rates_and_frame_rates(samplerate, fps, seconds):
     """The chunk arithmetic, window schedule, filterbank and DynamicNumber coefficients all depend on (samplerate, fps): the tape and
