@@ -21,10 +21,11 @@ Prints ONE JSON line (rank 0): value = frames/s of the whole job, plus
   roofline     — the dominant kernel (named by the library: sfx_last_kernel). It is bound by VALU issue and LDS bandwidth, not
                  by HBM, so `bound` is "valu": achieved = instruction lanes per second from the launch time measured HERE (HIP
                  events on the launch stream inside the timed region) x the instructions per supersample rocprofv3 counts IN THIS
-                 RUN (two short children of this script under `rocprofv3 --pmc`: the VALU class counters and GRBM_GUI_ACTIVE;
-                 `--no-live-counters` skips them). What a short run cannot afford — HBM traffic, LDS and wave-state counters —
-                 comes from the tracked profile of THIS build (profiles/*.json, checked against the library's source
-                 fingerprint — stale counters are dropped, loudly); `roofline.counters_from` says which is which. The HBM view the contract asks for sits beside it under `hbm`: algorithmic bytes over
+                 RUN (five short children of this script under `rocprofv3 --kernel-trace --pmc`, one per pass: the VALU class
+                 counters, GRBM_GUI_ACTIVE, FETCH_SIZE, WRITE_SIZE, the LDS and wave-state counters; `--no-live-counters` skips
+                 them). Where the profiler is missing or a pass fails the tracked profile of THIS build stands in (profiles/*.json,
+                 checked against the library's source fingerprint — stale counters are dropped, loudly);
+                 `roofline.counters_from` says which it was. The HBM view the contract asks for sits beside it under `hbm`: algorithmic bytes over
                  the same launch time, and `traffic` = measured FETCH_SIZE + WRITE_SIZE per launch from the same profile.
   cpu_baseline — the oracle (kind "port": plain-C restatement of the reference path) on the host cores of this box, all cores
                  and one thread, over bands of three frames of the same workload; rank 0 at N = 1 only, AFTER the GPU legs.
@@ -185,7 +186,9 @@ def profile_counters(kernel: str) -> dict | None:
 
 LIVE_PASSES = (("SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
                 "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT", "SQ_THREAD_CYCLES_VALU"),
-               ("GRBM_GUI_ACTIVE", "GRBM_COUNT"))
+               ("GRBM_GUI_ACTIVE", "GRBM_COUNT"),
+               ("FETCH_SIZE",), ("WRITE_SIZE",),                     # (each in a pass of its own, as the microarchitecture guide prescribes)
+               ("SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"))
 
 
 def live_counters(args, kernel: str) -> dict | None:
@@ -225,7 +228,7 @@ def live_counters(args, kernel: str) -> dict | None:
                 print(f"bench.py: counter pass {index} gave nothing for '{kernel}' (rc {done.returncode}): the tracked profile stands\n{done.stderr[-400:]}", file=sys.stderr)
                 return None
             counters.update({name: sum(values)/len(values) for name, values in found.items()})
-            if index == len(LIVE_PASSES) - 1:                       # the pass GRBM_GUI_ACTIVE came from: its own durations give the clock
+            if "GRBM_GUI_ACTIVE" in names:                          # the pass GRBM_GUI_ACTIVE came from: its own durations give the clock
                 for table in out.glob("**/*kernel_trace.csv"):
                     with open(table) as handle:
                         for row in csv.DictReader(handle):
@@ -514,8 +517,7 @@ def main() -> None:
         counters_from = str(PROFILE.relative_to(ROOT)) if counters else None
         profiled = any(key.startswith(("ROCPROF", "ROCP_")) for key in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")   # this run IS a profiler's child
         if c3 and world == 1 and not distributed and not profiled and not args.no_live_counters:
-            # the driver's run measures its own instruction counters; what a short run cannot afford —
-            # the HBM traffic passes, the LDS and wave-state counters — stays with the tracked profile when its sources match
+            # the driver's run measures its own counters; the tracked profile fills in what a pass did not give
             live = live_counters(args, kernel)
             if live:
                 tracked = counters if (counters and counters.get("frames_per_launch") == live["frames_per_launch"]) else None   # per-launch counters of another launch size do not mix
