@@ -26,6 +26,43 @@ def random_camera(rng):
                 iCameraPosition=(float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.2, 0.2)), 0.0), iCameraSeparation=float(rng.uniform(0.02, 0.1)))
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_default_fragment_random_sizes_and_cameras(gpu, seed):
+    """default.glsl's fused kernel (k_separable_fused<default>) resolves most pixels from column and row MEANS and shares one evaluation
+    of the polar terms between the rows of a walk, four rows or a pixel — which tier a pixel takes depends on its size in gluv units
+    and on where the ring and the checkerboard's edges fall, so: random sizes from thumbnails to 2560x1440 (walks of 8 and of 16 rows,
+    partial blocks, widths that are not multiples of four), zoomed / panned / dollied cameras (the ring anywhere, or nowhere), a wanted
+    aspect narrower than the frame (columns out of bounds), any iTau, bottom-up and top-down rows; whole frames against the oracle
+    within 1 LSB."""
+    from shaderflow_amd import _native as N
+    rng = np.random.default_rng(9100 + seed)
+    w, h = [(int(rng.integers(40, 900)), int(rng.integers(24, 500))), (1280, 720), (1920, 1080), (2560, 1440), (1000, 1000), (3001, 403)][min(seed % 8, 5)]
+    u, arrays, params = visualizer_inputs(w, h, seed=seed)
+    u.iSSAA, u.iTau = 2.0, float(rng.random())
+    if seed % 3:
+        u.iCameraZoom = float(rng.choice([0.2, 0.55, 0.74, 1.0, 1.3, 2.2, 5.0]))
+        u.iCameraPosition[0] = float(rng.uniform(-0.8, 0.8)); u.iCameraPosition[1] = float(rng.uniform(-0.5, 0.5))
+        u.iCameraIsometric = float(rng.choice([0.0, 0.3])); u.iCameraDolly = float(rng.choice([0.0, 0.4]))
+    if seed % 5 == 4:
+        u.iWantAspect = float(0.8*w/h)
+    prog, _ = gpu.program("default")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    top_down = bool(rng.integers(0, 2))
+    N.check(gpu.lib.sfx_ctx_output_top_down(gpu.ctx.handle, int(top_down)))
+    try:
+        got = gpu.render_resolve(prog, w, h, 2, 2)
+    finally:
+        N.check(gpu.lib.sfx_ctx_output_top_down(gpu.ctx.handle, 0))
+    assert gpu.lib.sfx_last_kernel().decode() == "k_separable_fused<default>", gpu.lib.sfx_last_kernel()
+    screen = O.render("default", u, oracle_textures(arrays, params), w*2, h*2, threads=8)
+    want = O.resolve(screen, w, h, 2, threads=8)
+    if top_down:
+        want = want[::-1]
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1, (seed, (w, h), lsb_report(got, want), np.argwhere(d > 1)[:5].tolist())
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_visualizer_random_configurations(gpu, seed):
     rng = np.random.default_rng(1000 + seed)
