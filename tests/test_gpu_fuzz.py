@@ -26,6 +26,37 @@ def random_camera(rng):
                 iCameraPosition=(float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.2, 0.2)), 0.0), iCameraSeparation=float(rng.uniform(0.02, 0.1)))
 
 
+@pytest.mark.parametrize("seed", range(18))
+def test_visualizer_rolled_and_tilted_cameras_random(gpu, seed):
+    """Cameras that are neither the identity nor axis aligned (rolled about the forward axis, tilted about the right one, zoomed and
+    panned on top) over random sizes and backgrounds, no SSAA / 2x / 4x: the host bounds a block's tap window from the camera's slopes
+    (capi camera_slopes) and picks tile and block shape per launch; whatever it picks — and whatever a block that still misses its
+    tile falls back to — is within 1 LSB of the oracle."""
+    import math
+    rng = np.random.default_rng(9300 + seed)
+    ssaa = (2, 1, 4)[seed % 3]
+    w = int(rng.integers(64, 520 if ssaa < 4 else 260)); h = int(rng.integers(40, 300 if ssaa < 4 else 150))
+    bg_size = (int(rng.integers(64, 480)), int(rng.integers(36, 270)))
+    u, arrays, params = visualizer_inputs(w, h, seed=seed, volume=float(rng.choice([0.0, 0.5, 0.9, 1.4])), bg_size=bg_size, time=float(rng.uniform(0, 40)))
+    params["background"] = ("linear", bool(rng.integers(0, 2)), bool(rng.integers(0, 2)))
+    roll, tilt = math.radians(float(rng.uniform(-180, 180))), math.radians(float(rng.choice([0.0, 0.0, 8.0, -15.0])))
+    c, s_, ct, st = math.cos(roll), math.sin(roll), math.cos(tilt), math.sin(tilt)
+    for name, vector in (("iCameraRight", (c, s_, 0.0)), ("iCameraUpward", (-s_*ct, c*ct, st)), ("iCameraForward", (s_*st, -c*st, ct))):
+        for i, v in enumerate(vector):
+            getattr(u, name)[i] = v
+    if seed % 2:
+        u.iCameraZoom = float(rng.uniform(0.7, 1.6)); u.iCameraPosition[0] = float(rng.uniform(-0.2, 0.2)); u.iCameraPosition[1] = float(rng.uniform(-0.2, 0.2))
+    u.iSSAA = float(ssaa)
+    screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, threads=8)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    got, want = (gpu.render(prog, w, h), screen) if ssaa == 1 else (gpu.render_resolve(prog, w, h, ssaa, 2), O.resolve(screen, w, h, 2, threads=4))
+    assert not gpu.lib.sfx_last_kernel().decode().startswith("k_visualizer_strip"), gpu.lib.sfx_last_kernel()
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1, (seed, (w, h, ssaa, bg_size), gpu.lib.sfx_last_kernel().decode(), lsb_report(got, want))
+
+
 @pytest.mark.parametrize("seed", range(48))
 def test_default_fragment_random_sizes_and_cameras(gpu, seed):
     """default.glsl's fused kernel (k_separable_fused<default>) resolves most pixels from column and row MEANS and shares one evaluation
