@@ -354,6 +354,9 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(SEP_
                     // the same test for the pixel alone: its reach is a seventh of the group's, so half of the band that four rows cannot
                     // share (0.05 < |circle| < 0.1 at 4K) is served by one evaluation per pixel instead of four
                     shared = default_shares_slope(centre, off) && default_shares_hue(1.5f*centre.width, centre.len, off);
+#ifdef SEP_STUB_UNSHARED                                               // tools/variants.sh: what does the per-sample tier cost? (wrong pixels in the band)
+                    shared = true;
+#endif
                     if (shared) { hue = default_wheel_colours(wheel_at(cy)); slope = default_slope(centre, cx, cy); slope_y = cy; }
                 }
                 DefaultBytes bytes = {0u, 0u, 0u};
