@@ -212,11 +212,21 @@ def live_counters(args, kernel: str) -> dict | None:
                        sys.executable, str(Path(__file__).resolve()), "--steps", "1", "--warmup", "1", "--frames-per-step", str(frames),
                        "--width", str(args.width), "--height", str(args.height), "--ssaa", str(args.ssaa),
                        "--no-cpu-baseline", "--no-export", "--no-live-counters"]
-            try:
-                done = subprocess.run(command, capture_output=True, text=True, timeout=240, env=dict(os.environ, TMPDIR="/tmp"), cwd=str(ROOT))
-            except (OSError, subprocess.TimeoutExpired) as error:
-                print(f"bench.py: counter pass {index} did not run ({error}): the tracked profile stands", file=sys.stderr)
+            try:                                                     # (a session of its own: a pass that overruns is ended with its whole process group)
+                child = subprocess.Popen(command, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, TMPDIR="/tmp"),
+                                         cwd=str(ROOT), start_new_session=True)
+            except OSError as error:
+                print(f"bench.py: counter pass {index} did not start ({error}): the tracked profile stands", file=sys.stderr)
                 return None
+            try:
+                _, errors = child.communicate(timeout=90)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(child.pid, signal.SIGKILL)
+                child.communicate()
+                print(f"bench.py: counter pass {index} took more than 90 s and was ended: the tracked profile stands", file=sys.stderr)
+                return None
+            done = subprocess.CompletedProcess(command, child.returncode, "", errors)
             found: dict = {}
             for table in out.glob("**/*counter_collection.csv"):
                 with open(table) as handle:
