@@ -336,10 +336,11 @@ extern "C" int sfx_ctx_tile_misses(sfx_handle h, unsigned long long* blocks) {
     if (!c->tile_misses) {
         HIP_TRY(hipMalloc((void**)&c->tile_misses, sizeof(unsigned)));
     } else {
+        HIP_TRY(hipMemcpyAsync(&count, c->tile_misses, sizeof count, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipMemcpy(&count, c->tile_misses, sizeof count, hipMemcpyDeviceToHost));
     }
-    HIP_TRY(hipMemset(c->tile_misses, 0, sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(c->tile_misses, 0, sizeof(unsigned), c->stream));       // ordered with the launches that count into it
+    HIP_TRY(hipStreamSynchronize(c->stream));
     if (blocks) *blocks = count;
     return SFX_OK;
 }
