@@ -78,6 +78,15 @@ int sfx_ctx_synchronize(sfx_handle ctx);
 /* Encoder hand-off (exporting.py:94-103 adds ffmpeg's `vflip` filter because GL rows are bottom-up): with enabled != 0
  * sfx_resolve / sfx_render_resolve / sfx_render_tape write their RGB8 frames top-down, so no filter is needed. */
 int sfx_ctx_output_top_down(sfx_handle ctx, int enabled);
+/* How LINEAR unorm8 textures of this context are filtered. OpenGL leaves the precision of the bilinear weights to the implementation
+ * (3.3 core section 3.8.11: >= 4 subtexel bits), so "the reference's OpenGL path" (shader.py:388-405 drawing through moderngl) is a
+ * family: SFX_FILTER_SPEC (default) uses float weights, as GPUs' drivers and SwiftShader do to within their precision; SFX_FILTER_FIXED8
+ * is Mesa llvmpipe's unorm8 path — the software rasteriser north_star names as the reference's CPU path: 24.8 fixed-point texel
+ * coordinates, 8-bit weights, every lerp rounded back to 8 bits — measured bit for bit on it (tests/golden/filter.npz). With it frames
+ * meet llvmpipe's within 1 LSB everywhere (float weights: up to 1.3 % of the values 2 LSB off where a filtered value is filtered or
+ * quantised again). Costs the table-driven and fused kernels (every draw becomes the generic kernel + the resolve pass). */
+enum { SFX_FILTER_SPEC = 0, SFX_FILTER_FIXED8 = 1 };
+int sfx_ctx_filter_model(sfx_handle ctx, int model);
 /* The context's two copy streams (read-out ring = turbopipe's role, exporting.py:147-171; shared-memory ring; peer windows) are chosen
  * once, on first use or by this call, so that neither shares a hardware queue with the render stream: HIP folds its streams onto a
  * few in-order queues, and a copy stream on the render stream's queue serialises read-out and render (C3: 2 080 → 1 215 frames/s).

@@ -75,6 +75,7 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_ctx_info": (C.c_int, [Handle, P(CtxInfo)]),
     "sfx_ctx_synchronize": (C.c_int, [Handle]),
     "sfx_ctx_output_top_down": (C.c_int, [Handle, C.c_int]),
+    "sfx_ctx_filter_model": (C.c_int, [Handle, C.c_int]),
     "sfx_ctx_copy_streams": (C.c_int, [Handle, P(C.c_int), P(C.c_int)]),
     "sfx_ctx_tile_misses": (C.c_int, [Handle, P(C.c_ulonglong)]),
     "sfx_ctx_destroy": (C.c_int, [Handle]),
@@ -202,6 +203,8 @@ class Context:
         self.handle = Handle()
         check(lib().sfx_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self.handle)))
         self.device = device
+        if os.environ.get("SHADERFLOW_FILTER_MODEL"):                 # "llvmpipe": frames within 1 LSB of the reference's llvmpipe frames everywhere
+            self.filter_model(os.environ["SHADERFLOW_FILTER_MODEL"])
 
     def info(self) -> CtxInfo:
         info = CtxInfo()
@@ -222,6 +225,14 @@ class Context:
         blocks = C.c_ulonglong()
         check(lib().sfx_ctx_tile_misses(self.handle, C.byref(blocks)))
         return blocks.value
+
+    def filter_model(self, model: str | int) -> None:
+        """How LINEAR unorm8 textures of this context are filtered (sfx_ctx_filter_model): "spec" — float weights, the default — or
+        "llvmpipe" / "fixed8": the 8-bit fixed-point filter of the software rasteriser the reference's CPU path runs on"""
+        code = {"spec": 0, "float": 0, "llvmpipe": 1, "fixed8": 1}.get(model.strip().lower()) if isinstance(model, str) else int(model)
+        if code is None:
+            raise ValueError(f"filter model {model!r}: 'spec' or 'llvmpipe'")
+        check(lib().sfx_ctx_filter_model(self.handle, code))
 
     def output_top_down(self, enabled: bool) -> None:
         check(lib().sfx_ctx_output_top_down(self.handle, 1 if enabled else 0))

@@ -146,6 +146,8 @@ class ShaderCamera(ShaderModule):
     def pipeline_token(self):
         # mode, projection and the quaternion the three basis vectors are rotated by (three numpy rotations per frame otherwise)
         rotation = self.rotation.value
+        if type(self).pipeline is not ShaderCamera.pipeline:
+            return None
         return (self.mode, self.projection, rotation.tobytes() if rotation.__class__ is np.ndarray else None) if rotation.__class__ is np.ndarray else None
 
     def pipeline(self) -> Iterable[ShaderVariable]:

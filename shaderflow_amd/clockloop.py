@@ -18,7 +18,7 @@ from typing import TYPE_CHECKING
 import numpy as np
 
 from shaderflow_amd import _native as N
-from shaderflow_amd.camera import ShaderCamera
+from shaderflow_amd.camera import CameraMode, ShaderCamera
 from shaderflow_amd.dynamics import ShaderDynamics
 from shaderflow_amd.module import ShaderModule
 from shaderflow_amd.scheduler import freewheel_clock
@@ -36,6 +36,11 @@ class ClockLoop:
         from shaderflow_amd.scene import ShaderScene
         if type(scene).update is not ShaderModule.update:
             return False
+        # a scene with a frame step, a message handler or scheduled tasks of its own keeps the ordinary loop (this one runs none of them)
+        if type(scene).next is not ShaderScene.next or type(scene).handle is not ShaderScene.handle:
+            return False
+        if any(task is not scene.vsync for task in scene.scheduler.tasks):
+            return False
         if type(scene).pipeline is not ShaderScene.pipeline and not ClockLoop.pipeline_is_static(scene):
             return False
         for module in scene.modules:
@@ -43,6 +48,8 @@ class ClockLoop:
                 continue
             if type(module) not in (ShaderCamera, ShaderDynamics, ShaderProgram, ShaderTexture):
                 return False
+            if isinstance(module, ShaderCamera) and module.mode == CameraMode.Spherical:
+                return False                                          # align() runs every update() there and may move rotation.target again (camera.py:220-236)
             if isinstance(module, ShaderDynamics):
                 # at rest, and staying there: the early-out of dynamics.py:222-225 — and no integral that keeps running
                 value, target = np.asarray(module.value), np.asarray(module.target)
@@ -113,6 +120,8 @@ class ClockLoop:
         runtime, fps = scene.runtime, scene.fps
         try:
             for k in range(total):
+                if scene.quit:                                        # ShaderMessage.Window.Close (scene.py:478-480), as the vsync loop honours it
+                    break
                 time = times[k]
                 scene.time, scene.dt, scene.rdt = time, dts[k], rdts[k]
                 scene._fused_this_frame = False

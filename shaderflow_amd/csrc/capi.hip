@@ -69,6 +69,7 @@ struct Context : Object {
     float tap_x[81], tap_y[81];
     std::vector<struct Program*> programs;   // live programs of this context (their sampler slots point at textures)
     int top_down = 0;                // frames leave with rows top-down (sfx_ctx_output_top_down)
+    int filter_model = SFX_FILTER_SPEC;   // sfx_ctx_filter_model: how LINEAR unorm8 textures of this context are filtered (tex_view)
     // per-frame column/row tables of the fast visualizer kernel (visualizer_fast.hpp), grown on demand
     void* vis_tables = nullptr; size_t vis_tables_bytes = 0;
     float* vis_bars = nullptr; size_t vis_bars_count = 0;          // sqrt(texel/1000) of a bound spectrogram (single launches)
@@ -103,7 +104,11 @@ static size_t dtype_size(int dtype) { return dtype == SFX_U8 ? 1 : (dtype == SFX
 static Tex tex_view(const Texture* t) {
     Tex v{};
     if (t) { v.data = t->data; v.width = t->width; v.height = t->height; v.components = t->components;
-             v.dtype = t->dtype; v.filter = t->filter; v.repeat_x = t->repeat_x; v.repeat_y = t->repeat_y; v.mips = t->mips; v.levels = t->levels; }
+             v.dtype = t->dtype; v.filter = t->filter; v.repeat_x = t->repeat_x; v.repeat_y = t->repeat_y; v.mips = t->mips; v.levels = t->levels;
+             // the context's filter model: LINEAR unorm8 textures through the fixed-point filter (glsl.hpp texture_fixed8). Every kernel
+             // with sampler arithmetic of its own asks for FILTER_LINEAR and so steps aside for the generic ones (mipmapped minification
+             // keeps the specification's arithmetic: its llvmpipe form is the oracle's checker switch only)
+             if (t->ctx && t->ctx->filter_model == SFX_FILTER_FIXED8 && t->dtype == SFX_U8 && t->filter == SFX_LINEAR) v.filter = FILTER_LINEAR_FIXED8; }
     return v;
 }
 
@@ -238,7 +243,8 @@ static EngineCopy* engine_copy(Context* c, const void* host, const void* device)
     if (hsa_amd_pointer_info(host, &host_info, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS)
         for (hsa_agent_t a : agents.second) if (a.handle == host_info.agentOwner.handle) e->cpu = a;      // the socket the ring lives on
     uint32_t free_mask = 0, preferred = 0;
-    if (hsa_amd_memory_copy_engine_status(e->cpu, e->gpu, &free_mask) != HSA_STATUS_SUCCESS && free_mask == 0) return nullptr;
+    // (informative only: a busy engine still takes the copy into its queue — the call must work, the mask need not be non-zero)
+    if (hsa_amd_memory_copy_engine_status(e->cpu, e->gpu, &free_mask) != HSA_STATUS_SUCCESS && hsa_amd_memory_get_preferred_copy_engine(e->cpu, e->gpu, &preferred) != HSA_STATUS_SUCCESS) return nullptr;
     if (hsa_amd_memory_get_preferred_copy_engine(e->cpu, e->gpu, &preferred) != HSA_STATUS_SUCCESS) preferred = 0;
     uint32_t pick = __builtin_popcount(preferred) >= 2 ? preferred : 0x3u;
     e->engine[0] = pick & (~pick + 1u);                              // lowest set bit
@@ -277,6 +283,7 @@ struct EngineLanes {
     static constexpr int LANES = 4;
     hsa_signal_t done[LANES] = {};
     bool busy[LANES] = {};
+    bool via_hsa[LANES] = {};                                       // the route the lane's copy in flight was issued on: it is finished on that one
 
     // `host` / `device`: the first frame's two ends (they name the agents). Called from the thread that issues.
     void resolve(Context* context, const void* host, const void* device) {
@@ -295,19 +302,38 @@ struct EngineLanes {
                 hsa_signal_store_relaxed(done[lane], 1);
                 status = hsa_amd_memory_async_copy(host, e->cpu, device, e->gpu, nbytes, 0, nullptr, done[lane]);
             }
-            if (status == HSA_STATUS_SUCCESS) { busy[lane] = true; return true; }
-            e = nullptr;                                             // HSA refuses: HIP's copy from here on
+            if (status == HSA_STATUS_SUCCESS) { busy[lane] = true; via_hsa[lane] = true; return true; }
+            // HSA refuses: HIP's copies from here on. The lanes still in flight through HSA keep their route (via_hsa) and are drained
+            // on it by finish(); nothing of theirs ever ran on the copy streams.
+            e = nullptr;
             if (context_copy_streams(c) != SFX_OK) return false;
         }
+        if (!c->copy_streams[0] && context_copy_streams(c) != SFX_OK) return false;
         if (hipMemcpyAsync(host, device, nbytes, hipMemcpyDeviceToHost, c->copy_streams[lane & 1]) != hipSuccess) { (void)hipGetLastError(); return false; }
-        busy[lane] = true;
+        busy[lane] = true; via_hsa[lane] = false;
         return true;
     }
-    void finish(int lane) {
-        if (!busy[lane]) return;
-        if (e) hsa_signal_wait_scacquire(done[lane], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
-        else hipStreamSynchronize(c->copy_streams[lane & 1]);       // (a stream's later copy too: in order, so nothing is released early)
+    // has the lane's copy ended (either way)? never blocks
+    bool landed(int lane) const {
+        if (!busy[lane]) return true;
+        if (via_hsa[lane]) return hsa_signal_load_scacquire(done[lane]) < 1;
+        return hipStreamQuery(c->copy_streams[lane & 1]) != hipErrorNotReady;
+    }
+    // false: the copy FAILED (the runtime left its signal negative, or the stream reports an error): the slot's bytes are not the frame
+    bool finish(int lane) {
+        if (!busy[lane]) return true;
+        bool ok = true;
+        if (via_hsa[lane]) {
+            // the wait may return before the condition holds (the specification allows spurious returns): ask again until it does;
+            // a failed copy leaves the signal NEGATIVE, which satisfies "< 1" as well, so the value itself is looked at
+            while (hsa_signal_wait_scacquire(done[lane], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+            ok = hsa_signal_load_relaxed(done[lane]) == 0;
+        } else {
+            ok = hipStreamSynchronize(c->copy_streams[lane & 1]) == hipSuccess;   // (a stream's later copy too: in order, so nothing is released early)
+            if (!ok) (void)hipGetLastError();
+        }
         busy[lane] = false;
+        return ok;
     }
     void release() {
         for (int lane = 0; lane < LANES; lane++) finish(lane);
@@ -392,6 +418,13 @@ extern "C" int sfx_ctx_synchronize(sfx_handle h) {
 extern "C" int sfx_ctx_output_top_down(sfx_handle h, int enabled) {
     CTX_OR_FAIL(c, h);
     c->top_down = enabled ? 1 : 0;
+    return SFX_OK;
+}
+
+extern "C" int sfx_ctx_filter_model(sfx_handle h, int model) {
+    CTX_OR_FAIL(c, h);
+    if (model != SFX_FILTER_SPEC && model != SFX_FILTER_FIXED8) return fail(SFX_E_INVALID, "filter model %d", model);
+    c->filter_model = model;
     return SFX_OK;
 }
 
@@ -701,6 +734,7 @@ struct Program : Object {
     // FRAG_JIT: a code object built by the host from a translated fragment (sfx_program_load)
     hipModule_t module = nullptr;
     hipFunction_t fn_render = nullptr, fn_fused[3] = {nullptr, nullptr, nullptr};     // ssaa 1, 2, 4
+    hipFunction_t fn_render_quads = nullptr;       // tiled code objects: the untiled twin of fn_render, whose lanes can form 2 x 2 quads (a mipmapped sampler)
     std::vector<JitBinding> bindings;
     unsigned flags = 0;                                             // sfx_jit_flags of the code object: 1 = takes screen-space derivatives
 };
@@ -776,6 +810,7 @@ extern "C" int sfx_program_load(sfx_handle h, const void* code_object, size_t nb
     if (e != hipSuccess) { p->module = nullptr; return bail(SFX_E_HIP, "hipModuleLoadData", e); }
     static const char* const fused_names[3] = {"sfx_jit_fused_1", "sfx_jit_fused_2", "sfx_jit_fused_4"};
     if ((e = hipModuleGetFunction(&p->fn_render, p->module, "sfx_jit_render")) != hipSuccess) return bail(SFX_E_INVALID, "code object has no sfx_jit_render", e);
+    if (hipModuleGetFunction(&p->fn_render_quads, p->module, "sfx_jit_render_quads") != hipSuccess) { p->fn_render_quads = nullptr; (void)hipGetLastError(); }   // optional
     for (int k = 0; k < 3; k++)
         if ((e = hipModuleGetFunction(&p->fn_fused[k], p->module, fused_names[k])) != hipSuccess) return bail(SFX_E_INVALID, "code object lacks a fused entry point", e);
     hipDeviceptr_t layout = nullptr; size_t layout_bytes = 0; unsigned long long compiled_layout = 0;
@@ -807,7 +842,12 @@ static bool samples_mipmaps(const Program* p) {
     for (int k = 0; k < TEX_SLOTS; k++) if (p->samplers[k] && p->samplers[k]->filter >= SFX_LINEAR_MIPMAP_LINEAR) return true;
     return false;
 }
-static bool fusable(const Program* p, int ssaa) { return !((p->flags & 1u) || samples_mipmaps(p)) || ssaa == 2; }
+// Under the fixed-point filter model final.glsl's taps go through that filter too (a tap between four texels is NOT their exact mean
+// there), so the resolve stays a pass of its own.
+static bool fusable(const Program* p, int ssaa) {
+    if (p->ctx->filter_model != SFX_FILTER_SPEC) return false;
+    return !((p->flags & 1u) || samples_mipmaps(p)) || ssaa == 2;
+}
 // rows a lane walks in the code object's sfx_jit_render / sfx_jit_fused_1 (shader_rows_1x of its shader policy; older flags words say 0)
 static int jit_rows_1x(const Program* p) { const int rows = (int)((p->flags >> 8) & 255u); return rows > 0 ? rows : 1; }
 extern "C" int sfx_program_fusable(sfx_handle h, int ssaa) {
@@ -1544,6 +1584,12 @@ static int launch_render_p(const Program* p, const RenderArgs& a, int frames, hi
     g_launch_ctx = p->ctx;
     if (p->fragment != FRAG_JIT) return launch_render(p->fragment, a, frames, s);
     using P = PlainShader<FRAG_DEFAULT>;
+    if (a.quads && jit_rows_1x(p) > 1) {
+        // a mipmapped sampler on a TILED translated fragment: its lanes walk rows and cannot form quads — the differences across a "quad"
+        // would be between unrelated pixels and the level of detail wrong without any error. The code object's untiled twin takes the draw.
+        if (!p->fn_render_quads) return fail(SFX_E_UNSUPPORTED, "a mipmapped texture is bound to a tiled translated fragment whose code object has no sfx_jit_render_quads: translate it again with this library's headers");
+        return launch_jit(p->fn_render_quads, a, dim3((a.wr + P::BLOCK_W - 1)/P::BLOCK_W, (a.hr + P::BLOCK_H - 1)/P::BLOCK_H, frames), dim3(P::BLOCK_W, P::BLOCK_H, 1), s);
+    }
     const int block_rows = P::BLOCK_H*jit_rows_1x(p);
     return launch_jit(p->fn_render, a, dim3((a.wr + P::BLOCK_W - 1)/P::BLOCK_W, (a.hr + block_rows - 1)/block_rows, frames), dim3(P::BLOCK_W, P::BLOCK_H, 1), s);
 }
@@ -1635,7 +1681,7 @@ extern "C" int sfx_resolve(sfx_handle h, sfx_handle src, sfx_handle dst, int sub
     USE_DEVICE(c);
     ResolveArgs a;
     a.screen = tex_view(s);
-    a.screen.filter = s->filter; a.screen.repeat_x = s->repeat_x; a.screen.repeat_y = s->repeat_y;
+    a.screen.repeat_x = s->repeat_x; a.screen.repeat_y = s->repeat_y;
     a.w = d->width; a.h = d->height; a.subsample = subsample < 1 ? 1 : subsample;
     a.out = (uint8_t*)d->data;
     a.screen_frame_stride = 0; a.out_frame_stride = 0; a.top_down = c->top_down;
@@ -1655,6 +1701,7 @@ extern "C" int sfx_render_resolve(sfx_handle h, sfx_handle final_tex, int ssaa, 
     if (t->dtype != SFX_U8 || t->components != 3) return fail(SFX_E_UNSUPPORTED, "fused target must be RGB8 (iFinal, scene.py:188-189)");
     if (subsample < 1) subsample = 1;
     if (!fused_supported(ssaa, subsample)) return fail(SFX_E_UNSUPPORTED, "final.glsl footprint for ssaa=%d subsample=%d leaves the pixel's block: use sfx_render + sfx_resolve", ssaa, subsample);
+    if (p->ctx->filter_model != SFX_FILTER_SPEC) return fail(SFX_E_UNSUPPORTED, "the context's fixed-point filter model filters final.glsl's taps as well: use sfx_render + sfx_resolve");
     if (!fusable(p, ssaa)) return fail(SFX_E_UNSUPPORTED, "the fragment takes screen-space derivatives, which the fused kernel's lane layout provides for ssaa 2 only: use sfx_render + sfx_resolve");
     USE_DEVICE(p->ctx);
     RenderArgs a;
@@ -1702,11 +1749,14 @@ static void ring_copier(Ring* r) {
     int in_lane[EngineLanes::LANES] = {-1, -1, -1, -1}, next = 0;
     auto finish = [&](int lane) {
         if (in_lane[lane] < 0) return;
-        r->lanes.finish(lane);
-        { std::lock_guard<std::mutex> lock(r->mutex); r->copying[in_lane[lane]] = 0; }
+        const bool ok = r->lanes.finish(lane);
+        { std::lock_guard<std::mutex> lock(r->mutex); if (!ok) r->copy_error = 1; r->copying[in_lane[lane]] = 0; }
         in_lane[lane] = -1;
         r->idle.notify_all();
     };
+    // frames that have landed are handed to the writer at once, not when their lane comes round again (a continuously fed queue
+    // never runs empty, and the copier is about to block on the NEXT frame's render)
+    auto release_landed = [&] { for (int lane = 0; lane < r->lane_count; lane++) if (in_lane[lane] >= 0 && r->lanes.landed(lane)) finish(lane); };
     for (;;) {
         Ring::CopyJob job;
         {
@@ -1722,8 +1772,10 @@ static void ring_copier(Ring* r) {
         }
         static const bool trace = getenv("SHADERFLOW_RING_TRACE") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
+        release_landed();
         hipEventSynchronize(job.ready);                              // the frame is complete on the render stream
         const auto t1 = std::chrono::steady_clock::now();
+        release_landed();
         finish(next);                                                // the lane's previous copy
         const auto t2 = std::chrono::steady_clock::now();
         if (trace) fprintf(stderr, "ring copier: slot %d event wait %.0f us, lane finish %.0f us\n", job.slot, std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count());
@@ -2630,7 +2682,7 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
     a.out = t->d_screen; a.out_frame_stride = (long)screen_frame; a.out_components = 4; a.out_dtype = DT_U8;
     if ((rc = launch_render_p(p, a, nframes, p->ctx->stream))) return rc;
     ResolveArgs r;
-    r.screen = Tex{t->d_screen, a.wr, a.hr, 4, DT_U8, FILTER_LINEAR, 0, 0};      // iScreen: linear, repeat(False) (scene.py:192-194)
+    r.screen = Tex{t->d_screen, a.wr, a.hr, 4, DT_U8, p->ctx->filter_model == SFX_FILTER_FIXED8 ? FILTER_LINEAR_FIXED8 : FILTER_LINEAR, 0, 0};      // iScreen: linear, repeat(False) (scene.py:192-194)
     r.w = width; r.h = height; r.subsample = subsample; r.out = (uint8_t*)device_out;
     r.screen_frame_stride = (long)screen_frame; r.out_frame_stride = (long)width*height*3; r.top_down = p->ctx->top_down;
     if ((rc = launch_resolve(p->ctx, r, nframes, p->ctx->stream))) return rc;

@@ -49,7 +49,9 @@ SF_HD void set_rgb(vec4& c, vec3 v) { c.x = v.x; c.y = v.y; c.z = v.z; }
 enum : int { DT_U8 = 0, DT_F32 = 1, DT_U16 = 2, DT_F16 = 3 };
 // FILTER_LINEAR_MIPMAP / FILTER_NEAREST_MIPMAP: texture.py:131-137 — moderngl.LINEAR_MIPMAP_LINEAR / NEAREST_MIPMAP_NEAREST as the
 // minification filter once `mipmaps=True` has built the chain (texture.py:277-278); the magnification filter stays LINEAR / NEAREST
-enum : int { FILTER_NEAREST = 0, FILTER_LINEAR = 1, FILTER_LINEAR_MIPMAP = 2, FILTER_NEAREST_MIPMAP = 3 };
+// FILTER_LINEAR_FIXED8: the context's opt-in filter model (sfx_ctx_filter_model, capi.hip tex_view) for LINEAR unorm8 textures — the
+// fixed-point bilinear filter of the software rasteriser the reference's CPU path runs on (below: texture_fixed8)
+enum : int { FILTER_NEAREST = 0, FILTER_LINEAR = 1, FILTER_LINEAR_MIPMAP = 2, FILTER_NEAREST_MIPMAP = 3, FILTER_LINEAR_FIXED8 = 4 };
 
 struct Tex {                       // one TextureBox of texture.py:56-70, rows bottom-up, tightly packed
     const void* data;
@@ -204,7 +206,34 @@ SF_HD float mip_lambda(const Tex& t, float dudx, float dvdx, float dudy, float d
     const float top = (float)((t.levels > 1 ? t.levels : 1) - 1);
     return lambda > top ? top : lambda;
 }
+// ---- the fixed-point filter model (opt-in, sfx_ctx_filter_model) ---------------------------------------------------------------------
+// OpenGL leaves the precision of the bilinear weights to the implementation (>= 4 subtexel bits, 3.3 core section 3.8.11). The float
+// weights above are one admissible choice; Mesa llvmpipe — the software rasteriser `north_star` names as the reference's CPU path, and
+// the renderer of tests/golden/mesa*.npz — makes another for unorm8 textures: texel coordinates in 24.8 fixed point, rint(s*N*256) - 128,
+// the low 8 bits the weight; a lerp along x on the bytes, a + ((w*(b - a) + 128) >> 8), ROUNDED BACK TO 8 BITS, then the same along y:
+// a filtered texel is always k/255. Measured bit for bit on that implementation (tests/golden/filter.npz, tests/test_gpu_filter_model.py;
+// the parity oracle keeps the checker's copy). With the model on, frames meet that implementation's within 1 LSB where
+// the float weights leave up to 1.3 % of the values 2 off (a second filter or a quantisation after the first: tests/test_gpu_mesa.py).
+SF_HD int fixed8_lerp(int w, int a, int b) { return (a + ((w*(b - a) + 128) >> 8)) & 255; }
+SF_COLD vec4 texture_fixed8(Tex t, vec2 uv) {
+    const int fx = (int)::rintf(uv.x*(float)t.width*256.0f) - 128, fy = (int)::rintf(uv.y*(float)t.height*256.0f) - 128;
+    const int wx = fx & 255, wy = fy & 255;
+    const int i0 = wrap_texel(fx >> 8, t.width, t.repeat_x), i1 = wrap_texel((fx >> 8) + 1, t.width, t.repeat_x);
+    const int j0 = wrap_texel(fy >> 8, t.height, t.repeat_y), j1 = wrap_texel((fy >> 8) + 1, t.height, t.repeat_y);
+    const uint8_t* data = (const uint8_t*)t.data;
+    const int n = t.components;
+    const uint8_t* p00 = data + ((size_t)j0*t.width + i0)*n; const uint8_t* p10 = data + ((size_t)j0*t.width + i1)*n;
+    const uint8_t* p01 = data + ((size_t)j1*t.width + i0)*n; const uint8_t* p11 = data + ((size_t)j1*t.width + i1)*n;
+    auto channel = [&](int k) { return unorm8_to_float((float)fixed8_lerp(wy, fixed8_lerp(wx, p00[k], p10[k]), fixed8_lerp(wx, p01[k], p11[k]))); };
+    vec4 c = {channel(0), 0.0f, 0.0f, 1.0f};
+    if (n > 1) c.y = channel(1);
+    if (n > 2) c.z = channel(2);
+    if (n > 3) c.w = channel(3);
+    return c;
+}
+
 SF_COLD vec4 texture_mipmapped(Tex t, vec2 uv) {
+    if (t.filter == FILTER_LINEAR_FIXED8) return texture_fixed8(t, uv);            // (shares the cold entry: one rare branch in texture())
     const float u = uv.x*(float)t.width, v = uv.y*(float)t.height;
     const float lambda = mip_lambda(t, quad_dx(u), quad_dx(v), quad_dy(u), quad_dy(v));
     const bool linear = (t.filter == FILTER_LINEAR_MIPMAP);

@@ -947,12 +947,23 @@ inline void sfx_jit_host_texture(sf::Tex* textures, int slot, const void* data, 
 // SF_JIT_TILED: the translator asked for an LDS tile (SF_JIT_TILE_SLOT) and the fragment takes no derivatives (a probe with
 // two live lanes has no neighbours to difference with).
 #define SF_JIT_TILED ((SF_JIT_TILE_SLOT >= 0) && !(SF_JIT_DERIVATIVES))
+// sfx_jit_render_quads: the tiled policy walks ROWS_1X rows per lane, so its lanes cannot be laid out as 2 x 2 quads; when a MIPMAPPED
+// texture is bound at run time (RenderArgs.quads: the level of detail needs the quad's differences, glsl.hpp texture_mipmapped) the
+// library launches this untiled twin instead, whose 64 x 4 blocks take the quad layout (render_kernels.hpp render_body). Untiled
+// code objects need none: their sfx_jit_render is that kernel already.
+#if SF_JIT_TILE_SLOT >= 0 && !(SF_JIT_DERIVATIVES)
+#define SF_JIT_QUADS_ENTRY(FRAGMENT) \
+    extern "C" __global__ __launch_bounds__(256) void sfx_jit_render_quads(const sf::RenderArgs a) { sf::render_body<sf::JitShader<FRAGMENT, false, false>>(a); }
+#else
+#define SF_JIT_QUADS_ENTRY(FRAGMENT)
+#endif
 #define SF_JIT_ENTRY_POINTS(FRAGMENT) \
     SF_JIT_HOST_POINTS(FRAGMENT) \
     extern "C" __device__ __attribute__((used)) const unsigned long long sfx_jit_layout = sf::render_args_layout(); \
     extern "C" __device__ __attribute__((used)) const unsigned sfx_jit_flags = (SF_JIT_DERIVATIVES ? 1u : 0u) | \
         ((unsigned)sf::shader_rows_1x<sf::JitShader<FRAGMENT, false, SF_JIT_TILED>>::value << 8); \
     extern "C" __global__ __launch_bounds__(256) void sfx_jit_render(const sf::RenderArgs a) { sf::render_body<sf::JitShader<FRAGMENT, (SF_JIT_DERIVATIVES != 0), SF_JIT_TILED>>(a); } \
+    SF_JIT_QUADS_ENTRY(FRAGMENT) \
     extern "C" __global__ __launch_bounds__(256) void sfx_jit_fused_1(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT, false, SF_JIT_TILED>, 1>(a); } \
     extern "C" __global__ __launch_bounds__(512) void sfx_jit_fused_2(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT, (SF_JIT_DERIVATIVES != 0), SF_JIT_TILED>, 2>(a); } \
     extern "C" __global__ __launch_bounds__(512) void sfx_jit_fused_4(const sf::RenderArgs a) { sf::render_resolve_body<sf::JitShader<FRAGMENT, false, SF_JIT_TILED>, 4>(a); }

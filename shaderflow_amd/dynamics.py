@@ -190,14 +190,14 @@ class ShaderDynamics(ShaderModule, DynamicNumber):
     def pipeline_token(self):
         # the bytes of what pipeline() exports: a frozen system (dynamics.py:222-225) is skipped, a moving one walked
         value = self.value
-        if value.__class__ is not np.ndarray:
-            return None
+        if value.__class__ is not np.ndarray or type(self).pipeline is not ShaderDynamics.pipeline:
+            return None                                              # (a subclass with a pipeline() of its own is walked every frame)
         token = value.tobytes()
         if self.integrate:
             token += np.asarray(self.integral).tobytes()
         if self.differentiate:
             token += np.asarray(self.derivative).tobytes()
-        return (self.primary, token)
+        return (self.name, self.type, self.primary, self.integrate, self.differentiate, token)
 
     def pipeline(self) -> Iterable[ShaderVariable]:
         if (not self.type):

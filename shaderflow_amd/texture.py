@@ -273,6 +273,8 @@ class ShaderTexture(ShaderModule):
 
     def pipeline_token(self):
         # Size / Layers / Temporal and one sampler per box: which DEVICE texture sits in which box, in matrix order (roll() rotates it)
+        if type(self).pipeline is not ShaderTexture.pipeline:
+            return None                                              # a subclass yields variables of its own: walk it every frame, as the reference does
         return (self.name, self.resolution, tuple(0 if box.texture is None else box.texture.serial for (_, _, box) in self.boxes))
 
     def pipeline(self) -> Iterable[ShaderVariable]:

@@ -113,12 +113,14 @@ def dynamics_scene(background, w, h, fps, frames, pick, threads=8):
 
 
 def audio_scene(fragment, pcm, samplerate, background, w, h, ssaa, subsample, fps, frames, pick=None, high=14000.0,
-                waveform_smooth=True, threads=8):
+                waveform_smooth=True, threads=8, screens=None, duration=None):
     """Visualizer / MusicBars / Waveform (demo.py:157-205): the audio tape of sfo_audio.c feeding the fragments of sfo_pixel.c.
-    `high`: upper note of from_notes (14 kHz Visualizer, 18 kHz MusicBars)"""
+    `high`: upper note of from_notes (14 kHz Visualizer, 18 kHz MusicBars); `screens`: a dict that receives the supersampled iScreen
+    of every picked frame (the edge-aware bound of the full-size tests needs the samples); `duration`: iDuration when the export is
+    longer than the `frames` replayed here"""
     planar = np.ascontiguousarray(pcm.T)
     times, dts, rdts = O.clock(fps, frames)
-    runtime = frames/fps
+    runtime = frames/fps if duration is None else duration
     _, tell = O.reader(rdts, samplerate, 2, planar.shape[1])
     fmin, fmax, bins = O.from_notes(O.lib().sfo_note_of_frequency(20.0, 440.0), O.lib().sfo_note_of_frequency(high, 440.0), True)
     indptr, indices, data = O.filterbank(0, 0, fmin, fmax, bins, 12, samplerate)
@@ -143,5 +145,7 @@ def audio_scene(fragment, pcm, samplerate, background, w, h, ssaa, subsample, fp
         if bg is not None:
             tex["background"] = bg
         screen = O.render(fragment, u, tex, int(w*ssaa), int(h*ssaa), threads=threads)
+        if screens is not None:
+            screens[k] = screen
         out[k] = O.resolve(screen, w, h, subsample, threads=threads)
     return np.stack([out[k] for k in pick])

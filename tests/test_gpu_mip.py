@@ -102,6 +102,31 @@ def test_probes_through_the_python_api(dtype, tag):
     assert d.max() <= limit and (d <= 2).mean() > 0.9, (tag, np.bincount(d.ravel())[:14])
 
 
+@pytest.mark.parametrize("tag", ["x3.3", "nearest.x3.3", "x9"])
+def test_tiled_translation_under_a_mipmapped_sampler_takes_the_quad_layout(monkeypatch, tag):
+    """ADVICE round 4: a translated fragment that got an LDS tile walks four rows per lane (JitShader<F, false, true>::ROWS_1X), so its
+    lanes cannot form 2 x 2 quads — with a mipmapped sampler bound the differences across a "quad" would be between unrelated pixels
+    and the level of detail silently wrong. The library launches the code object's untiled twin (sfx_jit_render_quads) for that draw.
+    SHADERFLOW_JIT_TILE=probe forces the tile for the probe's sampler: same frames as the untiled translation pinned above — the
+    oracle's specification arithmetic ≤ 1 LSB, the reference's llvmpipe frame within its measured distance"""
+    monkeypatch.setenv("SHADERFLOW_JIT_TILE", "probe")
+    filter = "nearest" if tag.startswith("nearest") else "linear"
+    key = tag.replace("nearest.", "")
+    scale, rotation = PROBES[key]
+    texels = mip_probe_texture(64, 48, np.uint8)
+    got, scene = product_probe(texels, scale, rotation, filter, stale=False)
+    assert "#define SF_JIT_TILE_SLOT" in scene.shader._translation_text            # the translation under test really is the tiled one
+    want = oracle_probe(texels, scale, rotation, filter, stale=False)[..., :3]
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1 and (d == 0).mean() > 0.98, (tag, lsb_report(got, want))
+    reference = G[f"probe.uint8.{filter}.{key}"][..., :3]
+    d = np.abs(got.astype(int) - reference.astype(int))
+    assert d.max() <= (6 if key == "x9" else 4) and (d <= 2).mean() > 0.9, (tag, np.bincount(d.ravel())[:14])
+    monkeypatch.setenv("SHADERFLOW_JIT_TILE", "0")
+    untiled, _ = product_probe(texels, scale, rotation, filter, stale=False)
+    assert np.array_equal(got, untiled)
+
+
 def test_fused_kernel_at_two_supersamples_takes_the_derivatives_across_the_pixels_quad():
     """ssaa 2: the four supersamples of a pixel are the four lanes of a quad in the fused kernel, so a mipmapped sampler stays fusable
     there (sfx_program_fusable) — level of detail in SUPERSAMPLE units, as the reference's render at render_resolution has it"""

@@ -291,6 +291,28 @@ def test_llvmpipe_filters_unorm8_textures_in_8_bit_fixed_point(tag):
     assert d.max() == 1 and 0.02 < (d == 1).mean() < 0.5                       # the specification's filter: close, not equal
 
 
+@pytest.mark.parametrize("tag", ["row", "grid.repeat", "grid.clamp"])
+def test_the_products_fixed_point_filter_is_llvmpipes(tag):
+    """The PRODUCT's opt-in filter model (csrc/glsl.hpp texture_fixed8, `sfx_ctx_filter_model`) is the same arithmetic in the kernels'
+    own header: the HOST build of the run-time translation of the probe's text (tests/jit_host.py compiles csrc/jit_runtime.hpp for the
+    CPU) reproduces every value llvmpipe filtered, byte for byte. The device build of the same header: tests/test_gpu_filter_model.py."""
+    import ctypes as C
+
+    from shaderflow_amd import glsl2hip
+    from tests.jit_host import HostFragment
+    texels = np.ascontiguousarray(F[f"filter.{tag.split('.')[0]}.texels"])
+    width, height, sx, sy, ox, oy, repeat = F[f"filter.{tag}.args"]
+    width, height, repeat = int(width), int(height), bool(repeat)
+    text = f"void main() {{ fragColor = texture(probe, astuv*vec2({float(sx)!r}, {float(sy)!r}) + vec2({float(ox)!r}, {float(oy)!r})); }}"
+    host = HostFragment(glsl2hip.translate(text, [("sampler2D", "probe")]), Path(__file__).parent.parent/"build"/"jit")
+    host.set_uniforms(O.default_uniforms(width, height))
+    binding = next(b for b in host.translation.bindings if b.name == "probe")
+    FILTER_LINEAR_FIXED8 = 4                                                         # csrc/glsl.hpp
+    host.lib.sfx_jit_host_texture(host.textures, binding.slot, texels.ctypes.data_as(C.c_void_p), texels.shape[1], texels.shape[0], texels.shape[2],
+                                  0, FILTER_LINEAR_FIXED8, int(repeat), int(repeat))
+    assert np.array_equal(host.render(width, height), F[f"filter.{tag}.k"])
+
+
 LLVMPIPE_CASES = {
     # tag: (oracle image under the switch, exact?)  — the bounds of the tests above WITHOUT the switch: max 2, up to 1.3 % at 2
     "sampler.linear.clamp": True, "sampler.linear.repeat": True, "final.64x36.k1": True, "dynamics": True,
@@ -398,6 +420,28 @@ def edge_aware_check(got_row: np.ndarray, want_row: np.ndarray, screen_rows: np.
     for side in (-1, 1):                                                          # the edge may run between this pixel and its neighbour
         high, low = np.maximum(high, np.roll(high, side, axis=0)), np.minimum(low, np.roll(low, side, axis=0))
     allowed = np.maximum(1, (high - low)//4 + 2)
+    assert (d <= allowed).all(), (where, np.argwhere(d > allowed)[:4].tolist(), int(d.max()))
+    return np.bincount(np.minimum(d.ravel(), 3), minlength=4)
+
+
+def edge_aware_frame(got: np.ndarray, want: np.ndarray, screen: np.ndarray, where, ssaa: int = 2) -> np.ndarray:
+    """edge_aware_check for a whole frame: `max ≤ 1 LSB`, except where ONE supersample under the pixel's resolve footprint sits on
+    the other side of an edge in one of the two renderings — then a value may move by a quarter of the spread of the samples under
+    the pixel and its four neighbours (the edge may run between two pixels, along either axis). `screen`: the oracle's iScreen of
+    the frame, (h·ssaa, w·ssaa, ≥3). Returns the |difference| histogram (0, 1, 2, ≥3)."""
+    h, w = got.shape[:2]
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    block = screen[:, :, :3].reshape(h, ssaa, w, ssaa, 3)
+    high, low = block.max(axis=(1, 3)).astype(np.int16), block.min(axis=(1, 3)).astype(np.int16)
+    if ssaa == 1:                                                                 # final.glsl's 3 x 3 tent: the eight texels around count as well
+        for axis in (0, 1):
+            high = np.maximum(high, np.maximum(np.roll(high, 1, axis), np.roll(high, -1, axis)))
+            low = np.minimum(low, np.minimum(np.roll(low, 1, axis), np.roll(low, -1, axis)))
+    top, bottom = high.copy(), low.copy()
+    for axis in (0, 1):
+        for side in (-1, 1):
+            top, bottom = np.maximum(top, np.roll(high, side, axis)), np.minimum(bottom, np.roll(low, side, axis))
+    allowed = np.maximum(1, (top - bottom)//4 + 2)
     assert (d <= allowed).all(), (where, np.argwhere(d > allowed)[:4].tolist(), int(d.max()))
     return np.bincount(np.minimum(d.ravel(), 3), minlength=4)
 
