@@ -349,6 +349,7 @@ def main() -> None:
     tape.bind_static_uniforms()
 
     frame_bytes = w*h*3
+    yuv_bytes = w*h*3//2
     # zeros, not empty: the first touch of fresh device memory is paid here, outside the timed region
     buffers = [torch.zeros(fpb*frame_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
     # N > 1: a step's frames are rendered and sent in `parts` pieces, so that only the last piece's transfer is exposed at the end
@@ -356,80 +357,107 @@ def main() -> None:
     parts = next(p for p in (4, 3, 2, 1) if fpb % p == 0) if distributed else 1
     piece = fpb//parts
     staged = distributed and dist.get_backend() == "gloo"
-    received = None
-    if distributed and rank == 0:
-        # rank 0 keeps the last two steps of every other rank (a real export hands them to the sink: parallel.contiguous_device_export)
-        where = "cpu" if staged else "cuda"
-        received = [[torch.zeros(fpb*frame_bytes, dtype=torch.uint8, device=where) for _ in range(2)] for _ in range(world)]
-    in_flight: list = []
-    # SHADERFLOW_SHARD=device-sdma: the gather as peer copies on the SDMA engines instead of RCCL kernels (parallel.SdmaTransfer):
-    # rank 0 exports two step buffers per source rank as IPC handles, every other rank maps its pair
-    sdma = distributed and os.environ.get("SHADERFLOW_SHARD", "").strip().lower() == "device-sdma"
-    loopback = distributed and world == 1 and dist.get_backend() == "nccl" and not sdma
-    windows = None
-    if sdma:
-        handles = [None]
+    loopback = distributed and world == 1 and dist.get_backend() == "nccl"
+
+    # ---- the gather (N > 1): every finished piece → rank 0's HBM. Two transports over the same buffers, measured as LEGS of this run:
+    #   "p2p"   grouped point-to-point calls of the process group's backend (RCCL over xGMI: the north star's gather; gloo in tests)
+    #   "sdma"  peer copies through IPC windows on SDMA engines NAMED through HSA (shaderflow_amd/parallel.py SdmaTransfer, sfx_peer_*)
+    # and two payloads: the rgb24 frames (the reference's byte stream: `value`) and — converted on the rank that rendered them —
+    # planar yuv420p, half the bytes per link (`yuv420p` beside it). SHADERFLOW_SHARD=device|device-sdma pins the transport.
+    from shaderflow_amd.parallel import DeviceArray
+    pinned = os.environ.get("SHADERFLOW_SHARD", "").strip().lower()
+    transports = [] if not distributed else (["sdma"] if pinned == "device-sdma" else (["p2p"] if pinned == "device" else ["p2p", "sdma"]))
+    received = raw_received = windows = None
+    planar_buffers = None
+    if distributed:
+        planar_buffers = [torch.zeros(fpb*yuv_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
         if rank == 0:
-            received = None
-            raw = [[context.alloc(fpb*frame_bytes) for _ in range(2)] for _ in range(world)]
-            handles = [[[context.peer_export(pointer) for pointer in pair] for pair in raw]]
-        dist.broadcast_object_list(handles, src=0)
-        if rank:
-            windows = [context.peer_open(handle) for handle in handles[0][rank]]
-
-    def transfer(index: int, q: int, view) -> None:
-        """piece q of step `index`: every other rank → rank 0, grouped point-to-point (the RCCL gather)"""
-        if not distributed:
-            return
-        lo, hi = q*piece*frame_bytes, (q + 1)*piece*frame_bytes
-        if sdma:
+            # rank 0 keeps the last two steps of every other rank (a real export hands them to the sink: parallel.contiguous_device_export);
+            # raw allocations, so that the SAME memory serves RCCL's receives (as torch views) and the peers' IPC windows
+            raw_received = [[context.alloc(fpb*frame_bytes) for _ in range(2)] for _ in range(world)]
+            received = [[torch.as_tensor(DeviceArray(pointer, fpb*frame_bytes), device=torch.device("cuda", local_rank)) for pointer in pair] for pair in raw_received]
+            for pair in received:
+                for tensor in pair:
+                    tensor.zero_()
+            torch.cuda.synchronize()
+            if staged:                                                # gloo carries host tensors only: the receives land in host staging (tests)
+                received = [[torch.zeros(fpb*frame_bytes, dtype=torch.uint8, device="cpu") for _ in range(2)] for _ in range(world)]
+        if "sdma" in transports:
+            handles = [None]
+            if rank == 0:
+                handles = [[[context.peer_export(pointer) for pointer in pair] for pair in raw_received]]
+            dist.broadcast_object_list(handles, src=0)
             if rank:
-                context.peer_copy(windows[index % 2] + lo, view.data_ptr(), hi - lo, lane=(index % 2)*parts + q)
-            return
-        if loopback:
-            # ONE rank over RCCL (SHADERFLOW_FORCE_DIST=1): the piece is sent to this rank itself — the same grouped point-to-point
-            # call, RCCL's own kernel on the render stream, the same ordering against the next render — so that everything the
-            # first multi-GPU run depends on has executed on a single GPU before (tests/test_gpu_rccl.py)
-            ops = [dist.P2POp(dist.irecv, received[0][index % 2][lo:hi], 0), dist.P2POp(dist.isend, view, 0)]
-        elif rank == 0:
-            ops = [dist.P2POp(dist.irecv, received[source][index % 2][lo:hi], source) for source in range(1, world)]
-        else:
-            ops = [dist.P2POp(dist.isend, view.cpu() if staged else view, 0)]
-        if ops:
-            in_flight.extend(dist.batch_isend_irecv(ops))
+                windows = [context.peer_open(handle) for handle in handles[0][rank]]
 
-    works_per_transfer = 2 if loopback else ((world - 1) if rank == 0 else 1)
+    class Gather:
+        """One transport x one payload: send(index, q, view) queues piece q of step `index`; drain() bounds what is in flight"""
+        def __init__(self, transport: str, payload_bytes: int):
+            self.transport, self.payload, self.in_flight = transport, payload_bytes, []
+            self.works_per_transfer = 2 if loopback else ((world - 1) if rank == 0 else 1)
 
-    def drain(keep_transfers: int = 0) -> None:
-        while len(in_flight) > keep_transfers*works_per_transfer:
-            in_flight.pop(0).wait()
+        def send(self, index: int, q: int, view) -> None:
+            lo, hi = q*piece*self.payload, (q + 1)*piece*self.payload
+            if self.transport == "sdma":
+                if rank:
+                    context.peer_copy(windows[index % 2] + lo, view.data_ptr(), hi - lo, lane=(index % 2)*parts + q)
+                return
+            if loopback:
+                # ONE rank over RCCL (SHADERFLOW_FORCE_DIST=1): the piece is sent to this rank itself — the same grouped point-to-point
+                # call, RCCL's own kernel on the render stream, the same ordering against the next render — so that everything the
+                # first multi-GPU run depends on has executed on a single GPU before (tests/test_gpu_rccl.py)
+                ops = [dist.P2POp(dist.irecv, received[0][index % 2][lo:hi], 0), dist.P2POp(dist.isend, view, 0)]
+            elif rank == 0:
+                ops = [dist.P2POp(dist.irecv, received[source][index % 2][lo:hi], source) for source in range(1, world)]
+            else:
+                ops = [dist.P2POp(dist.isend, view.cpu() if staged else view, 0)]
+            if ops:
+                self.in_flight.extend(dist.batch_isend_irecv(ops))
 
-    def step(index: int, timed_slot: int | None):
+        def fence(self, index: int, q: int) -> None:
+            if self.transport == "sdma" and rank:
+                context.peer_fence((index % 2)*parts + q)          # the copy that last read this piece of this buffer (two steps ago) has left it
+
+        def drain(self, keep_transfers: int = 0) -> None:
+            while len(self.in_flight) > keep_transfers*self.works_per_transfer:
+                self.in_flight.pop(0).wait()
+
+        def flush(self) -> None:
+            self.drain()
+            if self.transport == "sdma" and rank:
+                context.peer_flush()                              # this rank's frames have landed in rank 0's HBM
+
+    def barrier(gather=None):
+        if gather is not None:
+            gather.flush()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(index: int, timed_slot, gather, planar: bool):
         first = first_frame + index*fpb
         target = buffers[index % 2]
         tape.build(first, fpb)
         if timed_slot is not None:
             context.event_record(2*timed_slot)
         for q in range(parts):
-            drain(keep_transfers=2*parts - 1)                     # the transfer that last used this piece of this buffer (two steps ago) is done
-            if sdma and rank:
-                context.peer_fence((index % 2)*parts + q)         # device-side: the render waits for the copy that last read this piece
+            if gather is not None:
+                gather.drain(keep_transfers=2*parts - 1)          # the transfer that last used this piece of this buffer (two steps ago) is done
+                gather.fence(index, q)
             view = target[q*piece*frame_bytes:(q + 1)*piece*frame_bytes]
             tape.render(piece, view.data_ptr(), first_slot=q*piece)
-            transfer(index, q, view)
+            if planar:
+                out = planar_buffers[index % 2][q*piece*yuv_bytes:(q + 1)*piece*yuv_bytes]
+                context.rgb_to_yuv420(view.data_ptr(), out.data_ptr(), w, h, piece)
+                view = out
+            if gather is not None:
+                gather.send(index, q, view)
         if timed_slot is not None:
             context.event_record(2*timed_slot + 1)
 
-    def barrier():
-        if sdma and rank:
-            context.peer_flush()                                  # this rank's frames have landed in rank 0's HBM
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     # Set-up, not a measured or counted step: first launches load code objects, commit scratch buffers and bring the GPU out of its
-    # idle power state; then the recurrences of every frame before this rank's range are replayed (audio kernels only, no render)
+    # idle power state
     started = time.perf_counter()
     launches = 0
     while launches < 2 or time.perf_counter() - started < 0.3:
@@ -437,47 +465,80 @@ def main() -> None:
         tape.render(fpb, buffers[launches % 2].data_ptr())
         torch.cuda.synchronize()
         launches += 1
-    N.check(N.lib().sfx_tape_reset(tape.handle))
-    for f in range(0, first_frame, fpb):
-        tape.build(f, min(fpb, first_frame - f))
-    if distributed:
-        transfer(0, 0, buffers[0][:piece*frame_bytes])            # the communicator opens its peer-to-peer channels on first use
-        drain()
 
-    for i in range(args.warmup):
-        step(i, None)
-    drain()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, i if i < 32 else None)
-    drain()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def run_leg(transport, planar: bool) -> dict:
+        """W untimed + K timed steps of this rank's range through one transport and payload; the max-over-ranks time of the K steps"""
+        gather = Gather(transport, yuv_bytes if planar else frame_bytes) if transport else None
+        # the recurrences of every frame before this rank's range are replayed (audio kernels only, no render): every leg starts from
+        # the same tape state
+        N.check(N.lib().sfx_tape_reset(tape.handle))
+        for f in range(0, first_frame, fpb):
+            tape.build(f, min(fpb, first_frame - f))
+        if gather is not None:
+            gather.send(0, 0, (planar_buffers if planar else buffers)[0][:piece*gather.payload])   # the communicator opens its peer-to-peer channels on first use
+            gather.flush()
+        for i in range(args.warmup):
+            step(i, None, gather, planar)
+        barrier(gather)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i, i if i < 32 else None, gather, planar)
+        barrier(gather)
+        elapsed = time.perf_counter() - t0
+        intact = None
+        if loopback and transport == "p2p":                       # what RCCL delivered is what was rendered (last step, both on this device)
+            last = args.warmup + args.steps - 1
+            sent = (planar_buffers if planar else buffers)[last % 2]
+            intact = bool(torch.equal(received[0][last % 2][:sent.numel()], sent))
+        if distributed:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staged else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        events = [context.event_elapsed_ms(2*i, 2*i + 1) for i in range(min(args.steps, 32))]
+        leg = {"transport": transport, "payload": "yuv420p" if planar else "rgb24", "elapsed_s": elapsed,
+               "value": round(world*args.steps*fpb/elapsed, 2) if elapsed > 0 else None, "events_ms": events, "loopback_intact": intact}
+        if distributed:
+            payload = yuv_bytes if planar else frame_bytes
+            mine = {"rank": rank, "render_ms_per_step": round(float(np.mean(events)), 3) if events else None,
+                    "render_frames_per_s": round(fpb/(float(np.mean(events))/1e3), 1) if events else None,
+                    "sent_GB_per_s": (round(args.steps*fpb*payload/elapsed/1e9, 2) if (rank or loopback) else 0.0),
+                    "peer_copies": context.peer_route() if transport == "sdma" else None}
+            leg["per_rank"] = [None]*world
+            dist.all_gather_object(leg["per_rank"], mine)
+        return leg
+
+    legs = []
+    if not distributed:
+        legs.append(run_leg(None, False))
+    else:
+        for transport in transports:
+            legs.append(run_leg(transport, False))
+        for transport in transports:
+            legs.append(run_leg(transport, True))
+    # the headline: rgb24 frames (the reference's stream) resident in rank 0's HBM through the faster of the measured transports
+    chosen = max((leg for leg in legs if leg["payload"] == "rgb24"), key=lambda leg: leg["value"] or 0.0)
+    elapsed = chosen["elapsed_s"]
+    sdma = chosen["transport"] == "sdma"
     dist_backend = dist.get_backend() if distributed else None
-    loopback_intact = None
-    if loopback:                                                   # what RCCL delivered is what was rendered (last step, both on this device)
-        last = args.warmup + args.steps - 1
-        loopback_intact = bool(torch.equal(received[0][last % 2], buffers[last % 2]))
+    loopback_intact = chosen["loopback_intact"]
+    ranks_seen, per_rank = world, chosen.get("per_rank")
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staged else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    ranks_seen, per_rank = world, None
-    if distributed:
-        # what an 8-GPU line needs to be read: did every rank take part, how fast did each render, how much did each link carry
+        # did every rank take part?
         ones = torch.ones(1, dtype=torch.float64, device="cpu" if staged else "cuda")
         dist.all_reduce(ones)
         ranks_seen = int(round(float(ones.item())))
-        events = [context.event_elapsed_ms(2*i, 2*i + 1) for i in range(min(args.steps, 32))]
-        mine = {"rank": rank, "render_ms_per_step": round(float(np.mean(events)), 3) if events else None,
-                "render_frames_per_s": round(fpb/(float(np.mean(events))/1e3), 1) if events else None,
-                "sent_GB_per_s": (round(args.steps*fpb*frame_bytes/elapsed/1e9, 2) if (rank or loopback) else 0.0)}
-        per_rank = [None]*world
-        dist.all_gather_object(per_rank, mine)
+        if windows:
+            for window in windows:
+                context.peer_close(window)
+        dist.barrier()
+        if raw_received:
+            del received
+            torch.cuda.synchronize()
+            for pair in raw_received:
+                for pointer in pair:
+                    context.free(pointer)
 
-    kernel_ms = [context.event_elapsed_ms(2*i, 2*i + 1) for i in range(min(args.steps, 32))]
+    kernel_ms = chosen["events_ms"]
     launch_s = (float(np.mean(kernel_ms))/1e3/parts) if kernel_ms else float("nan")     # one launch = `piece` frames
     kernel = N.lib().sfx_last_kernel().decode()
     frames_total = world*args.steps*fpb
@@ -497,9 +558,10 @@ def main() -> None:
         barrier()
         took = time.perf_counter() - t1
         planar = None
-        if world == 1 and not distributed:
+        if True:
             # the same export with the frames converted to planar yuv420p on the device (scene.main(pixel_format="yuv420p"), opt-in:
-            # SURVEY §8 f1's optional half): 12.4 MB per frame over PCIe instead of 24.9
+            # SURVEY §8 f1's optional half): 12.4 MB per frame over PCIe instead of 24.9 — since round 5 in every shard mode too, converted
+            # on the rank that rendered the frame
             scene3 = build_scene(prepared=False)
             barrier()
             t2 = time.perf_counter()
@@ -597,9 +659,17 @@ def main() -> None:
         if per_rank is not None:
             result["per_rank"] = per_rank
             inbound = sum(r["sent_GB_per_s"] for r in per_rank)
-            result["gather"] = {"backend": "sdma peer copies (hipIpc + hipMemcpyAsync)" if sdma else dist_backend, "pieces_per_step": parts, "inbound_GB_per_s_rank0": round(inbound, 2), "loopback": loopback, "loopback_intact": loopback_intact,
-                                "note": "sent_GB_per_s = frames a rank sent to rank 0 / the timed region: every peer has its own xGMI link to rank 0; "
-                                        "a rank whose render_frames_per_s x 24.9 MB exceeds what its link sustains is link-bound (DESIGN.md §6)"}
+            result["gather"] = {"backend": "sdma peer copies (hipIpc windows + SDMA engines named through HSA)" if sdma else dist_backend, "chosen": chosen["transport"],
+                                "pieces_per_step": parts, "inbound_GB_per_s_rank0": round(inbound, 2), "loopback": loopback and not sdma, "loopback_intact": loopback_intact,
+                                "legs": [{"transport": leg["transport"], "payload": leg["payload"], "value": leg["value"], "unit": "frames/s",
+                                          "ms_per_step": round(leg["elapsed_s"]/max(1, args.steps)*1e3, 3), "loopback_intact": leg["loopback_intact"], "per_rank": leg.get("per_rank")} for leg in legs],
+                                "note": "every leg is W untimed + K timed steps of the same frame ranges; `value` is the fastest rgb24 leg (the reference's byte stream resident in "
+                                        "rank 0's HBM), the yuv420p legs move half the bytes per link (converted on the rendering rank). sent_GB_per_s = what a rank sent to rank 0 / "
+                                        "the timed region: every peer has its own xGMI link to rank 0; a rank whose render_frames_per_s x frame bytes exceeds what its link "
+                                        "sustains is link-bound (DESIGN.md §6). peer_copies: the SDMA engines a rank's copies were issued on"}
+            planar_legs = [leg for leg in legs if leg["payload"] == "yuv420p" and leg["value"]]
+            if planar_legs:
+                result["value_yuv420p"] = max(leg["value"] for leg in planar_legs)
     else:
         result = None
 

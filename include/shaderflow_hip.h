@@ -348,10 +348,15 @@ int sfx_device_read(sfx_handle ctx, const void* device_ptr, void* host, size_t n
 int sfx_peer_export(sfx_handle ctx, void* device_ptr, void* handle64);
 int sfx_peer_open(sfx_handle ctx, const void* handle64, void** device_ptr);
 int sfx_peer_close(sfx_handle ctx, void* device_ptr);
-/* asynchronous; ordered after what the context's stream holds now. `lane` (0..15) names the source buffer for sfx_peer_fence */
+/* asynchronous; ordered after what the context's stream holds now. `lane` (0..15) tags the source buffer for sfx_peer_fence. The copy is
+ * issued by a thread of the context on one of the two SDMA engines HSA recommends for the (owner of the window, this GPU) pair — named,
+ * not drawn (hsa_amd_memory_async_copy_on_engine), up to four in flight; HIP copy streams where HSA does not answer (SHADERFLOW_PEER=hip). */
 int sfx_peer_copy(sfx_handle ctx, void* remote_dst, const void* local_src, size_t nbytes, int lane);
-int sfx_peer_fence(sfx_handle ctx, int lane);    /* later work on the context's stream waits for the lane's last copy (device side) */
+int sfx_peer_fence(sfx_handle ctx, int lane);    /* host wait: the lane's last copy has left its source (a pipelined sender asks a step later) */
 int sfx_peer_flush(sfx_handle ctx);              /* host wait: every copy issued so far has landed */
+/* how the context's peer copies travel: *via_engines 1 = named SDMA engines (engine_ids[2]: their indices), 0 = HIP copy streams, -1 = none
+ * issued yet; copies / bytes queued so far. Any pointer may be NULL. */
+int sfx_peer_route(sfx_handle ctx, int* via_engines, int* engine_ids, unsigned long long* copies, unsigned long long* bytes);
 
 #ifdef __cplusplus
 }

@@ -120,6 +120,7 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_peer_copy": (C.c_int, [Handle, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "sfx_peer_fence": (C.c_int, [Handle, C.c_int]),
     "sfx_peer_flush": (C.c_int, [Handle]),
+    "sfx_peer_route": (C.c_int, [Handle, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "sfx_shm_create": (C.c_int, [Handle, C.c_char_p, C.c_int, C.c_int, C.c_size_t, C.c_int, P(Handle)]),
     "sfx_shm_push": (C.c_int, [Handle, C.c_void_p]),
     "sfx_shm_flush": (C.c_int, [Handle]),
@@ -203,8 +204,6 @@ class Context:
         self.handle = Handle()
         check(lib().sfx_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self.handle)))
         self.device = device
-        if os.environ.get("SHADERFLOW_FILTER_MODEL"):                 # "llvmpipe": frames within 1 LSB of the reference's llvmpipe frames everywhere
-            self.filter_model(os.environ["SHADERFLOW_FILTER_MODEL"])
 
     def info(self) -> CtxInfo:
         info = CtxInfo()
@@ -265,6 +264,13 @@ class Context:
         handle = C.create_string_buffer(64)
         check(lib().sfx_peer_export(self.handle, C.c_void_p(ptr), handle))
         return handle.raw
+
+    def peer_route(self) -> dict:
+        """How this context's peer copies travel: {"route": "sdma-engines" | "hip-streams" | None, "engines": [ids], "copies", "bytes"}"""
+        via, ids, copies, nbytes = C.c_int(), (C.c_int*2)(), C.c_ulonglong(), C.c_ulonglong()
+        check(lib().sfx_peer_route(self.handle, C.byref(via), ids, C.byref(copies), C.byref(nbytes)))
+        route = {1: "sdma-engines", 0: "hip-streams"}.get(via.value)
+        return {"route": route, "engines": [int(i) for i in ids] if via.value == 1 else [], "copies": int(copies.value), "bytes": int(nbytes.value)}
 
     def peer_open(self, handle: bytes) -> int:
         ptr = C.c_void_p()

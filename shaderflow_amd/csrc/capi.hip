@@ -84,11 +84,11 @@ struct Context : Object {
     // queues, so hipFree's implicit wait knows nothing of them: sfx_device_free asks them first.
     std::vector<std::pair<void*, void (*)(void*)>> readouts;
     struct EngineCopy* engines = nullptr;                           // agents and SDMA engines of the read-out (EngineLanes); null until first use
+    struct EngineCopy* peer_engines = nullptr;                      // … of the peer copies (PeerCopier)
+    struct PeerCopier* peer = nullptr;                              // the sharded export's peer copies: a thread that issues them on named engines
     // peer copies of the sharded export's "device-sdma" mode: the copy streams, an event per lane (sfx_peer_*)
-    hipStream_t peer_streams[2] = {nullptr, nullptr};
-    hipEvent_t peer_ready = nullptr, peer_done[16] = {};
-    uint64_t peer_copies = 0;
 };
+static void peer_stop(Context* c);                                 // (defined with the peer windows)
 static thread_local Context* g_launch_ctx = nullptr;               // the context whose program is being launched (scratch owner)
 
 struct Texture : Object {
@@ -210,7 +210,7 @@ static int context_copy_streams(Context* c) {
 // probed copy streams.
 struct EngineCopy {
     bool usable = false;
-    hsa_agent_t gpu{}, cpu{};
+    hsa_agent_t gpu{}, cpu{};                                       // the source's agent (this context's GPU) and the destination's (a CPU socket, or — peer copies — the GPU that owns the window)
     uint32_t engine[2] = {0, 0};
 };
 
@@ -256,6 +256,42 @@ static EngineCopy* engine_copy(Context* c, const void* host, const void* device)
     return e;
 }
 
+// The same for a PEER copy (sharded export, "device-sdma"): the destination is a window another process exported (sfx_peer_open) — its
+// owner is another GPU of the node (or, in the one-GPU tests, this one). The engines are the ones HSA recommends for that ordered
+// pair of agents: on the node's fully connected fabric every peer has its own xGMI link and the runtime pairs links with SDMA
+// engines, so NAMING them keeps two copies of one rank on the engines of ITS link instead of on whichever engine is idle
+// (hipMemcpyAsync's lottery). SHADERFLOW_PEER_ENGINES=a,b overrides, SHADERFLOW_PEER=hip keeps HIP's copy streams.
+static EngineCopy* peer_engine_copy(Context* c, const void* remote, const void* local) {
+    static std::mutex lock;
+    std::lock_guard<std::mutex> guard(lock);
+    if (c->peer_engines) return c->peer_engines->usable ? c->peer_engines : nullptr;
+    EngineCopy* e = c->peer_engines = new EngineCopy();
+    const char* route = getenv("SHADERFLOW_PEER");
+    if (route && strcmp(route, "engine")) return nullptr;
+    if (hsa_init() != HSA_STATUS_SUCCESS) return nullptr;
+    hsa_amd_pointer_info_t here{}, there{};
+    here.size = sizeof(here); there.size = sizeof(there);
+    if (hsa_amd_pointer_info(local, &here, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || here.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return nullptr;
+    if (hsa_amd_pointer_info(remote, &there, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || there.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return nullptr;
+    e->gpu = here.agentOwner; e->cpu = there.agentOwner;            // (`cpu` = the destination's agent: the GPU that owns the window)
+    std::pair<std::vector<hsa_agent_t>, std::vector<hsa_agent_t>> agents;
+    if (hsa_iterate_agents(collect_agents, &agents) != HSA_STATUS_SUCCESS) return nullptr;
+    bool source_known = false, target_known = false;
+    for (hsa_agent_t a : agents.first) { source_known |= (a.handle == e->gpu.handle); target_known |= (a.handle == e->cpu.handle); }
+    if (!source_known || !target_known) return nullptr;
+    uint32_t preferred = 0, free_mask = 0;
+    if (hsa_amd_memory_get_preferred_copy_engine(e->cpu, e->gpu, &preferred) != HSA_STATUS_SUCCESS) preferred = 0;
+    if (!preferred && hsa_amd_memory_copy_engine_status(e->cpu, e->gpu, &free_mask) == HSA_STATUS_SUCCESS) preferred = free_mask;
+    if (!preferred) return nullptr;                                   // no engine serves the pair (HSA's own choice would be a blit kernel)
+    e->engine[0] = preferred & (~preferred + 1u);
+    const uint32_t rest = preferred & (preferred - 1u);
+    e->engine[1] = rest ? (rest & (~rest + 1u)) : e->engine[0];
+    int a = -1, b = -1;
+    if (const char* named = getenv("SHADERFLOW_PEER_ENGINES")) if (sscanf(named, "%d,%d", &a, &b) == 2 && a >= 0 && a < 16 && b >= 0 && b < 16) { e->engine[0] = 1u << a; e->engine[1] = 1u << b; }
+    e->usable = true;
+    return e;
+}
+
 // device-to-device copy of a frame as a KERNEL on the caller's stream (hipMemcpyAsync hands it to a copy engine: measured 5.6 GB/s for
 // a 6.2 MB frame inside the frame loop — 1.1 ms per frame; this is 2-3 us)
 typedef unsigned int frame_u4 __attribute__((ext_vector_type(4)));
@@ -284,12 +320,14 @@ struct EngineLanes {
     hsa_signal_t done[LANES] = {};
     bool busy[LANES] = {};
     bool via_hsa[LANES] = {};                                       // the route the lane's copy in flight was issued on: it is finished on that one
+    hipMemcpyKind kind = hipMemcpyDeviceToHost;                     // the HIP route's direction (read-out, or a peer copy)
 
     // `host` / `device`: the first frame's two ends (they name the agents). Called from the thread that issues.
-    void resolve(Context* context, const void* host, const void* device) {
+    void resolve(Context* context, const void* host, const void* device, bool peer = false) {
         if (resolved) return;
         resolved = true; c = context;
-        e = engine_copy(context, host, device);
+        e = peer ? peer_engine_copy(context, host, device) : engine_copy(context, host, device);
+        kind = peer ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
         if (e) for (auto& signal : done) if (hsa_signal_create(0, 0, nullptr, &signal) != HSA_STATUS_SUCCESS) { e = nullptr; break; }
         if (!e) (void)context_copy_streams(context);                  // the lanes are HIP copy streams then
     }
@@ -309,7 +347,7 @@ struct EngineLanes {
             if (context_copy_streams(c) != SFX_OK) return false;
         }
         if (!c->copy_streams[0] && context_copy_streams(c) != SFX_OK) return false;
-        if (hipMemcpyAsync(host, device, nbytes, hipMemcpyDeviceToHost, c->copy_streams[lane & 1]) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipMemcpyAsync(host, device, nbytes, kind, c->copy_streams[lane & 1]) != hipSuccess) { (void)hipGetLastError(); return false; }
         busy[lane] = true; via_hsa[lane] = false;
         return true;
     }
@@ -436,8 +474,7 @@ extern "C" int sfx_ctx_destroy(sfx_handle h) {
     hipFree(c->vis_tables); hipFree(c->vis_bars); hipFree(c->resolve_tables); hipFree(c->tile_misses);
     for (hipStream_t stream : c->copy_streams) if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
     delete c->engines;
-    if (c->peer_ready) hipEventDestroy(c->peer_ready);
-    for (auto& e : c->peer_done) if (e) hipEventDestroy(e);
+    peer_stop(c);
     if (c->own_stream) hipStreamDestroy(c->stream);
     c->magic = 0;
     delete c;
@@ -504,45 +541,135 @@ extern "C" int sfx_peer_open(sfx_handle h, const void* handle64, void** device_p
     HIP_TRY(hipIpcOpenMemHandle(device_ptr, handle, hipIpcMemLazyEnablePeerAccess));
     return SFX_OK;
 }
+// Peer copies are issued by a thread of the context, like the read-out's (EngineLanes): it waits ON THE HOST for the source to be
+// complete on the render stream (an event per tag), hands the copy to one of the two SDMA engines HSA recommends for the pair of
+// GPUs — up to four in flight, two per engine — and waits on HSA's signals. Nothing passes through a HIP queue, so no hardware-queue
+// sharing with the render stream and no engine lottery; where HSA does not answer the lanes are HIP's copy streams.
+struct PeerCopier {
+    Context* ctx = nullptr;
+    struct Job { void* dst; const void* src; size_t nbytes; int tag; };
+    std::thread worker;
+    std::mutex mutex;
+    std::condition_variable wake, idle;
+    std::deque<Job> queue;
+    EngineLanes lanes;
+    hipEvent_t ready[16] = {};
+    int pending[16] = {};                                            // copies of a tag queued or in flight
+    int error = 0;
+    bool stop = false;
+    uint64_t copies = 0, bytes = 0;
+};
+
+static void peer_copier(PeerCopier* p) {
+    hipSetDevice(p->ctx->device);
+    int in_lane[EngineLanes::LANES] = {-1, -1, -1, -1}, next = 0;
+    auto finish = [&](int lane) {
+        if (in_lane[lane] < 0) return;
+        const bool ok = p->lanes.finish(lane);
+        { std::lock_guard<std::mutex> lock(p->mutex); if (!ok) p->error = 1; p->pending[in_lane[lane]]--; }
+        in_lane[lane] = -1;
+        p->idle.notify_all();
+    };
+    for (;;) {
+        PeerCopier::Job job;
+        {
+            std::unique_lock<std::mutex> lock(p->mutex);
+            if (p->queue.empty()) {
+                lock.unlock();
+                for (int k = 0; k < EngineLanes::LANES; k++) finish((next + k) % EngineLanes::LANES);
+                lock.lock();
+                p->wake.wait(lock, [&] { return p->stop || !p->queue.empty(); });
+                if (p->queue.empty()) return;
+            }
+            job = p->queue.front(); p->queue.pop_front();
+        }
+        for (int lane = 0; lane < EngineLanes::LANES; lane++) if (in_lane[lane] >= 0 && p->lanes.landed(lane)) finish(lane);
+        hipEventSynchronize(p->ready[job.tag]);                      // the source is complete on the render stream
+        finish(next);
+        p->lanes.resolve(p->ctx, job.dst, job.src, true);
+        if (!p->lanes.issue(next, job.dst, job.src, job.nbytes)) {
+            std::lock_guard<std::mutex> lock(p->mutex);
+            p->error = 1; p->pending[job.tag]--;
+            p->idle.notify_all();
+            continue;
+        }
+        in_lane[next] = job.tag;
+        next = (next + 1) % EngineLanes::LANES;
+    }
+}
+
+static void peer_stop(Context* c) {
+    PeerCopier* p = c->peer;
+    if (!p) return;
+    { std::lock_guard<std::mutex> lock(p->mutex); p->stop = true; }
+    p->wake.notify_all();
+    if (p->worker.joinable()) p->worker.join();
+    p->lanes.release();
+    for (auto& e : p->ready) if (e) hipEventDestroy(e);
+    { auto& list = c->readouts; list.erase(std::remove_if(list.begin(), list.end(), [&](const std::pair<void*, void (*)(void*)>& e) { return e.first == p; }), list.end()); }
+    delete p;
+    c->peer = nullptr;
+}
+static int peer_wait(PeerCopier* p, int tag) {                      // tag < 0: every tag
+    std::unique_lock<std::mutex> lock(p->mutex);
+    p->idle.wait(lock, [&] { if (tag >= 0) return p->pending[tag] == 0; for (int n : p->pending) if (n) return false; return true; });
+    return p->error ? fail(SFX_E_HIP, "peer copy: neither HSA nor HIP completed the copy") : SFX_OK;
+}
+
 extern "C" int sfx_peer_close(sfx_handle h, void* device_ptr) {
     CTX_OR_FAIL(c, h);
     USE_DEVICE(c);
-    for (hipStream_t stream : c->peer_streams) if (stream) HIP_TRY(hipStreamSynchronize(stream));
+    if (c->peer) { const int rc = peer_wait(c->peer, -1); if (rc) return rc; }
     HIP_TRY(hipIpcCloseMemHandle(device_ptr));
     return SFX_OK;
 }
-// `nbytes` from `local_src` (complete on the context's stream when this call is made) to `remote_dst` (inside a window opened with
-// sfx_peer_open, or any device pointer): asynchronous, on a copy stream. `lane` (0..15) names the source buffer for sfx_peer_fence.
+// `nbytes` from `local_src` (complete on the context's stream once everything queued there so far has run) to `remote_dst` (inside a
+// window opened with sfx_peer_open, or any device pointer): asynchronous. `lane` (0..15) tags the source buffer for sfx_peer_fence.
 extern "C" int sfx_peer_copy(sfx_handle h, void* remote_dst, const void* local_src, size_t nbytes, int lane) {
     CTX_OR_FAIL(c, h);
     if (!remote_dst || !local_src || lane < 0 || lane >= 16) return fail(SFX_E_INVALID, "peer copy: pointers / lane %d", lane);
     USE_DEVICE(c);
-    if (!c->peer_ready) {
-        HIP_TRY(hipEventCreateWithFlags(&c->peer_ready, hipEventDisableTiming));
-        { int rc = context_copy_streams(c); if (rc) return rc; }
-        c->peer_streams[0] = c->copy_streams[0]; c->peer_streams[1] = c->copy_streams[1];
+    if (!c->peer) {
+        c->peer = new PeerCopier();
+        c->peer->ctx = c;
+        c->peer->worker = std::thread(peer_copier, c->peer);
+        c->readouts.push_back({c->peer, [](void* copier) { (void)peer_wait((PeerCopier*)copier, -1); }});   // sfx_device_free waits for copies in flight
     }
-    if (!c->peer_done[lane]) HIP_TRY(hipEventCreateWithFlags(&c->peer_done[lane], hipEventDisableTiming));
-    hipStream_t stream = c->peer_streams[c->peer_copies++ & 1];
-    HIP_TRY(hipEventRecord(c->peer_ready, c->stream));
-    HIP_TRY(hipStreamWaitEvent(stream, c->peer_ready, 0));
-    HIP_TRY(hipMemcpyAsync(remote_dst, local_src, nbytes, hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(hipEventRecord(c->peer_done[lane], stream));
+    PeerCopier* p = c->peer;
+    { const int rc = peer_wait(p, lane); if (rc) return rc; }      // the tag's event is recorded again below: its previous copy must have taken it
+    if (!p->ready[lane]) HIP_TRY(hipEventCreateWithFlags(&p->ready[lane], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(p->ready[lane], c->stream));
+    {
+        std::lock_guard<std::mutex> lock(p->mutex);
+        p->pending[lane]++;
+        p->queue.push_back({remote_dst, local_src, nbytes, lane});
+        p->copies++; p->bytes += nbytes;
+    }
+    p->wake.notify_one();
     return SFX_OK;
 }
-// work queued on the context's stream from now on waits for the last copy of `lane` (its source may then be overwritten); no host wait
+// the last copy tagged `lane` has left its source (which may then be overwritten). A HOST wait since round 5 — the copies run outside
+// HIP's queues, there is no event a stream could wait for; a pipelined sender asks about a copy it queued a whole step ago.
 extern "C" int sfx_peer_fence(sfx_handle h, int lane) {
     CTX_OR_FAIL(c, h);
     if (lane < 0 || lane >= 16) return fail(SFX_E_INVALID, "peer fence: lane %d", lane);
-    USE_DEVICE(c);
-    if (c->peer_done[lane]) HIP_TRY(hipStreamWaitEvent(c->stream, c->peer_done[lane], 0));
-    return SFX_OK;
+    return c->peer ? peer_wait(c->peer, lane) : SFX_OK;
 }
 // every copy issued so far has landed (host wait)
 extern "C" int sfx_peer_flush(sfx_handle h) {
     CTX_OR_FAIL(c, h);
-    USE_DEVICE(c);
-    for (hipStream_t stream : c->peer_streams) if (stream) HIP_TRY(hipStreamSynchronize(stream));
+    return c->peer ? peer_wait(c->peer, -1) : SFX_OK;
+}
+// How this context's peer copies travel: *via_engines 1 = SDMA engines named through HSA (engine_ids: their indices), 0 = HIP's copy
+// streams (HSA did not answer, or SHADERFLOW_PEER=hip), -1 = no copy has been issued yet. For measurements and their records.
+extern "C" int sfx_peer_route(sfx_handle h, int* via_engines, int* engine_ids /* [2] */, unsigned long long* copies, unsigned long long* bytes) {
+    CTX_OR_FAIL(c, h);
+    PeerCopier* p = c->peer;
+    const bool resolved = p && p->lanes.resolved;
+    if (via_engines) *via_engines = !resolved ? -1 : (p->lanes.e ? 1 : 0);
+    if (engine_ids) for (int k = 0; k < 2; k++) engine_ids[k] = (resolved && p->lanes.e) ? __builtin_ctz(p->lanes.e->engine[k] ? p->lanes.e->engine[k] : 1u) : -1;
+    if (copies) *copies = p ? p->copies : 0;
+    if (bytes) *bytes = p ? p->bytes : 0;
     return SFX_OK;
 }
 

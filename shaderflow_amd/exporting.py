@@ -122,7 +122,7 @@ class ExportingHelper:
         else:
             self.path = Path(output).expanduser().absolute()
             self.path.parent.mkdir(parents=True, exist_ok=True)
-            raw = self.path.suffix.lower() in (".rgb", ".raw", ".rgb24")
+            raw = self.path.suffix.lower() in (".rgb", ".raw", ".rgb24", ".yuv", ".i420")
             self.kind = "path-raw" if (raw or not self.ffmpeg.available()) else "path-ffmpeg"
             if self.kind == "path-raw" and not raw:
                 logger.warning(f"No ffmpeg binary on PATH: writing raw rgb24 frames (rows bottom-up) to {self.path}")

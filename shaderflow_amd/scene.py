@@ -78,6 +78,9 @@ class ShaderScene(ShaderModule):
         return self._final.texture.components
 
     subsample: int = field(default=2, converter=lambda x: int(max(1, x)))
+    filter_model: Optional[str] = None
+    """None / "spec": float bilinear weights (the default); "llvmpipe": the 8-bit fixed-point filter of the software rasteriser the
+    reference's CPU path runs on — frames within 1 LSB of its frames everywhere, at the price of the table-driven and fused kernels"""
 
     def initialize(self) -> None:
         if self._initialized:
@@ -85,6 +88,9 @@ class ShaderScene(ShaderModule):
         self._initialized = True
         if self.context is None:
             self.context = N.Context(self.device) if self.device is not None else N.default_context()
+        # how LINEAR unorm8 textures are filtered (sfx_ctx_filter_model): the scene's own wish, else SHADERFLOW_FILTER_MODEL, else the float
+        # weights — said every time, because the process-wide default context outlives scenes
+        self.context.filter_model(self.filter_model or os.environ.get("SHADERFLOW_FILTER_MODEL") or "spec")
         logger.info(f"Initializing scene {self.name} on {self.context.info().device_name.decode()}")
 
         # Default modules. The reference also registers a frametimer and a keyboard (scene.py:135-136): UI-only
@@ -338,8 +344,6 @@ class ShaderScene(ShaderModule):
             self.ssaa = ssaa
 
         export = ExportingHelper(self, top_down=top_down, pixel_format=(pixel_format or os.environ.get("SHADERFLOW_PIXEL_FORMAT") or "rgb24"))
-        if export.planar and (is_sharded() or shard is not None):
-            raise NotImplementedError("pixel_format='yuv420p' is a single-process option (the sharded modes move rgb24 frames)")
         if (self.exporting):
             # Every rank of a sharded export resolves the sink the same way — its kind decides the row order the kernels write
             # (exporting.py:94-118) — but only rank 0 opens it and owns the read-out ring (tape.py, _sharded_frame_loop)
@@ -390,7 +394,9 @@ class ShaderScene(ShaderModule):
         from shaderflow_amd.parallel import (FrameGather, HostDelivery, frame_modes, interleaved_host_export, interleaved_runs, shard_batches,
                                              shard_mode, sharded_frame_loop)
         total = export.total_frames
-        frame_bytes = self.width*self.height*3
+        # the frames a rank keeps, sends and delivers are SINK frames: rgb24 copies of iFinal, or — pixel_format "yuv420p" — planar frames
+        # converted on the rank that rendered them, straight into the batch buffer (half the bytes over every link)
+        frame_bytes = export.frame_bytes
         batches = shard_batches(0, total, batch)
         warmup = self.shard_warmup
         if warmup == "auto":
@@ -399,6 +405,13 @@ class ShaderScene(ShaderModule):
         modes = frame_modes(batches, world, rank, warmup)
         context = self.context
         distributed = is_sharded()
+
+        def keep(target: int) -> None:                          # iFinal of the frame just rendered → its place in the batch buffer
+            if export.planar:
+                export.to_yuv(self._final.texture.texture.device_ptr(), target)
+            else:
+                context.copy(target, self._final.texture.texture.device_ptr(), frame_bytes)
+        export._device_frames_are_planar = export.planar       # what the sink's rank pipes from device buffers is converted already
         if distributed and shard_mode() == "host":
             # every rank reads the frames of its own batches out over its own PCIe link into shared memory; rank 0's writer thread
             # hands them to the sink in frame order (parallel.HostDelivery)
@@ -413,7 +426,7 @@ class ShaderScene(ShaderModule):
                     self._skip_render = (mode == 0)
                     self._one_frame()
                     if mode == 2:
-                        context.copy(pointer + i*frame_bytes, self._final.texture.texture.device_ptr(), frame_bytes)
+                        keep(pointer + i*frame_bytes)
 
             try:
                 interleaved_host_export(world, rank, batches, advance, lambda count, pointer: None, delivery, pointers)
@@ -441,7 +454,7 @@ class ShaderScene(ShaderModule):
             self._skip_render = (mode == 0)
             self._one_frame()
             if mode == 2:
-                context.copy(pointer_of(buffer) + offset, self._final.texture.texture.device_ptr(), frame_bytes)
+                keep(pointer_of(buffer) + offset)
 
         def emit(buffer, count: int) -> None:                   # rank 0 of a process group: frames arrive in order
             for i in range(count):
@@ -468,6 +481,7 @@ class ShaderScene(ShaderModule):
             return export.finish()
         finally:
             self._skip_render = False
+            export._device_frames_are_planar = False
             context.synchronize()
             if gather is None:
                 for pointer in tensors:

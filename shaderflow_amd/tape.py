@@ -249,11 +249,11 @@ class FrameTape:
             verdict = [True]
             if rank == 0:
                 free, _ = torch.cuda.mem_get_info(context.device)
-                verdict[0] = total*frame_bytes + (4 << 30) < free
+                verdict[0] = total*export.frame_bytes + (4 << 30) < free
             dist.broadcast_object_list(verdict, src=0)
             if not verdict[0]:
                 if rank == 0:
-                    print(f"shaderflow_amd: {total} frames of {frame_bytes >> 20} MiB do not fit rank 0's free device memory: "
+                    print(f"shaderflow_amd: {total} frames of {export.frame_bytes >> 20} MiB do not fit rank 0's free device memory: "
                           f"SHADERFLOW_SHARD={mode} falls back to host mode", flush=True)
                 mode = "host"
         try:
@@ -291,17 +291,28 @@ class FrameTape:
                         context.free(pointer)
             elif mode == "host":
                 # every rank reads its own batches out over its own PCIe link into shared memory; rank 0's writer thread hands
-                # them to the sink in frame order (parallel.HostDelivery): no collective on the data path
-                slots = int(os.environ.get("SHADERFLOW_SHM_SLOTS", 0)) or max(4, min(2*self.batch, (4 << 30)//frame_bytes))
-                delivery = HostDelivery(context, world, rank, frame_bytes, slots, export.fileno if rank == 0 else None,
+                # them to the sink in frame order (parallel.HostDelivery): no collective on the data path. pixel_format "yuv420p":
+                # the rank that rendered a batch converts it (one kernel behind the render) and the PLANAR frames travel — 12.4
+                # instead of 24.9 MB per 4K frame over every link
+                sink_bytes = export.frame_bytes
+                slots = int(os.environ.get("SHADERFLOW_SHM_SLOTS", 0)) or max(4, min(2*self.batch, (4 << 30)//sink_bytes))
+                delivery = HostDelivery(context, world, rank, sink_bytes, slots, export.fileno if rank == 0 else None,
                                         interleaved_runs(world, batches))
-                buffers = [context.alloc(frame_bytes*self.batch) for _ in range(2)]
+                buffers = [context.alloc(sink_bytes*self.batch) for _ in range(2)]
+                scratch = context.alloc(frame_bytes*self.batch) if export.planar else None      # (stream-ordered: one RGB batch suffices)
+
+                def render_sink_frames(count: int, buffer: int) -> None:
+                    if scratch is None:
+                        self.render(count, buffer)
+                    else:
+                        self.render(count, scratch)
+                        export.to_yuv(scratch, buffer, count)
                 try:
-                    interleaved_host_export(world, rank, batches, lambda first, count, buffer: self.build(first, count), self.render, delivery, buffers)
+                    interleaved_host_export(world, rank, batches, lambda first, count, buffer: self.build(first, count), render_sink_frames, delivery, buffers)
                 finally:
                     delivery.finish()
                     context.synchronize()
-                    for pointer in buffers:
+                    for pointer in buffers + ([scratch] if scratch is not None else []):
                         context.free(pointer)
                 export.frame = total
             else:
@@ -310,38 +321,51 @@ class FrameTape:
                 device = torch.device("cuda", context.device)
                 first, last = shard_frames(total, world, rank)
                 frames_here = total if rank == 0 else (last - first)
+                # what is resident, sent and handed to the sink are SINK frames: rgb24, or — pixel_format "yuv420p" — the planar frames
+                # the rendering rank converts behind every batch (half the bytes over every xGMI link and over rank 0's PCIe link)
+                sink_bytes = export.frame_bytes
+                scratch = context.alloc(frame_bytes*self.batch) if export.planar else None
+                export._device_frames_are_planar = export.planar
                 window = None
                 if mode == "device-sdma":
                     # peer windows: rank 0's buffer is ONE raw allocation (IPC handles name whole allocations), mapped by every rank
                     if rank == 0:
-                        window = context.alloc(max(1, frames_here)*frame_bytes)
-                        resident = torch.as_tensor(DeviceArray(window, max(1, frames_here)*frame_bytes), device=device)
+                        window = context.alloc(max(1, frames_here)*sink_bytes)
+                        resident = torch.as_tensor(DeviceArray(window, max(1, frames_here)*sink_bytes), device=device)
                     else:
-                        resident = torch.zeros(max(1, frames_here)*frame_bytes, dtype=torch.uint8, device=device)
+                        resident = torch.zeros(max(1, frames_here)*sink_bytes, dtype=torch.uint8, device=device)
                     torch.cuda.synchronize(device)
-                    transfer = SdmaTransfer(world, rank, context, frame_bytes, window)
+                    transfer = SdmaTransfer(world, rank, context, sink_bytes, window)
                 else:
-                    resident = torch.zeros(max(1, frames_here)*frame_bytes, dtype=torch.uint8, device=device)
+                    resident = torch.zeros(max(1, frames_here)*sink_bytes, dtype=torch.uint8, device=device)
                     torch.cuda.synchronize(device)              # the fill runs on torch's stream, the renders on the context's
                     transfer = RangeTransfer(world, rank, device)
 
                 def render(first_frame, count, view):
-                    self.render(count, view.data_ptr())
+                    if scratch is None:
+                        self.render(count, view.data_ptr())
+                    else:
+                        self.render(count, scratch)
+                        export.to_yuv(scratch, view.data_ptr(), count)
                     context.synchronize()                       # the context's stream is not torch's: complete before the send
 
                 def emit(view, count):
-                    emit_frames(view.data_ptr(), count)
+                    emit_frames(view.data_ptr(), count, stride=sink_bytes)
 
                 # a rank that raises mid-export must not leave the others waiting for its chunks, nor rank 0's whole-export allocation
                 # and the peers' mappings behind: the outcome is exchanged, then every rank tears down
                 failure: Optional[BaseException] = None
                 try:
-                    contiguous_device_export(world, rank, total, self.batch, frame_bytes, self.build, render, emit, resident, transfer)
+                    contiguous_device_export(world, rank, total, self.batch, sink_bytes, self.build, render, emit, resident, transfer)
                     export.drain()                              # `resident` outlives the queued reads
                 except BaseException as error:
                     failure = error
                     transfer.abort()
                 finally:
+                    export._device_frames_are_planar = False
+                    if scratch is not None:
+                        context.synchronize()
+                        context.free(scratch)
                     if mode == "device-sdma":
                         import torch.distributed as dist
                         try:

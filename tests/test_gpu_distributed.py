@@ -31,13 +31,13 @@ def _build(name: str):
 KW = {"Visualizer": dict(width=96, height=54, fps=60.0, ssaa=2, time=130/60), "MotionBlur": dict(width=64, height=36, fps=30.0, ssaa=1, time=70/30)}
 
 
-def _rank(rank: int, world: int, port: int, name: str, path: str, top_down=None, mode="host"):
+def _rank(rank: int, world: int, port: int, name: str, path: str, top_down=None, mode="host", pixel_format=None):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", RANK=str(rank), WORLD_SIZE=str(world), SHADERFLOW_SHARD=mode,
                       SHADERFLOW_SHM_SLOTS="5")                       # fewer ring slots than a batch: the back-pressure path runs too
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        _build(name).main(output=path, top_down=top_down, **KW[name])
+        _build(name).main(output=path, top_down=top_down, pixel_format=pixel_format, **KW[name])
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -61,6 +61,30 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_export(tmp_path, name
     ctx = mp.get_context("spawn")
     port = _free_port()
     procs = [ctx.Process(target=_rank, args=(r, 2, port, name, path, top_down, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    sharded = open(path, "rb").read()
+    assert len(sharded) == len(whole)
+    assert sharded == whole, f"{np.count_nonzero(np.frombuffer(sharded, np.uint8) != np.frombuffer(whole, np.uint8))} bytes differ"
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("mode", ["host", "device", "device-sdma"])
+@pytest.mark.parametrize("name", ["Visualizer", "MotionBlur"])
+def test_two_ranks_deliver_yuv420p_frames_converted_where_they_were_rendered(tmp_path, name, mode):
+    """pixel_format="yuv420p" in every shard mode: the rank that rendered a batch converts it and the PLANAR
+    frames — half the bytes — are what crosses the rank's link (shared-memory ring, RCCL / staged point-to-point, peer window). The
+    file rank 0 writes is the single-process yuv420p export, byte for byte; tape scene and frame-loop scene."""
+    whole = _build(name).main(output=bytes, pixel_format="yuv420p", **KW[name])
+    frames = round(KW[name]["time"]*KW[name]["fps"])
+    assert len(whole) == frames*KW[name]["width"]*KW[name]["height"]*3//2
+    path = str(tmp_path/"sharded.yuv")
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, name, path, None, mode, "yuv420p")) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

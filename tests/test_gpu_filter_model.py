@@ -62,7 +62,7 @@ def test_the_device_filter_is_llvmpipes_byte_for_byte(gpu, tag):
     N.check(gpu.lib.sfx_program_destroy(prog))
     gpu.ctx.filter_model("llvmpipe")
     d = np.abs(spec.astype(int) - want.astype(int))
-    assert d.max() == 1 and 0.02 < (d == 1).mean() < 0.5
+    assert 1 <= d.max() <= 2 and 0.02 < (d >= 1).mean() < 0.5
 
 
 def within_one(tag: str, got: np.ndarray, key: str = "image", identical: float = 0.94) -> None:
