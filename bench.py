@@ -389,6 +389,8 @@ def main() -> None:
             dist.broadcast_object_list(handles, src=0)
             if rank:
                 windows = [context.peer_open(handle) for handle in handles[0][rank]]
+            elif loopback:
+                windows = list(raw_received[0])                     # ONE rank: the copies go to this rank's own receive buffers (no IPC mapping of one's own allocation)
 
     class Gather:
         """One transport x one payload: send(index, q, view) queues piece q of step `index`; drain() bounds what is in flight"""
@@ -399,7 +401,7 @@ def main() -> None:
         def send(self, index: int, q: int, view) -> None:
             lo, hi = q*piece*self.payload, (q + 1)*piece*self.payload
             if self.transport == "sdma":
-                if rank:
+                if rank or loopback:
                     context.peer_copy(windows[index % 2] + lo, view.data_ptr(), hi - lo, lane=(index % 2)*parts + q)
                 return
             if loopback:
@@ -415,7 +417,7 @@ def main() -> None:
                 self.in_flight.extend(dist.batch_isend_irecv(ops))
 
         def fence(self, index: int, q: int) -> None:
-            if self.transport == "sdma" and rank:
+            if self.transport == "sdma" and (rank or loopback):
                 context.peer_fence((index % 2)*parts + q)          # the copy that last read this piece of this buffer (two steps ago) has left it
 
         def drain(self, keep_transfers: int = 0) -> None:
@@ -424,7 +426,7 @@ def main() -> None:
 
         def flush(self) -> None:
             self.drain()
-            if self.transport == "sdma" and rank:
+            if self.transport == "sdma" and (rank or loopback):
                 context.peer_flush()                              # this rank's frames have landed in rank 0's HBM
 
     def barrier(gather=None):
@@ -486,7 +488,7 @@ def main() -> None:
         barrier(gather)
         elapsed = time.perf_counter() - t0
         intact = None
-        if loopback and transport == "p2p":                       # what RCCL delivered is what was rendered (last step, both on this device)
+        if loopback:                                               # what RCCL / the copy engines delivered is what was rendered (last step, both on this device)
             last = args.warmup + args.steps - 1
             sent = (planar_buffers if planar else buffers)[last % 2]
             intact = bool(torch.equal(received[0][last % 2][:sent.numel()], sent))
@@ -527,7 +529,7 @@ def main() -> None:
         ones = torch.ones(1, dtype=torch.float64, device="cpu" if staged else "cuda")
         dist.all_reduce(ones)
         ranks_seen = int(round(float(ones.item())))
-        if windows:
+        if windows and rank:
             for window in windows:
                 context.peer_close(window)
         dist.barrier()
@@ -660,7 +662,7 @@ def main() -> None:
             result["per_rank"] = per_rank
             inbound = sum(r["sent_GB_per_s"] for r in per_rank)
             result["gather"] = {"backend": "sdma peer copies (hipIpc windows + SDMA engines named through HSA)" if sdma else dist_backend, "chosen": chosen["transport"],
-                                "pieces_per_step": parts, "inbound_GB_per_s_rank0": round(inbound, 2), "loopback": loopback and not sdma, "loopback_intact": loopback_intact,
+                                "pieces_per_step": parts, "inbound_GB_per_s_rank0": round(inbound, 2), "loopback": loopback, "loopback_intact": loopback_intact,
                                 "legs": [{"transport": leg["transport"], "payload": leg["payload"], "value": leg["value"], "unit": "frames/s",
                                           "ms_per_step": round(leg["elapsed_s"]/max(1, args.steps)*1e3, 3), "loopback_intact": leg["loopback_intact"], "per_rank": leg.get("per_rank")} for leg in legs],
                                 "note": "every leg is W untimed + K timed steps of the same frame ranges; `value` is the fastest rgb24 leg (the reference's byte stream resident in "

@@ -222,7 +222,12 @@ def test_bench_with_two_ranks_prints_one_line_for_the_whole_job():
     # a multi-rank line is diagnosable: every rank took part, each one's render rate and what it sent to rank 0
     assert record["rccl_ranks"] == 2 and [r["rank"] for r in record["per_rank"]] == [0, 1]
     assert all(r["render_frames_per_s"] > 0 for r in record["per_rank"]) and record["per_rank"][1]["sent_GB_per_s"] > 0
-    assert record["gather"]["backend"] == "gloo" and record["value_host"] == record["export_host"]["value"]
+    # no pin (the driver's launch): both transports x both payloads are measured as legs; the headline is the faster rgb24 leg
+    legs = {(leg["transport"], leg["payload"]): leg for leg in record["gather"]["legs"]}
+    assert set(legs) == {("p2p", "rgb24"), ("sdma", "rgb24"), ("p2p", "yuv420p"), ("sdma", "yuv420p")} and all(leg["value"] > 0 for leg in legs.values())
+    assert record["gather"]["chosen"] in ("p2p", "sdma") and record["value"] == max(legs[("p2p", "rgb24")]["value"], legs[("sdma", "rgb24")]["value"])
+    assert legs[("sdma", "rgb24")]["per_rank"][1]["peer_copies"]["copies"] > 0 and legs[("sdma", "rgb24")]["per_rank"][0]["peer_copies"]["copies"] == 0
+    assert record["value_host"] == record["export_host"]["value"] and record["export_host"]["yuv420p"]["value"] > 0
     # the second number: the same frames through a real sharded export, read-out to host memory included (host mode)
     assert record["export_host"]["frames"] == 16 and record["export_host"]["value"] > 0 and "SHADERFLOW_SHARD=host" in record["export_host"]["mode"]
     assert record["roofline"]["bound"] == "valu" and record["roofline"]["kernel"].startswith("k_") and record["roofline"]["hbm"]["achieved"] > 0

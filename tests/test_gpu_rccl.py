@@ -57,6 +57,11 @@ def test_bench_over_rccl_on_one_gpu(shard):
         assert set(legs) == {("p2p", "rgb24"), ("p2p", "yuv420p")} and legs[("p2p", "yuv420p")]["loopback_intact"] is True
     elif shard == "device-sdma":
         assert "sdma" in record["gather"]["backend"] and set(legs) == {("sdma", "rgb24"), ("sdma", "yuv420p")}
+        # one rank: the copies run from this rank's frame buffers into its own receive buffers — the copier thread, the named engines
+        # (or HIP's streams where HSA declines a same-device pair) and the fences, with the delivered bytes compared
+        route = legs[("sdma", "rgb24")]["per_rank"][0]["peer_copies"]
+        assert route["route"] in ("sdma-engines", "hip-streams") and route["copies"] > 0
+        assert legs[("sdma", "rgb24")]["loopback_intact"] is True and legs[("sdma", "yuv420p")]["loopback_intact"] is True
     else:
         # the driver's launch: no pin — both transports and both payloads are measured as legs, the headline is the faster rgb24 leg
         assert set(legs) == {("p2p", "rgb24"), ("sdma", "rgb24"), ("p2p", "yuv420p"), ("sdma", "yuv420p")}

@@ -73,4 +73,4 @@ def test_c3_export_in_yuv420p_is_not_bound_by_the_bus():
         scene.main(width=3840, height=2160, ssaa=2, fps=60.0, time=20.0, output="/dev/null", pixel_format=pixel_format)
         rates[pixel_format] = 1200/(time.perf_counter() - started)
     print(rates)
-    assert rates["yuv420p"] > 1.15*rates["rgb24"], rates
+    assert rates["yuv420p"] > 1.08*rates["rgb24"], rates          # (boxes differ; profiles/ hold the measured rates: 2 100-2 200 vs 2 440-2 790)
