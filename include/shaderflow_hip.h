@@ -243,6 +243,12 @@ int sfx_stft_plan(sfx_handle ctx, int fft_n, int window, int bins, int channels,
 /* FourierMagnitude (spectrogram.py:20-26): what `fft()` makes of the complex bins. Power (the default) = (x*conj(x)).real,
  * Amplitude = np.abs(x); both evaluated in float64 and cast to float32 like the reference (:169-171). */
 enum { SFX_MAGNITUDE_POWER = 0, SFX_MAGNITUDE_AMPLITUDE = 1 };
+/* `sample_rateio != 1` (spectrogram.py:144-167): the transform takes fft_size = int(2**fft_n * ratio) samples (even, <= 16384), sample
+ * n being (float)(in[tap_a[n]] + tap_w[n]*(in[tap_b[n]] - in[tap_a[n]])), evaluated in float64, over the last 2**fft_n ring samples:
+ * the read positions of samplerate.resample(x, ratio, 'linear') (spectrogram.py:167: libsamplerate's linear converter), which depend
+ * on the sizes and the ratio only. The CSR matrix has fft_size/2 + 1 columns; built-in windows are evaluated for fft_size. */
+int sfx_stft_plan_resampled(sfx_handle ctx, int fft_n, int fft_size, const int32_t* tap_a, const int32_t* tap_b, const double* tap_w,
+                            int window, int bins, int channels, const int32_t* indptr, const int32_t* indices, const float* data, sfx_handle* plan);
 int sfx_stft_plan_magnitude(sfx_handle plan, int magnitude);
 /* A window function of the caller's own (spectrogram.py:90-108 lets `window` be any callable N -> array): its float64 values
  * replace the plan's table; n = 2**fft_n. */

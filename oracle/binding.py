@@ -149,6 +149,16 @@ def fft_power(pcm: np.ndarray, tell: int, fft_n: int = 12, window_kind: int = 0,
     return out
 
 
+def resample_linear(data: np.ndarray, ratio: float, n_out: int) -> np.ndarray:
+    """samplerate.resample(x, ratio, 'linear') of one channel (spectrogram.py:167; parity unpinned: sfo_audio.c says why)"""
+    data = np.ascontiguousarray(data, np.float32)
+    out = np.zeros(n_out, np.float32)
+    lib().sfo_resample_linear.restype = C.c_int
+    lib().sfo_resample_linear.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_double, C.POINTER(C.c_float), C.c_int]
+    generated = lib().sfo_resample_linear(_p(data, C.c_float), len(data), float(ratio), _p(out, C.c_float), n_out)
+    return out[:generated]
+
+
 def filterbank(scale: int, interp: int, fmin: float, fmax: float, bins: int, fft_n: int, samplerate: float):
     fft_bins = (1 << fft_n)//2 + 1
     cap = max(64, bins*min(fft_bins, 4096))

@@ -63,6 +63,11 @@ void sfo_fft_power(const float* pcm, int64_t total, int channels, int64_t tell,
 void sfo_fft_amplitude(const float* pcm, int64_t total, int channels, int64_t tell,
                        int fft_n, int window_kind, float* out);
 
+/* spectrogram.py:167 samplerate.resample(x, ratio, 'linear') — libsamplerate's linear converter under src_simple; PARITY UNPINNED (the
+ * package is neither vendored nor importable here: the published algorithm of src_linear.c restated, see sfo_audio.c). Returns the
+ * number of frames generated (<= n_out). */
+int sfo_resample_linear(const float* in, int n_in, double ratio, float* out, int n_out);
+
 /* spectrogram.py:186-224 (+ scales :73-87, kernels :44-70). Returns nnz (or -needed if cap is too
  * small). CSR of the (bins, fft_bins) float32 matrix. */
 int sfo_filterbank(int scale, int interp, double fmin, double fmax, int bins, int fft_n,

@@ -138,6 +138,38 @@ void sfo_fft_amplitude(const float* pcm, int64_t total, int channels, int64_t te
     fft_magnitude(pcm, total, channels, tell, fft_n, window_kind, 1, out);
 }
 
+/* spectrogram.py:158-167 `samplerate.resample(x, ratio, 'linear')`: libsamplerate's linear converter as src_simple drives it (a
+ * fresh state: last_value = in[0], last_position = 0, a constant ratio). The `samplerate` package (python-samplerate 0.x, a binding of
+ * libsamplerate's src_linear.c) is NOT vendored in /root/reference and not importable in this environment: PARITY UNPINNED for this
+ * option — what follows restates the published algorithm of src_linear.c (linear_vari_process: the "samples before the first sample
+ * of the input array" loop, then the main loop; input_index += 1/ratio in float64; fmod_one / lrint carry the integer part into in_used),
+ * sequentially, sample by sample, as the library does. The product derives read positions with its own copy of the position loop and
+ * interpolates on the device; tests compare the two on random data and both with a vector computed by hand. Returns frames generated. */
+static double fmod_one(double x) { double res = x - (double)lrint(x); return res < 0.0 ? res + 1.0 : res; }
+int sfo_resample_linear(const float* in, int n_in, double ratio, float* out, int n_out) {
+    if (n_in < 1 || !(ratio > 0.0)) return 0;
+    double input_index = 0.0;
+    const double last_value = in[0];
+    long in_used = 0;
+    int gen = 0;
+    while (input_index < 1.0 && gen < n_out) {
+        if ((double)in_used + (1.0 + input_index) >= (double)n_in) break;
+        out[gen++] = (float)(last_value + input_index*((double)in[0] - last_value));
+        input_index += 1.0/ratio;
+    }
+    double rem = fmod_one(input_index);
+    in_used += lrint(input_index - rem);
+    input_index = rem;
+    while (gen < n_out && (double)in_used + input_index < (double)n_in) {
+        out[gen++] = (float)((double)in[in_used - 1] + input_index*((double)in[in_used] - (double)in[in_used - 1]));
+        input_index += 1.0/ratio;
+        rem = fmod_one(input_index);
+        in_used += lrint(input_index - rem);
+        input_index = rem;
+    }
+    return gen;
+}
+
 /* ---------------------------------------------------------------------------------------------- */
 /* Filterbank */
 

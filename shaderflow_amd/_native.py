@@ -135,6 +135,8 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_audio_upload": (C.c_int, [Handle, P(C.c_float), C.c_int64, C.c_int, C.c_int, P(Handle)]),
     "sfx_audio_destroy": (C.c_int, [Handle]),
     "sfx_stft_plan": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_int32), P(C.c_int32), P(C.c_float), P(Handle)]),
+    "sfx_stft_plan_resampled": (C.c_int, [Handle, C.c_int, C.c_int, P(C.c_int32), P(C.c_int32), P(C.c_double), C.c_int, C.c_int, C.c_int,
+                                          P(C.c_int32), P(C.c_int32), P(C.c_float), P(Handle)]),
     "sfx_stft_plan_magnitude": (C.c_int, [Handle, C.c_int]),
     "sfx_stft_plan_window": (C.c_int, [Handle, P(C.c_double), C.c_int]),
     "sfx_stft_plan_destroy": (C.c_int, [Handle]),

@@ -7,7 +7,10 @@ stay numpy/scipy code — they run once per configuration and define WHAT is com
 STFT (`window*frame → radix-2 FFT in float64 → |X|² → float32`, :155-171) and the filterbank product
 (:175-176) are HIP kernels reached through an `sfx_stft_plan`. Options the kernels implement: the three windows,
 `FourierMagnitude.Power` and `.Amplitude`, any scale/interpolation (they only shape the CSR matrix). `sample_rateio != 1`
-(third-party `samplerate` resampler, :158-167: un-vendored, not importable here) raises NotImplementedError.
+(:158-167 resamples with the third-party `samplerate` package's 'linear' converter — un-vendored, not importable here): the converter's
+read positions depend on the sizes and the ratio alone, so its float64 position loop runs here once per plan (`linear_resample_taps`)
+and the device interpolates; PARITY UNPINNED for that option (no reference output can be generated without the package: the
+restatement of libsamplerate's src_linear.c is checked against the oracle's own sequential restatement and a hand-computed vector).
 """
 from __future__ import annotations
 
@@ -83,6 +86,36 @@ class SpectrogramWindow:
         return np.ones(size)
 
 
+def linear_resample_taps(n_in: int, ratio: float, n_out: int) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Where `samplerate.resample(x, ratio, 'linear')` (spectrogram.py:167) reads: output n = float32(x[a[n]] + w[n]*(x[b[n]] - x[a[n]])),
+    evaluated in float64. libsamplerate's linear converter (src_linear.c, through src_simple: a fresh state whose `last_value` is x[0])
+    emits x[0] while its float64 `input_index` is below one, then interpolates between x[in_used - 1] and x[in_used] — a one-sample
+    delay — advancing input_index += 1/ratio and carrying the integer part into `in_used` with fmod_one / lrint after every output.
+    Nothing of it depends on the samples, so the loop runs here. Returns as many taps as the converter generates (<= n_out)."""
+    def fmod_one(x: float) -> float:
+        res = x - float(np.rint(x))                                  # lrint: round half to even
+        return res + 1.0 if res < 0.0 else res
+    a, b, w = np.zeros(n_out, np.int32), np.zeros(n_out, np.int32), np.zeros(n_out, np.float64)
+    out, input_index, in_used, step = 0, 0.0, 0, 1.0/float(ratio)
+    while input_index < 1.0 and out < n_out:
+        if in_used + (1.0 + input_index) >= n_in:
+            break
+        a[out], b[out], w[out] = 0, 0, input_index                   # last_value + input_index*(x[0] - last_value) with last_value = x[0]
+        out += 1
+        input_index += step
+    rem = fmod_one(input_index)
+    in_used += int(np.rint(input_index - rem))
+    input_index = rem
+    while out < n_out and in_used + input_index < n_in:
+        a[out], b[out], w[out] = in_used - 1, in_used, input_index
+        out += 1
+        input_index += step
+        rem = fmod_one(input_index)
+        in_used += int(np.rint(input_index - rem))
+        input_index = rem
+    return a[:out], b[:out], w[:out]
+
+
 _WINDOW_CODES = {SpectrogramWindow.hanning: 0, SpectrogramWindow.hann_poisson_window: 1, SpectrogramWindow.none: 2}
 
 
@@ -155,8 +188,13 @@ class BrokenSpectrogram:
 
     def plan(self) -> N.Handle:
         """The sfx_stft_plan of the current configuration (rebuilt when it changes)"""
+        taps = None
         if self.sample_rateio != 1:
-            raise NotImplementedError("sample_rateio != 1 needs the third-party 'samplerate' resampler, which has no device path")
+            # the converter must deliver exactly fft_size samples, or `window(fft_size) * data` does not broadcast (spectrogram.py:169-170)
+            taps = linear_resample_taps(int(2**self.fft_n), self.sample_rateio, self.fft_size)
+            if self.sample_rateio < 1 or len(taps[0]) != self.fft_size:
+                raise ValueError(f"operands could not be broadcast together with shapes ({self.fft_size},) ({self.audio.channels},{len(taps[0])}) "
+                                 f"(sample_rateio = {self.sample_rateio})")
         if self.magnitude not in (FourierMagnitude.Power, FourierMagnitude.Amplitude):
             raise NotImplementedError("custom magnitudes have no device kernel (FourierMagnitude.Power, .Amplitude)")
         custom = None
@@ -177,9 +215,16 @@ class BrokenSpectrogram:
             indices = np.ascontiguousarray(matrix.indices, np.int32)
             data = np.ascontiguousarray(matrix.data, np.float32)
             handle = N.Handle()
-            N.check(N.lib().sfx_stft_plan(self._context().handle, self.fft_n, _WINDOW_CODES.get(self.window, _WINDOW_CODES[SpectrogramWindow.none]), self.spectrogram_bins,
-                                          self.audio.channels, N.as_ptr(indptr, C.c_int32), N.as_ptr(indices, C.c_int32),
-                                          N.as_ptr(data, C.c_float), C.byref(handle)))
+            code = _WINDOW_CODES.get(self.window, _WINDOW_CODES[SpectrogramWindow.none])
+            if taps is None:
+                N.check(N.lib().sfx_stft_plan(self._context().handle, self.fft_n, code, self.spectrogram_bins,
+                                              self.audio.channels, N.as_ptr(indptr, C.c_int32), N.as_ptr(indices, C.c_int32),
+                                              N.as_ptr(data, C.c_float), C.byref(handle)))
+            else:
+                tap_a, tap_b, tap_w = (np.ascontiguousarray(t) for t in taps)
+                N.check(N.lib().sfx_stft_plan_resampled(self._context().handle, self.fft_n, self.fft_size, N.as_ptr(tap_a, C.c_int32), N.as_ptr(tap_b, C.c_int32),
+                                                        N.as_ptr(tap_w, C.c_double), code, self.spectrogram_bins, self.audio.channels,
+                                                        N.as_ptr(indptr, C.c_int32), N.as_ptr(indices, C.c_int32), N.as_ptr(data, C.c_float), C.byref(handle)))
             N.check(N.lib().sfx_stft_plan_magnitude(handle, int(amplitude)))
             if custom is not None:
                 N.check(N.lib().sfx_stft_plan_window(handle, N.as_ptr(custom, C.c_double), int(custom.size)))

@@ -25,17 +25,30 @@ __device__ __forceinline__ float stream_at(const float* pcm, long total, int c, 
 // in-LDS radix-2 decimation-in-time FFT in float64 (numpy computes window*data and the rfft in float64 and only
 // then casts, spectrogram.py:169-171), and split into the N/2+1 real-input bins.
 // twiddle[k] = exp(-2*pi*i*k/N), k < N/2, and window[n] are float64 tables built by the host.
+//
+// `sample_rateio != 1` (spectrogram.py:144-167): the transform's N = int(2**fft_n * ratio) inputs are the last `in_size` = 2**fft_n
+// samples of the ring RESAMPLED by libsamplerate's "linear" converter. That converter is a one-sample-delayed linear interpolation
+// whose read positions depend on the sizes and the ratio alone (src_linear.c accumulates input_index += 1/ratio in float64), so the
+// host runs its position loop once per plan and the device applies the taps: out[n] = (float)(in[a] + w*(in[b] - in[a])) in float64.
+struct ResampleTap { int a, b; double w; };
+__device__ __forceinline__ double stft_input(const float* pcm, long total, int c, long first, int n, const ResampleTap* __restrict__ taps) {
+    if (!taps) return (double)stream_at(pcm, total, c, first + n);
+    const ResampleTap t = taps[n];
+    const double a = (double)stream_at(pcm, total, c, first + t.a), b = (double)stream_at(pcm, total, c, first + t.b);
+    return (double)(float)(a + t.w*(b - a));                          // the converter writes float32 samples
+}
+
 __global__ __launch_bounds__(256) void k_stft_power(const float* __restrict__ pcm, long total, const long* __restrict__ tell,
-                                                    int fft_n, const double* __restrict__ window,
+                                                    int fft_n, int in_size, const ResampleTap* __restrict__ taps, const double* __restrict__ window,
                                                     const double2* __restrict__ twiddle, float* __restrict__ power, int amplitude) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2* z = (double2*)smem;
     const int N = 1 << fft_n, M = N >> 1, logM = fft_n - 1;
     const int frame = blockIdx.x, c = blockIdx.y, channels = gridDim.y;
-    const long first = tell[frame] - N - 1;                         // audio/module.py:137-138
+    const long first = tell[frame] - in_size - 1;                   // audio/module.py:137-138
     for (int n = threadIdx.x; n < M; n += blockDim.x) {
-        const double re = window[2*n]*(double)stream_at(pcm, total, c, first + 2*n);
-        const double im = window[2*n + 1]*(double)stream_at(pcm, total, c, first + 2*n + 1);
+        const double re = window[2*n]*stft_input(pcm, total, c, first, 2*n, taps);
+        const double im = window[2*n + 1]*stft_input(pcm, total, c, first, 2*n + 1, taps);
         z[__brev((unsigned)n) >> (32 - logM)] = make_double2(re, im);
     }
     __syncthreads();
@@ -62,6 +75,35 @@ __global__ __launch_bounds__(256) void k_stft_power(const float* __restrict__ pc
         const double xr = er + (orr*w.x - oi*w.y), xi = ei + (orr*w.y + oi*w.x);
         // FourierMagnitude.Power = (x*conj(x)).real, spectrogram.py:25-26; .Amplitude = np.abs(x) = hypot in float64, :22-23
         out[k] = amplitude ? (float)::hypot(xr, xi) : (float)(xr*xr + xi*xi);
+    }
+}
+
+// The same for a transform size that is NOT a power of two (sample_rateio = 1.5: 6 144 inputs): the plain DFT sum in float64, which is
+// what np.fft.rfft computes to rounding. The windowed inputs of the (frame, channel) in LDS; a thread owns bins k, k + 256, … and
+// walks the unit circle by table: twiddle[j] = exp(-2*pi*i*j/N), j < N, read at j = k*n mod N, kept by adding k and wrapping — no
+// angle is ever multiplied out, so the sum's error is that of N additions (~1e-13 relative), far inside the path's 1e-5. O(N^2) per
+// block; 600 blocks of 19 M multiply-adds per 300-frame batch at N = 6 144: a few milliseconds, on an option nothing in the
+// reference's tree uses.
+__global__ __launch_bounds__(256) void k_dft_power(const float* __restrict__ pcm, long total, const long* __restrict__ tell, int N, int in_size,
+                                                   const ResampleTap* __restrict__ taps, const double* __restrict__ window,
+                                                   const double2* __restrict__ twiddle /* [N] */, float* __restrict__ power, int amplitude) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* x = (double*)smem;
+    const int frame = blockIdx.x, c = blockIdx.y, channels = gridDim.y;
+    const long first = tell[frame] - in_size - 1;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) x[n] = window[n]*stft_input(pcm, total, c, first, n, taps);
+    __syncthreads();
+    const int bins = N/2 + 1;
+    float* out = power + ((long)frame*channels + c)*bins;
+    for (int k = threadIdx.x; k < bins; k += blockDim.x) {
+        double re = 0.0, im = 0.0;
+        int j = 0;
+        for (int n = 0; n < N; n++) {
+            const double2 w = twiddle[j];
+            re = fma(x[n], w.x, re); im = fma(x[n], w.y, im);
+            j += k; if (j >= N) j -= N;
+        }
+        out[k] = amplitude ? (float)::hypot(re, im) : (float)(re*re + im*im);
     }
 }
 

@@ -1571,6 +1571,16 @@ static int launch_fused(int fragment, const RenderArgs& a0, int ssaa, int frames
     hipMemcpyAsync(host.data(), d_timers, host.size()*sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
     hipStreamSynchronize(s);
     for (size_t k = 0; k < host.size(); k++) t[k % 8] += host[k];
+    if (g_last_kernel.rfind("k_visualizer_strip<", 0) == 0) {
+        // the strip kernel's phases (visualizer_fast.hpp VisualizerStrip::run): wave cycles incl. stalls; column 7 counts diagonal folds
+        const double total = (double)(t[0] + t[1] + t[2] + t[3] + t[4] + t[5] + t[6]);
+        static const char* names[] = {"prologue+stage+barrier", "row-lines", "column-lines", "diagonals", "post", "exchange+resolve", "store"};
+        const double waves = (double)frames*(double)((a.wr + 255)/256)*(double)((a.hr + 17)/18)*8.0;
+        fprintf(stderr, "[section timers] %s, %d frames:", g_last_kernel.c_str(), frames);
+        for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.1f%%", names[k], 100.0*(double)t[k]/total);
+        fprintf(stderr, " | %.0f wave-cycles per wave, %.2f diagonal folds per wave (of 180 advances)\n", total/waves, (double)t[7]/waves);
+        return rc;
+    }
     const double total = (double)(t[0] + t[1] + t[2] + t[3]);
     static const char* names[] = {"varyings+pre", "setup", "run", "resolve+store", "  setup.reduce", "  setup.stage", "  setup.barrier", "  run.blur"};
     fprintf(stderr, "[section timers] %d frames:", frames);
@@ -2202,6 +2212,8 @@ struct FilterbankScratch { float* d_partial = nullptr; size_t floats = 0; };
 struct Plan : Object {
     Context* ctx;
     int fft_n, window, bins, channels, fft_bins, nnz;
+    int fft_size = 0;                // inputs of the transform: 2**fft_n, or int(2**fft_n * sample_rateio) (spectrogram.py:144-146)
+    ResampleTap* d_taps = nullptr;   // sample_rateio != 1: where libsamplerate's linear converter reads input sample n of the transform
     int amplitude = 0;               // FourierMagnitude: 0 Power, 1 Amplitude (spectrogram.py:20-26)
     double* d_window = nullptr; double2* d_twiddle = nullptr;
     int *d_indptr = nullptr, *d_indices = nullptr; float* d_data = nullptr;
@@ -2224,27 +2236,48 @@ static int plan_reserve(Plan* p, int frames) {
 }
 
 // A window of the caller's own (spectrogram.py:155-171 multiplies by whatever `self.window(N)` returns, in float64): replaces the
-// plan's table; `n` must be the plan's 2**fft_n.
+// plan's table; `n` must be the plan's transform size (2**fft_n, or int(2**fft_n * sample_rateio) of a resampled plan).
 extern "C" int sfx_stft_plan_window(sfx_handle h, const double* window, int n) {
     Plan* p = get<Plan>(h, MAGIC_PLAN);
-    if (!p || !window || n != (1 << p->fft_n)) return fail(SFX_E_INVALID, "stft plan window: %d values for a plan of %d", n, p ? (1 << p->fft_n) : 0);
+    if (!p || !window || n != p->fft_size) return fail(SFX_E_INVALID, "stft plan window: %d values for a plan of %d", n, p ? p->fft_size : 0);
     USE_DEVICE(p->ctx);
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     HIP_TRY(hipMemcpy(p->d_window, window, sizeof(double)*n, hipMemcpyHostToDevice));
     return SFX_OK;
 }
 
+static int make_stft_plan(sfx_handle h, int fft_n, int fft_size, const int32_t* tap_a, const int32_t* tap_b, const double* tap_w, int window, int bins, int channels,
+                          const int32_t* indptr, const int32_t* indices, const float* data, sfx_handle* out);
 extern "C" int sfx_stft_plan(sfx_handle h, int fft_n, int window, int bins, int channels,
                              const int32_t* indptr, const int32_t* indices, const float* data, sfx_handle* out) {
+    return make_stft_plan(h, fft_n, (fft_n >= 0 && fft_n < 30) ? (1 << fft_n) : 0, nullptr, nullptr, nullptr, window, bins, channels, indptr, indices, data, out);
+}
+// `sample_rateio != 1` (spectrogram.py:144-167): the transform takes `fft_size` = int(2**fft_n * ratio) samples, sample n of which is
+// (float)(in[tap_a[n]] + tap_w[n]*(in[tap_b[n]] - in[tap_a[n]])) over the last 2**fft_n samples of the ring — the read positions of
+// libsamplerate's "linear" converter (samplerate.resample(x, ratio, 'linear'), spectrogram.py:167), which the host derives once per plan
+// by running the converter's own float64 position loop (shaderflow_amd/audio/spectrogram.py linear_resample_taps). The built-in windows
+// are evaluated for `fft_size`; the filterbank's columns are its fft_size/2 + 1 bins. Power-of-two sizes keep the radix-2 kernel, any
+// other size (<= 16 384) takes the float64 DFT sum.
+extern "C" int sfx_stft_plan_resampled(sfx_handle h, int fft_n, int fft_size, const int32_t* tap_a, const int32_t* tap_b, const double* tap_w,
+                                       int window, int bins, int channels, const int32_t* indptr, const int32_t* indices, const float* data, sfx_handle* out) {
+    if (!tap_a || !tap_b || !tap_w) return fail(SFX_E_INVALID, "resampled stft plan: null tap tables");
+    return make_stft_plan(h, fft_n, fft_size, tap_a, tap_b, tap_w, window, bins, channels, indptr, indices, data, out);
+}
+static int make_stft_plan(sfx_handle h, int fft_n, int fft_size, const int32_t* tap_a, const int32_t* tap_b, const double* tap_w, int window, int bins, int channels,
+                          const int32_t* indptr, const int32_t* indices, const float* data, sfx_handle* out) {
     CTX_OR_FAIL(c, h);
     if (!out || fft_n < 4 || fft_n > 14 || bins < 1 || channels < 1 || !indptr) return fail(SFX_E_INVALID, "stft plan fft_n=%d bins=%d channels=%d", fft_n, bins, channels);
     if (window < 0 || window > SFX_WINDOW_NONE) return fail(SFX_E_INVALID, "window %d", window);
+    if (fft_size < 16 || fft_size > 16384 || (fft_size & 1)) return fail(SFX_E_UNSUPPORTED, "stft transform of %d samples: even sizes from 16 to 16384", fft_size);
     USE_DEVICE(c);
-    const int N = 1 << fft_n, fft_bins = N/2 + 1, nnz = indptr[bins];
+    const int in_size = 1 << fft_n;
+    const int N = fft_size, fft_bins = N/2 + 1, nnz = indptr[bins];
+    const bool radix2 = (N & (N - 1)) == 0;
     for (int r = 0; r < bins; r++) if (indptr[r] > indptr[r + 1]) return fail(SFX_E_INVALID, "indptr not monotone");
     for (int j = 0; j < nnz; j++) if (indices[j] < 0 || indices[j] >= fft_bins) return fail(SFX_E_INVALID, "column %d outside %d fft bins", indices[j], fft_bins);
+    if (tap_a) for (int n = 0; n < N; n++) if (tap_a[n] < 0 || tap_a[n] >= in_size || tap_b[n] < 0 || tap_b[n] >= in_size) return fail(SFX_E_INVALID, "resample tap %d reads outside the %d ring samples", n, in_size);
     Plan* p = new Plan();
-    p->magic = MAGIC_PLAN; p->ctx = c; p->fft_n = fft_n; p->window = window; p->bins = bins; p->channels = channels;
+    p->magic = MAGIC_PLAN; p->ctx = c; p->fft_n = fft_n; p->fft_size = N; p->window = window; p->bins = bins; p->channels = channels;
     p->fft_bins = fft_bins; p->nnz = nnz;
     // windows: spectrogram.py:92-108 (np.hanning is the symmetric Hann)
     std::vector<double> win(N);
@@ -2254,12 +2287,20 @@ extern "C" int sfx_stft_plan(sfx_handle h, int fft_n, int window, int bins, int 
         else if (window == SFX_WINDOW_HANN_POISSON) win[i] = 0.5*(1.0 - ::cos(2.0*pi*(double)i/(double)N))*::exp(-2.0*::fabs((double)(N - 2*i))/(double)N);
         else win[i] = 1.0;
     }
-    std::vector<double2> tw(N/2);
-    for (int k = 0; k < N/2; k++) { const double ang = -2.0*pi*(double)k/(double)N; tw[k] = make_double2(::cos(ang), ::sin(ang)); }
+    // radix-2: exp(-2 pi i k/N) for k < N/2; the DFT sum walks the whole circle
+    const int ntw = radix2 ? N/2 : N;
+    std::vector<double2> tw(ntw);
+    for (int k = 0; k < ntw; k++) { const double ang = -2.0*pi*(double)k/(double)N; tw[k] = make_double2(::cos(ang), ::sin(ang)); }
     HIP_TRY(hipMalloc(&p->d_window, sizeof(double)*N));
-    HIP_TRY(hipMalloc(&p->d_twiddle, sizeof(double2)*(N/2)));
+    HIP_TRY(hipMalloc(&p->d_twiddle, sizeof(double2)*ntw));
     HIP_TRY(hipMemcpy(p->d_window, win.data(), sizeof(double)*N, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(p->d_twiddle, tw.data(), sizeof(double2)*(N/2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->d_twiddle, tw.data(), sizeof(double2)*ntw, hipMemcpyHostToDevice));
+    if (tap_a) {
+        std::vector<ResampleTap> taps(N);
+        for (int n = 0; n < N; n++) taps[n] = ResampleTap{tap_a[n], tap_b[n], tap_w[n]};
+        HIP_TRY(hipMalloc(&p->d_taps, sizeof(ResampleTap)*N));
+        HIP_TRY(hipMemcpy(p->d_taps, taps.data(), sizeof(ResampleTap)*N, hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMalloc(&p->d_indptr, sizeof(int)*(bins + 1)));
     HIP_TRY(hipMalloc(&p->d_indices, sizeof(int)*(nnz + 1)));
     HIP_TRY(hipMalloc(&p->d_data, sizeof(float)*(nnz + 1)));
@@ -2287,8 +2328,10 @@ extern "C" int sfx_stft_plan(sfx_handle h, int fft_n, int window, int bins, int 
     HIP_TRY(hipMalloc(&p->d_band, sizeof(int2)*band.size()));
     HIP_TRY(hipMemcpy(p->d_dense, dense.data(), sizeof(float)*dense.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p->d_band, band.data(), sizeof(int2)*band.size(), hipMemcpyHostToDevice));
-    if ((size_t)(N/2)*sizeof(double2) > 64*1024)
+    if (radix2 && (size_t)(N/2)*sizeof(double2) > 64*1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_stft_power, hipFuncAttributeMaxDynamicSharedMemorySize, (N/2)*(int)sizeof(double2)));
+    if (!radix2 && (size_t)N*sizeof(double) > 64*1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_dft_power, hipFuncAttributeMaxDynamicSharedMemorySize, N*(int)sizeof(double)));
     *out = handle_of(p);
     return SFX_OK;
 }
@@ -2306,7 +2349,7 @@ extern "C" int sfx_stft_plan_destroy(sfx_handle h) {
     if (!p) return fail(SFX_E_INVALID, "invalid plan handle");
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
-    hipFree(p->d_window); hipFree(p->d_twiddle); hipFree(p->d_indptr); hipFree(p->d_indices); hipFree(p->d_data);
+    hipFree(p->d_taps); hipFree(p->d_window); hipFree(p->d_twiddle); hipFree(p->d_indptr); hipFree(p->d_indices); hipFree(p->d_data);
     hipFree(p->d_dense); hipFree(p->d_band); hipFree(p->d_tell); hipFree(p->d_power); hipFree(p->d_out); hipFree(p->scratch.d_partial);
     p->magic = 0;
     delete p;
@@ -2320,17 +2363,28 @@ static int check_audio(const Plan* p, const Audio* a) {
     return SFX_OK;
 }
 
-// K3: one wave for up to 256 values plus one for the float64 systems (no barriers), 1024 threads for up to 2048
+// K3: one wave for up to 256 values plus one for the float64 systems (no barriers), 1024 threads for up to 2048 — and, since
+// `spectrogram_bins` is anything the user says (spectrogram.py:184; 1 025 stereo bins already exceed 2 048 values), 4 / 8 / 16 values
+// per thread for up to 16 384: the early-out's maximum is still ONE block-wide reduction per frame (the recurrence couples the values
+// through it, so the scan stays in one block; at 16 waves a thread may hold 128 registers)
+constexpr int DYNAMICS_SCAN_LIMIT = 16384;
 template <class... Args> static void launch_dynamics_scan(hipStream_t s, int nframes, int n, Args... args) {
     if (n <= 256) hipLaunchKernelGGL((k_dynamics_scan<64, 4, true>), dim3(1), dim3(128), 0, s, nframes, n, args...);
-    else hipLaunchKernelGGL((k_dynamics_scan<1024, 2>), dim3(1), dim3(1024), 0, s, nframes, n, args...);
+    else if (n <= 2048) hipLaunchKernelGGL((k_dynamics_scan<1024, 2>), dim3(1), dim3(1024), 0, s, nframes, n, args...);
+    else if (n <= 4096) hipLaunchKernelGGL((k_dynamics_scan<1024, 4>), dim3(1), dim3(1024), 0, s, nframes, n, args...);
+    else if (n <= 8192) hipLaunchKernelGGL((k_dynamics_scan<1024, 8>), dim3(1), dim3(1024), 0, s, nframes, n, args...);
+    else hipLaunchKernelGGL((k_dynamics_scan<1024, 16>), dim3(1), dim3(1024), 0, s, nframes, n, args...);
 }
 
 // device-side launches shared by the per-frame entry points and the tape
 static void launch_stft(const Plan* p, const Audio* a, const long* d_tell, int frames, float* d_power, hipStream_t s) {
-    const int N = 1 << p->fft_n;
-    hipLaunchKernelGGL(k_stft_power, dim3(frames, p->channels), dim3(256), (N/2)*sizeof(double2), s,
-                       a->pcm, a->samples, d_tell, p->fft_n, p->d_window, p->d_twiddle, d_power, p->amplitude);
+    const int N = p->fft_size, in_size = 1 << p->fft_n;
+    if ((N & (N - 1)) == 0)
+        hipLaunchKernelGGL(k_stft_power, dim3(frames, p->channels), dim3(256), (N/2)*sizeof(double2), s,
+                           a->pcm, a->samples, d_tell, __builtin_ctz((unsigned)N), in_size, p->d_taps, p->d_window, p->d_twiddle, d_power, p->amplitude);
+    else
+        hipLaunchKernelGGL(k_dft_power, dim3(frames, p->channels), dim3(256), (size_t)N*sizeof(double), s,
+                           a->pcm, a->samples, d_tell, N, in_size, p->d_taps, p->d_window, p->d_twiddle, d_power, p->amplitude);
 }
 static void launch_filterbank(Plan* p, FilterbankScratch& scratch, int frames, int use_mfma, const float* d_power, float* d_out, hipStream_t s) {
     const int ncols = frames*p->channels;
@@ -2425,7 +2479,7 @@ extern "C" int sfx_dynamics_scan(sfx_handle h, int nframes, int n, const float* 
                                  float precision, float* state, float* values) {
     CTX_OR_FAIL(c, h);
     if (nframes < 1 || n < 1 || !targets || !coeff || !state || !values) return fail(SFX_E_INVALID, "dynamics scan: null array or nothing to do");
-    if (n > 2048) return fail(SFX_E_UNSUPPORTED, "dynamics scan handles up to 2048 values per system, got %d", n);
+    if (n > DYNAMICS_SCAN_LIMIT) return fail(SFX_E_UNSUPPORTED, "dynamics scan handles up to %d values per system, got %d", DYNAMICS_SCAN_LIMIT, n);
     USE_DEVICE(c);
     hipStream_t s = c->stream;
     float *d_targets = nullptr, *d_state = nullptr, *d_values = nullptr; DynCoeffF32* d_coeff = nullptr;
@@ -2585,7 +2639,7 @@ extern "C" int sfx_tape_create(sfx_handle hp, sfx_handle ha, const sfx_tape_desc
     int rc = check_audio(p, a);
     if (rc) return rc;
     if (!desc || !out || max_frames < 1) return fail(SFX_E_INVALID, "null desc/output or no frames");
-    if (p->bins*p->channels > 2048) return fail(SFX_E_UNSUPPORTED, "dynamics scan handles up to 2048 spectrogram values, got %d", p->bins*p->channels);
+    if (p->bins*p->channels > DYNAMICS_SCAN_LIMIT) return fail(SFX_E_UNSUPPORTED, "dynamics scan handles up to %d spectrogram values, got %d", DYNAMICS_SCAN_LIMIT, p->bins*p->channels);
     USE_DEVICE(p->ctx);
     Tape* t = new Tape();
     t->magic = MAGIC_TAPE; t->plan = p; t->audio = a; t->ctx = p->ctx; t->desc = *desc; t->max_frames = max_frames;

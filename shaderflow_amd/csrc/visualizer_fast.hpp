@@ -479,6 +479,13 @@ struct VisualizerFast {
 // the four lanes of a quad: wave w holds the WALK consecutive sample rows of row group w % ROW_GROUPS for the 64 sample columns of
 // column group w / ROW_GROUPS; the RGBA8 texels meet in LDS (over the cells, which are dead by then) and one thread per output pixel resolves all
 // three channels — cheaper than the DPP exchange it replaces.
+#ifdef SF_SECTION_TIMERS
+#define SF_COUNT_FOLD() (sf_folds++)
+#define SF_FOLDS_OUT(a) do { if ((threadIdx.x & 63) == 0 && (a).timers) atomicAdd(&(a).timers[(((blockIdx.x + blockIdx.z*gridDim.x)*8 + (threadIdx.x >> 6)) % SF_TIMER_ROWS)*8 + 7], (unsigned long long)sf_folds); } while (0)
+#else
+#define SF_COUNT_FOLD() do {} while (0)
+#define SF_FOLDS_OUT(a) do {} while (0)
+#endif
 template <int TILE_PITCH, int TILE_ROWS, int S, int WALK, int COLUMN_GROUPS = 8/S, bool HALF_CELLS = (S == 1)>
 struct VisualizerStrip {
     // S x S supersamples per pixel (2 or 4), or S == 1: no resolve, the RGBA8 samples go to iScreen (the two-pass configuration).
@@ -536,6 +543,10 @@ struct VisualizerStrip {
 
     __device__ static void run(const RenderArgs& a, const VisTables& t) {
         __shared__ __attribute__((aligned(16))) Shared sh;
+        SF_TICK_INIT();                                               // profiling builds (-DSF_SECTION_TIMERS): wave cycles per phase, see capi.hip
+#ifdef SF_SECTION_TIMERS
+        int sf_folds = 0;                                             // diagonal cell folds of this wave (wave-uniform branches)
+#endif
         const int frame = blockIdx.z;
         const int tile_index = xcd_band_order(blockIdx.x, gridDim.x);
         // (the division runs on the vector unit: say that its results are the same in every lane)
@@ -569,6 +580,7 @@ struct VisualizerStrip {
             sh.ysteps[row][w] = t.ysteps[((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*10 + w];
         }
         __syncthreads();
+        SF_TICK(a, 0);                                                // prologue: tables, staging the cell tile, the first barrier
 
         const float4 c0 = ce[0];
         const float xr = c0.x, fx = c0.y;
@@ -609,6 +621,7 @@ struct VisualizerStrip {
                     acc[r][0] = fmaf(r0.y, Q[0], P[0]); acc[r][1] = fmaf(r0.y, Q[1], P[1]); acc[r][2] = fmaf(r0.y, Q[2], P[2]);
                 }
             }
+            SF_TICK(a, 1);                                            // row-lines
             // ---- the column-lines: the strip's column of cells fetched and folded with fx once, every sample takes the cells its slots cover ----
             {
                 int start[WALK];
@@ -653,6 +666,7 @@ struct VisualizerStrip {
                     }
                 }
             }
+            SF_TICK(a, 2);                                            // column-lines
             // ---- the four diagonal directions: per walk step the x halves once for the strip; the y halves (fraction and row of
             //      cells of y +- k*s, k_visualizer_axis<1>'s ysteps) are wave-uniform: scalar loads, scalar branches ----
             {
@@ -687,6 +701,7 @@ struct VisualizerStrip {
                         const int cell_row = VIS_STRIP_YSTEPS_LDS ? __builtin_amdgcn_readfirstlane(__float_as_int(side ? y[r].w : y[r].z)) : __float_as_int(side ? y[r].w : y[r].z);
                         if (cell_row != previous[side]) {
                             previous[side] = cell_row;
+                            SF_COUNT_FOLD();
                             Quad p0, p1, p2, m0, m1, m2;
                             load_cell(tile + (cxp + cell_row), p0, p1, p2);
                             load_cell(tile + (cxm + cell_row), m0, m1, m2);
@@ -725,6 +740,7 @@ struct VisualizerStrip {
             }
         }
 
+        SF_TICK(a, 3);                                                // diagonals
         // ---- visualizer.frag:36-73 per sample, then the texels meet in LDS ----
         uint32_t texel[WALK];
         {
@@ -744,6 +760,7 @@ struct VisualizerStrip {
                 if (r < rows && inside) screen[(long)(jr0 + r)*a.wr + i] = texel[r];
             return;
         }
+        SF_TICK(a, 4);                                                // post-processing
         __syncthreads();                                              // every wave is done with the cells
         uint32_t* texels = (uint32_t*)sh.cells;                       // [RROWS][COLS]
         uint8_t* staged = (uint8_t*)sh.cells + STAGED;                 // [PIXEL_ROWS][BLOCK_PX*3]
@@ -766,6 +783,8 @@ struct VisualizerStrip {
             s[2] = (uint8_t)resolve_channel_any<S>(block, a.subsample, 16);
         }
         __syncthreads();
+        SF_TICK(a, 5);                                                // barrier + texel exchange + resolve + barrier
+        SF_FOLDS_OUT(a);
         uint8_t* out = (uint8_t*)a.out + (long)frame*a.out_frame_stride;
 #if VIS_STRIP_SWEEP_STORE
         // a full-width block of a frame whose rows are whole 16-byte groups: all rows leave in ONE sweep of 16-byte stores by as many
@@ -782,6 +801,7 @@ struct VisualizerStrip {
                     stream_store16((uint4*)row + c, (const uint4*)staged + e);
                 }
             }
+            SF_TICK(a, 6);                                            // the sweep of stores
             return;
         }
 #endif

@@ -91,8 +91,8 @@ class FrameTape:
             return False
         if not spectrograms:
             return True                                           # Waveform-like scenes: the tape carries a private spectrogram nobody samples
-        if spectrograms[0].spectrogram_bins*audio.channels > 2048:
-            return False                                          # the scan kernel walks up to 2048 values per frame
+        if spectrograms[0].spectrogram_bins*audio.channels > 16384:
+            return False                                          # the scan kernel walks up to 16 384 values per frame (csrc/capi.hip DYNAMICS_SCAN_LIMIT)
         # a scrolling spectrogram (length > 0) keeps one state of its texture per frame of a batch in HBM (sfx_tape_desc.length_samples)
         if spectrograms[0].length_samples*spectrograms[0].spectrogram_bins*audio.channels*4*FrameTape.BATCH > FrameTape.SCROLL_BYTES:
             return False

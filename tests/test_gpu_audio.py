@@ -108,6 +108,34 @@ def test_stft_sizes_windows_and_start_of_stream(gpu, golden):
         close(got[k], O.fft_power(pcm, t))
 
 
+@pytest.mark.parametrize("ratio,fft_n", [(2, 11), (3, 11), (4, 12), (3, 12)])
+def test_sample_rateio_resamples_before_the_transform(ratio, fft_n):
+    """spectrogram.py:144-171 with `sample_rateio` = 2, 3, 4: the last 2**fft_n ring samples through samplerate's 'linear' converter
+    (restated: parity unpinned, sfo_audio.c says why), `np.hanning(fft_size)` over fft_size = 2**fft_n * ratio samples, rfft in float64,
+    power. Ratios 2 and 4 keep the radix-2 kernel at the larger size, 3 (6 144 / 12 288 samples) takes the float64 DFT sum; against
+    numpy on the oracle's resampled data, 1e-5 relative — `fft()` and `next()` (the filterbank has fft_size/2 + 1 columns)"""
+    from examples.scenes import MusicBars, make
+    rng = np.random.default_rng(40 + ratio)
+    pcm = (0.4*rng.standard_normal((20000, 2))).astype(np.float32)
+    scene = make(MusicBars, audio=(pcm, 44100))
+    scene.initialize()
+    scene.audio.tell = 19000
+    spectrogram = scene.spectrogram
+    spectrogram.fft_n, spectrogram.sample_rateio = fft_n, ratio
+    size, fft_size = 2**fft_n, 2**fft_n*ratio
+    assert spectrogram.fft_size == fft_size and spectrogram.fft_bins == fft_size//2 + 1
+    got = spectrogram.fft()
+    data = pcm.T[:, 19000 - size - 1:19000 - 1]
+    resampled = np.stack([O.resample_linear(channel, ratio, fft_size) for channel in data])
+    assert resampled.shape == (2, fft_size)
+    spectrum = np.fft.rfft(np.hanning(fft_size)*resampled)
+    want = (spectrum*spectrum.conj()).real.astype(np.float32)
+    assert got.shape == want.shape
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-5*float(want.max())), float(np.abs(got - want).max()/want.max())
+    columns = spectrogram.next()
+    assert np.allclose(columns, spectrogram.spectrogram_matrix().dot(want.T).T, rtol=2e-5, atol=2e-5*float(np.abs(columns).max()))
+
+
 def test_window_function_of_the_callers_own():
     """`window` may be any callable N -> array (spectrogram.py:90-108, 155-171 multiply by what it returns, in
     float64). The host evaluates it like the reference does and the plan takes the table (sfx_stft_plan_window): the device's power
@@ -291,6 +319,32 @@ def test_scalar_dynamics_scan_bit_exact(gpu, golden, tag):
     if integrate:
         assert np.array_equal(out[:, 0, 1], g[f"{tag}_integrals"])
     assert np.array_equal(out[:, 0, 2], g[f"{tag}_derivatives"])
+
+
+@pytest.mark.parametrize("n", [2049, 2050, 4097, 9000, 16384])
+def test_dynamics_scan_beyond_2048_values(gpu, n):
+    """`spectrogram_bins` is whatever the user says (spectrogram.py:184): 1 025 stereo bins are 2 050 values. Up to 16 384 values the
+    scan keeps 4 / 8 / 16 of them per thread of its one block; bit for bit the oracle's float32 recurrence, the whole-array early-out
+    (a held target: the state must freeze for every value at once, and move again) and the hand-over between two calls included"""
+    rng = np.random.default_rng(n)
+    frames = 120
+    dts = np.full(frames, 1/60); dts[0] = 0.0
+    targets = np.abs(rng.standard_normal((frames, n))).astype(np.float32)
+    targets[20:100] = targets[20]                                   # held: the system converges and freezes, then moves again
+    system = O.DynF32(n, 8, 1, 0)
+    want = np.stack([system.step(targets[k], float(dts[k])).copy() for k in range(frames)])
+    frozen = [k for k in range(30, 100) if np.array_equal(want[k], want[k - 1])]
+    assert len(frozen) > 20 and not np.array_equal(want[-1], want[99]), "the fixture no longer exercises the early-out"
+    coeff = _coeff_table(8, 1, 0, dts, np.float32)
+    state = np.zeros(3*n, np.float32)
+    got = np.zeros_like(targets)
+    for first, count in ((0, 33), (33, frames - 33)):
+        N.check(gpu.lib.sfx_dynamics_scan(gpu.ctx.handle, count, n, N.as_ptr(targets[first:], C.c_float),
+                                          C.cast(coeff[first:].ctypes.data, C.POINTER(N.DynCoeffF32)), np.float32(1e-6),
+                                          N.as_ptr(state, C.c_float), N.as_ptr(got[first:], C.c_float)))
+    assert np.array_equal(got, want), np.argwhere(got != want)[:4]
+    assert gpu.lib.sfx_dynamics_scan(gpu.ctx.handle, 1, 16385, N.as_ptr(targets, C.c_float), C.cast(coeff.ctypes.data, C.POINTER(N.DynCoeffF32)),
+                                     np.float32(1e-6), N.as_ptr(state, C.c_float), N.as_ptr(got, C.c_float)) == N.E_UNSUPPORTED
 
 
 def test_dynamics_coefficients_match_the_oracle():

@@ -189,3 +189,21 @@ def test_dynamics_early_out_freezes_the_whole_array(golden):
     got = np.stack([system.step(targets[k], float(o["hold_dts"][k])).copy() for k in range(len(targets))])
     assert np.array_equal(got, want)
     assert np.array_equal(want[200], want[399]) and not np.array_equal(want[399], want[400])
+
+
+def test_linear_resampler_restatements_agree():
+    """`sample_rateio != 1` (spectrogram.py:158-167) resamples with samplerate's 'linear' converter — a package that is neither vendored
+    nor importable here, so this option's parity is UNPINNED: libsamplerate's src_linear.c is restated twice — the oracle generates the
+    samples sequentially as the library does, the product derives the read positions with its own copy of the position loop and
+    interpolates (on the device) — and the two must agree to the bit; plus a vector small enough to follow by hand."""
+    from shaderflow_amd.audio.spectrogram import linear_resample_taps
+    # in = [1, 3, 7], ratio 2: x[0] while input_index < 1 (0, .5), then the one-sample delay: 1, 2 | 3, 5 — six frames
+    assert O.resample_linear(np.array([1, 3, 7], np.float32), 2, 6).tolist() == [1.0, 1.0, 1.0, 2.0, 3.0, 5.0]
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(4096).astype(np.float32)
+    for ratio in (2, 3, 4, 7):
+        n_out = 4096*ratio
+        want = O.resample_linear(x, ratio, n_out)
+        a, b, w = linear_resample_taps(4096, ratio, n_out)
+        got = (x[a].astype(np.float64) + w*(x[b].astype(np.float64) - x[a].astype(np.float64))).astype(np.float32)
+        assert len(want) == n_out and np.array_equal(got, want), ratio       # integer ratios deliver exactly fft_size samples
