@@ -513,6 +513,28 @@ struct VisualizerStrip {
         q0 = *(const Quad*)p; q1 = *(const Quad*)(p + PLANE); q2 = *(const Quad*)(p + 2*PLANE);
     }
     template <class T> __device__ __forceinline__ static float F(T x) { return (float)x; }     // a cell component as a multiply-add operand
+    // The y half of a cell alone: C = t01 - t00 and D = the second difference (the last six of the cell's twelve values). A cell is the
+    // texel-row basis in disguise — A + C and B + D are the A and B of the cell ABOVE — so whoever moves up by exactly one row of cells
+    // already holds that row's x-folded base (U' = U + V, P' = P + Q) and needs only these: half the LDS bytes and a third fewer
+    // multiply-adds per fold.
+// MEASURED AND NOT KEPT (profiles/r05_variants.txt): 3 104 -> 2 644 frames/s at C3 with the same six waves per SIMD (a third scalar branch
+// per advance, a dependent add chain through U, and 8-byte reads at +24 of 48-byte cells), 2 146 with the 84 registers the unconstrained
+// build takes. The knob stays for the record.
+#ifndef VIS_STRIP_ADJACENT
+#define VIS_STRIP_ADJACENT 0
+#endif
+    __device__ __forceinline__ static void load_cd(const char* p, float (&c)[3], float (&d)[3]) {
+        if constexpr (HALF) {
+            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+            const half2v a = *(const half2v*)(p + PLANE + 4);          // q1.zw
+            const Quad b = *(const Quad*)(p + 2*PLANE);                 // q2
+            c[0] = (float)a.x; c[1] = (float)a.y; c[2] = (float)b.x; d[0] = (float)b.y; d[1] = (float)b.z; d[2] = (float)b.w;
+        } else {
+            const float2 a = *(const float2*)(p + 24);                  // q1.zw
+            const float4 b = *(const float4*)(p + 32);                  // q2
+            c[0] = a.x; c[1] = a.y; c[2] = b.x; d[0] = b.y; d[1] = b.z; d[2] = b.w;
+        }
+    }
     static_assert(COLUMN_GROUPS*ROW_GROUPS == 8 && RROWS % S == 0 && COLS % S == 0, "block geometry");
     using Fast = VisualizerFast<TILE_PITCH, TILE_ROWS, 128>;
 #ifndef VIS_STRIP_COLUMN_BRANCHFREE
@@ -524,11 +546,24 @@ struct VisualizerStrip {
     // the cell tile; once every wave is done with it, the texel exchange and the staged RGB8 rows live in the same memory
     static constexpr int CELLS_BYTES = TILE_ROWS*TILE_PITCH*(HALF_CELLS ? 24 : 48);
     static constexpr int EXCHANGE_BYTES = (S == 1) ? 0 : (int)sizeof(uint32_t)*ROW_GROUPS*WALK*64*COLUMN_GROUPS + (ROW_GROUPS*WALK/S)*(64*COLUMN_GROUPS/S)*3;
+    // Round 5 (profiles/r05_ubench_valu_sgpr.txt): a VALU instruction with a SCALAR source — v_mov_b32 v, s included — issues in 4.2
+    // cycles, not 2.5. The kernel moved 31 wave-uniform values per supersample from scalar to vector registers (fractions of the
+    // diagonal taps, LDS addresses of the column-line's weights): 10 % of its issue cycles. Both now arrive in vector registers through
+    // LDS reads at an address held in ONE vector register plus an immediate offset — no VALU instruction at all:
+#ifndef VIS_STRIP_YFRAC_LDS
+#define VIS_STRIP_YFRAC_LDS 0                                          // the two fractions of every (row, walk step) staged per block; ds_read_b64 at v_w + r*80
+#endif
+#ifndef VIS_STRIP_COLW_ALIGNED
+#define VIS_STRIP_COLW_ALIGNED 1                                       // the column-line's (n, s) weights per WAVE, aligned to the strip's first cell and zero padded: ds_read_b64 at v_k + r*COLW_SLOTS*8
+#endif
+    static constexpr int COLW_SLOTS = VIS_LINE_CELLS + 6;              // cells a strip's column can span: the 8 slots of a line + the rows of cells its samples cross
     struct Shared {
         float4 cells[(CELLS_BYTES > EXCHANGE_BYTES ? CELLS_BYTES : EXCHANGE_BYTES)/16 + 1];     // (float16 cells without SSAA) later: uint32 texels[RROWS][COLS], then the RGB8 rows at STAGED
         float4 row_entries[RROWS][VIS_ENTRY_QUADS];
         float4 ysteps[VIS_STRIP_YSTEPS_LDS ? RROWS : 1][10];
         float4 zeros;                                                  // weights of a slot that does not exist
+        float2 yfrac[VIS_STRIP_YFRAC_LDS ? RROWS : 1][10];             // { frac(y+), frac(y-) } of k_visualizer_axes' ysteps
+        float2 colw[VIS_STRIP_COLW_ALIGNED ? 8 : 1][WALK][COLW_SLOTS]; // per wave: weights[r][k - first]
     };
     static constexpr int STAGED = (int)sizeof(uint32_t)*RROWS*COLS;    // byte offset of the staged RGB8 rows inside the (dead) cell tile, after the texels
     static_assert(S == 1 || STAGED + PIXEL_ROWS*BLOCK_PX*3 == EXCHANGE_BYTES, "the texel exchange and the staged rows live in the cell tile");
@@ -579,6 +614,12 @@ struct VisualizerStrip {
             const int jr = by*RROWS + row;
             sh.ysteps[row][w] = t.ysteps[((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*10 + w];
         }
+        if (VIS_STRIP_YFRAC_LDS && tid >= THREADS - RROWS*10) {     // (the last threads: the first ones fetch the row entries)
+            const int e = tid - (THREADS - RROWS*10), row = e / 10, w = e - row*10;
+            const int jr = by*RROWS + row;
+            const float4 y = t.ysteps[((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*10 + w];
+            sh.yfrac[row][w] = make_float2(y.x, y.y);
+        }
         __syncthreads();
         SF_TICK(a, 0);                                                // prologue: tables, staging the cell tile, the first barrier
 
@@ -599,12 +640,25 @@ struct VisualizerStrip {
                 const float4 c3 = ce[3], c4 = ce[4], c5 = ce[5], c6 = ce[6];
                 const float n[8] = {c3.x, c3.z, c4.x, c4.z, c5.x, c5.z, c6.x, c6.z}, s[8] = {c3.y, c3.w, c4.y, c4.w, c5.y, c5.w, c6.y, c6.w};
                 float P[3] = {0.0f, 0.0f, 0.0f}, Q[3] = {0.0f, 0.0f, 0.0f};
-                int previous = -1;
+                int previous = -2*ROWBYTES;                           // (no row of cells: neither equal nor adjacent to a real one)
 #pragma unroll
                 for (int r = 0; r < WALK; r++) if (r < rows) {
                     const float4 r0 = sh.row_entries[row0 + r][0];
                     const int cell_row = __builtin_amdgcn_readfirstlane(__float_as_int(r0.z));       // the wave's lanes share their rows
-                    if (cell_row != previous) {
+                    if (VIS_STRIP_ADJACENT && cell_row == previous + ROWBYTES) {
+                        // one row of cells up: its base line is this one's top (P' = P + Q); only the y halves of the eight cells are new
+                        previous = cell_row;
+                        const char* line = tile + (__float_as_int(c0.w) + cell_row);
+                        P[0] = P[0] + Q[0]; P[1] = P[1] + Q[1]; P[2] = P[2] + Q[2];
+                        Q[0] = Q[1] = Q[2] = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < VIS_LINE_CELLS; k++) {
+                            float c[3], d[3];
+                            load_cd(line + k*CELL, c, d);
+                            Q[0] = fmaf(n[k], c[0], Q[0]); Q[1] = fmaf(n[k], c[1], Q[1]); Q[2] = fmaf(n[k], c[2], Q[2]);
+                            Q[0] = fmaf(s[k], d[0], Q[0]); Q[1] = fmaf(s[k], d[1], Q[1]); Q[2] = fmaf(s[k], d[2], Q[2]);
+                        }
+                    } else if (cell_row != previous) {
                         previous = cell_row;
                         const char* line = tile + (__float_as_int(c0.w) + cell_row);
                         P[0] = P[1] = P[2] = Q[0] = Q[1] = Q[2] = 0.0f;
@@ -633,6 +687,47 @@ struct VisualizerStrip {
                 }
                 const int first = start[0];
                 const char* column_cells = tile + __float_as_int(c0.z);
+                if (VIS_STRIP_COLW_ALIGNED && last - first <= COLW_SLOTS) {
+                    // this wave's weights, aligned to the strip's first cell: colw[r][j] = (n, s) of row r for cell first + j, zeros where
+                    // the row's eight slots do not reach. Built by the wave itself (LDS operations of one wave execute in order: no barrier)
+                    float2* mine = &sh.colw[wave][0][0];
+#pragma unroll
+                    for (int e = lane; e < WALK*COLW_SLOTS; e += 64) {
+                        const int r = e / COLW_SLOTS, j = e - r*COLW_SLOTS;
+                        const int begin = __float_as_int(sh.row_entries[row0 + r][0].w)/ROWBYTES;
+                        const int slot = j + first - begin;
+                        const bool covered = r < rows && slot >= 0 && slot < VIS_LINE_CELLS;
+                        mine[e] = covered ? *(const float2*)((const char*)sh.row_entries[row0 + r] + 48 + slot*8) : make_float2(0.0f, 0.0f);
+                    }
+                    int vzero;
+                    asm("v_mov_b32 %0, 0" : "=v"(vzero));                   // the table's address lives in a VECTOR register: ds_read_b64 v, v_k offset:r*COLW_SLOTS*8
+                    // (NOT `asm volatile`: a side-effecting asm counts as a possible store, after which the compiler no longer proves the
+                    // per-frame tables unclobbered and fetches them with vector instead of scalar loads — 78 -> 100 registers)
+                    const char* weights_k = (const char*)mine + vzero;
+                    const char* cell_k = column_cells + first*ROWBYTES;
+                    float U0 = 0.0f, U1 = 0.0f, U2 = 0.0f, V0 = 0.0f, V1 = 0.0f, V2 = 0.0f;
+                    for (int k = first; k < last; k++) {
+                        if (VIS_STRIP_ADJACENT && k > first) {
+                            // the cell above: its base is this cell's top (U' = U + V), only the y half is fetched
+                            float c[3], d[3];
+                            load_cd(cell_k, c, d);
+                            U0 = U0 + V0; U1 = U1 + V1; U2 = U2 + V2;
+                            V0 = fmaf(fx, d[0], c[0]); V1 = fmaf(fx, d[1], c[1]); V2 = fmaf(fx, d[2], c[2]);
+                        } else {
+                            Quad q0, q1, q2;
+                            load_cell(cell_k, q0, q1, q2);
+                            U0 = fmaf(fx, F(q0.w), F(q0.x)); U1 = fmaf(fx, F(q1.x), F(q0.y)); U2 = fmaf(fx, F(q1.y), F(q0.z));
+                            V0 = fmaf(fx, F(q2.y), F(q1.z)); V1 = fmaf(fx, F(q2.z), F(q1.w)); V2 = fmaf(fx, F(q2.w), F(q2.x));
+                        }
+#pragma unroll
+                        for (int r = 0; r < WALK; r++) {
+                            const float2 w = *(const float2*)(weights_k + r*COLW_SLOTS*8);
+                            acc[r][0] = fmaf(w.x, U0, acc[r][0]); acc[r][1] = fmaf(w.x, U1, acc[r][1]); acc[r][2] = fmaf(w.x, U2, acc[r][2]);
+                            acc[r][0] = fmaf(w.y, V0, acc[r][0]); acc[r][1] = fmaf(w.y, V1, acc[r][1]); acc[r][2] = fmaf(w.y, V2, acc[r][2]);
+                        }
+                        weights_k += 8; cell_k += ROWBYTES;
+                    }
+                } else
                 for (int k = first; k < last; k++) {
                     Quad q0, q1, q2;
                     load_cell(column_cells + k*ROWBYTES, q0, q1, q2);
@@ -679,6 +774,9 @@ struct VisualizerStrip {
                     ysteps[r] = t.ysteps + ((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*10;
                 }
                 float xp = xr + first, xm = xr - first;
+                // the fractions of this wave's rows at walk step w: ONE vector register holds the address, the rows are immediate offsets
+                int yfrac_w = 0;                                      // byte offset of walk step w inside this wave's rows of sh.yfrac, in a VECTOR register
+                if (VIS_STRIP_YFRAC_LDS) asm("v_mov_b32 %0, 0" : "=v"(yfrac_w));
 #ifndef VIS_STRIP_SWEEP_STORE
 #define VIS_STRIP_SWEEP_STORE 1        // 0: wave 0 stores the block's rows one after the other while seven waves hold the block's LDS and registers (-6 %)
 #endif
@@ -692,14 +790,36 @@ struct VisualizerStrip {
                     float4 y[WALK];
 #pragma unroll
                     for (int r = 0; r < WALK; r++) y[r] = VIS_STRIP_YSTEPS_LDS ? sh.ysteps[row0 + r][w] : ysteps[r][w];   // { frac(y+), frac(y-), row bytes(y+), row bytes(y-) }
+#ifndef VIS_STRIP_YFRAC_VMEM
+#define VIS_STRIP_YFRAC_VMEM 0                                         // 1: the two fractions of a row's entry ALSO through a vector load (the same address in every lane: one L1 line), so they arrive in vector registers — the scalar copy costs a v_mov per use (VALU forms with an SGPR source issue at half rate); needs 18 more VGPRs: a 6-wave build
+#endif
+                    float2 yf[WALK];
+                    if (VIS_STRIP_YFRAC_VMEM) {
+                        int vzero;
+                        asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));          // an offset the compiler cannot prove uniform: keeps the load on the vector memory path
+#pragma unroll
+                        for (int r = 0; r < WALK; r++) yf[r] = *(const float2*)((const char*)&ysteps[r][w] + vzero);
+                    }
 #ifndef VIS_STRIP_SIDES_TOGETHER
 #define VIS_STRIP_SIDES_TOGETHER 1                                     // 1: both y sides of a walk step advance row by row together (their first cells are fetched at once)
 #endif
                     float U[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}}, V[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
-                    int previous[2] = {-1, -1};
-                    auto advance = [&](int r, int side) {
+                    int previous[2] = {-2*ROWBYTES, -2*ROWBYTES};     // (no row of cells: neither equal nor adjacent to a real one)
+                    auto advance = [&](int r, int side, float ay_lds) {
                         const int cell_row = VIS_STRIP_YSTEPS_LDS ? __builtin_amdgcn_readfirstlane(__float_as_int(side ? y[r].w : y[r].z)) : __float_as_int(side ? y[r].w : y[r].z);
-                        if (cell_row != previous[side]) {
+                        if (VIS_STRIP_ADJACENT && cell_row == previous[side] + ROWBYTES) {
+                            // one row of cells up: U' = U + V, V' from the y halves of the two cells
+                            previous[side] = cell_row;
+                            SF_COUNT_FOLD();
+                            float* u = U[side]; float* v = V[side];
+                            float cp[3], dp[3], cm[3], dm[3];
+                            load_cd(tile + (cxp + cell_row), cp, dp);
+                            load_cd(tile + (cxm + cell_row), cm, dm);
+                            u[0] = u[0] + v[0]; u[1] = u[1] + v[1]; u[2] = u[2] + v[2];
+                            v[0] = cp[0] + cm[0]; v[1] = cp[1] + cm[1]; v[2] = cp[2] + cm[2];
+                            v[0] = fmaf(axp, dp[0], v[0]); v[1] = fmaf(axp, dp[1], v[1]); v[2] = fmaf(axp, dp[2], v[2]);
+                            v[0] = fmaf(axm, dm[0], v[0]); v[1] = fmaf(axm, dm[1], v[1]); v[2] = fmaf(axm, dm[2], v[2]);
+                        } else if (cell_row != previous[side]) {
                             previous[side] = cell_row;
                             SF_COUNT_FOLD();
                             Quad p0, p1, p2, m0, m1, m2;
@@ -721,21 +841,31 @@ struct VisualizerStrip {
                             v[0] = fmaf(axp, F(p2.y), v[0]);  v[1] = fmaf(axp, F(p2.z), v[1]);  v[2] = fmaf(axp, F(p2.w), v[2]);
                             v[0] = fmaf(axm, F(m2.y), v[0]);  v[1] = fmaf(axm, F(m2.z), v[1]);  v[2] = fmaf(axm, F(m2.w), v[2]);
                         }
-                        const float ay = VIS_STRIP_YSTEPS_LDS ? (side ? y[r].y : y[r].x) : in_vgpr(side ? y[r].y : y[r].x);
+                        float ay;
+                        if (VIS_STRIP_YFRAC_LDS) ay = ay_lds;
+                        else ay = VIS_STRIP_YFRAC_VMEM ? (side ? yf[r].y : yf[r].x) : (VIS_STRIP_YSTEPS_LDS ? (side ? y[r].y : y[r].x) : in_vgpr(side ? y[r].y : y[r].x));
                         acc[r][0] = acc[r][0] + U[side][0];           acc[r][1] = acc[r][1] + U[side][1];           acc[r][2] = acc[r][2] + U[side][2];
                         acc[r][0] = fmaf(ay, V[side][0], acc[r][0]);  acc[r][1] = fmaf(ay, V[side][1], acc[r][1]);  acc[r][2] = fmaf(ay, V[side][2], acc[r][2]);
                     };
-                    if (VIS_STRIP_SIDES_TOGETHER) {
+                    if (VIS_STRIP_YFRAC_LDS) {
+                        // both fractions of a row in one ds_read_b64 (address = one vector register + the row's immediate offset)
 #pragma unroll
-                        for (int r = 0; r < WALK; r++) if (r < rows) { advance(r, 0); advance(r, 1); }
+                        for (int r = 0; r < WALK; r++) if (r < rows) {
+                            const float2 mine = *(const float2*)((const char*)&sh.yfrac[row0 + r][0] + yfrac_w);
+                            advance(r, 0, mine.x); advance(r, 1, mine.y);
+                        }
+                    } else if (VIS_STRIP_SIDES_TOGETHER) {
+#pragma unroll
+                        for (int r = 0; r < WALK; r++) if (r < rows) { advance(r, 0, 0.0f); advance(r, 1, 0.0f); }
                     } else {
 #pragma unroll
                         for (int side = 0; side < 2; side++) {
 #pragma unroll
-                            for (int r = 0; r < WALK; r++) if (r < rows) advance(r, side);
+                            for (int r = 0; r < WALK; r++) if (r < rows) advance(r, side, 0.0f);
                         }
                     }
                     xp = xp + step; xm = xm - step;
+                    if (VIS_STRIP_YFRAC_LDS) yfrac_w += 8;
                 }
             }
         }

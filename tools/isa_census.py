@@ -21,7 +21,10 @@ import json
 import re
 import sys
 
-# cycles a wave64 instruction of the class occupies its SIMD's issue port (profiles/r02_ubench_valu.txt, at the sustained clock)
+# cycles a wave64 instruction of the class occupies its SIMD's issue port (profiles/r02_ubench_valu.txt, r05_ubench_valu_sgpr.txt, at
+# the sustained clock): 2 for the f32 add / mul / fma, moves and integer adds between VECTOR registers; 4 for conversions, min / max /
+# med3, fract / floor, shifts, compares, readfirstlane, SDWA — and for ANY form with a scalar-register source (v_mov_b32 v, s included);
+# 8 for the transcendentals
 CLASSES = [
     # (class, regex on the mnemonic, cycles)
     ("fma_f32", r"v_(fma|fmac|fmaak|fmamk|mad|mac)_f32", 2),
@@ -33,7 +36,7 @@ CLASSES = [
     ("cvt", r"v_cvt_", 4),
     ("fract_floor", r"v_(fract|floor|ceil|rndne|trunc)_f32", 4),
     ("minmax_med", r"v_(min|max|med3|min3|max3)_", 4),
-    ("cmp", r"v_cmpx?_", 2),
+    ("cmp", r"v_cmpx?_", 4),                                          # 4.3 measured, into vcc or into a scalar pair (profiles/r05_ubench_valu_sgpr.txt)
     ("cndmask", r"v_cndmask_", 2),
     ("mov", r"v_(mov_b32|mov_b64|accvgpr)", 2),
     ("dpp_swizzle", r"v_(mov_b32_dpp|permlane|swap)", 4),
@@ -129,8 +132,8 @@ def parse(listing: str, kernel: str) -> tuple[str, list[Block]]:
             block = blocks[-1]
             kind = classify(mnemonic, operands)
             block.counts[kind] += 1
-            if kind in VALU and uses_sgpr_source(mnemonic, operands):
-                block.sgpr_forms += 1
+            if kind in VALU and uses_sgpr_source(mnemonic, operands) and dict((n, c) for n, _, c in CLASSES).get(kind) == 2:
+                block.sgpr_forms += 1                                 # full-rate forms pay for a scalar source; half-rate ones already take 4
             block.instructions.append((mnemonic, operands))
             if current_line:
                 block.lines[current_line] += 1

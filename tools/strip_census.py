@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""
+ISA census of k_visualizer_strip<72, 12, 2, 9, 8, 4, false>: instructions per supersample BY CLASS, priced with
+the issue cycles tools/ubench_valu.hip measured, so that bench.py's `issue_model` prices the 16 % of the VALU instructions no hardware
+class counter covers ("other": moves, selects, compares, min/max, fract/floor, readfirstlane) with what they are instead of a 2-or-4 band.
+
+Method. `tools/isa_census.py LISTING KERNEL --dump blocks.json` (LISTING built with -gline-tables-only) gives every basic block's
+instructions by class and the source lines it was generated from. The kernel's control flow is SCALAR (the lanes of a wave share their
+rows): which blocks run is decided by per-frame tables, and the unrolled copies of a phase are identical, so a block's executions per
+wave follow from a handful of event rates:
+    folds      diagonal cell folds per wave — MEASURED by the profiling build (-DSF_SECTION_TIMERS counts them: 53.0 of 180 advances at C3);
+               the first advance of every (step, side) always folds (20), the other 160 fold with p = (folds - 20)/160; the row-line's
+               P/Q fold follows the same statistic (a new row of cells under the next sample): 1 + 8 p per strip
+    columns    iterations of the column-line loop: 8 slots + the distinct cell rows under the strip - 1 = 8 + 8 p
+    exact      waves that re-run the polar chain exactly (speculation margin): 2 % (1-3 % of the row-waves)
+    far/bars/strips  divergent colour branches of visualizer.frag:49-73 (a wave runs a branch when ANY lane takes it): estimates, small blocks
+The model's per-class totals are then CHECKED against the hardware's class counters of the same launch (SQ_INSTS_VALU_*): the split of
+"other" is credible to the extent the counted classes agree.
+
+usage: tools/strip_census.py blocks.json [bench.json with roofline.issue_model] [--folds 53.0]
+"""
+from __future__ import annotations
+
+import argparse
+import collections
+import json
+import re
+import sys
+
+sys.path.insert(0, __file__.rsplit("/", 1)[0])
+from isa_census import CLASSES, VALU  # noqa: E402
+
+CYCLES = {name: cycles for name, _, cycles in CLASSES}
+
+
+def vf_lines(block) -> collections.Counter:
+    out: collections.Counter = collections.Counter()
+    for line, count in block["lines"].items():
+        name, _, number = line.partition(":")
+        if name == "visualizer_fast.hpp" and number.isdigit():
+            out[int(number)] += count
+    return out
+
+
+def other_lines(block) -> collections.Counter:
+    out: collections.Counter = collections.Counter()
+    for line, count in block["lines"].items():
+        if not line.startswith("visualizer_fast.hpp"):
+            out[line] += count
+    return out
+
+
+def main() -> None:
+    parser = argparse.ArgumentParser()
+    parser.add_argument("blocks")
+    parser.add_argument("bench", nargs="?")
+    parser.add_argument("--folds", type=float, default=53.0, help="diagonal folds per wave measured by the -DSF_SECTION_TIMERS build")
+    parser.add_argument("--exact", type=float, default=0.02)
+    args = parser.parse_args()
+    blocks = json.load(open(args.blocks))
+    p = (args.folds - 20.0)/160.0
+    rates = {"fold_first": 1.0, "fold_next": p, "row_folds": 1.0 + 8.0*p, "column_iterations": 8.0 + 8.0*p, "exact": args.exact,
+             "pow_branch": 0.95, "mix_branch": 0.30, "strips": 0.06, "staging_rounds": 864.0/512.0, "resolve_rounds": 2.25}
+
+    # ---- a weight per block: walk the listing in order, phase by phase ------------------------------------------------------------
+    weights = [0.0]*len(blocks)
+    why = [""]*len(blocks)
+    phase = "prologue"
+    diag_fold_seen = 0
+    row_fold_seen = 0
+    for i, block in enumerate(blocks):
+        n = sum(block["counts"].values())
+        lines, others = vf_lines(block), other_lines(block)
+        top = lines.most_common(1)[0][0] if lines else 0
+        if phase == "prologue" and any(586 <= line <= 611 for line in lines):
+            phase = "rowline"
+        if phase == "rowline" and any(613 <= line <= 655 for line in lines):
+            phase = "colline"
+        if phase == "colline" and any(658 <= line <= 680 for line in lines):
+            phase = "diag"
+        if phase == "diag" and any(728 <= line <= 737 for line in lines):
+            phase = "post"
+        if phase == "post" and any(747 <= line <= 770 for line in lines) and not any(191 <= line <= 271 for line in lines):
+            phase = "resolve"
+        if phase == "resolve" and any(line >= 771 for line in lines) and not any(line < 771 for line in lines):
+            phase = "store"
+
+        if phase == "prologue":
+            if any(334 <= line <= 362 for line in lines) or (n in (83, 84) and "vmem" in block["counts"]):
+                weights[i], why[i] = 0.0, "blur_direct (a window off its tile: never at C3)"
+            elif any("glsl.hpp:8" in line for line in others) and not lines:
+                weights[i], why[i] = rates["staging_rounds"]*0.02, "wrap_texel's modulo (texels outside the texture: the frame's rim)"
+            elif any(278 <= line <= 308 for line in lines):
+                weights[i], why[i] = rates["staging_rounds"], "staging loop"
+            else:
+                weights[i], why[i] = 1.0, "prologue"
+            # the blur_direct chain's helper blocks (glsl.hpp wrap, its loop control) sit between its bodies: they run only with it
+            if 2 < i and why[i] == "prologue" and not lines and any(k.startswith("glsl.hpp") for k in others):
+                weights[i], why[i] = 0.0, "blur_direct helper"
+        elif phase == "rowline":
+            if n > 100:
+                row_fold_seen += 1
+                weights[i] = 1.0 if row_fold_seen == 1 else p
+                why[i] = "row-line P/Q fold"
+            else:
+                weights[i], why[i] = 1.0, "row-line per sample"
+        elif phase == "colline":
+            if block["targets"] and block["targets"][0] == block["label"]:
+                weights[i], why[i] = rates["column_iterations"], "column-line loop body"
+            else:
+                weights[i], why[i] = 1.0, "column-line set-up"
+        elif phase == "diag":
+            fold = n in (28, 29) and "lds" in block["counts"]
+            skip_path = (not block["counts"].get("lds")) and all(cls in ("salu", "branch", "mov", "waitcnt") for cls in block["counts"]) and n <= 14 and top in (0, 715) and i > 0 and "diagonal set-up" not in why[i - 1]
+            if fold:
+                diag_fold_seen += 1
+                weights[i] = 10.0*(1.0 if diag_fold_seen <= 2 else p)
+                why[i] = "diagonal fold"
+            elif any(658 <= line <= 675 for line in lines) and n > 60:
+                weights[i], why[i] = 1.0, "diagonal set-up"
+            elif skip_path and re.fullmatch(r"\.LBB\d+_\d+", block["label"]) and block["counts"].get("salu", 0) >= 2 and not block["counts"].get("smem"):
+                weights[i], why[i] = 0.0, "rows beyond the frame (never inside it)"
+            elif block["counts"].get("mov", 0) >= 10 and n <= 14:
+                weights[i], why[i] = 0.0, "rows beyond the frame (zeroed sums)"
+            else:
+                weights[i], why[i] = 10.0, "diagonal per step / per advance"
+        elif phase == "post":
+            text = " ".join(others)
+            if "glsl.hpp:81" in text or "glsl.hpp:82" in text:
+                weights[i], why[i] = 9.0*0.0, "wrap_texel's modulo (bin outside the texture: never)"
+            elif "sfmath.hpp:110" in text or "sfmath.hpp:99" in text or "glsl.hpp:403" in text or "__clang_hip_math.h:722" in text:
+                weights[i], why[i] = rates["exact"], "exact polar chain (speculation re-run)"
+            elif 249 in lines or "fragments.hpp:0" in text:
+                weights[i], why[i] = rates["pow_branch"], "pow((len - r)/2, 0.05): lanes beyond their bar"
+            elif top == 188 and 248 in lines:
+                weights[i], why[i] = rates["mix_branch"], "mix towards white: lanes inside a bar"
+            elif 262 in lines or (top == 0 and n <= 3 and i > 0 and "strips" in why[i - 1]):
+                weights[i], why[i] = rates["strips"], "waveform strips / out-of-aspect bars"
+            else:
+                weights[i], why[i] = 1.0, "post"
+        elif phase == "resolve":
+            loop = any(754 <= line <= 766 for line in lines) or any("render_kernels.hpp:30" in k or "render_kernels.hpp:28" in k or "render_kernels.hpp:0" in k for k in others)
+            weights[i], why[i] = (rates["resolve_rounds"] if loop else 1.0), "texel exchange + resolve"
+        else:
+            sweep = any(775 <= line <= 783 for line in lines)
+            weights[i], why[i] = (1.0 if sweep or any(line in (769, 774, 777) for line in lines) else 0.0), ("sweep store" if sweep else "store (row-by-row fallback: not at C3)")
+
+    # ---- totals ---------------------------------------------------------------------------------------------------------------------
+    by_phase: dict[str, collections.Counter] = collections.defaultdict(collections.Counter)
+    total: collections.Counter = collections.Counter()
+    sgpr = 0.0
+    for block, weight, reason in zip(blocks, weights, why):
+        group = reason.split(" (")[0].split(":")[0]
+        for cls, count in block["counts"].items():
+            total[cls] += count*weight
+            by_phase[group][cls] += count*weight
+        sgpr += block["sgpr_forms"]*weight
+    samples = 9.0
+    valu_total = sum(total[c] for c in VALU)
+    print(f"event rates: {json.dumps({k: round(v, 4) for k, v in rates.items()})}")
+    print(f"\nwave-instructions per wave (576 supersamples) -> per supersample (x 64 lanes / 576 = / 9):")
+    print(f"  {'class':16s} {'per wave':>10s} {'per sample':>11s} {'cycles':>7s} {'issue cycles / sample':>22s}")
+    cycles_total = 0.0
+    for name, _, cycles in CLASSES:
+        if total[name] == 0:
+            continue
+        print(f"  {name:16s} {total[name]:10.1f} {total[name]/samples:11.2f} {cycles:7d} {total[name]/samples*cycles:22.2f}")
+        if name in VALU:
+            cycles_total += total[name]/samples*cycles
+    print(f"  {'SGPR-source forms':16s} {sgpr:10.1f} {sgpr/samples:11.2f} {'+2':>7s} {sgpr/samples*2:22.2f}")
+    cycles_total += sgpr/samples*2
+    print(f"  VALU: {valu_total:.0f} per wave = {valu_total/samples:.1f} per supersample; {cycles_total:.1f} issue cycles per supersample = {cycles_total/(valu_total/samples):.3f} cycles per VALU instruction")
+    print(f"  scalar: {total['salu']/samples:.1f} SALU + {total['smem']/samples:.1f} SMEM + {total['branch']/samples:.1f} branches + {total['waitcnt']/samples:.1f} waits per supersample; LDS {total['lds']/samples:.1f}, VMEM {total['vmem']/samples:.2f}")
+    print("\nby phase (VALU instructions per supersample | share):")
+    for group, counts in sorted(by_phase.items(), key=lambda kv: -sum(kv[1][c] for c in VALU)):
+        v = sum(counts[c] for c in VALU)
+        if v > 0.5:
+            print(f"  {group:40s} {v/samples:8.1f}  {100*v/valu_total:5.1f} %")
+
+    hw_map = {"fma_f32": ["fma_f32"], "add_f32": ["add_f32"], "mul_f32": ["mul_f32"], "trans_f32": ["trans"], "cvt": ["cvt"],
+              "int32": ["int_shift_mul", "int_add_logic"]}
+    other_classes = [c for c in VALU if not any(c in v for v in hw_map.values())]
+    if args.bench:
+        record = json.loads([line for line in open(args.bench) if line.startswith("{")][-1])
+        model = record["roofline"]["issue_model"]
+        frames = record["roofline"]["frames_per_launch"]
+        waves = frames*30*240*8.0
+        print(f"\ncheck against the hardware's class counters of the same launch ({args.bench}; wave-instructions per wave):")
+        print(f"  {'class':12s} {'model':>9s} {'measured':>9s} {'model/measured':>15s}")
+        for hw, mine in hw_map.items():
+            modelled = sum(total[c] for c in mine)
+            measured = model["instructions"][hw]/waves
+            print(f"  {hw:12s} {modelled:9.1f} {measured:9.1f} {modelled/measured:15.3f}")
+        modelled_other = sum(total[c] for c in other_classes)
+        print(f"  {'other':12s} {modelled_other:9.1f} {model['instructions']['other']/waves:9.1f} {modelled_other/(model['instructions']['other']/waves):15.3f}")
+        print(f"  {'all':12s} {valu_total:9.1f} {model['instructions']['all']/waves:9.1f} {valu_total/(model['instructions']['all']/waves):15.3f}")
+    other_cycles = sum(total[c]*CYCLES[c] for c in other_classes)
+    other_count = sum(total[c] for c in other_classes)
+    print(f"\n'other' (no hardware class counter): {other_count/samples:.1f} per supersample = " + ", ".join(f"{c} {total[c]/samples:.1f}" for c in other_classes if total[c] > 0.05*samples))
+    print(f"  priced by class: {other_cycles/other_count:.3f} issue cycles per instruction (bench.py issue_model: OTHER_CYCLES)")
+
+
+if __name__ == "__main__":
+    main()
