@@ -255,7 +255,30 @@ CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2, "SQ_INSTS_VALU_MUL_F32": 2, "SQ_INST
                 "SQ_INSTS_VALU_TRANS_F32": 8, "SQ_INSTS_VALU_ADD_F16": 4, "SQ_INSTS_VALU_FMA_F16": 4}
 
 
-def issue_model(cs: dict, launch_ns: float | None) -> dict | None:
+CENSUS = ROOT/"profiles"/"r05_strip_isa_census.json"      # tools/strip_census.py --json: what the uncounted VALU instructions ARE
+
+
+def census_prices(kernel: str) -> dict | None:
+    """The ISA census of the strip kernel (profiles/r05_strip_isa_census.txt): issue cycles of the instructions no hardware class counter
+    covers, and how many full-rate forms take a scalar source (+2 cycles each). Only for the kernel and the sources it was counted on."""
+    import hashlib
+    try:
+        census = json.loads(CENSUS.read_text())
+    except (OSError, ValueError):
+        return None
+    if census.get("kernel", "").replace(" ", "") != kernel.replace(" ", ""):
+        return None
+    digest = hashlib.sha256()
+    csrc = ROOT/"shaderflow_amd"/"csrc"
+    for name in ("visualizer_fast.hpp", "visualizer_kernels.hpp", "render_kernels.hpp", "fragments.hpp", "glsl.hpp", "sfmath.hpp", "Makefile"):
+        digest.update(name.encode()); digest.update((csrc/name).read_bytes())
+    if digest.hexdigest()[:16] != census.get("strip_sources_fingerprint"):
+        print(f"bench.py: {CENSUS.name} was counted on other kernel sources: issue_model keeps its 2-or-4 band; re-run tools/strip_census.py", file=sys.stderr)
+        return None
+    return census
+
+
+def issue_model(cs: dict, launch_ns: float | None, census: dict | None = None) -> dict | None:
     """VALU issue cycles the profiled launch NEEDED (rocprofv3's per-class instruction counters x the measured cycles per class; the
     instructions no class counter covers — moves, selects, compares, min/max, bit operations — priced at 2 cycles for `frac_low` and at
     4 for `frac`) over the SIMD cycles it HAD (GRBM_GUI_ACTIVE counts every XCD: / 8 = cycles of the launch at the clock the chip
@@ -268,7 +291,17 @@ def issue_model(cs: dict, launch_ns: float | None) -> dict | None:
     priced = sum(classes[name]*cycles for name, cycles in CLASS_CYCLES.items())
     cycles = cs["GRBM_GUI_ACTIVE"]/8.0
     had = cycles*256*4
-    return {"frac": round((priced + 4*other)/had, 4), "frac_low": round((priced + 2*other)/had, 4),
+    by_census = None
+    if census:
+        # one number instead of the band: the uncounted instructions at the price of what the ISA census found them to
+        # be, plus the two extra cycles every full-rate form with a scalar source takes (v_mov_b32 v, s: 4.2 cycles, r05_ubench_valu_sgpr.txt)
+        by_census = round((priced + census["other_cycles_per_instruction"]*other
+                           + 2.0*census["sgpr_source_full_rate_forms_per_valu_instruction"]*cs["SQ_INSTS_VALU"])/had, 4)
+    return {"frac": by_census if by_census is not None else round((priced + 4*other)/had, 4), "frac_census": by_census,
+            "frac_other_at_4": round((priced + 4*other)/had, 4), "frac_low": round((priced + 2*other)/had, 4),
+            "census": ({"other_cycles_per_instruction": census["other_cycles_per_instruction"],
+                        "sgpr_source_full_rate_forms_per_valu_instruction": census["sgpr_source_full_rate_forms_per_valu_instruction"],
+                        "from": str(CENSUS.relative_to(ROOT))} if census else None),
             "simd_cycles_available": had, "effective_clock_GHz": round(cycles/launch_ns, 3) if launch_ns else None,
             "instructions": {"add_f32": classes["SQ_INSTS_VALU_ADD_F32"], "mul_f32": classes["SQ_INSTS_VALU_MUL_F32"], "fma_f32": classes["SQ_INSTS_VALU_FMA_F32"],
                              "int32": classes["SQ_INSTS_VALU_INT32"], "cvt": classes["SQ_INSTS_VALU_CVT"], "trans_f32": classes["SQ_INSTS_VALU_TRANS_F32"],
@@ -611,7 +644,7 @@ def main() -> None:
                 traffic = (cs["FETCH_SIZE"] + cs["WRITE_SIZE"])*1024.0*piece/profiled_frames
             if cs.get("GRBM_GUI_ACTIVE") and cs.get("SQ_LDS_IDX_ACTIVE"):
                 lds_busy = cs["SQ_LDS_IDX_ACTIVE"]/(cs["GRBM_GUI_ACTIVE"]/8.0*256.0)     # LDS-array cycles / (cycles x CUs); GRBM counts per XCD
-            issue = issue_model(cs, (counters.get("duration") or {}).get("average_ns"))
+            issue = issue_model(cs, (counters.get("duration") or {}).get("average_ns"), census_prices(kernel))
         lane_ops = samples_per_s*per_sample if per_sample else None
         result = {
             "metric": "frames/sec at 4K 2xSSAA music-visualizer" if c3 else f"frames/sec {args.scene} {w}x{h} {s}xSSAA",

@@ -199,6 +199,21 @@ int sfx_ring_destroy(sfx_handle ring);
  * capi.hip, restated in the oracle. Half the bytes over PCIe and the pipe: ffmpeg takes `-pix_fmt yuv420p` rawvideo as it is. */
 int sfx_rgb_to_yuv420(sfx_handle ctx, const void* rgb, void* yuv, int width, int height, int frames, int matrix);
 
+/* The frame loop of a scene in which nothing but the clock moves (layered / temporal scenes without host logic: demo.py's Multipass,
+ * MotionBlur, Life), `nframes` frames in ONE call: scene.next (scene.py:456-479) = every program's render (shader.py:388-405: a draw per
+ * layer into row 0 of its texture matrix, then texture.roll(), texture.py:295-298), iFinal's resolve (shader.py:391-396), exporting.pipe
+ * (exporting.py:151-174). `passes` in the order scene.next renders; `matrices[m].textures` is [temporal][layers] in the matrix' CURRENT
+ * order (the call rolls its own copy: the host rolls its matrices by `nframes` afterwards), `names` the sampler name of every box or
+ * NULL. `clock[f]` = iTime, iTau, iDeltatime, iFrame of frame f. With a ring and fd >= 0 every frame is read out and piped
+ * (slot (first_slot + f) % slots; `planar_slots`: device staging per slot for yuv420p, or NULL for rgb24). */
+enum { SFX_PASS_LAYERS = 0, SFX_PASS_FUSED = 1, SFX_PASS_RESOLVE = 2 };
+typedef struct sfx_sequence_pass { sfx_handle program; int kind; int matrix; sfx_handle target; int ssaa; int subsample; } sfx_sequence_pass;
+typedef struct sfx_sequence_matrix { int temporal, layers; const sfx_handle* textures; const char* const* names; } sfx_sequence_matrix;
+typedef struct sfx_clock_tick { float time, tau, deltatime; int32_t frame; } sfx_clock_tick;      /* sfx_uniform_set_clock's arguments */
+int sfx_clock_sequence_run(sfx_handle ctx, const sfx_sequence_pass* passes, int npasses, const sfx_sequence_matrix* matrices, int nmatrices,
+                           const sfx_clock_tick* clock, int nframes, sfx_handle ring, int first_slot, int fd,
+                           void* const* planar_slots, int yuv_matrix, int width, int height);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* Cross-process frame queue of a sharded export (one process per GPU; no reference equivalent). The sink takes
  * one byte stream, so one process owns it (rank 0) — but every rank reads its finished frames out over its OWN PCIe link into a

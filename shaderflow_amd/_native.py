@@ -53,6 +53,21 @@ class FrameClock(C.Structure):
     _fields_ = [("iTime", C.c_float), ("iTau", C.c_float), ("iSpectrogramOffset", C.c_float), ("iFrame", C.c_int32)]
 
 
+class SequencePass(C.Structure):
+    _fields_ = [("program", Handle), ("kind", C.c_int), ("matrix", C.c_int), ("target", Handle), ("ssaa", C.c_int), ("subsample", C.c_int)]
+
+
+class SequenceMatrix(C.Structure):
+    _fields_ = [("temporal", C.c_int), ("layers", C.c_int), ("textures", C.POINTER(Handle)), ("names", C.POINTER(C.c_char_p))]
+
+
+class ClockTick(C.Structure):
+    _fields_ = [("time", C.c_float), ("tau", C.c_float), ("deltatime", C.c_float), ("frame", C.c_int32)]
+
+
+PASS_LAYERS, PASS_FUSED, PASS_RESOLVE = 0, 1, 2
+
+
 class Binding(C.Structure):
     """sfx_binding (include/shaderflow_hip.h): a uniform or sampler name of a loaded program"""
     _fields_ = [("name", C.c_char_p), ("sampler", C.c_int), ("slot", C.c_int), ("count", C.c_int), ("integer", C.c_int)]
@@ -149,6 +164,8 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_tape_create": (C.c_int, [Handle, Handle, P(TapeDesc), C.c_int, P(Handle)]),
     "sfx_clock_tape_create": (C.c_int, [Handle, C.c_int, P(Handle)]),
     "sfx_tape_reset": (C.c_int, [Handle]),
+    "sfx_clock_sequence_run": (C.c_int, [Handle, P(SequencePass), C.c_int, P(SequenceMatrix), C.c_int, P(ClockTick), C.c_int, Handle, C.c_int, C.c_int,
+                                         P(C.c_void_p), C.c_int, C.c_int, C.c_int]),
     "sfx_tape_build": (C.c_int, [Handle, C.c_int, P(C.c_int64), P(FrameClock), P(DynCoeffF32), P(DynCoeffF64), P(DynCoeffF64)]),
     "sfx_tape_read": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "sfx_tape_destroy": (C.c_int, [Handle]),

@@ -105,6 +105,69 @@ class ClockLoop:
             handles = (N.Handle*count)(*[box.texture.handle if box.texture is not None else N.Handle() for (_, _, box) in texture.boxes])
             N.check(N.lib().sfx_sampler_bind_many(program.program, names, handles, count))
 
+    # the same loop without python between the frames (csrc/capi.hip sfx_clock_sequence_run) ---------------------------------------------
+
+    CHUNK = 240                                                        # frames per native call: the encoder and `scene.quit` are looked at in between
+
+    def native_sequence(self, export: "ExportingHelper", turbo: bool) -> bool:
+        """Whether the frames can be rendered, rolled, resolved, read out and piped by ONE native call per chunk: a turbo export without a
+        progress relay (a relay wants a python call per frame), every program compiled. SHADERFLOW_CLOCK_SEQUENCE=0 keeps the python loop
+        (A/B measurements, and the byte-equality test of the two)."""
+        import os
+        if os.environ.get("SHADERFLOW_CLOCK_SEQUENCE", "1") == "0" or not turbo or export.relay is not None:
+            return False
+        return all(program.program is not None for program in self.programs)
+
+    def run_native(self, export: "ExportingHelper", times, dts, rdts, total: int) -> None:
+        scene, lib = self.scene, N.lib()
+        runtime, fps = scene.runtime, scene.fps
+        # texture matrices: every program's own (its draws go to row 0) — the same objects `rolling` lists when they are temporal
+        textures = [program.texture for program in self.programs]
+        index = {id(texture): m for m, texture in enumerate(textures)}
+        passes = (N.SequencePass*len(self.programs))()
+        for k, program in enumerate(self.programs):
+            if program.texture.final:
+                passes[k] = N.SequencePass(N.Handle(), N.PASS_RESOLVE, index[id(scene.shader.texture)], program.texture.fbo.handle, 0, scene.subsample)
+            elif program is scene.shader and scene._can_fuse(program):
+                passes[k] = N.SequencePass(program.program, N.PASS_FUSED, index[id(program.texture)], scene._final.texture.fbo.handle, int(scene.ssaa), scene.subsample)
+            else:
+                passes[k] = N.SequencePass(program.program, N.PASS_LAYERS, index[id(program.texture)], N.Handle(), 0, 0)
+        keep = []                                                      # ctypes arrays the structures point into
+
+        def matrix_tables():
+            tables = (N.SequenceMatrix*len(textures))()
+            for m, texture in enumerate(textures):
+                boxes = [box for (_, _, box) in texture.boxes]
+                handles = (N.Handle*len(boxes))(*[box.texture.handle if box.texture is not None else N.Handle() for box in boxes])
+                names = None
+                if texture.name and texture.temporal > 1:
+                    names = (C.c_char_p*len(boxes))(*[texture._sampler_name(t, l).encode() for (t, l, _) in texture.boxes])
+                keep.extend([handles, names])
+                tables[m] = N.SequenceMatrix(texture.temporal, texture.layers, handles, names)
+            return tables
+        planar = None
+        if export.planar and export._yuv_slots:
+            planar = (C.c_void_p*len(export._yuv_slots))(*export._yuv_slots)
+        piping = export.fileno is not None and export.ring is not None
+        done = 0
+        while done < total and not scene.quit:
+            count = min(self.CHUNK, total - done)
+            export._check_encoder()
+            ticks = (N.ClockTick*count)()
+            for i in range(count):
+                time = times[done + i]
+                ticks[i] = N.ClockTick(time, (time/runtime) % 1.0, dts[done + i], round(time*fps))
+            N.check(lib.sfx_clock_sequence_run(scene.context.handle, passes, len(self.programs), matrix_tables(), len(textures), ticks, count,
+                                               export.ring if piping else N.Handle(), export.frame % max(1, export.slots), export.fileno if piping else -1,
+                                               planar, 1 if export.yuv_matrix == "bt709" else 0, scene.width, scene.height))
+            for texture in textures:
+                texture.roll(count)                                   # the native call rolled its own copy of every matrix it drew into
+            export.frame += count
+            done += count
+            keep.clear()
+        if done:
+            scene.time, scene.dt, scene.rdt = times[done - 1], dts[done - 1], rdts[done - 1]
+
     def run(self, export: "ExportingHelper", turbo: bool):
         scene = self.scene
         total = export.total_frames
@@ -118,6 +181,13 @@ class ClockLoop:
             if not program.texture.final:
                 program.use_scene_pipeline()
         runtime, fps = scene.runtime, scene.fps
+        if self.native_sequence(export, turbo):
+            try:
+                self.run_native(export, times, dts, rdts, total)
+            finally:
+                for program in self.programs:
+                    program._pushed.clear(); program._pushed_plain.clear(); program._module_tokens.clear()
+            return export.finish()
         try:
             for k in range(total):
                 if scene.quit:                                        # ShaderMessage.Window.Close (scene.py:478-480), as the vsync loop honours it

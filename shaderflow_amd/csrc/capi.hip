@@ -9,6 +9,7 @@
 #include "visualizer_fast.hpp"
 #include "resolve_fast.hpp"
 #include "separable_fast.hpp"
+#include "layered_fast.hpp"
 #include "uniform_table.hpp"
 
 #include <hsa/hsa.h>
@@ -79,6 +80,8 @@ struct Context : Object {
     // queue with `stream` (context_copy_streams)
     hipStream_t copy_streams[2] = {nullptr, nullptr};
     unsigned* tile_misses = nullptr;                               // device counter of sfx_ctx_tile_misses, allocated by its first call
+    struct sf::MultipassTaps* multipass_taps = nullptr;            // multipass.frag's blur taps on the device (layered_fast.hpp), built on first use
+    float multipass_reach[2] = {0.0f, 0.0f};
     int copy_candidates = 0, copy_colliding = 0;                   // how many streams the choice looked at / found serialised behind `stream`
     // read-out rings of this context: (ring, "every frame handed to it so far has left device memory"). Their copies run outside HIP's
     // queues, so hipFree's implicit wait knows nothing of them: sfx_device_free asks them first.
@@ -471,7 +474,7 @@ extern "C" int sfx_ctx_destroy(sfx_handle h) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (auto& e : c->events) hipEventDestroy(e);
-    hipFree(c->vis_tables); hipFree(c->vis_bars); hipFree(c->resolve_tables); hipFree(c->tile_misses);
+    hipFree(c->vis_tables); hipFree(c->vis_bars); hipFree(c->resolve_tables); hipFree(c->tile_misses); hipFree(c->multipass_taps);
     for (hipStream_t stream : c->copy_streams) if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
     delete c->engines;
     peer_stop(c);
@@ -1242,6 +1245,54 @@ static const size_t VIS_LDS_LIMIT = 150*1024;                         // leave r
 
 static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hipStream_t s, bool to_screen);
 
+// ---- the second layer of multipass.frag / motionblur.frag (layered_fast.hpp): 1 launched, 0 not this path's configuration -----------
+#ifndef LAYERED_FAST
+#define LAYERED_FAST 1
+#endif
+static int launch_multipass_layer1(const RenderArgs& a, int frames, hipStream_t s) {
+    Context* ctx = g_launch_ctx;
+    const Tex& first = a.tex[TEX_HISTORY];
+    static const bool off = [] { const char* e = getenv("SHADERFLOW_LAYERED_FAST"); return e && atoi(e) == 0; }();     // A/B switch for measurements
+    if (!LAYERED_FAST || off || !ctx || a.u.iLayer != 1 || !first.data || first.dtype != DT_U8 || first.components != 4 || first.filter != FILTER_LINEAR) return 0;
+    if (!ctx->multipass_taps) {
+        MultipassTaps table;
+        multipass_tap_table(table, 5.0f, 8, 8);                     // multipass.frag:41 blur(iScreen0x0, astuv, 5, 8, 8)
+        if (table.count > LAYERED_MAX_TAPS) return 0;
+        if (hipMalloc((void**)&ctx->multipass_taps, sizeof table) != hipSuccess) return fail(SFX_E_HIP, "multipass tap table: out of device memory");
+        if (hipMemcpy(ctx->multipass_taps, &table, sizeof table, hipMemcpyHostToDevice) != hipSuccess) return fail(SFX_E_HIP, "multipass tap table: upload failed");
+        ctx->multipass_reach[0] = table.reach_u; ctx->multipass_reach[1] = table.reach_v;
+    }
+    // texels under a block of 64 x 8 pixels plus the blur's reach on both sides (and the bilinear neighbour, and a texel of slack per side)
+    const int tile_w = (int)ceilf((float)MP_BLOCK_W*(float)first.width/(float)a.wr + 2.0f*ctx->multipass_reach[0]*(float)first.width) + 6;
+    const int tile_h = (int)ceilf((float)MP_BLOCK_H*(float)first.height/(float)a.hr + 2.0f*ctx->multipass_reach[1]*(float)first.height) + 6;
+    const size_t lds = (size_t)tile_w*tile_h*sizeof(float4);
+    if (lds > 96*1024) return 0;                                    // a layer far larger than its target: the generic kernel
+    if (lds > 48*1024) hipFuncSetAttribute((const void*)k_multipass_layer1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    g_last_kernel = "k_multipass_layer1";
+    hipLaunchKernelGGL(k_multipass_layer1, dim3((a.wr + MP_BLOCK_W - 1)/MP_BLOCK_W, (a.hr + MP_BLOCK_H - 1)/MP_BLOCK_H, frames), dim3(MP_BLOCK_W, MP_BLOCK_H), lds, s,
+                       a, ctx->multipass_taps, tile_w, tile_h);
+    return 1;
+}
+static int launch_motionblur_layer1(const RenderArgs& a, int frames, hipStream_t s) {
+    static const bool off = [] { const char* e = getenv("SHADERFLOW_LAYERED_FAST"); return e && atoi(e) == 0; }();
+    const int temporal = (int)a.u.user[USER_SCREEN_TEMPORAL];
+    if (!LAYERED_FAST || off || a.u.iLayer != 1 || temporal < 1 || temporal > TEX_HISTORY_DEPTH) return 0;
+    const Tex& first = a.tex[TEX_HISTORY];
+    MotionblurArgs m{};
+    m.temporal = temporal;
+    for (int t = 0; t < temporal; t++) {
+        const Tex& layer = a.tex[TEX_HISTORY + t];
+        // one size, one sampler state: then addressing and weights of texture(iScreen{t}x0, astuv) are one computation per pixel
+        if (!layer.data || layer.dtype != DT_U8 || layer.components != 4 || layer.filter != FILTER_LINEAR || layer.width != first.width || layer.height != first.height
+            || layer.repeat_x != first.repeat_x || layer.repeat_y != first.repeat_y) return 0;
+        m.layer[t] = (const uint32_t*)layer.data;
+        m.factor[t] = sf::smoothstep(1.0f, 0.0f, (float)t/(float)temporal);                  // motionblur.frag:11
+    }
+    g_last_kernel = "k_motionblur_layer1";
+    hipLaunchKernelGGL(k_motionblur_layer1, dim3((a.wr + 63)/64, (a.hr + 3)/4, frames), dim3(64, 4), 0, s, a, m);
+    return 1;
+}
+
 static int launch_render(int fragment, const RenderArgs& a, int frames, hipStream_t s) {
     switch (fragment) {
         case FRAG_DEFAULT: launch_render_t<PlainShader<FRAG_DEFAULT>>(a, frames, s); break;
@@ -1283,8 +1334,16 @@ static int launch_render(int fragment, const RenderArgs& a, int frames, hipStrea
         case FRAG_SHADERTOY: launch_render_t<PlainShader<FRAG_SHADERTOY>>(a, frames, s); break;
         case FRAG_DYNAMICS: launch_render_t<PlainShader<FRAG_DYNAMICS>>(a, frames, s); break;
         case FRAG_AUDIO: launch_render_t<PlainShader<FRAG_AUDIO>>(a, frames, s); break;
-        case FRAG_MULTIPASS: launch_render_t<PlainShader<FRAG_MULTIPASS>>(a, frames, s); break;
-        case FRAG_MOTIONBLUR: launch_render_t<PlainShader<FRAG_MOTIONBLUR>>(a, frames, s); break;
+        case FRAG_MULTIPASS: {
+            const int fast = launch_multipass_layer1(a, frames, s);
+            if (fast != 0) return fast < 0 ? fast : SFX_OK;
+            launch_render_t<PlainShader<FRAG_MULTIPASS>>(a, frames, s); break;
+        }
+        case FRAG_MOTIONBLUR: {
+            const int fast = launch_motionblur_layer1(a, frames, s);
+            if (fast != 0) return fast < 0 ? fast : SFX_OK;
+            launch_render_t<PlainShader<FRAG_MOTIONBLUR>>(a, frames, s); break;
+        }
         case FRAG_LIFE_SIMULATION: launch_render_t<PlainShader<FRAG_LIFE_SIMULATION>>(a, frames, s); break;
         case FRAG_LIFE_VISUALS: launch_render_t<PlainShader<FRAG_LIFE_VISUALS>>(a, frames, s); break;
         case FRAG_VIDEO: launch_render_t<PlainShader<FRAG_VIDEO>>(a, frames, s); break;
@@ -2116,6 +2175,97 @@ extern "C" int sfx_ring_destroy(sfx_handle h) {
     for (auto& f : r->fences) hipEventDestroy(f);
     r->magic = 0;
     delete r;
+    return SFX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Clock sequence: the frame loop of scenes in which nothing but the clock moves, WITHOUT a host language between the frames.
+// scene.next (scene.py:456-479) → every program's render (shader.py:388-405: a draw per layer into row 0 of its texture matrix, then the
+// matrix rolls, texture.py:295-298) → iFinal's resolve → exporting.pipe (exporting.py:151-174), `nframes` times in one call. Per frame
+// the host side is: four stores per program (the clock uniforms), one pointer per sampler of a rolled matrix, the launches, one ring
+// hand-off — a few microseconds, where clockloop.ClockLoop's python needed ~70. The same launches with the same arguments in the same
+// order as ShaderScene.next, so the same frames (tests/test_gpu_multipass.py::test_clock_sequence_gives_the_frame_loops_bytes).
+static int resolve_sampler(const Program* p, const char* name) {
+    if (p->fragment == FRAG_JIT) { for (const auto& b : p->bindings) if (b.sampler && b.name == name) return b.slot; return -1; }
+    return sampler_slot(p->fragment, name);
+}
+extern "C" int sfx_clock_sequence_run(sfx_handle hc, const sfx_sequence_pass* passes, int npasses, const sfx_sequence_matrix* matrices, int nmatrices,
+                                      const sfx_clock_tick* clock, int nframes, sfx_handle hring, int first_slot, int fd,
+                                      void* const* planar_slots, int yuv_matrix, int width, int height) {
+    CTX_OR_FAIL(c, hc);
+    Ring* ring = hring ? get<Ring>(hring, MAGIC_RING) : nullptr;
+    if (!passes || npasses < 1 || nmatrices < 0 || (nmatrices && !matrices) || !clock || nframes < 0) return fail(SFX_E_INVALID, "clock sequence: null tables");
+    if (hring && !ring) return fail(SFX_E_INVALID, "clock sequence: invalid ring handle");
+    USE_DEVICE(c);
+    // the matrices as this call rolls them: order[m][t] = row of the caller's table that sits at depth t now
+    std::vector<std::vector<int>> order(nmatrices);
+    for (int m = 0; m < nmatrices; m++) {
+        if (matrices[m].temporal < 1 || matrices[m].layers < 1 || !matrices[m].textures) return fail(SFX_E_INVALID, "clock sequence: matrix %d", m);
+        order[m].resize(matrices[m].temporal);
+        for (int t = 0; t < matrices[m].temporal; t++) order[m][t] = t;
+    }
+    auto box = [&](int m, int t, int l) -> sfx_handle { return matrices[m].textures[order[m][t]*matrices[m].layers + (l < 0 ? matrices[m].layers + l : l)]; };
+    // sampler slots of every (program, named box), resolved once: the names never change, only what sits behind them
+    struct Bind { Program* p; int slot, m, t, l; };
+    std::vector<Bind> binds;
+    for (int k = 0; k < npasses; k++) {
+        if (passes[k].kind == SFX_PASS_RESOLVE) continue;
+        Program* p = get<Program>(passes[k].program, MAGIC_PROG);
+        if (!p || p->ctx != c) return fail(SFX_E_INVALID, "clock sequence: pass %d has no program of this context", k);
+        if (passes[k].matrix < 0 || passes[k].matrix >= nmatrices) return fail(SFX_E_INVALID, "clock sequence: pass %d names matrix %d", k, passes[k].matrix);
+        for (int m = 0; m < nmatrices; m++) {
+            if (!matrices[m].names || matrices[m].temporal < 2) continue;     // (samplers of a matrix that never rolls were bound by the host)
+            for (int t = 0; t < matrices[m].temporal; t++) for (int l = 0; l < matrices[m].layers; l++) {
+                const char* name = matrices[m].names[t*matrices[m].layers + l];
+                const int slot = name ? resolve_sampler(p, name) : -1;
+                if (slot >= 0) binds.push_back({p, slot, m, t, l});
+            }
+        }
+    }
+    for (int f = 0; f < nframes; f++) {
+        const sfx_clock_tick& now = clock[f];
+        bool fused = false;
+        for (int k = 0; k < npasses; k++) {
+            const sfx_sequence_pass& pass = passes[k];
+            if (pass.kind == SFX_PASS_RESOLVE) {
+                if (fused) continue;                                // the main pass resolved into iFinal already (shader.py:391-396)
+                if (pass.matrix < 0 || pass.matrix >= nmatrices) return fail(SFX_E_INVALID, "clock sequence: resolve pass %d names matrix %d", k, pass.matrix);
+                const int rc = sfx_resolve(hc, box(pass.matrix, 0, -1), pass.target, pass.subsample);
+                if (rc) return rc;
+                continue;
+            }
+            Program* p = get<Program>(pass.program, MAGIC_PROG);
+            p->u.iTime = now.time; p->u.iTau = now.tau; p->u.iDeltatime = now.deltatime; p->u.iFrame = now.frame;      // sfx_uniform_set_clock
+            for (const Bind& b : binds) if (b.p == p) b.p->samplers[b.slot] = get<Texture>(box(b.m, b.t, b.l), MAGIC_TEX);
+            if (pass.kind == SFX_PASS_FUSED) {
+                const int rc = sfx_render_resolve(pass.program, pass.target, pass.ssaa, pass.subsample);
+                if (rc) return rc;
+                fused = true;
+            } else {
+                for (int l = 0; l < matrices[pass.matrix].layers; l++) {
+                    const int rc = sfx_render(pass.program, box(pass.matrix, 0, l), l);      // shader.py:400-403: iLayer = l, into row 0
+                    if (rc) return rc;
+                }
+            }
+            std::vector<int>& rows = order[pass.matrix];              // texture.roll(): the oldest row becomes row 0
+            std::rotate(rows.begin(), rows.end() - 1, rows.end());
+        }
+        if (ring && fd >= 0) {                                      // exporting.pipe (exporting.py:151-174)
+            const int slot = (first_slot + f) % ring->slots;
+            int rc;
+            if (planar_slots) {
+                if ((rc = sfx_ring_pipe_sync(hring, slot))) return rc;
+                Texture* final_texture = get<Texture>(passes[npasses - 1].target, MAGIC_TEX);
+                if (!final_texture) return fail(SFX_E_INVALID, "clock sequence: the last pass has no target to convert");
+                if ((rc = sfx_rgb_to_yuv420(hc, final_texture->data, planar_slots[slot], width, height, 1, yuv_matrix))) return rc;
+                rc = sfx_ring_read_device_async(hring, planar_slots[slot], slot);
+            } else {
+                rc = sfx_ring_read_async(hring, passes[npasses - 1].target, slot);
+            }
+            if (rc) return rc;
+            if ((rc = sfx_ring_pipe(hring, slot, fd))) return rc;
+        }
+    }
     return SFX_OK;
 }
 

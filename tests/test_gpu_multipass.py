@@ -295,11 +295,25 @@ def test_clock_loop_gives_the_frame_loops_bytes(name, monkeypatch):
     runs = []
     original = ClockLoop.run
     monkeypatch.setattr(ClockLoop, "run", lambda self, export, turbo: (runs.append(name), original(self, export, turbo))[1])
-    lean = build(True).main(**kw)
-    assert runs == [name]
+    natives = []
+    native = ClockLoop.run_native
+    monkeypatch.setattr(ClockLoop, "run_native", lambda self, *args: (natives.append(name), native(self, *args))[1])
+    lean = build(True).main(**kw)                                     # the native sequence: one C call per chunk of frames
+    assert runs == [name] and natives == [name]
+    monkeypatch.setenv("SHADERFLOW_CLOCK_SEQUENCE", "0")
+    python = build(True).main(**kw)                                   # the same loop with python between the frames
+    assert runs == [name, name] and natives == [name]
     loop = build(False).main(**kw)
-    assert runs == [name] and len(lean) == len(loop) == 14*96*54*3
+    assert runs == [name, name] and len(lean) == len(loop) == 14*96*54*3
     assert lean == loop, f"{np.count_nonzero(np.frombuffer(lean, np.uint8) != np.frombuffer(loop, np.uint8))} bytes differ"
+    assert python == loop
+    # … and as yuv420p (the conversion and the read-out of every frame inside the native call)
+    monkeypatch.delenv("SHADERFLOW_CLOCK_SEQUENCE")
+    planar = build(True).main(pixel_format="yuv420p", **kw)
+    assert natives == [name, name] and planar == build(False).main(pixel_format="yuv420p", **kw) and len(planar) == 14*96*54*3//2
+    # a chunk boundary in the middle of the temporal history (MotionBlur keeps ten frames): three frames per native call
+    monkeypatch.setattr(ClockLoop, "CHUNK", 3)
+    assert build(True).main(**kw) == loop
     # a scene with python logic between frames never qualifies, nor one whose DynamicNumbers are still moving
     scripted = scenes.make(scenes.Dynamics, background=synth.background_image(120, 68, seed=4))
     scripted.initialize()

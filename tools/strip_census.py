@@ -31,6 +31,8 @@ sys.path.insert(0, __file__.rsplit("/", 1)[0])
 from isa_census import CLASSES, VALU  # noqa: E402
 
 CYCLES = {name: cycles for name, _, cycles in CLASSES}
+# the files k_visualizer_strip is compiled from (bench.py ties the census to them, not to the whole library)
+STRIP_SOURCES = ("visualizer_fast.hpp", "visualizer_kernels.hpp", "render_kernels.hpp", "fragments.hpp", "glsl.hpp", "sfmath.hpp", "Makefile")
 
 
 def vf_lines(block) -> collections.Counter:
@@ -50,14 +52,52 @@ def other_lines(block) -> collections.Counter:
     return out
 
 
+def source_ranges(path: str) -> dict:
+    """Line ranges of the kernel's phases in visualizer_fast.hpp, from the markers in its text (the listing's .loc lines refer to them)"""
+    text = open(path).read().split("\n")
+    def find(needle: str, after: int = 0) -> int:
+        for number, line in enumerate(text, 1):
+            if number > after and needle in line:
+                return number
+        raise SystemExit(f"marker '{needle}' not found in {path}")
+    strip = find("struct VisualizerStrip {")
+    marks = {
+        "post_fn": (find("__device__ __forceinline__ uint32_t visualizer_fast_post("), find("// Stages the window")),
+        "stage_fn": (find("__device__ __forceinline__ void visualizer_fast_stage("), find("// ---- the fused kernel ----")),
+        "blur_direct": (find("__device__ static void blur_direct("), find("__device__ static void run(const RenderArgs& a, const VisTables& t) {")),
+        "load_cell": (find("__device__ __forceinline__ static void load_cell(", strip), find("template <class T> __device__ __forceinline__ static float F(", strip)),
+        "rowline": (find("// ---- the row-lines:", strip), find("// row-lines", strip)),
+        "colline": (find("// ---- the column-lines:", strip), find("// column-lines", strip)),
+        "diag": (find("// ---- the four diagonal directions:", strip), find("// diagonals", strip)),
+        "post": (find("// ---- visualizer.frag:36-73 per sample", strip), find("// post-processing", strip)),
+        "resolve": (find("// every wave is done with the cells", strip), find("// barrier + texel exchange + resolve + barrier", strip)),
+        "diag_setup_end": (find("#pragma unroll VIS_STRIP_DIAG_UNROLL", strip),)*2,
+        "advance_use": (find("acc[r][0] = acc[r][0] + U[side][0];", strip),)*2,
+        "pow_line": (find("col = col*ColourMath<true>::pow((len - rr)*0.5f, 0.05f);"),)*2,
+        "mix_line": (find("if (len < rr) col = mix(col, vec3{1.0f, 1.0f, 1.0f}, smoothstep01(0.5f + bar));"),)*2,
+        "strips_line": (find("if (strip_top) { col = col*0.8f; opacity = opacity*0.8f; }"),)*2,
+        "smoothstep01": (find("__device__ __forceinline__ float smoothstep01("),)*2,
+        "store": (find("// barrier + texel exchange + resolve + barrier", strip), find("template <int TILE_PITCH, int TILE_ROWS, int S, int WALK, int MIN_WAVES", strip)),
+        "sweep": (find("constexpr int GROUPS = BLOCK_PX*3/16;", strip), find("// the sweep of stores", strip)),
+    }
+    return marks
+
+
+def within(lines, span) -> bool:
+    return any(span[0] <= line <= span[1] for line in lines)
+
+
 def main() -> None:
     parser = argparse.ArgumentParser()
+    parser.add_argument("--source", default=__file__.rsplit("/", 2)[0] + "/shaderflow_amd/csrc/visualizer_fast.hpp")
     parser.add_argument("blocks")
     parser.add_argument("bench", nargs="?")
     parser.add_argument("--folds", type=float, default=53.0, help="diagonal folds per wave measured by the -DSF_SECTION_TIMERS build")
     parser.add_argument("--exact", type=float, default=0.02)
+    parser.add_argument("--json", help="write the prices bench.py's issue_model reads (profiles/r05_strip_isa_census.json)")
     args = parser.parse_args()
     blocks = json.load(open(args.blocks))
+    M = source_ranges(args.source)
     p = (args.folds - 20.0)/160.0
     rates = {"fold_first": 1.0, "fold_next": p, "row_folds": 1.0 + 8.0*p, "column_iterations": 8.0 + 8.0*p, "exact": args.exact,
              "pow_branch": 0.95, "mix_branch": 0.30, "strips": 0.06, "staging_rounds": 864.0/512.0, "resolve_rounds": 2.25}
@@ -72,25 +112,25 @@ def main() -> None:
         n = sum(block["counts"].values())
         lines, others = vf_lines(block), other_lines(block)
         top = lines.most_common(1)[0][0] if lines else 0
-        if phase == "prologue" and any(586 <= line <= 611 for line in lines):
+        if phase == "prologue" and within(lines, M["rowline"]):
             phase = "rowline"
-        if phase == "rowline" and any(613 <= line <= 655 for line in lines):
+        if phase == "rowline" and within(lines, M["colline"]):
             phase = "colline"
-        if phase == "colline" and any(658 <= line <= 680 for line in lines):
+        if phase == "colline" and within(lines, (M["diag"][0], M["diag_setup_end"][0] + 6)):
             phase = "diag"
-        if phase == "diag" and any(728 <= line <= 737 for line in lines):
+        if phase == "diag" and within(lines, M["post"]):
             phase = "post"
-        if phase == "post" and any(747 <= line <= 770 for line in lines) and not any(191 <= line <= 271 for line in lines):
+        if phase == "post" and within(lines, M["resolve"]) and not within(lines, M["post_fn"]):
             phase = "resolve"
-        if phase == "resolve" and any(line >= 771 for line in lines) and not any(line < 771 for line in lines):
+        if phase == "resolve" and within(lines, (M["store"][0] + 1, M["store"][1])) and not any(line <= M["store"][0] for line in lines):
             phase = "store"
 
         if phase == "prologue":
-            if any(334 <= line <= 362 for line in lines) or (n in (83, 84) and "vmem" in block["counts"]):
+            if within(lines, M["blur_direct"]) or (n in (83, 84) and "vmem" in block["counts"]):
                 weights[i], why[i] = 0.0, "blur_direct (a window off its tile: never at C3)"
             elif any("glsl.hpp:8" in line for line in others) and not lines:
                 weights[i], why[i] = rates["staging_rounds"]*0.02, "wrap_texel's modulo (texels outside the texture: the frame's rim)"
-            elif any(278 <= line <= 308 for line in lines):
+            elif within(lines, M["stage_fn"]):
                 weights[i], why[i] = rates["staging_rounds"], "staging loop"
             else:
                 weights[i], why[i] = 1.0, "prologue"
@@ -111,12 +151,12 @@ def main() -> None:
                 weights[i], why[i] = 1.0, "column-line set-up"
         elif phase == "diag":
             fold = n in (28, 29) and "lds" in block["counts"]
-            skip_path = (not block["counts"].get("lds")) and all(cls in ("salu", "branch", "mov", "waitcnt") for cls in block["counts"]) and n <= 14 and top in (0, 715) and i > 0 and "diagonal set-up" not in why[i - 1]
+            skip_path = (not block["counts"].get("lds")) and all(cls in ("salu", "branch", "mov", "waitcnt") for cls in block["counts"]) and n <= 14 and not within(lines, (M["diag"][0], M["diag_setup_end"][0] + 12)) and i > 0 and "diagonal set-up" not in why[i - 1]
             if fold:
                 diag_fold_seen += 1
                 weights[i] = 10.0*(1.0 if diag_fold_seen <= 2 else p)
                 why[i] = "diagonal fold"
-            elif any(658 <= line <= 675 for line in lines) and n > 60:
+            elif within(lines, (M["diag"][0], M["diag_setup_end"][0])) and n > 60:
                 weights[i], why[i] = 1.0, "diagonal set-up"
             elif skip_path and re.fullmatch(r"\.LBB\d+_\d+", block["label"]) and block["counts"].get("salu", 0) >= 2 and not block["counts"].get("smem"):
                 weights[i], why[i] = 0.0, "rows beyond the frame (never inside it)"
@@ -130,20 +170,29 @@ def main() -> None:
                 weights[i], why[i] = 9.0*0.0, "wrap_texel's modulo (bin outside the texture: never)"
             elif "sfmath.hpp:110" in text or "sfmath.hpp:99" in text or "glsl.hpp:403" in text or "__clang_hip_math.h:722" in text:
                 weights[i], why[i] = rates["exact"], "exact polar chain (speculation re-run)"
-            elif 249 in lines or "fragments.hpp:0" in text:
+            elif M["pow_line"][0] in lines or "fragments.hpp:0" in text:
                 weights[i], why[i] = rates["pow_branch"], "pow((len - r)/2, 0.05): lanes beyond their bar"
-            elif top == 188 and 248 in lines:
+            elif top == M["smoothstep01"][0] and M["mix_line"][0] in lines:
                 weights[i], why[i] = rates["mix_branch"], "mix towards white: lanes inside a bar"
-            elif 262 in lines or (top == 0 and n <= 3 and i > 0 and "strips" in why[i - 1]):
+            elif M["strips_line"][0] in lines or (top == 0 and n <= 3 and i > 0 and "strips" in why[i - 1]):
                 weights[i], why[i] = rates["strips"], "waveform strips / out-of-aspect bars"
             else:
                 weights[i], why[i] = 1.0, "post"
         elif phase == "resolve":
-            loop = any(754 <= line <= 766 for line in lines) or any("render_kernels.hpp:30" in k or "render_kernels.hpp:28" in k or "render_kernels.hpp:0" in k for k in others)
+            loop = within(lines, (M["resolve"][0] + 6, M["resolve"][1] - 2)) or any("render_kernels.hpp:30" in k or "render_kernels.hpp:28" in k or "render_kernels.hpp:0" in k for k in others)
             weights[i], why[i] = (rates["resolve_rounds"] if loop else 1.0), "texel exchange + resolve"
         else:
-            sweep = any(775 <= line <= 783 for line in lines)
-            weights[i], why[i] = (1.0 if sweep or any(line in (769, 774, 777) for line in lines) else 0.0), ("sweep store" if sweep else "store (row-by-row fallback: not at C3)")
+            sweep = within(lines, M["sweep"])
+            weights[i], why[i] = (1.0 if sweep or within(lines, (M["store"][0], M["sweep"][0] + 2)) else 0.0), ("sweep store" if sweep else "store (row-by-row fallback: not at C3)")
+
+    # two column loops in the listing = the aligned-table loop and its fallback (a strip spanning more cells than the table holds: never
+    # at C3): the fallback does not run
+    loops = [i for i, reason in enumerate(why) if reason == "column-line loop body"]
+    if len(loops) > 1:
+        keep = min(loops, key=lambda i: blocks[i]["counts"].get("salu", 0))
+        for i in loops:
+            if i != keep:
+                weights[i], why[i] = 0.0, "column-line fallback loop (never at C3)"
 
     # ---- totals ---------------------------------------------------------------------------------------------------------------------
     by_phase: dict[str, collections.Counter] = collections.defaultdict(collections.Counter)
@@ -198,6 +247,21 @@ def main() -> None:
     other_count = sum(total[c] for c in other_classes)
     print(f"\n'other' (no hardware class counter): {other_count/samples:.1f} per supersample = " + ", ".join(f"{c} {total[c]/samples:.1f}" for c in other_classes if total[c] > 0.05*samples))
     print(f"  priced by class: {other_cycles/other_count:.3f} issue cycles per instruction (bench.py issue_model: OTHER_CYCLES)")
+    if args.json:
+        import hashlib
+        from pathlib import Path
+        csrc = Path(args.source).parent
+        digest = hashlib.sha256()
+        for name in STRIP_SOURCES:
+            digest.update(name.encode()); digest.update((csrc/name).read_bytes())
+        json.dump({"kernel": "k_visualizer_strip<72, 12, 2, 9, 8, 4, false>", "strip_sources_fingerprint": digest.hexdigest()[:16],
+                   "other_cycles_per_instruction": round(other_cycles/other_count, 4),
+                   "sgpr_source_full_rate_forms_per_valu_instruction": round(sgpr/valu_total, 5),
+                   "valu_instructions_per_supersample_modelled": round(valu_total/samples, 2),
+                   "average_issue_cycles_per_valu_instruction": round(cycles_total/(valu_total/samples), 4),
+                   "other_by_class_per_supersample": {c: round(total[c]/samples, 2) for c in other_classes if total[c] > 0},
+                   "event_rates": rates, "how": "tools/strip_census.py on tools/isa_census.py --dump of the -gline-tables-only listing; prices: profiles/r02_ubench_valu.txt, r05_ubench_valu_sgpr.txt"},
+                  open(args.json, "w"), indent=1)
 
 
 if __name__ == "__main__":
