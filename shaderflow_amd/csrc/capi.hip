@@ -312,6 +312,15 @@ static hipError_t frame_copy(void* dst, const void* src, size_t nbytes, hipStrea
     return hipGetLastError();
 }
 
+// A frame is complete on the render stream: polled for ~200 us before the thread blocks (hipEventSynchronize wakes up late: see finish())
+static void wait_frame_ready(hipEvent_t event) {
+    const auto started = std::chrono::steady_clock::now();
+    while (hipEventQuery(event) == hipErrorNotReady) {
+        if (std::chrono::steady_clock::now() - started > std::chrono::microseconds(200)) { hipEventSynchronize(event); return; }
+        __builtin_ia32_pause();
+    }
+}
+
 struct EngineLanes {
     Context* c = nullptr;
     EngineCopy* e = nullptr;                                        // null: the lanes are the context's copy streams
@@ -354,6 +363,11 @@ struct EngineLanes {
         busy[lane] = true; via_hsa[lane] = false;
         return true;
     }
+    // ~200 us in HSA's timestamp ticks (the hint of an ACTIVE wait)
+    static uint64_t poll_ticks() {
+        static const uint64_t ticks = [] { uint64_t hz = 0; return (hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &hz) == HSA_STATUS_SUCCESS && hz) ? hz/5000 : 20000; }();
+        return ticks;
+    }
     // has the lane's copy ended (either way)? never blocks
     bool landed(int lane) const {
         if (!busy[lane]) return true;
@@ -366,8 +380,11 @@ struct EngineLanes {
         bool ok = true;
         if (via_hsa[lane]) {
             // the wait may return before the condition holds (the specification allows spurious returns): ask again until it does;
-            // a failed copy leaves the signal NEGATIVE, which satisfies "< 1" as well, so the value itself is looked at
-            while (hsa_signal_wait_scacquire(done[lane], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+            // a failed copy leaves the signal NEGATIVE, which satisfies "< 1" as well, so the value itself is looked at.
+            // Polled first: a blocked wait is woken by an interrupt tens of microseconds after the copy ended, which at 1080p (a frame
+            // every 60-110 us) is a large part of the frame; after ~200 us of polling the thread blocks like before.
+            if (hsa_signal_wait_scacquire(done[lane], HSA_SIGNAL_CONDITION_LT, 1, poll_ticks(), HSA_WAIT_STATE_ACTIVE) >= 1)
+                while (hsa_signal_wait_scacquire(done[lane], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
             ok = hsa_signal_load_relaxed(done[lane]) == 0;
         } else {
             ok = hipStreamSynchronize(c->copy_streams[lane & 1]) == hipSuccess;   // (a stream's later copy too: in order, so nothing is released early)
@@ -587,7 +604,7 @@ static void peer_copier(PeerCopier* p) {
             job = p->queue.front(); p->queue.pop_front();
         }
         for (int lane = 0; lane < EngineLanes::LANES; lane++) if (in_lane[lane] >= 0 && p->lanes.landed(lane)) finish(lane);
-        hipEventSynchronize(p->ready[job.tag]);                      // the source is complete on the render stream
+        wait_frame_ready(p->ready[job.tag]);                         // the source is complete on the render stream
         finish(next);
         p->lanes.resolve(p->ctx, job.dst, job.src, true);
         if (!p->lanes.issue(next, job.dst, job.src, job.nbytes)) {
@@ -1269,7 +1286,7 @@ static int launch_multipass_layer1(const RenderArgs& a, int frames, hipStream_t 
     if (lds > 96*1024) return 0;                                    // a layer far larger than its target: the generic kernel
     if (lds > 48*1024) hipFuncSetAttribute((const void*)k_multipass_layer1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     g_last_kernel = "k_multipass_layer1";
-    hipLaunchKernelGGL(k_multipass_layer1, dim3((a.wr + MP_BLOCK_W - 1)/MP_BLOCK_W, (a.hr + MP_BLOCK_H - 1)/MP_BLOCK_H, frames), dim3(MP_BLOCK_W, MP_BLOCK_H), lds, s,
+    hipLaunchKernelGGL(k_multipass_layer1, dim3((a.wr + MP_BLOCK_W - 1)/MP_BLOCK_W, (a.hr + MP_BLOCK_H - 1)/MP_BLOCK_H, frames), dim3(MP_BLOCK_W, MP_BLOCK_H/MP_ROWS), lds, s,
                        a, ctx->multipass_taps, tile_w, tile_h);
     return 1;
 }
@@ -1969,7 +1986,7 @@ static void ring_copier(Ring* r) {
         static const bool trace = getenv("SHADERFLOW_RING_TRACE") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
         release_landed();
-        hipEventSynchronize(job.ready);                              // the frame is complete on the render stream
+        wait_frame_ready(job.ready);                                 // the frame is complete on the render stream
         const auto t1 = std::chrono::steady_clock::now();
         release_landed();
         finish(next);                                                // the lane's previous copy

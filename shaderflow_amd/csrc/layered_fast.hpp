@@ -43,11 +43,14 @@ inline void multipass_tap_table(MultipassTaps& t, float radius, int directions, 
     }
 }
 
-constexpr int MP_BLOCK_W = 64, MP_BLOCK_H = 8;
+#ifndef MP_ROWS_PER_THREAD
+#define MP_ROWS_PER_THREAD 2
+#endif
+constexpr int MP_BLOCK_W = 64, MP_BLOCK_H = 8, MP_ROWS = MP_ROWS_PER_THREAD, MP_THREADS = MP_BLOCK_W*MP_BLOCK_H/MP_ROWS;
 
-// One thread per pixel of a 64 x 8 block. The tile: the texels of iScreen0x0 under the block plus the blur's reach, wrapped as the
+// 64 x 8 pixels per block, MP_ROWS of a column per thread. The tile: the texels of iScreen0x0 under the block plus the blur's reach, wrapped as the
 // sampler wraps (so a tap indexes it without any clamp), four floats per texel (texel() of glsl.hpp applied once), in dynamic LDS.
-__global__ __launch_bounds__(MP_BLOCK_W*MP_BLOCK_H) void k_multipass_layer1(const RenderArgs a, const MultipassTaps* __restrict__ taps, int tile_w, int tile_h) {
+__global__ __launch_bounds__(MP_THREADS) void k_multipass_layer1(const RenderArgs a, const MultipassTaps* __restrict__ taps, int tile_w, int tile_h) {
     extern __shared__ __attribute__((aligned(16))) float4 mp_tile[];
     __shared__ float tap_x[LAYERED_MAX_TAPS], tap_y[LAYERED_MAX_TAPS], tap_w[LAYERED_MAX_TAPS];
     const int tid = threadIdx.y*MP_BLOCK_W + threadIdx.x;
@@ -70,54 +73,74 @@ __global__ __launch_bounds__(MP_BLOCK_W*MP_BLOCK_H) void k_multipass_layer1(cons
     const int tw = x1 - x0 + 1, th = y1 - y0 + 1;
     const bool tiled = any_right && tw <= tile_w && th <= tile_h;                          // (a block of the left half reads one texel per pixel: no tile)
     if (tiled) {
-        for (int e = tid; e < tw*th; e += MP_BLOCK_W*MP_BLOCK_H) {
+        for (int e = tid; e < tw*th; e += MP_THREADS) {
             const int ty = e / tw, tx = e - ty*tw;
             const vec4 c = texel(first, wrap_texel(x0 + tx, first.width, first.repeat_x), wrap_texel(y0 + ty, first.height, first.repeat_y));
             mp_tile[e] = make_float4(c.x, c.y, c.z, c.w);
         }
     }
-    if (any_right) for (int e = tid; e < count && e < LAYERED_MAX_TAPS; e += MP_BLOCK_W*MP_BLOCK_H) { tap_x[e] = taps->ox[e]; tap_y[e] = taps->oy[e]; tap_w[e] = taps->weight[e]; }
+    if (any_right) for (int e = tid; e < count && e < LAYERED_MAX_TAPS; e += MP_THREADS) { tap_x[e] = taps->ox[e]; tap_y[e] = taps->oy[e]; tap_w[e] = taps->weight[e]; }
     __syncthreads();
-    if (i >= a.wr || j >= a.hr) return;
-    make_varyings(f, i, j, a.wr, a.hr, a.aspect, a.inv_wr, a.inv_hr);
+    if (i >= a.wr) return;
 
     // the tile's byte offset of texel (fu, fv) in FLOAT arithmetic (small integers: exact), one conversion instead of two plus an integer
     // multiply: 16*((fv - y0)*tw + (fu - x0)) = fv*tw16 + (fu*16 - origin)
     const float tw16 = (float)(tw*16), origin = (float)((y0*tw + x0)*16);
     const char* tile_bytes = (const char*)mp_tile;
     const int up = tw*16;
-    vec4 col;
-    if (f.gluv.x < 0.0f) {                                                                 // multipass.frag:35, 38-39
-        col = texture(first, f.astuv);
-        col.x = 1.0f - col.x;
-    } else {
-        vec4 color = {0.0f, 0.0f, 0.0f, 0.0f};                                             // :11
-#pragma unroll 3
-        for (int k = 0; k < count; k++) {
-            const vec2 uv = f.astuv + vec2{tap_x[k], tap_y[k]};                            // :18 texture(image, stuv + offset)
-            vec4 sample;
-            if (tiled) {
-                // texture() of glsl.hpp, LINEAR: the same operations; the four texels from the tile (already wrapped, already floats)
-                const float u = uv.x*W, v = uv.y*H;
-                const float ub = u - 0.5f, vb = v - 0.5f;
-                const float fu = ::floorf(ub), fv = ::floorf(vb);
-                const float ax = ub - fu, by = vb - fv;
-                const char* cell = tile_bytes + (int)fmaf(fv, tw16, fmaf(fu, 16.0f, -origin));
-                const float4 t00 = *(const float4*)cell, t10 = *(const float4*)(cell + 16), t01 = *(const float4*)(cell + up), t11 = *(const float4*)(cell + up + 16);
-                const float na = 1.0f - ax, nb = 1.0f - by;
-                const float w00 = na*nb, w10 = ax*nb, w01 = na*by, w11 = ax*by;
-                sample = {bilerp(w00, w10, w01, w11, t00.x, t10.x, t01.x, t11.x), bilerp(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y),
-                          bilerp(w00, w10, w01, w11, t00.z, t10.z, t01.z, t11.z), 1.0f};   // (alpha is overwritten below: never computed)
-            } else {
-                sample = texture(first, uv);
-            }
-            const float weight = tap_w[k];
-            color = color + sample*weight;                                                 // :20
-        }
-        col = color/taps->weights;                                                         // :25
+    // MP_ROWS pixels per thread (rows threadIdx.y and threadIdx.y + MP_BLOCK_H/MP_ROWS of the block): two independent chains of LDS
+    // reads and multiply-adds per tap, one read of the tap table for both
+    vec2 astuv[MP_ROWS]; vec4 color[MP_ROWS]; bool inside[MP_ROWS], left[MP_ROWS]; bool any_blur = false;
+#pragma unroll
+    for (int q = 0; q < MP_ROWS; q++) {
+        const int jq = j + q*(MP_BLOCK_H/MP_ROWS);
+        inside[q] = jq < a.hr;
+        make_varyings(f, i, inside[q] ? jq : j, a.wr, a.hr, a.aspect, a.inv_wr, a.inv_hr);
+        astuv[q] = f.astuv; left[q] = f.gluv.x < 0.0f;
+        color[q] = {0.0f, 0.0f, 0.0f, 0.0f};                                               // :11
+        any_blur = any_blur || (inside[q] && !left[q]);
     }
-    col.w = 1.0f;                                                                          // :44
-    store_target(a, blockIdx.z, i, j, col);
+    if (any_blur) {
+#pragma unroll 2
+        for (int k = 0; k < count; k++) {
+            const vec2 offset = {tap_x[k], tap_y[k]};
+            const float weight = tap_w[k];
+#pragma unroll
+            for (int q = 0; q < MP_ROWS; q++) {
+                const vec2 uv = astuv[q] + offset;                                         // :18 texture(image, stuv + offset)
+                vec4 sample;
+                if (tiled) {
+                    // texture() of glsl.hpp, LINEAR: the same operations; the four texels from the tile (already wrapped, already floats)
+                    const float u = uv.x*W, v = uv.y*H;
+                    const float ub = u - 0.5f, vb = v - 0.5f;
+                    const float fu = ::floorf(ub), fv = ::floorf(vb);
+                    const float ax = ub - fu, by = vb - fv;
+                    const char* cell = tile_bytes + (int)fmaf(fv, tw16, fmaf(fu, 16.0f, -origin));
+                    const float4 t00 = *(const float4*)cell, t10 = *(const float4*)(cell + 16), t01 = *(const float4*)(cell + up), t11 = *(const float4*)(cell + up + 16);
+                    const float na = 1.0f - ax, nb = 1.0f - by;
+                    const float w00 = na*nb, w10 = ax*nb, w01 = na*by, w11 = ax*by;
+                    sample = {bilerp(w00, w10, w01, w11, t00.x, t10.x, t01.x, t11.x), bilerp(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y),
+                              bilerp(w00, w10, w01, w11, t00.z, t10.z, t01.z, t11.z), 1.0f};   // (alpha is overwritten below: never computed)
+                } else {
+                    sample = texture(first, uv);
+                }
+                color[q] = color[q] + sample*weight;                                       // :20
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MP_ROWS; q++) {
+        if (!inside[q]) continue;
+        vec4 col;
+        if (left[q]) {                                                                     // multipass.frag:35, 38-39
+            col = texture(first, astuv[q]);
+            col.x = 1.0f - col.x;
+        } else {
+            col = color[q]/taps->weights;                                                  // :25
+        }
+        col.w = 1.0f;                                                                      // :44
+        store_target(a, blockIdx.z, i, j + q*(MP_BLOCK_H/MP_ROWS), col);
+    }
 }
 
 // ---- motionblur.frag:8-15 -----------------------------------------------------------------------------------------------------------
