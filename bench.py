@@ -653,8 +653,9 @@ def main() -> None:
             "ms_per_step": round(elapsed/max(1, args.steps)*1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{scene_class.__name__} scene {w}x{h} {s}xSSAA subsample 2, 60 fps, {seconds:.0f} s synthetic stereo sine sweep @44.1 kHz, "
-                                   f"1920x1080 synthetic background; step = {fpb} frames (STFT + filterbank + dynamics tape, column/row tables, fused fragment+resolve)",
+            "config": {"workload": f"{scene_class.__name__} scene {w}x{h} {s}xSSAA subsample 2, 60 fps, {seconds:.0f} s synthetic stereo sine sweep @44.1 kHz"
+                                   + (f" (BASELINE's 60 s clip grown so that each of the {world}x({args.warmup}+{args.steps}) steps renders {fpb} NEW frames: same per-frame work)" if seconds > args.seconds else "")
+                                   + f", 1920x1080 synthetic background; step = {fpb} frames (STFT + filterbank + dynamics tape, column/row tables, fused fragment+resolve)",
                        "frames_per_step": fpb, "global_frames_per_step": fpb*world,
                        "parallelism": f"contiguous frame range per rank x{world}" + (f", every step sent to rank 0 {'as SDMA peer copies (IPC windows)' if sdma else 'over ' + dist.get_backend()} in {parts} pieces" if distributed else ""),
                        "ranks": world, "filterbank": "mfma" if tape.use_mfma else "csr"},

@@ -1118,6 +1118,24 @@ static void fill_args(const Program* p, RenderArgs& a) {
     a.top_down = p->ctx->top_down;
     a.tile_misses = p->ctx->tile_misses;
     a.quads = samples_mipmaps(p) ? 1 : 0;                           // the unfused kernel lays its lanes out as 2 x 2 quads: implicit derivatives
+    // a camera rolled about its forward axis (and zoomed / panned): iCamera.gluv is affine in gluv — three evaluations of get_camera give
+    // the map the LDS-tiled visualizer kernels bound their blocks' windows with (visualizer_kernels.hpp setup 1a')
+    a.affine_camera = 0;
+    const Uniforms& u = a.u;
+    if (!a.identity_camera && !a.axis_camera && u.iCameraProjection == 0) {
+        // (whether the map IS affine is measured, not read off the basis vectors: a rotation by quaternions leaves 1e-17 in components
+        // that are zero on paper. Three evaluations define the map, two more — at far corners of the screen — must land on it.)
+        auto at = [&](float gx, float gy) { Frag f{}; f.u = &u; f.aspect = a.aspect; f.gluv = vec2{gx, gy}; f.agluv = f.gluv/vec2{a.aspect, 1.0f}; return get_camera(f).gluv; };
+        const vec2 origin = at(0.0f, 0.0f), along_x = at(1.0f, 0.0f), along_y = at(0.0f, 1.0f);
+        auto predicted = [&](float gx, float gy) { return vec2{origin.x + gx*(along_x.x - origin.x) + gy*(along_y.x - origin.x), origin.y + gx*(along_x.y - origin.y) + gy*(along_y.y - origin.y)}; };
+        auto lands = [&](float gx, float gy) { const vec2 is = at(gx, gy), want = predicted(gx, gy); return fabsf(is.x - want.x) < 1e-4f*(1.0f + fabsf(want.x)) && fabsf(is.y - want.y) < 1e-4f*(1.0f + fabsf(want.y)); };
+        if (lands(-a.aspect, 1.0f) && lands(a.aspect, -0.8f) && fabsf(origin.x) < 1e6f && fabsf(origin.y) < 1e6f) {
+            a.affine_camera = 1;
+            a.cam_affine[0] = origin.x; a.cam_affine[1] = origin.y;
+            a.cam_affine[2] = along_x.x - origin.x; a.cam_affine[3] = along_x.y - origin.y;
+            a.cam_affine[4] = along_y.x - origin.x; a.cam_affine[5] = along_y.y - origin.y;
+        }
+    }
 }
 
 // RN(1/n) if glsl.hpp pixel_centre(i, n, RN(1/n)) equals the IEEE quotient (i + 0.5)/n for every pixel index of an n-pixel axis,
@@ -1393,6 +1411,9 @@ static int launch_render(int fragment, const RenderArgs& a, int frames, hipStrea
 #ifndef VIS_MIN_WAVES_S4
 #define VIS_MIN_WAVES_S4 6
 #endif
+#ifndef VIS_ROLLED_LANE_COST
+#define VIS_ROLLED_LANE_COST 2.0f                                       // (see launch_fused: the shapes of rolled cameras)
+#endif
 
 template <class SHADER, int S> static void launch_fused_k(const RenderArgs& a, dim3 grid, dim3 block, size_t dynamic_lds, hipStream_t s) {
     note_kernel(__PRETTY_FUNCTION__, "k_render_resolve", S);
@@ -1507,7 +1528,7 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
 #define VIS_STRIP_PITCH2 72
 #endif
 #ifndef VIS_STRIP_WAVES2
-#define VIS_STRIP_WAVES2 8
+#define VIS_STRIP_WAVES2 6                                             // what the kernel HAS: 51.8 KB of LDS per block = three blocks = six waves per SIMD (78 registers); asking for 8 only made the compiler say so on every build
 #endif
 #ifndef VIS_STRIP_WAVES4
 #define VIS_STRIP_WAVES4 6
@@ -1714,16 +1735,21 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
                 if (ssaa == 2 && !a.identity_camera && !a.axis_camera) {
                     // a rolled or tilted camera: a block's window grows with the block's extent along BOTH axes, so squarer blocks
                     // stage fewer cells per pixel (C3 rolled by 45 degrees: 64 x 2 pixels see 31 x 31 cells, 32 x 4 see 23 x 23)
-                    struct Shape { int px, rows; } const shapes[] = {{128, 1}, {64, 2}, {32, 4}};
+                    // (round 5: and quads that WALK two or four rows — one sample per lane left every per-block cost, the camera's ray, the
+                    // window and the staging, 56 % of a rolled launch, to be paid per sample)
+                    struct Shape { int px, rows, walk; } const shapes[] = {{128, 1, 1}, {64, 2, 1}, {32, 4, 1}, {32, 4, 4}};
+                    // (measured at C3, 17 / 45 degrees: 32 x 4 x 1: 684 / 662 frames/s, 32 x 4 x 4: 743 / 663; the two-row walks and the
+                    // 64-wide ones spill or leave blocks off their tile and lose: profiles/r05_rolled_camera.txt)
                     int best = -1, best_tw = 0, best_th = 0;
                     float best_cost = 0.0f;
                     static const int only = [] { const char* e = getenv("SHADERFLOW_VIS_SHAPE"); return e ? atoi(e) : -1; }();   // A/B switch for measurements
-                    for (int k = 0; k < 3; k++) {
+                    for (int k = 0; k < 4; k++) {
                         int w = 0, h = 0;
                         if (only >= 0 && k != only) continue;
-                        visualizer_window_bound(a, shapes[k].px*2, shapes[k].rows*2, w, h);
+                        visualizer_window_bound(a, shapes[k].px*2, shapes[k].rows*shapes[k].walk*2, w, h);
                         if ((size_t)w*h*48 > 72*1024) continue;                       // two 512-thread blocks per CU at least
-                        const float cost = (float)w*(float)h/(float)(shapes[k].px*shapes[k].rows);
+                        // cells staged per pixel + what a block pays once per LANE (ray set-up, window, barriers), in cells' worth
+                        const float cost = (float)w*(float)h/(float)(shapes[k].px*shapes[k].rows*shapes[k].walk) + VIS_ROLLED_LANE_COST/(float)shapes[k].walk;
                         if (best < 0 || cost < best_cost) { best = k; best_cost = cost; best_tw = w; best_th = h; }
                     }
                     if (best >= 0) {
@@ -1733,7 +1759,8 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
                         if (best == 0) return launch_fused_s<VisualizerShader<0, 0, 4, VIS_FUSED_ROWS, VIS_THREAD_ROWS, 128>>(d, ssaa, frames, s, lds);
                         // eight waves per SIMD, not the four of the other tiles sized per launch: 555 -> 696 frames/s at C3 rolled by 17 degrees
                         if (best == 1) return launch_fused_s<VisualizerShader<0, 0, 8, 1, 2, 64>>(d, ssaa, frames, s, lds);
-                        return launch_fused_s<VisualizerShader<0, 0, 8, 1, 4, 32>>(d, ssaa, frames, s, lds);
+                        if (best == 2) return launch_fused_s<VisualizerShader<0, 0, 8, 1, 4, 32>>(d, ssaa, frames, s, lds);
+                        return launch_fused_s<VisualizerShader<0, 0, 4, 4, 4, 32>>(d, ssaa, frames, s, lds);
                     }
                 }
                 if (ssaa != 1) {

@@ -48,6 +48,8 @@ struct RenderArgs {
     float inv_wr, inv_hr;            // RN(1/wr), RN(1/hr) when the host verified glsl.hpp pixel_centre() for them, else 0
     int quads;                       // a bound sampler is mipmapped: k_render covers 32 x 2 pixels per wave as 2 x 2 quads (64 x 4 blocks), helper lanes shaded
     unsigned* tile_misses;           // when set (sfx_ctx_tile_misses): counts the blocks of the LDS-tiled kernels that fell back to the generic taps
+    int affine_camera;               // iCamera.gluv is an AFFINE function of gluv (a camera rolled about its forward axis, zoomed, panned): cam_affine holds it
+    float cam_affine[6];             // iCamera.gluv = (cam_affine[0], [1]) + gluv.x*([2], [3]) + gluv.y*([4], [5]) — for BOUNDS only (a block's window), never for a sample
 #ifdef SF_SECTION_TIMERS
     unsigned long long* timers;      // profiling builds (tools/variants.sh): per-section shader-clock sums, see SF_TICK
 #endif
@@ -67,6 +69,7 @@ constexpr unsigned long long render_args_layout() {
     SF_LAYOUT_MEMBER(tap_x); SF_LAYOUT_MEMBER(tap_y); SF_LAYOUT_MEMBER(vis_consts); SF_LAYOUT_MEMBER(vis); SF_LAYOUT_MEMBER(has_vis);
     SF_LAYOUT_MEMBER(identity_camera); SF_LAYOUT_MEMBER(axis_camera); SF_LAYOUT_MEMBER(aspect); SF_LAYOUT_MEMBER(bg_scale_x); SF_LAYOUT_MEMBER(tile_pitch);
     SF_LAYOUT_MEMBER(tile_rows); SF_LAYOUT_MEMBER(top_down); SF_LAYOUT_MEMBER(inv_wr); SF_LAYOUT_MEMBER(inv_hr); SF_LAYOUT_MEMBER(quads); SF_LAYOUT_MEMBER(tile_misses);
+    SF_LAYOUT_MEMBER(affine_camera); SF_LAYOUT_MEMBER(cam_affine);
 #undef SF_LAYOUT_MEMBER
     h = layout_mix(h, sizeof(RenderArgs)); h = layout_mix(h, sizeof(Uniforms)); h = layout_mix(h, sizeof(Tex));
     h = layout_mix(h, sizeof(FrameDyn)); h = layout_mix(h, sizeof(VisualizerConsts));

@@ -147,6 +147,44 @@ struct VisualizerShader {
                 ok = (tw <= pitch_of(a)) && (th <= rows_of(a));
             }
             if (tid == 0) { sh.x0 = x0; sh.y0 = y0; sh.ok = ok; sh.consts = c; }      // read by run() after the staging barrier
+        } else if (a.affine_camera) {
+            // 1a'. A camera rolled about its forward axis (zoomed, panned): iCamera.gluv is an affine function of gluv, so the centre
+            // taps of a block are bounded by those of its four corner samples — which every thread derives itself from the block's
+            // place in the grid: no reduction and no barrier before the staging (round 4 spent 29 % of a rolled launch in the block-wide
+            // minimum and its three barriers). The affine map is the HOST's (three get_camera evaluations); the samples themselves keep
+            // the generic chain, and the bound carries a margin for the difference (a twentieth of a texel + the rounding of the chain).
+            int i_lo, i_hi, j_lo, j_hi;                               // the block's sample rectangle
+            if (blockDim.y == 1 && gridDim.y == 1) {                  // the fused kernel (render_resolve_body): a 1-D grid of pixel tiles
+                const int ss = a.wr/a.w;
+                const int bpx = (ss == 1) ? 128 : BLOCK_PX, rows = (ss == 1) ? 2*shader_rows_1x<VisualizerShader>::value : THREAD_ROWS*FUSED_ROWS;
+                const int blocks_x = (a.w + bpx - 1)/bpx;
+                const int tile_index = xcd_band_order(blockIdx.x, gridDim.x);
+                const int bx = tile_index % blocks_x, by = tile_index / blocks_x;
+                i_lo = bx*bpx*ss; i_hi = min((bx + 1)*bpx, a.w)*ss - 1; j_lo = by*rows*ss; j_hi = min((by + 1)*rows, a.h)*ss - 1;
+            } else {                                                  // the unfused kernel (render_body)
+                const int rows = BLOCK_H*shader_rows_1x<VisualizerShader>::value;
+                i_lo = blockIdx.x*BLOCK_W; i_hi = min(i_lo + BLOCK_W, a.wr) - 1; j_lo = blockIdx.y*rows; j_hi = min(j_lo + rows, a.hr) - 1;
+            }
+            float x_lo = INFINITY, x_hi = -INFINITY, y_lo = INFINITY, y_hi = -INFINITY;
+#pragma unroll
+            for (int corner = 0; corner < 4; corner++) {
+                Frag g = f;
+                make_varyings(g, (corner & 1) ? i_hi : i_lo, (corner & 2) ? j_hi : j_lo, a.wr, a.hr, a.aspect);
+                const vec2 uv = {fmaf(g.gluv.y, a.cam_affine[4], fmaf(g.gluv.x, a.cam_affine[2], a.cam_affine[0])),
+                                 fmaf(g.gluv.y, a.cam_affine[5], fmaf(g.gluv.x, a.cam_affine[3], a.cam_affine[1]))};
+                const vec2 bgc = (gluv2stuv(uv) - vec2{0.5f, 0.5f})*c.zoom2 + vec2{0.5f, 0.5f} + vec2{c.off_x, c.off_y};   // visualizer_pre
+                const vec2 st = gluv2stuv(stuv2gluv(bgc)*vec2{a.bg_scale_x, 1.0f});                                          // pre(): stexture's chain
+                const float xc = st.x*(float)bg.width - 0.5f, yc = st.y*(float)bg.height - 0.5f;
+                x_lo = fminf(x_lo, xc); x_hi = fmaxf(x_hi, xc); y_lo = fminf(y_lo, yc); y_hi = fmaxf(y_hi, yc);
+            }
+            const float slack = 0.05f + 1.0e-5f*(fabsf(x_lo) + fabsf(x_hi) + fabsf(y_lo) + fabsf(y_hi));
+            if ((c.intensity == c.intensity) && fabsf(x_lo) < 1e8f && fabsf(x_hi) < 1e8f && fabsf(y_lo) < 1e8f && fabsf(y_hi) < 1e8f && rx < 64.0f && ry < 64.0f) {
+                x0 = (int)floorf(x_lo - rx - slack); y0 = (int)floorf(y_lo - ry - slack);
+                tw = (int)floorf(x_hi + rx + slack) - x0 + 1;
+                th = (int)floorf(y_hi + ry + slack) - y0 + 1;
+                ok = (tw <= pitch_of(a)) && (th <= rows_of(a));
+            }
+            if (tid == 0) { sh.x0 = x0; sh.y0 = y0; sh.tw = tw; sh.th = th; sh.ok = ok; sh.consts = c; }      // read by run() after the staging barrier
         } else {
         // 1b. bounding box of the centre taps (as minima of x, -x, y, -y)
         float lo_x = INFINITY, hi_x = INFINITY, lo_y = INFINITY, hi_y = INFINITY;

@@ -9,12 +9,18 @@ What is left to decide is how the finished RGB8 frames reach the ONE process tha
 * **device** — the north star's design: every rank renders ONE CONTIGUOUS frame range (`shard_frames`) into HBM — a whole
   60 s 4K export is 89.6 GB of RGB8, an eighth of it 11.2 GB: resident, not streamed — and sends it chunk by chunk to rank 0
   (`RangeTransfer`: grouped point-to-point sends = the RCCL gather; on the fully connected xGMI fabric every peer has its own
-  link to rank 0, ≈ 45 GB/s each against 24.9 MB x frames/s per rank: nothing to bucket). The frames then sit in rank 0's HBM;
+  link to rank 0 — 76 GB/s per direction in the KFD topology of the pool's nodes (DESIGN.md §6 has the per-link budget: RCCL's
+  point-to-point kernels are assumed at ≈ 75 % of that, SDMA peer copies at ≈ 88 %) against 24.9 MB x frames/s per rank, or 12.4 MB as
+  yuv420p: nothing to bucket). The frames then sit in rank 0's HBM;
   to reach a HOST sink they all cross rank 0's single PCIe link: ceiling ≈ 55 GB/s / 24.9 MB ≈ 2 200 frames/s at 4K whatever N is.
 * **device-sdma** — the same layout as "device", but the gather is not a collective: rank 0 exports its resident buffer as an IPC
-  handle, every other rank maps it and copies its finished chunks to where they belong with `hipMemcpyAsync` on a copy stream
-  (`SdmaTransfer`, sfx_peer_*): the SDMA engines move the bytes over the rank's own xGMI link at close to link rate and no compute
-  unit is taken from the render — what RCCL's point-to-point kernels cannot offer. A gloo side channel carries "chunk k has landed".
+  handle, every other rank maps it and copies its finished chunks to where they belong on SDMA engines NAMED through HSA
+  (`SdmaTransfer`, sfx_peer_*: a thread of the context issues hsa_amd_memory_async_copy_on_engine on the two engines HSA recommends
+  for the pair of GPUs, up to four copies in flight): the engines move the bytes over the rank's own xGMI link at close to link rate
+  and no compute unit is taken from the render — what RCCL's point-to-point kernels cannot offer. A gloo side channel carries
+  "chunk k has landed".
+* every mode moves SINK frames: rgb24, or — `scene.main(pixel_format="yuv420p")` — planar frames converted on the rank that rendered
+  them (half the bytes per link; round 5).
 * **host** — every rank reads its finished frames out over ITS OWN PCIe link into a shared-memory ring and rank 0's native
   writer thread interleaves them in frame order (`HostDelivery`, csrc/shm_ring.inc): no collective on the data path, ceiling
   N x min(render, PCIe) until the sink or host memory bandwidth binds. Here batches alternate between the ranks (batch b on
