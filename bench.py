@@ -50,7 +50,7 @@ B_ALG_PER_FRAME = {  # iScreen write + resolve read + iFinal w
 }
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 256*4*32*2.4e9    # 256 CU x 4 SIMD32 x 2.4 GHz = 78.6e12 lane-instructions/s (157.3 TFLOP/s FMA)
-PROFILE = ROOT/"profiles"/"r04_bench_c3.json"      # written by tools/profile_bench.sh → tools/summarize_profile.py
+PROFILE = ROOT/"profiles"/"r05_bench_c3.json"      # written by tools/profile_bench.sh → tools/summarize_profile.py
 # The north star's CPU baseline measured with THE REFERENCE ITSELF (its own Python + numpy FFT + its GLSL on Mesa llvmpipe), in the
 # build container — it cannot travel to the GPU box (tools/measure_reference_cpu.py, profiles/r03_reference_llvmpipe.txt). Static.
 REFERENCE_LLVMPIPE = {"value": 0.477, "unit": "frames/s", "cores": 8, "kind": "reference",

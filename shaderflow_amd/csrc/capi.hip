@@ -1273,8 +1273,12 @@ static void visualizer_window_bound(const RenderArgs& a, int sx, int sy, int& tw
         else xx = yy = 1e9f;
     }
     const float rx = intensity*a.bg_scale_x*(float)bg.width*1.101f + 0.001f, ry = intensity*(float)bg.height*1.101f + 0.001f;
-    tw = (int)floorf(fminf((float)(sx - 1)*xx + (float)(sy - 1)*xy + 2.0f*rx, 1e6f)) + 2;
-    th = (int)floorf(fminf((float)(sx - 1)*yx + (float)(sy - 1)*yy + 2.0f*ry, 1e6f)) + 2;
+    // the affine cameras' blocks bound their window from four corners through the HOST's map and widen it by a slack for the difference
+    // to the samples' own chain (VisualizerShader::setup 1a': 0.05 texel + 1e-5 of the four coordinates' magnitudes): the tile holds it
+    // for coordinates within one repeat of the background (blocks further out take the generic taps)
+    const float slack = a.affine_camera ? 2.0f*(0.05f + 1.0e-5f*4.0f*2.0f*(float)(bg.width > bg.height ? bg.width : bg.height)) : 0.0f;
+    tw = (int)floorf(fminf((float)(sx - 1)*xx + (float)(sy - 1)*xy + 2.0f*rx + slack, 1e6f)) + 2;
+    th = (int)floorf(fminf((float)(sx - 1)*yx + (float)(sy - 1)*yy + 2.0f*ry + slack, 1e6f)) + 2;
 }
 static const size_t VIS_LDS_LIMIT = 150*1024;                         // leave room for the static shared state of the kernels
 
@@ -1602,7 +1606,7 @@ static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hi
 #endif
         if (WALK4 != VIS_MID4_WALK && fits(128, 4*VIS_MID4_WALK, 40, VIS_MID4_ROWS)) return launch_visualizer_tables_and_kernel<40, VIS_MID4_ROWS, 4, VIS_MID4_WALK, 8, 2, VIS_MID4_HALF>(ctx, a, frames, s);
         // 720p at 4x SSAA (0.32 texel per sample)
-        if (fits(128, 4*VIS_SPARSE4_WALK, 56, VIS_SPARSE4_ROWS)) return launch_visualizer_tables_and_kernel<56, VIS_SPARSE4_ROWS, 4, VIS_SPARSE4_WALK, 8, 2, VIS_SPARSE4_HALF>(ctx, a, frames, s);
+        if (fits(128, 4*VIS_SPARSE4_WALK, 56, VIS_SPARSE4_ROWS)) return launch_visualizer_tables_and_kernel<56, VIS_SPARSE4_ROWS, 4, VIS_SPARSE4_WALK, 6, 2, VIS_SPARSE4_HALF>(ctx, a, frames, s);
     }
     return 0;
 }
@@ -1754,6 +1758,9 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
                     }
                     if (best >= 0) {
                         RenderArgs d = a;
+                        // an odd pitch: a cell is 12 dwords, and with the camera turned by a quarter the lanes of a wave read down a
+                        // COLUMN of cells — 16 cells per row put every one of them on the same banks (730 -> 448 frames/s at C3, 90 degrees)
+                        best_tw |= 1;
                         d.tile_pitch = best_tw; d.tile_rows = best_th;
                         const size_t lds = (size_t)best_tw*best_th*48;
                         if (best == 0) return launch_fused_s<VisualizerShader<0, 0, 4, VIS_FUSED_ROWS, VIS_THREAD_ROWS, 128>>(d, ssaa, frames, s, lds);
@@ -1776,6 +1783,9 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
                     }
                     if (best_px) {
                         RenderArgs d = a;
+                        // an odd pitch: a cell is 12 dwords, and with the camera turned by a quarter the lanes of a wave read down a
+                        // COLUMN of cells — 16 cells per row put every one of them on the same banks (730 -> 448 frames/s at C3, 90 degrees)
+                        best_tw |= 1;
                         d.tile_pitch = best_tw; d.tile_rows = best_th;
                         const size_t lds = (size_t)best_tw*best_th*48;
                         if (best_px == 128) return launch_fused_s<VisualizerShader<0, 0, 4, VIS_FUSED_ROWS, VIS_THREAD_ROWS, 128>>(d, ssaa, frames, s, lds);

@@ -236,13 +236,20 @@ __device__ __forceinline__ uint32_t blue_texel(float below, float ramp, float on
 #ifndef SEP_WAVES
 #define SEP_WAVES 8                     // waves per SIMD asked of the compiler (tools/variants.sh: 4 halves the occupancy, to tell latency from issue)
 #endif
+// what is asked is what a CU can hold: a block is four waves (one per SIMD) and SEP_ROWS KB of staged rows, so 160 KB of LDS keep
+// 160/SEP_ROWS blocks — the 32-row walks live at 4 waves per SIMD and say so (round 4 asked for 8 everywhere and the compiler
+// answered "final occupancy is 4" on every build)
+constexpr int sep_waves(int sep_rows) {
+    const int by_lds = (160*1024)/(sep_rows*SEP_PIXELS*4 + 64);
+    return by_lds < SEP_WAVES ? by_lds : SEP_WAVES;
+}
 // S == 2. grid (ceil(w/SEP_PIXELS), ceil(h/(SEP_ROWS*CHUNKS)), frames), block SEP_PIXELS threads. A block makes CHUNKS walks of SEP_ROWS
 // rows one below the other with its column entries in registers: the stores of a walk drain while the next one is computed. (A wave
 // does not retire before its stores are acknowledged — microseconds under load — and a block that makes one walk spends that time
 // holding its registers and LDS: default.glsl's smooth frames ran at 3.7 TB/s with their waves 87 % idle, and neither fewer
 // instructions nor fewer LDS operations moved them.)
 template <int KIND, int SEP_ROWS, int CHUNKS = 1>
-__global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(SEP_WAVES))) void k_separable_fused(const RenderArgs a, const SepTables t) {
+__global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(sep_waves(SEP_ROWS)))) void k_separable_fused(const RenderArgs a, const SepTables t) {
     // a pixel is staged as ONE dword (red in the low byte): 64 lanes write 64 consecutive banks in one pass. (As three byte stores per
     // pixel — lanes sharing dwords — the LDS' write port bounded the smooth frames of default.glsl: 6.4 us where issue asks for 4.)
     __shared__ __attribute__((aligned(16))) uint32_t staged[SEP_ROWS][SEP_PIXELS];

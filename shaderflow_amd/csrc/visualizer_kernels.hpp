@@ -220,6 +220,9 @@ struct VisualizerShader {
         }
         SF_TICK(a, 4);                               // window (incl. its barriers)
         if (ok == 0 && tid == 0 && a.tile_misses) atomicAdd(a.tile_misses, 1u);
+#ifdef SF_DEBUG_MISS                                                    // tools/variants_par.sh "miss:-DSF_DEBUG_MISS": which blocks leave their tile, and by how much
+        if (ok == 0 && tid == 0) printf("block %d: window %d x %d at (%d, %d), tile %d x %d, affine %d\n", (int)blockIdx.x, tw, th, x0, y0, pitch_of(a), rows_of(a), a.affine_camera);
+#endif
         if (ok != 1) { __syncthreads(); return; }    // sh.ok is read by run(): publish it like the staged path does
         // 2. stage the cells
         const uint8_t* data = (const uint8_t*)bg.data;
