@@ -800,12 +800,20 @@ struct VisualizerStrip {
 #pragma unroll
                         for (int r = 0; r < WALK; r++) yf[r] = *(const float2*)((const char*)&ysteps[r][w] + vzero);
                     }
+#ifndef VIS_STRIP_FIRST_ROW_FOLDS
+#define VIS_STRIP_FIRST_ROW_FOLDS 1                                    // 1: a walk step's first row folds without asking (it always does: `previous` starts at no row) — the compiler then drops the thirteen v_mov 0 that initialised U and V for the path nobody takes (14 of 554 instructions per supersample)
+#endif
+#ifndef VIS_STRIP_SUM_SIDES
+#define VIS_STRIP_SUM_SIDES 0                                          // 1: U(y+) + U(y-) summed when a side folds and added to a row once (three adds per row and step less, three more per fold; another order of the same sum). Needs VIS_STRIP_SIDES_TOGETHER
+#endif
 #ifndef VIS_STRIP_SIDES_TOGETHER
 #define VIS_STRIP_SIDES_TOGETHER 1                                     // 1: both y sides of a walk step advance row by row together (their first cells are fetched at once)
 #endif
                     float U[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}}, V[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
                     int previous[2] = {-2*ROWBYTES, -2*ROWBYTES};     // (no row of cells: neither equal nor adjacent to a real one)
-                    auto advance = [&](int r, int side, float ay_lds) {
+                    float UU[3] = {0.0f, 0.0f, 0.0f};
+                    auto advance = [&](int r, int side, float ay_lds, bool folded_other = false) -> bool {
+                        bool folded = false;
                         const int cell_row = VIS_STRIP_YSTEPS_LDS ? __builtin_amdgcn_readfirstlane(__float_as_int(side ? y[r].w : y[r].z)) : __float_as_int(side ? y[r].w : y[r].z);
                         if (VIS_STRIP_ADJACENT && cell_row == previous[side] + ROWBYTES) {
                             // one row of cells up: U' = U + V, V' from the y halves of the two cells
@@ -819,8 +827,9 @@ struct VisualizerStrip {
                             v[0] = cp[0] + cm[0]; v[1] = cp[1] + cm[1]; v[2] = cp[2] + cm[2];
                             v[0] = fmaf(axp, dp[0], v[0]); v[1] = fmaf(axp, dp[1], v[1]); v[2] = fmaf(axp, dp[2], v[2]);
                             v[0] = fmaf(axm, dm[0], v[0]); v[1] = fmaf(axm, dm[1], v[1]); v[2] = fmaf(axm, dm[2], v[2]);
-                        } else if (cell_row != previous[side]) {
+                        } else if ((VIS_STRIP_FIRST_ROW_FOLDS && r == 0) || cell_row != previous[side]) {
                             previous[side] = cell_row;
+                            folded = true;
                             SF_COUNT_FOLD();
                             Quad p0, p1, p2, m0, m1, m2;
                             load_cell(tile + (cxp + cell_row), p0, p1, p2);
@@ -844,8 +853,17 @@ struct VisualizerStrip {
                         float ay;
                         if (VIS_STRIP_YFRAC_LDS) ay = ay_lds;
                         else ay = VIS_STRIP_YFRAC_VMEM ? (side ? yf[r].y : yf[r].x) : (VIS_STRIP_YSTEPS_LDS ? (side ? y[r].y : y[r].x) : in_vgpr(side ? y[r].y : y[r].x));
-                        acc[r][0] = acc[r][0] + U[side][0];           acc[r][1] = acc[r][1] + U[side][1];           acc[r][2] = acc[r][2] + U[side][2];
+                        if (VIS_STRIP_SUM_SIDES) {
+                            // the two sides' U enter a row as ONE sum, renewed when a side folds (side 1 runs second: it adds the sum)
+                            if (side == 1) {
+                                if (folded || folded_other) { UU[0] = U[0][0] + U[1][0]; UU[1] = U[0][1] + U[1][1]; UU[2] = U[0][2] + U[1][2]; }
+                                acc[r][0] = acc[r][0] + UU[0];        acc[r][1] = acc[r][1] + UU[1];                acc[r][2] = acc[r][2] + UU[2];
+                            }
+                        } else {
+                            acc[r][0] = acc[r][0] + U[side][0];       acc[r][1] = acc[r][1] + U[side][1];           acc[r][2] = acc[r][2] + U[side][2];
+                        }
                         acc[r][0] = fmaf(ay, V[side][0], acc[r][0]);  acc[r][1] = fmaf(ay, V[side][1], acc[r][1]);  acc[r][2] = fmaf(ay, V[side][2], acc[r][2]);
+                        return folded;
                     };
                     if (VIS_STRIP_YFRAC_LDS) {
                         // both fractions of a row in one ds_read_b64 (address = one vector register + the row's immediate offset)
@@ -856,7 +874,7 @@ struct VisualizerStrip {
                         }
                     } else if (VIS_STRIP_SIDES_TOGETHER) {
 #pragma unroll
-                        for (int r = 0; r < WALK; r++) if (r < rows) { advance(r, 0, 0.0f); advance(r, 1, 0.0f); }
+                        for (int r = 0; r < WALK; r++) if (r < rows) { const bool first = advance(r, 0, 0.0f); advance(r, 1, 0.0f, first); }
                     } else {
 #pragma unroll
                         for (int side = 0; side < 2; side++) {

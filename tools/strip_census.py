@@ -94,6 +94,7 @@ def main() -> None:
     parser.add_argument("bench", nargs="?")
     parser.add_argument("--folds", type=float, default=53.0, help="diagonal folds per wave measured by the -DSF_SECTION_TIMERS build")
     parser.add_argument("--exact", type=float, default=0.02)
+    parser.add_argument("--weights-out", help="write [label, weight, why] per block as JSON (to look at a phase's blocks by hand)")
     parser.add_argument("--json", help="write the prices bench.py's issue_model reads (profiles/r05_strip_isa_census.json)")
     args = parser.parse_args()
     blocks = json.load(open(args.blocks))
@@ -194,6 +195,9 @@ def main() -> None:
             if i != keep:
                 weights[i], why[i] = 0.0, "column-line fallback loop (never at C3)"
 
+    if args.weights_out:
+        json.dump([[b["label"], w, r] for b, w, r in zip(blocks, weights, why)], open(args.weights_out, "w"))
+
     # ---- totals ---------------------------------------------------------------------------------------------------------------------
     by_phase: dict[str, collections.Counter] = collections.defaultdict(collections.Counter)
     total: collections.Counter = collections.Counter()
@@ -220,11 +224,12 @@ def main() -> None:
     cycles_total += sgpr/samples*2
     print(f"  VALU: {valu_total:.0f} per wave = {valu_total/samples:.1f} per supersample; {cycles_total:.1f} issue cycles per supersample = {cycles_total/(valu_total/samples):.3f} cycles per VALU instruction")
     print(f"  scalar: {total['salu']/samples:.1f} SALU + {total['smem']/samples:.1f} SMEM + {total['branch']/samples:.1f} branches + {total['waitcnt']/samples:.1f} waits per supersample; LDS {total['lds']/samples:.1f}, VMEM {total['vmem']/samples:.2f}")
-    print("\nby phase (VALU instructions per supersample | share):")
+    print("\nby phase (VALU instructions per supersample | share | of which moves, compares, selects, integer | LDS, SALU):")
     for group, counts in sorted(by_phase.items(), key=lambda kv: -sum(kv[1][c] for c in VALU)):
         v = sum(counts[c] for c in VALU)
         if v > 0.5:
-            print(f"  {group:40s} {v/samples:8.1f}  {100*v/valu_total:5.1f} %")
+            print(f"  {group:40s} {v/samples:8.1f}  {100*v/valu_total:5.1f} %   mov {counts['mov']/samples:5.1f} cmp {counts['cmp']/samples:5.1f} cndmask {counts['cndmask']/samples:5.1f} "
+                  f"int {(counts['int_shift_mul'] + counts['int_add_logic'])/samples:5.1f}   lds {counts['lds']/samples:5.1f} salu {counts['salu']/samples:5.1f}")
 
     hw_map = {"fma_f32": ["fma_f32"], "add_f32": ["add_f32"], "mul_f32": ["mul_f32"], "trans_f32": ["trans"], "cvt": ["cvt"],
               "int32": ["int_shift_mul", "int_add_logic"]}
