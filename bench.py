@@ -398,6 +398,7 @@ def main() -> None:
     # and two payloads: the rgb24 frames (the reference's byte stream: `value`) and — converted on the rank that rendered them —
     # planar yuv420p, half the bytes per link (`yuv420p` beside it). SHADERFLOW_SHARD=device|device-sdma pins the transport.
     from shaderflow_amd.parallel import DeviceArray
+    os.environ.setdefault("SHADERFLOW_COPY_TIMEOUT", "30")          # an engine copy that never completes is reported after 30 s (capi.hip EngineLanes::finish), not waited for
     pinned = os.environ.get("SHADERFLOW_SHARD", "").strip().lower()
     transports = [] if not distributed else (["sdma"] if pinned == "device-sdma" else (["p2p"] if pinned == "device" else ["p2p", "sdma"]))
     received = raw_received = windows = None
@@ -415,15 +416,41 @@ def main() -> None:
             torch.cuda.synchronize()
             if staged:                                                # gloo carries host tensors only: the receives land in host staging (tests)
                 received = [[torch.zeros(fpb*frame_bytes, dtype=torch.uint8, device="cpu") for _ in range(2)] for _ in range(world)]
+        sdma_dropped = None
         if "sdma" in transports:
+            # PREFLIGHT, collectively: export / open the windows and move one small piece through them. The peer copies have run on ONE
+            # GPU only (a loopback window); if anything in them does not hold between two real GPUs, every rank drops the transport
+            # together — the run keeps its RCCL legs and says why — instead of one rank raising inside a timed leg while the others wait.
+            problem = ""
             handles = [None]
-            if rank == 0:
-                handles = [[[context.peer_export(pointer) for pointer in pair] for pair in raw_received]]
+            try:
+                if rank == 0:
+                    handles = [[[context.peer_export(pointer) for pointer in pair] for pair in raw_received]]
+            except Exception as error:                               # noqa: BLE001 — whatever it is, the other ranks must hear of it
+                problem = f"rank 0 export: {error}"
             dist.broadcast_object_list(handles, src=0)
-            if rank:
-                windows = [context.peer_open(handle) for handle in handles[0][rank]]
-            elif loopback:
-                windows = list(raw_received[0])                     # ONE rank: the copies go to this rank's own receive buffers (no IPC mapping of one's own allocation)
+            try:
+                if not problem and handles[0] is not None:
+                    if rank:
+                        windows = [context.peer_open(handle) for handle in handles[0][rank]]
+                    elif loopback:
+                        windows = list(raw_received[0])             # ONE rank: the copies go to this rank's own receive buffers (no IPC mapping of one's own allocation)
+                    if windows and (rank or loopback):
+                        probe = torch.full((4096,), 0xA5, dtype=torch.uint8, device="cuda")
+                        torch.cuda.current_stream().synchronize()
+                        context.peer_copy(windows[0], probe.data_ptr(), probe.numel(), lane=0)
+                        context.peer_flush()
+                elif rank:
+                    problem = "no window handles from rank 0"
+            except Exception as error:                               # noqa: BLE001
+                problem = f"rank {rank}: {error}"
+            problems = [None]*world
+            dist.all_gather_object(problems, problem)
+            if any(problems):
+                sdma_dropped = "; ".join(text for text in problems if text)
+                transports = [t for t in transports if t != "sdma"] or ["p2p"]
+                if rank == 0:
+                    print(f"bench.py: SDMA peer copies dropped from this run ({sdma_dropped})", file=sys.stderr)
 
     class Gather:
         """One transport x one payload: send(index, q, view) queues piece q of step `index`; drain() bounds what is in flight"""
@@ -695,7 +722,7 @@ def main() -> None:
         if per_rank is not None:
             result["per_rank"] = per_rank
             inbound = sum(r["sent_GB_per_s"] for r in per_rank)
-            result["gather"] = {"backend": "sdma peer copies (hipIpc windows + SDMA engines named through HSA)" if sdma else dist_backend, "chosen": chosen["transport"],
+            result["gather"] = {"sdma_dropped": sdma_dropped, "backend": "sdma peer copies (hipIpc windows + SDMA engines named through HSA)" if sdma else dist_backend, "chosen": chosen["transport"],
                                 "pieces_per_step": parts, "inbound_GB_per_s_rank0": round(inbound, 2), "loopback": loopback, "loopback_intact": loopback_intact,
                                 "legs": [{"transport": leg["transport"], "payload": leg["payload"], "value": leg["value"], "unit": "frames/s",
                                           "ms_per_step": round(leg["elapsed_s"]/max(1, args.steps)*1e3, 3), "loopback_intact": leg["loopback_intact"], "per_rank": leg.get("per_rank")} for leg in legs],

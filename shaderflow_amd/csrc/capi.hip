@@ -383,8 +383,15 @@ struct EngineLanes {
             // a failed copy leaves the signal NEGATIVE, which satisfies "< 1" as well, so the value itself is looked at.
             // Polled first: a blocked wait is woken by an interrupt tens of microseconds after the copy ended, which at 1080p (a frame
             // every 60-110 us) is a large part of the frame; after ~200 us of polling the thread blocks like before.
-            if (hsa_signal_wait_scacquire(done[lane], HSA_SIGNAL_CONDITION_LT, 1, poll_ticks(), HSA_WAIT_STATE_ACTIVE) >= 1)
-                while (hsa_signal_wait_scacquire(done[lane], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+            // The blocked wait is bounded (SHADERFLOW_COPY_TIMEOUT seconds, default 120): a copy whose signal never moves — an engine
+            // that does not reach the other agent: the peer copies have only ever run on one GPU — is REPORTED as failed instead of
+            // hanging its export. (Its signal is then left alone: the engine may still write it.)
+            if (hsa_signal_wait_scacquire(done[lane], HSA_SIGNAL_CONDITION_LT, 1, poll_ticks(), HSA_WAIT_STATE_ACTIVE) >= 1) {
+                static const int limit = [] { const char* e = getenv("SHADERFLOW_COPY_TIMEOUT"); const int v = e ? atoi(e) : 120; return v > 0 ? v : 120; }();
+                int seconds = 0;
+                while (hsa_signal_wait_scacquire(done[lane], HSA_SIGNAL_CONDITION_LT, 1, poll_ticks()*5000, HSA_WAIT_STATE_BLOCKED) >= 1)
+                    if (++seconds >= limit) break;
+            }
             ok = hsa_signal_load_relaxed(done[lane]) == 0;
         } else {
             ok = hipStreamSynchronize(c->copy_streams[lane & 1]) == hipSuccess;   // (a stream's later copy too: in order, so nothing is released early)
