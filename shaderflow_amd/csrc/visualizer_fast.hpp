@@ -687,7 +687,9 @@ struct VisualizerStrip {
                 }
                 const int first = start[0];
                 const char* column_cells = tile + __float_as_int(c0.z);
-                if (VIS_STRIP_COLW_ALIGNED && last - first <= COLW_SLOTS) {
+                // (a tile of at most COLW_SLOTS rows of cells cannot hold a longer run: the other loop is then not even compiled, and with it
+                // go the 2 x 27 v_mov that carried the accumulators into and out of the registers the two loops disagreed about)
+                if (VIS_STRIP_COLW_ALIGNED && (TILE_ROWS <= COLW_SLOTS || last - first <= COLW_SLOTS)) {
                     // this wave's weights, aligned to the strip's first cell: colw[r][j] = (n, s) of row r for cell first + j, zeros where
                     // the row's eight slots do not reach. Built by the wave itself (LDS operations of one wave execute in order: no barrier)
                     float2* mine = &sh.colw[wave][0][0];
@@ -803,6 +805,9 @@ struct VisualizerStrip {
 #ifndef VIS_STRIP_FIRST_ROW_FOLDS
 #define VIS_STRIP_FIRST_ROW_FOLDS 1                                    // 1: a walk step's first row folds without asking (it always does: `previous` starts at no row) — the compiler then drops the thirteen v_mov 0 that initialised U and V for the path nobody takes (14 of 554 instructions per supersample)
 #endif
+#ifndef VIS_STRIP_PK_SIDES
+#define VIS_STRIP_PK_SIDES 1                                           // 1: red and green of a row advance together as v_pk_add_f32 / v_pk_fma_f32 with the row's SCALAR fractions broadcast by op_sel (tools/ubench_pk_f32.hip: a scalar pair costs a packed form nothing, a v_mov v, s 4.2 cycles); blue keeps scalar-source fmas. Needs VIS_STRIP_SIDES_TOGETHER, no YFRAC_* / SUM_SIDES
+#endif
 #ifndef VIS_STRIP_SUM_SIDES
 #define VIS_STRIP_SUM_SIDES 0                                          // 1: U(y+) + U(y-) summed when a side folds and added to a row once (three adds per row and step less, three more per fold; another order of the same sum). Needs VIS_STRIP_SIDES_TOGETHER
 #endif
@@ -853,6 +858,19 @@ struct VisualizerStrip {
                         float ay;
                         if (VIS_STRIP_YFRAC_LDS) ay = ay_lds;
                         else ay = VIS_STRIP_YFRAC_VMEM ? (side ? yf[r].y : yf[r].x) : (VIS_STRIP_YSTEPS_LDS ? (side ? y[r].y : y[r].x) : in_vgpr(side ? y[r].y : y[r].x));
+                        if (VIS_STRIP_PK_SIDES) {
+                            typedef float pk2 __attribute__((ext_vector_type(2)));
+                            pk2 a01 = {acc[r][0], acc[r][1]};
+                            const pk2 u01 = {U[side][0], U[side][1]}, v01 = {V[side][0], V[side][1]};
+                            const pk2 fractions = {y[r].x, y[r].y};               // a scalar pair: { frac(y+), frac(y-) }
+                            asm("v_pk_add_f32 %0, %0, %1" : "+v"(a01) : "v"(u01));
+                            if (side == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a01) : "s"(fractions), "v"(v01));
+                            else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a01) : "s"(fractions), "v"(v01));
+                            acc[r][0] = a01.x; acc[r][1] = a01.y;
+                            acc[r][2] = acc[r][2] + U[side][2];
+                            acc[r][2] = fmaf(side ? y[r].y : y[r].x, V[side][2], acc[r][2]);
+                            return folded;
+                        }
                         if (VIS_STRIP_SUM_SIDES) {
                             // the two sides' U enter a row as ONE sum, renewed when a side folds (side 1 runs second: it adds the sum)
                             if (side == 1) {

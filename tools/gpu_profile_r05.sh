@@ -27,7 +27,8 @@ bash tools/gpu_profile_light_r05.sh > /dev/null 2>&1
 python tools/parity_histogram_r03.py > gpurun_out/r05/parity_histogram.txt 2>&1
 : > gpurun_out/r05/bench_other_configs.jsonl
 for cfg in "--width 256 --height 256 --ssaa 1 --frames-per-step 60" "--width 1920 --height 1080 --ssaa 1 --frames-per-step 60" "--width 1920 --height 1080 --ssaa 2 --frames-per-step 60" "--width 2560 --height 1440 --ssaa 2 --frames-per-step 60" \
-           "--width 7680 --height 4320 --ssaa 4 --frames-per-step 8" "--scene bars --frames-per-step 60" "--scene waveform --frames-per-step 60" "--scene basic --frames-per-step 60" "--scene bars --width 1920 --height 1080 --ssaa 2 --frames-per-step 60"; do
+           "--width 7680 --height 4320 --ssaa 4 --frames-per-step 8" "--scene bars --frames-per-step 60" "--scene waveform --frames-per-step 60" "--scene basic --frames-per-step 60" "--scene bars --width 1920 --height 1080 --ssaa 2 --frames-per-step 60" \
+           "--scene bars --frames-per-step 300" "--scene waveform --frames-per-step 300" "--scene basic --frames-per-step 300"; do
   timeout 300 python bench.py --steps 4 --warmup 2 --no-cpu-baseline $cfg 2>/dev/null | tail -1 >> gpurun_out/r05/bench_other_configs.jsonl
 done
 { python tools/profile_frame_loop.py; python tools/profile_clock_loop.py; python tools/experiments/clock_scenes_rates.py; } 2>&1 | grep "frames/s" > gpurun_out/r05/frame_loop.txt
@@ -39,7 +40,7 @@ tail -2 gpurun_out/r05/bench_c3.err; cat gpurun_out/r05/bench_c3.line.json
 python3 - <<'PY'
 import json
 for line in open("gpurun_out/r05/bench_other_configs.jsonl"):
-    d = json.loads(line); print(d["metric"], d["value"], d["roofline"]["kernel"], d["roofline"]["launch_ms"], d["roofline"].get("frac"), (d.get("export_host") or {}).get("value"))
+    d = json.loads(line); print(d["metric"], d["value"], d["roofline"]["kernel"], d["roofline"]["launch_ms"], d["roofline"].get("frames_per_launch"), d["roofline"].get("frac"), (d.get("export_host") or {}).get("value"))
 PY
 cat gpurun_out/r05/filterbank.txt
 tail -30 gpurun_out/r05/parity_histogram.txt

@@ -151,9 +151,13 @@ def main() -> None:
             else:
                 weights[i], why[i] = 1.0, "column-line set-up"
         elif phase == "diag":
-            fold = n in (28, 29) and "lds" in block["counts"]
+            fold = 28 <= n <= 31 and block["counts"].get("lds", 0) == 6
             skip_path = (not block["counts"].get("lds")) and all(cls in ("salu", "branch", "mov", "waitcnt") for cls in block["counts"]) and n <= 14 and not within(lines, (M["diag"][0], M["diag_setup_end"][0] + 12)) and i > 0 and "diagonal set-up" not in why[i - 1]
-            if fold:
+            if block["counts"].get("lds", 0) >= 12 and n > 40:
+                # VIS_STRIP_FIRST_ROW_FOLDS: the first row's two folds (twelve reads) sit in the step's own block; every other fold is conditional
+                diag_fold_seen = 2
+                weights[i], why[i] = 10.0, "diagonal per step / per advance"
+            elif fold:
                 diag_fold_seen += 1
                 weights[i] = 10.0*(1.0 if diag_fold_seen <= 2 else p)
                 why[i] = "diagonal fold"
@@ -161,7 +165,7 @@ def main() -> None:
                 weights[i], why[i] = 1.0, "diagonal set-up"
             elif skip_path and re.fullmatch(r"\.LBB\d+_\d+", block["label"]) and block["counts"].get("salu", 0) >= 2 and not block["counts"].get("smem"):
                 weights[i], why[i] = 0.0, "rows beyond the frame (never inside it)"
-            elif block["counts"].get("mov", 0) >= 10 and n <= 14:
+            elif block["counts"].get("mov", 0) >= 10 and n <= 18:
                 weights[i], why[i] = 0.0, "rows beyond the frame (zeroed sums)"
             else:
                 weights[i], why[i] = 10.0, "diagonal per step / per advance"
@@ -202,12 +206,14 @@ def main() -> None:
     by_phase: dict[str, collections.Counter] = collections.defaultdict(collections.Counter)
     total: collections.Counter = collections.Counter()
     sgpr = 0.0
+    sgpr_by_phase: collections.Counter = collections.Counter()
     for block, weight, reason in zip(blocks, weights, why):
         group = reason.split(" (")[0].split(":")[0]
         for cls, count in block["counts"].items():
             total[cls] += count*weight
             by_phase[group][cls] += count*weight
         sgpr += block["sgpr_forms"]*weight
+        sgpr_by_phase[group] += block["sgpr_forms"]*weight
     samples = 9.0
     valu_total = sum(total[c] for c in VALU)
     print(f"event rates: {json.dumps({k: round(v, 4) for k, v in rates.items()})}")
@@ -229,7 +235,7 @@ def main() -> None:
         v = sum(counts[c] for c in VALU)
         if v > 0.5:
             print(f"  {group:40s} {v/samples:8.1f}  {100*v/valu_total:5.1f} %   mov {counts['mov']/samples:5.1f} cmp {counts['cmp']/samples:5.1f} cndmask {counts['cndmask']/samples:5.1f} "
-                  f"int {(counts['int_shift_mul'] + counts['int_add_logic'])/samples:5.1f}   lds {counts['lds']/samples:5.1f} salu {counts['salu']/samples:5.1f}")
+                  f"int {(counts['int_shift_mul'] + counts['int_add_logic'])/samples:5.1f} sgpr-src {sgpr_by_phase[group]/samples:5.1f} pk {counts['pk_f32']/samples:5.1f}   lds {counts['lds']/samples:5.1f} salu {counts['salu']/samples:5.1f}")
 
     hw_map = {"fma_f32": ["fma_f32"], "add_f32": ["add_f32"], "mul_f32": ["mul_f32"], "trans_f32": ["trans"], "cvt": ["cvt"],
               "int32": ["int_shift_mul", "int_add_logic"]}
