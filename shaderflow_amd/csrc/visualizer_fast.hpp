@@ -785,6 +785,9 @@ struct VisualizerStrip {
 #ifndef VIS_STRIP_DIAG_UNROLL
 #define VIS_STRIP_DIAG_UNROLL 1
 #endif
+                float acc_blue[WALK];
+#pragma unroll
+                for (int r = 0; r < WALK; r++) acc_blue[r] = 0.0f;
 #pragma unroll VIS_STRIP_DIAG_UNROLL
                 for (int w = 0; w < 10; w++) {
                     const float axp = __builtin_amdgcn_fractf(xp), axm = __builtin_amdgcn_fractf(xm);
@@ -804,6 +807,9 @@ struct VisualizerStrip {
                     }
 #ifndef VIS_STRIP_FIRST_ROW_FOLDS
 #define VIS_STRIP_FIRST_ROW_FOLDS 1                                    // 1: a walk step's first row folds without asking (it always does: `previous` starts at no row) — the compiler then drops the thirteen v_mov 0 that initialised U and V for the path nobody takes (14 of 554 instructions per supersample)
+#endif
+#ifndef VIS_STRIP_PK_BLUE
+#define VIS_STRIP_PK_BLUE 0                                            // 1 (with PK_SIDES): blue's two sides as one packed pair into a split accumulator (nine more registers over the walk)
 #endif
 #ifndef VIS_STRIP_PK_SIDES
 #define VIS_STRIP_PK_SIDES 1                                           // 1: red and green of a row advance together as v_pk_add_f32 / v_pk_fma_f32 with the row's SCALAR fractions broadcast by op_sel (tools/ubench_pk_f32.hip: a scalar pair costs a packed form nothing, a v_mov v, s 4.2 cycles); blue keeps scalar-source fmas. Needs VIS_STRIP_SIDES_TOGETHER, no YFRAC_* / SUM_SIDES
@@ -867,6 +873,17 @@ struct VisualizerStrip {
                             if (side == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a01) : "s"(fractions), "v"(v01));
                             else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a01) : "s"(fractions), "v"(v01));
                             acc[r][0] = a01.x; acc[r][1] = a01.y;
+                            if (VIS_STRIP_PK_BLUE) {
+                                // blue of both sides at once, side 1's share into a second accumulator (added after the walk)
+                                if (side == 1) {
+                                    pk2 ab = {acc[r][2], acc_blue[r]};
+                                    const pk2 ub = {U[0][2], U[1][2]}, vb = {V[0][2], V[1][2]};
+                                    asm("v_pk_add_f32 %0, %0, %1" : "+v"(ab) : "v"(ub));
+                                    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(ab) : "s"(fractions), "v"(vb));
+                                    acc[r][2] = ab.x; acc_blue[r] = ab.y;
+                                }
+                                return folded;
+                            }
                             acc[r][2] = acc[r][2] + U[side][2];
                             acc[r][2] = fmaf(side ? y[r].y : y[r].x, V[side][2], acc[r][2]);
                             return folded;
@@ -902,6 +919,10 @@ struct VisualizerStrip {
                     }
                     xp = xp + step; xm = xm - step;
                     if (VIS_STRIP_YFRAC_LDS) yfrac_w += 8;
+                }
+                if (VIS_STRIP_PK_SIDES && VIS_STRIP_PK_BLUE) {
+#pragma unroll
+                    for (int r = 0; r < WALK; r++) acc[r][2] = acc[r][2] + acc_blue[r];
                 }
             }
         }
