@@ -795,6 +795,19 @@ struct VisualizerStrip {
                     float4 y[WALK];
 #pragma unroll
                     for (int r = 0; r < WALK; r++) y[r] = VIS_STRIP_YSTEPS_LDS ? sh.ysteps[row0 + r][w] : ysteps[r][w];   // { frac(y+), frac(y-), row bytes(y+), row bytes(y-) }
+#ifndef VIS_STRIP_YSTEPS_TOGETHER
+#define VIS_STRIP_YSTEPS_TOGETHER 0                                    // 1: every row's scalar load of a walk step is issued before the step's first fold (left alone the compiler sinks each load to its row: s_load, s_waitcnt 0, s_cmp); measured: 3 200 against 3 210 frames/s — the other waves hide that latency already
+#endif
+                    if (VIS_STRIP_YSTEPS_TOGETHER && !VIS_STRIP_YSTEPS_LDS) {
+                        static_assert(WALK <= 10, "the operand list below names ten rows");
+                        // one scalar move whose INPUTS are all the rows' entries: nothing of the step can start before every load is out
+                        // (plain asm, not volatile: see the column lines — a side-effecting asm turns the table loads into vector loads)
+#define SF_YZ(k) "s"(__float_as_int(y[(k) < WALK ? (k) : WALK - 1].z))
+                        int first_bytes;
+                        asm("s_mov_b32 %0, %1" : "=s"(first_bytes) : SF_YZ(0), SF_YZ(1), SF_YZ(2), SF_YZ(3), SF_YZ(4), SF_YZ(5), SF_YZ(6), SF_YZ(7), SF_YZ(8), SF_YZ(9));
+#undef SF_YZ
+                        y[0].z = __int_as_float(first_bytes);
+                    }
 #ifndef VIS_STRIP_YFRAC_VMEM
 #define VIS_STRIP_YFRAC_VMEM 0                                         // 1: the two fractions of a row's entry ALSO through a vector load (the same address in every lane: one L1 line), so they arrive in vector registers — the scalar copy costs a v_mov per use (VALU forms with an SGPR source issue at half rate); needs 18 more VGPRs: a 6-wave build
 #endif
