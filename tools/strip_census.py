@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """
-ISA census of k_visualizer_strip<72, 12, 2, 9, 8, 4, false>: instructions per supersample BY CLASS, priced with
+ISA census of k_visualizer_strip<72, 12, 2, 9, 6, 4, false>: instructions per supersample BY CLASS, priced with
 the issue cycles tools/ubench_valu.hip measured, so that bench.py's `issue_model` prices the 16 % of the VALU instructions no hardware
 class counter covers ("other": moves, selects, compares, min/max, fract/floor, readfirstlane) with what they are instead of a 2-or-4 band.
 
@@ -265,7 +265,7 @@ def main() -> None:
         digest = hashlib.sha256()
         for name in STRIP_SOURCES:
             digest.update(name.encode()); digest.update((csrc/name).read_bytes())
-        json.dump({"kernel": "k_visualizer_strip<72, 12, 2, 9, 8, 4, false>", "strip_sources_fingerprint": digest.hexdigest()[:16],
+        json.dump({"kernel": "k_visualizer_strip<72, 12, 2, 9, 6, 4, false>", "strip_sources_fingerprint": digest.hexdigest()[:16],
                    "other_cycles_per_instruction": round(other_cycles/other_count, 4),
                    "sgpr_source_full_rate_forms_per_valu_instruction": round(sgpr/valu_total, 5),
                    "valu_instructions_per_supersample_modelled": round(valu_total/samples, 2),
