@@ -295,12 +295,15 @@ def issue_model(cs: dict, launch_ns: float | None, census: dict | None = None) -
     if census:
         # one number instead of the band: the uncounted instructions at the price of what the ISA census found them to
         # be, plus the two extra cycles every full-rate form with a scalar source takes (v_mov_b32 v, s: 4.2 cycles, r05_ubench_valu_sgpr.txt)
+        # … and the two extra cycles of every packed-f32 form: the class counters count a v_pk_fma_f32 once, as an fma (r05_ubench_pk_f32.txt)
         by_census = round((priced + census["other_cycles_per_instruction"]*other
-                           + 2.0*census["sgpr_source_full_rate_forms_per_valu_instruction"]*cs["SQ_INSTS_VALU"])/had, 4)
+                           + 2.0*census["sgpr_source_full_rate_forms_per_valu_instruction"]*cs["SQ_INSTS_VALU"]
+                           + 2.0*census.get("packed_f32_forms_per_valu_instruction", 0.0)*cs["SQ_INSTS_VALU"])/had, 4)
     return {"frac": by_census if by_census is not None else round((priced + 4*other)/had, 4), "frac_census": by_census,
             "frac_other_at_4": round((priced + 4*other)/had, 4), "frac_low": round((priced + 2*other)/had, 4),
             "census": ({"other_cycles_per_instruction": census["other_cycles_per_instruction"],
                         "sgpr_source_full_rate_forms_per_valu_instruction": census["sgpr_source_full_rate_forms_per_valu_instruction"],
+                        "packed_f32_forms_per_valu_instruction": census.get("packed_f32_forms_per_valu_instruction", 0.0),
                         "from": str(CENSUS.relative_to(ROOT))} if census else None),
             "simd_cycles_available": had, "effective_clock_GHz": round(cycles/launch_ns, 3) if launch_ns else None,
             "instructions": {"add_f32": classes["SQ_INSTS_VALU_ADD_F32"], "mul_f32": classes["SQ_INSTS_VALU_MUL_F32"], "fma_f32": classes["SQ_INSTS_VALU_FMA_F32"],
@@ -700,7 +703,7 @@ def main() -> None:
                                  "algorithmic_bytes_per_launch": b_alg*piece,
                                  "measured": round(traffic/launch_s/1e9, 1) if traffic else None,
                                  "note": "algorithmic bytes = the reference's two-pass data-flow (SURVEY.md §8d); the fused kernel writes the RGB8 frame only"},
-                         "note": "FP32 VALU issue binds the kernel (the 91-tap blur folded to ~550 instructions per supersample, DESIGN.md §4; LDS ~55 % busy); "
+                         "note": "FP32 VALU issue binds the kernel (the 91-tap blur folded to ~470 instructions per supersample, DESIGN.md §4; LDS ~70 % busy); "
                                  "HBM carries the finished RGB8 frames and L2-resident tables only, so the HBM figure is a fraction of what the two-pass data-flow would move"},
         }
         if args.scene != "visualizer":

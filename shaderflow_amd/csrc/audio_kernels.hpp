@@ -171,23 +171,27 @@ __global__ __launch_bounds__(64) void k_filterbank_mfma(const float* __restrict_
     }
 }
 
-// A block adds the splits of a 32-column x 32-bin tile — read along the columns, as k_filterbank_mfma wrote them — and turns the tile in
-// LDS so that it leaves along the bins, the order of the RG texel rows (spectrogram.py:306). (Round 4's one-thread-per-output version read
-// eight partials a cache line apart per lane: 65 us per 300 frames, more than the CSR kernel it was meant to beat.)
+// A block adds the splits of a 32-column x 8-bin tile — read along the columns, as k_filterbank_mfma wrote them, one output per thread
+// with its eight partials in flight together — and turns the tile in LDS so that it leaves along the bins, the order of the RG texel
+// rows (spectrogram.py:306). (Round 4's version read eight partials a cache line apart per lane, one after the other: 65 us per 300
+// frames, more than the CSR kernel it was meant to beat; 1 024 outputs per block still took 48 us: too few loads in flight.)
 __global__ __launch_bounds__(256) void k_filterbank_reduce(const float* __restrict__ partial, int rows_pad, int bins, int channels, int ncols, float* __restrict__ out) {
-    __shared__ float tile[32][33];
-    const int c0 = blockIdx.x*32, r0 = blockIdx.y*32;
-    for (int e = threadIdx.x; e < 1024; e += 256) {
-        const int cl = e & 31, rl = e >> 5;
+    __shared__ float tile[8][33];
+    const int c0 = blockIdx.x*32, r0 = blockIdx.y*8;
+    {
+        const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
         const int col = c0 + cl, r = r0 + rl;
+        float part[FILTERBANK_SPLITS];
+#pragma unroll
+        for (int split = 0; split < FILTERBANK_SPLITS; split++) part[split] = (col < ncols && r < bins) ? partial[((long)split*rows_pad + r)*ncols + col] : 0.0f;
         float sum = 0.0f;
-        if (col < ncols && r < bins)
-            for (int split = 0; split < FILTERBANK_SPLITS; split++) sum = sum + partial[((long)split*rows_pad + r)*ncols + col];
+#pragma unroll
+        for (int split = 0; split < FILTERBANK_SPLITS; split++) sum = sum + part[split];      // the splits in their fixed order
         tile[rl][cl] = sum;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 1024; e += 256) {
-        const int rl = e & 31, cl = e >> 5;
+    {
+        const int rl = threadIdx.x & 7, cl = threadIdx.x >> 3;
         const int col = c0 + cl, r = r0 + rl;
         if (col < ncols && r < bins) out[((long)(col / channels)*bins + r)*channels + (col % channels)] = tile[rl][cl];
     }

@@ -2609,7 +2609,7 @@ static void launch_filterbank(Plan* p, FilterbankScratch& scratch, int frames, i
     if (use_mfma) {
         hipLaunchKernelGGL(k_filterbank_mfma, dim3((ncols + 31)/32, p->row_tiles, FILTERBANK_SPLITS), dim3(64), 0, s,
                            p->d_dense, p->k_pad, p->d_band, p->fft_bins, ncols, d_power, scratch.d_partial);
-        hipLaunchKernelGGL(k_filterbank_reduce, dim3((ncols + 31)/32, (p->bins + 31)/32), dim3(256), 0, s, scratch.d_partial, p->row_tiles*32, p->bins, p->channels, ncols, d_out);
+        hipLaunchKernelGGL(k_filterbank_reduce, dim3((ncols + 31)/32, (p->bins + 7)/8), dim3(256), 0, s, scratch.d_partial, p->row_tiles*32, p->bins, p->channels, ncols, d_out);
     } else {
         const long total = (long)ncols*p->bins;
         hipLaunchKernelGGL(k_filterbank_csr, dim3((unsigned)((total + 255)/256)), dim3(256), 0, s,

@@ -397,7 +397,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 def test_bench_measures_the_instruction_counters_of_its_own_run():
     """The benchmark's configuration (C3) as the driver runs it, short: the dominant kernel's VALU counters come from two rocprofv3
     children of the run itself, and they say what the ISA census says (profiles/r05_strip_isa_census.txt) —
-    549 instructions per supersample in rounds 3-4, ~510 since round 5 packs the diagonal rows' red and green into v_pk_* forms (one
+    549 instructions per supersample in rounds 3-4, 472 since round 5 packs the diagonal rows' red and green into v_pk_* forms (one
     instruction, two operations). Skipped where the profiler is not installed."""
     import json
     import shutil
@@ -413,7 +413,7 @@ def test_bench_measures_the_instruction_counters_of_its_own_run():
     record = json.loads([line for line in out.stdout.splitlines() if line.startswith("{")][-1])
     roofline = record["roofline"]
     assert roofline["counters_from"].startswith("live: SQ_INSTS_VALU"), (roofline["counters_from"], out.stderr[-1500:])
-    assert 490.0 < roofline["valu_instructions_per_supersample"] < 535.0, roofline
+    assert 455.0 < roofline["valu_instructions_per_supersample"] < 490.0, roofline
     assert 0.5 < roofline["issue_cycles_frac"] < 1.0 and 0.4 < roofline["frac"] < 0.8, roofline
     assert 1.8 < roofline["issue_model"]["effective_clock_GHz"] < 2.5, roofline["issue_model"]
 

@@ -9,20 +9,7 @@ cp gpurun_out/prof_r05_summary.txt gpurun_out/r05/rocprofv3_bench_c3_summary.txt
 cp gpurun_out/prof_r05.json gpurun_out/r05/bench_c3.json
 cp gpurun_out/prof_r05.json profiles/r05_bench_c3.json      # the final bench line below reads its counters from here (same sources, same box)
 find gpurun_out/prof_r05/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/r05/rocprofv3_kernel_stats.csv
-# the filterbank both ways: kernel-trace averages of the same bench command (bit-exact CSR is what the timed run uses)
-for fb in csr mfma; do
-  rm -rf gpurun_out/fb_$fb
-  SHADERFLOW_FILTERBANK=$fb rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/fb_$fb -o trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-export > gpurun_out/fb_$fb.log 2>&1
-done
-python3 - > gpurun_out/r05/filterbank.txt <<'PY'
-import csv, glob
-print("filterbank of the bench command (C3: 300 frames x 2 channels x 2049 FFT bins -> 360 bins per launch), rocprofv3 --kernel-trace --stats, bench.py --steps 3 --warmup 1")
-for fb in ("csr", "mfma"):
-    for f in glob.glob(f"gpurun_out/fb_{fb}/**/*kernel_stats.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "filterbank" in r["Name"] or "stft" in r["Name"]:
-                print(f"  SHADERFLOW_FILTERBANK={fb:5s} {r['Name'].split('(')[0][:60]:60s} calls {int(r['Calls']):4d}  average {float(r['AverageNs'])/1e3:9.1f} us")
-PY
+bash tools/experiments/filterbank_timing.sh > /dev/null 2>&1
 bash tools/gpu_profile_light_r05.sh > /dev/null 2>&1
 python tools/parity_histogram_r03.py > gpurun_out/r05/parity_histogram.txt 2>&1
 : > gpurun_out/r05/bench_other_configs.jsonl

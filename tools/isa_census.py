@@ -30,7 +30,9 @@ CLASSES = [
     ("fma_f32", r"v_(fma|fmac|fmaak|fmamk|mad|mac)_f32", 2),
     ("add_f32", r"v_(add|sub|subrev)_f32", 2),
     ("mul_f32", r"v_mul_f32", 2),
-    ("pk_f32", r"v_pk_(fma|add|mul)_f32", 4),
+    ("pk_fma_f32", r"v_pk_fma_f32", 4),                               # the packed forms cost two plain ones whatever their sources (profiles/r05_ubench_pk_f32.txt);
+    ("pk_add_f32", r"v_pk_add_f32", 4),                               # the hardware counts each ONCE, in its plain form's class counter
+    ("pk_mul_f32", r"v_pk_mul_f32", 4),
     ("fma_mix", r"v_fma_mix", 4),
     ("trans", r"v_(rcp|rsq|sqrt|exp|log|sin|cos)_(f32|iflag_f32|legacy_f32)", 8),
     ("cvt", r"v_cvt_", 4),

@@ -235,9 +235,11 @@ def main() -> None:
         v = sum(counts[c] for c in VALU)
         if v > 0.5:
             print(f"  {group:40s} {v/samples:8.1f}  {100*v/valu_total:5.1f} %   mov {counts['mov']/samples:5.1f} cmp {counts['cmp']/samples:5.1f} cndmask {counts['cndmask']/samples:5.1f} "
-                  f"int {(counts['int_shift_mul'] + counts['int_add_logic'])/samples:5.1f} sgpr-src {sgpr_by_phase[group]/samples:5.1f} pk {counts['pk_f32']/samples:5.1f}   lds {counts['lds']/samples:5.1f} salu {counts['salu']/samples:5.1f}")
+                  f"int {(counts['int_shift_mul'] + counts['int_add_logic'])/samples:5.1f} sgpr-src {sgpr_by_phase[group]/samples:5.1f} pk {(counts['pk_fma_f32'] + counts['pk_add_f32'] + counts['pk_mul_f32'])/samples:5.1f}   lds {counts['lds']/samples:5.1f} salu {counts['salu']/samples:5.1f}")
 
-    hw_map = {"fma_f32": ["fma_f32"], "add_f32": ["add_f32"], "mul_f32": ["mul_f32"], "trans_f32": ["trans"], "cvt": ["cvt"],
+    # (the packed forms are counted ONCE by their plain form's class counter: r05_bench_c3 lost 20 adds and 20 fmas per supersample when
+    # forty of each became twenty packed ones)
+    hw_map = {"fma_f32": ["fma_f32", "pk_fma_f32"], "add_f32": ["add_f32", "pk_add_f32"], "mul_f32": ["mul_f32", "pk_mul_f32"], "trans_f32": ["trans"], "cvt": ["cvt"],
               "int32": ["int_shift_mul", "int_add_logic"]}
     other_classes = [c for c in VALU if not any(c in v for v in hw_map.values())]
     if args.bench:
@@ -268,10 +270,11 @@ def main() -> None:
         json.dump({"kernel": "k_visualizer_strip<72, 12, 2, 9, 6, 4, false>", "strip_sources_fingerprint": digest.hexdigest()[:16],
                    "other_cycles_per_instruction": round(other_cycles/other_count, 4),
                    "sgpr_source_full_rate_forms_per_valu_instruction": round(sgpr/valu_total, 5),
+                   "packed_f32_forms_per_valu_instruction": round((total["pk_fma_f32"] + total["pk_add_f32"] + total["pk_mul_f32"])/valu_total, 5),
                    "valu_instructions_per_supersample_modelled": round(valu_total/samples, 2),
                    "average_issue_cycles_per_valu_instruction": round(cycles_total/(valu_total/samples), 4),
                    "other_by_class_per_supersample": {c: round(total[c]/samples, 2) for c in other_classes if total[c] > 0},
-                   "event_rates": rates, "how": "tools/strip_census.py on tools/isa_census.py --dump of the -gline-tables-only listing; prices: profiles/r02_ubench_valu.txt, r05_ubench_valu_sgpr.txt"},
+                   "event_rates": rates, "how": "tools/strip_census.py on tools/isa_census.py --dump of the -gline-tables-only listing; prices: profiles/r02_ubench_valu.txt, r05_ubench_valu_sgpr.txt, r05_ubench_pk_f32.txt"},
                   open(args.json, "w"), indent=1)
 
 
