@@ -227,6 +227,37 @@ def test_c2_two_pass_whole_frames_through_the_tape():
         assert histogram[:2].sum()/histogram.sum() >= 0.99999, (k, histogram, lsb_report(got[k], want[n]))
 
 
+@pytest.mark.parametrize("degrees", [5.0, 17.0, 45.0])
+def test_c3_under_a_rolled_camera(gpu, degrees):
+    """BASELINE config 3 with the camera rolled about its forward axis (camera.py rotate2d): the LDS-tiled
+    per-sample kernel in its round-5 shape (32 x 16 pixel blocks whose quads walk four rows, a tile sized per launch with an odd
+    pitch, the window from the block's four corners through the host's affine map) — no block may leave its tile, and the frame's
+    first and last rows plus six seeded 16-row bands (every band crosses a block seam) are within 1 LSB of the oracle"""
+    import math
+    w, h, ssaa = 3840, 2160, 2
+    u, arrays, params = visualizer_inputs(w, h, seed=61, volume=0.8, bg_size=(1920, 1080))
+    arrays["background"] = np.ascontiguousarray(np.flipud(synth.background_image(1920, 1080)))
+    u.iSSAA = float(ssaa)
+    c, s = math.cos(math.radians(degrees)), math.sin(math.radians(degrees))
+    for i, (right, up) in enumerate(zip((c, s, 0.0), (-s, c, 0.0))):
+        u.iCameraRight[i], u.iCameraUpward[i] = right, up
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    gpu.ctx.tile_misses()
+    got = gpu.render_resolve(prog, w, h, ssaa, 2)
+    assert gpu.ctx.tile_misses() == 0
+    assert gpu.lib.sfx_last_kernel().decode() == "k_render_resolve<VisualizerShader<0, 0, 4, 4, 4, 32>, 2>", gpu.lib.sfx_last_kernel()
+    textures = oracle_textures(arrays, params)
+    rng = np.random.default_rng(int(degrees*1000))
+    bands = [(0, 16), (h - 16, h)] + [(int(y), int(y) + 16) for y in rng.integers(16, h - 32, size=6)]
+    for first, last in bands:
+        screen = O.render("visualizer", u, textures, w*ssaa, h*ssaa, rows=(first*ssaa, last*ssaa), threads=THREADS)
+        want = O.resolve(screen, w, h, 2, rows=(first, last), threads=THREADS)[first:last]
+        d = np.abs(got[first:last].astype(int) - want.astype(int))
+        assert d.max() <= 1, (degrees, first, lsb_report(got[first:last], want))
+
+
 def test_c4_rows_around_block_seams(gpu):
     """BASELINE config 4: 7680x4320 at 4xSSAA (530.8 M supersamples); the 4x instance's blocks are 10 output rows high"""
     w, h, ssaa = 7680, 4320, 4
