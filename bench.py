@@ -704,7 +704,10 @@ def main() -> None:
                                  "measured": round(traffic/launch_s/1e9, 1) if traffic else None,
                                  "note": "algorithmic bytes = the reference's two-pass data-flow (SURVEY.md §8d); the fused kernel writes the RGB8 frame only"},
                          "note": "FP32 VALU issue binds the kernel (the 91-tap blur folded to ~470 instructions per supersample, DESIGN.md §4; LDS ~70 % busy); "
-                                 "HBM carries the finished RGB8 frames and L2-resident tables only, so the HBM figure is a fraction of what the two-pass data-flow would move"},
+                                 "HBM carries the finished RGB8 frames and L2-resident tables only, so the HBM figure is a fraction of what the two-pass data-flow would move. "
+                                 "`frac` = SQ_INSTS_VALU x 64 lanes / launch time / peak counts every instruction ONCE: since round 5 forty adds and fmas per supersample "
+                                 "are twenty packed forms (one instruction, two issue slots) and 39 moves are gone, so the same frame takes 472 instead of 549 "
+                                 "instructions and `frac` FELL (0.70 -> 0.61-0.63) while frames/s rose; the share of issue SLOTS in use is issue_model.frac_census"},
         }
         if args.scene != "visualizer":
             # the light fragments are bound by the HBM write of the finished frame: the roofline is the FUSED lower bound — W·H·3 bytes
