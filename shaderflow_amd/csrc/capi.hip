@@ -1631,7 +1631,14 @@ template <int KIND> static int launch_separable(const RenderArgs& a, int ssaa, i
         if (sp.width != 1 || sp.filter != FILTER_NEAREST) return 0;
     }
     if (KIND == SEP_WAVEFORM && a.hr > 0xffff) return 0;              // its column entries pack a first row and a row count into 16 bits each
-    const size_t bytes = (size_t)frames*((size_t)a.wr + a.hr)*sizeof(float4);
+    // default.glsl in two passes (separable_fast.hpp k_default_quads): a byte per group of four rows and block of 256 pixels, after the tables
+    // OPT-IN (SHADERFLOW_DEFAULT_QUADS=1, read per launch so that a test can turn it on): measured slower than the one pass — a smooth
+    // frame takes 6.3 us either way, and the second pass pays for skipping (profiles/r05_basic_quads.txt)
+    const char* quads_env = getenv("SHADERFLOW_DEFAULT_QUADS");
+    const bool quads = KIND == SEP_DEFAULT && quads_env && atoi(quads_env) == 1 && (a.w & 3) == 0 && a.w >= 256 && a.h >= 4;
+    const int done_groups = (a.h + 3)/4, done_blocks = (a.w + 255)/256;
+    const size_t tables = (size_t)frames*((size_t)a.wr + a.hr)*sizeof(float4);
+    const size_t bytes = tables + (quads ? (size_t)frames*done_groups*done_blocks : 0);
     if (ctx->vis_tables_bytes < bytes) {
         hipStreamSynchronize(s);
         hipFree(ctx->vis_tables); ctx->vis_tables = nullptr; ctx->vis_tables_bytes = 0;
@@ -1641,6 +1648,8 @@ template <int KIND> static int launch_separable(const RenderArgs& a, int ssaa, i
     SepTables t;
     t.columns = (float4*)ctx->vis_tables;
     t.rows = t.columns + (size_t)frames*a.wr;
+    t.done = quads ? (uint8_t*)ctx->vis_tables + tables : nullptr;
+    t.done_groups = done_groups; t.done_blocks = done_blocks;
     hipLaunchKernelGGL(k_separable_axis<KIND>, dim3((a.wr + a.hr + 255)/256, frames), dim3(256), 0, s, a, t);
     if constexpr (KIND != SEP_DEFAULT) {
         // rows as runs, four pixels = one 12-byte store per lane (k_separable_runs); odd widths keep the per-pixel kernel
@@ -1653,6 +1662,14 @@ template <int KIND> static int launch_separable(const RenderArgs& a, int ssaa, i
     }
     g_last_kernel = std::string("k_separable_fused<") + (KIND == SEP_BARS ? "bars" : (KIND == SEP_WAVEFORM ? "waveform" : "default")) + ">";
     const int blocks_x = (a.w + SEP_PIXELS - 1)/SEP_PIXELS;
+    if constexpr (KIND == SEP_DEFAULT) {
+        // the smooth tier first, four pixels per lane; what it writes it marks, and the second pass skips
+        if (quads) {
+            hipLaunchKernelGGL(k_default_quads, dim3(done_blocks, (a.h + 4*DQ_ROWS*DQ_WALKS - 1)/(4*DQ_ROWS*DQ_WALKS), frames), dim3(256), 0, s, a, t);
+            hipLaunchKernelGGL((k_separable_fused<KIND, SEP_ROWS_DEFAULT, 1, true>), dim3(blocks_x, (a.h + SEP_ROWS_DEFAULT - 1)/SEP_ROWS_DEFAULT, frames), dim3(SEP_PIXELS), 0, s, a, t);
+            return 1;
+        }
+    }
     if (KIND == SEP_DEFAULT && (long)blocks_x*((a.h + SEP_ROWS_DEFAULT*SEP_CHUNKS_DEFAULT - 1)/(SEP_ROWS_DEFAULT*SEP_CHUNKS_DEFAULT))*frames >= 8192)
         hipLaunchKernelGGL((k_separable_fused<KIND, SEP_ROWS_DEFAULT, SEP_CHUNKS_DEFAULT>), dim3(blocks_x, (a.h + SEP_ROWS_DEFAULT*SEP_CHUNKS_DEFAULT - 1)/(SEP_ROWS_DEFAULT*SEP_CHUNKS_DEFAULT), frames), dim3(SEP_PIXELS), 0, s, a, t);
     else if (KIND == SEP_DEFAULT && (long)blocks_x*((a.h + SEP_ROWS_DEFAULT - 1)/SEP_ROWS_DEFAULT)*frames >= 2048)

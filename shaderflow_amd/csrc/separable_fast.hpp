@@ -43,6 +43,8 @@ constexpr int SEP_ROWS_DEFAULT = SEP_ROWS_DEFAULT_N;
 struct SepTables {
     float4* columns;                     // [frame][wr]
     float4* rows;                        // [frame][hr]
+    uint8_t* done;                       // default.glsl in two passes (k_default_quads): [frame][groups of four rows][256-pixel blocks], 1 = already written. nullptr: one pass
+    int done_groups, done_blocks;
 };
 
 // astuv.y of sample row j (vertex/default.glsl:1-17 for one coordinate, glsl.hpp make_varyings) and the number of rows below a height
@@ -248,7 +250,9 @@ constexpr int sep_waves(int sep_rows) {
 // does not retire before its stores are acknowledged — microseconds under load — and a block that makes one walk spends that time
 // holding its registers and LDS: default.glsl's smooth frames ran at 3.7 TB/s with their waves 87 % idle, and neither fewer
 // instructions nor fewer LDS operations moved them.)
-template <int KIND, int SEP_ROWS, int CHUNKS = 1>
+// (TWO_PASS: default.glsl after k_default_quads — the instance that reads that kernel's marks; a template argument because even
+// the untaken branches on a null map cost the one-pass kernel 3 %)
+template <int KIND, int SEP_ROWS, int CHUNKS = 1, bool TWO_PASS = false>
 __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(sep_waves(SEP_ROWS)))) void k_separable_fused(const RenderArgs a, const SepTables t) {
     // a pixel is staged as ONE dword (red in the low byte): 64 lanes write 64 consecutive banks in one pass. (As three byte stores per
     // pixel — lanes sharing dwords — the LDS' write port bounded the smooth frames of default.glsl: 6.4 us where issue asks for 4.)
@@ -307,6 +311,20 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(sep_
         if (chunk) {
             __syncthreads();                                           // the previous walk's rows have left the LDS
             smooth_until = 0; shared_until = 0; attempted = false; wheel_until = 0;
+        }
+        // default.glsl in two passes: the groups of four rows k_default_quads has already written (block-uniform: a block's 256 pixels are
+        // one wave of that kernel)
+        unsigned done_mask = 0u;
+        if constexpr (KIND == SEP_DEFAULT && TWO_PASS) {
+            if (t.done) {
+                const uint8_t* done = t.done + ((long)frame*t.done_groups + (block_row*SEP_ROWS)/4)*t.done_blocks + blockIdx.x;
+#pragma unroll
+                for (int g = 0; g < SEP_ROWS/4; g++)
+                    if ((int)block_row*SEP_ROWS + 4*g < a.h && done[(long)g*t.done_blocks]) done_mask |= 1u << g;
+                done_mask = __builtin_amdgcn_readfirstlane(done_mask);
+                const int groups_here = (min((int)block_row*SEP_ROWS + SEP_ROWS, a.h) - (int)block_row*SEP_ROWS + 3)/4;
+                if (done_mask == (1u << groups_here) - 1u) continue;    // nothing left of this walk (no barrier is skipped by only some threads: the mask is the block's)
+            }
         }
         if constexpr (KIND == SEP_DEFAULT) {
             // default.glsl: the walk in groups of four rows. (A row of the tiers below is ~3 KB of code: it exists once, in a loop.)
@@ -443,6 +461,7 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(sep_
             for (int r = 0; r < SEP_ROWS; r += 4) {
                 const int py = block_row*SEP_ROWS + r;
                 if (py >= a.h) break;
+                if (TWO_PASS && ((done_mask >> (r >> 2)) & 1u)) continue;  // written by k_default_quads
                 const float4 r0 = rows[2*py], r1 = rows[2*py + 1];        // block-uniform: scalar loads
                 // rows in groups of four: the group's first row evaluates the polar terms at the point in the middle of its sixteen samples
                 // and, where default_shares_slope / default_shares_hue allow, the four rows use them (`shared_until` = the first block row
@@ -576,7 +595,7 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(sep_
 #pragma unroll
             for (int i = 0; i < SEP_ROWS/4; i++) {
                 const int r = wave + 4*i;
-                if (r < rows_here) {
+                if (r < rows_here && !(TWO_PASS && ((done_mask >> (r >> 2)) & 1u))) {
                     const int py = block_row*SEP_ROWS + r;
                     const uint4 p = *(const uint4*)&staged[r][4*lane];
                     uint8_t* row = block_out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3;
@@ -594,12 +613,150 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(sep_
 #pragma unroll 1
         for (int r = 0; r < SEP_ROWS; r++) {
             const int py = block_row*SEP_ROWS + r;
-            if (py < a.h && tid < pixels_here) {
+            if (py < a.h && tid < pixels_here && !(TWO_PASS && ((done_mask >> (r >> 2)) & 1u))) {
                 uint8_t* pixel = out + (long)(a.top_down ? a.h - 1 - py : py)*a.w*3 + (long)(x0 + tid)*3;
                 const uint32_t rgb = staged[r][tid];
                 pixel[0] = (uint8_t)rgb; pixel[1] = (uint8_t)(rgb >> 8); pixel[2] = (uint8_t)(rgb >> 16);
             }
         }
+    }
+}
+
+// ---- default.glsl's smooth tier, four pixels per lane (round 5) ---------------------------------------------------------------------
+// k_separable_fused<default> gives a lane ONE pixel column: a row of a wave is 192 bytes that no lane can store by itself, so every
+// row is staged in LDS, read back four pixels at a time, permuted and stored — and of the 470 vector + 347 scalar instructions a smooth
+// wave spends on 1 024 pixels, 176 are the fragment's arithmetic (profiles/r04_basic_tiers.txt: a frame that is smooth everywhere
+// runs at 0.50 of the HBM roof with the VALU 97 % active). Here a lane owns FOUR adjacent pixels = 12 bytes = one non-temporal
+// `global_store_dwordx3` straight from registers (v_cvt_pk_u8_f32 puts a byte anywhere in a dword: the three dwords of four RGB
+// pixels are built in place); a wave covers 256 pixels — exactly a block of k_separable_fused — and walks DQ_ROWS rows. It serves the
+// SMOOTH tier only, with that kernel's arithmetic (same evaluation points, same formula: see its smooth_row): groups of four rows where
+// the test holds for all 256 pixels are written and marked in `t.done`; k_separable_fused then runs over the frame as before and
+// skips what is marked (the band, 16 % of the wave-rows at 4K, keeps its per-pixel tiers and its own one-pixel lanes).
+// MEASURED AND NOT THE DEFAULT (profiles/r05_basic_quads.txt): a frame that is smooth everywhere takes 6.3 us through this kernel
+// and 6.4 through the staged one — the staging was not the cost — and at the Basic scene's zoom the second pass' skipping makes the
+// pair slower than the one pass (84 400 against 92 300 frames/s). Kept behind SHADERFLOW_DEFAULT_QUADS=1 with its parity test.
+constexpr int DQ_ROWS = 16;                                            // rows of a walk (= SEP_ROWS_DEFAULT: the whole-walk evaluation point is the same)
+#ifndef DQ_WALKS
+#define DQ_WALKS 4                                                     // walks a wave makes one below the other with its columns in registers (a wave that ends waits for its stores' acknowledgements)
+#endif
+#ifndef DQ_WAVES
+#define DQ_WAVES 4                                                     // 128 registers, no spill: 5 waves spill 15, 6 spill 33 and lose a quarter (profiles/r05_basic_quads.txt)
+#endif
+struct DefaultQuadPixel { float cx, half_reach, cz, g0, b0; };        // a pixel column: gluv.x at its centre, half the sample spacing, the column means of the smooth tier
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DQ_WAVES))) void k_default_quads(const RenderArgs a, const SepTables t) {
+    const int frame = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int y_wave = (blockIdx.y*4 + wave)*DQ_ROWS*DQ_WALKS;
+    if (y_wave >= a.h) return;
+    const int bx = blockIdx.x;
+    const bool full_block = bx*256 + 256 <= a.w && (a.w & 3) == 0 && (a.out_frame_stride & 3) == 0 && (((uintptr_t)a.out) & 3) == 0;
+    if (!full_block) {                                                 // a partial block of columns: the other kernel's
+        const int groups = (min(y_wave + DQ_ROWS*DQ_WALKS, a.h) - y_wave + 3)/4;
+        uint8_t* done = t.done + ((long)frame*t.done_groups + y_wave/4)*t.done_blocks + bx;
+        for (int g = lane; g < groups; g += 64) done[(long)g*t.done_blocks] = 0;
+        return;
+    }
+    const int px0 = bx*256 + lane*4;
+    const float4* columns = t.columns + (long)frame*a.wr + 2*px0;
+    const float4* rows = t.rows + (long)frame*a.hr;
+    const float tau = a.dyn ? a.dyn[a.frame0 + frame].iTau : a.u.iTau;
+    const float hue_shift = (2.0f*TAU*tau) - (PI/4.0f);               // default.glsl:22
+    DefaultQuadPixel pixel[4];
+    bool outside = false;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const float4 c0 = columns[2*p], c1 = columns[2*p + 1];
+        const bool odd0 = (__float_as_int(c0.y) & 1) != 0, odd1 = (__float_as_int(c1.y) & 1) != 0;
+        const float even_rows0 = odd0 ? DEFAULT_ODD : DEFAULT_EVEN, even_rows1 = odd1 ? DEFAULT_ODD : DEFAULT_EVEN;
+        pixel[p].cx = 0.5f*(c0.x + c1.x);
+        pixel[p].half_reach = 0.5f*sf::abs(c1.x - c0.x);
+        pixel[p].cz = 0.5f*(c0.z + c1.z);
+        pixel[p].g0 = 0.5f*fmaf(c0.z, even_rows0, c1.z*even_rows1);
+        pixel[p].b0 = 0.5f*(even_rows0 + even_rows1);
+        outside = outside || ((__float_as_int(c0.w) | __float_as_int(c1.w)) != 0);
+    }
+    uint8_t* out = (uint8_t*)a.out + (long)frame*a.out_frame_stride + (long)px0*3;
+    const long pitch = (long)a.w*3;
+    const float row_step = sf::abs(rows[2*y_wave + 1].x - rows[2*y_wave].x);
+    const unsigned long long everybody = __builtin_amdgcn_ballot_w64(true);
+
+    // one evaluation of the polar terms per pixel, at (its column's centre, cy): may `rows_reach` rows around cy share it? (k_separable_fused)
+    DefaultRing ring[4]; DefaultHue hue[4]; float slope_y[4], group_y = 0.0f;
+    auto evaluate = [&](float cy, float rows_reach) -> bool {
+        bool fine = !outside;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const float reach = pixel[p].half_reach + rows_reach*row_step;
+            ring[p] = default_ring(pixel[p].cx, cy);
+            fine = fine && default_shares_slope(ring[p], reach) && default_shares_hue(1.5f*ring[p].width, ring[p].len, reach);
+        }
+        if (__builtin_amdgcn_ballot_w64(fine) != everybody) return false;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            hue[p] = default_hue(pixel[p].cx, cy, hue_shift);
+            slope_y[p] = default_slope(ring[p], pixel[p].cx, cy).y;
+        }
+        group_y = cy;
+        return true;
+    };
+#pragma unroll 1
+    for (int walk = 0; walk < DQ_WALKS; walk++) {
+    const int y_first = y_wave + walk*DQ_ROWS;
+    if (y_first >= a.h) break;
+    uint8_t* done = t.done + ((long)frame*t.done_groups + y_first/4)*t.done_blocks + bx;
+    const int groups_here = (min(y_first + DQ_ROWS, a.h) - y_first + 3)/4;
+    const bool whole_walk = (y_first + DQ_ROWS <= a.h) && evaluate(0.5f*(rows[2*y_first + DQ_ROWS - 1].x + rows[2*y_first + DQ_ROWS].x), (float)DQ_ROWS - 0.5f);
+#pragma unroll 1
+    for (int g = 0; g < groups_here; g++) {
+        const int py = y_first + 4*g;
+        bool smooth = py + 3 < a.h;
+        if (smooth && !whole_walk) smooth = evaluate(0.5f*(rows[2*py + 3].x + rows[2*py + 4].x), 3.5f);
+        float4 e[8];
+        if (smooth) {
+            int mixed = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) e[k] = rows[2*py + k];        // wave-uniform: scalar loads
+#pragma unroll
+            for (int k = 1; k < 8; k++) mixed |= __float_as_int(e[k].y) ^ __float_as_int(e[0].y);
+            smooth = (mixed & 1) == 0;                                 // the eight sample rows in one square of the checkerboard's rows
+        }
+        if (lane == 0) done[(long)g*t.done_blocks] = smooth ? 1 : 0;
+        if (!smooth) continue;
+        const bool odd_rows = (__float_as_int(e[0].y) & 1) != 0;
+        float ground_of_rows[4], base_of_rows[4], half_slope[4], offset[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const bool disc = ring[p].circle < 0.0f;
+            ground_of_rows[p] = disc ? DEFAULT_DISC*pixel[p].cz : (odd_rows ? (DEFAULT_EVEN + DEFAULT_ODD)*pixel[p].cz - pixel[p].g0 : pixel[p].g0);
+            base_of_rows[p] = disc ? DEFAULT_DISC : (odd_rows ? (DEFAULT_EVEN + DEFAULT_ODD) - pixel[p].b0 : pixel[p].b0);
+            half_slope[p] = 0.5f*slope_y[p];
+            offset[p] = fmaf(-slope_y[p], group_y, ring[p].width*255.0f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // the row's three values in VECTOR registers: a full-rate form with a scalar source issues at half rate (profiles/r05_ubench_valu_sgpr.txt)
+            float y0, y1, rw;
+            asm("v_mov_b32 %0, %1" : "=v"(y0) : "s"(e[2*k].x));
+            asm("v_mov_b32 %0, %1" : "=v"(y1) : "s"(e[2*k + 1].x));
+            asm("v_mov_b32 %0, %1" : "=v"(rw) : "s"(e[2*k].w));
+            uint32_t d0 = 0u, d1 = 0u, d2 = 0u;                       // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+            float red[4], green[4], blue[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const float vignette = clamp01(pixel[p].cz*rw);
+                const float glow = fmaf(half_slope[p], y0, fmaf(half_slope[p], y1, offset[p]))*vignette;
+                const float ground = __builtin_fminf(rw*ground_of_rows[p], base_of_rows[p]);
+                red[p] = fmaf(glow, hue[p].red, ground); green[p] = fmaf(glow, hue[p].green, ground); blue[p] = fmaf(glow, hue[p].blue, ground);
+            }
+            d0 = __builtin_amdgcn_cvt_pk_u8_f32(red[0], 0u, d0); d0 = __builtin_amdgcn_cvt_pk_u8_f32(green[0], 1u, d0); d0 = __builtin_amdgcn_cvt_pk_u8_f32(blue[0], 2u, d0);
+            d0 = __builtin_amdgcn_cvt_pk_u8_f32(red[1], 3u, d0); d1 = __builtin_amdgcn_cvt_pk_u8_f32(green[1], 0u, d1); d1 = __builtin_amdgcn_cvt_pk_u8_f32(blue[1], 1u, d1);
+            d1 = __builtin_amdgcn_cvt_pk_u8_f32(red[2], 2u, d1); d1 = __builtin_amdgcn_cvt_pk_u8_f32(green[2], 3u, d1); d2 = __builtin_amdgcn_cvt_pk_u8_f32(blue[2], 0u, d2);
+            d2 = __builtin_amdgcn_cvt_pk_u8_f32(red[3], 1u, d2); d2 = __builtin_amdgcn_cvt_pk_u8_f32(green[3], 2u, d2); d2 = __builtin_amdgcn_cvt_pk_u8_f32(blue[3], 3u, d2);
+            const int y = py + k;
+            typedef uint32_t Triple __attribute__((ext_vector_type(3), aligned(4)));
+            __builtin_nontemporal_store(Triple{d0, d1, d2}, (Triple*)(out + (long)(a.top_down ? a.h - 1 - y : y)*pitch));
+        }
+    }
     }
 }
 

@@ -74,13 +74,16 @@ def test_dense_2x_instances_whole_frame(gpu, w, h, kernel):
         assert d.max() <= 1, (volume, lsb_report(got, want), np.argwhere(d > 1)[:5].tolist())
 
 
-@pytest.mark.parametrize("zoom,tau", [(1.0, 0.37), (0.55, 0.81)])
-def test_basic_whole_frame_4k(gpu, zoom, tau):
+@pytest.mark.parametrize("zoom,tau,quads", [(1.0, 0.37, False), (0.55, 0.81, False), (1.0, 0.37, True), (0.2, 0.5, True)])
+def test_basic_whole_frame_4k(gpu, zoom, tau, quads, monkeypatch):
     """default.glsl (the Basic scene) at 3840x2160 2xSSAA: k_separable_fused<default> shares the polar terms between the four
     samples of a pixel in three tiers by the distance to the ring (separable_fast.hpp default_shares_ring / default_shares_hue) —
     where the tiers fall depends on the size of a pixel, so the whole frame at the size bench.py --scene basic times, and a
     zoomed camera that puts the ring elsewhere"""
     w, h = 3840, 2160
+    # (quads: the opt-in two-pass arrangement of round 5 — the smooth tier by k_default_quads, four pixels per lane, the rest by the
+    # kernel above, which skips what that one marked: same bound)
+    monkeypatch.setenv("SHADERFLOW_DEFAULT_QUADS", "1" if quads else "0")
     u, arrays, params = visualizer_inputs(w, h, seed=5)
     u.iSSAA, u.iTau, u.iCameraZoom = 2.0, tau, zoom
     prog, _ = gpu.program("default")
