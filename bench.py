@@ -617,24 +617,37 @@ def main() -> None:
         # the whole clip when the default workload is measured (60 s = 3 600 frames: the north star's export), a bounded piece otherwise
         whole_clip = (w, h, s) == (3840, 2160, 2) and args.steps >= 8
         frames_export = int(seconds*60) if whole_clip else max(fpb, min(world*args.steps*fpb, int(seconds*60)))
-        barrier()
-        t1 = time.perf_counter()
-        scene2.main(width=w, height=h, ssaa=s, fps=60.0, time=frames_export/60.0, output="/dev/null")
-        barrier()
-        took = time.perf_counter() - t1
-        planar = None
-        if True:
-            # the same export with the frames converted to planar yuv420p on the device (scene.main(pixel_format="yuv420p"), opt-in:
-            # SURVEY §8 f1's optional half): 12.4 MB per frame over PCIe instead of 24.9 — since round 5 in every shard mode too, converted
-            # on the rank that rendered the frame
-            scene3 = build_scene(prepared=False)
+        def timed_export(scene_to_run, pixel_format):
+            """scene.main() to /dev/null between two barriers; a rank that fails still reaches the second barrier and tells the others
+            (an export leg that does not work between real GPUs must cost the line its `export_host`, not the whole line)"""
             barrier()
-            t2 = time.perf_counter()
-            scene3.main(width=w, height=h, ssaa=s, fps=60.0, time=frames_export/60.0, output="/dev/null", pixel_format="yuv420p")
+            started = time.perf_counter()
+            problem = ""
+            try:
+                extra = {"pixel_format": pixel_format} if pixel_format else {}
+                scene_to_run.main(width=w, height=h, ssaa=s, fps=60.0, time=frames_export/60.0, output="/dev/null", **extra)
+            except Exception as error:                               # noqa: BLE001
+                problem = f"rank {rank}: {type(error).__name__}: {error}"
             barrier()
-            planar = {"value": round(frames_export/(time.perf_counter() - t2), 2), "unit": "frames/s", "frames": frames_export,
-                      "note": "BT.601 limited range, chroma from the rounded 2x2 mean; not the reference's byte stream (it hands ffmpeg rgb24)"}
-        export = {"value": round(frames_export/took, 2), "unit": "frames/s", "frames": frames_export, "seconds": round(took, 3), "yuv420p": planar,
+            seconds_taken = time.perf_counter() - started
+            problems = [problem]
+            if distributed:
+                problems = [None]*world
+                dist.all_gather_object(problems, problem)
+            problems = [text for text in problems if text]
+            if problems and rank == 0:
+                print(f"bench.py: export leg ({pixel_format or 'rgb24'}) failed: {'; '.join(problems)}", file=sys.stderr)
+            return seconds_taken, "; ".join(problems)
+
+        took, failed = timed_export(scene2, None)
+        # the same export with the frames converted to planar yuv420p on the device (scene.main(pixel_format="yuv420p"), opt-in:
+        # SURVEY §8 f1's optional half): 12.4 MB per frame over PCIe instead of 24.9 — since round 5 in every shard mode too, converted
+        # on the rank that rendered the frame
+        took_planar, failed_planar = timed_export(build_scene(prepared=False), "yuv420p")
+        planar = {"value": round(frames_export/took_planar, 2) if not failed_planar else None, "unit": "frames/s", "frames": frames_export, "error": failed_planar or None,
+                  "note": "BT.601 limited range, chroma from the rounded 2x2 mean; not the reference's byte stream (it hands ffmpeg rgb24)"}
+        export = {"value": round(frames_export/took, 2) if not failed else None, "unit": "frames/s", "frames": frames_export, "seconds": round(took, 3), "yuv420p": planar,
+                  "error": failed or None,
                   "mode": ("pinned ring + writer thread" if world == 1 else f"sharded export, SHADERFLOW_SHARD={os.environ.get('SHADERFLOW_SHARD', 'host')}"),
                   "note": "whole scene.main(): tape schedule, table set-up, render, read-out over PCIe, write to /dev/null"}
 
