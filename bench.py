@@ -438,6 +438,8 @@ def main() -> None:
                         windows = [context.peer_open(handle) for handle in handles[0][rank]]
                     elif loopback:
                         windows = list(raw_received[0])             # ONE rank: the copies go to this rank's own receive buffers (no IPC mapping of one's own allocation)
+                    if os.environ.get("SHADERFLOW_BENCH_INJECT") == "sdma-preflight" and rank == world - 1:
+                        raise RuntimeError("injected: this rank's peer copies do not work")     # tests: the run must go on without the transport
                     if windows and (rank or loopback):
                         probe = torch.full((4096,), 0xA5, dtype=torch.uint8, device="cuda")
                         torch.cuda.current_stream().synchronize()

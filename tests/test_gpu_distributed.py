@@ -199,6 +199,27 @@ def test_bench_with_two_ranks_over_peer_windows():
 
 
 @pytest.mark.timeout(400)
+def test_bench_goes_on_without_a_transport_that_fails_its_preflight():
+    """The SDMA peer copies have only ever run on one GPU: if they do not work between two real ones, EVERY rank drops the transport
+    together before any timed leg (a collective preflight) and the line says so — here rank 1's preflight is made to fail"""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, SHADERFLOW_DIST_BACKEND="gloo", SHADERFLOW_BENCH_INJECT="sdma-preflight")
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), str(root/"bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--frames-per-step", "4", "--width", "384", "--height", "216", "--no-export"]
+    out = subprocess.run(command, capture_output=True, text=True, timeout=360, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    record = json.loads([line for line in out.stdout.splitlines() if line.startswith("{")][-1])
+    assert "injected" in record["gather"]["sdma_dropped"] and record["gather"]["chosen"] == "p2p"
+    assert {(leg["transport"], leg["payload"]) for leg in record["gather"]["legs"]} == {("p2p", "rgb24"), ("p2p", "yuv420p")}
+    assert record["value"] > 0 and record["rccl_ranks"] == 2
+
+
+@pytest.mark.timeout(400)
 def test_bench_with_two_ranks_prints_one_line_for_the_whole_job():
     """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one rank per GPU), here with two ranks on the one
     test GPU over gloo: barrier + max-over-ranks timing, the gather to rank 0, ONE JSON line from rank 0 with the aggregate"""
