@@ -2281,6 +2281,10 @@ extern "C" int sfx_clock_sequence_run(sfx_handle hc, const sfx_sequence_pass* pa
         if (matrices[m].temporal < 1 || matrices[m].layers < 1 || !matrices[m].textures) return fail(SFX_E_INVALID, "clock sequence: matrix %d", m);
         order[m].resize(matrices[m].temporal);
         for (int t = 0; t < matrices[m].temporal; t++) order[m][t] = t;
+        for (int k = 0; k < matrices[m].temporal*matrices[m].layers; k++) {
+            Texture* texture = get<Texture>(matrices[m].textures[k], MAGIC_TEX);
+            if (!texture || texture->ctx != c) return fail(SFX_E_INVALID, "clock sequence: matrix %d, box %d is not a texture of this context", m, k);
+        }
     }
     auto box = [&](int m, int t, int l) -> sfx_handle { return matrices[m].textures[order[m][t]*matrices[m].layers + (l < 0 ? matrices[m].layers + l : l)]; };
     // sampler slots of every (program, named box), resolved once: the names never change, only what sits behind them
