@@ -281,3 +281,22 @@ def test_module_skipping_keeps_the_order_in_which_modules_override_each_other():
     third.token = "t1"
     program.use_scene_pipeline()
     assert [m.walks for m in scene.modules] == [3, 3, 2] and program.sent == [("other", 3.0)]
+
+
+def test_issue_model_prices_the_uncounted_scalar_source_and_packed_forms():
+    """bench.py roofline.issue_model (ONE number): class counters x their prices + the uncounted forms at the
+    census' price + two cycles per full-rate form with a scalar source and per packed-f32 form (the class counters count a
+    v_pk_fma_f32 once, as an fma), over the SIMD cycles the launch had. Hand-computed."""
+    import bench
+    cs = {"SQ_INSTS_VALU": 1000.0, "SQ_INSTS_VALU_ADD_F32": 200.0, "SQ_INSTS_VALU_MUL_F32": 100.0, "SQ_INSTS_VALU_FMA_F32": 400.0,
+          "SQ_INSTS_VALU_INT32": 50.0, "SQ_INSTS_VALU_CVT": 30.0, "SQ_INSTS_VALU_TRANS_F32": 20.0, "GRBM_GUI_ACTIVE": 8.0*4.0, "SQ_THREAD_CYCLES_VALU": 1000.0*64.0}
+    census = {"other_cycles_per_instruction": 3.0, "sgpr_source_full_rate_forms_per_valu_instruction": 0.10, "packed_f32_forms_per_valu_instruction": 0.08}
+    model = bench.issue_model(cs, 2.0, census)
+    had = 4.0*256*4                                                   # GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs
+    priced = 200*2 + 100*2 + 400*2 + 50*4 + 30*4 + 20*8
+    other = 1000 - (200 + 100 + 400 + 50 + 30 + 20)
+    assert model["instructions"]["other"] == other and model["simd_cycles_available"] == had
+    assert model["frac_census"] == round((priced + 3.0*other + 2.0*0.10*1000 + 2.0*0.08*1000)/had, 4) == model["frac"]
+    assert model["frac_low"] == round((priced + 2*other)/had, 4) and model["frac_other_at_4"] == round((priced + 4*other)/had, 4)
+    assert model["effective_clock_GHz"] == 2.0 and model["lane_utilisation"] == 1.0
+    assert bench.issue_model(cs, 2.0, None)["frac_census"] is None   # no census for this kernel: the 2-or-4 band stays
