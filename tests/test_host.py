@@ -300,3 +300,25 @@ def test_issue_model_prices_the_uncounted_scalar_source_and_packed_forms():
     assert model["frac_low"] == round((priced + 2*other)/had, 4) and model["frac_other_at_4"] == round((priced + 4*other)/had, 4)
     assert model["effective_clock_GHz"] == 2.0 and model["lane_utilisation"] == 1.0
     assert bench.issue_model(cs, 2.0, None)["frac_census"] is None   # no census for this kernel: the 2-or-4 band stays
+
+
+def test_isa_census_classes_and_scalar_sources():
+    """tools/isa_census.py (the evidence behind issue_model's one number): which class an instruction is priced in, and which
+    full-rate forms read a scalar register"""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent/"tools"))
+    import isa_census as census
+    cases = {"v_fmac_f32": "fma_f32", "v_fmaak_f32": "fma_f32", "v_add_f32": "add_f32", "v_pk_fma_f32": "pk_fma_f32", "v_pk_add_f32": "pk_add_f32",
+             "v_rcp_f32": "trans", "v_cvt_pk_u8_f32": "cvt", "v_med3_f32": "minmax_med", "v_cmp_gt_f32": "cmp", "v_cndmask_b32": "cndmask",
+             "v_mov_b32": "mov", "v_readfirstlane_b32": "readlane", "v_add_u32": "int_add_logic", "v_lshlrev_b32": "int_shift_mul",
+             "ds_read_b128": "lds", "s_load_dwordx4": "smem", "s_waitcnt": "waitcnt", "s_cbranch_scc1": "branch", "s_add_u32": "salu",
+             "global_store_dwordx3": "vmem"}
+    for mnemonic, want in cases.items():
+        assert census.classify(mnemonic, "") == want, (mnemonic, census.classify(mnemonic, ""))
+    assert census.classify("v_mov_b32", "v1, v2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") == "dpp_swizzle"
+    assert census.uses_sgpr_source("v_mov_b32", "v8, s9") and census.uses_sgpr_source("v_fmac_f32", "v50, s8, v32")
+    assert census.uses_sgpr_source("v_pk_fma_f32", "v[38:39], s[8:9], v[8:9], v[38:39] op_sel_hi:[0,1,1]")
+    assert not census.uses_sgpr_source("v_fmac_f32", "v50, v52, v13") and not census.uses_sgpr_source("v_readfirstlane_b32", "s22, v1")
+    cycles = {name: c for name, _, c in census.CLASSES}
+    assert cycles["fma_f32"] == 2 and cycles["pk_fma_f32"] == 4 and cycles["trans"] == 8 and cycles["cvt"] == 4
