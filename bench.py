@@ -314,19 +314,83 @@ def issue_model(cs: dict, launch_ns: float | None, census: dict | None = None) -
             "lane_utilisation": round(cs["SQ_THREAD_CYCLES_VALU"]/(cs["SQ_INSTS_VALU"]*64.0), 4) if cs.get("SQ_THREAD_CYCLES_VALU") else None}
 
 
+def refuse(sentence: str) -> "NoReturn":
+    """One sentence on stderr and a non-zero exit: a line that says `n_gpus: 1` when N were asked for must never be printed"""
+    print(f"bench.py: {sentence}", file=sys.stderr, flush=True)
+    raise SystemExit(2)
+
+
+def launcher_command(gpus: int, argv: list[str], port: int) -> list[str]:
+    """`python bench.py --gpus N` with no launcher around it: the command of the N ranks, exactly what the driver itself uses for N > 1"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+
+
+def spawn_ranks(args, argv: list[str]) -> int:
+    """--gpus N > 1 and no WORLD_SIZE: this process BECOMES the launcher's parent. Nothing here has imported torch or the HIP library
+    (no GPU call: the ranks are a CHILD process, never an exec of a process that touched the GPU); rank 0's JSON line is relayed as
+    this process' last stdout line, everything else the ranks print goes to stderr, and the child's exit code is this one's."""
+    import socket
+    import subprocess
+    with socket.socket() as probe:                                  # a free port for the rendezvous (the driver passes its own when IT launches)
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
+    command = launcher_command(args.gpus, argv, port)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), SHADERFLOW_BENCH_SPAWNED="1")
+    print(f"bench.py: --gpus {args.gpus} without a launcher: starting {' '.join(command[1:8])} …", file=sys.stderr, flush=True)
+    child = subprocess.Popen(command, stdout=subprocess.PIPE, text=True, env=env, cwd=str(ROOT))
+    line = None
+    for text in child.stdout:
+        candidate = text.strip()
+        record = None
+        if candidate.startswith("{") and candidate.endswith("}"):
+            try:
+                record = json.loads(candidate)
+            except ValueError:
+                record = None
+        if isinstance(record, dict) and "metric" in record and "n_gpus" in record:
+            line = candidate
+        else:
+            sys.stderr.write(text)
+    rc = child.wait()
+    if rc != 0:
+        print(f"bench.py: the {args.gpus} ranks ended with exit code {rc}: no line", file=sys.stderr, flush=True)
+        return rc
+    if line is None:
+        print(f"bench.py: the {args.gpus} ranks ended without a JSON line", file=sys.stderr, flush=True)
+        return 3
+    record = json.loads(line)
+    if record.get("n_gpus") != args.gpus or record.get("rccl_ranks") != args.gpus:
+        print(f"bench.py: asked for {args.gpus} GPUs, the line says n_gpus {record.get('n_gpus')} / rccl_ranks {record.get('rccl_ranks')}: refused", file=sys.stderr, flush=True)
+        return 4
+    sys.stderr.flush()
+    print(line, flush=True)
+    return 0
+
+
 def main() -> None:
     args = parse_args()
+    if args.gpus < 1:
+        refuse(f"--gpus {args.gpus}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # (before torch, before the HIP library, before any GPU call)
+        raise SystemExit(spawn_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        # either way the line would not be what was asked for: N ranks under --gpus 1, or ONE rank under --gpus N (a launcher that set
+        # WORLD_SIZE=1) — the latter printed `n_gpus: 1` silently until round 5
+        refuse(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
 
     # the host driver of this pool supports dmabuf IPC only: without this RCCL's cross-process buffers fail (hipIpcGetMemHandle)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch                                                  # before the HIP library: one HIP runtime per process
 
+    backend = os.environ.get("SHADERFLOW_DIST_BACKEND", "nccl")
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
+        refuse(f"--gpus {world} under RCCL needs {world} visible GPUs, this node shows {torch.cuda.device_count()} (one rank per GPU; several ranks on one device is the gloo test's set-up)")
     local_rank %= max(1, torch.cuda.device_count())               # more ranks than devices only happens in the gloo test
     torch.cuda.set_device(local_rank)
     distributed = world > 1 or os.environ.get("SHADERFLOW_FORCE_DIST") == "1"     # the env var exercises the RCCL path on one GPU
@@ -334,7 +398,6 @@ def main() -> None:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL ("nccl") is the backend; SHADERFLOW_DIST_BACKEND=gloo lets tests run several ranks on ONE device (RCCL refuses that)
-        backend = os.environ.get("SHADERFLOW_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -660,6 +723,9 @@ def main() -> None:
         if (w, h, s) == (3840, 2160, 2):
             baseline["llvmpipe_container"] = REFERENCE_LLVMPIPE
 
+    if ranks_seen != args.gpus:
+        # the all-reduce over the process group counted another number of ranks than --gpus: whatever the cause, no line
+        refuse(f"rank {rank}: the process group counted {ranks_seen} ranks, --gpus {args.gpus} was asked for")
     if rank == 0:
         c3 = (w, h, s) == (3840, 2160, 2) and args.scene == "visualizer"
         b_alg = B_ALG_PER_FRAME.get((w, h, s), float(w*s*h*s*8 + w*h*6))

@@ -2,14 +2,10 @@
 // Host-side state only: handles, the fragment registry, uniform/sampler tables, launch geometry, the
 // pinned read-out ring with its pipe writer thread, and the audio plan/tape objects.
 
-#include "../../include/shaderflow_hip.h"
-
+#include "launch.hpp"
+#include "launch_geometry.hpp"
 #include "audio_kernels.hpp"
 #include "visualizer_kernels.hpp"
-#include "visualizer_fast.hpp"
-#include "resolve_fast.hpp"
-#include "separable_fast.hpp"
-#include "layered_fast.hpp"
 #include "uniform_table.hpp"
 
 #include <hsa/hsa.h>
@@ -34,73 +30,23 @@ using namespace sf;
 // ---------------------------------------------------------------------------------------------------------
 // Errors and handles
 
-static thread_local std::string g_error;
-static thread_local std::string g_last_kernel;   // which render kernel instance the last launch on this thread picked (sfx_last_kernel)
+thread_local std::string g_error;
+thread_local std::string g_last_kernel;   // which render kernel instance the last launch on this thread picked (sfx_last_kernel)
 
-static int fail(int code, const char* fmt, ...) {
+int fail(int code, const char* fmt, ...) {
     char buf[1024];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
     g_error = buf;
     return code;
 }
-#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(SFX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
 extern "C" const char* sfx_last_error(void) { return g_error.c_str(); }
 extern "C" const char* sfx_version(void) { return "shaderflow_hip 0.2 (gfx950)"; }
 // (defined after the kernel headers) fingerprint of the kernel-argument layout this library was built with
 extern "C" uint64_t sfx_abi_layout(void);
 
-enum : uint32_t { MAGIC_CTX = 0x53465843, MAGIC_TEX = 0x53465854, MAGIC_PROG = 0x53465850, MAGIC_RING = 0x53465852,
-                  MAGIC_AUDIO = 0x53465841, MAGIC_PLAN = 0x5346584c, MAGIC_TAPE = 0x53465854 + 0x100, MAGIC_SHM = 0x53465853 };
-
-struct Object { uint32_t magic; };
-
-template <class T> static T* get(sfx_handle h, uint32_t magic) {
-    Object* o = reinterpret_cast<Object*>(static_cast<uintptr_t>(h));
-    return (o && o->magic == magic) ? static_cast<T*>(o) : nullptr;
-}
-template <class T> static sfx_handle handle_of(T* p) { return static_cast<sfx_handle>(reinterpret_cast<uintptr_t>(p)); }
-
-struct Context : Object {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    hipEvent_t events[64] = {};
-    hipDeviceProp_t prop;
-    float tap_x[81], tap_y[81];
-    std::vector<struct Program*> programs;   // live programs of this context (their sampler slots point at textures)
-    int top_down = 0;                // frames leave with rows top-down (sfx_ctx_output_top_down)
-    int filter_model = SFX_FILTER_SPEC;   // sfx_ctx_filter_model: how LINEAR unorm8 textures of this context are filtered (tex_view)
-    // per-frame column/row tables of the fast visualizer kernel (visualizer_fast.hpp), grown on demand
-    void* vis_tables = nullptr; size_t vis_tables_bytes = 0;
-    float* vis_bars = nullptr; size_t vis_bars_count = 0;          // sqrt(texel/1000) of a bound spectrogram (single launches)
-    void* resolve_tables = nullptr; size_t resolve_tables_bytes = 0;   // column/row tap tables of k_resolve_fast
-    long resolve_tables_key[8] = {};                               // the geometry (and stream) they were built for
-    // the context's two copy streams (read-out ring, shared-memory ring, peer windows): chosen once so that neither shares a hardware
-    // queue with `stream` (context_copy_streams)
-    hipStream_t copy_streams[2] = {nullptr, nullptr};
-    unsigned* tile_misses = nullptr;                               // device counter of sfx_ctx_tile_misses, allocated by its first call
-    struct sf::MultipassTaps* multipass_taps = nullptr;            // multipass.frag's blur taps on the device (layered_fast.hpp), built on first use
-    float multipass_reach[2] = {0.0f, 0.0f};
-    int copy_candidates = 0, copy_colliding = 0;                   // how many streams the choice looked at / found serialised behind `stream`
-    // read-out rings of this context: (ring, "every frame handed to it so far has left device memory"). Their copies run outside HIP's
-    // queues, so hipFree's implicit wait knows nothing of them: sfx_device_free asks them first.
-    std::vector<std::pair<void*, void (*)(void*)>> readouts;
-    struct EngineCopy* engines = nullptr;                           // agents and SDMA engines of the read-out (EngineLanes); null until first use
-    struct EngineCopy* peer_engines = nullptr;                      // … of the peer copies (PeerCopier)
-    struct PeerCopier* peer = nullptr;                              // the sharded export's peer copies: a thread that issues them on named engines
-    // peer copies of the sharded export's "device-sdma" mode: the copy streams, an event per lane (sfx_peer_*)
-};
 static void peer_stop(Context* c);                                 // (defined with the peer windows)
-static thread_local Context* g_launch_ctx = nullptr;               // the context whose program is being launched (scratch owner)
-
-struct Texture : Object {
-    Context* ctx;
-    int width, height, components, dtype, filter = SFX_LINEAR, repeat_x = 1, repeat_y = 1;
-    void* data = nullptr;
-    size_t nbytes = 0;
-    void* mips = nullptr; int levels = 1;      // levels 1… of the chain, built by sfx_texture_build_mipmaps (glsl.hpp mip_level says where each one starts)
-};
+thread_local Context* g_launch_ctx = nullptr;               // the context whose program is being launched (scratch owner)
 
 static size_t dtype_size(int dtype) { return dtype == SFX_U8 ? 1 : (dtype == SFX_F32 ? 4 : 2); }
 
@@ -115,8 +61,6 @@ static Tex tex_view(const Texture* t) {
     return v;
 }
 
-#define CTX_OR_FAIL(var, h) Context* var = get<Context>(h, MAGIC_CTX); if (!var) return fail(SFX_E_INVALID, "invalid context handle")
-#define USE_DEVICE(ctx) HIP_TRY(hipSetDevice((ctx)->device))
 
 // ---------------------------------------------------------------------------------------------------------
 // Context
@@ -1195,491 +1139,56 @@ static int check_samplers(int fragment, const RenderArgs& a) {
     return rc;
 }
 
-// "k_render<…>" / "k_render_resolve<…, S>" of the instance a launch picked, from the compiler's spelling of the enclosing template
-static void note_kernel(const char* pretty, const char* kernel, int ssaa = 0) {
-    std::string text(pretty);
-    const size_t at = text.find("SHADER = ");
-    std::string shader = at == std::string::npos ? text : text.substr(at + 9);
-    size_t end = shader.find(", S = ");                             // "[SHADER = …, S = 2]" / "[SHADER = …]"
-    if (end == std::string::npos) end = shader.find_first_of(";]");
-    if (end != std::string::npos) shader.resize(end);
-    for (size_t k; (k = shader.find("sf::")) != std::string::npos; ) shader.erase(k, 4);
-    g_last_kernel = std::string(kernel) + "<" + shader + (ssaa ? ", " + std::to_string(ssaa) : std::string()) + ">";
-}
 extern "C" const char* sfx_last_kernel(void) { return g_last_kernel.c_str(); }
 
-template <class SHADER> static void launch_render_t(const RenderArgs& a, int frames, hipStream_t s, size_t dynamic_lds = 0) {
-    note_kernel(__PRETTY_FUNCTION__, "k_render");
-    dim3 grid((a.wr + SHADER::BLOCK_W - 1)/SHADER::BLOCK_W, (a.hr + SHADER::BLOCK_H - 1)/SHADER::BLOCK_H, frames), block(SHADER::BLOCK_W, SHADER::BLOCK_H, 1);
-    if (dynamic_lds > 48*1024) hipFuncSetAttribute((const void*)k_render<SHADER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_lds);
-    hipLaunchKernelGGL(k_render<SHADER>, grid, block, dynamic_lds, s, a);
-}
-
-// Upper bound of the background window (in texel cells) that a block of `sx` x `sy` shaded samples needs for
-// visualizer.frag's taps — the numbers VisualizerShader::setup derives per block, bounded over the frames of a launch.
-// Texels per sample are zoom^2 * background.height / shaded_height on both axes (visualizer.frag:17, gtexture); on the
-// tape path the per-frame zoom and blur radius live on the device, so their largest values are used (z <= 0.93,
-// intensity <= 0.003). A zoomed / panned camera scales each axis by its slope; any other camera (rolled, tilted) mixes the axes:
-// camera_slopes() bounds the four partial derivatives of iCamera.gluv over the screen. The kernel still checks every block
-// (a window that does not fit falls back to the generic taps), so the bound decides speed, never results.
-
-// Bounds of |d iCamera.gluv / d gluv| over the screen for a camera that is neither the identity nor axis aligned, from get_camera on
-// a 17 x 17 lattice of fragments. A camera rolled about its untouched forward axis (right.z == up.z == 0, forward == z) keeps `t` of
-// CameraRay2D constant: the map is affine and the lattice differences ARE the slopes; a tilted camera is projective, where the
-// slope inside a lattice cell can exceed the difference across it — half as much again covers it for the tilts a plane in front of
-// the camera allows before the horizon enters the screen (and the horizon itself fails the finiteness check).
-static bool camera_slopes(const RenderArgs& a, float (&slope)[2][2]) {
-    const Uniforms& u = a.u;
-    const bool affine = u.iCameraProjection == 0 && u.iCameraRight[2] == 0.0f && u.iCameraUpward[2] == 0.0f
-        && u.iCameraForward[0] == 0.0f && u.iCameraForward[1] == 0.0f && u.iCameraForward[2] == 1.0f;
-    if (u.iCameraProjection != 0) return false;          // stereoscopic jumps at the centre column, equirectangular wraps
-    constexpr int G = 16;
-    vec2 hit[G + 1][G + 1];
-    for (int j = 0; j <= G; j++) for (int i = 0; i <= G; i++) {
-        Frag f{};
-        f.u = &u; f.aspect = a.aspect;
-        f.gluv = vec2{a.aspect*(2.0f*(float)i/(float)G - 1.0f), 2.0f*(float)j/(float)G - 1.0f};
-        f.agluv = f.gluv/vec2{a.aspect, 1.0f};
-        const Camera c = get_camera(f);
-        if (!(fabsf(c.gluv.x) < 1e6f) || !(fabsf(c.gluv.y) < 1e6f)) return false;
-        hit[j][i] = c.gluv;
-    }
-    const float step_x = 2.0f*a.aspect/(float)G, step_y = 2.0f/(float)G, margin = affine ? 1.002f : 1.5f;
-    slope[0][0] = slope[0][1] = slope[1][0] = slope[1][1] = 0.0f;
-    for (int j = 0; j <= G; j++) for (int i = 0; i <= G; i++) {
-        if (i < G) {
-            slope[0][0] = fmaxf(slope[0][0], fabsf(hit[j][i + 1].x - hit[j][i].x)/step_x);
-            slope[1][0] = fmaxf(slope[1][0], fabsf(hit[j][i + 1].y - hit[j][i].y)/step_x);
-        }
-        if (j < G) {
-            slope[0][1] = fmaxf(slope[0][1], fabsf(hit[j + 1][i].x - hit[j][i].x)/step_y);
-            slope[1][1] = fmaxf(slope[1][1], fabsf(hit[j + 1][i].y - hit[j][i].y)/step_y);
-        }
-    }
-    for (auto& row : slope) for (float& v : row) v *= margin;
-    return true;
-}
-
-static void visualizer_window_bound(const RenderArgs& a, int sx, int sy, int& tw, int& th) {
-    const Tex& bg = a.tex[TEX_BACKGROUND];
-    const float zoom2 = a.has_vis ? a.vis.zoom2 : 0.93f*0.93f;
-    const float intensity = a.has_vis ? fabsf(a.vis.intensity) : 0.003f;
-    const float density = zoom2*(float)bg.height/(float)a.hr;
-    // texels along x / y per sample step along x / y
-    float xx = density, xy = 0.0f, yx = 0.0f, yy = density;
-    if (a.axis_camera && !a.identity_camera) {
-        // a zoomed / panned camera: iCamera.gluv is an affine function of gluv per axis (glsl.hpp camera_along_axis): its slopes
-        bool behind = false;
-        const float sx_ = (camera_along_axis<0>(a.u, 1.0f, a.aspect, behind) - camera_along_axis<0>(a.u, -1.0f, a.aspect, behind))/2.0f;
-        const float sy_ = (camera_along_axis<1>(a.u, 1.0f, a.aspect, behind) - camera_along_axis<1>(a.u, -1.0f, a.aspect, behind))/2.0f;
-        xx *= fabsf(sx_)*1.001f; yy *= fabsf(sy_)*1.001f;
-        if (!(xx == xx) || !(yy == yy)) { xx = yy = 1e9f; }
-    } else if (!a.identity_camera) {
-        float slope[2][2];
-        if (camera_slopes(a, slope)) { xx = density*slope[0][0]; xy = density*slope[0][1]; yx = density*slope[1][0]; yy = density*slope[1][1]; }
-        else xx = yy = 1e9f;
-    }
-    const float rx = intensity*a.bg_scale_x*(float)bg.width*1.101f + 0.001f, ry = intensity*(float)bg.height*1.101f + 0.001f;
-    // the affine cameras' blocks bound their window from four corners through the HOST's map and widen it by a slack for the difference
-    // to the samples' own chain (VisualizerShader::setup 1a': 0.05 texel + 1e-5 of the four coordinates' magnitudes): the tile holds it
-    // for coordinates within one repeat of the background (blocks further out take the generic taps)
-    const float slack = a.affine_camera ? 2.0f*(0.05f + 1.0e-5f*4.0f*2.0f*(float)(bg.width > bg.height ? bg.width : bg.height)) : 0.0f;
-    tw = (int)floorf(fminf((float)(sx - 1)*xx + (float)(sy - 1)*xy + 2.0f*rx + slack, 1e6f)) + 2;
-    th = (int)floorf(fminf((float)(sx - 1)*yx + (float)(sy - 1)*yy + 2.0f*ry + slack, 1e6f)) + 2;
-}
-static const size_t VIS_LDS_LIMIT = 150*1024;                         // leave room for the static shared state of the kernels
-
-static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hipStream_t s, bool to_screen);
-
-// ---- the second layer of multipass.frag / motionblur.frag (layered_fast.hpp): 1 launched, 0 not this path's configuration -----------
-#ifndef LAYERED_FAST
-#define LAYERED_FAST 1
-#endif
-static int launch_multipass_layer1(const RenderArgs& a, int frames, hipStream_t s) {
-    Context* ctx = g_launch_ctx;
-    const Tex& first = a.tex[TEX_HISTORY];
-    static const bool off = [] { const char* e = getenv("SHADERFLOW_LAYERED_FAST"); return e && atoi(e) == 0; }();     // A/B switch for measurements
-    if (!LAYERED_FAST || off || !ctx || a.u.iLayer != 1 || !first.data || first.dtype != DT_U8 || first.components != 4 || first.filter != FILTER_LINEAR) return 0;
-    if (!ctx->multipass_taps) {
-        MultipassTaps table;
-        multipass_tap_table(table, 5.0f, 8, 8);                     // multipass.frag:41 blur(iScreen0x0, astuv, 5, 8, 8)
-        if (table.count > LAYERED_MAX_TAPS) return 0;
-        if (hipMalloc((void**)&ctx->multipass_taps, sizeof table) != hipSuccess) return fail(SFX_E_HIP, "multipass tap table: out of device memory");
-        if (hipMemcpy(ctx->multipass_taps, &table, sizeof table, hipMemcpyHostToDevice) != hipSuccess) return fail(SFX_E_HIP, "multipass tap table: upload failed");
-        ctx->multipass_reach[0] = table.reach_u; ctx->multipass_reach[1] = table.reach_v;
-    }
-    // texels under a block of 64 x 8 pixels plus the blur's reach on both sides (and the bilinear neighbour, and a texel of slack per side)
-    const int tile_w = (int)ceilf((float)MP_BLOCK_W*(float)first.width/(float)a.wr + 2.0f*ctx->multipass_reach[0]*(float)first.width) + 6;
-    const int tile_h = (int)ceilf((float)MP_BLOCK_H*(float)first.height/(float)a.hr + 2.0f*ctx->multipass_reach[1]*(float)first.height) + 6;
-    const size_t lds = (size_t)tile_w*tile_h*sizeof(float4);
-    if (lds > 96*1024) return 0;                                    // a layer far larger than its target: the generic kernel
-    if (lds > 48*1024) hipFuncSetAttribute((const void*)k_multipass_layer1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    g_last_kernel = "k_multipass_layer1";
-    hipLaunchKernelGGL(k_multipass_layer1, dim3((a.wr + MP_BLOCK_W - 1)/MP_BLOCK_W, (a.hr + MP_BLOCK_H - 1)/MP_BLOCK_H, frames), dim3(MP_BLOCK_W, MP_BLOCK_H/MP_ROWS), lds, s,
-                       a, ctx->multipass_taps, tile_w, tile_h);
-    return 1;
-}
-static int launch_motionblur_layer1(const RenderArgs& a, int frames, hipStream_t s) {
-    static const bool off = [] { const char* e = getenv("SHADERFLOW_LAYERED_FAST"); return e && atoi(e) == 0; }();
-    const int temporal = (int)a.u.user[USER_SCREEN_TEMPORAL];
-    if (!LAYERED_FAST || off || a.u.iLayer != 1 || temporal < 1 || temporal > TEX_HISTORY_DEPTH) return 0;
-    const Tex& first = a.tex[TEX_HISTORY];
-    MotionblurArgs m{};
-    m.temporal = temporal;
-    for (int t = 0; t < temporal; t++) {
-        const Tex& layer = a.tex[TEX_HISTORY + t];
-        // one size, one sampler state: then addressing and weights of texture(iScreen{t}x0, astuv) are one computation per pixel
-        if (!layer.data || layer.dtype != DT_U8 || layer.components != 4 || layer.filter != FILTER_LINEAR || layer.width != first.width || layer.height != first.height
-            || layer.repeat_x != first.repeat_x || layer.repeat_y != first.repeat_y) return 0;
-        m.layer[t] = (const uint32_t*)layer.data;
-        m.factor[t] = sf::smoothstep(1.0f, 0.0f, (float)t/(float)temporal);                  // motionblur.frag:11
-    }
-    g_last_kernel = "k_motionblur_layer1";
-    hipLaunchKernelGGL(k_motionblur_layer1, dim3((a.wr + 63)/64, (a.hr + 3)/4, frames), dim3(64, 4), 0, s, a, m);
-    return 1;
-}
-
 static int launch_render(int fragment, const RenderArgs& a, int frames, hipStream_t s) {
+    using namespace sfl;
     switch (fragment) {
-        case FRAG_DEFAULT: launch_render_t<PlainShader<FRAG_DEFAULT>>(a, frames, s); break;
-        case FRAG_MISSING: launch_render_t<PlainShader<FRAG_MISSING>>(a, frames, s); break;
         case FRAG_VISUALIZER: {
             int tw = 0, th = 0;
             {
-                const int fast = launch_visualizer_fast(a, 1, frames, s, true);      // identity camera, RGBA8 target, window inside the strip kernel's tile
+                const int fast = launch_visualizer_fast(g_launch_ctx, a, 1, frames, s, true);      // identity camera, RGBA8 target, window inside the strip kernel's tile
                 if (fast != 0) return fast < 0 ? fast : SFX_OK;
             }
             if (visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) {
                 // first choice: 64 x 8 samples per block over a 64 x 15 tile — three 512-thread blocks per CU and two staged cells per
                 // sample, against two 256-thread blocks and five cells for the 128 x 2 shape (1080p without SSAA: 8.4 -> see DESIGN §7)
                 visualizer_window_bound(a, 64, 8, tw, th);
-                if (tw > 0 && tw <= 64 && th <= 15) { launch_render_t<VisualizerShader<64, 15, 6, 1, 1, 128, 64, 8>>(a, frames, s); break; }
+                if (tw > 0 && tw <= 64 && th <= 15) return render_visualizer_tiled(TILED_R_64x15_WALK8, a, frames, s, 0);
                 // sparser outputs (720p over a 1080-row background: 1.3 texels per sample): the same block shape over a tile sized per
                 // launch, as long as two blocks share a CU — the 128 x 2 shape would need a 174 x 11 window there (one 256-thread block per CU)
                 if (tw > 0 && (size_t)tw*th*48 <= 76*1024) {
                     RenderArgs d = a;
                     d.tile_pitch = tw; d.tile_rows = th;
-                    launch_render_t<VisualizerShader<0, 0, 4, 1, 1, 128, 64, 8>>(d, frames, s, (size_t)tw*th*48);
-                    break;
+                    return render_visualizer_tiled(TILED_R_DYNAMIC_WALK8, d, frames, s, (size_t)tw*th*48);
                 }
                 visualizer_window_bound(a, 128, 2, tw, th);
             }
-            if (tw > 0 && tw <= 128 && th <= 10) launch_render_t<VisualizerShader<128, 10, 1>>(a, frames, s);
-            else if (tw > 0 && (size_t)tw*th*48 <= VIS_LDS_LIMIT) {           // a window wider than the fixed tile: tile sized per launch
+            if (tw > 0 && tw <= 128 && th <= 10) return render_visualizer_tiled(TILED_R_128x10, a, frames, s, 0);
+            if (tw > 0 && (size_t)tw*th*48 <= VIS_LDS_LIMIT) {           // a window wider than the fixed tile: tile sized per launch
                 RenderArgs d = a;
                 d.tile_pitch = tw; d.tile_rows = th;
-                launch_render_t<VisualizerShader<0, 0, 1>>(d, frames, s, (size_t)tw*th*48);
+                return render_visualizer_tiled(TILED_R_DYNAMIC, d, frames, s, (size_t)tw*th*48);
             }
-            else launch_render_t<PlainShader<FRAG_VISUALIZER>>(a, frames, s);
-            break;
+            return render_plain(fragment, a, frames, s);
         }
-        case FRAG_BARS: launch_render_t<PlainShader<FRAG_BARS>>(a, frames, s); break;
-        case FRAG_WAVEFORM: launch_render_t<PlainShader<FRAG_WAVEFORM>>(a, frames, s); break;
-        case FRAG_MULTI_CHILD: launch_render_t<PlainShader<FRAG_MULTI_CHILD>>(a, frames, s); break;
-        case FRAG_MULTI_MAIN: launch_render_t<PlainShader<FRAG_MULTI_MAIN>>(a, frames, s); break;
-        case FRAG_SHADERTOY: launch_render_t<PlainShader<FRAG_SHADERTOY>>(a, frames, s); break;
-        case FRAG_DYNAMICS: launch_render_t<PlainShader<FRAG_DYNAMICS>>(a, frames, s); break;
-        case FRAG_AUDIO: launch_render_t<PlainShader<FRAG_AUDIO>>(a, frames, s); break;
         case FRAG_MULTIPASS: {
-            const int fast = launch_multipass_layer1(a, frames, s);
+            const int fast = launch_multipass_layer1(g_launch_ctx, a, frames, s);
             if (fast != 0) return fast < 0 ? fast : SFX_OK;
-            launch_render_t<PlainShader<FRAG_MULTIPASS>>(a, frames, s); break;
+            return render_plain(fragment, a, frames, s);
         }
         case FRAG_MOTIONBLUR: {
-            const int fast = launch_motionblur_layer1(a, frames, s);
+            const int fast = launch_motionblur_layer1(g_launch_ctx, a, frames, s);
             if (fast != 0) return fast < 0 ? fast : SFX_OK;
-            launch_render_t<PlainShader<FRAG_MOTIONBLUR>>(a, frames, s); break;
+            return render_plain(fragment, a, frames, s);
         }
-        case FRAG_LIFE_SIMULATION: launch_render_t<PlainShader<FRAG_LIFE_SIMULATION>>(a, frames, s); break;
-        case FRAG_LIFE_VISUALS: launch_render_t<PlainShader<FRAG_LIFE_VISUALS>>(a, frames, s); break;
-        case FRAG_VIDEO: launch_render_t<PlainShader<FRAG_VIDEO>>(a, frames, s); break;
-        case FRAG_RAYMARCH: launch_render_t<PlainShader<FRAG_RAYMARCH>>(a, frames, s); break;
-        case FRAG_MANDELBROT: launch_render_t<PlainShader<FRAG_MANDELBROT>>(a, frames, s); break;
-        case FRAG_TETRATION: launch_render_t<PlainShader<FRAG_TETRATION>>(a, frames, s); break;
-        default: return fail(SFX_E_UNSUPPORTED, "fragment %d has no render kernel", fragment);
+        default: return render_plain(fragment, a, frames, s);
     }
-    return SFX_OK;
 }
 
-#ifndef VIS_PITCH_SS
-#define VIS_PITCH_SS 80
-#endif
-#ifndef VIS_FUSED_ROWS
-#define VIS_FUSED_ROWS 1
-#endif
-#ifndef VIS_THREAD_ROWS
-#define VIS_THREAD_ROWS 1
-#endif
-#ifndef VIS_BLOCK_PX
-#define VIS_BLOCK_PX 128
-#endif
-#ifndef VIS_ROWS_SS
-#define VIS_ROWS_SS 10
-#endif
-#ifndef VIS_MIN_WAVES_SS
-#define VIS_MIN_WAVES_SS 8
-#endif
-#ifndef VIS_MIN_WAVES_S4
-#define VIS_MIN_WAVES_S4 6
-#endif
 #ifndef VIS_ROLLED_LANE_COST
 #define VIS_ROLLED_LANE_COST 2.0f                                       // (see launch_fused: the shapes of rolled cameras)
 #endif
-
-template <class SHADER, int S> static void launch_fused_k(const RenderArgs& a, dim3 grid, dim3 block, size_t dynamic_lds, hipStream_t s) {
-    note_kernel(__PRETTY_FUNCTION__, "k_render_resolve", S);
-    if (dynamic_lds > 48*1024) hipFuncSetAttribute((const void*)k_render_resolve<SHADER, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_lds);
-    hipLaunchKernelGGL((k_render_resolve<SHADER, S>), grid, block, dynamic_lds, s, a);
-}
-
-template <class SHADER> static int launch_fused_s(const RenderArgs& a, int ssaa, int frames, hipStream_t s, size_t dynamic_lds = 0) {
-    constexpr int rows = SHADER::FUSED_ROWS*SHADER::THREAD_ROWS, threads = 4*SHADER::BLOCK_PX*SHADER::THREAD_ROWS;
-    const int blocks_x = (a.w + SHADER::BLOCK_PX - 1)/SHADER::BLOCK_PX;          // S >= 2; S == 1 always covers 128 x 2 pixels
-    const int row_blocks = (a.h + rows - 1)/rows;
-    if (ssaa == 1) launch_fused_k<SHADER, 1>(a, dim3(((a.w + 127)/128)*((a.h + 1)/2), 1, frames), dim3(256), dynamic_lds, s);
-    else if (ssaa == 2) launch_fused_k<SHADER, 2>(a, dim3(blocks_x*row_blocks, 1, frames), dim3(threads), dynamic_lds, s);
-    else if (ssaa == 4) launch_fused_k<SHADER, 4>(a, dim3(blocks_x*row_blocks, 1, frames), dim3(threads), dynamic_lds, s);
-    else return fail(SFX_E_UNSUPPORTED, "fused ssaa %d", ssaa);
-    return SFX_OK;
-}
-
-// One geometry of the fast path: the tables for it, then the kernel. STRIP_S == 0: k_visualizer_fast (a quad of lanes per pixel,
-// 2x SSAA); otherwise k_visualizer_strip<PITCH, ROWS, STRIP_S, WALK, WAVES, CG> (lanes walk strips of their column; 2x or 4x SSAA
-// fused with the resolve, or STRIP_S == 1: the samples to an RGBA8 iScreen).
-template <int PITCH, int ROWS, int STRIP_S, int WALK, int WAVES, int CG = (STRIP_S ? 8/STRIP_S : 4), bool HALF = (STRIP_S == 1)>
-static int launch_visualizer_tables_and_kernel(Context* ctx, const RenderArgs& a, int frames, hipStream_t s) {
-    constexpr int COLS = STRIP_S ? 64*CG : 256;                       // sample columns per block
-    constexpr int BLOCK_ROWS = STRIP_S ? (8/CG)*WALK : 2;             // sample rows per block
-    VisTables t;
-    t.blocks_x = (a.wr + COLS - 1)/COLS; t.blocks_y = (a.hr + BLOCK_ROWS - 1)/BLOCK_ROWS;
-    t.block_columns = COLS; t.block_rows = BLOCK_ROWS; t.tile_pitch = PITCH; t.tile_rows = ROWS;
-    t.cell_bytes = HALF ? 8 : 48;                                     // float16 cells in three planes where the lanes of a wave read different cells (visualizer_fast.hpp)
-    const size_t entries = (size_t)frames*((size_t)a.wr + a.hr)*VIS_ENTRY_QUADS*sizeof(float4);
-    const size_t blocks = (size_t)frames*((size_t)t.blocks_x + t.blocks_y)*sizeof(int4);
-    const size_t ysteps = STRIP_S ? (size_t)frames*a.hr*10*sizeof(float4) : 0;
-    if (ctx->vis_tables_bytes < entries + blocks + ysteps) {
-        hipStreamSynchronize(s);
-        hipFree(ctx->vis_tables); ctx->vis_tables = nullptr; ctx->vis_tables_bytes = 0;
-        if (hipMalloc(&ctx->vis_tables, entries + blocks + ysteps) != hipSuccess) return fail(SFX_E_HIP, "visualizer tables of %d frames: out of device memory", frames);
-        ctx->vis_tables_bytes = entries + blocks + ysteps;
-    }
-    t.columns = (float4*)ctx->vis_tables;
-    t.rows = t.columns + (size_t)frames*a.wr*VIS_ENTRY_QUADS;
-    t.block_x = (int4*)(t.rows + (size_t)frames*a.hr*VIS_ENTRY_QUADS);
-    t.block_y = t.block_x + (size_t)frames*t.blocks_x;
-    t.ysteps = STRIP_S ? (float4*)(t.block_y + (size_t)frames*t.blocks_y) : nullptr;
-    hipLaunchKernelGGL(k_visualizer_axes, dim3((a.wr + 127)/128 + (a.hr + 127)/128, frames), dim3(128), 0, s, a, t);
-    if constexpr (STRIP_S != 0) {
-        g_last_kernel = "k_visualizer_strip<" + std::to_string(PITCH) + ", " + std::to_string(ROWS) + ", " + std::to_string(STRIP_S) + ", " + std::to_string(WALK) + ", " + std::to_string(WAVES) + ", " + std::to_string(CG) + (HALF ? ", true>" : ", false>");
-        hipLaunchKernelGGL((k_visualizer_strip<PITCH, ROWS, STRIP_S, WALK, WAVES, CG, HALF>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(512), 0, s, a, t);
-    } else {
-        g_last_kernel = "k_visualizer_fast<" + std::to_string(PITCH) + ", " + std::to_string(ROWS) + ", 128, " + std::to_string(WAVES) + ">";
-        hipLaunchKernelGGL((k_visualizer_fast<PITCH, ROWS, 128, WAVES>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(512), 0, s, a, t);
-    }
-    return 1;
-}
-
-// ---- the fast visualizer path (visualizer_fast.hpp) -----------------------------------------------------------------------
-// Identity camera, unorm8 bilinear background, 2x or 4x SSAA, the window of a block inside one of the compiled tiles, and a blur
-// whose axis lines fit their slots at the largest radius the launch can see. Returns 1 when it launched, 0 when the configuration
-// is not its own (the caller then takes VisualizerShader), < 0 on errors.
-#ifndef VIS_FAST
-#define VIS_FAST 1
-#endif
-#ifndef VIS_FAST_WALK
-#define VIS_FAST_WALK 8
-#endif
-static int launch_visualizer_fast(const RenderArgs& a0, int ssaa, int frames, hipStream_t s, bool to_screen) {
-    Context* ctx = g_launch_ctx;
-    // fused: 2x or 4x SSAA into the RGB8 frame; to_screen: the samples themselves into an RGBA8 iScreen (the two-pass configuration)
-    if (to_screen ? (ssaa != 1 || a0.out_dtype != DT_U8 || a0.out_components != 4) : (ssaa != 2 && ssaa != 4)) return 0;
-    if (!VIS_FAST || !ctx || !(a0.identity_camera || a0.axis_camera) || !visualizer_tile_applicable(a0.tex[TEX_BACKGROUND])) return 0;
-    const char* toggle = getenv("SHADERFLOW_VIS_FAST");              // A/B switch for measurements: 0 = round 1's kernels, 1 = k_visualizer_fast
-    if (toggle && atoi(toggle) == 0) return 0;
-    const Tex& bg = a0.tex[TEX_BACKGROUND];
-    const Tex& sp = a0.tex[TEX_SPECTROGRAM];
-    RenderArgs a = a0;
-    if (!a.tape_bars) {
-        // a bound one-column RG32F spectrogram: the bar heights per texel into the context's scratch (k_visualizer_bars)
-        if (a.dyn || a.tape_spectrogram || !sp.data || sp.dtype != DT_F32 || sp.components != 2 || sp.width != 1 || sp.filter != FILTER_NEAREST) return 0;
-        const size_t count = (size_t)sp.height*2;
-        if (ctx->vis_bars_count < count) {
-            hipStreamSynchronize(s);
-            hipFree(ctx->vis_bars); ctx->vis_bars = nullptr; ctx->vis_bars_count = 0;
-            if (hipMalloc(&ctx->vis_bars, sizeof(float)*count) != hipSuccess) return fail(SFX_E_HIP, "visualizer bar table: out of device memory");
-            ctx->vis_bars_count = count;
-        }
-        hipLaunchKernelGGL(k_visualizer_bars, dim3((unsigned)((count + 255)/256)), dim3(256), 0, s, (const float*)sp.data, (long)count, ctx->vis_bars);
-        a.tape_bars = ctx->vis_bars; a.spectrogram_stride = 0;
-    } else if (sp.width != 1 || sp.components != 2) return 0;
-    // the axis lines must fit their slots at the largest blur radius of the launch (visualizer_window_bound's conventions)
-    const float intensity = a.has_vis ? fabsf(a.vis.intensity) : 0.003f;
-    const float ax = intensity*a.bg_scale_x*(float)bg.width;
-    const float reach_line = (fabsf(a.tap_x[0]) + 9.0f*fabsf(a.tap_x[1] - a.tap_x[0]))*ax;
-    if (!(2.0f*reach_line + 1.0e-3f < (float)(VIS_LINE_CELLS - 1))) return 0;
-    auto fits = [&](int columns, int rows, int pitch, int tile_rows) {
-        int tw = 0, th = 0;
-        visualizer_window_bound(a, columns, rows, tw, th);
-        return tw <= pitch && th <= tile_rows;
-    };
-    // build knobs of the strip kernel (tools/variants.sh): rows a lane walks at 2x / 4x SSAA, rows of cells of the tiles, resident waves per SIMD
-#ifndef VIS_STRIP_WALK2
-#define VIS_STRIP_WALK2 (VIS_FAST_WALK == 8 ? 9 : VIS_FAST_WALK)     // nine rows: the longest strip that stays inside 64 VGPRs (ten spill), +2 % over eight
-#endif
-#ifndef VIS_STRIP_WALK4
-#define VIS_STRIP_WALK4 (VIS_FAST_WALK == 8 ? 10 : VIS_FAST_WALK)
-#endif
-#ifndef VIS_STRIP_ROWS2
-#define VIS_STRIP_ROWS2 (VIS_STRIP_WALK2 <= 4 ? 10 : (VIS_STRIP_WALK2 <= 6 ? 11 : 12))
-#endif
-#ifndef VIS_STRIP_ROWS4
-#define VIS_STRIP_ROWS4 13
-#endif
-#ifndef VIS_STRIP_PITCH2
-#define VIS_STRIP_PITCH2 72
-#endif
-#ifndef VIS_STRIP_WAVES2
-#define VIS_STRIP_WAVES2 6                                             // what the kernel HAS: 51.8 KB of LDS per block = three blocks = six waves per SIMD (78 registers); asking for 8 only made the compiler say so on every build
-#endif
-#ifndef VIS_STRIP_WAVES4
-#define VIS_STRIP_WAVES4 6
-#endif
-    constexpr int WALK2 = VIS_STRIP_WALK2, WALK4 = VIS_STRIP_WALK4;
-    const bool plain = toggle && atoi(toggle) == 1;                   // force the quad-per-pixel kernel
-    if (ssaa == 1) {
-        // no SSAA: 0.87 texel per sample at 1080p over a 1080-row background — nothing to share along a strip, but the tables, the
-        // folded tap pairs and the speculated post-processing still apply. 64 columns x 8 rows per block over a 66 x 15 tile
-        // (three blocks per CU), or strips of two rows over 66 x 22 (two)
-#ifndef VIS_STRIP_WALK1
-#define VIS_STRIP_WALK1 2
-#endif
-        if (VIS_STRIP_WALK1 == 2 && fits(64, 16, 66, 22)) return launch_visualizer_tables_and_kernel<66, 22, 1, 2, 4, 1>(ctx, a, frames, s);
-        if (fits(64, 8, 66, 15)) return launch_visualizer_tables_and_kernel<66, 15, 1, 1, 6, 1>(ctx, a, frames, s);
-    } else if (ssaa == 2) {
-#ifndef VIS_STRIP_HALF2
-#define VIS_STRIP_HALF2 false
-#endif
-// float16 cells (visualizer_fast.hpp): where the lanes of a wave read DIFFERENT cells the kernel is bound by LDS bandwidth and
-// half the bytes win — 1080p 2x 7 200 -> 7 970, 1440p 2x 4 480 -> 4 920, 720p 2x 9 430 -> 13 270 frames/s (profiles/r03_variants.txt);
-// at 4K 2x the lanes share their cells and plain float32 multiply-adds are cheaper
-#ifndef VIS_DENSE_HALF
-#define VIS_DENSE_HALF true
-#endif
-#ifndef VIS_SPARSE_HALF
-#define VIS_SPARSE_HALF true
-#endif
-#ifndef VIS_STRIP_HALF4
-#define VIS_STRIP_HALF4 false
-#endif
-#ifndef VIS_MID4_HALF
-#define VIS_MID4_HALF false
-#endif
-#ifndef VIS_SPARSE4_HALF
-#define VIS_SPARSE4_HALF false
-#endif
-        if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*WALK2, VIS_STRIP_PITCH2, VIS_STRIP_ROWS2)) return launch_visualizer_tables_and_kernel<VIS_STRIP_PITCH2, VIS_STRIP_ROWS2, 2, WALK2, VIS_STRIP_WAVES2, 4, VIS_STRIP_HALF2>(ctx, a, frames, s);
-        // denser outputs (1080p or 1440p at 2x SSAA over a 1080-row background: up to 0.43 texel per sample): strips of six rows
-        // over a 120 x 13 tile, two blocks per CU
-#ifndef VIS_DENSE_WALK
-#define VIS_DENSE_WALK 6                                              // the longest strip whose 120-cell-wide tile still leaves two blocks per CU
-#endif
-#ifndef VIS_DENSE_ROWS
-#define VIS_DENSE_ROWS 13
-#endif
-        if (VIS_FAST_WALK > 0 && !plain && fits(256, 2*VIS_DENSE_WALK, 120, VIS_DENSE_ROWS)) return launch_visualizer_tables_and_kernel<120, VIS_DENSE_ROWS, 2, VIS_DENSE_WALK, 4, 4, VIS_DENSE_HALF>(ctx, a, frames, s);
-        // sparser still (720p at 2x SSAA: 0.65 texel per sample): 128 columns x 12 rows per block, strips of three, 92 x 16 tile
-#ifndef VIS_SPARSE_WALK
-#define VIS_SPARSE_WALK 3
-#endif
-#ifndef VIS_SPARSE_ROWS
-#define VIS_SPARSE_ROWS 16
-#endif
-        if (VIS_FAST_WALK > 0 && !plain && fits(128, 4*VIS_SPARSE_WALK, 92, VIS_SPARSE_ROWS)) return launch_visualizer_tables_and_kernel<92, VIS_SPARSE_ROWS, 2, VIS_SPARSE_WALK, 4, 2, VIS_SPARSE_HALF>(ctx, a, frames, s);
-        if (fits(256, 2, 72, 10)) return launch_visualizer_tables_and_kernel<72, 10, 0, 0, 8>(ctx, a, frames, s);
-    } else if (VIS_FAST_WALK > 0) {
-        if (fits(128, 4*WALK4, 40, VIS_STRIP_ROWS4)) return launch_visualizer_tables_and_kernel<40, VIS_STRIP_ROWS4, 4, WALK4, VIS_STRIP_WAVES4, 2, VIS_STRIP_HALF4>(ctx, a, frames, s);
-        // 1080p at 4x SSAA: the same tile width with strips of six rows
-#ifndef VIS_MID4_WALK
-#define VIS_MID4_WALK 6
-#endif
-#ifndef VIS_MID4_ROWS
-#define VIS_MID4_ROWS 14
-#endif
-#ifndef VIS_SPARSE4_WALK
-#define VIS_SPARSE4_WALK 6
-#endif
-#ifndef VIS_SPARSE4_ROWS
-#define VIS_SPARSE4_ROWS 16
-#endif
-        if (WALK4 != VIS_MID4_WALK && fits(128, 4*VIS_MID4_WALK, 40, VIS_MID4_ROWS)) return launch_visualizer_tables_and_kernel<40, VIS_MID4_ROWS, 4, VIS_MID4_WALK, 8, 2, VIS_MID4_HALF>(ctx, a, frames, s);
-        // 720p at 4x SSAA (0.32 texel per sample)
-        if (fits(128, 4*VIS_SPARSE4_WALK, 56, VIS_SPARSE4_ROWS)) return launch_visualizer_tables_and_kernel<56, VIS_SPARSE4_ROWS, 4, VIS_SPARSE4_WALK, 6, 2, VIS_SPARSE4_HALF>(ctx, a, frames, s);
-    }
-    return 0;
-}
-
-// ---- bars.frag / waveform.frag with per-frame column and row tables (separable_fast.hpp) ---------------------------------------
-// 1 launched, 0 not this path's configuration (the caller takes PlainShader), < 0 error.
-template <int KIND> static int launch_separable(const RenderArgs& a, int ssaa, int frames, hipStream_t s) {
-    Context* ctx = g_launch_ctx;
-    if (!ctx || ssaa != 2) return 0;
-    if (getenv("SHADERFLOW_SEPARABLE") && atoi(getenv("SHADERFLOW_SEPARABLE")) == 0) return 0;        // A/B switch for measurements
-    if (KIND == SEP_DEFAULT && !(a.identity_camera || a.axis_camera)) return 0;   // default.glsl reads iCamera.gluv: separable per axis without a rotation only
-    if (KIND == SEP_BARS) {
-        // a one-column spectrogram picked with nearest filtering: the look-up is a function of the sample column alone
-        const Tex& sp = a.tex[TEX_SPECTROGRAM];
-        if (sp.width != 1 || sp.filter != FILTER_NEAREST) return 0;
-    }
-    if (KIND == SEP_WAVEFORM && a.hr > 0xffff) return 0;              // its column entries pack a first row and a row count into 16 bits each
-    // default.glsl in two passes (separable_fast.hpp k_default_quads): a byte per group of four rows and block of 256 pixels, after the tables
-    // OPT-IN (SHADERFLOW_DEFAULT_QUADS=1, read per launch so that a test can turn it on): measured slower than the one pass — a smooth
-    // frame takes 6.3 us either way, and the second pass pays for skipping (profiles/r05_basic_quads.txt)
-    const char* quads_env = getenv("SHADERFLOW_DEFAULT_QUADS");
-    const bool quads = KIND == SEP_DEFAULT && quads_env && atoi(quads_env) == 1 && (a.w & 3) == 0 && a.w >= 256 && a.h >= 4;
-    const int done_groups = (a.h + 3)/4, done_blocks = (a.w + 255)/256;
-    const size_t tables = (size_t)frames*((size_t)a.wr + a.hr)*sizeof(float4);
-    const size_t bytes = tables + (quads ? (size_t)frames*done_groups*done_blocks : 0);
-    if (ctx->vis_tables_bytes < bytes) {
-        hipStreamSynchronize(s);
-        hipFree(ctx->vis_tables); ctx->vis_tables = nullptr; ctx->vis_tables_bytes = 0;
-        if (hipMalloc(&ctx->vis_tables, bytes) != hipSuccess) return fail(SFX_E_HIP, "column/row tables of %d frames: out of device memory", frames);
-        ctx->vis_tables_bytes = bytes;
-    }
-    SepTables t;
-    t.columns = (float4*)ctx->vis_tables;
-    t.rows = t.columns + (size_t)frames*a.wr;
-    t.done = quads ? (uint8_t*)ctx->vis_tables + tables : nullptr;
-    t.done_groups = done_groups; t.done_blocks = done_blocks;
-    hipLaunchKernelGGL(k_separable_axis<KIND>, dim3((a.wr + a.hr + 255)/256, frames), dim3(256), 0, s, a, t);
-    if constexpr (KIND != SEP_DEFAULT) {
-        // rows as runs, four pixels = one 12-byte store per lane (k_separable_runs); odd widths keep the per-pixel kernel
-        const char* runs = getenv("SHADERFLOW_SEPARABLE_RUNS");     // A/B switch for measurements
-        if (a.w % 4 == 0 && !(runs && atoi(runs) == 0)) {
-            g_last_kernel = std::string("k_separable_runs<") + (KIND == SEP_BARS ? "bars" : "waveform") + ">";
-            hipLaunchKernelGGL(k_separable_runs<KIND>, dim3((a.w + 255)/256, (a.h + 4*SEP_RUN_ROWS - 1)/(4*SEP_RUN_ROWS), frames), dim3(256), 0, s, a, t);
-            return 1;
-        }
-    }
-    g_last_kernel = std::string("k_separable_fused<") + (KIND == SEP_BARS ? "bars" : (KIND == SEP_WAVEFORM ? "waveform" : "default")) + ">";
-    const int blocks_x = (a.w + SEP_PIXELS - 1)/SEP_PIXELS;
-    if constexpr (KIND == SEP_DEFAULT) {
-        // the smooth tier first, four pixels per lane; what it writes it marks, and the second pass skips
-        if (quads) {
-            hipLaunchKernelGGL(k_default_quads, dim3(done_blocks, (a.h + 4*DQ_ROWS*DQ_WALKS - 1)/(4*DQ_ROWS*DQ_WALKS), frames), dim3(256), 0, s, a, t);
-            hipLaunchKernelGGL((k_separable_fused<KIND, SEP_ROWS_DEFAULT, 1, true>), dim3(blocks_x, (a.h + SEP_ROWS_DEFAULT - 1)/SEP_ROWS_DEFAULT, frames), dim3(SEP_PIXELS), 0, s, a, t);
-            return 1;
-        }
-    }
-    if (KIND == SEP_DEFAULT && (long)blocks_x*((a.h + SEP_ROWS_DEFAULT*SEP_CHUNKS_DEFAULT - 1)/(SEP_ROWS_DEFAULT*SEP_CHUNKS_DEFAULT))*frames >= 8192)
-        hipLaunchKernelGGL((k_separable_fused<KIND, SEP_ROWS_DEFAULT, SEP_CHUNKS_DEFAULT>), dim3(blocks_x, (a.h + SEP_ROWS_DEFAULT*SEP_CHUNKS_DEFAULT - 1)/(SEP_ROWS_DEFAULT*SEP_CHUNKS_DEFAULT), frames), dim3(SEP_PIXELS), 0, s, a, t);
-    else if (KIND == SEP_DEFAULT && (long)blocks_x*((a.h + SEP_ROWS_DEFAULT - 1)/SEP_ROWS_DEFAULT)*frames >= 2048)
-        hipLaunchKernelGGL((k_separable_fused<KIND, SEP_ROWS_DEFAULT>), dim3(blocks_x, (a.h + SEP_ROWS_DEFAULT - 1)/SEP_ROWS_DEFAULT, frames), dim3(SEP_PIXELS), 0, s, a, t);
-    else if ((long)blocks_x*((a.h + SEP_ROWS_LARGE - 1)/SEP_ROWS_LARGE)*frames >= 2048)
-        hipLaunchKernelGGL((k_separable_fused<KIND, SEP_ROWS_LARGE>), dim3(blocks_x, (a.h + SEP_ROWS_LARGE - 1)/SEP_ROWS_LARGE, frames), dim3(SEP_PIXELS), 0, s, a, t);
-    else
-        hipLaunchKernelGGL((k_separable_fused<KIND, SEP_ROWS_SMALL>), dim3(blocks_x, (a.h + SEP_ROWS_SMALL - 1)/SEP_ROWS_SMALL, frames), dim3(SEP_PIXELS), 0, s, a, t);
-    return 1;
-}
 
 #ifdef SF_SECTION_TIMERS
 static int launch_fused_inner(int fragment, const RenderArgs& a, int ssaa, int frames, hipStream_t s, bool force_generic);
@@ -1723,28 +1232,29 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
                              = false
 #endif
                              ) {
+    using namespace sfl;
+    if (ssaa != 1 && ssaa != 2 && ssaa != 4) return fail(SFX_E_UNSUPPORTED, "fused ssaa %d", ssaa);
     switch (fragment) {
         case FRAG_DEFAULT:
             if (!force_generic) {
-                const int fast = launch_separable<SEP_DEFAULT>(a, ssaa, frames, s);
+                const int fast = launch_separable(SEPARABLE_DEFAULT, g_launch_ctx, a, ssaa, frames, s);
                 if (fast != 0) return fast < 0 ? fast : SFX_OK;
             }
-            return launch_fused_s<PlainShader<FRAG_DEFAULT>>(a, ssaa, frames, s);
-        case FRAG_MISSING: return launch_fused_s<PlainShader<FRAG_MISSING>>(a, ssaa, frames, s);
+            return fused_plain(fragment, a, ssaa, frames, s);
         case FRAG_VISUALIZER:
             if (!force_generic) {
-                const int fast = launch_visualizer_fast(a, ssaa, frames, s, false);
+                const int fast = launch_visualizer_fast(g_launch_ctx, a, ssaa, frames, s, false);
                 if (fast != 0) return fast < 0 ? fast : SFX_OK;
             }
             if (!force_generic && visualizer_tile_applicable(a.tex[TEX_BACKGROUND])) {
                 // the block shades 128*ssaa x rows*ssaa samples (S == 1: 128 x 2 pixels); pick the fixed tile when its window fits
-                int tw = 0, th = 0;
-                visualizer_window_bound(a, (ssaa == 1 ? 128 : VIS_BLOCK_PX)*ssaa, (ssaa == 1 ? 2 : VIS_FUSED_ROWS*VIS_THREAD_ROWS)*ssaa, tw, th);
-                if (ssaa == 1 && tw <= 128 && th <= 10) return launch_fused_s<VisualizerShader<128, 10, 1>>(a, ssaa, frames, s);
-                if (ssaa != 1 && tw <= VIS_PITCH_SS && th <= VIS_ROWS_SS) {
+                int tw = 0, th = 0, pitch_ss = 0, rows_ss = 0, block_px = 0, block_rows = 0;
+                tiled_fused_limits(pitch_ss, rows_ss, block_px, block_rows);
+                visualizer_window_bound(a, (ssaa == 1 ? 128 : block_px)*ssaa, (ssaa == 1 ? 2 : block_rows)*ssaa, tw, th);
+                if (ssaa == 1 && tw <= 128 && th <= 10) return fused_visualizer_tiled(TILED_F_128x10, a, ssaa, frames, s, 0);
+                if (ssaa != 1 && tw <= pitch_ss && th <= rows_ss) {
                     // four samples per lane need more registers: 6 waves per SIMD without spills beat 8 with (8K 4xSSAA: 55 -> 63 frames/s)
-                    if (ssaa == 4) return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_S4, VIS_FUSED_ROWS>>(a, ssaa, frames, s);
-                    return launch_fused_s<VisualizerShader<VIS_PITCH_SS, VIS_ROWS_SS, VIS_MIN_WAVES_SS, VIS_FUSED_ROWS, VIS_THREAD_ROWS, VIS_BLOCK_PX>>(a, ssaa, frames, s);
+                    return fused_visualizer_tiled(ssaa == 4 ? TILED_F_SS_S4 : TILED_F_SS, a, ssaa, frames, s, 0);
                 }
                 if (ssaa == 2) {
                     // 0.43 texel per sample (1080p output at 2x SSAA over a 1080-row background): 64 pixels x 2 rows per block see a
@@ -1752,13 +1262,13 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
                     // below holds two
                     int tw2 = 0, th2 = 0;
                     visualizer_window_bound(a, 64*2, 2*2, tw2, th2);
-                    if (tw2 <= 64 && th2 <= 11) return launch_fused_s<VisualizerShader<64, 11, 8, 1, 2, 64>>(a, ssaa, frames, s);
+                    if (tw2 <= 64 && th2 <= 11) return fused_visualizer_tiled(TILED_F_64x11, a, ssaa, frames, s, 0);
                 }
                 if (ssaa == 4) {
                     // the same for 4x SSAA at 0.2-0.3 texel per sample (1080p / 720p outputs): 32 pixels x 4 rows per block, a 56 x 14 tile (37 KB)
                     int tw4 = 0, th4 = 0;
                     visualizer_window_bound(a, 32*4, 4*4, tw4, th4);
-                    if (tw4 <= 56 && th4 <= 14) return launch_fused_s<VisualizerShader<56, 14, VIS_MIN_WAVES_S4, 1, 4, 32>>(a, ssaa, frames, s);
+                    if (tw4 <= 56 && th4 <= 14) return fused_visualizer_tiled(TILED_F_56x14, a, ssaa, frames, s, 0);
                 }
                 if (ssaa == 2 && !a.identity_camera && !a.axis_camera) {
                     // a rolled or tilted camera: a block's window grows with the block's extent along BOTH axes, so squarer blocks
@@ -1775,6 +1285,10 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
                         int w = 0, h = 0;
                         if (only >= 0 && k != only) continue;
                         visualizer_window_bound(a, shapes[k].px*2, shapes[k].rows*shapes[k].walk*2, w, h);
+                        // an odd pitch: a cell is 12 dwords, and with the camera turned by a quarter the lanes of a wave read down a
+                        // COLUMN of cells — 16 cells per row put every one of them on the same banks (730 -> 448 frames/s at C3, 90 degrees).
+                        // (made odd BEFORE the LDS test: what is checked is what is launched)
+                        w |= 1;
                         if ((size_t)w*h*48 > 72*1024) continue;                       // two 512-thread blocks per CU at least
                         // cells staged per pixel + what a block pays once per LANE (ray set-up, window, barriers), in cells' worth
                         const float cost = (float)w*(float)h/(float)(shapes[k].px*shapes[k].rows*shapes[k].walk) + VIS_ROLLED_LANE_COST/(float)shapes[k].walk;
@@ -1782,68 +1296,49 @@ static int launch_fused_body(int fragment, const RenderArgs& a, int ssaa, int fr
                     }
                     if (best >= 0) {
                         RenderArgs d = a;
-                        // an odd pitch: a cell is 12 dwords, and with the camera turned by a quarter the lanes of a wave read down a
-                        // COLUMN of cells — 16 cells per row put every one of them on the same banks (730 -> 448 frames/s at C3, 90 degrees)
-                        best_tw |= 1;
                         d.tile_pitch = best_tw; d.tile_rows = best_th;
                         const size_t lds = (size_t)best_tw*best_th*48;
-                        if (best == 0) return launch_fused_s<VisualizerShader<0, 0, 4, VIS_FUSED_ROWS, VIS_THREAD_ROWS, 128>>(d, ssaa, frames, s, lds);
-                        // eight waves per SIMD, not the four of the other tiles sized per launch: 555 -> 696 frames/s at C3 rolled by 17 degrees
-                        if (best == 1) return launch_fused_s<VisualizerShader<0, 0, 8, 1, 2, 64>>(d, ssaa, frames, s, lds);
-                        if (best == 2) return launch_fused_s<VisualizerShader<0, 0, 8, 1, 4, 32>>(d, ssaa, frames, s, lds);
-                        return launch_fused_s<VisualizerShader<0, 0, 4, 4, 4, 32>>(d, ssaa, frames, s, lds);
+                        // (best == 1, 2: eight waves per SIMD, not the four of the other tiles sized per launch: 555 -> 696 frames/s at C3 rolled by 17 degrees)
+                        static const TiledFused kernels[] = {TILED_F_DYN_128, TILED_F_DYN_64x2, TILED_F_DYN_32x4, TILED_F_DYN_32x4_WALK4};
+                        return fused_visualizer_tiled(kernels[best], d, ssaa, frames, s, lds);
                     }
                 }
                 if (ssaa != 1) {
                     // denser backgrounds (1080p output at 2x SSAA over a 1080-row background: 0.43 texel per sample; backgrounds
                     // larger than the output): the tile is sized per launch in dynamic LDS, and the block narrows from 128 to 64
                     // or 32 pixels until its window leaves room for at least two blocks per CU
-                    const int rows = VIS_FUSED_ROWS*VIS_THREAD_ROWS*ssaa;
+                    const int rows = block_rows*ssaa;
                     int best_px = 0, best_tw = 0, best_th = 0;
                     for (int px : {128, 64, 32}) {
                         visualizer_window_bound(a, px*ssaa, rows, tw, th);
+                        tw |= 1;                                                      // an odd pitch (see above), before the LDS test
                         const size_t lds = (size_t)tw*th*48;
                         if (lds <= VIS_LDS_LIMIT) { best_px = px; best_tw = tw; best_th = th; if (lds <= 64*1024) break; }
                     }
                     if (best_px) {
                         RenderArgs d = a;
-                        // an odd pitch: a cell is 12 dwords, and with the camera turned by a quarter the lanes of a wave read down a
-                        // COLUMN of cells — 16 cells per row put every one of them on the same banks (730 -> 448 frames/s at C3, 90 degrees)
-                        best_tw |= 1;
                         d.tile_pitch = best_tw; d.tile_rows = best_th;
                         const size_t lds = (size_t)best_tw*best_th*48;
-                        if (best_px == 128) return launch_fused_s<VisualizerShader<0, 0, 4, VIS_FUSED_ROWS, VIS_THREAD_ROWS, 128>>(d, ssaa, frames, s, lds);
-                        if (best_px == 64) return launch_fused_s<VisualizerShader<0, 0, 4, VIS_FUSED_ROWS, VIS_THREAD_ROWS, 64>>(d, ssaa, frames, s, lds);
-                        return launch_fused_s<VisualizerShader<0, 0, 4, VIS_FUSED_ROWS, VIS_THREAD_ROWS, 32>>(d, ssaa, frames, s, lds);
+                        return fused_visualizer_tiled(best_px == 128 ? TILED_F_DYN_128 : (best_px == 64 ? TILED_F_DYN_64 : TILED_F_DYN_32), d, ssaa, frames, s, lds);
                     }
                 } else if ((size_t)tw*th*48 <= VIS_LDS_LIMIT) {
                     RenderArgs d = a;
                     d.tile_pitch = tw; d.tile_rows = th;
-                    return launch_fused_s<VisualizerShader<0, 0, 4>>(d, ssaa, frames, s, (size_t)tw*th*48);
+                    return fused_visualizer_tiled(TILED_F_DYN_1X, d, ssaa, frames, s, (size_t)tw*th*48);
                 }
             }
-            return launch_fused_s<PlainShader<FRAG_VISUALIZER>>(a, ssaa, frames, s);
+            return fused_plain(fragment, a, ssaa, frames, s);
         case FRAG_BARS: {
-            const int fast = force_generic ? 0 : launch_separable<SEP_BARS>(a, ssaa, frames, s);
+            const int fast = force_generic ? 0 : launch_separable(SEPARABLE_BARS, g_launch_ctx, a, ssaa, frames, s);
             if (fast != 0) return fast < 0 ? fast : SFX_OK;
-            return launch_fused_s<PlainShader<FRAG_BARS>>(a, ssaa, frames, s);
+            return fused_plain(fragment, a, ssaa, frames, s);
         }
         case FRAG_WAVEFORM: {
-            const int fast = force_generic ? 0 : launch_separable<SEP_WAVEFORM>(a, ssaa, frames, s);
+            const int fast = force_generic ? 0 : launch_separable(SEPARABLE_WAVEFORM, g_launch_ctx, a, ssaa, frames, s);
             if (fast != 0) return fast < 0 ? fast : SFX_OK;
-            return launch_fused_s<PlainShader<FRAG_WAVEFORM>>(a, ssaa, frames, s);
+            return fused_plain(fragment, a, ssaa, frames, s);
         }
-        case FRAG_MULTI_CHILD: return launch_fused_s<PlainShader<FRAG_MULTI_CHILD>>(a, ssaa, frames, s);
-        case FRAG_MULTI_MAIN: return launch_fused_s<PlainShader<FRAG_MULTI_MAIN>>(a, ssaa, frames, s);
-        case FRAG_SHADERTOY: return launch_fused_s<PlainShader<FRAG_SHADERTOY>>(a, ssaa, frames, s);
-        case FRAG_DYNAMICS: return launch_fused_s<PlainShader<FRAG_DYNAMICS>>(a, ssaa, frames, s);
-        case FRAG_AUDIO: return launch_fused_s<PlainShader<FRAG_AUDIO>>(a, ssaa, frames, s);
-        case FRAG_LIFE_VISUALS: return launch_fused_s<PlainShader<FRAG_LIFE_VISUALS>>(a, ssaa, frames, s);
-        case FRAG_VIDEO: return launch_fused_s<PlainShader<FRAG_VIDEO>>(a, ssaa, frames, s);
-        case FRAG_RAYMARCH: return launch_fused_s<PlainShader<FRAG_RAYMARCH>>(a, ssaa, frames, s);
-        case FRAG_MANDELBROT: return launch_fused_s<PlainShader<FRAG_MANDELBROT>>(a, ssaa, frames, s);
-        case FRAG_TETRATION: return launch_fused_s<PlainShader<FRAG_TETRATION>>(a, ssaa, frames, s);
-        default: return fail(SFX_E_UNSUPPORTED, "fragment %d has no fused kernel", fragment);
+        default: return fused_plain(fragment, a, ssaa, frames, s);
     }
 }
 
@@ -1897,53 +1392,6 @@ extern "C" int sfx_render(sfx_handle h, sfx_handle target, int layer) {
     return launch_status();
 }
 
-// final.glsl as a pass: k_resolve_fast (resolve_fast.hpp) for a linear, clamped iScreen and the kernels it is compiled for, else
-// the generic k_resolve. `frames` launches share the tables (they depend on the sizes only).
-#ifndef RESOLVE_FAST
-#define RESOLVE_FAST 1
-#endif
-static int launch_resolve(Context* ctx, const ResolveArgs& a, int frames, hipStream_t s) {
-    const char* toggle = getenv("SHADERFLOW_RESOLVE_FAST");         // A/B switch for measurements
-    const bool fast = RESOLVE_FAST && ctx && !(toggle && atoi(toggle) == 0) && a.screen.filter == FILTER_LINEAR && !a.screen.repeat_x && !a.screen.repeat_y &&
-                      a.subsample >= 1 && a.subsample <= 3 && a.screen.width > 0 && a.screen.height > 0;
-    if (fast) {
-        const size_t bytes = ((size_t)a.w + a.h)*a.subsample*sizeof(int4);
-        if (ctx->resolve_tables_bytes < bytes) {
-            hipStreamSynchronize(s);
-            hipFree(ctx->resolve_tables); ctx->resolve_tables = nullptr; ctx->resolve_tables_bytes = 0; memset(ctx->resolve_tables_key, 0, sizeof ctx->resolve_tables_key);
-            if (hipMalloc(&ctx->resolve_tables, bytes) != hipSuccess) return fail(SFX_E_HIP, "resolve tables: out of device memory");
-            ctx->resolve_tables_bytes = bytes;
-        }
-        int4* columns = (int4*)ctx->resolve_tables; int4* rows = columns + (size_t)a.w*a.subsample;
-        // the tables are a function of the geometry alone: a frame loop resolves the same geometry every frame (two launches of
-        // ≈ 5 us each per frame saved; a stream other than the one that built them rebuilds)
-        const long key[8] = {a.w, a.h, a.screen.width, a.screen.height, a.screen.repeat_x, a.screen.repeat_y, a.subsample, (long)(uintptr_t)s};
-        if (memcmp(key, ctx->resolve_tables_key, sizeof key) != 0) {
-            hipLaunchKernelGGL(k_resolve_axis<0>, dim3((a.w + 127)/128), dim3(128), 0, s, a, columns);
-            hipLaunchKernelGGL(k_resolve_axis<1>, dim3((a.h + 127)/128), dim3(128), 0, s, a, rows);
-            memcpy(ctx->resolve_tables_key, key, sizeof key);
-        }
-        const ResolveTables t{columns, rows};
-        const char* tent = getenv("SHADERFLOW_RESOLVE_TENT");        // A/B switch for measurements
-        if (a.subsample == 2 && a.screen.width == a.w && a.screen.height == a.h && !(tent && atoi(tent) == 0)) {
-            // the two-pass configuration (no SSAA, final.glsl's 3 x 3 tent): four pixels per thread, each texel read once
-            hipLaunchKernelGGL(k_resolve_tent, dim3((a.w + TENT_BW - 1)/TENT_BW, (a.h + TENT_BH - 1)/TENT_BH, frames), dim3(TENT_BW, TENT_BH/TENT_ROWS_PER_THREAD), 0, s, a, t);
-            return SFX_OK;
-        }
-        const dim3 grid((a.w + 63)/64, (a.h + 3)/4, frames), block(64, 4);
-        // iScreen texels under a block of 64 x 4 pixels, two more per axis for the bilinear neighbours: the LDS window (a block
-        // whose own window is larger — it cannot be — or a launch over the cap reads iScreen directly)
-        const long tw = ((long)64*a.screen.width + a.w - 1)/a.w + 3, th = ((long)4*a.screen.height + a.h - 1)/a.h + 3;
-        const int window = tw*th <= RESOLVE_WINDOW_TEXELS ? (int)(tw*th) : 0;
-        const size_t lds = (size_t)window*sizeof(float4);
-        if (a.subsample == 1) hipLaunchKernelGGL(k_resolve_fast<1>, grid, block, lds, s, a, t, window);
-        else if (a.subsample == 2) hipLaunchKernelGGL(k_resolve_fast<2>, grid, block, lds, s, a, t, window);
-        else hipLaunchKernelGGL(k_resolve_fast<3>, grid, block, lds, s, a, t, window);
-        return SFX_OK;
-    }
-    hipLaunchKernelGGL(k_resolve, dim3((a.w + 63)/64, (a.h + 3)/4, frames), dim3(64, 4), 0, s, a);
-    return SFX_OK;
-}
 
 extern "C" int sfx_resolve(sfx_handle h, sfx_handle src, sfx_handle dst, int subsample) {
     CTX_OR_FAIL(c, h);
@@ -1959,7 +1407,7 @@ extern "C" int sfx_resolve(sfx_handle h, sfx_handle src, sfx_handle dst, int sub
     a.w = d->width; a.h = d->height; a.subsample = subsample < 1 ? 1 : subsample;
     a.out = (uint8_t*)d->data;
     a.screen_frame_stride = 0; a.out_frame_stride = 0; a.top_down = c->top_down;
-    { const int rc = launch_resolve(c, a, 1, c->stream); if (rc) return rc; }
+    { const int rc = sfl::launch_resolve(c, a, 1, c->stream); if (rc) return rc; }
     return launch_status();
 }
 
@@ -3070,12 +2518,11 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
     if (rc) return rc;
     a.has_vis = 0;                                                  // per-frame audio uniforms live on the device
     if (p->fragment == FRAG_VISUALIZER) {
-        hipLaunchKernelGGL(k_visualizer_consts, dim3((nframes + 63)/64), dim3(64), 0, p->ctx->stream, t->d_dyn, frame0, nframes, t->d_vis);
+        sfl::visualizer_consts_frames(t->d_dyn, frame0, nframes, t->d_vis, p->ctx->stream);
         a.vis_consts = t->d_vis;
         if (t->plan && t->width == 1 && a.tex[TEX_SPECTROGRAM].components == 2 && a.tex[TEX_SPECTROGRAM].filter == FILTER_NEAREST) {
             const long count = (long)nframes*t->n;
-            hipLaunchKernelGGL(k_visualizer_bars, dim3((unsigned)((count + 255)/256)), dim3(256), 0, p->ctx->stream,
-                               t->d_columns + (long)frame0*t->n, count, t->d_bars + (long)frame0*t->n);
+            sfl::visualizer_bars(t->d_columns + (long)frame0*t->n, count, t->d_bars + (long)frame0*t->n, p->ctx->stream);
             a.tape_bars = t->d_bars;
         }
     }
@@ -3097,6 +2544,6 @@ extern "C" int sfx_render_tape(sfx_handle hp, sfx_handle ht, int frame0, int nfr
     r.screen = Tex{t->d_screen, a.wr, a.hr, 4, DT_U8, p->ctx->filter_model == SFX_FILTER_FIXED8 ? FILTER_LINEAR_FIXED8 : FILTER_LINEAR, 0, 0};      // iScreen: linear, repeat(False) (scene.py:192-194)
     r.w = width; r.h = height; r.subsample = subsample; r.out = (uint8_t*)device_out;
     r.screen_frame_stride = (long)screen_frame; r.out_frame_stride = (long)width*height*3; r.top_down = p->ctx->top_down;
-    if ((rc = launch_resolve(p->ctx, r, nframes, p->ctx->stream))) return rc;
+    if ((rc = sfl::launch_resolve(p->ctx, r, nframes, p->ctx->stream))) return rc;
     return launch_status();
 }

@@ -101,8 +101,7 @@ __global__ __launch_bounds__(MP_THREADS) void k_multipass_layer1(const RenderArg
         any_blur = any_blur || (inside[q] && !left[q]);
     }
     if (any_blur) {
-#pragma unroll 2
-        for (int k = 0; k < count; k++) {
+        for (int k = 0; k < count; k++) {                                                  // (not unrolled: the optimizer declines, and said so on every build)
             const vec2 offset = {tap_x[k], tap_y[k]};
             const float weight = tap_w[k];
 #pragma unroll

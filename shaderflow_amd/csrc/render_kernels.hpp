@@ -245,6 +245,7 @@ __device__ __forceinline__ vec3 final_glsl(const Tex& screen, vec2 astuv, vec2 r
     return accumulator/(float)(kernel*kernel);                                               // :31
 }
 
+#ifdef SF_UNIT_RESOLVE       // a non-template kernel lives in ONE translation unit of the library (launch_resolve.hip)
 __global__ __launch_bounds__(256) void k_resolve(const ResolveArgs a) {
     const int i = blockIdx.x*64 + threadIdx.x;
     const int j = blockIdx.y*4 + threadIdx.y;
@@ -258,6 +259,10 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveArgs a) {
     uint8_t* p = a.out + (long)blockIdx.z*a.out_frame_stride + ((long)row*a.w + i)*3;
     p[0] = (uint8_t)unorm8(c.x); p[1] = (uint8_t)unorm8(c.y); p[2] = (uint8_t)unorm8(c.z);
 }
+#endif
+
+__device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }   // sf::clamp(x, 0, 1) for every non-NaN x (the sign of a zero is squared away by its users)
+__device__ __forceinline__ float smoothstep01(float t) { t = clamp01(t); return t*t*(3.0f - 2.0f*t); }   // sf::smoothstep(0, 1, t)
 
 // ---- DPP helpers ---------------------------------------------------------------------------------------
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {

@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void k_resolve_tent(const ResolveArgs a, const
     uint8_t* out = a.out + (long)blockIdx.z*a.out_frame_stride;
     constexpr int GROUPS = TENT_BW*3/16;
     if (i_first + TENT_BW <= a.w && (a.w*3) % 16 == 0 && ((uintptr_t)out & 15) == 0) {
-#pragma unroll
-        for (int e = tid; e < TENT_BH*GROUPS; e += 256) {
+        static_assert(TENT_BH*GROUPS <= 256, "one 16-byte group per thread");
+        if (const int e = tid; e < TENT_BH*GROUPS) {
             const int row = e/GROUPS, c = e - row*GROUPS, jr = j_first + row;
             if (jr < a.h) stream_store16((uint4*)(out + (long)(a.top_down ? a.h - 1 - jr : jr)*a.w*3 + (long)i_first*3) + c, (const uint4*)&staged[0][0] + e);
         }

@@ -264,7 +264,6 @@ __global__ __launch_bounds__(SEP_PIXELS) __attribute__((amdgpu_waves_per_eu(sep_
     __shared__ uint32_t occupancy_pad[SEP_LDS_PAD/4];
     if (a.w < 0) occupancy_pad[tid] = (uint32_t)tid;
 #endif
-    const bool inside = px < a.w;
     const float4* columns = t.columns + (long)frame*a.wr;
     const float4* rows = t.rows + (long)frame*a.hr;
     const int i0 = (2*px < a.wr) ? 2*px : a.wr - 1, i1 = (2*px + 1 < a.wr) ? 2*px + 1 : a.wr - 1;

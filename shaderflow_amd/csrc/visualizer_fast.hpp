@@ -184,8 +184,6 @@ __global__ __launch_bounds__(128) void k_visualizer_axes(const RenderArgs a, con
 #ifndef VIS_SPECULATE
 #define VIS_SPECULATE 1
 #endif
-__device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }   // sf::clamp(x, 0, 1) for every non-NaN x (the sign of a zero is squared away by its users)
-__device__ __forceinline__ float smoothstep01(float t) { t = clamp01(t); return t*t*(3.0f - 2.0f*t); }   // sf::smoothstep(0, 1, t)
 
 template <bool WITH_ALPHA = false>                               // the fused kernels never look at alpha (final.glsl takes .rgb); iScreen holds it
 __device__ __forceinline__ uint32_t visualizer_fast_post(const RenderArgs& a, int frame, const VisualizerConsts& c, float r, float g, float b,
@@ -210,13 +208,13 @@ __device__ __forceinline__ uint32_t visualizer_fast_post(const RenderArgs& a, in
     // for the lanes that are certain of their side of both radii by 5e-4 — is this one times |shrink| (one square root for two)
     const float reach = __builtin_amdgcn_sqrtf(c1.z + r1.z);
 
-    float circle, len, bar, rr;
+    float len, bar, rr;
     auto heights = [&](float circle_, float len_) {                                             // :45-46, :52, given the angle
         const int bin = wrap_texel((int)::floorf(circle_*height), sp.height, sp.repeat_y);
         const float amplitude = bars[2*bin + ((music_uv.y < 0.0f) ? 0 : 1)];                    // sqrt(texel/1000), the channel :52 picks
         bar = amplitude*(0.05f + 3.0f*smoothstep01(circle_*0.5f));                              // smoothstep(0, 2, circle): x/2 is exact
         rr = radius + 0.5f*bar;
-        circle = circle_; len = len_;
+        len = len_;
     };
     bool certain = false;
     if (VIS_SPECULATE) {

@@ -32,6 +32,7 @@
 namespace sf {
 
 
+#ifdef SF_UNIT_VISUALIZER_TABLES       // non-template kernels live in ONE translation unit of the library (launch_visualizer_strip.hip)
 __global__ void k_visualizer_consts(const FrameDyn* __restrict__ dyn, int frame0, int nframes, VisualizerConsts* __restrict__ out) {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= nframes) return;
@@ -46,6 +47,7 @@ __global__ void k_visualizer_bars(const float* __restrict__ columns, long n, flo
     const long k = (long)blockIdx.x*blockDim.x + threadIdx.x;
     if (k < n) bars[k] = sf::sqrt(columns[k]/1000.0f);
 }
+#endif
 
 // TILE_PITCH: cells per tile row (48 B each): 128 covers a 128-pixel block without supersampling, 80 is enough when
 // the block's 128 pixels are 2x or 4x supersampled (the window is then ~64 cells wide) and lets more blocks share a CU.

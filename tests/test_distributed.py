@@ -328,3 +328,145 @@ def test_shm_ring_is_cut_to_the_free_space_of_its_filesystem(tmp_path, monkeypat
     monkeypatch.setattr(os, "statvfs", lambda path: Stat(64 << 20))                # a container's default /dev/shm
     with pytest.raises(RuntimeError, match="frame ring needs"):
         parallel.shm_slots_that_fit(frame, 120, 8)
+
+
+# ---- bench.py as the driver may start it: `python bench.py --gpus N` with no launcher (missing 1) -------------------
+
+def _bench_module():
+    import importlib.util
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("bench_under_test", root/"bench.py")
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)                                 # (imports nothing heavy at module level: no torch, no HIP library)
+    return module, root
+
+
+def test_bench_launcher_command_is_the_drivers_own():
+    bench, root = _bench_module()
+    command = bench.launcher_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], 29513)
+    assert command[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in command
+    assert command[command.index("--master-addr") + 1] == "127.0.0.1" and command[command.index("--master-port") + 1] == "29513"
+    at = command.index(str(root/"bench.py"))
+    assert command[at + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]            # the ranks get the SAME arguments
+
+
+def _run_bench(arguments, **env_changes):
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "SHADERFLOW_DIST_BACKEND")}
+    env.update(env_changes)
+    return subprocess.run([sys.executable, str(root/"bench.py"), *arguments], capture_output=True, text=True, timeout=280, cwd=root, env=env)
+
+
+@pytest.mark.timeout(300)
+def test_bench_refuses_one_rank_under_gpus_2():
+    """WORLD_SIZE=1 with --gpus 2 (a launcher that started ONE rank): until round 5 this rendered on one GPU and printed `n_gpus: 1`"""
+    out = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    assert out.returncode != 0 and out.stdout.strip() == "" and "--gpus 2 but WORLD_SIZE=1" in out.stderr
+    out = _run_bench(["--gpus", "1", "--steps", "1", "--warmup", "0"], WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    assert out.returncode != 0 and out.stdout.strip() == "" and "--gpus 1 but WORLD_SIZE=2" in out.stderr
+
+
+@pytest.mark.timeout(300)
+def test_plain_bench_command_spawns_its_ranks_and_fails_loudly_without_gpus():
+    """No launcher, --gpus 2, a node without (enough) GPUs: the parent starts the ranks as a child process, every rank refuses with one
+    sentence, the parent exits non-zero and prints NO line. (On a GPU box the same command is tests/test_gpu_distributed.py's.)"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs are visible: the command would run")
+    out = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--frames-per-step", "2", "--width", "64", "--height", "36"])
+    assert out.returncode != 0 and out.stdout.strip() == "", out.stdout[-500:]
+    assert "without a launcher" in out.stderr and "needs 2 visible GPUs" in out.stderr and "no line" in out.stderr
+
+
+# ---- the sharded export's orchestration at the north star's size: world 8, 3 601 frames (uneven ranges), a failing middle rank ------
+
+def _spawn_world(target, world, args, timeout=150):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, *args, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    return procs, out
+
+
+@pytest.mark.timeout(240)
+def test_contiguous_device_export_world_8_uneven_ranges():
+    """BASELINE config 5's layout (3 600 frames over 8 ranks) plus one frame, so that the ranges are uneven: 451 + 7 x 450"""
+    total, batch, world = 3601, 60, 8
+    assert [shard_frames(total, world, r)[1] - shard_frames(total, world, r)[0] for r in range(world)] == [451] + [450]*7
+    procs, out = _spawn_world(_device_mode_worker, world, (total, batch))
+    emitted = out.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert emitted == list(range(total))
+
+
+@pytest.mark.timeout(240)
+def test_round_robin_export_world_8_uneven_rounds():
+    total, batch, world = 3601, 60, 8                              # 61 batches: 7 full rounds of 8, a round of 5, the last batch of 1 frame
+    procs, out = _spawn_world(_export_worker, world, (total, batch))
+    emitted = out.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert emitted == list(range(total))
+
+
+def _failing_device_worker(rank: int, world: int, port: int, total: int, batch: int, failing: int, out):
+    """_device_mode_worker with rank `failing` raising in its third render: nobody may hang — the failing rank ends with its error, rank 0
+    (which waits for that rank's chunks) with an error of its own, the others finish their sends"""
+    from shaderflow_amd.parallel import RangeTransfer, contiguous_device_export
+    import datetime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    frame_bytes = 8
+    first, last = shard_frames(total, world, rank)
+    resident = torch.zeros((total if rank == 0 else max(1, last - first))*frame_bytes, dtype=torch.uint8)
+    renders, emitted = [0], []
+
+    def render(f, c, view):
+        renders[0] += 1
+        if rank == failing and renders[0] == 3:
+            raise RuntimeError("injected: this rank's render failed")
+        view[:] = torch.arange(f, f + c, dtype=torch.int64).view(torch.uint8)
+
+    def emit(view, c):
+        emitted.extend(np.frombuffer(view.numpy().tobytes(), np.int64).tolist())
+
+    transfer = RangeTransfer(world, rank, torch.device("cpu"))
+    outcome = "done"
+    try:
+        contiguous_device_export(world, rank, total, batch, frame_bytes, lambda f, c: None, render, emit, resident, transfer)
+    except BaseException as error:                                  # noqa: BLE001 — what the export does with it: tape.py:361-363
+        outcome = f"{type(error).__name__}: {error}"
+        transfer.abort()
+    out.put((rank, outcome, len(emitted), emitted == list(range(len(emitted)))))
+    out.close(); out.join_thread()                                   # (the queue's feeder thread has written before the process ends)
+    os._exit(0 if outcome == "done" else 1)                         # (no destroy_process_group: a peer is gone, as after a real failure)
+
+
+@pytest.mark.timeout(300)
+def test_contiguous_device_export_world_8_with_a_failing_middle_rank():
+    total, batch, world, failing = 3601, 60, 8, 3
+    procs, out = _spawn_world(_failing_device_worker, world, (total, batch, failing))
+    reports = {}
+    for _ in range(world):
+        rank, outcome, count, in_order = out.get(timeout=200)
+        reports[rank] = (outcome, count, in_order)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode is not None, "a rank hung"
+    assert "injected" in reports[failing][0]
+    assert reports[0][0] != "done", reports[0]                      # rank 0 cannot have emitted rank 3's frames: it must say so, not finish
+    first_of_failing = shard_frames(total, world, failing)[0]
+    # what rank 0 DID hand to the sink is a correct prefix: its own range, ranks 1-2, and the chunks rank 3 sent before it failed
+    assert reports[0][2] and first_of_failing <= reports[0][1] <= first_of_failing + 2*batch, reports[0]
+    for rank in (1, 2, 4, 5, 6, 7):
+        assert reports[rank][0] == "done", (rank, reports[rank])

@@ -252,3 +252,25 @@ def test_bench_with_two_ranks_prints_one_line_for_the_whole_job():
     # the second number: the same frames through a real sharded export, read-out to host memory included (host mode)
     assert record["export_host"]["frames"] == 16 and record["export_host"]["value"] > 0 and "SHADERFLOW_SHARD=host" in record["export_host"]["mode"]
     assert record["roofline"]["bound"] == "valu" and record["roofline"]["kernel"].startswith("k_") and record["roofline"]["hbm"]["achieved"] > 0
+
+
+@pytest.mark.timeout(500)
+def test_plain_bench_command_with_gpus_2_becomes_two_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it — how the driver starts its 1-GPU bench, and how a first hardware scaling
+    run might be started: the process must BECOME two ranks (a child torch.distributed.run, started before anything touches the GPU)
+    and relay rank 0's line, never print a silent `n_gpus: 1` (missing 1)"""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(SHADERFLOW_DIST_BACKEND="gloo")
+    command = [sys.executable, str(root/"bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames-per-step", "4", "--width", "384", "--height", "216", "--no-export"]
+    out = subprocess.run(command, capture_output=True, text=True, timeout=420, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [line for line in out.stdout.splitlines() if line.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]           # the JSON line is the only — so the last — stdout line
+    record = json.loads(lines[0])
+    assert record["n_gpus"] == 2 and record["rccl_ranks"] == 2 and record["config"]["ranks"] == 2 and record["value"] > 0
+    assert "without a launcher" in out.stderr

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """
-ISA census of one kernel of `make asm`'s output (shaderflow_amd/csrc/capi.gfx950.s): the kernel's basic blocks, the instructions of
+ISA census of one kernel of `make asm`'s output (shaderflow_amd/csrc/launch_visualizer_strip.gfx950.s): the kernel's basic blocks, the instructions of
 every block by CLASS (the classes tools/ubench_valu.hip prices: full-rate f32 add / mul / fma and moves, half-rate conversions /
 min-max / fract / shifts / SGPR-operand forms, quarter-rate transcendentals; scalar ALU, scalar loads, branches, waits, LDS, global),
 the source lines a block was generated from (when the listing carries `.loc`: build it with -gline-tables-only), and — given how often

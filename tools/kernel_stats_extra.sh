@@ -2,7 +2,7 @@
 # kernel_stats.sh with extra -D flags: tools/kernel_stats_extra.sh "<flags>" <kernel name pattern>
 cd "$(dirname "$0")/../shaderflow_amd/csrc" || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
-  -fno-fast-math -fno-slp-vectorize -fno-gpu-flush-denormals-to-zero -Wno-unused-value $1 --cuda-device-only -c capi.hip -o /tmp/capi_x.o \
+  -fno-fast-math -fno-slp-vectorize -fno-gpu-flush-denormals-to-zero -Wno-unused-value $1 --cuda-device-only -c ${UNIT:-launch_visualizer_strip}.hip -o /tmp/unit_x.o \
   -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import re, sys, subprocess
 rows, cur = [], {}
