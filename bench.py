@@ -423,6 +423,9 @@ def main() -> None:
     render_stream = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(render_stream)
     context = N.Context(local_rank, render_stream.cuda_stream)
+    count_fallbacks = os.environ.get("SHADERFLOW_BENCH_TILE_MISSES") == "1"     # diagnostics: blocks / waves that left their kernel's fast tier (sfx_ctx_tile_misses)
+    if count_fallbacks:
+        context.tile_misses()                                     # allocates and zeroes the device counter
 
     def build_scene(prepared: bool = True):
         scene = make(scene_class, audio=(None if args.scene == "basic" else (pcm, 44100)), background=(background if args.scene == "visualizer" else None), context=context)
@@ -668,6 +671,8 @@ def main() -> None:
                 for pointer in pair:
                     context.free(pointer)
 
+    if count_fallbacks:
+        print(f"bench.py: tile misses / tier fallbacks counted on the device: {context.tile_misses()} over {(args.warmup + args.steps)*fpb*len(legs)} frames", file=sys.stderr)
     kernel_ms = chosen["events_ms"]
     launch_s = (float(np.mean(kernel_ms))/1e3/parts) if kernel_ms else float("nan")     # one launch = `piece` frames
     kernel = N.lib().sfx_last_kernel().decode()

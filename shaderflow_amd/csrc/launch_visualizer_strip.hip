@@ -33,18 +33,62 @@ static int launch_visualizer_tables_and_kernel(Context* ctx, const RenderArgs& a
     const size_t entries = (size_t)frames*((size_t)a.wr + a.hr)*VIS_ENTRY_QUADS*sizeof(float4);
     const size_t blocks = (size_t)frames*((size_t)t.blocks_x + t.blocks_y)*sizeof(int4);
     const size_t ysteps = STRIP_S ? (size_t)frames*a.hr*10*sizeof(float4) : 0;
-    if (ctx->vis_tables_bytes < entries + blocks + ysteps) {
+    // the pixel tier (visualizer_fast.hpp visualizer_pixel_gains): fused 2x / 4x launches whose bars come as a table; SHADERFLOW_VIS_PIXEL_TIER=0
+    // turns it off (A/B measurements, and the tests that compare the two tiers)
+    const Tex& sp = a.tex[TEX_SPECTROGRAM];
+    const char* tier_env = getenv("SHADERFLOW_VIS_PIXEL_TIER");
+    float reach_uv = 0.0f, reach_agluv = 0.0f;
+    bool tier = STRIP_S >= 2 && a.tape_bars && sp.height > 0 && !(tier_env && atoi(tier_env) == 0);
+    if (tier) {
+        // how far a supersample lies from its pixel's centre: (S - 1)/(2S) of the pixel per axis, bounded by 0.3 of its diagonal for S <= 4
+        // (0.25 at 2x, 0.375 at 4x … of the HALF diagonal 0.5): in iCamera.gluv units through the axis camera's slopes, and in agluv units
+        float slope_x = 1.0f, slope_y = 1.0f;
+        if (!a.identity_camera) {
+            bool behind = false;
+            slope_x = fabsf(camera_along_axis<0>(a.u, 1.0f, a.aspect, behind) - camera_along_axis<0>(a.u, -1.0f, a.aspect, behind))/2.0f;
+            slope_y = fabsf(camera_along_axis<1>(a.u, 1.0f, a.aspect, behind) - camera_along_axis<1>(a.u, -1.0f, a.aspect, behind))/2.0f;
+        }
+        const float px = 2.0f*a.aspect/(float)a.w*slope_x, py = 2.0f/(float)a.h*slope_y;
+        const float part = STRIP_S == 2 ? 0.30f : 0.45f;               // of the pixel's diagonal: 0.25 / 0.375 exactly, with a margin
+        reach_uv = part*sqrtf(px*px + py*py);
+        reach_agluv = part*sqrtf(4.0f/((float)a.w*(float)a.w) + 4.0f/((float)a.h*(float)a.h));
+        if (!(reach_uv < 1.0f) || !(reach_uv > 0.0f)) tier = false;   // (a degenerate camera: NaN or nothing to bound)
+    }
+    const size_t pixel_entries = tier ? (size_t)frames*((size_t)a.w + a.h)*sizeof(float4) : 0;
+    const size_t bars2 = tier ? (size_t)frames*sp.height*2*sizeof(float2) : 0;
+    const size_t classes = tier ? (size_t)frames*t.blocks_x*t.blocks_y*8 : 0;
+    const size_t needed = entries + blocks + ysteps + pixel_entries + bars2 + classes;
+    if (ctx->vis_tables_bytes < needed) {
         hipStreamSynchronize(s);
         hipFree(ctx->vis_tables); ctx->vis_tables = nullptr; ctx->vis_tables_bytes = 0;
-        if (hipMalloc(&ctx->vis_tables, entries + blocks + ysteps) != hipSuccess) return fail(SFX_E_HIP, "visualizer tables of %d frames: out of device memory", frames);
-        ctx->vis_tables_bytes = entries + blocks + ysteps;
+        if (hipMalloc(&ctx->vis_tables, needed) != hipSuccess) return fail(SFX_E_HIP, "visualizer tables of %d frames: out of device memory", frames);
+        ctx->vis_tables_bytes = needed;
     }
     t.columns = (float4*)ctx->vis_tables;
     t.rows = t.columns + (size_t)frames*a.wr*VIS_ENTRY_QUADS;
     t.block_x = (int4*)(t.rows + (size_t)frames*a.hr*VIS_ENTRY_QUADS);
     t.block_y = t.block_x + (size_t)frames*t.blocks_x;
     t.ysteps = STRIP_S ? (float4*)(t.block_y + (size_t)frames*t.blocks_y) : nullptr;
+    char* after = (char*)ctx->vis_tables + entries + blocks + ysteps;
+    t.pixel_columns = tier ? (float4*)after : nullptr;
+    t.pixel_rows = tier ? t.pixel_columns + (size_t)frames*a.w : nullptr;
+    float2* spread = tier ? (float2*)(after + pixel_entries) : nullptr;
+    t.bars2 = spread;
+    t.pixel_reach_uv = reach_uv; t.pixel_reach_agluv = reach_agluv;
+    uint8_t* wave_classes = tier ? (uint8_t*)(after + pixel_entries + bars2) : nullptr;
+    t.wave_classes = wave_classes;
+    if (tier) {
+        const long count = (long)frames*sp.height*2;
+        hipLaunchKernelGGL(k_visualizer_bar_spread, dim3((unsigned)((count + 255)/256)), dim3(256), 0, s, a.tape_bars + (long)a.frame0*a.spectrogram_stride,
+                           (long)a.spectrogram_stride, frames, sp.height, sp.repeat_y, spread);
+    }
     hipLaunchKernelGGL(k_visualizer_axes, dim3((a.wr + 127)/128 + (a.hr + 127)/128, frames), dim3(128), 0, s, a, t);
+    if constexpr (STRIP_S >= 2) {
+        if (tier) {
+            const long tiles = (long)t.blocks_x*t.blocks_y*8;
+            hipLaunchKernelGGL((k_visualizer_classify<STRIP_S, WALK, CG>), dim3((unsigned)((tiles + 255)/256), frames), dim3(256), 0, s, a, t, wave_classes);
+        }
+    }
     if constexpr (STRIP_S != 0) {
         g_last_kernel = "k_visualizer_strip<" + std::to_string(PITCH) + ", " + std::to_string(ROWS) + ", " + std::to_string(STRIP_S) + ", " + std::to_string(WALK) + ", " + std::to_string(WAVES) + ", " + std::to_string(CG) + (HALF ? ", true>" : ", false>");
         hipLaunchKernelGGL((k_visualizer_strip<PITCH, ROWS, STRIP_S, WALK, WAVES, CG, HALF>), dim3(t.blocks_x*t.blocks_y, 1, frames), dim3(512), 0, s, a, t);

@@ -44,7 +44,29 @@ struct VisTables {
     int block_columns, block_rows;       // samples per block along x / y
     int tile_pitch, tile_rows;           // LDS tile the offsets are computed for (cells)
     int cell_bytes;                      // distance between neighbouring cells of a tile row: 48 (float32 cells, three float4 together) or 8 (float16 cells in three planes)
+    // the PIXEL tier (round 6, VisualizerStrip::pixel_tier): visualizer.frag:36-62's position-only factors once per output pixel
+    float4* pixel_columns;               // [frame][w] = q1 of the pixel's centre column { rot_c*u, -rot_s*u, u*u, agluv.x^2 }; null: no pixel tier
+    float4* pixel_rows;                  // [frame][h] = q1 of the pixel's centre row    { rot_s*u,  rot_c*u, u*u, agluv.y^2 }
+    const float2* bars2;                 // [frame][spectrogram height][2 channels] = { bar amplitude sqrt(texel/1000), its largest difference to a neighbouring bin / the other channel at the ends }
+    float pixel_reach_uv;                // how far a supersample can lie from its pixel's centre, in iCamera.gluv units (with a margin: 0.3 of the pixel's diagonal)
+    float pixel_reach_agluv;             // ... in agluv units
+    const uint8_t* wave_classes;         // [frame][blocks_y*blocks_x][8 waves]: 1 = the wave's tile takes the pixel tier (k_visualizer_classify)
 };
+
+// { amplitude, spread }: the bar of a spectrogram texel and how far the bars a NEIGHBOURING position could pick differ from it — the bins
+// on either side (wrapped as the sampler wraps them) and, for the first and the last bin, the other channel (visualizer.frag:52 switches
+// channel where music_uv.y changes sign, i.e. at circle = 0 and circle = 1). One thread per (frame, bin, channel).
+__global__ void k_visualizer_bar_spread(const float* __restrict__ bars, long frame_stride, int frames, int height, int repeat_y, float2* __restrict__ out) {
+    const long k = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= (long)frames*height*2) return;
+    const int frame = (int)(k/(height*2)), e = (int)(k - (long)frame*height*2), bin = e >> 1, ch = e & 1;
+    const float* b = bars + frame*frame_stride;
+    const float mine = b[2*bin + ch];
+    const float below = b[2*wrap_texel(bin - 1, height, repeat_y) + ch], above = b[2*wrap_texel(bin + 1, height, repeat_y) + ch];
+    float spread = fmaxf(fabsf(below - mine), fabsf(above - mine));
+    if (bin == 0 || bin == height - 1) spread = fmaxf(spread, fabsf(b[2*bin + (1 - ch)] - mine));
+    out[k] = make_float2(mine, (spread == spread) ? spread : __builtin_inff());            // a NaN bar: never certain
+}
 
 // One axis of the sample grid: thread k builds the entry of column (AXIS == 0) or row (AXIS == 1) k of frame blockIdx.y.
 template <int AXIS>
@@ -161,6 +183,16 @@ __device__ __forceinline__ void visualizer_axis_entry(const RenderArgs& a, const
     e[4] = make_float4(wn[2], ws[2], wn[3], ws[3]);
     e[5] = make_float4(wn[4], ws[4], wn[5], ws[5]);
     e[6] = make_float4(wn[6], ws[6], wn[7], ws[7]);
+    // the pixel tier's entry of output pixel k along this axis: the same terms at the pixel's CENTRE (between its supersamples)
+    const int pixels = AXIS == 0 ? a.w : a.h;
+    if (t.pixel_columns && k < pixels) {
+        const float pc = ((float)k + 0.5f)/(float)pixels;
+        const float pag = pc*2.0f - 1.0f, pg = pag*aspect;
+        bool pbehind = false;
+        const float puv = a.identity_camera ? pg : camera_along_axis<AXIS>(u, pg, a.aspect, pbehind);
+        (AXIS == 0 ? t.pixel_columns : t.pixel_rows)[(long)frame*pixels + k] =
+            AXIS == 0 ? make_float4(c.rot_c*puv, (-c.rot_s)*puv, puv*puv, pag*pag) : make_float4(c.rot_s*puv, c.rot_c*puv, puv*puv, pag*pag);
+    }
 }
 // both axes in ONE launch (the two tables are latency-bound chains of a few thousand threads each: side by side they take the time
 // of one — 53 instead of 105 us per 60 frames of 4K): blocks [0, ceil(wr/128)) build columns, the rest rows; frame = blockIdx.y
@@ -266,6 +298,144 @@ __device__ __forceinline__ uint32_t visualizer_fast_post(const RenderArgs& a, in
     texel = __builtin_amdgcn_cvt_pk_u8_f32(col.y, 1u, texel);
     texel = __builtin_amdgcn_cvt_pk_u8_f32(col.z, 2u, texel);
     return WITH_ALPHA ? (texel | alpha) : texel;
+}
+
+// ---- the pixel tier (round 6) ------------------------------------------------------------------------------------------------------
+// visualizer.frag:36-62 is, per channel, AFFINE in the blur's sum: texel_c = (sum_c + space_c*w)*A*vignette with
+//     A = norm*flash*ring*(1 - sm)*255,  w = sm/(norm*flash*ring*(1 - sm))      (flash :36, ring = 0.5 | pow((len - rr)/2, 0.05) :49-58, sm :62)
+// and A, w depend on the sample's POSITION only — through the most expensive part of the fragment (the polar chain: 70 of visualizer_fast_post's
+// 110 instructions). The supersamples of a pixel lie a quarter of a pixel from its centre, so where A varies by less than a fraction of an LSB
+// across the pixel one evaluation at the centre serves them all: the strip kernel then spends eleven instructions per supersample (vignette,
+// strips, three multiply-adds, three products, three conversions) instead of 110, and the position-only part once per pixel ROW of a lane's column.
+//
+// WHERE that holds is decided per WAVE TILE (the 64 sample columns x WALK sample rows of one wave) by k_visualizer_classify, one thread per
+// tile and frame, BEFORE the strip kernel runs — so a wave knows from one byte which of its two paths it takes, nothing of the other path is
+// alive in its registers, and no lane ever mixes the two. The tile's rectangle of whole output pixels is bounded in music_uv space (a rotation
+// and a uniform scale of iCamera.gluv: still a rectangle): len_min / len_max = the distances of its nearest / farthest point from the origin,
+// the bins its angles can reach (+ one on either side), the largest bar and the largest bar-to-neighbour difference among them
+// (k_visualizer_bar_spread). With `reach` = the largest distance of a supersample from its pixel's centre (VisTables::pixel_reach_*):
+//   * the ring's gain: all inside the disc (len_max < radius - reach): the constant 0.5; all outside every bar the tile can see
+//     (len_min - reach > rr_hi + drr_hi): pow(x, 0.05), x = (len - rr)/2, whose relative change over |dx| <= (reach + drr_hi)/2 is at most
+//     0.05*dx/(x_min - dx); anything else (the disc's edge, the bars, their outline) is the per-sample path's;
+//   * the flash 1 + f*cl^6 changes by at most 6*f*cl_max^5*reach_agluv/(1 + f*cl_min^6) of itself;
+//   * sm = smoothstep(length(uv)/20) moves by < 1e-5 of itself over a pixel: nothing.
+// A tile takes the pixel tier when (ring + flash bounds)*255 < 0.4 LSB: every supersample's texel then differs from its own evaluation by less
+// than half an LSB BEFORE quantisation, so after final.glsl's mean a frame differs from the per-sample kernel's by at most 1 LSB (in practice
+// by one in a few per cent of the values, none further: tests/test_gpu_fullsize.py compares both with the oracle).
+struct PixelGains { float A, w; };          // texel_c = (sum_c + space_c*w)*A*vignette, space = (1, 11, 26) (:9; A carries the 255, w the sm/(1 - sm))
+__device__ __forceinline__ PixelGains visualizer_pixel_gains(const RenderArgs& a, const VisTables& t, int frame, const VisualizerConsts& c, const float4 pc1, const float4 pr1) {
+    const float norm = 1.0f/(255.0f*10.0f*8.0f);
+    const float radius = 0.17f;
+    PixelGains g;
+    // :36 the flash
+    const float la = __builtin_amdgcn_sqrtf(pc1.w + pr1.w);
+    const float cl = clamp01(la - 0.3f);
+    const float c2l = cl*cl;
+    const float fl = fmaf(c.flash, c2l*c2l*c2l, 1.0f);
+    // :39-46 the polar chain at the centre (visualizer_fast_post's speculated form: the centre needs no exact bits — a tile whose bars could
+    // change the gain by a fraction of an LSB is not here)
+    const float mx = (pc1.x + pr1.x)*c.shrink, my = (pc1.y + pr1.y)*c.shrink;
+    const float reach = __builtin_amdgcn_sqrtf(pc1.z + pr1.z);
+    const float len = reach*sf::abs(c.shrink);
+    const float ax = sf::abs(mx), ay = sf::abs(my);
+    const float hi = __builtin_fmaxf(ax, ay), lo = __builtin_fminf(ax, ay);
+    const float q = lo*__builtin_amdgcn_rcpf(hi);
+    const bool upper = q > 0x1.a8279ap-2f;
+    const float u = upper ? (q - 1.0f)*__builtin_amdgcn_rcpf(q + 1.0f) : q;
+    const float z = u*u;
+    float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = fmaf(p, z, 1.99777106478e-1f);
+    p = fmaf(p, z, -3.33329491539e-1f);
+    float angle = (upper ? QUARTER_PI : 0.0f) + fmaf(p*z, u, u);
+    if (ay > ax) angle = HALF_PI - angle;
+    if (mx < 0.0f) angle = 0x1.921fb6p+1f - angle;
+    const float circle = angle*0x1.45f306p-2f;
+    const Tex& sp = a.tex[TEX_SPECTROGRAM];
+    const int bin = wrap_texel((int)::floorf(circle*(float)sp.height), sp.height, sp.repeat_y);
+    const float amplitude = t.bars2[(long)frame*sp.height*2 + 2*bin + ((my < 0.0f) ? 0 : 1)].x;
+    const float rr = fmaf(0.5f*(0.05f + 3.0f*smoothstep01(circle*0.5f)), amplitude, radius);
+    const float ring = (len < radius) ? 0.5f : ColourMath<true>::pow((len - rr)*0.5f, 0.05f);          // (a classified tile is all inside or all outside the bars)
+    const float sm = smoothstep01(reach*0.05f);                                                         // :62
+    // mix(col, space, sm)*255 = (sum*(norm*flash*ring)*(1 - sm) + space*sm)*255 = (sum + space*w)*A
+    g.A = ((norm*255.0f)*fl)*(ring*(1.0f - sm));
+    g.w = sm*__builtin_amdgcn_rcpf(g.A);                                                                // (space_c = {1, 11, 26}/255: the 255 cancels against A's)
+    return g;
+}
+
+// One thread per (frame, wave tile): 1 = the tile takes the pixel tier. Launched after k_visualizer_axes / k_visualizer_bar_spread.
+template <int S, int WALK, int COLUMN_GROUPS>
+__global__ __launch_bounds__(256) void k_visualizer_classify(const RenderArgs a, const VisTables t, uint8_t* __restrict__ classes) {
+    constexpr int ROW_GROUPS = 8/COLUMN_GROUPS, COLS = 64*COLUMN_GROUPS, RROWS = ROW_GROUPS*WALK;
+    const long tiles = (long)t.blocks_x*t.blocks_y*8;
+    const long k = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    const int frame = blockIdx.y;
+    if (k >= tiles) return;
+    const int wave = (int)(k & 7), block = (int)(k >> 3), bx = block % t.blocks_x, by = block / t.blocks_x;
+    const int group = wave % ROW_GROUPS, x0 = bx*COLS + (wave/ROW_GROUPS)*64, y0 = by*RROWS + group*WALK;
+    uint8_t verdict = 0;
+    Uniforms u; Tex tex[TEX_HISTORY];
+    frame_view(a, frame, u, tex);
+    const VisualizerConsts c = a.vis_consts ? a.vis_consts[a.frame0 + frame] : (a.has_vis ? a.vis : visualizer_consts(u.iTime, u.iAudioVolume, u.iAudioSTD));
+    // the tile's whole output pixels: columns [px0, px1], rows [py0, py1] (a tile beyond the frame's edge has no samples: no verdict needed)
+    const int px0 = x0/S, px1 = min(x0 + 63, a.wr - 1)/S, py0 = y0/S, py1 = min(y0 + WALK - 1, a.hr - 1)/S;
+    if (x0 < a.wr && y0 < a.hr && c.flash >= 0.0f && c.shrink == c.shrink) {
+        // the rectangle's edges in iCamera.gluv and agluv (the camera is the identity or acts per axis: glsl.hpp camera_along_axis)
+        bool behind = false;
+        auto edge_x = [&](int pixel_edge, float& ag) { ag = (float)pixel_edge/(float)a.w*2.0f - 1.0f; const float g = ag*a.aspect; return a.identity_camera ? g : camera_along_axis<0>(u, g, a.aspect, behind); };
+        auto edge_y = [&](int pixel_edge, float& ag) { ag = (float)pixel_edge/(float)a.h*2.0f - 1.0f; return a.identity_camera ? ag : camera_along_axis<1>(u, ag, a.aspect, behind); };
+        float agx0, agx1, agy0, agy1;
+        const float ux0 = edge_x(px0, agx0), ux1 = edge_x(px1 + 1, agx1), uy0 = edge_y(py0, agy0), uy1 = edge_y(py1 + 1, agy1);
+        // music_uv = rotate2d(-PI/2)*uv*shrink (:39-40): the corners, through the same products the tables hold
+        float mx[4], my[4];
+        const float cx[4] = {ux0, ux1, ux0, ux1}, cy[4] = {uy0, uy0, uy1, uy1};
+        for (int q = 0; q < 4; q++) { mx[q] = (c.rot_c*cx[q] + c.rot_s*cy[q])*c.shrink; my[q] = ((-c.rot_s)*cx[q] + c.rot_c*cy[q])*c.shrink; }
+        const float shrink = sf::abs(c.shrink);
+        // distances: |uv| over the rectangle [ulo, uhi] x [vlo, vhi]
+        const float ulo = fminf(ux0, ux1), uhi = fmaxf(ux0, ux1), vlo = fminf(uy0, uy1), vhi = fmaxf(uy0, uy1);
+        const float nx = fmaxf(fmaxf(ulo, -uhi), 0.0f), ny = fmaxf(fmaxf(vlo, -vhi), 0.0f);              // the nearest point's |u|, |v|
+        const float fx = fmaxf(fabsf(ulo), fabsf(uhi)), fy = fmaxf(fabsf(vlo), fabsf(vhi));              // the farthest corner's
+        const float len_min = sqrtf(nx*nx + ny*ny)*shrink*(1.0f - 1.0e-5f), len_max = sqrtf(fx*fx + fy*fy)*shrink*(1.0f + 1.0e-5f);
+        const float radius = 0.17f, far = t.pixel_reach_uv*shrink;
+        // the flash: cl over the rectangle in agluv
+        const float anx = fmaxf(fmaxf(fminf(agx0, agx1), -fmaxf(agx0, agx1)), 0.0f), any = fmaxf(fmaxf(fminf(agy0, agy1), -fmaxf(agy0, agy1)), 0.0f);
+        const float afx = fmaxf(fabsf(agx0), fabsf(agx1)), afy = fmaxf(fabsf(agy0), fabsf(agy1));
+        const float cl_min = fminf(fmaxf(sqrtf(anx*anx + any*any) - 0.3f, 0.0f), 1.0f), cl_max = fminf(fmaxf(sqrtf(afx*afx + afy*afy) - 0.3f, 0.0f), 1.0f);
+        const float cl_min2 = cl_min*cl_min, cl_max2 = cl_max*cl_max;
+        const float rel_flash = c.flash*6.0f*t.pixel_reach_agluv*(cl_max2*cl_max2*cl_max)/(1.0f + c.flash*cl_min2*cl_min2*cl_min2);
+        float rel_ring = __builtin_inff();
+        if (len_max < radius - far) rel_ring = 0.0f;                                                    // all of it inside the disc (:49-50)
+        else if (nx > 0.0f || ny > 0.0f) {
+            // the angles the tile can see: `circle` = |atan(y, x)|/PI over a convex region that does not hold the origin takes its extremes at
+            // corners — unless the region crosses the line y = 0, where circle reaches 0 (x > 0) or 1 (x < 0) and the channel switches
+            const Tex& sp = tex[TEX_SPECTROGRAM];
+            float lo = 2.0f, hi = -1.0f, ylo = my[0], yhi = my[0], xlo = mx[0], xhi = mx[0];
+            for (int q = 0; q < 4; q++) {
+                const float circle = sf::abs(atan1n(vec2{mx[q], my[q]}));
+                lo = fminf(lo, circle); hi = fmaxf(hi, circle);
+                ylo = fminf(ylo, my[q]); yhi = fmaxf(yhi, my[q]); xlo = fminf(xlo, mx[q]); xhi = fmaxf(xhi, mx[q]);
+            }
+            const bool crosses = ylo <= 0.0f && yhi >= 0.0f;
+            if (crosses) { if (xhi > 0.0f) lo = 0.0f; if (xlo < 0.0f) hi = 1.0f; }
+            // (one bin of slack on either side: the speculated angle of a pixel's centre is 2e-5 bins from the exact one, its samples 0.07)
+            const int b0 = max((int)floorf(lo*(float)sp.height) - 1, 0), b1 = min((int)floorf(hi*(float)sp.height) + 1, sp.height - 1);
+            const float2* bars = t.bars2 + (long)frame*sp.height*2;
+            float amp = 0.0f, spread = 0.0f;
+            bool finite = true;
+            for (int b = b0; b <= b1; b++)
+                for (int ch = (crosses || ylo < 0.0f) ? 0 : 1; ch <= ((crosses || yhi >= 0.0f) ? 1 : 0); ch++) {
+                    const float2 e = bars[2*b + ch];
+                    amp = fmaxf(amp, e.x); spread = fmaxf(spread, e.y);
+                    finite = finite && (e.x == e.x) && (e.y < __builtin_inff());
+                }
+            const float t_hi = fminf(fmaxf(hi*0.5f, 0.0f), 1.0f), F_hi = 0.05f + 3.0f*(t_hi*t_hi*(3.0f - 2.0f*t_hi));
+            // F itself moves by at most 2.25 per unit of circle: over a pixel's angular half-width reach/len, in units of circle reach/(PI*len)
+            const float rr_hi = radius + 0.5f*F_hi*amp, drr = 0.5f*F_hi*spread + 1.2f*(t.pixel_reach_uv/(PI*fmaxf(len_min/shrink, 1.0e-6f)))*amp;
+            const float x_min = (len_min - rr_hi)*0.5f, dx = (far + drr)*0.5f + 1.0e-6f;
+            if (finite && x_min - dx > 0.0f) rel_ring = 0.05f*dx/(x_min - dx);
+        }
+        if (!behind && (rel_ring + rel_flash)*255.0f < 0.4f) verdict = 1;                               // (a NaN anywhere: not the tier)
+    }
+    classes[(long)frame*tiles + k] = verdict;
 }
 
 // Stages the window [x0, x0+tw) x [y0, y0+th) of the background as difference-basis cells (VisualizerShader::setup step 2)
@@ -484,6 +654,9 @@ struct VisualizerFast {
 #define SF_COUNT_FOLD() do {} while (0)
 #define SF_FOLDS_OUT(a) do {} while (0)
 #endif
+// (Round 6: the measured dead ends that used to sit here as VIS_STRIP_* build knobs — adjacent-row folds, the fractions through LDS or
+// vector memory, the two sides' U summed once, blue packed into a split accumulator, the rows' scalar loads issued together, a store
+// per row instead of the sweep — are gone from the source; what each cost is profiles/r05_variants.txt and HISTORY.)
 template <int TILE_PITCH, int TILE_ROWS, int S, int WALK, int COLUMN_GROUPS = 8/S, bool HALF_CELLS = (S == 1)>
 struct VisualizerStrip {
     // S x S supersamples per pixel (2 or 4), or S == 1: no resolve, the RGBA8 samples go to iScreen (the two-pass configuration).
@@ -511,67 +684,82 @@ struct VisualizerStrip {
         q0 = *(const Quad*)p; q1 = *(const Quad*)(p + PLANE); q2 = *(const Quad*)(p + 2*PLANE);
     }
     template <class T> __device__ __forceinline__ static float F(T x) { return (float)x; }     // a cell component as a multiply-add operand
-    // The y half of a cell alone: C = t01 - t00 and D = the second difference (the last six of the cell's twelve values). A cell is the
-    // texel-row basis in disguise — A + C and B + D are the A and B of the cell ABOVE — so whoever moves up by exactly one row of cells
-    // already holds that row's x-folded base (U' = U + V, P' = P + Q) and needs only these: half the LDS bytes and a third fewer
-    // multiply-adds per fold.
-// MEASURED AND NOT KEPT (profiles/r05_variants.txt): 3 104 -> 2 644 frames/s at C3 with the same six waves per SIMD (a third scalar branch
-// per advance, a dependent add chain through U, and 8-byte reads at +24 of 48-byte cells), 2 146 with the 84 registers the unconstrained
-// build takes. The knob stays for the record.
-#ifndef VIS_STRIP_ADJACENT
-#define VIS_STRIP_ADJACENT 0
-#endif
-    __device__ __forceinline__ static void load_cd(const char* p, float (&c)[3], float (&d)[3]) {
-        if constexpr (HALF) {
-            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-            const half2v a = *(const half2v*)(p + PLANE + 4);          // q1.zw
-            const Quad b = *(const Quad*)(p + 2*PLANE);                 // q2
-            c[0] = (float)a.x; c[1] = (float)a.y; c[2] = (float)b.x; d[0] = (float)b.y; d[1] = (float)b.z; d[2] = (float)b.w;
-        } else {
-            const float2 a = *(const float2*)(p + 24);                  // q1.zw
-            const float4 b = *(const float4*)(p + 32);                  // q2
-            c[0] = a.x; c[1] = a.y; c[2] = b.x; d[0] = b.y; d[1] = b.z; d[2] = b.w;
-        }
-    }
     static_assert(COLUMN_GROUPS*ROW_GROUPS == 8 && RROWS % S == 0 && COLS % S == 0, "block geometry");
     using Fast = VisualizerFast<TILE_PITCH, TILE_ROWS, 128>;
-#ifndef VIS_STRIP_COLUMN_BRANCHFREE
-#define VIS_STRIP_COLUMN_BRANCHFREE 1                                  // 1: the column-line takes the weights of all rows of a cell at once (zeros for rows whose slots do not cover it)
-#endif
-#ifndef VIS_STRIP_YSTEPS_LDS
-#define VIS_STRIP_YSTEPS_LDS 0                                         // 1: the block's ysteps through LDS (broadcast reads + v_readfirstlane) instead of scalar loads
-#endif
     // the cell tile; once every wave is done with it, the texel exchange and the staged RGB8 rows live in the same memory
     static constexpr int CELLS_BYTES = TILE_ROWS*TILE_PITCH*(HALF_CELLS ? 24 : 48);
     static constexpr int EXCHANGE_BYTES = (S == 1) ? 0 : (int)sizeof(uint32_t)*ROW_GROUPS*WALK*64*COLUMN_GROUPS + (ROW_GROUPS*WALK/S)*(64*COLUMN_GROUPS/S)*3;
     // Round 5 (profiles/r05_ubench_valu_sgpr.txt): a VALU instruction with a SCALAR source — v_mov_b32 v, s included — issues in 4.2
-    // cycles, not 2.5. The kernel moved 31 wave-uniform values per supersample from scalar to vector registers (fractions of the
-    // diagonal taps, LDS addresses of the column-line's weights): 10 % of its issue cycles. Both now arrive in vector registers through
-    // LDS reads at an address held in ONE vector register plus an immediate offset — no VALU instruction at all:
-#ifndef VIS_STRIP_YFRAC_LDS
-#define VIS_STRIP_YFRAC_LDS 0                                          // the two fractions of every (row, walk step) staged per block; ds_read_b64 at v_w + r*80
-#endif
-#ifndef VIS_STRIP_COLW_ALIGNED
-#define VIS_STRIP_COLW_ALIGNED 1                                       // the column-line's (n, s) weights per WAVE, aligned to the strip's first cell and zero padded: ds_read_b64 at v_k + r*COLW_SLOTS*8
-#endif
+    // cycles, not 2.5. The column-line's wave-uniform weights therefore arrive in vector registers through LDS reads at an address held
+    // in ONE vector register plus an immediate offset — no VALU instruction at all: per WAVE, aligned to the strip's first cell and zero
+    // padded: ds_read_b64 at v_k + r*COLW_SLOTS*8
     static constexpr int COLW_SLOTS = VIS_LINE_CELLS + 6;              // cells a strip's column can span: the 8 slots of a line + the rows of cells its samples cross
     struct Shared {
         float4 cells[(CELLS_BYTES > EXCHANGE_BYTES ? CELLS_BYTES : EXCHANGE_BYTES)/16 + 1];     // (float16 cells without SSAA) later: uint32 texels[RROWS][COLS], then the RGB8 rows at STAGED
         float4 row_entries[RROWS][VIS_ENTRY_QUADS];
-        float4 ysteps[VIS_STRIP_YSTEPS_LDS ? RROWS : 1][10];
         float4 zeros;                                                  // weights of a slot that does not exist
-        float2 yfrac[VIS_STRIP_YFRAC_LDS ? RROWS : 1][10];             // { frac(y+), frac(y-) } of k_visualizer_axes' ysteps
-        float2 colw[VIS_STRIP_COLW_ALIGNED ? 8 : 1][WALK][COLW_SLOTS]; // per wave: weights[r][k - first]
+        float2 colw[8][WALK][COLW_SLOTS];                              // per wave: weights[r][k - first]
     };
     static constexpr int STAGED = (int)sizeof(uint32_t)*RROWS*COLS;    // byte offset of the staged RGB8 rows inside the (dead) cell tile, after the texels
     static_assert(S == 1 || STAGED + PIXEL_ROWS*BLOCK_PX*3 == EXCHANGE_BYTES, "the texel exchange and the staged rows live in the cell tile");
 
-    // a wave-uniform float that has to sit in a vector register: VALU operations with a scalar operand issue at half rate on gfx950
-    // (tools/ubench_valu.hip), one v_mov per value used three times is cheaper
-    __device__ __forceinline__ static float in_vgpr(float uniform) {
-        float v;
-        asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform));
-        return v;
+    // The pixel tier of this wave (visualizer_pixel_gains): OFFSET = the wave's first sample row modulo S. Fills texel[] for every row.
+    // The S lanes that hold the S sample columns of one pixel column SHARE the work: in round j lane l evaluates the gains of pixel row
+    // S*j + l % S of the wave's SLOTS pixel rows (at 2x: five pixel rows in three rounds, at 4x: up to four in one), and a sample takes its
+    // pixel's pair (A, w) from the lane that evaluated it through a quad_perm broadcast — DPP operands of the instructions that use them.
+    template <int SOURCE> __device__ __forceinline__ static float from_pixel_lane(float v) {
+        constexpr int CTRL = S == 2 ? (SOURCE | (SOURCE << 2) | ((2 + SOURCE) << 4) | ((2 + SOURCE) << 6)) : SOURCE*0x55;    // quad_perm: [s, s, 2+s, 2+s] / [s, s, s, s]
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+    }
+    template <int OFFSET>
+    __device__ __forceinline__ static void pixel_tier(const RenderArgs& a, const VisTables& t, int frame, const VisualizerConsts& c, const float (&acc)[WALK][3], uint32_t (&texel)[WALK],
+                                                      const float4 c2, const Shared& sh, int bx, int by, int row0, int rows, int column) {
+        static_assert(S == 2 || S == 4, "the lanes of a pixel column are a pair or a quad");
+        constexpr int SLOTS = (OFFSET + WALK - 1)/S + 1;              // pixel rows this wave's sample rows fall into
+        constexpr int ROUNDS = (SLOTS + S - 1)/S;
+        const int pixel_column = min((bx*COLS + column)/S, a.w - 1);
+        float4 pc1 = t.pixel_columns[(long)frame*a.w + pixel_column];
+        const int pixel_row0 = by*PIXEL_ROWS + row0/S + (column % S);  // this lane's pixel row of round 0
+        // The waveform strips (:72-73) scale a sample by 0.8 each: a factor of its own per sample, evaluated only by the waves that can see a
+        // strip — the rows of a wave are consecutive, 1 - gluv.y falls and 1 + gluv.y rises with the row, so the wave's last and first rows
+        // decide for all of them
+        const float4 r2_first = sh.row_entries[row0][2], r2_last = sh.row_entries[row0 + (rows > 0 ? rows - 1 : 0)][2];
+        const bool strips = __builtin_amdgcn_ballot_w64((r2_last.y < c2.y) || (r2_first.z < c2.z)) != 0;
+        PixelGains gains[ROUNDS];
+#pragma unroll
+        for (int j = 0; j < ROUNDS; j++) {
+            const int pixel_row = pixel_row0 + S*j;
+            const float4 pr1 = t.pixel_rows[(long)frame*a.h + (pixel_row < a.h ? pixel_row : a.h - 1)];
+            gains[j] = visualizer_pixel_gains(a, t, frame, c, pc1, pr1);
+            // the rounds ONE AFTER THE OTHER: left alone the scheduler interleaves the independent evaluations and their live values no longer
+            // fit the 80 registers — an empty asm makes the next round's first input depend on this round's result (plain asm, not volatile:
+            // see the column lines)
+            asm("" : "+v"(pc1.x) : "v"(gains[j].w));
+        }
+        auto apply = [&](int r, float A, float w) {
+            const float4 r2 = sh.row_entries[row0 + r][2];
+            float scale = (c2.x*r2.x)*A;                              // the vignette's two factors and the pixel's gain
+            if (strips) {
+                if (r2.y < c2.y) scale = scale*0.8f;                  // :72
+                if (r2.z < c2.z) scale = scale*0.8f;                  // :73
+            }
+            const float v0 = fmaf(1.0f, w, acc[r][0])*scale, v1 = fmaf(11.0f, w, acc[r][1])*scale, v2 = fmaf(26.0f, w, acc[r][2])*scale;
+            uint32_t packed = __builtin_amdgcn_cvt_pk_u8_f32(v0, 0u, 0u);
+            packed = __builtin_amdgcn_cvt_pk_u8_f32(v1, 1u, packed);
+            texel[r] = __builtin_amdgcn_cvt_pk_u8_f32(v2, 2u, packed);
+        };
+#pragma unroll
+        for (int r = 0; r < WALK; r++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int p = (OFFSET + r)/S;                             // (constants after unrolling)
+            const PixelGains& g = gains[p/S];
+            switch (p % S) {
+                case 0: apply(r, from_pixel_lane<0>(g.A), from_pixel_lane<0>(g.w)); break;
+                case 1: apply(r, from_pixel_lane<1>(g.A), from_pixel_lane<1>(g.w)); break;
+                case 2: apply(r, from_pixel_lane<2 % S>(g.A), from_pixel_lane<2 % S>(g.w)); break;
+                default: apply(r, from_pixel_lane<3 % S>(g.A), from_pixel_lane<3 % S>(g.w)); break;
+            }
+        }
     }
 
     __device__ static void run(const RenderArgs& a, const VisTables& t) {
@@ -607,17 +795,6 @@ struct VisualizerStrip {
             sh.row_entries[row][quad] = t.rows[((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*VIS_ENTRY_QUADS + quad];
         }
         if (tid == 0) sh.zeros = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (VIS_STRIP_YSTEPS_LDS && tid < RROWS*10) {
-            const int row = tid / 10, w = tid - row*10;
-            const int jr = by*RROWS + row;
-            sh.ysteps[row][w] = t.ysteps[((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*10 + w];
-        }
-        if (VIS_STRIP_YFRAC_LDS && tid >= THREADS - RROWS*10) {     // (the last threads: the first ones fetch the row entries)
-            const int e = tid - (THREADS - RROWS*10), row = e / 10, w = e - row*10;
-            const int jr = by*RROWS + row;
-            const float4 y = t.ysteps[((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*10 + w];
-            sh.yfrac[row][w] = make_float2(y.x, y.y);
-        }
         __syncthreads();
         SF_TICK(a, 0);                                                // prologue: tables, staging the cell tile, the first barrier
 
@@ -643,20 +820,7 @@ struct VisualizerStrip {
                 for (int r = 0; r < WALK; r++) if (r < rows) {
                     const float4 r0 = sh.row_entries[row0 + r][0];
                     const int cell_row = __builtin_amdgcn_readfirstlane(__float_as_int(r0.z));       // the wave's lanes share their rows
-                    if (VIS_STRIP_ADJACENT && cell_row == previous + ROWBYTES) {
-                        // one row of cells up: its base line is this one's top (P' = P + Q); only the y halves of the eight cells are new
-                        previous = cell_row;
-                        const char* line = tile + (__float_as_int(c0.w) + cell_row);
-                        P[0] = P[0] + Q[0]; P[1] = P[1] + Q[1]; P[2] = P[2] + Q[2];
-                        Q[0] = Q[1] = Q[2] = 0.0f;
-#pragma unroll
-                        for (int k = 0; k < VIS_LINE_CELLS; k++) {
-                            float c[3], d[3];
-                            load_cd(line + k*CELL, c, d);
-                            Q[0] = fmaf(n[k], c[0], Q[0]); Q[1] = fmaf(n[k], c[1], Q[1]); Q[2] = fmaf(n[k], c[2], Q[2]);
-                            Q[0] = fmaf(s[k], d[0], Q[0]); Q[1] = fmaf(s[k], d[1], Q[1]); Q[2] = fmaf(s[k], d[2], Q[2]);
-                        }
-                    } else if (cell_row != previous) {
+                    if (cell_row != previous) {
                         previous = cell_row;
                         const char* line = tile + (__float_as_int(c0.w) + cell_row);
                         P[0] = P[1] = P[2] = Q[0] = Q[1] = Q[2] = 0.0f;
@@ -687,7 +851,7 @@ struct VisualizerStrip {
                 const char* column_cells = tile + __float_as_int(c0.z);
                 // (a tile of at most COLW_SLOTS rows of cells cannot hold a longer run: the other loop is then not even compiled, and with it
                 // go the 2 x 27 v_mov that carried the accumulators into and out of the registers the two loops disagreed about)
-                if (VIS_STRIP_COLW_ALIGNED && (TILE_ROWS <= COLW_SLOTS || last - first <= COLW_SLOTS)) {
+                if (TILE_ROWS <= COLW_SLOTS || last - first <= COLW_SLOTS) {
                     // this wave's weights, aligned to the strip's first cell: colw[r][j] = (n, s) of row r for cell first + j, zeros where
                     // the row's eight slots do not reach. Built by the wave itself (LDS operations of one wave execute in order: no barrier)
                     float2* mine = &sh.colw[wave][0][0];
@@ -707,18 +871,10 @@ struct VisualizerStrip {
                     const char* cell_k = column_cells + first*ROWBYTES;
                     float U0 = 0.0f, U1 = 0.0f, U2 = 0.0f, V0 = 0.0f, V1 = 0.0f, V2 = 0.0f;
                     for (int k = first; k < last; k++) {
-                        if (VIS_STRIP_ADJACENT && k > first) {
-                            // the cell above: its base is this cell's top (U' = U + V), only the y half is fetched
-                            float c[3], d[3];
-                            load_cd(cell_k, c, d);
-                            U0 = U0 + V0; U1 = U1 + V1; U2 = U2 + V2;
-                            V0 = fmaf(fx, d[0], c[0]); V1 = fmaf(fx, d[1], c[1]); V2 = fmaf(fx, d[2], c[2]);
-                        } else {
-                            Quad q0, q1, q2;
-                            load_cell(cell_k, q0, q1, q2);
-                            U0 = fmaf(fx, F(q0.w), F(q0.x)); U1 = fmaf(fx, F(q1.x), F(q0.y)); U2 = fmaf(fx, F(q1.y), F(q0.z));
-                            V0 = fmaf(fx, F(q2.y), F(q1.z)); V1 = fmaf(fx, F(q2.z), F(q1.w)); V2 = fmaf(fx, F(q2.w), F(q2.x));
-                        }
+                        Quad q0, q1, q2;
+                        load_cell(cell_k, q0, q1, q2);
+                        U0 = fmaf(fx, F(q0.w), F(q0.x)); U1 = fmaf(fx, F(q1.x), F(q0.y)); U2 = fmaf(fx, F(q1.y), F(q0.z));
+                        V0 = fmaf(fx, F(q2.y), F(q1.z)); V1 = fmaf(fx, F(q2.z), F(q1.w)); V2 = fmaf(fx, F(q2.w), F(q2.x));
 #pragma unroll
                         for (int r = 0; r < WALK; r++) {
                             const float2 w = *(const float2*)(weights_k + r*COLW_SLOTS*8);
@@ -729,35 +885,25 @@ struct VisualizerStrip {
                     }
                 } else
                 for (int k = first; k < last; k++) {
+                    // a run of cells longer than the aligned table (tiles taller than COLW_SLOTS rows only): the weights of all rows of a cell
+                    // at once, zeros for rows whose slots do not cover it
                     Quad q0, q1, q2;
                     load_cell(column_cells + k*ROWBYTES, q0, q1, q2);
                     const float U0 = fmaf(fx, F(q0.w), F(q0.x)), U1 = fmaf(fx, F(q1.x), F(q0.y)), U2 = fmaf(fx, F(q1.y), F(q0.z));
                     const float V0 = fmaf(fx, F(q2.y), F(q1.z)), V1 = fmaf(fx, F(q2.z), F(q1.w)), V2 = fmaf(fx, F(q2.w), F(q2.x));
-                    if (VIS_STRIP_COLUMN_BRANCHFREE) {
-                        float2 weights[WALK];
-#pragma unroll
-                        for (int r = 0; r < WALK; r++) {
-                            const int slot = k - start[r];
-                            const bool covered = r < rows && slot >= 0 && slot < VIS_LINE_CELLS;
-                            const char* source = covered ? (const char*)sh.row_entries[row0 + r] + 48 + slot*8 : (const char*)&sh.zeros;
-                            weights[r] = *(const float2*)source;
-                        }
-#pragma unroll
-                        for (int r = 0; r < WALK; r++) {
-                            const float2 w = weights[r];
-                            acc[r][0] = fmaf(w.x, U0, acc[r][0]); acc[r][1] = fmaf(w.x, U1, acc[r][1]); acc[r][2] = fmaf(w.x, U2, acc[r][2]);
-                            acc[r][0] = fmaf(w.y, V0, acc[r][0]); acc[r][1] = fmaf(w.y, V1, acc[r][1]); acc[r][2] = fmaf(w.y, V2, acc[r][2]);
-                        }
-                        continue;
-                    }
+                    float2 weights[WALK];
 #pragma unroll
                     for (int r = 0; r < WALK; r++) {
                         const int slot = k - start[r];
-                        if (r < rows && slot >= 0 && slot < VIS_LINE_CELLS) {
-                            const float2 w = *(const float2*)((const char*)sh.row_entries[row0 + r] + 48 + slot*8);   // (n, s) of this cell
-                            acc[r][0] = fmaf(w.x, U0, acc[r][0]); acc[r][1] = fmaf(w.x, U1, acc[r][1]); acc[r][2] = fmaf(w.x, U2, acc[r][2]);
-                            acc[r][0] = fmaf(w.y, V0, acc[r][0]); acc[r][1] = fmaf(w.y, V1, acc[r][1]); acc[r][2] = fmaf(w.y, V2, acc[r][2]);
-                        }
+                        const bool covered = r < rows && slot >= 0 && slot < VIS_LINE_CELLS;
+                        const char* source = covered ? (const char*)sh.row_entries[row0 + r] + 48 + slot*8 : (const char*)&sh.zeros;
+                        weights[r] = *(const float2*)source;
+                    }
+#pragma unroll
+                    for (int r = 0; r < WALK; r++) {
+                        const float2 w = weights[r];
+                        acc[r][0] = fmaf(w.x, U0, acc[r][0]); acc[r][1] = fmaf(w.x, U1, acc[r][1]); acc[r][2] = fmaf(w.x, U2, acc[r][2]);
+                        acc[r][0] = fmaf(w.y, V0, acc[r][0]); acc[r][1] = fmaf(w.y, V1, acc[r][1]); acc[r][2] = fmaf(w.y, V2, acc[r][2]);
                     }
                 }
             }
@@ -774,84 +920,22 @@ struct VisualizerStrip {
                     ysteps[r] = t.ysteps + ((long)frame*a.hr + (jr < a.hr ? jr : a.hr - 1))*10;
                 }
                 float xp = xr + first, xm = xr - first;
-                // the fractions of this wave's rows at walk step w: ONE vector register holds the address, the rows are immediate offsets
-                int yfrac_w = 0;                                      // byte offset of walk step w inside this wave's rows of sh.yfrac, in a VECTOR register
-                if (VIS_STRIP_YFRAC_LDS) asm("v_mov_b32 %0, 0" : "=v"(yfrac_w));
-#ifndef VIS_STRIP_SWEEP_STORE
-#define VIS_STRIP_SWEEP_STORE 1        // 0: wave 0 stores the block's rows one after the other while seven waves hold the block's LDS and registers (-6 %)
-#endif
-#ifndef VIS_STRIP_DIAG_UNROLL
-#define VIS_STRIP_DIAG_UNROLL 1
-#endif
-                float acc_blue[WALK];
-#pragma unroll
-                for (int r = 0; r < WALK; r++) acc_blue[r] = 0.0f;
-#pragma unroll VIS_STRIP_DIAG_UNROLL
+#pragma unroll 1
                 for (int w = 0; w < 10; w++) {
                     const float axp = __builtin_amdgcn_fractf(xp), axm = __builtin_amdgcn_fractf(xm);
                     const int cxp = (int)((xp - axp)*(float)CELL), cxm = (int)((xm - axm)*(float)CELL);
                     float4 y[WALK];
 #pragma unroll
-                    for (int r = 0; r < WALK; r++) y[r] = VIS_STRIP_YSTEPS_LDS ? sh.ysteps[row0 + r][w] : ysteps[r][w];   // { frac(y+), frac(y-), row bytes(y+), row bytes(y-) }
-#ifndef VIS_STRIP_YSTEPS_TOGETHER
-#define VIS_STRIP_YSTEPS_TOGETHER 0                                    // 1: every row's scalar load of a walk step is issued before the step's first fold (left alone the compiler sinks each load to its row: s_load, s_waitcnt 0, s_cmp); measured: 3 200 against 3 210 frames/s — the other waves hide that latency already
-#endif
-                    if (VIS_STRIP_YSTEPS_TOGETHER && !VIS_STRIP_YSTEPS_LDS) {
-                        static_assert(WALK <= 10, "the operand list below names ten rows");
-                        // one scalar move whose INPUTS are all the rows' entries: nothing of the step can start before every load is out
-                        // (plain asm, not volatile: see the column lines — a side-effecting asm turns the table loads into vector loads)
-#define SF_YZ(k) "s"(__float_as_int(y[(k) < WALK ? (k) : WALK - 1].z))
-                        int first_bytes;
-                        asm("s_mov_b32 %0, %1" : "=s"(first_bytes) : SF_YZ(0), SF_YZ(1), SF_YZ(2), SF_YZ(3), SF_YZ(4), SF_YZ(5), SF_YZ(6), SF_YZ(7), SF_YZ(8), SF_YZ(9));
-#undef SF_YZ
-                        y[0].z = __int_as_float(first_bytes);
-                    }
-#ifndef VIS_STRIP_YFRAC_VMEM
-#define VIS_STRIP_YFRAC_VMEM 0                                         // 1: the two fractions of a row's entry ALSO through a vector load (the same address in every lane: one L1 line), so they arrive in vector registers — the scalar copy costs a v_mov per use (VALU forms with an SGPR source issue at half rate); needs 18 more VGPRs: a 6-wave build
-#endif
-                    float2 yf[WALK];
-                    if (VIS_STRIP_YFRAC_VMEM) {
-                        int vzero;
-                        asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));          // an offset the compiler cannot prove uniform: keeps the load on the vector memory path
-#pragma unroll
-                        for (int r = 0; r < WALK; r++) yf[r] = *(const float2*)((const char*)&ysteps[r][w] + vzero);
-                    }
-#ifndef VIS_STRIP_FIRST_ROW_FOLDS
-#define VIS_STRIP_FIRST_ROW_FOLDS 1                                    // 1: a walk step's first row folds without asking (it always does: `previous` starts at no row) — the compiler then drops the thirteen v_mov 0 that initialised U and V for the path nobody takes (14 of 554 instructions per supersample)
-#endif
-#ifndef VIS_STRIP_PK_BLUE
-#define VIS_STRIP_PK_BLUE 0                                            // 1 (with PK_SIDES): blue's two sides as one packed pair into a split accumulator (nine more registers over the walk)
-#endif
-#ifndef VIS_STRIP_PK_SIDES
-#define VIS_STRIP_PK_SIDES 1                                           // 1: red and green of a row advance together as v_pk_add_f32 / v_pk_fma_f32 with the row's SCALAR fractions broadcast by op_sel (tools/ubench_pk_f32.hip: a scalar pair costs a packed form nothing, a v_mov v, s 4.2 cycles); blue keeps scalar-source fmas. Needs VIS_STRIP_SIDES_TOGETHER, no YFRAC_* / SUM_SIDES
-#endif
-#ifndef VIS_STRIP_SUM_SIDES
-#define VIS_STRIP_SUM_SIDES 0                                          // 1: U(y+) + U(y-) summed when a side folds and added to a row once (three adds per row and step less, three more per fold; another order of the same sum). Needs VIS_STRIP_SIDES_TOGETHER
-#endif
-#ifndef VIS_STRIP_SIDES_TOGETHER
-#define VIS_STRIP_SIDES_TOGETHER 1                                     // 1: both y sides of a walk step advance row by row together (their first cells are fetched at once)
-#endif
+                    for (int r = 0; r < WALK; r++) y[r] = ysteps[r][w];   // { frac(y+), frac(y-), row bytes(y+), row bytes(y-) }
                     float U[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}}, V[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
                     int previous[2] = {-2*ROWBYTES, -2*ROWBYTES};     // (no row of cells: neither equal nor adjacent to a real one)
-                    float UU[3] = {0.0f, 0.0f, 0.0f};
-                    auto advance = [&](int r, int side, float ay_lds, bool folded_other = false) -> bool {
-                        bool folded = false;
-                        const int cell_row = VIS_STRIP_YSTEPS_LDS ? __builtin_amdgcn_readfirstlane(__float_as_int(side ? y[r].w : y[r].z)) : __float_as_int(side ? y[r].w : y[r].z);
-                        if (VIS_STRIP_ADJACENT && cell_row == previous[side] + ROWBYTES) {
-                            // one row of cells up: U' = U + V, V' from the y halves of the two cells
+                    // both y sides of a walk step advance row by row together (their first cells are fetched at once)
+                    auto advance = [&](int r, int side) {
+                        const int cell_row = __float_as_int(side ? y[r].w : y[r].z);
+                        // (a walk step's first row folds without asking — it always does: `previous` starts at no row — so that the compiler drops
+                        // the thirteen v_mov 0 that initialised U and V for the path nobody takes)
+                        if (r == 0 || cell_row != previous[side]) {
                             previous[side] = cell_row;
-                            SF_COUNT_FOLD();
-                            float* u = U[side]; float* v = V[side];
-                            float cp[3], dp[3], cm[3], dm[3];
-                            load_cd(tile + (cxp + cell_row), cp, dp);
-                            load_cd(tile + (cxm + cell_row), cm, dm);
-                            u[0] = u[0] + v[0]; u[1] = u[1] + v[1]; u[2] = u[2] + v[2];
-                            v[0] = cp[0] + cm[0]; v[1] = cp[1] + cm[1]; v[2] = cp[2] + cm[2];
-                            v[0] = fmaf(axp, dp[0], v[0]); v[1] = fmaf(axp, dp[1], v[1]); v[2] = fmaf(axp, dp[2], v[2]);
-                            v[0] = fmaf(axm, dm[0], v[0]); v[1] = fmaf(axm, dm[1], v[1]); v[2] = fmaf(axm, dm[2], v[2]);
-                        } else if ((VIS_STRIP_FIRST_ROW_FOLDS && r == 0) || cell_row != previous[side]) {
-                            previous[side] = cell_row;
-                            folded = true;
                             SF_COUNT_FOLD();
                             Quad p0, p1, p2, m0, m1, m2;
                             load_cell(tile + (cxp + cell_row), p0, p1, p2);
@@ -872,68 +956,23 @@ struct VisualizerStrip {
                             v[0] = fmaf(axp, F(p2.y), v[0]);  v[1] = fmaf(axp, F(p2.z), v[1]);  v[2] = fmaf(axp, F(p2.w), v[2]);
                             v[0] = fmaf(axm, F(m2.y), v[0]);  v[1] = fmaf(axm, F(m2.z), v[1]);  v[2] = fmaf(axm, F(m2.w), v[2]);
                         }
-                        float ay;
-                        if (VIS_STRIP_YFRAC_LDS) ay = ay_lds;
-                        else ay = VIS_STRIP_YFRAC_VMEM ? (side ? yf[r].y : yf[r].x) : (VIS_STRIP_YSTEPS_LDS ? (side ? y[r].y : y[r].x) : in_vgpr(side ? y[r].y : y[r].x));
-                        if (VIS_STRIP_PK_SIDES) {
-                            typedef float pk2 __attribute__((ext_vector_type(2)));
-                            pk2 a01 = {acc[r][0], acc[r][1]};
-                            const pk2 u01 = {U[side][0], U[side][1]}, v01 = {V[side][0], V[side][1]};
-                            const pk2 fractions = {y[r].x, y[r].y};               // a scalar pair: { frac(y+), frac(y-) }
-                            asm("v_pk_add_f32 %0, %0, %1" : "+v"(a01) : "v"(u01));
-                            if (side == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a01) : "s"(fractions), "v"(v01));
-                            else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a01) : "s"(fractions), "v"(v01));
-                            acc[r][0] = a01.x; acc[r][1] = a01.y;
-                            if (VIS_STRIP_PK_BLUE) {
-                                // blue of both sides at once, side 1's share into a second accumulator (added after the walk)
-                                if (side == 1) {
-                                    pk2 ab = {acc[r][2], acc_blue[r]};
-                                    const pk2 ub = {U[0][2], U[1][2]}, vb = {V[0][2], V[1][2]};
-                                    asm("v_pk_add_f32 %0, %0, %1" : "+v"(ab) : "v"(ub));
-                                    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(ab) : "s"(fractions), "v"(vb));
-                                    acc[r][2] = ab.x; acc_blue[r] = ab.y;
-                                }
-                                return folded;
-                            }
-                            acc[r][2] = acc[r][2] + U[side][2];
-                            acc[r][2] = fmaf(side ? y[r].y : y[r].x, V[side][2], acc[r][2]);
-                            return folded;
-                        }
-                        if (VIS_STRIP_SUM_SIDES) {
-                            // the two sides' U enter a row as ONE sum, renewed when a side folds (side 1 runs second: it adds the sum)
-                            if (side == 1) {
-                                if (folded || folded_other) { UU[0] = U[0][0] + U[1][0]; UU[1] = U[0][1] + U[1][1]; UU[2] = U[0][2] + U[1][2]; }
-                                acc[r][0] = acc[r][0] + UU[0];        acc[r][1] = acc[r][1] + UU[1];                acc[r][2] = acc[r][2] + UU[2];
-                            }
-                        } else {
-                            acc[r][0] = acc[r][0] + U[side][0];       acc[r][1] = acc[r][1] + U[side][1];           acc[r][2] = acc[r][2] + U[side][2];
-                        }
-                        acc[r][0] = fmaf(ay, V[side][0], acc[r][0]);  acc[r][1] = fmaf(ay, V[side][1], acc[r][1]);  acc[r][2] = fmaf(ay, V[side][2], acc[r][2]);
-                        return folded;
+                        // red and green of a row advance together as v_pk_add_f32 / v_pk_fma_f32 with the row's SCALAR fractions broadcast by
+                        // op_sel (tools/ubench_pk_f32.hip: a scalar pair costs a packed form nothing, a v_mov v, s 4.2 cycles); blue keeps
+                        // scalar-source fmas
+                        typedef float pk2 __attribute__((ext_vector_type(2)));
+                        pk2 a01 = {acc[r][0], acc[r][1]};
+                        const pk2 u01 = {U[side][0], U[side][1]}, v01 = {V[side][0], V[side][1]};
+                        const pk2 fractions = {y[r].x, y[r].y};               // a scalar pair: { frac(y+), frac(y-) }
+                        asm("v_pk_add_f32 %0, %0, %1" : "+v"(a01) : "v"(u01));
+                        if (side == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a01) : "s"(fractions), "v"(v01));
+                        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a01) : "s"(fractions), "v"(v01));
+                        acc[r][0] = a01.x; acc[r][1] = a01.y;
+                        acc[r][2] = acc[r][2] + U[side][2];
+                        acc[r][2] = fmaf(side ? y[r].y : y[r].x, V[side][2], acc[r][2]);
                     };
-                    if (VIS_STRIP_YFRAC_LDS) {
-                        // both fractions of a row in one ds_read_b64 (address = one vector register + the row's immediate offset)
 #pragma unroll
-                        for (int r = 0; r < WALK; r++) if (r < rows) {
-                            const float2 mine = *(const float2*)((const char*)&sh.yfrac[row0 + r][0] + yfrac_w);
-                            advance(r, 0, mine.x); advance(r, 1, mine.y);
-                        }
-                    } else if (VIS_STRIP_SIDES_TOGETHER) {
-#pragma unroll
-                        for (int r = 0; r < WALK; r++) if (r < rows) { const bool first = advance(r, 0, 0.0f); advance(r, 1, 0.0f, first); }
-                    } else {
-#pragma unroll
-                        for (int side = 0; side < 2; side++) {
-#pragma unroll
-                            for (int r = 0; r < WALK; r++) if (r < rows) advance(r, side, 0.0f);
-                        }
-                    }
+                    for (int r = 0; r < WALK; r++) if (r < rows) { advance(r, 0); advance(r, 1); }
                     xp = xp + step; xm = xm - step;
-                    if (VIS_STRIP_YFRAC_LDS) yfrac_w += 8;
-                }
-                if (VIS_STRIP_PK_SIDES && VIS_STRIP_PK_BLUE) {
-#pragma unroll
-                    for (int r = 0; r < WALK; r++) acc[r][2] = acc[r][2] + acc_blue[r];
                 }
             }
         }
@@ -942,11 +981,31 @@ struct VisualizerStrip {
         // ---- visualizer.frag:36-73 per sample, then the texels meet in LDS ----
         uint32_t texel[WALK];
         {
-            const float4 c1 = ce[1], c2 = ce[2];
+            const float4 c2 = ce[2];
+            bool per_sample = true;
+            if constexpr (S >= 2) {
+                // the pixel tier for the waves whose tile k_visualizer_classify cleared — unless a lane's column lies outside the wanted aspect (:11-14)
+                if (t.pixel_columns && t.wave_classes[((long)frame*gridDim.x + tile_index)*8 + wave] != 0 && __builtin_amdgcn_ballot_w64(__float_as_int(c2.w) != 0) == 0) {
+                    // which output pixel a sample row belongs to depends on the wave's first row modulo S — a constant per instance of the tier,
+                    // so that every index below is one
+                    if constexpr ((WALK % S) == 0) pixel_tier<0>(a, t, frame, c, acc, texel, c2, sh, bx, by, row0, rows, column);
+                    else {
+                        const int offset = row0 % S;
+                        if (offset == 0) pixel_tier<0>(a, t, frame, c, acc, texel, c2, sh, bx, by, row0, rows, column);
+                        else if (offset == 1) pixel_tier<1 % S>(a, t, frame, c, acc, texel, c2, sh, bx, by, row0, rows, column);
+                        else if (offset == 2) pixel_tier<2 % S>(a, t, frame, c, acc, texel, c2, sh, bx, by, row0, rows, column);
+                        else pixel_tier<3 % S>(a, t, frame, c, acc, texel, c2, sh, bx, by, row0, rows, column);
+                    }
+                    per_sample = false;
+                } else if (a.tile_misses && (threadIdx.x & 63) == 0) atomicAdd(a.tile_misses, 1u);      // (diagnostics: sfx_ctx_tile_misses counts the WAVES that evaluate per sample)
+            }
+            if (per_sample) {
+                const float4 c1 = ce[1];
 #pragma unroll
-            for (int r = 0; r < WALK; r++) {
-                texel[r] = 0;
-                if (r < rows) texel[r] = visualizer_fast_post<S == 1>(a, frame, c, acc[r][0], acc[r][1], acc[r][2], c1, c2, sh.row_entries[row0 + r][1], sh.row_entries[row0 + r][2]);
+                for (int r = 0; r < WALK; r++) {
+                    texel[r] = 0;
+                    if (r < rows) texel[r] = visualizer_fast_post<S == 1>(a, frame, c, acc[r][0], acc[r][1], acc[r][2], c1, c2, sh.row_entries[row0 + r][1], sh.row_entries[row0 + r][2]);
+                }
             }
         }
         if constexpr (S == 1) {
@@ -984,7 +1043,6 @@ struct VisualizerStrip {
         SF_TICK(a, 5);                                                // barrier + texel exchange + resolve + barrier
         SF_FOLDS_OUT(a);
         uint8_t* out = (uint8_t*)a.out + (long)frame*a.out_frame_stride;
-#if VIS_STRIP_SWEEP_STORE
         // a full-width block of a frame whose rows are whole 16-byte groups: all rows leave in ONE sweep of 16-byte stores by as many
         // threads as there are groups (216 at 2x) — the block ends a store latency after its resolve instead of nine
         constexpr int GROUPS = BLOCK_PX*3/16;
@@ -1002,7 +1060,6 @@ struct VisualizerStrip {
             SF_TICK(a, 6);                                            // the sweep of stores
             return;
         }
-#endif
 #pragma unroll
         for (int r = 0; r < PIXEL_ROWS; r++) {
             const int py = by*PIXEL_ROWS + r;
