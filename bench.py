@@ -191,10 +191,17 @@ LIVE_PASSES = (("SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32
                ("SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"))
 
 
-def live_counters(args, kernel: str) -> dict | None:
-    """The instruction counters of `kernel` measured IN THIS RUN: one short child of this script per pass under `rocprofv3 --kernel-trace
-    --pmc` (counters in runs of their own, the program itself after `--`), this run's frames per launch. The same structure as
-    profile_counters(); None — with the reason on stderr — when the profiler is not there or a pass fails (the tracked profile stands)."""
+def clean_kernel_name(raw: str) -> str:
+    return raw.replace("sf::", "").replace("void ", "").split("(")[0].strip()
+
+
+def live_counters(args, kernel: str | None) -> dict | None:
+    """The instruction counters of this configuration's DOMINANT kernel measured IN THIS RUN: one short child of this script per pass under
+    `rocprofv3 --kernel-trace --pmc` (counters in runs of their own, the program itself after `--`), this run's frames per launch. The
+    dominant kernel is the one the trace gives the most GPU time (C2's last launch is the resolve, its dominant kernel the strip kernel:
+    `kernel`, the library's last launch, only breaks ties and names the kernel when the trace is empty). The same structure as
+    profile_counters() plus `kernel` and `share` (its part of the traced GPU time); None — with the reason on stderr — when the profiler
+    is not there or a pass fails (the tracked profile stands)."""
     import csv
     import shutil
     import subprocess
@@ -203,15 +210,15 @@ def live_counters(args, kernel: str) -> dict | None:
         print("bench.py: no rocprofv3 on PATH: the roofline's counters come from the tracked profile", file=sys.stderr)
         return None
     frames = args.frames_per_step
-    counters: dict = {}
-    durations: list = []
+    per_kernel: dict = {}                                           # kernel -> counter -> values
+    durations: dict = {}                                            # kernel -> durations (ns) of the GRBM pass' trace
     with tempfile.TemporaryDirectory(prefix="shaderflow_bench_pmc_", dir="/tmp") as scratch:
         for index, names in enumerate(LIVE_PASSES):
             out = Path(scratch)/f"pass{index}"
             command = ["rocprofv3", "--kernel-trace", "--pmc", *names, "-f", "csv", "-d", str(out), "-o", "pmc", "--",
                        sys.executable, str(Path(__file__).resolve()), "--steps", "1", "--warmup", "1", "--frames-per-step", str(frames),
-                       "--width", str(args.width), "--height", str(args.height), "--ssaa", str(args.ssaa),
-                       "--no-cpu-baseline", "--no-export", "--no-live-counters"]
+                       "--width", str(args.width), "--height", str(args.height), "--ssaa", str(args.ssaa), "--scene", args.scene,
+                       "--camera-zoom", str(args.camera_zoom), "--no-cpu-baseline", "--no-export", "--no-live-counters"]
             try:                                                     # (a session of its own: a pass that overruns is ended with its whole process group)
                 child = subprocess.Popen(command, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, TMPDIR="/tmp"),
                                          cwd=str(ROOT), start_new_session=True)
@@ -226,26 +233,34 @@ def live_counters(args, kernel: str) -> dict | None:
                 child.communicate()
                 print(f"bench.py: counter pass {index} took more than 90 s and was ended: the tracked profile stands", file=sys.stderr)
                 return None
-            done = subprocess.CompletedProcess(command, child.returncode, "", errors)
-            found: dict = {}
+            found = 0
             for table in out.glob("**/*counter_collection.csv"):
                 with open(table) as handle:
                     for row in csv.DictReader(handle):
-                        name = row["Kernel_Name"].replace("sf::", "").replace("void ", "").split("(")[0]
-                        if name.replace(" ", "") == kernel.replace(" ", ""):
-                            found.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-            if done.returncode != 0 or not found:
-                print(f"bench.py: counter pass {index} gave nothing for '{kernel}' (rc {done.returncode}): the tracked profile stands\n{done.stderr[-400:]}", file=sys.stderr)
+                        per_kernel.setdefault(clean_kernel_name(row["Kernel_Name"]), {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                        found += 1
+            if child.returncode != 0 or not found:
+                print(f"bench.py: counter pass {index} gave nothing (rc {child.returncode}): the tracked profile stands\n{errors[-400:]}", file=sys.stderr)
                 return None
-            counters.update({name: sum(values)/len(values) for name, values in found.items()})
             if "GRBM_GUI_ACTIVE" in names:                          # the pass GRBM_GUI_ACTIVE came from: its own durations give the clock
                 for table in out.glob("**/*kernel_trace.csv"):
                     with open(table) as handle:
                         for row in csv.DictReader(handle):
-                            name = row["Kernel_Name"].replace("sf::", "").replace("void ", "").split("(")[0]
-                            if name.replace(" ", "") == kernel.replace(" ", ""):
-                                durations.append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
-    return {"counters": counters, "duration": {"average_ns": sum(durations)/len(durations)} if durations else None, "frames_per_launch": frames}
+                            durations.setdefault(clean_kernel_name(row["Kernel_Name"]), []).append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    squeezed = {name.replace(" ", ""): name for name in per_kernel}
+    # the render kernels of this library only (torch's fills, RCCL's and the audio tape's kernels are not the roofline's subject)
+    candidates = {name: sum(values) for name, values in durations.items() if name.startswith("k_") and not name.startswith(("k_stft", "k_dft", "k_filterbank", "k_dynamics", "k_waveform", "k_volume", "k_spectrogram"))}
+    total = sum(candidates.values())
+    dominant = max(candidates, key=candidates.get) if candidates else kernel
+    if dominant is None or dominant.replace(" ", "") not in squeezed:
+        print(f"bench.py: the counter passes hold nothing for '{dominant}': the tracked profile stands", file=sys.stderr)
+        return None
+    counters = {name: sum(values)/len(values) for name, values in per_kernel[squeezed[dominant.replace(" ", "")]].items()}
+    spans = durations.get(dominant) or []
+    # launches of the dominant kernel per traced step: the counters are per LAUNCH, a step of this run may take several (none today)
+    return {"kernel": dominant, "counters": counters, "duration": {"average_ns": sum(spans)/len(spans)} if spans else None, "frames_per_launch": frames,
+            "share": round(candidates[dominant]/total, 4) if total and dominant in candidates else None,
+            "others": {name: round(value/total, 4) for name, value in sorted(candidates.items(), key=lambda item: -item[1])[1:4]} if total else None}
 
 
 # SIMD cycles a wave64 VALU instruction of each class occupies, as measured on this chip (tools/ubench_valu.hip,
@@ -255,7 +270,7 @@ CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2, "SQ_INSTS_VALU_MUL_F32": 2, "SQ_INST
                 "SQ_INSTS_VALU_TRANS_F32": 8, "SQ_INSTS_VALU_ADD_F16": 4, "SQ_INSTS_VALU_FMA_F16": 4}
 
 
-CENSUS = ROOT/"profiles"/"r05_strip_isa_census.json"      # tools/strip_census.py --json: what the uncounted VALU instructions ARE
+CENSUS = ROOT/"profiles"/"r06_strip_isa_census.json"      # tools/strip_census.py --json: what the uncounted VALU instructions ARE
 
 
 def census_prices(kernel: str) -> dict | None:
@@ -270,7 +285,7 @@ def census_prices(kernel: str) -> dict | None:
         return None
     digest = hashlib.sha256()
     csrc = ROOT/"shaderflow_amd"/"csrc"
-    for name in ("visualizer_fast.hpp", "visualizer_kernels.hpp", "render_kernels.hpp", "fragments.hpp", "glsl.hpp", "sfmath.hpp", "Makefile"):
+    for name in ("visualizer_fast.hpp", "visualizer_kernels.hpp", "render_kernels.hpp", "fragments.hpp", "glsl.hpp", "sfmath.hpp", "launch_visualizer_strip.hip", "Makefile"):
         digest.update(name.encode()); digest.update((csrc/name).read_bytes())
     if digest.hexdigest()[:16] != census.get("strip_sources_fingerprint"):
         print(f"bench.py: {CENSUS.name} was counted on other kernel sources: issue_model keeps its 2-or-4 band; re-run tools/strip_census.py", file=sys.stderr)
@@ -739,10 +754,16 @@ def main() -> None:
         counters = profile_counters(kernel) if c3 else None
         counters_from = str(PROFILE.relative_to(ROOT)) if counters else None
         profiled = any(key.startswith(("ROCPROF", "ROCP_")) for key in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")   # this run IS a profiler's child
-        if c3 and world == 1 and not distributed and not profiled and not args.no_live_counters:
-            # the driver's run measures its own counters; the tracked profile fills in what a pass did not give
+        dominant_share = other_kernels = None
+        if world == 1 and not distributed and not profiled and not args.no_live_counters:
+            # EVERY configuration's run measures its own counters (round 5, missing 3): the dominant kernel by traced
+            # GPU time; the tracked profile fills in what a pass did not give (C3 only: it is the profile of C3's kernel)
             live = live_counters(args, kernel)
             if live:
+                if live["kernel"].replace(" ", "") != kernel.replace(" ", ""):
+                    counters = None                                 # (the tracked profile names the library's last launch)
+                kernel = live["kernel"]
+                dominant_share, other_kernels = live["share"], live["others"]
                 tracked = counters if (counters and counters.get("frames_per_launch") == live["frames_per_launch"]) else None   # per-launch counters of another launch size do not mix
                 merged = dict(tracked["counters"]) if tracked else {}
                 merged.update(live["counters"])
@@ -777,7 +798,7 @@ def main() -> None:
                        "ranks": world, "filterbank": "mfma" if tape.use_mfma else "csr"},
             "rccl_ranks": ranks_seen,
             "realtime_factor": round(value/60.0, 2),
-            "roofline": {"bound": "valu", "kernel": kernel,
+            "roofline": {"bound": "valu", "kernel": kernel, "kernel_share_of_gpu_time": dominant_share, "other_kernels": other_kernels,
                          "achieved": round(lane_ops/1e12, 2) if lane_ops else None, "peak": round(VALU_PEAK_LANE_OPS/1e12, 1), "unit": "T lane-instr/s",
                          "frac": round(lane_ops/VALU_PEAK_LANE_OPS, 4) if lane_ops else None,
                          "valu_instructions_per_supersample": round(per_sample, 1) if per_sample else None,
@@ -800,8 +821,11 @@ def main() -> None:
             # per frame, the only bytes a fused kernel has to move (last column) — not the two-pass data-flow
             fused_bytes = float(w*h*3)*piece
             written = fused_bytes/launch_s/1e9
-            result["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": round(written, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(written/HBM_PEAK_GBS, 4), "traffic": None,
+            result["roofline"] = {"bound": "hbm", "kernel": kernel, "kernel_share_of_gpu_time": dominant_share, "other_kernels": other_kernels,
+                                  "achieved": round(written, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(written/HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_over_algorithmic": round(traffic/fused_bytes, 3) if traffic else None,
+                                  "valu_instructions_per_supersample": round(per_sample, 1) if per_sample else None, "lds_busy": round(lds_busy, 3) if lds_busy else None,
+                                  "issue_cycles_frac": issue["frac"] if issue else None, "issue_model": issue, "counters_from": counters_from,
                                   "algorithmic_bytes_per_launch": fused_bytes, "launch_ms": round(launch_s*1e3, 4), "frames_per_launch": piece,
                                   "two_pass_accounting": {"achieved": round(hbm_achieved, 1), "frac": round(hbm_achieved/HBM_PEAK_GBS, 4),
                                                           "note": "the reference's iScreen write + read + iFinal write + read-out; a fused kernel never moves iScreen, so this can exceed 1"},

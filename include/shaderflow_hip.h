@@ -274,6 +274,11 @@ int sfx_stft_plan_destroy(sfx_handle plan);
  * tell[k] = samples read when frame k is produced. */
 int sfx_stft_power(sfx_handle plan, sfx_handle audio, const int64_t* tell, int nframes,
                    float* power /* [nframes][channels][fft_bins] */);
+/* np.fft.rfft(window*frame) itself, float64 (re, im) pairs: spectrum[frame][channel][fft_bins][2] — for a `magnitude` callable of the
+ * user's own (reference: shaderflow/audio/spectrogram.py:20-41 accepts any callable on the complex spectrum, :169-171 applies it); the host
+ * applies the callable and hands its float32 result [frame][channel][fft_bins] to sfx_filterbank_apply (= :175-176 on given magnitudes). */
+int sfx_stft_spectrum(sfx_handle plan, sfx_handle audio, const int64_t* tell, int nframes, double* spectrum);
+int sfx_filterbank_apply(sfx_handle plan, const float* magnitudes, int nframes, int use_mfma, float* out /* [nframes][bins][channels] */);
 /* M.dot(fft().T): out[frame][bin][channel] — the (bins, 2) buffer of spectrogram.py:176,306.
  * use_mfma = 1: dense banded GEMM on v_mfma_f32_32x32x2_f32; 0: CSR rows in scipy's order (bit-exact). */
 int sfx_spectrogram_targets(sfx_handle plan, sfx_handle audio, const int64_t* tell, int nframes,

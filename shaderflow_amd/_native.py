@@ -156,6 +156,8 @@ PROTOTYPES: dict[str, tuple] = {
     "sfx_stft_plan_window": (C.c_int, [Handle, P(C.c_double), C.c_int]),
     "sfx_stft_plan_destroy": (C.c_int, [Handle]),
     "sfx_stft_power": (C.c_int, [Handle, Handle, P(C.c_int64), C.c_int, P(C.c_float)]),
+    "sfx_stft_spectrum": (C.c_int, [Handle, Handle, P(C.c_int64), C.c_int, P(C.c_double)]),
+    "sfx_filterbank_apply": (C.c_int, [Handle, P(C.c_float), C.c_int, C.c_int, P(C.c_float)]),
     "sfx_spectrogram_targets": (C.c_int, [Handle, Handle, P(C.c_int64), C.c_int, C.c_int, P(C.c_float)]),
     "sfx_waveform_rows": (C.c_int, [Handle, P(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]),
     "sfx_volume_std": (C.c_int, [Handle, P(C.c_int64), C.c_int, C.c_int, P(C.c_float)]),

@@ -6,7 +6,8 @@ SpectrogramWindow) and the filterbank construction (`spectrogram_frequencies`, `
 stay numpy/scipy code — they run once per configuration and define WHAT is computed. Device side: the per-frame
 STFT (`window*frame → radix-2 FFT in float64 → |X|² → float32`, :155-171) and the filterbank product
 (:175-176) are HIP kernels reached through an `sfx_stft_plan`. Options the kernels implement: the three windows,
-`FourierMagnitude.Power` and `.Amplitude`, any scale/interpolation (they only shape the CSR matrix). `sample_rateio != 1`
+`FourierMagnitude.Power` and `.Amplitude` (any other `magnitude` callable runs on the host between the device's FFT and filterbank:
+`device_magnitude`), any scale/interpolation (they only shape the CSR matrix). `sample_rateio != 1`
 (:158-167 resamples with the third-party `samplerate` package's 'linear' converter — un-vendored, not importable here): the converter's
 read positions depend on the sizes and the ratio alone, so its float64 position loop runs here once per plan (`linear_resample_taps`)
 and the device interpolates; PARITY UNPINNED for that option (no reference output can be generated without the package: the
@@ -195,8 +196,13 @@ class BrokenSpectrogram:
             if self.sample_rateio < 1 or len(taps[0]) != self.fft_size:
                 raise ValueError(f"operands could not be broadcast together with shapes ({self.fft_size},) ({self.audio.channels},{len(taps[0])}) "
                                  f"(sample_rateio = {self.sample_rateio})")
-        if self.magnitude not in (FourierMagnitude.Power, FourierMagnitude.Amplitude):
-            raise NotImplementedError("custom magnitudes have no device kernel (FourierMagnitude.Power, .Amplitude)")
+        if not callable(self.magnitude):
+            raise TypeError(f"spectrogram magnitude {self.magnitude!r} is not callable")
+        if self.fft_size > 16384:
+            # (the reference computes any size; here a frame's transform lives in one workgroup's LDS — 16 384 float64 inputs at most. Said
+            # here, in the caller's terms, not only as the library's UNSUPPORTED: ADVICE round 5)
+            raise ValueError(f"fft_size = 2**fft_n * sample_rateio = {self.fft_size} samples: the device transform takes at most 16384 "
+                             f"(fft_n = {self.fft_n}, sample_rateio = {self.sample_rateio}: lower one of them)")
         custom = None
         if self.window not in _WINDOW_CODES:
             # a window function of the user's own (the reference multiplies by whatever `self.window(N)` returns, in float64,
@@ -242,8 +248,26 @@ class BrokenSpectrogram:
             raise RuntimeError("The spectrogram's audio has no device-resident PCM: load a file into ShaderAudio first")
         return native
 
+    @property
+    def device_magnitude(self) -> bool:
+        """Whether `magnitude` is one the STFT kernel evaluates itself. Any OTHER callable (the reference takes any function of the complex
+        spectrum, spectrogram.py:20-41, 169-171) is applied HERE, on the host, between two device stages: the float64 spectrum comes back
+        from the device (sfx_stft_spectrum), the callable runs in numpy exactly as `self.magnitude(np.fft.rfft(…)).astype(dtype)` does there,
+        and its result goes through the filterbank on the device (sfx_filterbank_apply) — slow (two round trips per frame), but it works;
+        the batched frame tape steps aside for it (tape.FrameTape.applicable)."""
+        return self.magnitude in (FourierMagnitude.Power, FourierMagnitude.Amplitude)
+
+    def spectrum(self) -> np.ndarray:
+        """(channels, fft_bins) complex128: np.fft.rfft(window*frame) of the last 2**fft_n samples, computed on the device (:169-170)"""
+        tell = np.array([self.audio.tell], np.int64)
+        pairs = np.zeros((self.audio.channels, self.fft_bins, 2), np.float64)
+        N.check(N.lib().sfx_stft_spectrum(self.plan(), self._native_audio(), N.as_ptr(tell, C.c_int64), 1, N.as_ptr(pairs, C.c_double)))
+        return pairs.view(np.complex128)[..., 0]
+
     def fft(self) -> np.ndarray:
         """(channels, fft_bins) float32 power of the last 2**fft_n samples (spectrogram.py:155-171)"""
+        if not self.device_magnitude:
+            return np.asarray(self.magnitude(self.spectrum())).astype(self.audio.dtype)       # :169-171
         tell = np.array([self.audio.tell], np.int64)
         out = np.zeros((self.audio.channels, self.fft_bins), np.float32)
         N.check(N.lib().sfx_stft_power(self.plan(), self._native_audio(), N.as_ptr(tell, C.c_int64), 1, N.as_ptr(out, C.c_float)))
@@ -251,8 +275,14 @@ class BrokenSpectrogram:
 
     def next(self) -> np.ndarray:
         """spectrogram_matrix().dot(fft().T).T: a (channels, bins) VIEW of a (bins, channels) buffer (:175-176)"""
-        tell = np.array([self.audio.tell], np.int64)
         out = np.zeros((self.spectrogram_bins, self.audio.channels), np.float32)
+        if not self.device_magnitude:
+            magnitudes = np.ascontiguousarray(self.fft(), np.float32)
+            if magnitudes.shape != (self.audio.channels, self.fft_bins):
+                raise ValueError(f"magnitude callable returned shape {magnitudes.shape}, expected ({self.audio.channels}, {self.fft_bins})")
+            N.check(N.lib().sfx_filterbank_apply(self.plan(), N.as_ptr(magnitudes, C.c_float), 1, 0, N.as_ptr(out, C.c_float)))
+            return out.T
+        tell = np.array([self.audio.tell], np.int64)
         N.check(N.lib().sfx_spectrogram_targets(self.plan(), self._native_audio(), N.as_ptr(tell, C.c_int64), 1, 0, N.as_ptr(out, C.c_float)))
         return out.T
 

@@ -107,7 +107,16 @@ class ClockLoop:
 
     # the same loop without python between the frames (csrc/capi.hip sfx_clock_sequence_run) ---------------------------------------------
 
-    CHUNK = 240                                                        # frames per native call: the encoder and `scene.quit` are looked at in between
+    CHUNK = 240                                                        # most frames per native call: the encoder and `scene.quit` are looked at in between
+    CHUNK_SECONDS = 0.25                                               # … and about how long a call may keep the host: the chunk is sized by the measured frame time
+
+    def chunk_frames(self, measured: "float | None") -> int:
+        """Frames of the next native call: CHUNK while nothing is known, then what fits CHUNK_SECONDS at the rate the last call ran at — a 4K
+        frame that waits for its ring slot takes 0.5 ms, so 240 of them held scene.quit, the encoder check and Ctrl-C for 120 ms at best and
+        for as long as the sink stalls at worst"""
+        if not measured or measured <= 0.0:
+            return min(self.CHUNK, 30)
+        return max(1, min(self.CHUNK, int(self.CHUNK_SECONDS/measured)))
 
     def native_sequence(self, export: "ExportingHelper", turbo: bool) -> bool:
         """Whether the frames can be rendered, rolled, resolved, read out and piped by ONE native call per chunk: a turbo export without a
@@ -150,9 +159,12 @@ class ClockLoop:
             planar = (C.c_void_p*len(export._yuv_slots))(*export._yuv_slots)
         piping = export.fileno is not None and export.ring is not None
         done = 0
+        per_frame = None                                               # seconds per frame of the last native call
+        import time as clock
         while done < total and not scene.quit:
-            count = min(self.CHUNK, total - done)
+            count = min(self.chunk_frames(per_frame), total - done)
             export._check_encoder()
+            started = clock.perf_counter()
             ticks = (N.ClockTick*count)()
             for i in range(count):
                 time = times[done + i]
@@ -160,6 +172,7 @@ class ClockLoop:
             N.check(lib.sfx_clock_sequence_run(scene.context.handle, passes, len(self.programs), matrix_tables(), len(textures), ticks, count,
                                                export.ring if piping else N.Handle(), export.frame % max(1, export.slots), export.fileno if piping else -1,
                                                planar, 1 if export.yuv_matrix == "bt709" else 0, scene.width, scene.height))
+            per_frame = (clock.perf_counter() - started)/count
             for texture in textures:
                 texture.roll(count)                                   # the native call rolled its own copy of every matrix it drew into
             export.frame += count

@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void k_stft_power(const float* __restrict__ pc
         double2 w = (k < M) ? twiddle[k] : make_double2(-1.0, 0.0);
         const double xr = er + (orr*w.x - oi*w.y), xi = ei + (orr*w.y + oi*w.x);
         // FourierMagnitude.Power = (x*conj(x)).real, spectrogram.py:25-26; .Amplitude = np.abs(x) = hypot in float64, :22-23
-        out[k] = amplitude ? (float)::hypot(xr, xi) : (float)(xr*xr + xi*xi);
+        // (amplitude == 2: the COMPLEX spectrum itself, float64 pairs — sfx_stft_spectrum: a `magnitude` callable of the user's own runs on the host)
+        if (amplitude == 2) ((double2*)power)[((long)frame*channels + c)*(M + 1) + k] = make_double2(xr, xi);
+        else out[k] = amplitude ? (float)::hypot(xr, xi) : (float)(xr*xr + xi*xi);
     }
 }
 
@@ -103,7 +105,8 @@ __global__ __launch_bounds__(256) void k_dft_power(const float* __restrict__ pcm
             re = fma(x[n], w.x, re); im = fma(x[n], w.y, im);
             j += k; if (j >= N) j -= N;
         }
-        out[k] = amplitude ? (float)::hypot(re, im) : (float)(re*re + im*im);
+        if (amplitude == 2) ((double2*)power)[((long)frame*channels + c)*bins + k] = make_double2(re, im);
+        else out[k] = amplitude ? (float)::hypot(re, im) : (float)(re*re + im*im);
     }
 }
 

@@ -213,8 +213,11 @@ static EngineCopy* peer_engine_copy(Context* c, const void* remote, const void* 
     std::lock_guard<std::mutex> guard(lock);
     if (c->peer_engines) return c->peer_engines->usable ? c->peer_engines : nullptr;
     EngineCopy* e = c->peer_engines = new EngineCopy();
+    // OPT-IN (SHADERFLOW_PEER=engine) since round 6: the named-engine route has only ever copied into its own process' window on ONE
+    // GPU. Until it has run between two real GPUs the default is HIP's copy streams (hipMemcpyAsync on the context's probed copy streams),
+    // which every ROCm release exercises; bench.py's "sdma" legs ask for the engines explicitly after their collective preflight.
     const char* route = getenv("SHADERFLOW_PEER");
-    if (route && strcmp(route, "engine")) return nullptr;
+    if (!route || strcmp(route, "engine")) return nullptr;
     if (hsa_init() != HSA_STATUS_SUCCESS) return nullptr;
     hsa_amd_pointer_info_t here{}, there{};
     here.size = sizeof(here); there.size = sizeof(there);
@@ -257,11 +260,23 @@ static hipError_t frame_copy(void* dst, const void* src, size_t nbytes, hipStrea
 }
 
 // A frame is complete on the render stream: polled for ~200 us before the thread blocks (hipEventSynchronize wakes up late: see finish())
-static void wait_frame_ready(hipEvent_t event) {
+// false: the event reported an error (a sticky one of the runtime, a failed launch before it): the frame must NOT be treated as rendered
+static bool wait_frame_ready(hipEvent_t event) {
     const auto started = std::chrono::steady_clock::now();
-    while (hipEventQuery(event) == hipErrorNotReady) {
-        if (std::chrono::steady_clock::now() - started > std::chrono::microseconds(200)) { hipEventSynchronize(event); return; }
+    for (;;) {
+        const hipError_t state = hipEventQuery(event);
+        if (state == hipSuccess) return true;
+        if (state != hipErrorNotReady) { (void)hipGetLastError(); return false; }
+        if (std::chrono::steady_clock::now() - started > std::chrono::microseconds(200)) {
+            if (hipEventSynchronize(event) == hipSuccess) return true;
+            (void)hipGetLastError();
+            return false;
+        }
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
     }
 }
 
@@ -289,6 +304,7 @@ struct EngineLanes {
     }
     // false: the copy could not be queued on any route
     bool issue(int lane, void* host, const void* device, size_t nbytes) {
+        if (e && !done[lane].handle) e = nullptr;                      // (a retired signal could not be replaced: HIP's copies from here on)
         if (e) {
             hsa_signal_store_relaxed(done[lane], 1);
             hsa_status_t status = hsa_amd_memory_async_copy_on_engine(host, e->cpu, device, e->gpu, nbytes, 0, nullptr, done[lane], (hsa_amd_sdma_engine_id_t)e->engine[lane & 1], false);
@@ -336,7 +352,16 @@ struct EngineLanes {
                 while (hsa_signal_wait_scacquire(done[lane], HSA_SIGNAL_CONDITION_LT, 1, poll_ticks()*5000, HSA_WAIT_STATE_BLOCKED) >= 1)
                     if (++seconds >= limit) break;
             }
-            ok = hsa_signal_load_relaxed(done[lane]) == 0;
+            const hsa_signal_value_t left = hsa_signal_load_relaxed(done[lane]);
+            ok = left == 0;
+            if (left >= 1) {
+                // TIMED OUT: the engine may still decrement this signal whenever its copy ends — armed again for the lane's next copy it
+                // would make that copy look complete before it is. The signal is RETIRED (left to the late copy, never destroyed or reused)
+                // and the lane gets a fresh one; when none can be had the lane leaves the engine route.
+                hsa_signal_t fresh{};
+                if (hsa_signal_create(0, 0, nullptr, &fresh) == HSA_STATUS_SUCCESS) done[lane] = fresh;
+                else { done[lane] = hsa_signal_t{}; e = nullptr; }
+            }
         } else {
             ok = hipStreamSynchronize(c->copy_streams[lane & 1]) == hipSuccess;   // (a stream's later copy too: in order, so nothing is released early)
             if (!ok) (void)hipGetLastError();
@@ -555,10 +580,10 @@ static void peer_copier(PeerCopier* p) {
             job = p->queue.front(); p->queue.pop_front();
         }
         for (int lane = 0; lane < EngineLanes::LANES; lane++) if (in_lane[lane] >= 0 && p->lanes.landed(lane)) finish(lane);
-        wait_frame_ready(p->ready[job.tag]);                         // the source is complete on the render stream
+        const bool rendered = wait_frame_ready(p->ready[job.tag]);   // the source is complete on the render stream (false: its event reports an error — nothing is copied)
         finish(next);
         p->lanes.resolve(p->ctx, job.dst, job.src, true);
-        if (!p->lanes.issue(next, job.dst, job.src, job.nbytes)) {
+        if (!rendered || !p->lanes.issue(next, job.dst, job.src, job.nbytes)) {
             std::lock_guard<std::mutex> lock(p->mutex);
             p->error = 1; p->pending[job.tag]--;
             p->idle.notify_all();
@@ -1495,14 +1520,14 @@ static void ring_copier(Ring* r) {
         static const bool trace = getenv("SHADERFLOW_RING_TRACE") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
         release_landed();
-        wait_frame_ready(job.ready);                                 // the frame is complete on the render stream
+        const bool rendered = wait_frame_ready(job.ready);           // the frame is complete on the render stream (false: its event reports an error — the slot is failed, not filled)
         const auto t1 = std::chrono::steady_clock::now();
         release_landed();
         finish(next);                                                // the lane's previous copy
         const auto t2 = std::chrono::steady_clock::now();
         if (trace) fprintf(stderr, "ring copier: slot %d event wait %.0f us, lane finish %.0f us\n", job.slot, std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count());
         r->lanes.resolve(r->ctx, r->host[job.slot], job.source);
-        if (!r->lanes.issue(next, r->host[job.slot], job.source, r->frame_bytes)) {
+        if (!rendered || !r->lanes.issue(next, r->host[job.slot], job.source, r->frame_bytes)) {
             std::lock_guard<std::mutex> lock(r->mutex);
             r->copy_error = 1; r->copying[job.slot] = 0;
             r->idle.notify_all();
@@ -1787,6 +1812,10 @@ extern "C" int sfx_clock_sequence_run(sfx_handle hc, const sfx_sequence_pass* pa
                 if ((rc = sfx_ring_pipe_sync(hring, slot))) return rc;
                 Texture* final_texture = get<Texture>(passes[npasses - 1].target, MAGIC_TEX);
                 if (!final_texture) return fail(SFX_E_INVALID, "clock sequence: the last pass has no target to convert");
+                // (the conversion reads width x height RGB8 texels and writes width*height*3/2 bytes: the caller's numbers must be the texture's)
+                if (final_texture->dtype != SFX_U8 || final_texture->components != 3 || final_texture->width != width || final_texture->height != height)
+                    return fail(SFX_E_INVALID, "clock sequence: yuv420p of a %d x %d frame was asked for, the last pass' target is %d x %d x %d (dtype %d)",
+                                width, height, final_texture->width, final_texture->height, final_texture->components, final_texture->dtype);
                 if ((rc = sfx_rgb_to_yuv420(hc, final_texture->data, planar_slots[slot], width, height, 1, yuv_matrix))) return rc;
                 rc = sfx_ring_read_device_async(hring, planar_slots[slot], slot);
             } else {
@@ -2057,14 +2086,16 @@ template <class... Args> static void launch_dynamics_scan(hipStream_t s, int nfr
 }
 
 // device-side launches shared by the per-frame entry points and the tape
-static void launch_stft(const Plan* p, const Audio* a, const long* d_tell, int frames, float* d_power, hipStream_t s) {
+// `what`: 0 power, 1 amplitude (float32 into d_power), 2 the complex spectrum (float64 pairs into d_power, which then is a double2 buffer)
+static void launch_stft(const Plan* p, const Audio* a, const long* d_tell, int frames, float* d_power, hipStream_t s, int what = -1) {
     const int N = p->fft_size, in_size = 1 << p->fft_n;
+    if (what < 0) what = p->amplitude;
     if ((N & (N - 1)) == 0)
         hipLaunchKernelGGL(k_stft_power, dim3(frames, p->channels), dim3(256), (N/2)*sizeof(double2), s,
-                           a->pcm, a->samples, d_tell, __builtin_ctz((unsigned)N), in_size, p->d_taps, p->d_window, p->d_twiddle, d_power, p->amplitude);
+                           a->pcm, a->samples, d_tell, __builtin_ctz((unsigned)N), in_size, p->d_taps, p->d_window, p->d_twiddle, d_power, what);
     else
         hipLaunchKernelGGL(k_dft_power, dim3(frames, p->channels), dim3(256), (size_t)N*sizeof(double), s,
-                           a->pcm, a->samples, d_tell, N, in_size, p->d_taps, p->d_window, p->d_twiddle, d_power, p->amplitude);
+                           a->pcm, a->samples, d_tell, N, in_size, p->d_taps, p->d_window, p->d_twiddle, d_power, what);
 }
 static void launch_filterbank(Plan* p, FilterbankScratch& scratch, int frames, int use_mfma, const float* d_power, float* d_out, hipStream_t s) {
     const int ncols = frames*p->channels;
@@ -2098,6 +2129,44 @@ extern "C" int sfx_stft_power(sfx_handle hp, sfx_handle ha, const int64_t* tell,
     launch_stft(p, a, p->d_tell, nframes, p->d_power, s);
     if ((rc = launch_status())) return rc;
     HIP_TRY(hipMemcpyAsync(power, p->d_power, sizeof(float)*(size_t)nframes*p->channels*p->fft_bins, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SFX_OK;
+}
+
+// `magnitude` callables of the user's own (spectrogram.py:20-41, 169-171 accepts ANY callable on the complex spectrum): the device computes
+// np.fft.rfft(window*frame) and hands the float64 pairs over, the host applies the callable, sfx_filterbank_apply takes its float32 result
+// through the filterbank. A slow path (two host round trips per call) for an option nothing in the reference's tree uses — but it works.
+extern "C" int sfx_stft_spectrum(sfx_handle hp, sfx_handle ha, const int64_t* tell, int nframes, double* spectrum) {
+    Plan* p = get<Plan>(hp, MAGIC_PLAN); Audio* a = get<Audio>(ha, MAGIC_AUDIO);
+    int rc = check_audio(p, a);
+    if (rc) return rc;
+    if (!tell || !spectrum || nframes < 1) return fail(SFX_E_INVALID, "null tell/spectrum or no frames");
+    USE_DEVICE(p->ctx);
+    if ((rc = plan_reserve(p, nframes))) return rc;
+    hipStream_t s = p->ctx->stream;
+    const size_t bytes = sizeof(double)*2*(size_t)nframes*p->channels*p->fft_bins;
+    void* d_spectrum = nullptr;
+    HIP_TRY(hipMalloc(&d_spectrum, bytes));
+    hipError_t e = hipMemcpyAsync(p->d_tell, tell, sizeof(long)*nframes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) { launch_stft(p, a, p->d_tell, nframes, (float*)d_spectrum, s, 2); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(spectrum, d_spectrum, bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(d_spectrum);
+    return e == hipSuccess ? SFX_OK : fail(SFX_E_HIP, "stft spectrum: %s", hipGetErrorString(e));
+}
+
+extern "C" int sfx_filterbank_apply(sfx_handle hp, const float* magnitudes, int nframes, int use_mfma, float* out) {
+    Plan* p = get<Plan>(hp, MAGIC_PLAN);
+    if (!p) return fail(SFX_E_INVALID, "invalid plan handle");
+    if (!magnitudes || !out || nframes < 1) return fail(SFX_E_INVALID, "null magnitudes/out or no frames");
+    USE_DEVICE(p->ctx);
+    int rc = plan_reserve(p, nframes);
+    if (rc) return rc;
+    hipStream_t s = p->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(p->d_power, magnitudes, sizeof(float)*(size_t)nframes*p->channels*p->fft_bins, hipMemcpyHostToDevice, s));
+    launch_filterbank(p, p->scratch, nframes, use_mfma, p->d_power, p->d_out, s);
+    if ((rc = launch_status())) return rc;
+    HIP_TRY(hipMemcpyAsync(out, p->d_out, sizeof(float)*(size_t)nframes*p->channels*p->bins, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return SFX_OK;
 }

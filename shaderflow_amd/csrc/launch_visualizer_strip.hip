@@ -172,6 +172,9 @@ int launch_visualizer_fast(Context* ctx, const RenderArgs& a0, int ssaa, int fra
 #ifndef VIS_STRIP_WALK1
 #define VIS_STRIP_WALK1 2
 #endif
+#ifdef VIS_STRIP_ROWS1                                               // (A/B builds: longer strips without SSAA, tools/variants.sh)
+        if (fits(64, 8*VIS_STRIP_WALK1, 66, VIS_STRIP_ROWS1)) return launch_visualizer_tables_and_kernel<66, VIS_STRIP_ROWS1, 1, VIS_STRIP_WALK1, VIS_STRIP_WAVES1, 1>(ctx, a, frames, s);
+#endif
         if (VIS_STRIP_WALK1 == 2 && fits(64, 16, 66, 22)) return launch_visualizer_tables_and_kernel<66, 22, 1, 2, 4, 1>(ctx, a, frames, s);
         if (fits(64, 8, 66, 15)) return launch_visualizer_tables_and_kernel<66, 15, 1, 1, 6, 1>(ctx, a, frames, s);
     } else if (ssaa == 2) {

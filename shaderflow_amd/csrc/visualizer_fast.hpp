@@ -416,8 +416,10 @@ __global__ __launch_bounds__(256) void k_visualizer_classify(const RenderArgs a,
             }
             const bool crosses = ylo <= 0.0f && yhi >= 0.0f;
             if (crosses) { if (xhi > 0.0f) lo = 0.0f; if (xlo < 0.0f) hi = 1.0f; }
-            // (one bin of slack on either side: the speculated angle of a pixel's centre is 2e-5 bins from the exact one, its samples 0.07)
-            const int b0 = max((int)floorf(lo*(float)sp.height) - 1, 0), b1 = min((int)floorf(hi*(float)sp.height) + 1, sp.height - 1);
+            // (the rectangle holds every supersample and every pixel centre of the tile; a hundredth of a bin of slack for the corners' own
+            // rounding and the centres' speculated angles, 2e-5 bins from the exact ones. What a pixel AT a bin's edge sees of the neighbouring
+            // bin is that bin's `spread`, which k_visualizer_bar_spread took over both neighbours)
+            const int b0 = max((int)floorf(lo*(float)sp.height - 0.01f), 0), b1 = min((int)floorf(hi*(float)sp.height + 0.01f), sp.height - 1);
             const float2* bars = t.bars2 + (long)frame*sp.height*2;
             float amp = 0.0f, spread = 0.0f;
             bool finite = true;
@@ -997,7 +999,7 @@ struct VisualizerStrip {
                         else pixel_tier<3 % S>(a, t, frame, c, acc, texel, c2, sh, bx, by, row0, rows, column);
                     }
                     per_sample = false;
-                } else if (a.tile_misses && (threadIdx.x & 63) == 0) atomicAdd(a.tile_misses, 1u);      // (diagnostics: sfx_ctx_tile_misses counts the WAVES that evaluate per sample)
+                } else if (t.pixel_columns && a.tile_misses && (threadIdx.x & 63) == 0) atomicAdd(a.tile_misses, 1u);      // (diagnostics: sfx_ctx_tile_misses counts the WAVES the classification sent to the per-sample path)
             }
             if (per_sample) {
                 const float4 c1 = ce[1];

@@ -395,6 +395,10 @@ class DeviceArray:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (pointer, False), "version": 2}
 
 
+class PeerWindowsUnavailable(RuntimeError):
+    """The collective preflight of SdmaTransfer failed on some rank: raised on EVERY rank, with every rank's reason"""
+
+
 class SdmaTransfer:
     """RangeTransfer's interface over peer windows (SHADERFLOW_SHARD=device-sdma): a chunk travels as ONE asynchronous device-to-device
     copy on a copy stream of the sending rank — SDMA engines, the rank's own xGMI link, no compute units, concurrent with the render of
@@ -402,16 +406,58 @@ class SdmaTransfer:
     on the host side: a sender waits for its PREVIOUS copy before it queues the next one (by then long done) and tells rank 0 with a
     one-integer message over gloo."""
 
-    def __init__(self, world: int, rank: int, context, frame_bytes: int, resident_pointer: Optional[int]):
+    def __init__(self, world: int, rank: int, context, frame_bytes: int, resident_pointer: Optional[int], probe_at: int = 0, probe_bytes: int = 0):
+        """Opens the windows and PROVES them, collectively: every sending rank moves `probe_bytes` through its window to `probe_at` (a place
+        of rank 0's buffer its own first chunk overwrites later), the outcomes are all-gathered, and on ANY failure every rank closes its
+        mapping and raises PeerWindowsUnavailable — so that the caller falls back for the whole group (tape.py: RCCL point-to-point), not one
+        rank inside a half-done export. The copies have run on ONE GPU only: what does not work between two real ones is
+        found here, before a frame is rendered. They travel on HIP's copy streams unless SHADERFLOW_PEER=engine names the SDMA engines."""
         import torch.distributed as dist
         self.world, self.rank, self.context, self.frame_bytes = world, rank, context, frame_bytes
         self.control = None if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")     # RCCL carries device tensors only
-        handle = [context.peer_export(resident_pointer) if rank == 0 else None]
-        dist.broadcast_object_list(handle, src=0, group=self.control)
-        self.window = None if rank == 0 else context.peer_open(handle[0])
+        self.window = None
         self.notices: list = []
         self.pending: Optional[int] = None
         self.chunks = 0
+        problem = ""
+        handle = [None]
+        try:
+            if rank == 0:
+                handle = [context.peer_export(resident_pointer)]
+        except Exception as error:                                   # noqa: BLE001 — whatever it is, the other ranks must hear of it
+            problem = f"rank 0 could not export its buffer: {error}"
+        dist.broadcast_object_list(handle, src=0, group=self.control)
+        probe = None
+        try:
+            if rank != 0 and not problem:
+                if handle[0] is None:
+                    problem = "no window handle from rank 0"
+                else:
+                    self.window = context.peer_open(handle[0])
+                    if os.environ.get("SHADERFLOW_PEER_INJECT") == f"preflight:{rank}":
+                        raise RuntimeError("injected: this rank's peer copies do not work")     # tests: every rank must fall back together
+                    if probe_bytes > 0:
+                        probe = context.alloc(probe_bytes)
+                        context.synchronize()
+                        context.peer_copy(self.window + probe_at, probe, probe_bytes, lane=15)
+                        context.peer_flush()
+        except Exception as error:                                   # noqa: BLE001
+            problem = f"rank {rank}: {error}"
+        finally:
+            if probe is not None:
+                context.free(probe)
+        problems = [None]*world
+        dist.all_gather_object(problems, problem, group=self.control)
+        failed = "; ".join(text for text in problems if text)
+        if failed:
+            try:
+                if self.window is not None:
+                    context.peer_close(self.window)
+            except Exception:                                        # noqa: BLE001 — the first failure is the one to report
+                pass
+            self.window = None
+            dist.barrier(group=self.control)                         # every peer has closed its mapping before rank 0 frees the buffer
+            raise PeerWindowsUnavailable(failed)
 
     def expect(self, source: int, chunk: int, view) -> None:
         pass                                                        # nothing to post: the sender writes into place

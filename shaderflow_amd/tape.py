@@ -91,6 +91,8 @@ class FrameTape:
             return False
         if not spectrograms:
             return True                                           # Waveform-like scenes: the tape carries a private spectrogram nobody samples
+        if not spectrograms[0].device_magnitude:
+            return False                                          # a `magnitude` callable of the user's own runs on the host, frame by frame (audio/spectrogram.py)
         if spectrograms[0].spectrogram_bins*audio.channels > 16384:
             return False                                          # the scan kernel walks up to 16 384 values per frame (csrc/capi.hip DYNAMICS_SCAN_LIMIT)
         # a scrolling spectrogram (length > 0) keeps one state of its texture per frame of a batch in HBM (sfx_tape_desc.length_samples)
@@ -225,7 +227,7 @@ class FrameTape:
         """The whole export. With an initialised torch.distributed process group (one process per GPU) the frames are sharded over
         the ranks and delivered to rank 0, which owns the sink: per-rank read-out into shared memory ("host", the default) or
         contiguous HBM-resident ranges sent over RCCL ("device") — shaderflow_amd/parallel.py."""
-        from shaderflow_amd.parallel import (DeviceArray, HostDelivery, RangeTransfer, SdmaTransfer, contiguous_device_export,
+        from shaderflow_amd.parallel import (DeviceArray, HostDelivery, PeerWindowsUnavailable, RangeTransfer, SdmaTransfer, contiguous_device_export,
                                              interleaved_host_export, interleaved_runs, is_sharded, rank_world, shard_batches, shard_frames, shard_mode)
         scene = self.scene
         total = export.total_frames
@@ -335,7 +337,16 @@ class FrameTape:
                     else:
                         resident = torch.zeros(max(1, frames_here)*sink_bytes, dtype=torch.uint8, device=device)
                     torch.cuda.synchronize(device)
-                    transfer = SdmaTransfer(world, rank, context, sink_bytes, window)
+                    try:
+                        transfer = SdmaTransfer(world, rank, context, sink_bytes, window, probe_at=first*sink_bytes,
+                                                probe_bytes=min(4096, max(0, last - first)*sink_bytes))
+                    except PeerWindowsUnavailable as unavailable:
+                        # decided by every rank together (the outcomes were all-gathered): the windows do not work here, the chunks travel
+                        # as RCCL point-to-point calls instead — the same resident buffers, nothing rendered yet
+                        if rank == 0:
+                            print(f"shaderflow_amd: peer windows unavailable ({unavailable}): SHADERFLOW_SHARD=device-sdma falls back to device mode", flush=True)
+                        mode = "device"
+                        transfer = RangeTransfer(world, rank, device)
                 else:
                     resident = torch.zeros(max(1, frames_here)*sink_bytes, dtype=torch.uint8, device=device)
                     torch.cuda.synchronize(device)              # the fill runs on torch's stream, the renders on the context's
@@ -366,16 +377,16 @@ class FrameTape:
                     if scratch is not None:
                         context.synchronize()
                         context.free(scratch)
-                    if mode == "device-sdma":
-                        import torch.distributed as dist
-                        try:
+                    try:
+                        if isinstance(transfer, SdmaTransfer):
+                            import torch.distributed as dist
                             transfer.close()                        # the peers' mappings of the window
                             dist.barrier(group=transfer.control)    # every peer has closed its mapping
-                        finally:
-                            if window is not None:
-                                del resident
-                                context.synchronize()
-                                context.free(window)
+                    finally:
+                        if window is not None:                      # (also after the fall-back to RCCL: the frames still live in the raw allocation)
+                            del resident
+                            context.synchronize()
+                            context.free(window)
                 if failure is not None:
                     raise failure
                 if rank != 0:

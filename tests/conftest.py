@@ -16,6 +16,7 @@ os.environ.setdefault("SHADERFLOW_JIT_CACHE", str(ROOT/"build"/"jit"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: timing assertions on a GPU box (pytest -m perf); not part of the parity suite")
 
 
 def pytest_sessionstart(session):

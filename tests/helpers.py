@@ -121,6 +121,19 @@ def visualizer_inputs(w, h, seed=0, bg_size=(96, 54), volume=0.8, std=0.2, time=
     return u, arrays, params
 
 
+def smooth_spectrum(bins: int = 115, seed: int = 0) -> np.ndarray:
+    """A spectrogram column like music's after the DynamicNumber smoothing: a few broad peaks over a low floor, (bins, 1, 2) float32 —
+    neighbouring bars differ little, so most of a frame's wave tiles take the strip kernel's pixel tier (visualizer_inputs' white-noise
+    column, whose neighbouring bars differ by whole bar heights, sends nearly every tile to the per-sample path)"""
+    rng = np.random.default_rng(seed)
+    b = np.arange(bins, dtype=np.float64)[:, None]
+    column = np.full((bins, 2), 2.0)
+    for _ in range(3):
+        centre, width, height = rng.uniform(8, bins - 8, 2), rng.uniform(5.0, 12.0, 2), rng.uniform(300.0, 2500.0, 2)
+        column += height*np.exp(-((b - centre)/width)**2)
+    return column.reshape(bins, 1, 2).astype(np.float32)
+
+
 def mip_probe_texture(width: int, height: int, dtype) -> np.ndarray:
     """The texture of the mipmap probes (tests/golden/make_golden_mip.py renders it on the reference): smooth gradients plus seeded
     noise, so that neighbouring levels differ visibly; (height, width, 4), row 0 = bottom"""

@@ -356,3 +356,61 @@ def test_dynamics_coefficients_match_the_oracle():
             a, b, c = C.c_double(), C.c_double(), C.c_double()
             assert O.lib().sfo_dyn_coeffs(C.byref(p), dt, C.byref(a), C.byref(b), C.byref(c)) == branch
             assert (a.value, b.value, c.value) == (k1, k2, k3)
+
+
+def test_magnitude_callables_of_the_users_own(gpu, golden):
+    """spectrogram.py:20-41, 169-171 takes ANY callable on the complex spectrum (missing 5): the device hands the float64
+    rFFT over (sfx_stft_spectrum), the host applies the callable as the reference does, the device's filterbank takes the result
+    (sfx_filterbank_apply). Checked against the reference's own FourierMagnitude members in fft.npz / options.npz through callables
+    that merely restate them, against numpy for one that does not, and for the tape stepping aside."""
+    from shaderflow_amd import ShaderScene
+    from shaderflow_amd.audio import ShaderAudio
+    from shaderflow_amd.audio.spectrogram import FourierMagnitude, ShaderSpectrogram
+    from shaderflow_amd.tape import FrameTape
+    g, o = golden("fft"), golden("options")
+    pcm = g["in_noise"]                                                 # (2, 4097) planar
+
+    class Listener(ShaderScene):
+        def build(self):
+            super().build()
+            self.audio = ShaderAudio(scene=self, name="iAudio")
+            self.audio.load(samples=np.ascontiguousarray(pcm.T), samplerate=44100)
+            self.spectrogram = ShaderSpectrogram(scene=self, audio=self.audio, length=0)
+
+    scene = Listener()
+    scene.initialize()
+    spectrogram, audio = scene.spectrogram, scene.audio
+    audio.tell = pcm.shape[1]
+    assert FrameTape.applicable(scene)
+    builtin_power, builtin_next = spectrogram.fft(), spectrogram.next().copy()
+    close(builtin_power, g["power_noise"])
+
+    spectrogram.magnitude = lambda x: (x*x.conjugate()).real            # FourierMagnitude.Power restated: not the member, so the host path runs
+    assert not spectrogram.device_magnitude and not FrameTape.applicable(scene)
+    spectrum = spectrogram.spectrum()
+    assert spectrum.shape == (2, 2049) and spectrum.dtype == np.complex128
+    window = np.hanning(4096)
+    want = np.fft.rfft(window*pcm[:, -4097:-1].astype(np.float64))      # the ring excludes the newest sample (audio/module.py:137-138)
+    assert np.abs(spectrum - want).max() <= 1e-9*np.abs(want).max()
+    assert np.array_equal(spectrogram.fft(), builtin_power)             # the same float64 pairs, the same formula, one rounding to float32
+    assert np.array_equal(spectrogram.next(), builtin_next)             # … and the same CSR product
+
+    spectrogram.magnitude = lambda x: np.abs(x)                         # FourierMagnitude.Amplitude restated
+    close(spectrogram.fft(), o["amplitude_noise"])
+    spectrogram.magnitude = FourierMagnitude.Amplitude
+    assert spectrogram.device_magnitude
+    close(spectrogram.fft(), o["amplitude_noise"])
+
+    spectrogram.magnitude = lambda x: np.log1p(np.abs(x.real)) + 0.25*np.abs(x.imag)      # nothing the device knows
+    got = spectrogram.fft()
+    ref = (np.log1p(np.abs(want.real)) + 0.25*np.abs(want.imag)).astype(np.float32)
+    assert got.dtype == np.float32 and np.abs(got - ref).max() <= 1e-5*np.abs(ref).max()
+    matrix = spectrogram.spectrogram_matrix()
+    close(spectrogram.next(), matrix.dot(got.T).T)
+    spectrogram.magnitude = lambda x: np.abs(x)[:, :7]                  # a callable that loses bins: said, not sent to the device
+    with pytest.raises(ValueError, match="magnitude callable returned shape"):
+        spectrogram.next()
+    spectrogram.magnitude = 3
+    with pytest.raises(TypeError, match="not callable"):
+        spectrogram.fft()
+    scene.destroy() if hasattr(scene, "destroy") else None

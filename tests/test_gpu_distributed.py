@@ -274,3 +274,30 @@ def test_plain_bench_command_with_gpus_2_becomes_two_ranks():
     record = json.loads(lines[0])
     assert record["n_gpus"] == 2 and record["rccl_ranks"] == 2 and record["config"]["ranks"] == 2 and record["value"] > 0
     assert "without a launcher" in out.stderr
+
+
+def _rank_with_env(rank: int, world: int, port: int, name: str, path: str, mode: str, extra: dict):
+    os.environ.update(extra)
+    _rank(rank, world, port, name, path, None, mode)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("extra", [{"SHADERFLOW_PEER_INJECT": "preflight:1"}, {"SHADERFLOW_PEER": "engine"}], ids=["preflight-fails", "named-engines"])
+def test_peer_windows_are_proved_collectively_before_the_first_frame(tmp_path, extra, capfd):
+    """SdmaTransfer moves a probe through every window and all-gathers the outcome BEFORE anything is rendered. With rank
+    1's preflight made to fail every rank falls back to RCCL-style point-to-point together and the export is still the single-process
+    one, byte for byte; with SHADERFLOW_PEER=engine (the SDMA engines named through HSA — opt-in since round 6, HIP's copy streams are
+    the default) the windows are used as before."""
+    whole = _build("Visualizer").main(output=bytes, **KW["Visualizer"])
+    path = str(tmp_path/"sharded.rgb")
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_with_env, args=(r, 2, port, "Visualizer", path, "device-sdma", extra)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    assert open(path, "rb").read() == whole
+    printed = capfd.readouterr().out
+    assert ("falls back to device mode" in printed) == ("SHADERFLOW_PEER_INJECT" in extra), printed[-500:]

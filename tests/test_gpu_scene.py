@@ -413,7 +413,7 @@ def test_bench_measures_the_instruction_counters_of_its_own_run():
     record = json.loads([line for line in out.stdout.splitlines() if line.startswith("{")][-1])
     roofline = record["roofline"]
     assert roofline["counters_from"].startswith("live: SQ_INSTS_VALU"), (roofline["counters_from"], out.stderr[-1500:])
-    assert 455.0 < roofline["valu_instructions_per_supersample"] < 490.0, roofline
+    assert 385.0 < roofline["valu_instructions_per_supersample"] < 425.0, roofline      # (403 with round 6's pixel tier; 472 in round 5, 549 in rounds 3-4)
     assert 0.5 < roofline["issue_cycles_frac"] < 1.0 and 0.4 < roofline["frac"] < 0.8, roofline
     assert 1.8 < roofline["issue_model"]["effective_clock_GHz"] < 2.5, roofline["issue_model"]
 

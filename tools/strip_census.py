@@ -32,7 +32,7 @@ from isa_census import CLASSES, VALU  # noqa: E402
 
 CYCLES = {name: cycles for name, _, cycles in CLASSES}
 # the files k_visualizer_strip is compiled from (bench.py ties the census to them, not to the whole library)
-STRIP_SOURCES = ("visualizer_fast.hpp", "visualizer_kernels.hpp", "render_kernels.hpp", "fragments.hpp", "glsl.hpp", "sfmath.hpp", "Makefile")
+STRIP_SOURCES = ("visualizer_fast.hpp", "visualizer_kernels.hpp", "render_kernels.hpp", "fragments.hpp", "glsl.hpp", "sfmath.hpp", "launch_visualizer_strip.hip", "Makefile")
 
 
 def vf_lines(block) -> collections.Counter:
@@ -62,7 +62,9 @@ def source_ranges(path: str) -> dict:
         raise SystemExit(f"marker '{needle}' not found in {path}")
     strip = find("struct VisualizerStrip {")
     marks = {
-        "post_fn": (find("__device__ __forceinline__ uint32_t visualizer_fast_post("), find("// Stages the window")),
+        "post_fn": (find("__device__ __forceinline__ uint32_t visualizer_fast_post("), find("// ---- the pixel tier (round 6)")),
+        "gains_fn": (find("__device__ __forceinline__ PixelGains visualizer_pixel_gains("), find("// One thread per (frame, wave tile)")),
+        "tier_fn": (find("template <int SOURCE> __device__ __forceinline__ static float from_pixel_lane(", strip), find("__device__ static void run(const RenderArgs& a, const VisTables& t) {", strip)),
         "stage_fn": (find("__device__ __forceinline__ void visualizer_fast_stage("), find("// ---- the fused kernel ----")),
         "blur_direct": (find("__device__ static void blur_direct("), find("__device__ static void run(const RenderArgs& a, const VisTables& t) {")),
         "load_cell": (find("__device__ __forceinline__ static void load_cell(", strip), find("template <class T> __device__ __forceinline__ static float F(", strip)),
@@ -71,12 +73,12 @@ def source_ranges(path: str) -> dict:
         "diag": (find("// ---- the four diagonal directions:", strip), find("// diagonals", strip)),
         "post": (find("// ---- visualizer.frag:36-73 per sample", strip), find("// post-processing", strip)),
         "resolve": (find("// every wave is done with the cells", strip), find("// barrier + texel exchange + resolve + barrier", strip)),
-        "diag_setup_end": (find("#pragma unroll VIS_STRIP_DIAG_UNROLL", strip),)*2,
-        "advance_use": (find("acc[r][0] = acc[r][0] + U[side][0];", strip),)*2,
+        "diag_setup_end": (find("for (int w = 0; w < 10; w++) {", find("// ---- the four diagonal directions:", strip)),)*2,
+        "advance_use": (find("acc[r][2] = acc[r][2] + U[side][2];", strip),)*2,
         "pow_line": (find("col = col*ColourMath<true>::pow((len - rr)*0.5f, 0.05f);"),)*2,
         "mix_line": (find("if (len < rr) col = mix(col, vec3{1.0f, 1.0f, 1.0f}, smoothstep01(0.5f + bar));"),)*2,
         "strips_line": (find("if (strip_top) { col = col*0.8f; opacity = opacity*0.8f; }"),)*2,
-        "smoothstep01": (find("__device__ __forceinline__ float smoothstep01("),)*2,
+        "smoothstep01": (0, 0),      # (round 6: moved to render_kernels.hpp — the mix branch is recognised by its own line alone)
         "store": (find("// barrier + texel exchange + resolve + barrier", strip), find("template <int TILE_PITCH, int TILE_ROWS, int S, int WALK, int MIN_WAVES", strip)),
         "sweep": (find("constexpr int GROUPS = BLOCK_PX*3/16;", strip), find("// the sweep of stores", strip)),
     }
@@ -94,6 +96,9 @@ def main() -> None:
     parser.add_argument("bench", nargs="?")
     parser.add_argument("--folds", type=float, default=53.0, help="diagonal folds per wave measured by the -DSF_SECTION_TIMERS build")
     parser.add_argument("--exact", type=float, default=0.02)
+    parser.add_argument("--per-sample", type=float, default=0.145, help="share of the waves that evaluate visualizer.frag:36-73 per sample (round 6: the others take the pixel tier); "
+                        "measured: sfx_ctx_tile_misses over a bench run / (frames x 57 600 waves)")
+    parser.add_argument("--strip-waves", type=float, default=0.215, help="share of the waves that can see a waveform strip (the tier evaluates its two compares per sample only there)")
     parser.add_argument("--weights-out", help="write [label, weight, why] per block as JSON (to look at a phase's blocks by hand)")
     parser.add_argument("--json", help="write the prices bench.py's issue_model reads (profiles/r05_strip_isa_census.json)")
     args = parser.parse_args()
@@ -101,7 +106,8 @@ def main() -> None:
     M = source_ranges(args.source)
     p = (args.folds - 20.0)/160.0
     rates = {"fold_first": 1.0, "fold_next": p, "row_folds": 1.0 + 8.0*p, "column_iterations": 8.0 + 8.0*p, "exact": args.exact,
-             "pow_branch": 0.95, "mix_branch": 0.30, "strips": 0.06, "staging_rounds": 864.0/512.0, "resolve_rounds": 2.25}
+             "pow_branch": 0.95, "mix_branch": 0.30, "strips": 0.06, "staging_rounds": 864.0/512.0, "resolve_rounds": 2.25,
+             "per_sample_waves": args.per_sample, "tier_waves": 1.0 - args.per_sample, "tier_strip_waves": args.strip_waves}
 
     # ---- a weight per block: walk the listing in order, phase by phase ------------------------------------------------------------
     weights = [0.0]*len(blocks)
@@ -126,6 +132,19 @@ def main() -> None:
         if phase == "resolve" and within(lines, (M["store"][0] + 1, M["store"][1])) and not any(line <= M["store"][0] for line in lines):
             phase = "store"
 
+        tier_lines = (within(lines, M["gains_fn"]) or within(lines, M["tier_fn"])) and not within(lines, M["post_fn"]) and not within(lines, (M["rowline"][0], M["store"][1]))
+        if tier_lines and phase != "prologue":
+            # the pixel tier (wherever the compiler laid its blocks out: they sit behind the store phase in the listing): two instances — the
+            # wave's first row modulo 2 —, each run by half of the tier's waves
+            text = " ".join(others)
+            share = 0.5*rates["tier_waves"]
+            if "glsl.hpp:81" in text or "glsl.hpp:82" in text:
+                weights[i], why[i] = 0.0, "wrap_texel's modulo (bin outside the texture: never)"
+            elif n <= 8 and block["counts"].get("mul_f32", 0) >= 1 and block["counts"].get("cmp", 0) + block["counts"].get("cndmask", 0) >= 1 and not block["counts"].get("cvt"):
+                weights[i], why[i] = share*rates["tier_strip_waves"], "pixel tier: waveform strips"
+            else:
+                weights[i], why[i] = share, "pixel tier"
+            continue
         if phase == "prologue":
             if within(lines, M["blur_direct"]) or (n in (83, 84) and "vmem" in block["counts"]):
                 weights[i], why[i] = 0.0, "blur_direct (a window off its tile: never at C3)"
@@ -171,18 +190,19 @@ def main() -> None:
                 weights[i], why[i] = 10.0, "diagonal per step / per advance"
         elif phase == "post":
             text = " ".join(others)
+            per_sample = rates["per_sample_waves"] if within(lines, M["post_fn"]) or any(k.startswith(("fragments.hpp", "sfmath.hpp", "__clang_hip_math.h")) for k in others) else 1.0
             if "glsl.hpp:81" in text or "glsl.hpp:82" in text:
                 weights[i], why[i] = 9.0*0.0, "wrap_texel's modulo (bin outside the texture: never)"
             elif "sfmath.hpp:110" in text or "sfmath.hpp:99" in text or "glsl.hpp:403" in text or "__clang_hip_math.h:722" in text:
-                weights[i], why[i] = rates["exact"], "exact polar chain (speculation re-run)"
+                weights[i], why[i] = rates["exact"]*rates["per_sample_waves"], "exact polar chain (speculation re-run)"
             elif M["pow_line"][0] in lines or "fragments.hpp:0" in text:
-                weights[i], why[i] = rates["pow_branch"], "pow((len - r)/2, 0.05): lanes beyond their bar"
-            elif top == M["smoothstep01"][0] and M["mix_line"][0] in lines:
-                weights[i], why[i] = rates["mix_branch"], "mix towards white: lanes inside a bar"
+                weights[i], why[i] = rates["pow_branch"]*rates["per_sample_waves"], "pow((len - r)/2, 0.05): lanes beyond their bar"
+            elif M["mix_line"][0] in lines and block["counts"].get("fma_f32", 0) >= 3 and n <= 24:
+                weights[i], why[i] = rates["mix_branch"]*rates["per_sample_waves"], "mix towards white: lanes inside a bar"
             elif M["strips_line"][0] in lines or (top == 0 and n <= 3 and i > 0 and "strips" in why[i - 1]):
-                weights[i], why[i] = rates["strips"], "waveform strips / out-of-aspect bars"
+                weights[i], why[i] = rates["strips"]*rates["per_sample_waves"], "waveform strips / out-of-aspect bars"
             else:
-                weights[i], why[i] = 1.0, "post"
+                weights[i], why[i] = per_sample, ("post (per-sample waves)" if per_sample < 1.0 else "post")
         elif phase == "resolve":
             loop = within(lines, (M["resolve"][0] + 6, M["resolve"][1] - 2)) or any("render_kernels.hpp:30" in k or "render_kernels.hpp:28" in k or "render_kernels.hpp:0" in k for k in others)
             weights[i], why[i] = (rates["resolve_rounds"] if loop else 1.0), "texel exchange + resolve"
