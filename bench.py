@@ -50,7 +50,7 @@ B_ALG_PER_FRAME = {  # iScreen write + resolve read + iFinal w
 }
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 256*4*32*2.4e9    # 256 CU x 4 SIMD32 x 2.4 GHz = 78.6e12 lane-instructions/s (157.3 TFLOP/s FMA)
-PROFILE = ROOT/"profiles"/"r05_bench_c3.json"      # written by tools/profile_bench.sh → tools/summarize_profile.py
+PROFILE = ROOT/"profiles"/"r06_bench_c3.json"      # written by tools/profile_bench.sh → tools/summarize_profile.py
 # The north star's CPU baseline measured with THE REFERENCE ITSELF (its own Python + numpy FFT + its GLSL on Mesa llvmpipe), in the
 # build container — it cannot travel to the GPU box (tools/measure_reference_cpu.py, profiles/r03_reference_llvmpipe.txt). Static.
 REFERENCE_LLVMPIPE = {"value": 0.477, "unit": "frames/s", "cores": 8, "kind": "reference",
@@ -810,11 +810,11 @@ def main() -> None:
                                  "algorithmic_bytes_per_launch": b_alg*piece,
                                  "measured": round(traffic/launch_s/1e9, 1) if traffic else None,
                                  "note": "algorithmic bytes = the reference's two-pass data-flow (SURVEY.md §8d); the fused kernel writes the RGB8 frame only"},
-                         "note": "FP32 VALU issue binds the kernel (the 91-tap blur folded to ~470 instructions per supersample, DESIGN.md §4; LDS ~70 % busy); "
-                                 "HBM carries the finished RGB8 frames and L2-resident tables only, so the HBM figure is a fraction of what the two-pass data-flow would move. "
-                                 "`frac` = SQ_INSTS_VALU x 64 lanes / launch time / peak counts every instruction ONCE: since round 5 forty adds and fmas per supersample "
-                                 "are twenty packed forms (one instruction, two issue slots) and 39 moves are gone, so the same frame takes 472 instead of 549 "
-                                 "instructions and `frac` FELL (0.70 -> 0.61-0.63) while frames/s rose; the share of issue SLOTS in use is issue_model.frac_census"},
+                         "note": "FP32 VALU issue binds the kernel (the 91-tap blur folded to ~300 instructions per supersample, visualizer.frag:36-62's position-only gains once per "
+                                 "output pixel for the wave tiles k_visualizer_classify clears — ~400 in all, DESIGN.md §4; LDS ~74 % busy); HBM carries the finished RGB8 frames "
+                                 "and L2-resident tables only, so the HBM figure is a fraction of what the two-pass data-flow would move. `frac` = SQ_INSTS_VALU x 64 lanes / launch "
+                                 "time / peak counts every instruction ONCE and FALLS whenever the same frame takes fewer instructions (549 in rounds 3-4, 472 in round 5, 403 in "
+                                 "round 6: 0.70 -> 0.63 -> 0.58) while frames/s rise; the share of issue SLOTS in use is issue_model.frac_census"},
         }
         if args.scene != "visualizer":
             # the light fragments are bound by the HBM write of the finished frame: the roofline is the FUSED lower bound — W·H·3 bytes

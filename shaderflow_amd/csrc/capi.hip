@@ -2342,6 +2342,9 @@ static bool tape_open_streams(Tape* t) {
     // slots instead of queueing behind the render's
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+    // (SHADERFLOW_TAPE_PRIORITY=normal: A/B switch for measurements — tools/experiments/timeline_overlap.py)
+    const char* priority = getenv("SHADERFLOW_TAPE_PRIORITY");
+    if (priority && !strcmp(priority, "normal")) greatest = 0;
     if (hipStreamCreateWithPriority(&t->audio_stream, hipStreamNonBlocking, greatest) != hipSuccess) return false;
     for (TapeBank& k : t->bank) {
         if (hipEventCreateWithFlags(&k.built, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&k.rendered, hipEventDisableTiming) != hipSuccess) return false;

@@ -52,6 +52,12 @@ def main() -> None:
         entry = per.setdefault(name, [0, 0]); entry[0] += b - a; entry[1] += 1
     for name, (total, count) in sorted(per.items(), key=lambda kv: -kv[1][0])[:12]:
         print(f"  {name[:70]:70s} {total/1e3:9.1f} us  {count:5d} launches  {total/count/1e3:8.2f} us each  {total/span*100:5.1f} % of the window")
+    import os
+    dump = int(os.environ.get("TIMELINE_DUMP", "0"))
+    if dump:
+        print(f"  first {dump} launches of the window (start, end relative to the window's start in us; queue; kernel):")
+        for a, b, name, queue in window[:dump]:
+            print(f"    {(a - t0)/1e3:10.1f} {(b - t0)/1e3:10.1f}  q{queue}  {name[:60]}")
 
 
 if __name__ == "__main__":
