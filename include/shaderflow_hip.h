@@ -375,8 +375,10 @@ int sfx_peer_export(sfx_handle ctx, void* device_ptr, void* handle64);
 int sfx_peer_open(sfx_handle ctx, const void* handle64, void** device_ptr);
 int sfx_peer_close(sfx_handle ctx, void* device_ptr);
 /* asynchronous; ordered after what the context's stream holds now. `lane` (0..15) tags the source buffer for sfx_peer_fence. The copy is
- * issued by a thread of the context on one of the two SDMA engines HSA recommends for the (owner of the window, this GPU) pair — named,
- * not drawn (hsa_amd_memory_async_copy_on_engine), up to four in flight; HIP copy streams where HSA does not answer (SHADERFLOW_PEER=hip). */
+ * issued by a thread of the context, up to four in flight: on the context's probed HIP copy streams (hipMemcpyAsync) by default, or —
+ * SHADERFLOW_PEER=engine, opt-in since round 6 until it has run between two GPUs — on the two SDMA engines HSA recommends for the (owner of
+ * the window, this GPU) pair, named, not drawn (hsa_amd_memory_async_copy_on_engine). A copy whose engine never signals is reported as
+ * failed after SHADERFLOW_COPY_TIMEOUT seconds and its signal is retired, never re-armed. */
 int sfx_peer_copy(sfx_handle ctx, void* remote_dst, const void* local_src, size_t nbytes, int lane);
 int sfx_peer_fence(sfx_handle ctx, int lane);    /* host wait: the lane's last copy has left its source (a pipelined sender asks a step later) */
 int sfx_peer_flush(sfx_handle ctx);              /* host wait: every copy issued so far has landed */
