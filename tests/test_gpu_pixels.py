@@ -193,6 +193,47 @@ def test_visualizer_lds_tile_kernel_with_a_moved_camera(gpu, camera, ssaa):
         assert_within_lsb(gpu.render_resolve(prog, w, h, ssaa, 2), O.resolve(screen, w, h, 2))
 
 
+@pytest.mark.parametrize("camera", [dict(), dict(iCameraZoom=0.8), dict(iCameraZoom=1.3, iCameraPosition=(0.11, -0.07, 0.0)),
+                                    dict(iCameraIsometric=0.35, iCameraZoom=0.9), dict(iCameraDolly=0.4, iCameraFocalLength=1.2),
+                                    dict(iCameraPosition=(0.0, 0.0, 1.5))])
+@pytest.mark.parametrize("ssaa,size", [(2, (1280, 720)), (2, (1920, 1080)), (4, (640, 360))])
+def test_pixel_tier_of_the_strip_kernels_under_axis_cameras(gpu, camera, ssaa, size):
+    """Round 6's pixel tier (visualizer.frag:36-62's position-only gains once per output pixel, for the wave tiles k_visualizer_classify
+    clears) on the OTHER strip instances and under cameras that zoom and pan: the classification bounds a tile's rectangle through
+    camera_along_axis, the pixel tables hold iCamera.gluv of the pixel centres. A spectrogram column whose neighbouring bars differ
+    little, so that the tier has tiles (the white-noise column of the test above sends nearly all of them to the per-sample path);
+    whole frames against the oracle, and some tile on each path — except from behind the plane, where every fragment is out of bounds."""
+    from tests.helpers import smooth_spectrum
+    w, h = size
+    u, arrays, params = visualizer_inputs(w, h, seed=31, volume=0.8, bg_size=(384, 216))
+    arrays["iSpectrogram"] = smooth_spectrum(seed=31)
+    for key, value in camera.items():
+        cur = getattr(u, key)
+        if hasattr(cur, "__len__"):
+            for i, v in enumerate(value):
+                cur[i] = v
+        else:
+            setattr(u, key, value)
+    u.iSSAA = float(ssaa)
+    screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, threads=16)
+    want = O.resolve(screen, w, h, 2)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    gpu.ctx.tile_misses()
+    got = gpu.render_resolve(prog, w, h, ssaa, 2)
+    per_sample_waves = gpu.ctx.tile_misses()
+    assert _last_kernel(gpu).startswith("k_visualizer_strip<"), _last_kernel(gpu)
+    assert_within_lsb(got, want)
+    behind = camera.get("iCameraPosition", (0, 0, 0))[2] > 1.0
+    assert per_sample_waves > 0
+    if not behind:
+        # (the kernel's name carries its geometry: <pitch, rows, S, WALK, waves, column groups, half>: a wave is 64 columns x WALK rows)
+        walk = int(_last_kernel(gpu).split("<")[1].split(",")[3])
+        waves = -(-w*ssaa//64)*(-(-h*ssaa//walk))
+        assert per_sample_waves < 0.9*waves, (per_sample_waves, waves, _last_kernel(gpu))
+
+
 @pytest.mark.parametrize("camera", [dict(iCameraZoom=0.8), dict(iCameraZoom=1.3, iCameraPosition=(0.11, -0.07, 0.0)),
                                     dict(iCameraIsometric=0.35, iCameraZoom=0.9), dict(iCameraDolly=0.4, iCameraFocalLength=1.2),
                                     dict(iCameraPosition=(0.0, 0.0, 1.5))])
