@@ -100,6 +100,9 @@ template <int KIND> static int launch_separable_t(Context* ctx, const RenderArgs
     }
     g_last_kernel = std::string("k_separable_fused<") + (KIND == SEP_BARS ? "bars" : (KIND == SEP_WAVEFORM ? "waveform" : "default")) + ">";
     const int blocks_x = (a.w + SEP_PIXELS - 1)/SEP_PIXELS;
+    // default.glsl's singular line (separable_fast.hpp k_default_singular), behind whichever kernels rendered the frames
+    struct SingularLine { const RenderArgs& a; int frames; hipStream_t s; bool armed;
+                          ~SingularLine() { if (armed) hipLaunchKernelGGL(k_default_singular, dim3((a.wr + a.hr + 255)/256, frames), dim3(256), 0, s, a); } } singular{a, frames, s, KIND == SEP_DEFAULT};
     if constexpr (KIND == SEP_DEFAULT) {
         // the smooth tier first, four pixels per lane; what it writes it marks, and the second pass skips
         if (quads) {
