@@ -203,7 +203,7 @@ __device__ __forceinline__ void default_colour(DefaultBytes& out, const DefaultH
 // each kept under SEP_DEFAULT_TOLERANCE. Rounds 3-5 asked for 4e-5 (0.01 LSB of a channel: a sample's quantisation then flips with
 // probability 2 %). Round 6: 4e-4 = 0.1 LSB per term — two terms, 0.2 LSB, plus the half LSB by which a pixel resolved from MEANS (the smooth
 // tier) can differ from the mean of its samples' roundings: 0.7 < 1, so the frame still differs from the reference's by ONE LSB at most
-// (`test_basic_whole_frame_4k`: four cameras and hue shifts, whole 4K frames; at 1.2e-3 the sum is 1.1 and the test finds the pixels), and
+// (`test_basic_whole_frame_4k`: ten cameras and hue shifts, whole 4K frames; at 1.2e-3 the sum is 1.1 and the test finds the pixels), and
 // the per-sample band — 60 instructions per supersample on 16 % of the pixels, two thirds of the kernel's time — shrinks: 96 100 -> 110 500
 // frames/s at 4K 2xSSAA (0.30 -> 0.345 of the HBM roof; 1e-4: 105 400). The tiers of k_separable_fused:
 //   * FOUR rows of pixels (sixteen samples per column pair) share one evaluation where both hold — |circle| > 0.1 at 4K, 87 % of the
