@@ -322,3 +322,14 @@ def test_isa_census_classes_and_scalar_sources():
     assert not census.uses_sgpr_source("v_fmac_f32", "v50, v52, v13") and not census.uses_sgpr_source("v_readfirstlane_b32", "s22, v1")
     cycles = {name: c for name, _, c in census.CLASSES}
     assert cycles["fma_f32"] == 2 and cycles["pk_fma_f32"] == 4 and cycles["trans"] == 8 and cycles["cvt"] == 4
+
+
+def test_clock_sequence_chunks_are_sized_by_time():
+    """the native clock sequence keeps the host for about a quarter of a second at most — scene.quit, the encoder check and
+    Ctrl-C are looked at between chunks — whatever a frame costs; 240 frames only when they are that cheap"""
+    from shaderflow_amd.clockloop import ClockLoop
+    loop = ClockLoop.__new__(ClockLoop)                            # (chunk_frames reads class constants only)
+    assert loop.chunk_frames(None) == 30 and loop.chunk_frames(0.0) == 30          # nothing measured yet: a short first chunk
+    assert loop.chunk_frames(0.0005) == 240                                        # 0.5 ms per frame: the cap
+    assert loop.chunk_frames(0.004) == 62                                          # 4 ms per frame (a sink that waits): 0.25 s worth
+    assert loop.chunk_frames(1.0) == 1                                             # a stalled encoder: frame by frame
