@@ -353,7 +353,27 @@ def spawn_ranks(args, argv: list[str]) -> int:
     command = launcher_command(args.gpus, argv, port)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), SHADERFLOW_BENCH_SPAWNED="1")
     print(f"bench.py: --gpus {args.gpus} without a launcher: starting {' '.join(command[1:8])} …", file=sys.stderr, flush=True)
-    child = subprocess.Popen(command, stdout=subprocess.PIPE, text=True, env=env, cwd=str(ROOT))
+    # (a session of its own, and this process' termination is the ranks': a driver that ends the bench on its clock must not leave N
+    # processes holding the GPUs)
+    import signal
+    child = subprocess.Popen(command, stdout=subprocess.PIPE, text=True, env=env, cwd=str(ROOT), start_new_session=True)
+
+    def end_ranks(signum=None, frame=None):
+        if child.poll() is None:
+            try:
+                os.killpg(child.pid, signal.SIGTERM)
+                child.wait(timeout=10)
+            except (OSError, subprocess.TimeoutExpired):
+                try:
+                    os.killpg(child.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+        if signum is not None:
+            raise SystemExit(128 + signum)
+    for name in ("SIGTERM", "SIGINT", "SIGHUP"):
+        signal.signal(getattr(signal, name), end_ranks)
+    import atexit
+    atexit.register(end_ranks)
     line = None
     for text in child.stdout:
         candidate = text.strip()
