@@ -108,6 +108,27 @@ class Gpu:
         self._live.clear()
 
 
+def usable_cores() -> int:
+    """Cores the oracle's thread pool may really use: the CPUs this process may be scheduled on, capped by the cgroup's CPU quota. The pool's
+    GPU boxes show 256 logical CPUs and grant 16 CPUs' worth of time: 256 runnable threads on 16 cores ran the oracle at 12x one thread
+    where 16 threads give 17.7x (tools/experiments/oracle_scaling.py) — a third of the full-size tests' time"""
+    import os
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    quota = None
+    try:
+        limit, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if limit != "max":
+            quota = max(1, int(float(limit)/float(period) + 0.5))
+    except (OSError, ValueError):
+        try:
+            limit, period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if limit > 0:
+                quota = max(1, int(limit/period + 0.5))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(visible, quota) if quota else visible)
+
+
 def visualizer_inputs(w, h, seed=0, bg_size=(96, 54), volume=0.8, std=0.2, time=1.25, bins=115):
     """Random but plausible inputs of visualizer.frag: (oracle uniforms, {name: ndarray}, sampler params)"""
     rng = np.random.default_rng(seed)

@@ -20,11 +20,11 @@ import pytest
 from oracle import binding as O
 from shaderflow_amd import synth
 from tests import replay as R
-from tests.helpers import Gpu, gpu_bind_all, lsb_report, oracle_textures, smooth_spectrum, visualizer_inputs
+from tests.helpers import Gpu, gpu_bind_all, lsb_report, oracle_textures, smooth_spectrum, usable_cores, visualizer_inputs
 from tests.test_oracle_mesa import edge_aware_frame
 
 pytestmark = pytest.mark.gpu
-THREADS = os.cpu_count() or 8
+THREADS = usable_cores()                                            # (not os.cpu_count(): the GPU boxes show 256 CPUs and grant 16)
 
 
 @pytest.fixture()
