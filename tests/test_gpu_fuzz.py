@@ -322,3 +322,46 @@ def test_tiled_translated_fragment_random_maps(gpu, tile_programs, seed):
         gpu.bind(prog, "background", texture)
         frames.append(gpu.render(prog, w, h, comps=4, dtype=np.float32).view(np.uint32) if ssaa == 0 else gpu.render_resolve(prog, w, h, ssaa, subsample))
     assert np.array_equal(frames[0], frames[1]), (kind, filter, repeat, values, taps, (w, h), (ssaa, subsample))
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_visualizer_pixel_tier_random_sizes_spectra_and_axis_cameras(gpu, seed):
+    """Round 6's pixel tier of the strip kernels (visualizer.frag:36-62's position-only gains once per output pixel, for the wave tiles a
+    per-frame classification clears): random frame sizes (odd ones, sizes that leave partial blocks and partial waves), 2x and 4x SSAA,
+    spectrogram columns from silence over smooth ones to a single loud bin, loudness / flash / time at random, the identity camera and
+    zoomed / panned ones, repeating and clamped backgrounds — whole frames against the oracle within 1 LSB, and the tier really ran."""
+    from tests.helpers import smooth_spectrum
+    rng = np.random.default_rng(6000 + seed)
+    ssaa = 2 if seed % 4 else 4
+    w, h = [(int(rng.integers(300, 1400)), int(rng.integers(170, 800))), (1280, 720), (1921, 1079), (960, 540)][seed % 4] if ssaa == 2 else (int(rng.integers(200, 700)), int(rng.integers(120, 400)))
+    bg_size = [(384, 216), (1920, 1080), (640, 360)][seed % 3]
+    u, arrays, params = visualizer_inputs(w, h, seed=seed, volume=float(rng.choice([0.0, 0.3, 0.8, 1.2])), bg_size=bg_size, time=float(rng.uniform(0, 60)), std=float(rng.uniform(0, 0.8)))
+    kind = seed % 3
+    if kind == 0:
+        arrays["iSpectrogram"] = smooth_spectrum(seed=seed)
+    elif kind == 1:
+        arrays["iSpectrogram"] = np.zeros((115, 1, 2), np.float32)
+    else:
+        column = np.full((115, 1, 2), 1.0e-3, np.float32)
+        column[int(rng.integers(2, 112)), 0, int(rng.integers(0, 2))] = float(rng.uniform(200.0, 3000.0))
+        arrays["iSpectrogram"] = column
+    params["background"] = ("linear", bool(rng.integers(0, 2)), bool(rng.integers(0, 2)))
+    if seed % 2:
+        u.iCameraZoom = float(rng.choice([0.7, 0.85, 1.2, 1.5]))
+        u.iCameraPosition[0] = float(rng.uniform(-0.15, 0.15)); u.iCameraPosition[1] = float(rng.uniform(-0.1, 0.1))
+    u.iSSAA = float(ssaa)
+    prog, _ = gpu.program("visualizer")
+    gpu.set_uniforms(prog, u)
+    gpu_bind_all(gpu, prog, arrays, params)
+    gpu.ctx.tile_misses()
+    got = gpu.render_resolve(prog, w, h, ssaa, 2)
+    per_sample_waves = gpu.ctx.tile_misses()
+    kernel = gpu.lib.sfx_last_kernel().decode()
+    screen = O.render("visualizer", u, oracle_textures(arrays, params), w*ssaa, h*ssaa, threads=16)
+    want = O.resolve(screen, w, h, 2, threads=16)
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1, (seed, (w, h), ssaa, kernel, lsb_report(got, want), np.argwhere(d > 1)[:5].tolist())
+    if kernel.startswith("k_visualizer_strip<"):
+        walk = int(kernel.split("<")[1].split(",")[3])
+        waves = -(-w*ssaa//64)*(-(-h*ssaa//walk))
+        assert 0 < per_sample_waves < waves, (seed, kernel, per_sample_waves, waves)       # both paths populated (the disc's edge is always per sample)
