@@ -219,6 +219,14 @@ int launch_visualizer_fast(Context* ctx, const RenderArgs& a0, int ssaa, int fra
         if (VIS_FAST_WALK > 0 && !plain && fits(128, 4*VIS_SPARSE_WALK, 92, VIS_SPARSE_ROWS)) return launch_visualizer_tables_and_kernel<92, VIS_SPARSE_ROWS, 2, VIS_SPARSE_WALK, 4, 2, VIS_SPARSE_HALF>(ctx, a, frames, s);
         if (fits(256, 2, 72, 10)) return launch_visualizer_tables_and_kernel<72, 10, 0, 0, 8>(ctx, a, frames, s);
     } else if (VIS_FAST_WALK > 0) {
+#ifdef VIS4_SWEEP_WALK                                               // (A/B builds: BASELINE config 4's LDS-tile sweep — tools/experiments/c4_tile_sweep.sh)
+        if (fits(64*VIS4_SWEEP_CG, (8/VIS4_SWEEP_CG)*VIS4_SWEEP_WALK, VIS4_SWEEP_PITCH, VIS4_SWEEP_ROWS))
+            return launch_visualizer_tables_and_kernel<VIS4_SWEEP_PITCH, VIS4_SWEEP_ROWS, 4, VIS4_SWEEP_WALK, VIS4_SWEEP_WAVES, VIS4_SWEEP_CG, false>(ctx, a, frames, s);
+#endif
+        // 8K at 4x over a 1080-row background (0.0625 texel per sample): a block's window is 17 cells wide — on a 20-cell pitch its staging loop
+        // has no idle half (round 6's tile sweep, profiles/r06_c4_tile_sweep.txt: 292.0 -> 295.9 frames/s, the same bytes); wider windows
+        // (smaller outputs, larger backgrounds) keep the 40-cell pitch
+        if (fits(128, 4*WALK4, 20, VIS_STRIP_ROWS4)) return launch_visualizer_tables_and_kernel<20, VIS_STRIP_ROWS4, 4, WALK4, VIS_STRIP_WAVES4, 2, VIS_STRIP_HALF4>(ctx, a, frames, s);
         if (fits(128, 4*WALK4, 40, VIS_STRIP_ROWS4)) return launch_visualizer_tables_and_kernel<40, VIS_STRIP_ROWS4, 4, WALK4, VIS_STRIP_WAVES4, 2, VIS_STRIP_HALF4>(ctx, a, frames, s);
         // 1080p at 4x SSAA: the same tile width with strips of six rows
 #ifndef VIS_MID4_WALK

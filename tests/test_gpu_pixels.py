@@ -491,7 +491,7 @@ def test_full_size_properties_8k_ssaa4(gpu):
     gpu.set_uniforms(prog, u)
     gpu_bind_all(gpu, prog, arrays, params)
     a = gpu.render_resolve(prog, w, h, ssaa, 2)
-    assert _last_kernel(gpu).startswith("k_visualizer_strip<40, 13, 4, "), _last_kernel(gpu)
+    assert _last_kernel(gpu).startswith("k_visualizer_strip<20, 13, 4, "), _last_kernel(gpu)      # (the 20-cell pitch of round 6's tile sweep: 17 cells of window)
     b = gpu.render_resolve(prog, w, h, ssaa, 2)
     assert np.array_equal(a, b)
     for rows in ((0, 1), (2159, 2161), (4319, 4320)):
