@@ -925,7 +925,7 @@ static void render_rows(const job_t* jb) {
 
 /* fragment/final.glsl:1-33; iScreen is RGBA8, linear, repeat(False) (scene.py:192-194, texture.py:108-112) */
 static void resolve_rows(const job_t* jb) {
-    sfo_texture screen = { jb->screen, jb->wr, jb->hr, 4, SFO_U8, SFO_LINEAR, 0, 0 };
+    sfo_texture screen = { jb->screen, jb->wr, jb->hr, 4, SFO_U8, SFO_LINEAR, 0, 0, 0, NULL };
     const int kernel = jb->subsample;
     const float resx = (float)jb->w, resy = (float)jb->h;               /* iResolution := scene.resolution, shader.py:394 */
     for (int j = jb->y0; j < jb->y1; j++) {
