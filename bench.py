@@ -502,7 +502,7 @@ def main() -> None:
     # and two payloads: the rgb24 frames (the reference's byte stream: `value`) and — converted on the rank that rendered them —
     # planar yuv420p, half the bytes per link (`yuv420p` beside it). SHADERFLOW_SHARD=device|device-sdma pins the transport.
     from shaderflow_amd.parallel import DeviceArray
-    os.environ.setdefault("SHADERFLOW_COPY_TIMEOUT", "30")          # an engine copy that never completes is reported after 30 s (capi.hip EngineLanes::finish), not waited for
+    os.environ.setdefault("SHADERFLOW_COPY_TIMEOUT", "30")          # an engine copy that never completes is reported after 30 s (capi_readout.hip EngineLanes::finish), not waited for
     pinned = os.environ.get("SHADERFLOW_SHARD", "").strip().lower()
     transports = [] if not distributed else (["sdma"] if pinned == "device-sdma" else (["p2p"] if pinned == "device" else ["p2p", "sdma"]))
     received = raw_received = windows = None

@@ -196,7 +196,7 @@ int sfx_ring_destroy(sfx_handle ring);
 /* Encoder hand-off, optional half (exporting.py:94-134): `frames` RGB8 frames (consecutive, width*height*3 bytes each) on
  * the device → planar yuv420p (I420: Y, U, V; width*height*3/2 bytes each) on the device, on the context's stream. BT.601 limited
  * range (matrix 0) or BT.709 limited (1) in 8-bit integer arithmetic, chroma from the rounded 2x2 mean of R, G, B — defined in
- * capi.hip, restated in the oracle. Half the bytes over PCIe and the pipe: ffmpeg takes `-pix_fmt yuv420p` rawvideo as it is. */
+ * capi_readout.hip, restated in the oracle. Half the bytes over PCIe and the pipe: ffmpeg takes `-pix_fmt yuv420p` rawvideo as it is. */
 int sfx_rgb_to_yuv420(sfx_handle ctx, const void* rgb, void* yuv, int width, int height, int frames, int matrix);
 
 /* The frame loop of a scene in which nothing but the clock moves (layered / temporal scenes without host logic: demo.py's Multipass,

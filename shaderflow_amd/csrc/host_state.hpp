@@ -1,5 +1,6 @@
 // host_state.hpp — what the translation units of libshaderflow_hip.so share on the HOST side: error reporting, handles, the context and
-// texture objects. capi.hip owns the definitions of the thread-local state; the launch units (launch_*.hip) only read it.
+// texture objects, and the few calls the C-ABI units (capi.hip, capi_readout.hip, capi_audio.hip) make into each other. capi.hip owns the
+// definitions of the thread-local state; the launch units (launch_*.hip) only read it.
 #pragma once
 
 #include "../../include/shaderflow_hip.h"
@@ -14,6 +15,7 @@
 
 extern thread_local std::string g_last_kernel;   // which render kernel instance the last launch on this thread picked (sfx_last_kernel)
 int fail(int code, const char* fmt, ...);         // sets sfx_last_error() of this thread, returns `code`
+int launch_status();                              // hipGetLastError() after a launch as an sfx status (capi.hip)
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(SFX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
 enum : uint32_t { MAGIC_CTX = 0x53465843, MAGIC_TEX = 0x53465854, MAGIC_PROG = 0x53465850, MAGIC_RING = 0x53465852,
@@ -70,3 +72,20 @@ struct Texture : Object {
 
 #define CTX_OR_FAIL(var, h) Context* var = get<Context>(h, MAGIC_CTX); if (!var) return fail(SFX_E_INVALID, "invalid context handle")
 #define USE_DEVICE(ctx) HIP_TRY(hipSetDevice((ctx)->device))
+
+// ---- between the C-ABI units ------------------------------------------------------------------------------------------------------
+// capi_readout.hip
+void readout_release(Context* c);                 // sfx_ctx_destroy: the context's peer copier, copy streams and engine records
+int ring_slot_count(sfx_handle ring);             // slots of a read-out ring; -1: not a ring
+// capi_audio.hip: what a render reads of a tape — the bank its last build filled (sfx_render_tape)
+struct TapeView {
+    Context* ctx; int max_frames;
+    bool audio;                                   // false: a clock tape (per-frame uniforms only)
+    sf::FrameDyn* dyn; sf::VisualizerConsts* vis;
+    hipEvent_t built, rendered;                   // the bank's: renders wait for `built`, and leave `rendered` behind their last kernel
+    int width, values, bins, channels;            // iSpectrogram: length_samples x bins x channels (values = bins*channels)
+    int points, pcm_channels;                     // iWaveform (points 0: none)
+    float *columns, *scroll, *rows, *bars;
+};
+bool tape_view(sfx_handle tape, TapeView* view);
+int tape_screen_scratch(sfx_handle tape, size_t bytes, hipStream_t stream, void** screen);   // iScreen of the two-pass path, grown on demand

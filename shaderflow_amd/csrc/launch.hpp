@@ -1,5 +1,5 @@
 // launch.hpp — the launch units of libshaderflow_hip.so. Every kernel family is instantiated in ONE translation unit (a clean build runs
-// them side by side under `make -j`, an edit of a kernel header rebuilds its unit only); capi.hip keeps the C-ABI, the objects and the
+// them side by side under `make -j`, an edit of a kernel header rebuilds its unit only); capi.hip (with capi_readout.hip and capi_audio.hip) keeps the C-ABI, the objects and the
 // choice between the families, and calls the units through these functions. Return conventions as before the split: the `launch_*`
 // pickers return 1 when they launched, 0 when the configuration is not theirs (the caller takes the next family), < 0 on errors.
 #pragma once

@@ -94,7 +94,7 @@ class FrameTape:
         if not spectrograms[0].device_magnitude:
             return False                                          # a `magnitude` callable of the user's own runs on the host, frame by frame (audio/spectrogram.py)
         if spectrograms[0].spectrogram_bins*audio.channels > 16384:
-            return False                                          # the scan kernel walks up to 16 384 values per frame (csrc/capi.hip DYNAMICS_SCAN_LIMIT)
+            return False                                          # the scan kernel walks up to 16 384 values per frame (csrc/capi_audio.hip DYNAMICS_SCAN_LIMIT)
         # a scrolling spectrogram (length > 0) keeps one state of its texture per frame of a batch in HBM (sfx_tape_desc.length_samples)
         if spectrograms[0].length_samples*spectrograms[0].spectrogram_bins*audio.channels*4*FrameTape.BATCH > FrameTape.SCROLL_BYTES:
             return False

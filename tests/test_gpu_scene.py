@@ -268,7 +268,7 @@ def test_waveform_scene_tape_equals_frame_loop(ssaa):
 
 @pytest.mark.parametrize("batch", [1, 2, 3, 7])
 def test_tape_banks_with_small_batches(batch, monkeypatch):
-    """The tape's two banks and streams (capi.hip Tape): with batches of a few frames the builds run far ahead of the renders and
+    """The tape's two banks and streams (capi_audio.hip Tape): with batches of a few frames the builds run far ahead of the renders and
     the banks alternate dozens of times — the frames must be the ones a single batch gives, for an audio scene with both passes
     (no SSAA: fragment into iScreen, then final.glsl) and for the fused path; tools/stress_tape_banks.py is the long version"""
     from examples.scenes import MusicBars, Visualizer, make

@@ -1,6 +1,6 @@
 """
 The optional half of the encoder hand-off (exporting.py:94-134 leaves rgb24 → yuv420p to ffmpeg's swscale on the CPU):
-planar 4:2:0 made on the device. The arithmetic is the product's own definition (capi.hip k_rgb_to_yuv420: BT.601 / BT.709 limited
+planar 4:2:0 made on the device. The arithmetic is the product's own definition (capi_readout.hip k_rgb_to_yuv420: BT.601 / BT.709 limited
 range, 8-bit integer coefficients, chroma from the rounded 2x2 mean), restated in the oracle; known answers pin the coefficients.
 """
 import numpy as np

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Compact per-kernel resource table (VGPR / SGPR / scratch / LDS / occupancy) from hipcc's remarks.
-# UNIT=<launch unit> picks the translation unit (default: launch_visualizer_strip; others: launch_generic, launch_visualizer_tiled, launch_separable, launch_resolve, capi)
+# UNIT=<launch unit> picks the translation unit (default: launch_visualizer_strip; others: launch_generic, launch_visualizer_tiled, launch_separable, launch_resolve, capi, capi_readout, capi_audio)
 cd "$(dirname "$0")/../shaderflow_amd/csrc" || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
   -fno-fast-math -fno-slp-vectorize -fno-gpu-flush-denormals-to-zero -Wno-unused-value --cuda-device-only -c ${UNIT:-launch_visualizer_strip}.hip -o /tmp/unit.o \
