@@ -561,8 +561,10 @@ def main() -> None:
     class Gather:
         """One transport x one payload: send(index, q, view) queues piece q of step `index`; drain() bounds what is in flight"""
         def __init__(self, transport: str, payload_bytes: int):
-            self.transport, self.payload, self.in_flight = transport, payload_bytes, []
-            self.works_per_transfer = 2 if loopback else ((world - 1) if rank == 0 else 1)
+            self.transport, self.payload = transport, payload_bytes
+            # one entry per TRANSFER (a piece of a step): the works its grouped call returned — RCCL coalesces a batch into ONE work,
+            # gloo returns one per operation, so the count of works says nothing about the count of transfers
+            self.in_flight: list[list] = []
 
         def send(self, index: int, q: int, view) -> None:
             lo, hi = q*piece*self.payload, (q + 1)*piece*self.payload
@@ -580,15 +582,16 @@ def main() -> None:
             else:
                 ops = [dist.P2POp(dist.isend, view.cpu() if staged else view, 0)]
             if ops:
-                self.in_flight.extend(dist.batch_isend_irecv(ops))
+                self.in_flight.append(list(dist.batch_isend_irecv(ops)))
 
         def fence(self, index: int, q: int) -> None:
             if self.transport == "sdma" and (rank or loopback):
                 context.peer_fence((index % 2)*parts + q)          # the copy that last read this piece of this buffer (two steps ago) has left it
 
         def drain(self, keep_transfers: int = 0) -> None:
-            while len(self.in_flight) > keep_transfers*self.works_per_transfer:
-                self.in_flight.pop(0).wait()
+            while len(self.in_flight) > keep_transfers:
+                for work in self.in_flight.pop(0):
+                    work.wait()
 
         def flush(self) -> None:
             self.drain()
