@@ -234,9 +234,17 @@ class HostDelivery:
         from shaderflow_amd import _native as N
         self.N, self.C = N, C
         self.rank, self.world, self.frame_bytes, self.pushed, self.failed = rank, world, frame_bytes, 0, False
-        name = [f"/shaderflow-{os.getpid()}-{id(self) & 0xffffff:x}", shm_slots_that_fit(frame_bytes, slots, world)]
+        # one segment name, one ring size — and ONE verdict on whether /dev/shm can hold it: rank 0's, for the whole group (a rank that
+        # raised by itself here would leave the others in the broadcast)
+        name = [f"/shaderflow-{os.getpid()}-{id(self) & 0xffffff:x}", 0, None]
+        try:
+            name[1] = shm_slots_that_fit(frame_bytes, slots, world)
+        except RuntimeError as error:
+            name[2] = str(error)
         if world > 1:
-            dist.broadcast_object_list(name, src=0)                 # one segment name and one ring size for the group
+            dist.broadcast_object_list(name, src=0)
+        if name[2]:
+            raise RuntimeError(name[2])
         slots = int(name[1])
         self.handle = N.Handle()
         failure = None

@@ -297,7 +297,9 @@ class FrameTape:
                 # the rank that rendered a batch converts it (one kernel behind the render) and the PLANAR frames travel — 12.4
                 # instead of 24.9 MB per 4K frame over every link
                 sink_bytes = export.frame_bytes
-                slots = int(os.environ.get("SHADERFLOW_SHM_SLOTS", 0)) or max(4, min(2*self.batch, (4 << 30)//sink_bytes))
+                # (a batch and a few: the writer takes the ranks' batches in turn, so a rank needs room for the batch it is producing while its
+                # previous one is being taken — with two batches per rank an 8-rank 4K export asked /dev/shm for 24 GB)
+                slots = int(os.environ.get("SHADERFLOW_SHM_SLOTS", 0)) or max(4, min(self.batch + 8, (4 << 30)//sink_bytes))
                 delivery = HostDelivery(context, world, rank, sink_bytes, slots, export.fileno if rank == 0 else None,
                                         interleaved_runs(world, batches))
                 buffers = [context.alloc(sink_bytes*self.batch) for _ in range(2)]
